@@ -1,0 +1,85 @@
+"""ctypes binding of libhsad.so (include/hsad.h).  Fails loudly when the library is missing —
+the product has no CPU or PyTorch fallback for the hot path."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libhsad.so")
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip",)]
+_lib = None
+
+
+class HsadError(RuntimeError):
+    pass
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [
+        ("num_games", C.c_int32), ("players", C.c_int32), ("hand_size", C.c_int32), ("bomb", C.c_int32),
+        ("seed0", C.c_int32), ("max_len", C.c_int32), ("sad", C.c_int32), ("shuffle_obs", C.c_int32),
+        ("shuffle_color", C.c_int32), ("knowledge_mode", C.c_int32), ("n_eps", C.c_int32), ("device", C.c_int32),
+        ("track_deck_history", C.c_int32), ("reserved", C.c_int32), ("eps_list", C.POINTER(C.c_float)),
+    ]
+
+
+# every symbol include/hsad.h declares: (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "hsad_last_error": (C.c_char_p, []),
+    "hsad_version": (C.c_char_p, []),
+    "hsad_env_create": (C.c_int, [C.POINTER(EnvConfig), C.POINTER(_P)]),
+    "hsad_env_destroy": (None, [_P]),
+    "hsad_env_feature_size": (C.c_int, [_P]),
+    "hsad_env_num_action": (C.c_int, [_P]),
+    "hsad_env_hand_feature_size": (C.c_int, [_P]),
+    "hsad_env_num_games": (C.c_int, [_P]),
+    "hsad_env_num_players": (C.c_int, [_P]),
+    "hsad_env_state_bytes": (C.c_int64, [_P]),
+    "hsad_env_bind_outputs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "hsad_env_reset": (C.c_int, [_P, _P]),
+    "hsad_env_step": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_env_policy_random": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
+    "hsad_env_rollout_random": (C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
+    "hsad_env_query": (C.c_int, [_P, _P, _P]),
+    "hsad_env_move_is_legal": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_env_deck_history": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_env_state_words": (C.c_int, [_P]),
+    "hsad_env_export_state": (C.c_int, [_P, _P, _P]),
+    "hsad_env_error_count": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+
+def build_library(verbose=False):
+    """Compile every HIP source for gfx950 into hanabi_sad_amd/libhsad.so (hipcc cross-compiles
+    without a GPU)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I" + os.path.join(_ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HsadError(
+            "libhsad.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "— there is no CPU fallback for the HIP hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HsadError("hsad call failed (%d): %s" % (rc, load_library().hsad_last_error().decode()))

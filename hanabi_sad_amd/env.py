@@ -1,0 +1,124 @@
+"""Batched device Hanabi environment: host-side owner of the tensors that libhsad's env kernels
+write.  One object = G games = what the reference builds as G `hanalearn.HanabiEnv` objects inside
+`HanabiVecEnv`s (pyhanabi/create.py:24-54; rela/env.h:29-108)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class BatchedHanabiEnv:
+    def __init__(self, num_games, players=2, hand_size=5, seed=1, bomb=0, eps_list=(0.0,), max_len=80, sad=False,
+                 shuffle_obs=False, shuffle_color=False, knowledge_mode=0, device="cuda:0", track_deck_history=True):
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HsadError("BatchedHanabiEnv needs a ROCm device (got %s); there is no CPU path" % device)
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        eps = (C.c_float * len(eps_list))(*[float(e) for e in eps_list])
+        cfg = _lib.EnvConfig(num_games, players, hand_size, int(bomb), int(seed), int(max_len), int(bool(sad)),
+                             int(bool(shuffle_obs)), int(bool(shuffle_color)), int(knowledge_mode), len(eps_list),
+                             dev_index, int(bool(track_deck_history)), 0, eps)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.hsad_env_create(C.byref(cfg), C.byref(self.h)))
+        L = self.lib
+        self.G, self.P, self.H = num_games, players, hand_size
+        self.F = L.hsad_env_feature_size(self.h)
+        self.A = L.hsad_env_num_action(self.h)
+        self.sad = bool(sad)
+        d = self.device
+        self.priv_s = torch.zeros(self.G, self.P, self.F, dtype=torch.float32, device=d)
+        self.legal_move = torch.zeros(self.G, self.P, self.A, dtype=torch.float32, device=d)
+        self.own_hand = torch.zeros(self.G, self.P, 3 * self.H, dtype=torch.float32, device=d)
+        self.eps = torch.zeros(self.G, self.P, dtype=torch.float32, device=d)
+        self.reward = torch.zeros(self.G, dtype=torch.float32, device=d)
+        self.terminal = torch.zeros(self.G, dtype=torch.uint8, device=d)
+        self.a = torch.zeros(self.G, self.P, dtype=torch.int64, device=d)
+        self.greedy_a = torch.zeros(self.G, self.P, dtype=torch.int64, device=d)
+        _lib.check(L.hsad_env_bind_outputs(self.h, self.priv_s.data_ptr(), self.legal_move.data_ptr(),
+                                           self.own_hand.data_ptr(), self.eps.data_ptr(), self.reward.data_ptr(),
+                                           self.terminal.data_ptr()))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.hsad_env_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference-shaped accessors (cpp/hanabi_env.h:53-72) --
+    def feature_size(self):
+        return self.F
+
+    def num_action(self):
+        return self.A
+
+    def hand_feature_size(self):
+        return self.lib.hsad_env_hand_feature_size(self.h)
+
+    def state_bytes(self):
+        return int(self.lib.hsad_env_state_bytes(self.h))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def obs(self):
+        """TensorDict view produced by VectorEnv::reset/step (rela/env.h:48-87)."""
+        return {"priv_s": self.priv_s, "legal_move": self.legal_move, "eps": self.eps, "own_hand": self.own_hand}
+
+    def reset(self):
+        _lib.check(self.lib.hsad_env_reset(self.h, self._stream()))
+        return self.obs()
+
+    def step(self, a, greedy_a=None):
+        assert a.dtype == torch.int64 and a.is_contiguous() and a.device == self.priv_s.device
+        g = greedy_a if greedy_a is not None else (a if self.sad else None)
+        _lib.check(self.lib.hsad_env_step(self.h, a.data_ptr(), g.data_ptr() if g is not None else None,
+                                          self._stream()))
+        return self.obs(), self.reward, self.terminal
+
+    def policy_random(self, policy_seed):
+        _lib.check(self.lib.hsad_env_policy_random(self.h, policy_seed, self.a.data_ptr(), self.greedy_a.data_ptr(),
+                                                   self._stream()))
+        return self.a, self.greedy_a
+
+    def rollout_random(self, n_iter, policy_seed):
+        _lib.check(self.lib.hsad_env_rollout_random(self.h, n_iter, policy_seed, self.a.data_ptr(),
+                                                    self.greedy_a.data_ptr(), self._stream()))
+
+    def query(self):
+        out = torch.zeros(self.G, 16, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_env_query(self.h, out.data_ptr(), self._stream()))
+        return out
+
+    def move_is_legal(self, uid):
+        uid = uid.to(self.device, torch.int32).contiguous()
+        out = torch.zeros(self.G, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.hsad_env_move_is_legal(self.h, uid.data_ptr(), out.data_ptr(), self._stream()))
+        return out
+
+    def deck_history(self):
+        out = torch.zeros(self.G, 50, dtype=torch.uint8, device=self.device)
+        cnt = torch.zeros(self.G, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_env_deck_history(self.h, out.data_ptr(), cnt.data_ptr(), self._stream()))
+        return out, cnt
+
+    def export_state(self):
+        w = self.lib.hsad_env_state_words(self.h)
+        out = torch.zeros(self.G, w, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_env_export_state(self.h, out.data_ptr(), self._stream()))
+        return out
+
+    def check_errors(self):
+        """Raises if any game hit what the reference treats as assert(false) (hanabi_env.cc:50,63-80)."""
+        n, g, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.hsad_env_error_count(self.h, C.byref(n), C.byref(g), C.byref(c)))
+        if n.value:
+            what = {1: "illegal move", 2: "illegal greedy move", 3: "step on a finished game"}.get(c.value, "?")
+            raise _lib.HsadError("%d game(s) violated the env contract; first: game %d, %s" % (n.value, g.value, what))

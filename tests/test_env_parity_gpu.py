@@ -1,0 +1,120 @@
+"""GPU parity: HIP env kernels (through the C ABI) vs the CPU oracle, bit-exact, step by step.
+
+Compared every iteration on identical seeds and identical action streams: priv_s, legal_move,
+own_hand, eps after reset-terminated; the sampled actions; priv_s/legal/own_hand/reward/terminal and
+the canonical integer state dump (incl. RNG draws consumed) after step."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.oracle import OracleEnv, policy_random
+
+pytestmark = pytest.mark.gpu
+
+EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]  # utils.generate_explore_eps(0.1, 7, 80)
+
+CONFIGS = [
+    # players, hand, sad, shuffle_color, knowledge_mode, bomb, max_len, G, iters
+    dict(players=2, hand_size=5, sad=False, shuffle_color=False, knowledge_mode=0, bomb=0, max_len=80, G=70, iters=120),
+    dict(players=2, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=1, max_len=80, G=70, iters=120),
+    dict(players=2, hand_size=5, sad=True, shuffle_color=False, knowledge_mode=1, bomb=0, max_len=12, G=65, iters=60),
+    dict(players=3, hand_size=5, sad=False, shuffle_color=True, knowledge_mode=1, bomb=0, max_len=-1, G=33, iters=80),
+    dict(players=5, hand_size=4, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80, G=64, iters=80),
+    dict(players=4, hand_size=4, sad=False, shuffle_color=False, knowledge_mode=0, bomb=1, max_len=80, G=17, iters=60),
+]
+
+
+def _cmp(name, dev, ref, it):
+    dev = dev.cpu().numpy()
+    if dev.dtype == np.float32:
+        same = dev.view(np.uint32) == np.ascontiguousarray(ref, np.float32).view(np.uint32)
+    else:
+        same = dev == ref
+    if not same.all():
+        bad = np.argwhere(~same)
+        raise AssertionError("%s differs at iteration %d: %d entries, first %s dev=%r ref=%r" % (
+            name, it, len(bad), bad[0], dev[tuple(bad[0])], np.asarray(ref)[tuple(bad[0])]))
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "p%dh%d_sad%d_sc%d_k%d" % (
+    c["players"], c["hand_size"], c["sad"], c["shuffle_color"], c["knowledge_mode"]))
+def test_env_bit_parity(cfg):
+    from hanabi_sad_amd import BatchedHanabiEnv
+    cfg = dict(cfg)
+    G, iters = cfg.pop("G"), cfg.pop("iters")
+    seed, pseed = 9000, 77
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", **cfg)
+    refs = [OracleEnv(seed=seed + g, eps_list=EPS, **cfg) for g in range(G)]
+    P, F, A, H = dev.P, dev.F, dev.A, dev.H
+    assert (F, A) == (refs[0].F, refs[0].A)
+    r_priv = np.zeros((G, P, F), np.float32)
+    r_legal = np.zeros((G, P, A), np.float32)
+    r_own = np.zeros((G, P, 3 * H), np.float32)
+    r_eps = np.zeros((G, P), np.float32)
+    r_rew = np.zeros((G,), np.float32)
+    r_term = np.zeros((G,), np.uint8)
+    r_a = np.zeros((G, P), np.int64)
+    r_g = np.zeros((G, P), np.int64)
+    counters = np.zeros((G,), np.int64)
+    n_reset = n_term = 0
+    for it in range(iters):
+        dev.reset()
+        for g, e in enumerate(refs):
+            if e.terminated():
+                o = e.reset()
+                n_reset += 1
+                r_priv[g], r_legal[g], r_own[g], r_eps[g] = o["priv_s"], o["legal_move"], o["own_hand"], o["eps"]
+        _cmp("reset priv_s", dev.priv_s, r_priv, it)
+        _cmp("reset legal_move", dev.legal_move, r_legal, it)
+        _cmp("reset own_hand", dev.own_hand, r_own, it)
+        _cmp("reset eps", dev.eps, r_eps, it)
+        a, ga = dev.policy_random(pseed)
+        for g, e in enumerate(refs):
+            r_a[g], r_g[g] = policy_random(r_legal[g], pseed, g, int(counters[g]))
+            counters[g] += 1
+        _cmp("policy a", a, r_a, it)
+        _cmp("policy greedy_a", ga, r_g, it)
+        dev.step(a, ga)
+        for g, e in enumerate(refs):
+            o, r, t = e.step(r_a[g], r_g[g])
+            r_priv[g], r_legal[g], r_own[g], r_eps[g] = o["priv_s"], o["legal_move"], o["own_hand"], o["eps"]
+            r_rew[g], r_term[g] = r, t
+            n_term += int(t)
+        dev.check_errors()
+        for e in refs:
+            e.terminated()  # VectorEnv::anyTerminated() runs right after step and latches lastScore_
+        _cmp("step priv_s", dev.priv_s, r_priv, it)
+        _cmp("step legal_move", dev.legal_move, r_legal, it)
+        _cmp("step own_hand", dev.own_hand, r_own, it)
+        _cmp("step eps", dev.eps, r_eps, it)
+        _cmp("step reward", dev.reward, r_rew, it)
+        _cmp("step terminal", dev.terminal, r_term, it)
+        r_state = np.stack([e.export_state() for e in refs])
+        _cmp("state dump", dev.export_state(), r_state, it)
+        q = dev.query().cpu().numpy()
+        assert (q[:, 0] == np.array([e.terminated() for e in refs])).all()
+        assert (q[:, 2] == np.array([e.get("score") for e in refs])).all()
+        assert (q[:, 5] == np.array([e.get("last_score") for e in refs])).all()
+    assert n_reset > G and n_term > 0  # several episodes per game were covered
+    dh, cnt = dev.deck_history()
+    dh, cnt = dh.cpu().numpy(), cnt.cpu().numpy()
+    for g, e in enumerate(refs):
+        ref_dh = e.deck_history()
+        assert cnt[g] == len(ref_dh) and list(dh[g, :cnt[g]]) == ref_dh
+
+
+def test_illegal_move_is_reported_not_applied():
+    from hanabi_sad_amd import BatchedHanabiEnv, HsadError
+    dev = BatchedHanabiEnv(4, seed=1, eps_list=[0.0], device="cuda:0")
+    dev.reset()
+    before = dev.export_state().clone()
+    a = torch.full((4, 2), 20, dtype=torch.int64, device="cuda:0")  # noop uid for the player on turn
+    dev.step(a)
+    with pytest.raises(HsadError):
+        dev.check_errors()
+    assert torch.equal(before, dev.export_state())
+    # stepping finished games is rejected the same way (assert(!terminated()) in the reference)
+    dev2 = BatchedHanabiEnv(2, seed=1, eps_list=[0.0], device="cuda:0")
+    dev2.step(torch.zeros(2, 2, dtype=torch.int64, device="cuda:0"))
+    with pytest.raises(HsadError):
+        dev2.check_errors()
