@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path (BASELINE.json): Hanabi env-steps/sec.
+
+`python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+
+A "step" = one iteration of the reference thread-loop body (cpp/thread_loop.h:46-72) over all G games
+of this rank: reset-terminated -> random-legal policy -> env step (+observe), i.e. G env-steps
+(Tachometer `act` unit: pyhanabi/utils.py:229-236).  Workload = BASELINE.json configs[1]:
+65,536 concurrent 2-player games per GPU, random-action policy, synthetic (random-policy) play.
+Games are independent, so N GPUs run N shards with no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel: env step) and, at N=1,
+`cpu_baseline` (the CPU oracle timed on this box's host cores — a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+GAMES_PER_GPU = 65536
+PLAYERS, HAND = 2, 5
+EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]  # utils.generate_explore_eps(0.1, 7, 80)
+
+
+def algorithmic_bytes_per_step(P, F, A, H, sad):
+    """obs outputs f32 + reward/terminal + actions in + nominal 128-B state r/w."""
+    return P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 * (1 + int(sad)) + 2 * 128
+
+
+def measured_traffic_bytes(G):
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/, collected with
+    separate --pmc WRITE_SIZE / FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM).  Only valid for
+    the configuration it was measured at; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        rec = json.load(open(path))["env_kernel<1,2,5> step+observe, G=65536"]
+        return rec["hbm_bytes_per_launch"] if G == 65536 else None
+    except Exception:
+        return None
+
+
+def cpu_baseline(seconds=8.0):
+    """The CPU oracle (port of the reference algorithm; the reference binary is unbuildable here: HLE
+    submodule absent) in the reference's config-1 shape: 1 thread, 80 games, max_len 80, random policy."""
+    from oracle.oracle import OracleVecEnv
+    import multiprocessing as mp
+
+    def run(seed, secs, q=None):
+        v = OracleVecEnv(80, seed, fast=True, players=PLAYERS, hand_size=HAND, eps_list=EPS, max_len=80)
+        v.rollout(20, 3)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            n += v.rollout(50, 3)
+        rate = n / (time.perf_counter() - t0)
+        if q is not None:
+            q.put(rate)
+        return rate, n
+
+    one, n_one = run(1, seconds)
+    ncores = os.cpu_count() or 1
+    q = mp.Queue()
+    procs = [mp.Process(target=run, args=(1000 * (i + 1), seconds, q)) for i in range(ncores)]
+    for p in procs:
+        p.start()
+    rates = [q.get() for _ in procs]
+    for p in procs:
+        p.join()
+    return {
+        "value": one, "unit": "env-steps/s", "cores": 1, "kind": "port",
+        "sample": "oracle/hanabi_oracle.cc (-O3 -march=native), 1 thread x 80 games (configs[0] shape), "
+                  "%d env-steps in %.0f s wall" % (n_one, seconds),
+        "all_cores_value": sum(rates), "all_cores": ncores,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-samples", type=int, default=50)
+    ap.add_argument("--partitions", type=int, default=1, help="stream partitions for the rollout (hsad_env_set_partitions)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from hanabi_sad_amd import BatchedHanabiEnv
+    from hanabi_sad_amd.dist import shard_range, shard_seed
+    G = args.games  # per GPU (weak scaling): rank r owns global games [r*G, (r+1)*G)
+    begin, _ = shard_range(G * world, rank, world)
+    env = BatchedHanabiEnv(G, players=PLAYERS, hand_size=HAND, seed=shard_seed(1, begin), eps_list=EPS, max_len=80,
+                           sad=False, device=dev, track_deck_history=False)
+    env.set_partitions(args.partitions)
+    policy_seed = 12345 + rank
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    env.rollout_random(args.warmup, policy_seed)
+    barrier()
+    t0 = time.perf_counter()
+    env.rollout_random(args.steps, policy_seed)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    env.check_errors()
+
+    # dominant kernel (env step) timed live with HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.kernel_samples)]
+    for e0, e1 in ev:
+        env.reset()
+        a, g = env.policy_random(policy_seed)
+        e0.record()
+        env.step(a, g)
+        e1.record()
+    torch.cuda.synchronize()
+    env.check_errors()
+    step_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+    bytes_per_step = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, False)
+    achieved = bytes_per_step * G / (step_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "hanabi_env_steps_per_sec",
+            "value": world * G * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: %d concurrent 2-player Hanabi games per GPU, random-legal policy, "
+                            "reset-terminated kernel + step/observe kernel (policy in-kernel), fp32 obs [G,2,783] "
+                            "written to HBM" % G,
+                "games_per_gpu": G, "players": PLAYERS, "hand_size": HAND, "feature_size": env.F,
+                "num_action": env.A, "max_len": 80, "sharding": "games sharded across ranks, no collective",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "env_kernel<1,2,5> (step+observe, actions from HBM)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(G),
+                "algorithmic_bytes_per_env_step": bytes_per_step, "avg_launch_ms": step_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -20,7 +20,7 @@ class EnvConfig(C.Structure):
         ("num_games", C.c_int32), ("players", C.c_int32), ("hand_size", C.c_int32), ("bomb", C.c_int32),
         ("seed0", C.c_int32), ("max_len", C.c_int32), ("sad", C.c_int32), ("shuffle_obs", C.c_int32),
         ("shuffle_color", C.c_int32), ("knowledge_mode", C.c_int32), ("n_eps", C.c_int32), ("device", C.c_int32),
-        ("track_deck_history", C.c_int32), ("reserved", C.c_int32), ("eps_list", C.POINTER(C.c_float)),
+        ("track_deck_history", C.c_int32), ("deal_mode", C.c_int32), ("eps_list", C.POINTER(C.c_float)),
     ]
 
 
@@ -42,11 +42,13 @@ SIGNATURES = {
     "hsad_env_step": (C.c_int, [_P, _P, _P, _P]),
     "hsad_env_policy_random": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
     "hsad_env_rollout_random": (C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
+    "hsad_env_set_partitions": (C.c_int, [_P, C.c_int]),
     "hsad_env_query": (C.c_int, [_P, _P, _P]),
     "hsad_env_move_is_legal": (C.c_int, [_P, _P, _P, _P]),
     "hsad_env_deck_history": (C.c_int, [_P, _P, _P, _P]),
     "hsad_env_state_words": (C.c_int, [_P]),
     "hsad_env_export_state": (C.c_int, [_P, _P, _P]),
+    "hsad_env_debug_timing": (C.c_int, [_P, _P]),
     "hsad_env_error_count": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 }
 

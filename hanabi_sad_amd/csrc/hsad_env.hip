@@ -45,11 +45,14 @@ enum : int {
   PL_BOARD = 4,   // fireworks 5x3b [0..14] | info [15..18] | life [19..20] | turns_to_play [21..23]
                   // | cur_player+1 [24..26] | next_non_chance_player [27..29]
   PL_MISC = 5,    // num_step [0..7] | deck_size [8..13] | term [14] | started [15] | last_score+1 [16..21]
+                  // | la_n [22..23] = number of buffered look-ahead RNG outputs
   PL_LASTMV = 6,  // newest non-deal move: type[0..2] player[3..5] target_off[6..8] colour[9..11]
                   // rank[12..14] card_index[15..17] reveal_mask[18..22] card_colour[23..25]
                   // card_rank[26..28] scored[29] info_token[30]
-  PL_DRAWS = 7,   // raw mt19937 draws consumed so far
-  PL_FIXED = 8
+  PL_DRAWS = 7,   // raw mt19937 draws consumed so far (logical; memory is la_n draws ahead)
+  PL_LA0 = 8,     // look-ahead: the next two tempered mt19937 outputs, regenerated off the critical path
+  PL_LA1 = 9,
+  PL_FIXED = 10
 };
 // then per player p: HAND(p) cards 5x5b [0..24] | len [25..27];  KCP(p) colour-plausible 5x5b;
 // KRP(p) rank-plausible 5x5b;  KH(p) hints 5x6b (hinted colour+1 [0..2], hinted rank+1 [3..5]);
@@ -58,28 +61,27 @@ enum : int {
 struct EnvParams {
   int G, Gpad, P, H, A, F, F0, LAL, OB, OD, OL, OK, DECKW;
   int max_len, sad, shuffle_color, bomb, kmode, n_eps, track_dh, npl;
-  int obs_words, legal_words, own_words;
-  int seed0;
+  int obs_words, legal_words, own_words, win_w;
+  int seed0, deal_mode;
+  int g_begin, g_count;            // launch covers games [g_begin, g_begin + g_count); g_begin % 64 == 0
+  unsigned long long policy_seed;  // MODE 2 (step with built-in random-legal policy)
+  int64_t* a_out;                  // MODE 2: where the sampled actions are recorded ([G,P] each)
+  int64_t* g_out;
   uint32_t* planes;
   uint32_t* mt;
   const float* eps_list;
   uint8_t* deck_hist;
   uint32_t* err;
   uint32_t* act_count;
+  unsigned long long* legal_bits;  // [G, P] compact legal-move masks (bit uid), side output for device consumers
   float* priv_s;
   float* legal;
   float* own;
   float* eps;
   float* reward;
   uint8_t* terminal;
+  unsigned long long* dbg;  // optional per-wave phase timestamps [grid][8] (hsad_env_debug_timing)
 };
-
-__device__ __forceinline__ int pl_hand(const EnvParams& ep, int p) { return PL_FIXED + p; }
-__device__ __forceinline__ int pl_kcp(const EnvParams& ep, int p) { return PL_FIXED + ep.P + p; }
-__device__ __forceinline__ int pl_krp(const EnvParams& ep, int p) { return PL_FIXED + 2 * ep.P + p; }
-__device__ __forceinline__ int pl_kh(const EnvParams& ep, int p) { return PL_FIXED + 3 * ep.P + p; }
-__device__ __forceinline__ int pl_eps(const EnvParams& ep, int p) { return PL_FIXED + 4 * ep.P + p; }
-__device__ __forceinline__ int pl_perm(const EnvParams& ep, int p) { return PL_FIXED + 5 * ep.P + p; }
 
 constexpr uint32_t kIdentityPerm = (0u) | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
 constexpr uint32_t kIdentityPermBoth = kIdentityPerm | (kIdentityPerm << 15);
@@ -94,31 +96,106 @@ __host__ __device__ constexpr uint64_t full_deck_bits() {
 }
 
 // ---- mt19937, incremental form -----------------------------------------------------------------
-__device__ __forceinline__ uint32_t mt_draw(uint32_t* mt, uint32_t& draws) {
-  uint32_t i = draws % (uint32_t)kMtN;
-  draws += 1;
-  uint32_t i1 = i + 1;
-  if (i1 == (uint32_t)kMtN) i1 = 0;
-  uint32_t im = i + kMtM;
-  if (im >= (uint32_t)kMtN) im -= kMtN;
-  uint32_t y = (mt[i] & 0x80000000u) | (mt[i1] & 0x7fffffffu);
-  uint32_t x = mt[im] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  mt[i] = x;
+// The generator state is advanced one word per draw:  x[i] <- x[i+397] ^ twist(x[i], x[i+1]),
+// output = temper(x[i]) — identical to std::mt19937's batch regeneration, without the 624-word stall.
+constexpr uint32_t kMtUpper = 0x80000000u, kMtLower = 0x7fffffffu, kMtMag = 0x9908b0dfu;
+
+__device__ __forceinline__ uint32_t mt_temper(uint32_t x) {
   x ^= x >> 11;
   x ^= (x << 7) & 0x9d2c5680u;
   x ^= (x << 15) & 0xefc60000u;
   x ^= x >> 18;
   return x;
 }
+__device__ __forceinline__ uint32_t mt_twist(uint32_t xi, uint32_t xi1, uint32_t xim) {
+  const uint32_t y = (xi & kMtUpper) | (xi1 & kMtLower);
+  return xim ^ (y >> 1) ^ ((y & 1u) ? kMtMag : 0u);
+}
+__device__ __forceinline__ uint32_t wrap624(uint32_t i) { return i >= (uint32_t)kMtN ? i - kMtN : i; }
+
+// Per-lane RNG context for one kernel invocation.  Draws are served, in order, from
+//  (1) the two look-ahead outputs carried in the state planes (regenerated off the critical path),
+//  (2) the reset kernel's LDS prefetch window (new state words for positions wbase+k, not yet in HBM),
+//  (3) the memory slow path (three dependent loads + one store per draw).
+struct Rng {
+  uint32_t* mt;
+  uint32_t draws;  // logical draws consumed
+  uint32_t la0, la1;
+  int la_n;
+  uint32_t spos;  // memory position the slow path regenerates next
+  uint32_t* win;  // LDS, lane-strided by kWave; nullptr when there is no window
+  int w_c, w_n;
+};
+
+__device__ __forceinline__ uint32_t rng_next(Rng& r) {
+  r.draws += 1;
+  if (r.la_n > 0) {
+    const uint32_t v = r.la0;
+    r.la0 = r.la1;
+    r.la_n -= 1;
+    return v;
+  }
+  if (r.w_c < r.w_n) {
+    const uint32_t v = mt_temper(r.win[r.w_c * kWave]);
+    r.w_c += 1;
+    return v;
+  }
+  const uint32_t i = r.spos;
+  const uint32_t x = mt_twist(r.mt[i], r.mt[wrap624(i + 1)], r.mt[wrap624(i + kMtM)]);
+  r.mt[i] = x;
+  r.spos = wrap624(i + 1);
+  return mt_temper(x);
+}
+
+__device__ __forceinline__ void la_push(Rng& r, uint32_t out) {
+  if (r.la_n == 0)
+    r.la0 = out;
+  else
+    r.la1 = out;
+  r.la_n += 1;
+}
+
+// Look-ahead refill, split so the loads are in flight while the observation rows are built.
+struct Refill {
+  uint32_t pos, r0, r1, r2, m0, m1;
+  int need;
+};
+__device__ __forceinline__ void refill_issue(Refill& f, const Rng& r, bool active) {
+  f.need = active ? 2 - r.la_n : 0;
+  f.pos = r.spos;
+  f.r0 = f.r1 = f.r2 = f.m0 = f.m1 = 0;
+  if (f.need > 0) {
+    const uint32_t i = f.pos;
+    f.r0 = r.mt[i];
+    f.r1 = r.mt[wrap624(i + 1)];
+    f.r2 = r.mt[wrap624(i + 2)];
+    f.m0 = r.mt[wrap624(i + kMtM)];
+    f.m1 = r.mt[wrap624(i + 1 + kMtM)];
+  }
+}
+__device__ __forceinline__ void refill_finish(const Refill& f, Rng& r) {
+  if (f.need > 0) {
+    const uint32_t x0 = mt_twist(f.r0, f.r1, f.m0);
+    r.mt[f.pos] = x0;
+    la_push(r, mt_temper(x0));
+    r.spos = wrap624(f.pos + 1);
+    if (f.need > 1) {
+      const uint32_t x1 = mt_twist(f.r1, f.r2, f.m1);
+      r.mt[r.spos] = x1;
+      la_push(r, mt_temper(x1));
+      r.spos = wrap624(r.spos + 1);
+    }
+  }
+}
 
 // libstdc++ uniform_int_distribution<>::_S_nd (Lemire) on a 32-bit generator: value in [0, range)
-__device__ __forceinline__ uint32_t uniform_below(uint32_t range, uint32_t* mt, uint32_t& draws) {
-  uint64_t product = (uint64_t)mt_draw(mt, draws) * (uint64_t)range;
+__device__ __forceinline__ uint32_t uniform_below(uint32_t range, Rng& r) {
+  uint64_t product = (uint64_t)rng_next(r) * (uint64_t)range;
   uint32_t low = (uint32_t)product;
   if (low < range) {
-    uint32_t threshold = (0u - range) % range;
+    const uint32_t threshold = (0u - range) % range;
     while (low < threshold) {
-      product = (uint64_t)mt_draw(mt, draws) * (uint64_t)range;
+      product = (uint64_t)rng_next(r) * (uint64_t)range;
       low = (uint32_t)product;
     }
   }
@@ -127,53 +204,78 @@ __device__ __forceinline__ uint32_t uniform_below(uint32_t range, uint32_t* mt, 
 
 __device__ __forceinline__ uint32_t cnt2(uint64_t bits, int t) { return (uint32_t)(bits >> (2 * t)) & 3u; }
 
-// HanabiState::ApplyRandomChance: std::discrete_distribution over the card types still in the deck
-// with double weights count/deck_size; returns the dealt card type.  Consumes two draws unless
-// fewer than two types remain (then libstdc++ returns index 0 without touching the generator).
-__device__ int deal_pick(uint64_t deck, int deck_size, uint32_t* mt, uint32_t& draws) {
-  int ntypes = 0, first_t = -1, last_t = -1;
+// Literal restatement of std::discrete_distribution<>(probs)(rng) with probs = count/deck_size
+// (libstdc++ random.tcc: normalise by the sequential sum, partial sums, last := 1.0,
+// p = generate_canonical<double,53> = (u1 + u2*2^32)/2^64, index = lower_bound(cp, p)).
+__device__ __noinline__ int deal_pick_exact(uint64_t deck, int deck_size, uint32_t u1, uint32_t u2) {
+  int last_t = -1;
 #pragma unroll
-  for (int t = 0; t < 25; ++t) {
-    if (cnt2(deck, t)) {
-      ++ntypes;
-      last_t = t;
-      if (first_t < 0) first_t = t;
-    }
-  }
-  if (ntypes < 2) return first_t;
+  for (int t = 0; t < 25; ++t)
+    if (cnt2(deck, t)) last_t = t;
   const double D = (double)deck_size;
   const double w1 = 1.0 / D, w2 = 2.0 / D, w3 = 3.0 / D;
   double sum = 0.0;
 #pragma unroll
   for (int t = 0; t < 25; ++t) {
-    uint32_t c = cnt2(deck, t);
+    const uint32_t c = cnt2(deck, t);
     if (c) sum += (c == 1 ? w1 : (c == 2 ? w2 : w3));
   }
   const double p1 = w1 / sum, p2 = w2 / sum, p3 = w3 / sum;
-  const uint32_t u1 = mt_draw(mt, draws);
-  const uint32_t u2 = mt_draw(mt, draws);
   double u = ((double)u1 + (double)u2 * 4294967296.0) / 18446744073709551616.0;
   if (u >= 1.0) u = 0x1.fffffffffffffp-1;  // nextafter(1, 0)
   double cum = 0.0;
   int pick = -1;
 #pragma unroll
   for (int t = 0; t < 25; ++t) {
-    uint32_t c = cnt2(deck, t);
+    const uint32_t c = cnt2(deck, t);
     if (c) {
       cum += (c == 1 ? p1 : (c == 2 ? p2 : p3));
-      double cp = (t == last_t) ? 1.0 : cum;
+      const double cp = (t == last_t) ? 1.0 : cum;
       if (pick < 0 && cp >= u) pick = t;
     }
   }
   return pick;
 }
 
+// HanabiState::ApplyRandomChance: returns the dealt card type.  Consumes two draws unless fewer than
+// two card types remain (libstdc++ then returns index 0 without touching the generator).
+//
+// Fast path (deal_mode 0): in exact arithmetic the pick is the first type whose cumulative count C_t
+// satisfies C_t/D >= S/2^64 with S = u1 + u2*2^32.  The fp64 computation above perturbs each side by
+// < 2^-47 (<= 55 roundings of 2^-53 on values <= 1), i.e. by < 2^-41.3 after scaling by D <= 50, so
+// whenever frac(S*D/2^64) lies in [2^-36, 1-2^-36] both give the same index; otherwise (probability
+// 2^-35 per deal) the literal fp64 restatement decides.  deal_mode 1 forces the literal path.
+__device__ __forceinline__ int deal_pick(int deal_mode, uint64_t deck, int deck_size, Rng& r) {
+  const uint64_t nz = (deck | (deck >> 1)) & 0x5555555555555555ull;
+  if (__popcll(nz) < 2) return (int)(__builtin_ctzll(nz) >> 1);
+  const uint32_t u1 = rng_next(r);
+  const uint32_t u2 = rng_next(r);
+  if (deal_mode == 0) {
+    const uint64_t S = (uint64_t)u1 | ((uint64_t)u2 << 32);
+    const uint64_t lo = S * (uint64_t)deck_size;
+    const uint64_t hi = __umul64hi(S, (uint64_t)deck_size);
+    if (lo >= (1ull << 28) && lo <= 0ull - (1ull << 28)) {
+      const uint32_t need = (uint32_t)hi + 1u;
+      const uint32_t dlo = (uint32_t)deck, dhi = (uint32_t)(deck >> 32);
+      uint32_t acc = 0;
+      int pick = -1;
+#pragma unroll
+      for (int t = 0; t < 25; ++t) {
+        acc += (t < 16) ? ((dlo >> (2 * t)) & 3u) : ((dhi >> (2 * (t - 16))) & 3u);
+        if (pick < 0 && acc >= need) pick = t;
+      }
+      return pick;
+    }
+  }
+  return deal_pick_exact(deck, deck_size, u1, u2);
+}
+
 // ---- small packed-field helpers -----------------------------------------------------------------
 __device__ __forceinline__ uint32_t remove_field(uint32_t x, int i, int w, int nfields) {
   const uint32_t total_mask = (nfields * w >= 32) ? 0xffffffffu : ((1u << (nfields * w)) - 1u);
-  uint32_t body = x & total_mask;
-  uint32_t low = body & ((1u << (i * w)) - 1u);
-  uint32_t high = ((i + 1) * w >= 32) ? 0u : (body >> ((i + 1) * w));
+  const uint32_t body = x & total_mask;
+  const uint32_t low = body & ((1u << (i * w)) - 1u);
+  const uint32_t high = ((i + 1) * w >= 32) ? 0u : (body >> ((i + 1) * w));
   return (x & ~total_mask) | low | (high << (i * w));
 }
 
@@ -190,8 +292,6 @@ __device__ __forceinline__ uint32_t board_set(uint32_t b, int shift, uint32_t ma
   return (b & ~(mask << shift)) | (v << shift);
 }
 
-// history-item record of `move` applied by `cur` in the current state (no mutation); also used for
-// the SAD greedy move (reference applies it to a clone only to read this back: hanabi_env.cc:82-91).
 struct MoveDec {
   int type;  // 0 invalid, 1 play, 2 discard, 3 reveal colour, 4 reveal rank
   int idx;   // card index
@@ -199,6 +299,7 @@ struct MoveDec {
   int val;   // colour or rank
 };
 
+// HanabiGame::GetMove: uid order discard, play, reveal colour, reveal rank
 __device__ __forceinline__ MoveDec decode_uid(int uid, int P, int H) {
   MoveDec m{0, 0, 0, 0};
   if (uid < 0) return m;
@@ -230,93 +331,104 @@ __device__ __forceinline__ MoveDec decode_uid(int uid, int P, int H) {
   return m;
 }
 
+// per-slot match mask of a packed hand word; cards are 5-bit colour*5+rank
 __device__ __forceinline__ uint32_t hand_match_mask(uint32_t hw, bool by_color, int val) {
   const int len = (hw >> 25) & 7;
   uint32_t m = 0;
-  for (int i = 0; i < len; ++i) {
-    int card = (hw >> (5 * i)) & 31;
-    int c = card / 5, r = card - 5 * c;
-    if ((by_color ? c : r) == val) m |= 1u << i;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int card = (hw >> (5 * i)) & 31;
+    const int c = (card * 13) >> 6;  // card / 5 for card < 32
+    const int r = card - 5 * c;
+    if (i < len && (by_color ? c : r) == val) m |= 1u << i;
   }
   return m;
 }
 
 #define ST(pl) s_st[(pl) * kWave + lane]
+#define STAMP(k)                                                                                        \
+  do {                                                                                                  \
+    if (ep.dbg && threadIdx.x == 0) ep.dbg[((size_t)(ep.g_begin / kWave) + blockIdx.x) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#define PLH(p) (PL_FIXED + (p))
+#define PLKCP(p) (PL_FIXED + P + (p))
+#define PLKRP(p) (PL_FIXED + 2 * P + (p))
+#define PLKH(p) (PL_FIXED + 3 * P + (p))
+#define PLEPS(p) (PL_FIXED + 4 * P + (p))
+#define PLPERM(p) (PL_FIXED + 5 * P + (p))
 
-__device__ bool move_is_legal(const EnvParams& ep, const uint32_t* s_st, int lane, const MoveDec& m) {
+__device__ __forceinline__ bool move_is_legal(int P, const uint32_t* s_st, int lane, const MoveDec& m) {
   const uint32_t board = ST(PL_BOARD);
   const int cur = board_cur(board);
   if (m.type == 0 || cur < 0) return false;
   if (m.type == 1 || m.type == 2) {
     if (m.type == 2 && board_info(board) >= 8) return false;
-    const int len = (ST(pl_hand(ep, cur)) >> 25) & 7;
+    const int len = (ST(PLH(cur)) >> 25) & 7;
     return m.idx < len;
   }
   if (board_info(board) <= 0) return false;
-  if (m.off < 1 || m.off >= ep.P) return false;
+  if (m.off < 1 || m.off >= P) return false;
   int q = cur + m.off;
-  if (q >= ep.P) q -= ep.P;
-  return hand_match_mask(ST(pl_hand(ep, q)), m.type == 3, m.val) != 0;
+  if (q >= P) q -= P;
+  return hand_match_mask(ST(PLH(q)), m.type == 3, m.val) != 0;
 }
 
-__device__ uint32_t make_history(const EnvParams& ep, const uint32_t* s_st, int lane, const MoveDec& m) {
+// history-item record of `move` applied by the player on turn in the current state (no mutation);
+// also used for the SAD greedy move (the reference applies it to a clone only to read this back:
+// cpp/hanabi_env.cc:82-91).
+__device__ __forceinline__ uint32_t make_history(int P, const uint32_t* s_st, int lane, const MoveDec& m) {
   const uint32_t board = ST(PL_BOARD);
   const int cur = board_cur(board);
   uint32_t rec = (uint32_t)m.type | ((uint32_t)cur << 3);
   if (m.type == 1 || m.type == 2) {
-    const uint32_t hw = ST(pl_hand(ep, cur));
+    const uint32_t hw = ST(PLH(cur));
     const int card = (hw >> (5 * m.idx)) & 31;
-    const int c = card / 5, r = card - 5 * c;
+    const int c = (card * 13) >> 6, r = card - 5 * c;
     rec |= (uint32_t)m.idx << 15;
     rec |= (uint32_t)c << 23;
     rec |= (uint32_t)r << 26;
     if (m.type == 2) {
       if (board_info(board) < 8) rec |= 1u << 30;
     } else {
-      const bool scored = (r == board_fw(board, c));
-      if (scored) {
+      if (r == board_fw(board, c)) {
         rec |= 1u << 29;
         if (r + 1 == 5 && board_info(board) < 8) rec |= 1u << 30;
       }
     }
   } else {
     int q = cur + m.off;
-    if (q >= ep.P) q -= ep.P;
+    if (q >= P) q -= P;
     rec |= (uint32_t)m.off << 6;
-    if (m.type == 3)
-      rec |= (uint32_t)m.val << 9;
-    else
-      rec |= (uint32_t)m.val << 12;
-    rec |= hand_match_mask(ST(pl_hand(ep, q)), m.type == 3, m.val) << 18;
+    rec |= (uint32_t)m.val << (m.type == 3 ? 9 : 12);
+    rec |= hand_match_mask(ST(PLH(q)), m.type == 3, m.val) << 18;
   }
   return rec;
 }
 
 // HanabiState::AdvanceToNextPlayer
-__device__ __forceinline__ uint32_t advance_player(const EnvParams& ep, const uint32_t* s_st, int lane,
-                                                   uint32_t board, int deck_size) {
+__device__ __forceinline__ uint32_t advance_player(int P, int H, const uint32_t* s_st, int lane, uint32_t board,
+                                                   int deck_size) {
   bool short_hand = false;
-  for (int p = 0; p < ep.P; ++p) short_hand |= (int)((ST(pl_hand(ep, p)) >> 25) & 7) < ep.H;
+  for (int p = 0; p < P; ++p) short_hand |= (int)((ST(PLH(p)) >> 25) & 7) < H;
   if (deck_size > 0 && short_hand) {
     board = board_set(board, 24, 7u, 0u);  // chance player (-1)
   } else {
-    int nxt = board_next(board);
+    const int nxt = board_next(board);
     board = board_set(board, 24, 7u, (uint32_t)(nxt + 1));
     int nn = nxt + 1;
-    if (nn >= ep.P) nn = 0;
+    if (nn >= P) nn = 0;
     board = board_set(board, 27, 7u, (uint32_t)nn);
   }
   return board;
 }
 
 // deal one card to the first short hand (kDeal branch of HanabiState::ApplyMove + ApplyRandomChance)
-__device__ void deal_one(const EnvParams& ep, uint32_t* s_st, int lane, uint32_t* mt, int g) {
+__device__ __forceinline__ void deal_one(const EnvParams& ep, int P, int H, uint32_t* s_st, int lane, Rng& rng,
+                                         int g) {
   uint64_t deck = (uint64_t)ST(PL_DECK_LO) | ((uint64_t)ST(PL_DECK_HI) << 32);
   uint32_t misc = ST(PL_MISC);
   int deck_size = (misc >> 8) & 63;
-  uint32_t draws = ST(PL_DRAWS);
-  const int t = deal_pick(deck, deck_size, mt, draws);
-  ST(PL_DRAWS) = draws;
+  const int t = deal_pick(ep.deal_mode, deck, deck_size, rng);
   deck -= (uint64_t)1 << (2 * t);
   ST(PL_DECK_LO) = (uint32_t)deck;
   ST(PL_DECK_HI) = (uint32_t)(deck >> 32);
@@ -325,30 +437,32 @@ __device__ void deal_one(const EnvParams& ep, uint32_t* s_st, int lane, uint32_t
   misc = (misc & ~(63u << 8)) | ((uint32_t)deck_size << 8);
   ST(PL_MISC) = misc;
   int to = 0;
-  for (int p = ep.P - 1; p >= 0; --p)
-    if ((int)((ST(pl_hand(ep, p)) >> 25) & 7) < ep.H) to = p;
-  uint32_t hw = ST(pl_hand(ep, to));
+  for (int p = P - 1; p >= 0; --p)
+    if ((int)((ST(PLH(p)) >> 25) & 7) < H) to = p;
+  uint32_t hw = ST(PLH(to));
   const int len = (hw >> 25) & 7;
   hw = (hw & ~(7u << 25)) | ((uint32_t)t << (5 * len)) | ((uint32_t)(len + 1) << 25);
-  ST(pl_hand(ep, to)) = hw;
-  ST(pl_kcp(ep, to)) |= 31u << (5 * len);
-  ST(pl_krp(ep, to)) |= 31u << (5 * len);
-  ST(pl_kh(ep, to)) &= ~(63u << (6 * len));
-  ST(PL_BOARD) = advance_player(ep, s_st, lane, ST(PL_BOARD), deck_size);
+  ST(PLH(to)) = hw;
+  ST(PLKCP(to)) |= 31u << (5 * len);
+  ST(PLKRP(to)) |= 31u << (5 * len);
+  ST(PLKH(to)) &= ~(63u << (6 * len));
+  ST(PL_BOARD) = advance_player(P, H, s_st, lane, ST(PL_BOARD), deck_size);
 }
 
-// ---- LDS bit-row helpers ---------------------------------------------------------------------------
-__device__ __forceinline__ void or_bits(uint32_t* b, uint32_t pos, uint64_t val) {
-  if (!val) return;
+// ---- LDS bit-row helpers (branch-free: OR-ing zero is a no-op) ------------------------------------
+__device__ __forceinline__ void or_bit(uint32_t* b, uint32_t pos) { atomicOr(&b[pos >> 5], 1u << (pos & 31)); }
+__device__ __forceinline__ void or_bits32(uint32_t* b, uint32_t pos, uint32_t val) {
+  const uint32_t w = pos >> 5, s = pos & 31;
+  const uint64_t v = (uint64_t)val << s;
+  atomicOr(&b[w], (uint32_t)v);
+  atomicOr(&b[w + 1], (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ void or_bits64(uint32_t* b, uint32_t pos, uint64_t val) {
   const uint32_t w = pos >> 5, s = pos & 31;
   const uint64_t lo = val << s;
-  const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
-  if (w0) atomicOr(&b[w], w0);
-  if (w1) atomicOr(&b[w + 1], w1);
-  if (s) {
-    const uint32_t w2 = (uint32_t)(val >> (64 - s));
-    if (w2) atomicOr(&b[w + 2], w2);
-  }
+  atomicOr(&b[w], (uint32_t)lo);
+  atomicOr(&b[w + 1], (uint32_t)(lo >> 32));
+  atomicOr(&b[w + 2], ((uint32_t)(val >> 32) >> (31u - s)) >> 1);
 }
 
 __device__ __forceinline__ uint32_t get4(const uint32_t* bits, uint32_t bp) {
@@ -360,8 +474,17 @@ __device__ __forceinline__ uint32_t get4(const uint32_t* bits, uint32_t bp) {
 }
 __device__ __forceinline__ uint32_t get1(const uint32_t* bits, uint32_t bp) { return (bits[bp >> 5] >> (bp & 31)) & 1u; }
 
+__device__ __forceinline__ float4 nib_to_f4(uint32_t nib) {
+  float4 v;
+  v.x = (nib & 1u) ? 1.f : 0.f;
+  v.y = (nib & 2u) ? 1.f : 0.f;
+  v.z = (nib & 4u) ? 1.f : 0.f;
+  v.w = (nib & 8u) ? 1.f : 0.f;
+  return v;
+}
+
 // out[i] = bit(bit0 + i) ? 1.f : 0.f for i in [0, n): 16-byte stores wherever the address allows.
-__device__ void stream_bits_f32(const uint32_t* bits, uint32_t bit0, float* out, uint32_t n, int lane) {
+__device__ __forceinline__ void stream_bits_f32(const uint32_t* bits, uint32_t bit0, float* out, uint32_t n, int lane) {
   const uintptr_t addr = (uintptr_t)out;
   uint32_t head = (uint32_t)(((16u - (uint32_t)(addr & 15u)) & 15u) >> 2);
   if (head > n) head = n;
@@ -369,25 +492,26 @@ __device__ void stream_bits_f32(const uint32_t* bits, uint32_t bit0, float* out,
   const uint32_t nbody = (n - head) >> 2;
   float4* o4 = reinterpret_cast<float4*>(out + head);
   const uint32_t b1 = bit0 + head;
-  for (uint32_t k = lane; k < nbody; k += kWave) {
-    const uint32_t nib = get4(bits, b1 + 4u * k);
-    float4 v;
-    v.x = (nib & 1u) ? 1.f : 0.f;
-    v.y = (nib & 2u) ? 1.f : 0.f;
-    v.z = (nib & 4u) ? 1.f : 0.f;
-    v.w = (nib & 8u) ? 1.f : 0.f;
-    o4[k] = v;
-  }
+  for (uint32_t k = lane; k < nbody; k += kWave) o4[k] = nib_to_f4(get4(bits, b1 + 4u * k));
   const uint32_t done = head + 4u * nbody;
   if ((uint32_t)lane < n - done) out[done + lane] = get1(bits, bit0 + done + lane) ? 1.f : 0.f;
 }
 
+// Same, for the wave-wide aligned case (bit0 == 0, out 16-byte aligned): every lane reads one 32-bit word
+// of bits and emits 8 consecutive float4 — 128 B per lane per iteration, 8 KiB per wave-iteration.
+__device__ __forceinline__ void stream_bits_f32_aligned(const uint32_t* bits, float* out, uint32_t n, int lane) {
+  float4* o4 = reinterpret_cast<float4*>(out);
+  const uint32_t nch = n >> 2;
+  for (uint32_t k = lane; k < nch; k += kWave) o4[k] = nib_to_f4((bits[k >> 3] >> ((k & 7u) * 4u)) & 15u);
+  const uint32_t done = nch << 2;
+  if ((uint32_t)lane < n - done) out[done + lane] = get1(bits, done + lane) ? 1.f : 0.f;
+}
+
 __device__ __forceinline__ uint32_t perm_c(uint32_t pm, int c) { return (pm >> (3 * c)) & 7u; }
 
-__device__ uint64_t encode_last_action(const EnvParams& ep, uint32_t rec, int observer, uint32_t pm) {
+__device__ __forceinline__ uint64_t encode_last_action(int P, int H, uint32_t rec, int observer, uint32_t pm) {
   const int type = rec & 7;
   if (!type) return 0;
-  const int P = ep.P, H = ep.H;
   int rel = (int)((rec >> 3) & 7) - observer;
   if (rel < 0) rel += P;
   uint64_t m = 1ull << rel;
@@ -416,9 +540,10 @@ __device__ uint64_t encode_last_action(const EnvParams& ep, uint32_t rec, int ob
 
 // Build the observation / legal-move / own-hand bit rows of this lane's game for every observer
 // (HanabiEnv::computeFeatureAndLegalMove, cpp/hanabi_env.cc:115-205, on top of the canonical encoder).
-__device__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, uint32_t* s_obs, uint32_t* s_legal,
-                           uint32_t* s_own, uint32_t greedy_rec) {
-  const int P = ep.P, H = ep.H;
+template <int TP, int TH>
+__device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, int g, uint32_t* s_obs,
+                                           uint32_t* s_legal, uint32_t* s_own, uint32_t greedy_rec) {
+  const int P = TP ? TP : ep.P, H = TH ? TH : ep.H;
   const uint32_t board = ST(PL_BOARD);
   const uint32_t misc = ST(PL_MISC);
   const int deck_size = (misc >> 8) & 63;
@@ -426,47 +551,54 @@ __device__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, 
   const uint32_t lastmv = ST(PL_LASTMV);
   const int cur = board_cur(board);
   const int info = board_info(board), life = board_life(board);
+  const uint32_t F = (uint32_t)ep.F;
 
-  for (int p = 0; p < P; ++p) {
-    const uint32_t base = (uint32_t)(lane * P + p) * (uint32_t)ep.F;
-    const uint32_t pm = ep.shuffle_color ? (ST(pl_perm(ep, p)) & 0x7fffu) : kIdentityPerm;
+#pragma unroll
+  for (int p = 0; p < (TP ? TP : 5); ++p) {
+    if (p >= P) break;
+    const uint32_t base = (uint32_t)(lane * P + p) * F;
+    const uint32_t pm = ep.shuffle_color ? (ST(PLPERM(p)) & 0x7fffu) : kIdentityPerm;
     uint32_t miss = 0;
-    for (int o = 0; o < P; ++o) {
+#pragma unroll
+    for (int o = 0; o < (TP ? TP : 5); ++o) {
+      if (o >= P) break;
       int q = p + o;
       if (q >= P) q -= P;
-      const uint32_t hw = ST(pl_hand(ep, q));
+      const uint32_t hw = ST(PLH(q));
       const int len = (hw >> 25) & 7;
       if (len < H) miss |= 1u << o;
-      const uint32_t kcp = ST(pl_kcp(ep, q)), krp = ST(pl_krp(ep, q)), kh = ST(pl_kh(ep, q));
-      for (int i = 0; i < len; ++i) {
-        if (o > 0) {
-          const int card = (hw >> (5 * i)) & 31;
-          const int c = card / 5, r = card - 5 * c;
-          or_bits(s_obs, base + (uint32_t)((o * H + i) * 25) + perm_c(pm, c) * 5u + (uint32_t)r, 1ull);
-        }
-        const uint32_t cp = (kcp >> (5 * i)) & 31u, rp = (krp >> (5 * i)) & 31u;
-        const uint32_t h6 = (kh >> (6 * i)) & 63u;
-        uint64_t m = 0;
+      const uint32_t kcp = ST(PLKCP(q)), krp = ST(PLKRP(q)), kh = ST(PLKH(q));
 #pragma unroll
-        for (int c = 0; c < 5; ++c)
-          if ((cp >> c) & 1u) m |= (uint64_t)rp << (perm_c(pm, c) * 5u);
-        if (h6 & 7u) m |= 1ull << (25u + perm_c(pm, (int)(h6 & 7u) - 1));
-        if (h6 >> 3) m |= 1ull << (30u + (h6 >> 3) - 1u);
-        or_bits(s_obs, base + (uint32_t)ep.OK + (uint32_t)((o * H + i) * 35), m);
+      for (int i = 0; i < (TH ? TH : 5); ++i) {
+        if (i < len) {
+          if (o > 0) {
+            const int card = (hw >> (5 * i)) & 31;
+            const int c = (card * 13) >> 6, r = card - 5 * c;
+            or_bit(s_obs, base + (uint32_t)((o * H + i) * 25) + perm_c(pm, c) * 5u + (uint32_t)r);
+          }
+          const uint32_t cp = (kcp >> (5 * i)) & 31u, rp = (krp >> (5 * i)) & 31u;
+          const uint32_t h6 = (kh >> (6 * i)) & 63u;
+          uint64_t m = 0;
+#pragma unroll
+          for (int c = 0; c < 5; ++c) m |= ((cp >> c) & 1u) ? ((uint64_t)rp << (perm_c(pm, c) * 5u)) : 0ull;
+          if (h6 & 7u) m |= 1ull << (25u + perm_c(pm, (int)(h6 & 7u) - 1));
+          if (h6 >> 3) m |= 1ull << (30u + (h6 >> 3) - 1u);
+          or_bits64(s_obs, base + (uint32_t)ep.OK + (uint32_t)((o * H + i) * 35), m);
+        }
       }
     }
-    or_bits(s_obs, base + (uint32_t)(P * H * 25), (uint64_t)miss);
+    or_bits32(s_obs, base + (uint32_t)(P * H * 25), miss);
     // board: deck thermometer | fireworks one-hot | info thermometer | life thermometer
-    or_bits(s_obs, base + (uint32_t)ep.OB, (1ull << deck_size) - 1ull);
+    or_bits64(s_obs, base + (uint32_t)ep.OB, (1ull << deck_size) - 1ull);
     uint64_t bm = 0;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
       const int f = board_fw(board, c);
-      if (f > 0) bm |= 1ull << (perm_c(pm, c) * 5u + (uint32_t)f - 1u);
+      bm |= (f > 0) ? (1ull << (perm_c(pm, c) * 5u + (uint32_t)f - 1u)) : 0ull;
     }
     bm |= (uint64_t)((1u << info) - 1u) << 25;
     bm |= (uint64_t)((1u << life) - 1u) << 33;
-    or_bits(s_obs, base + (uint32_t)(ep.OB + ep.DECKW), bm);
+    or_bits64(s_obs, base + (uint32_t)(ep.OB + ep.DECKW), bm);
     // discards: thermometers of width 3,2,2,2,1 per colour
     uint64_t dm = 0;
 #pragma unroll
@@ -479,14 +611,14 @@ __device__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, 
         dm |= (uint64_t)((1u << n) - 1u) << (pc * 10u + roff);
       }
     }
-    or_bits(s_obs, base + (uint32_t)ep.OD, dm);
-    or_bits(s_obs, base + (uint32_t)ep.OL, encode_last_action(ep, lastmv, p, pm));
-    if (ep.sad) or_bits(s_obs, base + (uint32_t)ep.F0, encode_last_action(ep, greedy_rec, p, pm));
+    or_bits64(s_obs, base + (uint32_t)ep.OD, dm);
+    or_bits64(s_obs, base + (uint32_t)ep.OL, encode_last_action(P, H, lastmv, p, pm));
+    if (ep.sad) or_bits64(s_obs, base + (uint32_t)ep.F0, encode_last_action(P, H, greedy_rec, p, pm));
 
     // legal moves (uids colour-permuted for this observer), noop iff nothing else is legal
     uint64_t lm = 0;
     if (p == cur) {
-      const uint32_t hw = ST(pl_hand(ep, p));
+      const uint32_t hw = ST(PLH(p));
       const int len = (hw >> 25) & 7;
       const uint64_t lenmask = (1ull << len) - 1ull;
       if (info < 8) lm |= lenmask;
@@ -495,14 +627,17 @@ __device__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, 
         for (int o = 1; o < P; ++o) {
           int q = p + o;
           if (q >= P) q -= P;
-          const uint32_t thw = ST(pl_hand(ep, q));
+          const uint32_t thw = ST(PLH(q));
           const int tl = (thw >> 25) & 7;
           uint32_t cm = 0, rm = 0;
-          for (int i = 0; i < tl; ++i) {
+#pragma unroll
+          for (int i = 0; i < (TH ? TH : 5); ++i) {
             const int card = (thw >> (5 * i)) & 31;
-            const int c = card / 5, r = card - 5 * c;
-            cm |= 1u << perm_c(pm, c);
-            rm |= 1u << r;
+            const int c = (card * 13) >> 6, r = card - 5 * c;
+            if (i < tl) {
+              cm |= 1u << perm_c(pm, c);
+              rm |= 1u << r;
+            }
           }
           lm |= (uint64_t)cm << (2 * H + (o - 1) * 5);
           lm |= (uint64_t)rm << (2 * H + (P - 1) * 5 + (o - 1) * 5);
@@ -510,20 +645,22 @@ __device__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, 
       }
     }
     if (!lm) lm = 1ull << (ep.A - 1);
-    or_bits(s_legal, (uint32_t)(lane * P + p) * (uint32_t)ep.A, lm);
+    or_bits64(s_legal, (uint32_t)(lane * P + p) * (uint32_t)ep.A, lm);
+    ep.legal_bits[(size_t)g * P + p] = lm;
 
     // own hand trinary [playable, discardable, other] (EncodeOwnHandTrinary)
     {
-      const uint32_t hw = ST(pl_hand(ep, p));
+      const uint32_t hw = ST(PLH(p));
       const int len = (hw >> 25) & 7;
       uint32_t om = 0;
-      for (int i = 0; i < len; ++i) {
+#pragma unroll
+      for (int i = 0; i < (TH ? TH : 5); ++i) {
         const int card = (hw >> (5 * i)) & 31;
-        const int c = card / 5, r = card - 5 * c;
+        const int c = (card * 13) >> 6, r = card - 5 * c;
         const int f = board_fw(board, c);
-        om |= 1u << (3 * i + (r == f ? 0 : (r < f ? 1 : 2)));
+        if (i < len) om |= 1u << (3 * i + (r == f ? 0 : (r < f ? 1 : 2)));
       }
-      or_bits(s_own, (uint32_t)(lane * P + p) * (uint32_t)(3 * H), (uint64_t)om);
+      or_bits32(s_own, (uint32_t)(lane * P + p) * (uint32_t)(3 * H), om);
     }
   }
 }
@@ -539,11 +676,11 @@ __device__ __forceinline__ uint64_t public_counts(uint64_t disc, uint32_t board)
   return pc;
 }
 
-// V0-belief fix-up of the knowledge section for ONE game row set (knowledge_mode=1): every plausible
-// entry becomes count/total as fp32 (EncodeV0Belief in the oracle).  Executed by the whole wave for
-// the games whose bit `active` is set; writes scattered 4-byte stores over the already streamed 0/1.
-__device__ void v0_fixup(const EnvParams& ep, const uint32_t* s_st, const uint32_t* s_obs, uint64_t active,
-                         int g0, int lane_id) {
+// V0-belief fix-up of the knowledge section (knowledge_mode=1): every plausible entry becomes
+// count/total as fp32 (EncodeV0Belief in the oracle).  Executed by the whole wave for the games whose
+// bit in `active` is set; scattered 4-byte stores over the already streamed 0/1 values.
+__device__ void v0_fixup(const EnvParams& ep, const uint32_t* s_st, const uint32_t* s_obs, uint64_t active, int g0,
+                         int lane_id) {
   const int P = ep.P, H = ep.H;
   const int per_row = P * H * 25;
   while (active) {
@@ -560,14 +697,14 @@ __device__ void v0_fixup(const EnvParams& ep, const uint32_t* s_st, const uint32
       const int o = slot / H, i = slot - o * H;
       int q = p + o;
       if (q >= P) q -= P;
-      const uint32_t hw = s_st[pl_hand(ep, q) * kWave + lg];
+      const uint32_t hw = s_st[PLH(q) * kWave + lg];
       if (i >= (int)((hw >> 25) & 7)) continue;
       const uint32_t bitpos = (uint32_t)(lg * P + p) * (uint32_t)ep.F + (uint32_t)ep.OK + (uint32_t)(slot * 35 + j);
       if (!get1(s_obs, bitpos)) continue;
-      const uint32_t permw = ep.shuffle_color ? s_st[pl_perm(ep, p) * kWave + lg] : kIdentityPermBoth;
+      const uint32_t permw = ep.shuffle_color ? s_st[PLPERM(p) * kWave + lg] : kIdentityPermBoth;
       const uint32_t inv = permw >> 15;
-      const uint32_t cp = (s_st[pl_kcp(ep, q) * kWave + lg] >> (5 * i)) & 31u;
-      const uint32_t rp = (s_st[pl_krp(ep, q) * kWave + lg] >> (5 * i)) & 31u;
+      const uint32_t cp = (s_st[PLKCP(q) * kWave + lg] >> (5 * i)) & 31u;
+      const uint32_t rp = (s_st[PLKRP(q) * kWave + lg] >> (5 * i)) & 31u;
       float total = 0.f;
       for (int c = 0; c < 5; ++c)
         if ((cp >> c) & 1u)
@@ -589,11 +726,36 @@ __device__ __forceinline__ void log_error(const EnvParams& ep, int g, int code) 
   }
 }
 
+// ---- counter-based random-legal policy ---------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t policy_hash(uint64_t seed, uint64_t game, uint64_t counter, uint64_t stream) {
+  const uint64_t k = mix64(seed ^ mix64(game * 0xD1342543DE82EF95ull + stream));
+  return (uint32_t)(mix64(k + counter) >> 32);
+}
+
+// k-th set bit of the legal mask, k = hash % popcount (same specification as oracle orc_policy_random)
+__device__ __forceinline__ int policy_pick(uint64_t seed, uint64_t game, uint64_t counter, int p, int stream,
+                                           uint64_t mask) {
+  const uint32_t h = policy_hash(seed, game, counter, (uint64_t)(p * 2 + stream));
+  int k = (int)(h % (uint32_t)__popcll(mask));
+  uint64_t m = mask;
+  while (k-- > 0) m &= m - 1;
+  return (int)__builtin_ctzll(m);
+}
+
 // =================================================================================================
 // MODE 0: VectorEnv::reset — (re)start every finished/not-started game, rewrite only their rows.
 // MODE 1: VectorEnv::step  — apply a[g][cur] (and the SAD greedy move), deal, observe all games.
+// MODE 2: MODE 1 with the random-legal policy evaluated in-kernel (hsad_env_rollout_random); the sampled
+//         actions are also written to a_out/g_out so the trajectory matches policy kernel + MODE 1.
+// TP/TH: compile-time players / hand size (0 = run-time values from EnvParams).
 // =================================================================================================
-template <int MODE>
+template <int MODE, int TP, int TH>
 __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t* __restrict__ a_in,
                                                     const int64_t* __restrict__ g_in) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -601,14 +763,16 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   uint32_t* s_obs = s_st + ep.npl * kWave;
   uint32_t* s_legal = s_obs + ep.obs_words;
   uint32_t* s_own = s_legal + ep.legal_words;
+  uint32_t* s_win = s_own + ep.own_words;  // reset kernel only: [2*win_w+1][kWave]
 
   const int lane = threadIdx.x;
-  const int g0 = blockIdx.x * kWave;
+  const int g0 = ep.g_begin + blockIdx.x * kWave;
   const int g = g0 + lane;
   const bool valid = g < ep.G;
   const int ng = min(kWave, ep.G - g0);
-  const int P = ep.P, H = ep.H;
+  const int P = TP ? TP : ep.P, H = TH ? TH : ep.H;
 
+  STAMP(0);
   const uint32_t misc0 = ep.planes[(size_t)PL_MISC * ep.Gpad + g];
   bool active;
   if (MODE == 0) {
@@ -617,20 +781,64 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   } else {
     active = valid;
   }
-  for (int pl = 0; pl < ep.npl; ++pl) ST(pl) = ep.planes[(size_t)pl * ep.Gpad + g];
+  // stage all state planes in LDS; loads issued in batches of 8 so they overlap
+  for (int pl0 = 0; pl0 < ep.npl; pl0 += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = ep.planes[(size_t)min(pl0 + j, ep.npl - 1) * ep.Gpad + g];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (pl0 + j < ep.npl) ST(pl0 + j) = v[j];
+  }
   {
     const int nz = ep.obs_words + ep.legal_words + ep.own_words;
-    for (int k = lane; k < nz; k += kWave) s_obs[k] = 0u;
+    uint4* z4 = reinterpret_cast<uint4*>(s_obs);
+    for (int k = lane; k < (nz >> 2); k += kWave) z4[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = (nz & ~3) + lane; k < nz; k += kWave) s_obs[k] = 0u;
   }
   __syncthreads();
+  STAMP(1);
 
-  uint32_t* mt = ep.mt + (size_t)g * kMtN;
+  Rng rng;
+  rng.mt = ep.mt + (size_t)g * kMtN;
+  rng.draws = ST(PL_DRAWS);
+  rng.la0 = ST(PL_LA0);
+  rng.la1 = ST(PL_LA1);
+  rng.la_n = (int)((ST(PL_MISC) >> 22) & 3u);
+  rng.spos = (rng.draws + (uint32_t)rng.la_n) % (uint32_t)kMtN;
+  rng.win = nullptr;
+  rng.w_c = rng.w_n = 0;
   uint32_t greedy_rec = 0;
   float reward = 0.f;
   bool term = false;
 
   if (MODE == 0) {
+    // ---- prefetch window: every mt19937 word this reset will regenerate, in one round trip ----
+    const int W = ep.win_w;
+    uint32_t* winA = s_win + lane;                   // x[wbase + k],       k in [0, W]
+    uint32_t* winB = s_win + (W + 1) * kWave + lane;  // x[wbase + k + 397], k in [0, W) -> new words
+    const uint32_t wbase = rng.spos;
     if (active) {
+      for (int k0 = 0; k0 <= W; k0 += 16) {
+        uint32_t va[16], vb[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const uint32_t k = (uint32_t)min(k0 + j, W);
+          va[j] = rng.mt[(wbase + k) % (uint32_t)kMtN];
+          vb[j] = rng.mt[(wbase + k + kMtM) % (uint32_t)kMtN];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (k0 + j <= W) {
+            winA[(k0 + j) * kWave] = va[j];
+            if (k0 + j < W) winB[(k0 + j) * kWave] = vb[j];
+          }
+      }
+      for (int k = 0; k < W; ++k) winB[k * kWave] = mt_twist(winA[k * kWave], winA[(k + 1) * kWave], winB[k * kWave]);
+      rng.win = winB;
+      rng.w_n = W;
+      rng.spos = (wbase + (uint32_t)W) % (uint32_t)kMtN;
+
       // HanabiEnv::reset (cpp/hanabi_env.cc:9-47): fresh HanabiState, deal until no chance node
       const uint64_t deck = full_deck_bits();
       ST(PL_DECK_LO) = (uint32_t)deck;
@@ -641,44 +849,49 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       ST(PL_MISC) = (ST(PL_MISC) & (63u << 16)) | (50u << 8) | (1u << 15);  // keep last_score; started
       ST(PL_LASTMV) = 0;
       for (int p = 0; p < P; ++p) {
-        ST(pl_hand(ep, p)) = 0;
-        ST(pl_kcp(ep, p)) = 0;
-        ST(pl_krp(ep, p)) = 0;
-        ST(pl_kh(ep, p)) = 0;
+        ST(PLH(p)) = 0;
+        ST(PLKCP(p)) = 0;
+        ST(PLKRP(p)) = 0;
+        ST(PLKH(p)) = 0;
       }
-      for (int k = 0; k < P * H; ++k) deal_one(ep, s_st, lane, mt, g);
-      uint32_t draws = ST(PL_DRAWS);
+      for (int k = 0; k < P * H; ++k) deal_one(ep, P, H, s_st, lane, rng, g);
       for (int p = 0; p < P; ++p) {
-        const uint32_t r = mt_draw(mt, draws);
-        ST(pl_eps(ep, p)) = __float_as_uint(ep.eps_list[r % (uint32_t)ep.n_eps]);
+        const uint32_t r = rng_next(rng);
+        ST(PLEPS(p)) = __float_as_uint(ep.eps_list[r % (uint32_t)ep.n_eps]);
       }
       if (ep.shuffle_color) {
-        const int fix = (int)(mt_draw(mt, draws) % (uint32_t)P);
+        const int fix = (int)(rng_next(rng) % (uint32_t)P);
         for (int p = 0; p < P; ++p) {
           uint32_t arr = kIdentityPerm;
           if (p != fix) {
-            // libstdc++ std::shuffle, 5 elements: pairs of swaps from one uniform_int draw each
-            auto getv = [&](int i) { return (arr >> (3 * i)) & 7u; };
+            // libstdc++ std::shuffle, 5 elements: two swaps per uniform_int draw
             auto swp = [&](int i, int j) {
-              const uint32_t vi = getv(i), vj = getv(j);
+              const uint32_t vi = (arr >> (3 * i)) & 7u, vj = (arr >> (3 * j)) & 7u;
               arr = (arr & ~(7u << (3 * i))) | (vj << (3 * i));
               arr = (arr & ~(7u << (3 * j))) | (vi << (3 * j));
             };
-            uint32_t x = uniform_below(6u, mt, draws);
+            uint32_t x = uniform_below(6u, rng);
             swp(1, (int)(x / 3u));
             swp(2, (int)(x % 3u));
-            x = uniform_below(20u, mt, draws);
+            x = uniform_below(20u, rng);
             swp(3, (int)(x / 5u));
             swp(4, (int)(x % 5u));
           }
           uint32_t inv = 0;
           for (int i = 0; i < 5; ++i) inv |= (uint32_t)i << (3 * ((arr >> (3 * i)) & 7u));
-          ST(pl_perm(ep, p)) = arr | (inv << 15);
+          ST(PLPERM(p)) = arr | (inv << 15);
         }
       } else {
-        for (int p = 0; p < P; ++p) ST(pl_perm(ep, p)) = kIdentityPermBoth;
+        for (int p = 0; p < P; ++p) ST(PLPERM(p)) = kIdentityPermBoth;
       }
-      ST(PL_DRAWS) = draws;
+      // top the look-ahead up from the window, then publish the regenerated words
+      while (rng.la_n < 2 && rng.w_c < rng.w_n) {
+        la_push(rng, mt_temper(winB[rng.w_c * kWave]));
+        rng.w_c += 1;
+      }
+      for (int k = 0; k < rng.w_c; ++k) rng.mt[(wbase + (uint32_t)k) % (uint32_t)kMtN] = winB[k * kWave];
+      if (rng.w_c < rng.w_n) rng.spos = (wbase + (uint32_t)rng.w_c) % (uint32_t)kMtN;
+      rng.w_n = rng.w_c;
     }
   } else {
     if (active) {
@@ -690,36 +903,54 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       if (!started || was_term || cur < 0) {
         log_error(ep, g, 3);  // assert(!terminated()) in HanabiEnv::step
       } else {
-        int uid = (int)a_in[(size_t)g * P + cur];
+        int uid, guid = 0;
+        if (MODE == 2) {
+          const uint32_t counter = ep.act_count[g];
+          ep.act_count[g] = counter + 1u;
+          uid = guid = 0;
+          for (int p = 0; p < P; ++p) {
+            const uint64_t mask = ep.legal_bits[(size_t)g * P + p];
+            const int pa = policy_pick(ep.policy_seed, (uint64_t)g, (uint64_t)counter, p, 0, mask);
+            const int pg = policy_pick(ep.policy_seed, (uint64_t)g, (uint64_t)counter, p, 1, mask);
+            ep.a_out[(size_t)g * P + p] = pa;
+            if (ep.g_out) ep.g_out[(size_t)g * P + p] = pg;
+            if (p == cur) {
+              uid = pa;
+              guid = pg;
+            }
+          }
+        } else {
+          uid = (int)a_in[(size_t)g * P + cur];
+          if (ep.sad) guid = (int)g_in[(size_t)g * P + cur];
+        }
         MoveDec mv = decode_uid(uid, P, H);
-        const uint32_t pinv = ep.shuffle_color ? (ST(pl_perm(ep, cur)) >> 15) : kIdentityPerm;
+        const uint32_t pinv = ep.shuffle_color ? (ST(PLPERM(cur)) >> 15) : kIdentityPerm;
         if (mv.type == 3) mv.val = (int)perm_c(pinv, mv.val);  // maybeInversePermuteColor_
-        bool ok = move_is_legal(ep, s_st, lane, mv);
+        bool ok = move_is_legal(P, s_st, lane, mv);
         if (!ok) log_error(ep, g, 1);
         if (ok && ep.sad) {
-          int guid = (int)g_in[(size_t)g * P + cur];
           MoveDec gm = decode_uid(guid, P, H);
           if (gm.type == 3) gm.val = (int)perm_c(pinv, gm.val);
-          if (!move_is_legal(ep, s_st, lane, gm)) {
+          if (!move_is_legal(P, s_st, lane, gm)) {
             ok = false;
             log_error(ep, g, 2);
           } else {
-            greedy_rec = make_history(ep, s_st, lane, gm);
+            greedy_rec = make_history(P, s_st, lane, gm);
           }
         }
         if (ok) {
           const int num_step = (int)(misc & 255u) + 1;
-          int deck_size = (misc >> 8) & 63;
+          const int deck_size = (misc >> 8) & 63;
           const int life0 = board_life(board);
           const int prev_score = (life0 <= 0 && ep.bomb) ? 0 : board_fw_sum(board);
-          const uint32_t rec = make_history(ep, s_st, lane, mv);
+          const uint32_t rec = make_history(P, s_st, lane, mv);
           // ---- HanabiState::ApplyMove ----
           if (deck_size == 0) board = board_set(board, 21, 7u, (uint32_t)(board_turns(board) - 1));
           if (mv.type <= 2) {
-            const uint32_t hw = ST(pl_hand(ep, cur));
+            const uint32_t hw = ST(PLH(cur));
             const int len = (hw >> 25) & 7;
             const int card = (hw >> (5 * mv.idx)) & 31;
-            const int c = card / 5, r = card - 5 * c;
+            const int c = (card * 13) >> 6, r = card - 5 * c;
             bool to_discard = true;
             if (mv.type == 2) {
               if ((rec >> 30) & 1u) board = board_set(board, 15, 15u, (uint32_t)(board_info(board) + 1));
@@ -740,33 +971,37 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
             }
             uint32_t nh = remove_field(hw, mv.idx, 5, 5);
             nh = (nh & ~(7u << 25)) | ((uint32_t)(len - 1) << 25);
-            ST(pl_hand(ep, cur)) = nh;
-            ST(pl_kcp(ep, cur)) = remove_field(ST(pl_kcp(ep, cur)), mv.idx, 5, 5);
-            ST(pl_krp(ep, cur)) = remove_field(ST(pl_krp(ep, cur)), mv.idx, 5, 5);
-            ST(pl_kh(ep, cur)) = remove_field(ST(pl_kh(ep, cur)), mv.idx, 6, 5);
+            ST(PLH(cur)) = nh;
+            ST(PLKCP(cur)) = remove_field(ST(PLKCP(cur)), mv.idx, 5, 5);
+            ST(PLKRP(cur)) = remove_field(ST(PLKRP(cur)), mv.idx, 5, 5);
+            ST(PLKH(cur)) = remove_field(ST(PLKH(cur)), mv.idx, 6, 5);
           } else {
             board = board_set(board, 15, 15u, (uint32_t)(board_info(board) - 1));
             int q = cur + mv.off;
             if (q >= P) q -= P;
-            const uint32_t hw = ST(pl_hand(ep, q));
+            const uint32_t hw = ST(PLH(q));
             const int len = (hw >> 25) & 7;
             const uint32_t match = (rec >> 18) & 31u;
-            uint32_t kp = ST(mv.type == 3 ? pl_kcp(ep, q) : pl_krp(ep, q));
-            uint32_t kh = ST(pl_kh(ep, q));
+            const int kpl = (mv.type == 3) ? PLKCP(q) : PLKRP(q);
+            uint32_t kp = ST(kpl);
+            uint32_t kh = ST(PLKH(q));
             const int hshift = (mv.type == 3) ? 0 : 3;
-            for (int i = 0; i < len; ++i) {
-              if ((match >> i) & 1u) {
-                kp = (kp & ~(31u << (5 * i))) | ((1u << mv.val) << (5 * i));
-                kh = (kh & ~(7u << (6 * i + hshift))) | ((uint32_t)(mv.val + 1) << (6 * i + hshift));
-              } else {
-                kp &= ~((1u << mv.val) << (5 * i));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              if (i < len) {
+                if ((match >> i) & 1u) {
+                  kp = (kp & ~(31u << (5 * i))) | ((1u << mv.val) << (5 * i));
+                  kh = (kh & ~(7u << (6 * i + hshift))) | ((uint32_t)(mv.val + 1) << (6 * i + hshift));
+                } else {
+                  kp &= ~((1u << mv.val) << (5 * i));
+                }
               }
             }
-            ST(mv.type == 3 ? pl_kcp(ep, q) : pl_krp(ep, q)) = kp;
-            ST(pl_kh(ep, q)) = kh;
+            ST(kpl) = kp;
+            ST(PLKH(q)) = kh;
           }
           ST(PL_LASTMV) = rec;
-          board = advance_player(ep, s_st, lane, board, deck_size);
+          board = advance_player(P, H, s_st, lane, board, deck_size);
           ST(PL_BOARD) = board;
           // ---- HanabiEnv::step tail (cpp/hanabi_env.cc:94-108) ----
           const int life1 = board_life(board);
@@ -781,7 +1016,7 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
           misc = (misc & ~255u) | (uint32_t)num_step;
           ST(PL_MISC) = misc;
           if (!term) {
-            while (board_cur(ST(PL_BOARD)) < 0) deal_one(ep, s_st, lane, mt, g);
+            while (board_cur(ST(PL_BOARD)) < 0) deal_one(ep, P, H, s_st, lane, rng, g);
           }
           misc = ST(PL_MISC);
           misc = (misc & ~(1u << 14)) | ((term ? 1u : 0u) << 14);
@@ -791,21 +1026,33 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       }
     }
   }
+  STAMP(2);
 
-  if (active) build_rows(ep, s_st, lane, s_obs, s_legal, s_own, greedy_rec);
-  // write state back (coalesced per plane)
-  if (active)
+  // look-ahead refill: loads go out now and are consumed after the rows are built
+  Refill rf;
+  refill_issue(rf, rng, active);
+  if (active) build_rows<TP, TH>(ep, s_st, lane, g, s_obs, s_legal, s_own, greedy_rec);
+  STAMP(3);
+  if (active) {
+    refill_finish(rf, rng);
+    ST(PL_DRAWS) = rng.draws;
+    ST(PL_LA0) = rng.la0;
+    ST(PL_LA1) = rng.la1;
+    ST(PL_MISC) = (ST(PL_MISC) & ~(3u << 22)) | ((uint32_t)rng.la_n << 22);
+    // write state back (coalesced per plane)
     for (int pl = 0; pl < ep.npl; ++pl) ep.planes[(size_t)pl * ep.Gpad + g] = ST(pl);
+  }
   __syncthreads();
+  STAMP(4);
 
   const size_t PF = (size_t)P * ep.F, PA = (size_t)P * ep.A, PO = (size_t)P * 3 * H;
-  if (MODE == 1) {
+  if (MODE >= 1) {
     // all ng games of the wave: one contiguous, 16-byte aligned range per output tensor
-    stream_bits_f32(s_obs, 0u, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), lane);
-    stream_bits_f32(s_legal, 0u, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), lane);
-    stream_bits_f32(s_own, 0u, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), lane);
+    stream_bits_f32_aligned(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), lane);
+    stream_bits_f32_aligned(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), lane);
+    stream_bits_f32_aligned(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), lane);
     if (valid) {
-      for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(pl_eps(ep, p)));
+      for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(PLEPS(p)));
       ep.reward[g] = reward;
       ep.terminal[g] = term ? 1 : 0;
     }
@@ -824,12 +1071,13 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       stream_bits_f32(s_own, (uint32_t)(lg * PO), ep.own + (size_t)(g0 + lg) * PO, (uint32_t)PO, lane);
     }
     if (active)
-      for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(pl_eps(ep, p)));
+      for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(PLEPS(p)));
     if (ep.kmode == 1) {
       __syncthreads();
       v0_fixup(ep, s_st, s_obs, todo_all, g0, lane);
     }
   }
+  STAMP(5);
 }
 
 // ---- init: zero planes, seed mt19937 (std::mt19937::seed: x0 = s; x_i = 1812433253*(x ^ x>>30) + i) ---
@@ -849,40 +1097,16 @@ __global__ void init_kernel(EnvParams ep) {
   ep.act_count[g] = 0u;
 }
 
-// ---- counter-based random-legal policy ---------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint32_t policy_hash(uint64_t seed, uint64_t game, uint64_t counter, uint64_t stream) {
-  const uint64_t k = mix64(seed ^ mix64(game * 0xD1342543DE82EF95ull + stream));
-  return (uint32_t)(mix64(k + counter) >> 32);
-}
-
+// ---- counter-based random-legal policy (kernel form; helpers are defined above env_kernel) ----
 __global__ void policy_kernel(EnvParams ep, uint64_t seed, int64_t* __restrict__ a, int64_t* __restrict__ ga) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ep.G) return;
+  const int g = ep.g_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ep.g_begin + ep.g_count || g >= ep.G) return;
   const uint32_t counter = ep.act_count[g];
   ep.act_count[g] = counter + 1u;
   for (int p = 0; p < ep.P; ++p) {
-    const float* row = ep.legal + ((size_t)g * ep.P + p) * ep.A;
-    uint64_t mask = 0;
-    for (int i = 0; i < ep.A; ++i)
-      if (row[i] != 0.f) mask |= 1ull << i;
-    const int n = __popcll(mask);
-    for (int s = 0; s < 2; ++s) {
-      const uint32_t h = policy_hash(seed, (uint64_t)g, (uint64_t)counter, (uint64_t)(p * 2 + s));
-      int k = (int)(h % (uint32_t)n);
-      uint64_t m = mask;
-      while (k-- > 0) m &= m - 1;
-      const int64_t pick = (int64_t)__builtin_ctzll(m);
-      if (s == 0)
-        a[(size_t)g * ep.P + p] = pick;
-      else if (ga)
-        ga[(size_t)g * ep.P + p] = pick;
-    }
+    const uint64_t mask = ep.legal_bits[(size_t)g * ep.P + p];  // same bits as the legal_move row
+    a[(size_t)g * ep.P + p] = policy_pick(seed, (uint64_t)g, (uint64_t)counter, p, 0, mask);
+    if (ga) ga[(size_t)g * ep.P + p] = policy_pick(seed, (uint64_t)g, (uint64_t)counter, p, 1, mask);
   }
 }
 
@@ -912,6 +1136,7 @@ __global__ void query_kernel(EnvParams ep, int32_t* __restrict__ out) {
 
 __global__ void legal_query_kernel(EnvParams ep, const int32_t* __restrict__ uid, uint8_t* __restrict__ out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = ep.P;
   if (g >= ep.G) return;
   const uint32_t board = GP(PL_BOARD);
   const int cur = board_cur(board);
@@ -919,12 +1144,12 @@ __global__ void legal_query_kernel(EnvParams ep, const int32_t* __restrict__ uid
   bool ok = false;
   if (m.type != 0 && cur >= 0) {
     if (m.type <= 2) {
-      const int len = (GP(pl_hand(ep, cur)) >> 25) & 7;
+      const int len = (GP(PLH(cur)) >> 25) & 7;
       ok = (m.idx < len) && !(m.type == 2 && board_info(board) >= 8);
     } else if (board_info(board) > 0 && m.off >= 1 && m.off < ep.P) {
       int q = cur + m.off;
       if (q >= ep.P) q -= ep.P;
-      ok = hand_match_mask(GP(pl_hand(ep, q)), m.type == 3, m.val) != 0;
+      ok = hand_match_mask(GP(PLH(q)), m.type == 3, m.val) != 0;
     }
   }
   out[g] = ok ? 1 : 0;
@@ -941,6 +1166,7 @@ __global__ void deck_history_kernel(EnvParams ep, uint8_t* __restrict__ out, int
 
 __global__ void export_state_kernel(EnvParams ep, int32_t* __restrict__ out, int words) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int P = ep.P;
   if (g >= ep.G) return;
   int32_t* o = out + (size_t)g * words;
   for (int i = 0; i < words; ++i) o[i] = 0;
@@ -982,7 +1208,7 @@ __global__ void export_state_kernel(EnvParams ep, int32_t* __restrict__ out, int
   o[74] = (int)((misc >> 16) & 63u) - 1;
   int base = 80;
   for (int p = 0; p < ep.P; ++p) {
-    const uint32_t hw = GP(pl_hand(ep, p)), kcp = GP(pl_kcp(ep, p)), krp = GP(pl_krp(ep, p)), kh = GP(pl_kh(ep, p));
+    const uint32_t hw = GP(PLH(p)), kcp = GP(PLKCP(p)), krp = GP(PLKRP(p)), kh = GP(PLKH(p));
     const int len = (hw >> 25) & 7;
     for (int i = 0; i < ep.H; ++i) {
       int32_t* s = o + base + (p * ep.H + i) * 6;
@@ -1000,7 +1226,7 @@ __global__ void export_state_kernel(EnvParams ep, int32_t* __restrict__ out, int
   }
   base += ep.P * ep.H * 6;
   for (int p = 0; p < ep.P; ++p) {
-    const uint32_t pw = ((misc >> 15) & 1u) ? GP(pl_perm(ep, p)) : kIdentityPermBoth;
+    const uint32_t pw = ((misc >> 15) & 1u) ? GP(PLPERM(p)) : kIdentityPermBoth;
     for (int c = 0; c < 5; ++c) {
       o[base + p * 5 + c] = perm_c(pw & 0x7fffu, c);
       o[base + ep.P * 5 + p * 5 + c] = perm_c(pw >> 15, c);
@@ -1031,12 +1257,55 @@ int set_error(int code, const char* fmt, ...) {
 
 struct hsad_env {
   EnvParams ep;
-  size_t lds_bytes;
+  size_t lds_bytes;        // step kernel
+  size_t lds_bytes_reset;  // reset kernel (adds the mt19937 prefetch window)
   size_t state_bytes;
   float* d_eps_list;
   bool bound;
   int device;
+  // rollout partitions: independent game ranges on private streams so that one partition's
+  // latency-bound phases overlap another partition's HBM-bound observation streaming
+  int n_part;         // streams created so far
+  int n_part_active;  // partitions used by hsad_env_rollout_random (1 = caller's stream only)
+  hipStream_t part_stream[16];
+  hipEvent_t part_done[16];
+  hipEvent_t fork;
 };
+
+namespace {
+
+typedef void (*EnvKernelFn)(EnvParams, const int64_t*, const int64_t*);
+
+// compile-time (players, hand) specialisations; anything else runs the generic <0,0> instance
+EnvKernelFn pick_env_kernel(int mode, int P, int H) {
+  if (P == 2 && H == 5) return mode == 0 ? env_kernel<0, 2, 5> : (mode == 1 ? env_kernel<1, 2, 5> : env_kernel<2, 2, 5>);
+  return mode == 0 ? env_kernel<0, 0, 0> : (mode == 1 ? env_kernel<1, 0, 0> : env_kernel<2, 0, 0>);
+}
+
+int configure_env_kernels(hsad_env* e) {
+  for (int mode = 0; mode < 3; ++mode) {
+    const size_t lds = mode ? e->lds_bytes : e->lds_bytes_reset;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_env_kernel(mode, e->ep.P, e->ep.H)),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  return HSAD_OK;
+}
+
+// launch one env kernel over games [g_begin, g_begin + g_count) (g_begin multiple of 64)
+void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipStream_t stream, int g_begin,
+                int g_count, uint64_t policy_seed = 0, int64_t* a_out = nullptr, int64_t* g_out = nullptr) {
+  const size_t lds = mode ? e->lds_bytes : e->lds_bytes_reset;
+  EnvParams ep = e->ep;
+  ep.g_begin = g_begin;
+  ep.g_count = g_count;
+  ep.policy_seed = policy_seed;
+  ep.a_out = a_out;
+  ep.g_out = g_out;
+  hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kWave), lds, stream,
+                     ep, a, g);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -1082,16 +1351,29 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   ep.track_dh = cfg->track_deck_history ? 1 : 0;
   ep.npl = PL_FIXED + 6 * P;
   ep.seed0 = cfg->seed0;
+  ep.deal_mode = cfg->deal_mode ? 1 : 0;  // 1 = always take the literal fp64 discrete_distribution path
+  {
+    const int n_static = 2 * P * H + P + (ep.shuffle_color ? 1 + 2 * (P - 1) : 0);
+    ep.win_w = n_static + 2 < 64 ? n_static + 2 : 64;
+  }
   // +3 words of slack: or_bits may touch up to two words past the last row
   ep.obs_words = (kWave * P * ep.F + 31) / 32 + 3;
   ep.legal_words = (kWave * P * ep.A + 31) / 32 + 3;
   ep.own_words = (kWave * P * 3 * H + 31) / 32 + 3;
+  ep.obs_words = (ep.obs_words + 3) & ~3;
+  ep.legal_words = (ep.legal_words + 3) & ~3;
+  ep.own_words = (ep.own_words + 3) & ~3;
   e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words);
+  e->lds_bytes_reset = e->lds_bytes + sizeof(uint32_t) * (size_t)(2 * ep.win_w + 1) * kWave;
   e->device = cfg->device;
   e->bound = false;
-  if (e->lds_bytes > 160 * 1024) {
+  e->n_part = 0;
+  e->n_part_active = 1;
+  e->fork = nullptr;
+  if (e->lds_bytes_reset > 160 * 1024) {
+    const size_t need = e->lds_bytes_reset;
     delete e;
-    return set_error(HSAD_ERR_INVALID, "configuration needs %zu B of LDS per wave (> 160 KiB)", e->lds_bytes);
+    return set_error(HSAD_ERR_INVALID, "configuration needs %zu B of LDS per wave (> 160 KiB)", need);
   }
 
   const size_t planes_b = sizeof(uint32_t) * (size_t)ep.npl * ep.Gpad;
@@ -1108,16 +1390,21 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   if ((he = hipMalloc(&ep.deck_hist, dh_b)) != hipSuccess) return fail("deck history");
   if ((he = hipMalloc(&ep.err, 16)) != hipSuccess) return fail("error log");
   if ((he = hipMalloc(&ep.act_count, sizeof(uint32_t) * ep.Gpad)) != hipSuccess) return fail("act counters");
+  if ((he = hipMalloc(&ep.legal_bits, sizeof(uint64_t) * (size_t)ep.Gpad * P)) != hipSuccess) return fail("legal bits");
+  HIP_TRY(hipMemset(ep.legal_bits, 0, sizeof(uint64_t) * (size_t)ep.Gpad * P));
   if ((he = hipMalloc(&e->d_eps_list, sizeof(float) * cfg->n_eps)) != hipSuccess) return fail("eps list");
   ep.eps_list = e->d_eps_list;
   e->state_bytes = planes_b + mt_b + dh_b;
   HIP_TRY(hipMemcpy(e->d_eps_list, cfg->eps_list, sizeof(float) * cfg->n_eps, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(ep.err, 0, 16));
   HIP_TRY(hipMemset(ep.deck_hist, 0, dh_b));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(env_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)e->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(env_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)e->lds_bytes));
+  {
+    int rc = configure_env_kernels(e);
+    if (rc != HSAD_OK) {
+      hsad_env_destroy(e);
+      return rc;
+    }
+  }
   hipLaunchKernelGGL(init_kernel, dim3((ep.Gpad + 255) / 256), dim3(256), 0, 0, ep);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());
@@ -1133,7 +1420,13 @@ void hsad_env_destroy(hsad_env* e) {
   if (e->ep.deck_hist) (void)hipFree(e->ep.deck_hist);
   if (e->ep.err) (void)hipFree(e->ep.err);
   if (e->ep.act_count) (void)hipFree(e->ep.act_count);
+  if (e->ep.legal_bits) (void)hipFree(e->ep.legal_bits);
   if (e->d_eps_list) (void)hipFree(e->d_eps_list);
+  for (int k = 0; k < e->n_part; ++k) {
+    (void)hipStreamDestroy(e->part_stream[k]);
+    (void)hipEventDestroy(e->part_done[k]);
+  }
+  if (e->fork) (void)hipEventDestroy(e->fork);
   delete e;
 }
 
@@ -1165,8 +1458,7 @@ int hsad_env_bind_outputs(hsad_env* e, float* priv_s, float* legal_move, float* 
 int hsad_env_reset(hsad_env* e, void* stream) {
   if (!e) return set_error(HSAD_ERR_INVALID, "null env");
   if (!e->bound) return set_error(HSAD_ERR_STATE, "hsad_env_bind_outputs must be called first");
-  hipLaunchKernelGGL(env_kernel<0>, dim3(e->ep.Gpad / kWave), dim3(kWave), e->lds_bytes, (hipStream_t)stream, e->ep,
-                     (const int64_t*)nullptr, (const int64_t*)nullptr);
+  launch_env(e, 0, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1176,8 +1468,7 @@ int hsad_env_step(hsad_env* e, const int64_t* a, const int64_t* greedy_a, void* 
   if (!e->bound) return set_error(HSAD_ERR_STATE, "hsad_env_bind_outputs must be called first");
   if (!a) return set_error(HSAD_ERR_INVALID, "action tensor is null");
   if (e->ep.sad && !greedy_a) return set_error(HSAD_ERR_INVALID, "sad=1 requires greedy_a");
-  hipLaunchKernelGGL(env_kernel<1>, dim3(e->ep.Gpad / kWave), dim3(kWave), e->lds_bytes, (hipStream_t)stream, e->ep, a,
-                     greedy_a);
+  launch_env(e, 1, a, greedy_a, (hipStream_t)stream, 0, e->ep.Gpad);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1186,21 +1477,63 @@ int hsad_env_policy_random(hsad_env* e, uint64_t policy_seed, int64_t* a, int64_
   if (!e) return set_error(HSAD_ERR_INVALID, "null env");
   if (!e->bound) return set_error(HSAD_ERR_STATE, "hsad_env_bind_outputs must be called first");
   if (!a) return set_error(HSAD_ERR_INVALID, "action tensor is null");
-  hipLaunchKernelGGL(policy_kernel, dim3((e->ep.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->ep, policy_seed,
-                     a, greedy_a);
+  EnvParams ep = e->ep;
+  ep.g_begin = 0;
+  ep.g_count = ep.G;
+  hipLaunchKernelGGL(policy_kernel, dim3((ep.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, ep, policy_seed, a,
+                     greedy_a);
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_env_set_partitions(hsad_env* e, int n_part) {
+  if (!e) return set_error(HSAD_ERR_INVALID, "null env");
+  if (n_part < 1 || n_part > 16) return set_error(HSAD_ERR_INVALID, "n_part must be 1..16");
+  const int blocks = e->ep.Gpad / kWave;
+  if (n_part > blocks) n_part = blocks;
+  HIP_TRY(hipSetDevice(e->device));
+  for (int k = e->n_part; k < n_part; ++k) {
+    HIP_TRY(hipStreamCreateWithFlags(&e->part_stream[k], hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&e->part_done[k], hipEventDisableTiming));
+  }
+  if (!e->fork) HIP_TRY(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
+  if (n_part > e->n_part) e->n_part = n_part;
+  e->n_part_active = n_part;
   return HSAD_OK;
 }
 
 int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64_t* a, int64_t* greedy_a,
                             void* stream) {
   if (!e) return set_error(HSAD_ERR_INVALID, "null env");
+  if (!e->bound) return set_error(HSAD_ERR_STATE, "hsad_env_bind_outputs must be called first");
+  if (!a) return set_error(HSAD_ERR_INVALID, "action tensor is null");
   if (e->ep.sad && !greedy_a) return set_error(HSAD_ERR_INVALID, "sad=1 requires greedy_a");
+  const int K = e->n_part_active;
+  const int blocks = e->ep.Gpad / kWave;
+  if (K <= 1) {
+    for (int i = 0; i < n_iter; ++i) {
+      launch_env(e, 0, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad);
+      launch_env(e, 2, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a);
+    }
+    HIP_TRY(hipGetLastError());
+    return HSAD_OK;
+  }
+  // fork: every partition stream waits for the work already queued on the caller's stream
+  HIP_TRY(hipEventRecord(e->fork, (hipStream_t)stream));
+  for (int k = 0; k < K; ++k) HIP_TRY(hipStreamWaitEvent(e->part_stream[k], e->fork, 0));
   for (int i = 0; i < n_iter; ++i) {
-    int rc;
-    if ((rc = hsad_env_reset(e, stream)) != HSAD_OK) return rc;
-    if ((rc = hsad_env_policy_random(e, policy_seed, a, greedy_a, stream)) != HSAD_OK) return rc;
-    if ((rc = hsad_env_step(e, a, greedy_a, stream)) != HSAD_OK) return rc;
+    for (int k = 0; k < K; ++k) {
+      const int b0 = (int)((long long)blocks * k / K), b1 = (int)((long long)blocks * (k + 1) / K);
+      if (b1 <= b0) continue;
+      launch_env(e, 0, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave);
+      launch_env(e, 2, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  // join
+  for (int k = 0; k < K; ++k) {
+    HIP_TRY(hipEventRecord(e->part_done[k], e->part_stream[k]));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, e->part_done[k], 0));
   }
   return HSAD_OK;
 }
@@ -1233,6 +1566,12 @@ int hsad_env_export_state(hsad_env* e, int32_t* out, void* stream) {
   hipLaunchKernelGGL(export_state_kernel, dim3((e->ep.G + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->ep, out,
                      hsad_env_state_words(e));
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_env_debug_timing(hsad_env* e, uint64_t* buf) {
+  if (!e) return set_error(HSAD_ERR_INVALID, "null env");
+  e->ep.dbg = reinterpret_cast<unsigned long long*>(buf);
   return HSAD_OK;
 }
 

@@ -11,7 +11,8 @@ from . import _lib
 
 class BatchedHanabiEnv:
     def __init__(self, num_games, players=2, hand_size=5, seed=1, bomb=0, eps_list=(0.0,), max_len=80, sad=False,
-                 shuffle_obs=False, shuffle_color=False, knowledge_mode=0, device="cuda:0", track_deck_history=True):
+                 shuffle_obs=False, shuffle_color=False, knowledge_mode=0, device="cuda:0", track_deck_history=True,
+                 deal_mode=0):
         self.lib = _lib.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -20,7 +21,7 @@ class BatchedHanabiEnv:
         eps = (C.c_float * len(eps_list))(*[float(e) for e in eps_list])
         cfg = _lib.EnvConfig(num_games, players, hand_size, int(bomb), int(seed), int(max_len), int(bool(sad)),
                              int(bool(shuffle_obs)), int(bool(shuffle_color)), int(knowledge_mode), len(eps_list),
-                             dev_index, int(bool(track_deck_history)), 0, eps)
+                             dev_index, int(bool(track_deck_history)), int(deal_mode), eps)
         self.h = C.c_void_p()
         _lib.check(self.lib.hsad_env_create(C.byref(cfg), C.byref(self.h)))
         L = self.lib
@@ -91,6 +92,10 @@ class BatchedHanabiEnv:
     def rollout_random(self, n_iter, policy_seed):
         _lib.check(self.lib.hsad_env_rollout_random(self.h, n_iter, policy_seed, self.a.data_ptr(),
                                                     self.greedy_a.data_ptr(), self._stream()))
+
+    def set_partitions(self, n_part):
+        """Number of independent game ranges rollout_random overlaps on private HIP streams."""
+        _lib.check(self.lib.hsad_env_set_partitions(self.h, int(n_part)))
 
     def query(self):
         out = torch.zeros(self.G, 16, dtype=torch.int32, device=self.device)

@@ -53,7 +53,8 @@ typedef struct hsad_env_config {
   int32_t n_eps;          /* length of eps_list (hanabi_env.cc:18-20)                               */
   int32_t device;         /* HIP device ordinal                                                     */
   int32_t track_deck_history; /* keep per-game dealt-card log for deck_history()                    */
-  int32_t reserved;
+  int32_t deal_mode;      /* 0 = exact integer fast path with fp64 fallback (default); 1 = always run the
+                             literal libstdc++ discrete_distribution fp64 arithmetic (same results)   */
   const float* eps_list;  /* HOST pointer, n_eps floats                                             */
 } hsad_env_config;
 
@@ -89,15 +90,22 @@ int hsad_env_reset(hsad_env* env, void* stream);
 int hsad_env_step(hsad_env* env, const int64_t* a, const int64_t* greedy_a, void* stream);
 
 /* Uniform-random-legal policy on the device (BASELINE.json configs[1]; stand-in for
- * R2D2Agent.act's multinomial branch, pyhanabi/r2d2.py:270).  Reads the bound legal_move tensor,
- * writes a and greedy_a [G, P] int64 (noop for players not on turn) and advances the per-game
+ * R2D2Agent.act's multinomial branch, pyhanabi/r2d2.py:270).  Reads the env's compact legal-move
+ * bit masks (the same bits the legal_move tensor is expanded from), writes a and greedy_a [G, P] int64 (noop for players not on turn) and advances the per-game
  * decision counter.  Stream: counter-based hash keyed (policy_seed, seed0-relative game id, counter). */
 int hsad_env_policy_random(hsad_env* env, uint64_t policy_seed, int64_t* a, int64_t* greedy_a, void* stream);
 
 /* n_iter iterations of the reference thread loop body (cpp/thread_loop.h:46-72) for all games:
- * reset-terminated -> random policy -> step.  Launch-only; returns before the GPU finishes. */
+ * reset-terminated -> random policy -> step (policy evaluated inside the step kernel; the sampled
+ * a / greedy_a are still written to the given tensors).  Launch-only; returns before the GPU finishes. */
 int hsad_env_rollout_random(hsad_env* env, int n_iter, uint64_t policy_seed, int64_t* a, int64_t* greedy_a,
                             void* stream);
+
+/* Split the games into n_part (1..16) independent ranges that hsad_env_rollout_random runs on private
+ * HIP streams (fork/join around the caller's stream), so one range's latency-bound reset/logic phases
+ * overlap another range's HBM-bound observation streaming.  Results are unaffected (games are
+ * independent).  Default 1 = everything on the caller's stream. */
+int hsad_env_set_partitions(hsad_env* env, int n_part);
 
 /* Per-game scalars, device int32 [G, HSAD_QUERY_WORDS]:
  * terminated(), getCurrentPlayer(), getScore(), getLife(), getInfo(), lastScore(), numStep,
@@ -121,6 +129,10 @@ int hsad_env_deck_history(hsad_env* env, uint8_t* out, int32_t* count, void* str
  * oracle/hanabi_oracle.cc orc_env_export_state; the two sides are written independently). */
 int hsad_env_state_words(const hsad_env* env);
 int hsad_env_export_state(hsad_env* env, int32_t* out, void* stream);
+
+/* Developer aid: when buf != NULL (device uint64 [ceil(G/64), 8]) the reset/step kernels store
+ * s_memtime stamps at their phase boundaries (load, logic, build rows, write-back, stream). */
+int hsad_env_debug_timing(hsad_env* env, uint64_t* buf);
 
 /* Number of games that hit an API-contract error (illegal move, step on a finished game) since
  * the last call; synchronises the device.  first_game/first_code (may be NULL) describe the first. */

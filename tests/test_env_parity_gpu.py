@@ -21,6 +21,10 @@ CONFIGS = [
     dict(players=3, hand_size=5, sad=False, shuffle_color=True, knowledge_mode=1, bomb=0, max_len=-1, G=33, iters=80),
     dict(players=5, hand_size=4, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80, G=64, iters=80),
     dict(players=4, hand_size=4, sad=False, shuffle_color=False, knowledge_mode=0, bomb=1, max_len=80, G=17, iters=60),
+    # literal fp64 discrete_distribution path on every deal (deal_mode=1) instead of the filtered integer path
+    dict(players=2, hand_size=5, sad=False, shuffle_color=False, knowledge_mode=0, bomb=0, max_len=80, G=70, iters=80,
+         deal_mode=1),
+    dict(players=5, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80, G=9, iters=60),
 ]
 
 
@@ -36,14 +40,15 @@ def _cmp(name, dev, ref, it):
             name, it, len(bad), bad[0], dev[tuple(bad[0])], np.asarray(ref)[tuple(bad[0])]))
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "p%dh%d_sad%d_sc%d_k%d" % (
-    c["players"], c["hand_size"], c["sad"], c["shuffle_color"], c["knowledge_mode"]))
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "p%dh%d_sad%d_sc%d_k%d_d%d" % (
+    c["players"], c["hand_size"], c["sad"], c["shuffle_color"], c["knowledge_mode"], c.get("deal_mode", 0)))
 def test_env_bit_parity(cfg):
     from hanabi_sad_amd import BatchedHanabiEnv
     cfg = dict(cfg)
     G, iters = cfg.pop("G"), cfg.pop("iters")
+    deal_mode = cfg.pop("deal_mode", 0)
     seed, pseed = 9000, 77
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", **cfg)
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", deal_mode=deal_mode, **cfg)
     refs = [OracleEnv(seed=seed + g, eps_list=EPS, **cfg) for g in range(G)]
     P, F, A, H = dev.P, dev.F, dev.A, dev.H
     assert (F, A) == (refs[0].F, refs[0].A)
@@ -118,3 +123,32 @@ def test_illegal_move_is_reported_not_applied():
     dev2.step(torch.zeros(2, 2, dtype=torch.int64, device="cuda:0"))
     with pytest.raises(HsadError):
         dev2.check_errors()
+
+
+@pytest.mark.parametrize("parts", [1, 3, 8])
+def test_rollout_random_matches_oracle(parts):
+    """hsad_env_rollout_random (fused policy, optional multi-stream partitions) == oracle thread-loop."""
+    from hanabi_sad_amd import BatchedHanabiEnv
+    from oracle.oracle import OracleVecEnv
+    G, iters, seed, pseed = 64 * 9 + 5, 60, 4242, 11
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, sad=True, shuffle_color=True, device="cuda:0")
+    dev.set_partitions(parts)
+    ref = OracleVecEnv(G, seed, players=2, hand_size=5, eps_list=EPS, sad=True, shuffle_color=True, max_len=80)
+    for chunk in range(3):
+        dev.rollout_random(iters // 3, pseed)
+        ref.rollout(iters // 3, pseed)
+        torch.cuda.synchronize()
+        dev.check_errors()
+        _cmp("priv_s", dev.priv_s, ref.priv_s, chunk)
+        _cmp("legal_move", dev.legal_move, ref.legal, chunk)
+        _cmp("own_hand", dev.own_hand, ref.own_hand, chunk)
+        _cmp("eps", dev.eps, ref.eps, chunk)
+        _cmp("reward", dev.reward, ref.reward, chunk)
+        _cmp("terminal", dev.terminal, ref.terminal, chunk)
+        _cmp("a", dev.a, ref.a, chunk)
+        _cmp("greedy_a", dev.greedy_a, ref.g, chunk)
+    r_state = np.stack([e.export_state() for e in ref.envs])
+    for e in ref.envs:
+        e.terminated()
+    r_state = np.stack([e.export_state() for e in ref.envs])
+    _cmp("state dump", dev.export_state(), r_state, 0)
