@@ -96,11 +96,18 @@ print("rank", rank, "ok")
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", str(script)]
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
