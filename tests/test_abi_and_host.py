@@ -92,7 +92,7 @@ assert max_over_ranks(1.0 + rank) == float(world)
 assert shard_seed(10, b) == 10 + b
 dist.barrier()
 dist.destroy_process_group()
-print("rank", rank, "ok")
+open(os.path.join(%r, "rank%%d.ok" %% rank), "w").write("ok")
 '''
 
 
@@ -105,9 +105,9 @@ def _free_port():
 
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(WORKER % (ROOT, str(tmp_path)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+    assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
