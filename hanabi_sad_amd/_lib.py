@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip",)]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip")]
 _lib = None
 
 
@@ -22,6 +22,10 @@ class EnvConfig(C.Structure):
         ("shuffle_color", C.c_int32), ("knowledge_mode", C.c_int32), ("n_eps", C.c_int32), ("device", C.c_int32),
         ("track_deck_history", C.c_int32), ("deal_mode", C.c_int32), ("eps_list", C.POINTER(C.c_float)),
     ]
+
+
+class Field(C.Structure):
+    _fields_ = [("width", C.c_int32), ("dtype", C.c_int32)]
 
 
 # every symbol include/hsad.h declares: (restype, argtypes)
@@ -50,6 +54,27 @@ SIGNATURES = {
     "hsad_env_export_state": (C.c_int, [_P, _P, _P]),
     "hsad_env_debug_timing": (C.c_int, [_P, _P]),
     "hsad_env_error_count": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hsad_aggregate_priority": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_float, _P, _P]),
+    "hsad_replay_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(Field), C.c_int, C.POINTER(_P)]),
+    "hsad_replay_destroy": (None, [_P]),
+    "hsad_replay_bytes": (C.c_int64, [_P]),
+    "hsad_replay_add": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_replay_sample": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P, _P]),
+    "hsad_replay_update_priority": (C.c_int, [_P, _P, C.c_int, _P]),
+    "hsad_replay_size": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "hsad_replay_get": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P]),
+    "hsad_replay_last_ids": (C.c_int, [_P, _P, C.c_int, _P]),
+    "hsad_replay_error_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "hsad_seqwriter_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(Field), C.c_int,
+                                        C.POINTER(_P)]),
+    "hsad_seqwriter_destroy": (None, [_P]),
+    "hsad_seqwriter_push_obs_action": (C.c_int, [_P, C.POINTER(_P), _P]),
+    "hsad_seqwriter_push_reward_terminal": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_seqwriter_can_pop": (C.c_int, [_P]),
+    "hsad_seqwriter_pop_transition": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P]),
+    "hsad_seqwriter_push_sequence": (C.c_int, [_P, _P, _P]),
+    "hsad_seqwriter_flush_to_replay": (C.c_int, [_P, _P, C.c_float, _P, _P]),
 }
 
 

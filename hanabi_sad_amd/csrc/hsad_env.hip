@@ -1310,6 +1310,11 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
 extern "C" {
 
 const char* hsad_last_error(void) { return g_last_error.c_str(); }
+// shared by the other translation units of libhsad (not part of the public header)
+int hsad_internal_set_error(int code, const char* msg) {
+  g_last_error = msg ? msg : "";
+  return code;
+}
 const char* hsad_version(void) { return "hsad 0.1 gfx950"; }
 
 int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {

@@ -1,0 +1,877 @@
+// hsad_replay.hip — device-resident prioritized sequence replay and actor-side buffers for MI355X.
+// Implements hsad_aggregate_priority, hsad_replay_* and hsad_seqwriter_* of include/hsad.h.
+//
+// Reference (all host C++ on ATen CPU tensors): rela::ConcurrentQueue / PrioritizedReplay<RNNTransition>
+// (rela/prioritized_replay.h:15-361), RNNTransition::makeBatch (rela/transition.cc:160-202), MultiStepBuffer
+// and R2D2Buffer (rela/transition_buffer.h:8-227), aggregatePriority (rela/r2d2_actor.h:10-21).
+//
+// MI355X design: everything lives in HBM (a 131,072-sequence buffer of 282 KB sequences is 37 GB — it
+// fits in the 288 GB of one GPU, so nothing is paged or staged through the host).  A transition is a
+// 16-byte-aligned *row* (all per-step fields of one env concatenated); rows move ring -> staging -> replay
+// with coalesced 16-byte copies and are only (de)interleaved into the reference's per-key tensors at the
+// API boundary.  Sampling is one stream-ordered launch (prefix sums over the weight ring + stratified
+// search + eviction + importance weights) — no locks, no prefetch thread, no host round trip; the only host
+// input is the batch of canonical uniform draws, produced by the same std::mt19937 +
+// std::uniform_real_distribution<float> the reference uses.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "hsad.h"
+
+extern "C" int hsad_internal_set_error(int code, const char* msg);
+
+namespace {
+
+constexpr int kMaxFields = 16;
+constexpr int kMaxBatch = 1024;
+
+int rfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return hsad_internal_set_error(code, buf);
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return rfail(HSAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ---- row layout -----------------------------------------------------------------------------------
+struct RowLayout {
+  int n_fields;
+  int width[kMaxFields];
+  int esize[kMaxFields];
+  int offset[kMaxFields];  // byte offset inside the row (8-byte aligned)
+  int row_bytes;           // multiple of 16
+};
+
+int make_layout(int n_fields, const hsad_field* f, RowLayout* L) {
+  if (n_fields < 1 || n_fields > kMaxFields) return rfail(HSAD_ERR_INVALID, "n_fields must be 1..%d", kMaxFields);
+  L->n_fields = n_fields;
+  int off = 0;
+  for (int k = 0; k < n_fields; ++k) {
+    if (f[k].width < 1) return rfail(HSAD_ERR_INVALID, "field %d has width %d", k, f[k].width);
+    int es = f[k].dtype == HSAD_F32 ? 4 : (f[k].dtype == HSAD_I64 ? 8 : (f[k].dtype == HSAD_U8 ? 1 : 0));
+    if (!es) return rfail(HSAD_ERR_INVALID, "field %d has unknown dtype %d", k, f[k].dtype);
+    L->width[k] = f[k].width;
+    L->esize[k] = es;
+    L->offset[k] = off;
+    off += (f[k].width * es + 7) & ~7;
+  }
+  L->row_bytes = (off + 15) & ~15;
+  return HSAD_OK;
+}
+
+struct FieldPtrs {
+  const void* p[kMaxFields];
+};
+struct FieldPtrsMut {
+  void* p[kMaxFields];
+};
+
+// One block per row.  src element (i, t) of field k lives at ((i*src_T + t) * width_k); dst row index is
+// given by dst_row(i, t).  n_dev (optional) bounds i.
+enum RowMap : int { MAP_RING = 0, MAP_LINEAR = 1 };
+
+// fields [n][T][w]  ->  rows[(slot0 + i) % ring][t]     (replay add)
+// fields [E][w] (T=1) -> rows[base_row + e]             (history ring push)
+__global__ void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows, int n, int T, int map, int slot0,
+                                 int ring, const int* __restrict__ n_dev, const int* __restrict__ slot0_dev) {
+  const int row = blockIdx.x;
+  const int i = row / T, t = row - i * T;
+  if (n_dev && i >= *n_dev) return;
+  const int s0 = slot0_dev ? *slot0_dev : slot0;
+  const size_t dst_row = (map == MAP_RING) ? ((size_t)((s0 + i) % ring) * T + t) : ((size_t)s0 + row);
+  unsigned char* dst = rows + dst_row * L.row_bytes;
+  for (int k = 0; k < L.n_fields; ++k) {
+    const int nbytes = L.width[k] * L.esize[k];
+    const unsigned char* s = static_cast<const unsigned char*>(src.p[k]) + (size_t)row * nbytes;
+    if (L.esize[k] >= 4) {
+      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
+      uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + L.offset[k]);
+      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = s4[j];
+    } else {
+      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) dst[L.offset[k] + j] = s[j];
+    }
+  }
+}
+
+// rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
+// or, with ids == nullptr, row index base_row + b (T must be 1 then) .
+__global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldPtrsMut dst, int B, int T,
+                                   const int* __restrict__ ids, int base_row) {
+  const int row = blockIdx.x;  // = t*B + b
+  const int t = row / B, b = row - t * B;
+  const size_t src_row = ids ? ((size_t)ids[b] * T + t) : ((size_t)base_row + b);
+  const unsigned char* s = rows + src_row * L.row_bytes;
+  for (int k = 0; k < L.n_fields; ++k) {
+    if (!dst.p[k]) continue;
+    const int nbytes = L.width[k] * L.esize[k];
+    unsigned char* d = static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes;
+    if (L.esize[k] >= 4) {
+      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s + L.offset[k]);
+      uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
+      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = s4[j];
+    } else {
+      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) d[j] = s[L.offset[k] + j];
+    }
+  }
+}
+
+// per-step scalars of sampled sequences: out[t][b] = store[ids[b]][t]
+__global__ void gather_scalars_kernel(const float* __restrict__ reward, const unsigned char* __restrict__ terminal,
+                                      const float* __restrict__ bootstrap, const float* __restrict__ seq_len,
+                                      const int* __restrict__ ids, int B, int T, float* o_reward,
+                                      unsigned char* o_terminal, float* o_bootstrap, float* o_seq_len) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= T * B) return;
+  const int t = idx / B, b = idx - t * B;
+  const size_t s = (size_t)ids[b] * T + t;
+  if (o_reward) o_reward[idx] = reward[s];
+  if (o_terminal) o_terminal[idx] = terminal[s];
+  if (o_bootstrap) o_bootstrap[idx] = bootstrap[s];
+  if (t == 0 && o_seq_len) o_seq_len[b] = seq_len[ids[b]];
+}
+
+// ---- replay control -------------------------------------------------------------------------------------
+struct ReplayCtl {
+  int head, tail, size, num_add;
+  double sum;  // ConcurrentQueue::sum_ (running, like the reference)
+  int n_sampled, err;
+  int add_start, add_n;  // slot range of the add in flight (consumed by the payload copy kernels)
+  int size_before_pop, pad;
+};
+
+struct ReplayDev {
+  ReplayCtl* ctl;
+  float* weights;
+  unsigned char* evicted;
+  int* sampled_ids;
+  float* sampled_w;
+  int ring, capacity;
+  float alpha, beta;
+};
+
+// PrioritizedReplay::add bookkeeping (ConcurrentQueue::blockAppend): weights = priority^alpha stored at
+// tail.., sequential float block sum added to the running double, tail/size/num_add advanced.
+__global__ void replay_add_ctl_kernel(ReplayDev rd, int n, const int* __restrict__ n_dev,
+                                      const float* __restrict__ priority) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ReplayCtl c = *rd.ctl;
+  int cnt = n_dev ? min(*n_dev, n) : n;
+  if (c.size + cnt > rd.ring) {  // the reference would block here until sample() pops
+    c.err += 1;
+    cnt = 0;
+  }
+  float sum = 0.f;
+  for (int i = 0; i < cnt; ++i) {
+    const float w = powf(priority[i], rd.alpha);
+    rd.weights[(c.tail + i) % rd.ring] = w;
+    sum += w;
+  }
+  c.add_start = c.tail;
+  c.add_n = cnt;
+  c.tail = (c.tail + cnt) % rd.ring;
+  c.size += cnt;
+  c.num_add += cnt;
+  c.sum += sum;
+  *rd.ctl = c;
+}
+
+// scalars of added sequences: store[(start+i)%ring][t] = src[i][t]
+__global__ void replay_add_scalars_kernel(ReplayDev rd, int n, int T, const float* __restrict__ reward,
+                                          const unsigned char* __restrict__ terminal,
+                                          const float* __restrict__ bootstrap, const float* __restrict__ seq_len,
+                                          float* s_reward, unsigned char* s_terminal, float* s_bootstrap,
+                                          float* s_seq_len) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cnt = rd.ctl->add_n, start = rd.ctl->add_start;
+  if (idx >= cnt * T) return;
+  const int i = idx / T, t = idx - i * T;
+  const size_t d = (size_t)((start + i) % rd.ring) * T + t;
+  s_reward[d] = reward[idx];
+  s_terminal[d] = terminal[idx];
+  s_bootstrap[d] = bootstrap[idx];
+  if (t == 0) s_seq_len[(start + i) % rd.ring] = seq_len[i];
+}
+
+// PrioritizedReplay::sample_ (rela/prioritized_replay.h:274-345) as one block.
+__global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B, const float* __restrict__ canon,
+                                                             float* __restrict__ weight_out) {
+  __shared__ double s_incl[1024];
+  __shared__ double s_red[1024];
+  __shared__ float s_rand[kMaxBatch];
+  __shared__ float s_w[kMaxBatch];
+  __shared__ float s_y[kMaxBatch];
+  __shared__ int s_id[kMaxBatch];
+  __shared__ float s_max;
+  const int tid = threadIdx.x;
+  const ReplayCtl c = *rd.ctl;
+  const int N = c.size, head = c.head, ring = rd.ring;
+  const float sum = (float)c.sum;
+  const float segment = sum / B;
+  if (tid < B) {
+    float r = canon[tid] * segment + tid * segment;  // uniform_real_distribution(0, segment)(rng) + i * segment
+    s_rand[tid] = fminf(sum - 0.1f, r);
+  }
+  // chunked prefix sums of the weights in ring order, accumulated in double like the reference's accSum
+  const int C = (N + 1023) / 1024;
+  {
+    double local = 0.0;
+    const int k0 = tid * C, k1 = min(k0 + C, N);
+    for (int k = k0; k < k1; ++k) local += (double)rd.weights[(head + k) % ring];
+    s_incl[tid] = local;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int j = 0; j < 1024; ++j) {
+      acc += s_incl[j];
+      s_incl[j] = acc;
+    }
+  }
+  __syncthreads();
+  if (tid < B) {
+    const float target = s_rand[tid];
+    // first chunk whose inclusive prefix reaches the target (and is positive)
+    int lo = 0, hi = 1023;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_incl[mid] >= (double)target && s_incl[mid] > 0.0)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    double acc = lo > 0 ? s_incl[lo - 1] : 0.0;
+    int found = -1;
+    float w = 0.f;
+    for (int k = lo * C; k < N; ++k) {
+      w = rd.weights[(head + k) % ring];
+      acc += (double)w;
+      if (acc > 0.0 && acc >= (double)target) {
+        found = k;
+        break;
+      }
+    }
+    if (found < 0) {  // the reference asserts here
+      atomicAdd(&rd.ctl->err, 1);
+      found = N > 0 ? N - 1 : 0;
+      w = N > 0 ? rd.weights[(head + found) % ring] : 0.f;
+    }
+    const int id = (head + found) % ring;
+    s_id[tid] = id;
+    s_w[tid] = w;
+    rd.sampled_ids[tid] = id;
+    rd.sampled_w[tid] = w;
+    rd.evicted[id] = 0;  // getElementAndMark
+  }
+  __syncthreads();
+  // pop storage if full (ConcurrentQueue::blockPop of the oldest size-capacity entries)
+  const int npop = N > rd.capacity ? N - rd.capacity : 0;
+  {
+    double local = 0.0;
+    for (int k = tid; k < npop; k += 1024) {
+      const int j = (head + k) % ring;
+      local += (double)rd.weights[j];
+      rd.evicted[j] = 1;
+    }
+    s_red[tid] = local;
+  }
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) s_red[tid] += s_red[tid + s];
+    __syncthreads();
+  }
+  // importance weights: (size * w / sum)^-beta / max   (size = pre-pop size_)
+  if (tid < B) {
+    const float wn = s_w[tid] / sum;
+    s_y[tid] = powf((float)N * wn, -rd.beta);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float m = s_y[0];
+    for (int i = 1; i < B; ++i) m = fmaxf(m, s_y[i]);
+    s_max = m;
+    ReplayCtl cc = *rd.ctl;
+    cc.sum -= s_red[0];
+    cc.head = (head + npop) % ring;
+    cc.size = N - npop;
+    cc.n_sampled = B;
+    cc.size_before_pop = N;
+    *rd.ctl = cc;
+  }
+  __syncthreads();
+  if (tid < B) weight_out[tid] = s_y[tid] / s_max;
+}
+
+// PrioritizedReplay::updatePriority -> ConcurrentQueue::update (sequential: duplicates see earlier writes)
+__global__ void replay_update_kernel(ReplayDev rd, int B, const float* __restrict__ priority) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  ReplayCtl c = *rd.ctl;
+  if (B == 0) {
+    c.n_sampled = 0;
+    *rd.ctl = c;
+    return;
+  }
+  if (c.n_sampled != B) {
+    c.err += 1;
+    *rd.ctl = c;
+    return;
+  }
+  double diff = 0.0;
+  for (int i = 0; i < B; ++i) {
+    const int id = rd.sampled_ids[i];
+    if (rd.evicted[id]) continue;
+    const float w = powf(priority[i], rd.alpha);
+    diff += (w - rd.weights[id]);
+    rd.weights[id] = w;
+  }
+  c.sum += diff;
+  c.n_sampled = 0;
+  *rd.ctl = c;
+}
+
+__global__ void ids_from_head_kernel(ReplayDev rd, int idx, int* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (rd.ctl->head + idx) % rd.ring;
+}
+
+// ---- aggregatePriority --------------------------------------------------------------------------------
+__global__ void aggregate_priority_kernel(const float* __restrict__ priority, const float* __restrict__ seq_len,
+                                          int T, int B, float eta, float c1m, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float len = seq_len[b];
+  float mx = 0.f;
+  double sum = 0.0;
+  bool first = true;
+  for (int t = 0; t < T; ++t) {
+    const float p = priority[(size_t)t * B + b] * ((float)t < len ? 1.f : 0.f);
+    sum += p;
+    mx = first ? p : fmaxf(mx, p);
+    first = false;
+  }
+  out[b] = eta * mx + c1m * ((float)sum / len);
+}
+
+// ---- sequence writer (MultiStepBuffer + R2D2Buffer) ----------------------------------------------------------
+struct SeqDev {
+  int E, n, T, depth;  // depth = n + 1 history slots
+  float gamma;
+  unsigned char* hist_rows;  // [depth][E][row_bytes]
+  float* hist_r;             // [depth][E]
+  unsigned char* hist_t;     // [depth][E]
+  unsigned char* st_rows;    // [E][T][row_bytes]
+  float* st_reward;          // [E][T]
+  unsigned char* st_terminal;
+  float* st_bootstrap;
+  float* st_prio;
+  int* next_idx;  // [E]
+  int* len;       // [E]
+  float* pend_reward;  // [E] transition popped by pop_transition, consumed by push_sequence
+  unsigned char* pend_terminal;
+  float* pend_bootstrap;
+  int* fin_env;    // [E] compacted list of finished envs
+  float* fin_prio;  // [E] aggregated priorities
+  float* fin_len;   // [E]
+  int* n_fin;       // [1]
+};
+
+// MultiStepBuffer::popTransition (rela/transition_buffer.h:51-99)
+__global__ void seq_pop_kernel(SeqDev sd, int head, float* o_reward, unsigned char* o_terminal, float* o_bootstrap) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= sd.E) return;
+  float bootstrap = 1.f;
+  int next = sd.n;
+  for (int step = 0; step < sd.n; ++step) {
+    if (sd.hist_t[(size_t)((head + step) % sd.depth) * sd.E + e]) {
+      bootstrap = 0.f;
+      next = step;
+      break;
+    }
+  }
+  const int initial = bootstrap != 0.f ? sd.n - 1 : next;
+  float acc = 0.f;
+  for (int step = initial; step >= 0; --step)
+    acc = sd.hist_r[(size_t)((head + step) % sd.depth) * sd.E + e] + sd.gamma * acc;
+  const unsigned char term = sd.hist_t[(size_t)head * sd.E + e];
+  sd.pend_reward[e] = acc;
+  sd.pend_terminal[e] = term;
+  sd.pend_bootstrap[e] = bootstrap;
+  if (o_reward) o_reward[e] = acc;
+  if (o_terminal) o_terminal[e] = term;
+  if (o_bootstrap) o_bootstrap[e] = bootstrap;
+}
+
+// R2D2Buffer::push (rela/transition_buffer.h:134-176): one block per env
+__global__ void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const float* __restrict__ priority,
+                                int* __restrict__ err) {
+  const int e = blockIdx.x;
+  const int idx = sd.next_idx[e];
+  if (idx >= sd.T || idx < 0) {  // assert(nextIdx < seqLen) in the reference
+    if (threadIdx.x == 0) atomicAdd(err, 1);
+    return;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(sd.hist_rows + ((size_t)pend_slot * sd.E + e) * row_bytes);
+  uint4* dst = reinterpret_cast<uint4*>(sd.st_rows + ((size_t)e * sd.T + idx) * row_bytes);
+  const int nq = row_bytes / 16;
+  for (int j = threadIdx.x; j < nq; j += blockDim.x) dst[j] = src[j];
+  const unsigned char term = sd.pend_terminal[e];
+  if (term) {  // pad the rest of the sequence: zeros, terminal = 1, bootstrap = 0, priority 0
+    uint4* pad = reinterpret_cast<uint4*>(sd.st_rows + ((size_t)e * sd.T + idx + 1) * row_bytes);
+    const size_t npad = (size_t)(sd.T - idx - 1) * nq;
+    for (size_t j = threadIdx.x; j < npad; j += blockDim.x) pad[j] = make_uint4(0, 0, 0, 0);
+    for (int t = idx + 1 + threadIdx.x; t < sd.T; t += blockDim.x) {
+      sd.st_reward[(size_t)e * sd.T + t] = 0.f;
+      sd.st_terminal[(size_t)e * sd.T + t] = 1;
+      sd.st_bootstrap[(size_t)e * sd.T + t] = 0.f;
+      sd.st_prio[(size_t)e * sd.T + t] = 0.f;
+    }
+  }
+  if (threadIdx.x == 0) {
+    sd.st_reward[(size_t)e * sd.T + idx] = sd.pend_reward[e];
+    sd.st_terminal[(size_t)e * sd.T + idx] = term;
+    sd.st_bootstrap[(size_t)e * sd.T + idx] = sd.pend_bootstrap[e];
+    sd.st_prio[(size_t)e * sd.T + idx] = priority[e];
+    if (term) {
+      sd.len[e] = idx + 1;
+      sd.next_idx[e] = sd.T;
+    } else {
+      sd.next_idx[e] = idx + 1;
+    }
+  }
+}
+
+// R2D2Buffer::popTransition bookkeeping + aggregatePriority for finished envs, ascending env order.
+__global__ __launch_bounds__(1024) void seq_collect_kernel(SeqDev sd, float eta, float c1m, int* n_out) {
+  __shared__ int s_cnt[1024];
+  const int tid = threadIdx.x;
+  const int per = (sd.E + 1023) / 1024;
+  const int e0 = tid * per, e1 = min(e0 + per, sd.E);
+  int cnt = 0;
+  for (int e = e0; e < e1; ++e) cnt += sd.len[e] > 0;
+  s_cnt[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int j = 0; j < 1024; ++j) {
+      const int v = s_cnt[j];
+      s_cnt[j] = acc;
+      acc += v;
+    }
+    sd.n_fin[0] = acc;
+    if (n_out) n_out[0] = acc;
+  }
+  __syncthreads();
+  int k = s_cnt[tid];
+  for (int e = e0; e < e1; ++e) {
+    const int L = sd.len[e];
+    if (L <= 0) continue;
+    float mx = 0.f;
+    double sum = 0.0;
+    for (int t = 0; t < sd.T; ++t) {
+      const float p = sd.st_prio[(size_t)e * sd.T + t] * (t < L ? 1.f : 0.f);
+      sum += p;
+      mx = t == 0 ? p : fmaxf(mx, p);
+    }
+    sd.fin_env[k] = e;
+    sd.fin_len[k] = (float)L;
+    sd.fin_prio[k] = eta * mx + c1m * ((float)sum / (float)L);
+    ++k;
+  }
+}
+
+// copy finished staging sequences into the replay ring (rows + scalars), then reset the env's cursor
+__global__ void seq_flush_copy_kernel(SeqDev sd, ReplayDev rd, int row_bytes, unsigned char* r_rows, float* r_reward,
+                                      unsigned char* r_terminal, float* r_bootstrap, float* r_seq_len) {
+  const int total = rd.ctl->add_n * sd.T;  // rows to move; grid-stride because the count only exists on the device
+  for (int row = blockIdx.x; row < total; row += gridDim.x) {
+    const int k = row / sd.T, t = row - k * sd.T;
+    const int e = sd.fin_env[k];
+    const int slot = (rd.ctl->add_start + k) % rd.ring;
+    const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
+    uint4* dst = reinterpret_cast<uint4*>(r_rows + ((size_t)slot * sd.T + t) * row_bytes);
+    for (int j = threadIdx.x; j < row_bytes / 16; j += blockDim.x) dst[j] = src[j];
+    if (threadIdx.x == 0) {
+      r_reward[(size_t)slot * sd.T + t] = sd.st_reward[(size_t)e * sd.T + t];
+      r_terminal[(size_t)slot * sd.T + t] = sd.st_terminal[(size_t)e * sd.T + t];
+      r_bootstrap[(size_t)slot * sd.T + t] = sd.st_bootstrap[(size_t)e * sd.T + t];
+      if (t == 0) r_seq_len[slot] = sd.fin_len[k];
+    }
+  }
+}
+
+__global__ void seq_reset_finished_kernel(SeqDev sd, const ReplayCtl* ctl) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= sd.n_fin[0]) return;
+  // sequences the replay refused (ring full) are dropped with an error already logged there
+  const int e = sd.fin_env[k];
+  sd.len[e] = 0;
+  sd.next_idx[e] = 0;
+}
+
+}  // namespace
+
+// ===================================================================================================
+struct hsad_replay {
+  RowLayout L;
+  ReplayDev rd;
+  int T, device;
+  unsigned char* rows;  // [ring][T][row_bytes]
+  float* reward;        // [ring][T]
+  unsigned char* terminal;
+  float* bootstrap;
+  float* seq_len;  // [ring]
+  float* d_canon;  // [kMaxBatch] canonical uniforms for the sample in flight
+  std::vector<float> h_canon;  // pageable staging (hipMemcpyAsync copies it before returning)
+  int* d_tmp_id;
+  std::mt19937 rng;
+  hipStream_t last_stream;
+  int64_t bytes;
+};
+
+struct hsad_seqwriter {
+  RowLayout L;
+  SeqDev sd;
+  int device;
+  int head, count, rt_count;  // deque state of the n+1 history (host side: it advances deterministically)
+  int pend_slot;              // history slot of the transition popped last (valid until the next push)
+  bool pending;
+  int* d_err;
+  int64_t bytes;
+};
+
+extern "C" {
+
+int hsad_aggregate_priority(const float* priority, const float* seq_len, int T, int B, float eta, float* out,
+                            void* stream) {
+  if (!priority || !seq_len || !out || T < 1 || B < 1) return rfail(HSAD_ERR_INVALID, "bad aggregate_priority args");
+  // the reference computes `(1.0 - eta) * pMean` with a double scalar that ATen narrows to float
+  const float c1m = (float)(1.0 - (double)eta);
+  hipLaunchKernelGGL(aggregate_priority_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, priority,
+                     seq_len, T, B, eta, c1m, out);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_create(int capacity, int seed, float alpha, float beta, int prefetch, int seq_len, int n_fields,
+                       const hsad_field* fields, int device, hsad_replay** out) {
+  (void)prefetch;
+  if (!out || !fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (capacity < 1 || seq_len < 1) return rfail(HSAD_ERR_INVALID, "capacity and seq_len must be >= 1");
+  hsad_replay* r = new (std::nothrow) hsad_replay();
+  if (!r) return rfail(HSAD_ERR_NOMEM, "host allocation failed");
+  int rc = make_layout(n_fields, fields, &r->L);
+  if (rc != HSAD_OK) {
+    delete r;
+    return rc;
+  }
+  HIP_TRY(hipSetDevice(device));
+  r->device = device;
+  r->T = seq_len;
+  r->rng.seed(seed);
+  r->last_stream = nullptr;
+  ReplayDev& rd = r->rd;
+  rd.ring = (int)(1.25 * capacity);
+  if (rd.ring < 1) rd.ring = 1;
+  rd.capacity = capacity;
+  rd.alpha = alpha;
+  rd.beta = beta;
+  const size_t ring = rd.ring, T = seq_len;
+  size_t total = 0;
+  auto alloc = [&](void** p, size_t n) {
+    total += n;
+    return hipMalloc(p, n);
+  };
+  hipError_t he = hipSuccess;
+  if ((he = alloc((void**)&r->rows, ring * T * r->L.row_bytes)) != hipSuccess ||
+      (he = alloc((void**)&r->reward, ring * T * 4)) != hipSuccess ||
+      (he = alloc((void**)&r->terminal, ring * T)) != hipSuccess ||
+      (he = alloc((void**)&r->bootstrap, ring * T * 4)) != hipSuccess ||
+      (he = alloc((void**)&r->seq_len, ring * 4)) != hipSuccess ||
+      (he = alloc((void**)&rd.weights, ring * 4)) != hipSuccess ||
+      (he = alloc((void**)&rd.evicted, ring)) != hipSuccess ||
+      (he = alloc((void**)&rd.ctl, sizeof(ReplayCtl))) != hipSuccess ||
+      (he = alloc((void**)&rd.sampled_ids, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&rd.sampled_w, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&r->d_canon, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&r->d_tmp_id, 16)) != hipSuccess) {
+    rfail(HSAD_ERR_NOMEM, "hipMalloc failed for the replay (%zu B so far): %s", total, hipGetErrorString(he));
+    hsad_replay_destroy(r);
+    return HSAD_ERR_NOMEM;
+  }
+  r->h_canon.resize(kMaxBatch);
+  HIP_TRY(hipMemset(rd.ctl, 0, sizeof(ReplayCtl)));
+  HIP_TRY(hipMemset(rd.weights, 0, ring * 4));
+  HIP_TRY(hipMemset(rd.evicted, 0, ring));
+  r->bytes = (int64_t)total;
+  *out = r;
+  return HSAD_OK;
+}
+
+void hsad_replay_destroy(hsad_replay* r) {
+  if (!r) return;
+  (void)hipSetDevice(r->device);
+  void* ptrs[] = {r->rows, r->reward, r->terminal, r->bootstrap, r->seq_len, r->rd.weights, r->rd.evicted, r->rd.ctl,
+                  r->rd.sampled_ids, r->rd.sampled_w, r->d_canon, r->d_tmp_id};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete r;
+}
+
+int64_t hsad_replay_bytes(const hsad_replay* r) { return r ? r->bytes : 0; }
+
+int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const float* reward, const uint8_t* terminal,
+                    const float* bootstrap, const float* seq_len, const float* priority, const int32_t* n_dev,
+                    void* stream) {
+  if (!r || !fields || !reward || !terminal || !bootstrap || !seq_len || !priority)
+    return rfail(HSAD_ERR_INVALID, "null argument");
+  if (n < 1) return HSAD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(1), 0, s, r->rd, n, n_dev, priority);
+  FieldPtrs fp;
+  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
+  // payload rows; add_n (<= n) from the control block bounds the copy
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, fp, r->rows, n, r->T, (int)MAP_RING, 0,
+                     r->rd.ring, &r->rd.ctl->add_n, &r->rd.ctl->add_start);
+  hipLaunchKernelGGL(replay_add_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->rd, n, r->T, reward,
+                     terminal, bootstrap, seq_len, r->reward, r->terminal, r->bootstrap, r->seq_len);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float* reward, uint8_t* terminal,
+                       float* bootstrap, float* seq_len, float* weight, void* stream) {
+  if (!r || !out_fields || !weight) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "batch must be 1..%d", kMaxBatch);
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  // canonical uniforms exactly as std::uniform_real_distribution<float> would draw them (libstdc++:
+  // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
+  // the segment depends on the device-side running sum)
+  for (int i = 0; i < batch; ++i) r->h_canon[i] = std::generate_canonical<float, 24>(r->rng);
+  HIP_TRY(hipMemcpyAsync(r->d_canon, r->h_canon.data(), sizeof(float) * batch, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight);
+  FieldPtrsMut fp;
+  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(batch * r->T), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
+                     r->rd.sampled_ids, 0);
+  hipLaunchKernelGGL(gather_scalars_kernel, dim3((batch * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
+                     r->bootstrap, r->seq_len, r->rd.sampled_ids, batch, r->T, reward, terminal, bootstrap, seq_len);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch, void* stream) {
+  if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
+  if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
+  r->last_stream = (hipStream_t)stream;
+  hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, r->rd, batch, priority);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_size(hsad_replay* r, int32_t* size, int32_t* num_add) {
+  if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
+  ReplayCtl c;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&c, r->rd.ctl, sizeof(c), hipMemcpyDeviceToHost));
+  if (size) *size = c.size;
+  if (num_add) *num_add = c.num_add;
+  return HSAD_OK;
+}
+
+int hsad_replay_error_count(hsad_replay* r, int32_t* count) {
+  if (!r || !count) return rfail(HSAD_ERR_INVALID, "null argument");
+  ReplayCtl c;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&c, r->rd.ctl, sizeof(c), hipMemcpyDeviceToHost));
+  *count = c.err;
+  return HSAD_OK;
+}
+
+int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* reward, uint8_t* terminal,
+                    float* bootstrap, float* seq_len, void* stream) {
+  if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
+  FieldPtrsMut fp;
+  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(r->T), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0);
+  hipLaunchKernelGGL(gather_scalars_kernel, dim3((r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
+                     r->bootstrap, r->seq_len, r->d_tmp_id, 1, r->T, reward, terminal, bootstrap, seq_len);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_last_ids(hsad_replay* r, int32_t* out, int batch, void* stream) {
+  if (!r || !out || batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad argument");
+  HIP_TRY(hipMemcpyAsync(out, r->rd.sampled_ids, sizeof(int) * batch, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return HSAD_OK;
+}
+
+// ---- sequence writer --------------------------------------------------------------------------------------
+int hsad_seqwriter_create(int num_envs, int multi_step, float gamma, int seq_len, int n_fields,
+                          const hsad_field* fields, int device, hsad_seqwriter** out) {
+  if (!out || !fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (num_envs < 1 || multi_step < 1 || seq_len < 1) return rfail(HSAD_ERR_INVALID, "bad seqwriter dimensions");
+  hsad_seqwriter* w = new (std::nothrow) hsad_seqwriter();
+  if (!w) return rfail(HSAD_ERR_NOMEM, "host allocation failed");
+  int rc = make_layout(n_fields, fields, &w->L);
+  if (rc != HSAD_OK) {
+    delete w;
+    return rc;
+  }
+  HIP_TRY(hipSetDevice(device));
+  w->device = device;
+  w->head = w->count = w->rt_count = 0;
+  w->pend_slot = 0;
+  w->pending = false;
+  SeqDev& sd = w->sd;
+  sd.E = num_envs;
+  sd.n = multi_step;
+  sd.T = seq_len;
+  sd.depth = multi_step + 1;
+  sd.gamma = gamma;
+  const size_t E = num_envs, T = seq_len, D = sd.depth, RB = w->L.row_bytes;
+  size_t total = 0;
+  hipError_t he = hipSuccess;
+  auto alloc = [&](void** p, size_t n) {
+    total += n;
+    hipError_t e = hipMalloc(p, n);
+    if (e == hipSuccess) e = hipMemset(*p, 0, n);
+    return e;
+  };
+  if ((he = alloc((void**)&sd.hist_rows, D * E * RB)) != hipSuccess ||
+      (he = alloc((void**)&sd.hist_r, D * E * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.hist_t, D * E)) != hipSuccess ||
+      (he = alloc((void**)&sd.st_rows, E * T * RB)) != hipSuccess ||
+      (he = alloc((void**)&sd.st_reward, E * T * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.st_terminal, E * T)) != hipSuccess ||
+      (he = alloc((void**)&sd.st_bootstrap, E * T * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.st_prio, E * T * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.next_idx, E * 4)) != hipSuccess || (he = alloc((void**)&sd.len, E * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.pend_reward, E * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.pend_terminal, E)) != hipSuccess ||
+      (he = alloc((void**)&sd.pend_bootstrap, E * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.fin_env, E * 4)) != hipSuccess || (he = alloc((void**)&sd.fin_prio, E * 4)) != hipSuccess ||
+      (he = alloc((void**)&sd.fin_len, E * 4)) != hipSuccess || (he = alloc((void**)&sd.n_fin, 16)) != hipSuccess ||
+      (he = alloc((void**)&w->d_err, 16)) != hipSuccess) {
+    rfail(HSAD_ERR_NOMEM, "hipMalloc failed for the sequence writer: %s", hipGetErrorString(he));
+    hsad_seqwriter_destroy(w);
+    return HSAD_ERR_NOMEM;
+  }
+  w->bytes = (int64_t)total;
+  *out = w;
+  return HSAD_OK;
+}
+
+void hsad_seqwriter_destroy(hsad_seqwriter* w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  SeqDev& sd = w->sd;
+  void* ptrs[] = {sd.hist_rows, sd.hist_r, sd.hist_t, sd.st_rows, sd.st_reward, sd.st_terminal, sd.st_bootstrap,
+                  sd.st_prio, sd.next_idx, sd.len, sd.pend_reward, sd.pend_terminal, sd.pend_bootstrap, sd.fin_env,
+                  sd.fin_prio, sd.fin_len, sd.n_fin, w->d_err};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete w;
+}
+
+int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields, void* stream) {
+  if (!w || !fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (w->count > w->sd.n) return rfail(HSAD_ERR_STATE, "history holds n+1 steps: pop_transition first");
+  if (w->pending) return rfail(HSAD_ERR_STATE, "push_sequence must consume the popped transition first");
+  const int slot = (w->head + w->count) % w->sd.depth;
+  FieldPtrs fp;
+  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? fields[k] : nullptr;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(w->sd.E), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
+                     w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr);
+  HIP_TRY(hipGetLastError());
+  w->count += 1;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_push_reward_terminal(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, void* stream) {
+  if (!w || !reward || !terminal) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (w->rt_count != w->count - 1) return rfail(HSAD_ERR_STATE, "reward/terminal must follow each obs/action push");
+  const int slot = (w->head + w->rt_count) % w->sd.depth;
+  HIP_TRY(hipMemcpyAsync(w->sd.hist_r + (size_t)slot * w->sd.E, reward, sizeof(float) * w->sd.E,
+                         hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(w->sd.hist_t + (size_t)slot * w->sd.E, terminal, w->sd.E, hipMemcpyDeviceToDevice,
+                         (hipStream_t)stream));
+  w->rt_count += 1;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_can_pop(const hsad_seqwriter* w) { return w && w->count == w->sd.n + 1 && w->rt_count == w->count; }
+
+int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, void* const* out_next_fields,
+                                  float* reward, uint8_t* terminal, float* bootstrap, void* stream) {
+  if (!w) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (!hsad_seqwriter_can_pop(w)) return rfail(HSAD_ERR_STATE, "history does not hold n+1 complete steps");
+  hipStream_t s = (hipStream_t)stream;
+  const SeqDev& sd = w->sd;
+  hipLaunchKernelGGL(seq_pop_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, w->head, reward, terminal,
+                     bootstrap);
+  for (int pass = 0; pass < 2; ++pass) {
+    void* const* of = pass == 0 ? out_fields : out_next_fields;
+    if (!of) continue;
+    const int slot = pass == 0 ? w->head : (w->head + sd.n) % sd.depth;
+    FieldPtrsMut fp;
+    for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? of[k] : nullptr;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(sd.E), dim3(256), 0, s, w->L, sd.hist_rows, fp, sd.E, 1,
+                       (const int*)nullptr, slot * sd.E);
+  }
+  HIP_TRY(hipGetLastError());
+  w->pend_slot = w->head;
+  w->pending = true;
+  w->head = (w->head + 1) % sd.depth;
+  w->count -= 1;
+  w->rt_count -= 1;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream) {
+  if (!w || !priority) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (!w->pending) return rfail(HSAD_ERR_STATE, "no popped transition to push");
+  hipLaunchKernelGGL(seq_push_kernel, dim3(w->sd.E), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
+                     w->pend_slot, priority, w->d_err);
+  HIP_TRY(hipGetLastError());
+  w->pending = false;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta, int32_t* n_finished_dev, void* stream) {
+  if (!w || !r) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (w->L.row_bytes != r->L.row_bytes || w->sd.T != r->T || w->L.n_fields != r->L.n_fields)
+    return rfail(HSAD_ERR_INVALID, "sequence writer and replay were created with different layouts");
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  const SeqDev& sd = w->sd;
+  const float c1m = (float)(1.0 - (double)eta);
+  hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
+  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(1), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
+  hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min(sd.E * sd.T, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
+                     r->reward, r->terminal, r->bootstrap, r->seq_len);
+  hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+"""Host mirror of the device replay / actor buffers in libhsad (include/hsad.h):
+
+* `aggregate_priority`            <- rela.aggregate_priority            (rela/pybind.cc:92, r2d2_actor.h:10-21)
+* `DeviceReplay`                  <- rela.RNNPrioritizedReplay          (rela/pybind.cc:46-58)
+* `SequenceWriter`                <- MultiStepBuffer + R2D2Buffer inside R2D2Actor (rela/r2d2_actor.h:23-172)
+
+Transitions are described by an ordered list of (name, width, dtype) fields = the keys of the reference's
+obs/action TensorDicts.  All tensors live on the GPU; there is no CPU path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}
+_TORCH_DT = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
+
+
+def _fields_struct(fields):
+    arr = (_lib.Field * len(fields))()
+    for i, (_, width, dtype) in enumerate(fields):
+        arr[i].width = int(width)
+        arr[i].dtype = _DT[dtype]
+    return arr
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def aggregate_priority(priority, seq_len, eta):
+    """priority [T,B] f32, seq_len [B] f32 (both on the GPU) -> [B] f32."""
+    lib = _lib.load_library()
+    if priority.device.type != "cuda":
+        raise _lib.HsadError("aggregate_priority needs GPU tensors; there is no CPU path")
+    priority = priority.contiguous().float()
+    seq_len = seq_len.contiguous().float()
+    T, B = priority.shape
+    out = torch.empty(B, dtype=torch.float32, device=priority.device)
+    _lib.check(lib.hsad_aggregate_priority(priority.data_ptr(), seq_len.data_ptr(), T, B, float(eta), out.data_ptr(),
+                                           _stream(priority.device)))
+    return out
+
+
+class DeviceReplay:
+    def __init__(self, capacity, seed, alpha, beta, prefetch, seq_len, fields, device="cuda:0"):
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HsadError("DeviceReplay needs a ROCm device; there is no CPU path")
+        self.fields = [(n, int(w), dt) for n, w, dt in fields]
+        self.T = int(seq_len)
+        self.h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.hsad_replay_create(int(capacity), int(seed), float(alpha), float(beta), int(prefetch),
+                                               self.T, len(self.fields), _fields_struct(self.fields), idx,
+                                               C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsad_replay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bytes(self):
+        return int(self.lib.hsad_replay_bytes(self.h))
+
+    def _check_field_tensors(self, tensors, lead):
+        out = []
+        for (name, w, dt), t in zip(self.fields, tensors):
+            want = torch.uint8 if dt == torch.bool else dt
+            t = t.to(want) if t.dtype != want else t
+            assert t.is_contiguous() and t.device == self.device, name
+            assert tuple(t.shape) in (tuple(lead) + (w,), tuple(lead)) or t.numel() == int(torch.tensor(lead).prod()) * w, \
+                (name, tuple(t.shape), lead, w)
+            out.append(t)
+        return out
+
+    def add(self, fields, reward, terminal, bootstrap, seq_len, priority, n_dev=None):
+        """fields: dict name -> [n, T, width]; reward/bootstrap [n,T] f32; terminal [n,T] bool/u8;
+        seq_len/priority [n] f32."""
+        n = int(priority.shape[0])
+        ts = self._check_field_tensors([fields[name] for name, _, _ in self.fields], (n, self.T))
+        terminal = terminal.to(torch.uint8).contiguous()
+        _lib.check(self.lib.hsad_replay_add(self.h, n, _ptr_array(ts), reward.contiguous().data_ptr(),
+                                            terminal.data_ptr(), bootstrap.contiguous().data_ptr(),
+                                            seq_len.contiguous().data_ptr(), priority.contiguous().data_ptr(),
+                                            None if n_dev is None else n_dev.data_ptr(), _stream(self.device)))
+
+    def sample(self, batch):
+        """-> (dict of fields [T,B,width], reward [T,B], terminal [T,B] bool, bootstrap [T,B], seq_len [B]), weight [B]"""
+        d, T = self.device, self.T
+        outs = [torch.empty(T, batch, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d)
+                for _, w, dt in self.fields]
+        reward = torch.empty(T, batch, dtype=torch.float32, device=d)
+        terminal = torch.empty(T, batch, dtype=torch.uint8, device=d)
+        bootstrap = torch.empty(T, batch, dtype=torch.float32, device=d)
+        seq_len = torch.empty(batch, dtype=torch.float32, device=d)
+        weight = torch.empty(batch, dtype=torch.float32, device=d)
+        _lib.check(self.lib.hsad_replay_sample(self.h, batch, _ptr_array(outs), reward.data_ptr(), terminal.data_ptr(),
+                                               bootstrap.data_ptr(), seq_len.data_ptr(), weight.data_ptr(),
+                                               _stream(d)))
+        fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
+        return (fields, reward, terminal.bool(), bootstrap, seq_len), weight
+
+    def update_priority(self, priority):
+        priority = priority.to(self.device, torch.float32).contiguous()
+        _lib.check(self.lib.hsad_replay_update_priority(self.h, priority.data_ptr(), int(priority.numel()),
+                                                        _stream(self.device)))
+
+    def _counts(self):
+        s, n = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.hsad_replay_size(self.h, C.byref(s), C.byref(n)))
+        return s.value, n.value
+
+    def size(self):
+        return self._counts()[0]
+
+    def num_add(self):
+        return self._counts()[1]
+
+    def get(self, idx):
+        d, T = self.device, self.T
+        outs = [torch.empty(T, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d) for _, w, dt in self.fields]
+        reward = torch.empty(T, dtype=torch.float32, device=d)
+        terminal = torch.empty(T, dtype=torch.uint8, device=d)
+        bootstrap = torch.empty(T, dtype=torch.float32, device=d)
+        seq_len = torch.empty(1, dtype=torch.float32, device=d)
+        _lib.check(self.lib.hsad_replay_get(self.h, int(idx), _ptr_array(outs), reward.data_ptr(), terminal.data_ptr(),
+                                            bootstrap.data_ptr(), seq_len.data_ptr(), _stream(d)))
+        return {name: t for (name, _, _), t in zip(self.fields, outs)}, reward, terminal.bool(), bootstrap, seq_len
+
+    def last_ids(self, batch):
+        out = torch.empty(batch, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_replay_last_ids(self.h, out.data_ptr(), batch, _stream(self.device)))
+        return out
+
+    def check_errors(self):
+        n = C.c_int32(0)
+        _lib.check(self.lib.hsad_replay_error_count(self.h, C.byref(n)))
+        if n.value:
+            raise _lib.HsadError("replay logged %d contract violation(s) (ring overflow on add, sample beyond the "
+                                 "weight sum, or update_priority without a matching sample)" % n.value)
+
+
+class SequenceWriter:
+    def __init__(self, num_envs, multi_step, gamma, seq_len, fields, device="cuda:0"):
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HsadError("SequenceWriter needs a ROCm device; there is no CPU path")
+        self.fields = [(n, int(w), dt) for n, w, dt in fields]
+        self.E, self.T = int(num_envs), int(seq_len)
+        self.h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.lib.hsad_seqwriter_create(self.E, int(multi_step), float(gamma), self.T, len(self.fields),
+                                                  _fields_struct(self.fields), idx, C.byref(self.h)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsad_seqwriter_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push_obs_action(self, fields):
+        ts = []
+        for name, w, dt in self.fields:
+            t = fields[name]
+            want = torch.uint8 if dt == torch.bool else dt
+            t = (t.to(want) if t.dtype != want else t).contiguous()
+            assert t.device == self.device and t.numel() == self.E * w, (name, tuple(t.shape))
+            ts.append(t)
+        _lib.check(self.lib.hsad_seqwriter_push_obs_action(self.h, _ptr_array(ts), _stream(self.device)))
+
+    def push_reward_terminal(self, reward, terminal):
+        reward = reward.to(torch.float32).contiguous()
+        terminal = terminal.to(torch.uint8).contiguous()
+        _lib.check(self.lib.hsad_seqwriter_push_reward_terminal(self.h, reward.data_ptr(), terminal.data_ptr(),
+                                                                _stream(self.device)))
+
+    def can_pop(self):
+        return bool(self.lib.hsad_seqwriter_can_pop(self.h))
+
+    def pop_transition(self, want_fields=True):
+        d, E = self.device, self.E
+        mk = lambda: [torch.empty(E, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d)
+                      for _, w, dt in self.fields]
+        cur = mk() if want_fields else None
+        nxt = mk() if want_fields else None
+        reward = torch.empty(E, dtype=torch.float32, device=d)
+        terminal = torch.empty(E, dtype=torch.uint8, device=d)
+        bootstrap = torch.empty(E, dtype=torch.float32, device=d)
+        _lib.check(self.lib.hsad_seqwriter_pop_transition(
+            self.h, _ptr_array(cur) if cur else None, _ptr_array(nxt) if nxt else None, reward.data_ptr(),
+            terminal.data_ptr(), bootstrap.data_ptr(), _stream(d)))
+        names = [n for n, _, _ in self.fields]
+        return (dict(zip(names, cur)) if cur else None, dict(zip(names, nxt)) if nxt else None, reward,
+                terminal.bool(), bootstrap)
+
+    def push_sequence(self, priority):
+        priority = priority.to(torch.float32).contiguous()
+        _lib.check(self.lib.hsad_seqwriter_push_sequence(self.h, priority.data_ptr(), _stream(self.device)))
+
+    def flush_to_replay(self, replay, eta):
+        n = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_seqwriter_flush_to_replay(self.h, replay.h, float(eta), n.data_ptr(),
+                                                           _stream(self.device)))
+        return n

@@ -138,6 +138,84 @@ int hsad_env_debug_timing(hsad_env* env, uint64_t* buf);
  * the last call; synchronises the device.  first_game/first_code (may be NULL) describe the first. */
 int hsad_env_error_count(hsad_env* env, int32_t* count, int32_t* first_game, int32_t* first_code);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Device-resident sequence replay and actor buffers.
+ * Replaces rela::PrioritizedReplay<RNNTransition> / ConcurrentQueue (rela/prioritized_replay.h:15-361),
+ * RNNTransition::makeBatch (rela/transition.cc:160-202), MultiStepBuffer and R2D2Buffer
+ * (rela/transition_buffer.h:8-227) and aggregatePriority (rela/r2d2_actor.h:10-21).
+ *
+ * A transition is described by n_fields per-step "fields" (the entries of the reference's obs and
+ * action TensorDicts, e.g. priv_s, legal_move, eps, own_hand, a, greedy_a); reward, terminal,
+ * bootstrap and seq_len are implicit.  All tensor arguments are device pointers.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum { HSAD_F32 = 0, HSAD_I64 = 1, HSAD_U8 = 2 } hsad_dtype;
+typedef struct hsad_field {
+  int32_t width; /* elements per step (per env)          */
+  int32_t dtype; /* hsad_dtype                            */
+} hsad_field;
+
+/* rela::aggregatePriority: priority float32 [T,B], seq_len float32 [B] -> out float32 [B]
+ * = eta * max_t(p*mask) + (1-eta) * sum_t(p*mask) / seq_len. */
+int hsad_aggregate_priority(const float* priority, const float* seq_len, int T, int B, float eta, float* out,
+                            void* stream);
+
+typedef struct hsad_replay hsad_replay;
+
+/* RNNPrioritizedReplay(capacity, seed, alpha, beta, prefetch) (rela/pybind.cc:46-58).  Storage is a ring
+ * of int(1.25*capacity) sequences of seq_len steps in HBM; prefetch is accepted for signature
+ * compatibility and ignored (sampling is a stream-ordered kernel, there is nothing to prefetch). */
+int hsad_replay_create(int capacity, int seed, float alpha, float beta, int prefetch, int seq_len, int n_fields,
+                       const hsad_field* fields, int device, hsad_replay** out);
+void hsad_replay_destroy(hsad_replay* r);
+int64_t hsad_replay_bytes(const hsad_replay* r);
+
+/* PrioritizedReplay::add(vector<RNNTransition>, priority): n sequences, fields[k] -> [n, T, width_k],
+ * reward/bootstrap float32 [n,T], terminal uint8 [n,T], seq_len/priority float32 [n].  Weight = priority^alpha.
+ * n_dev (may be NULL): device int32 holding the actual count (<= n) for sync-free producers.
+ * Unlike the reference, a full ring is an error (HSAD_ERR_STATE via hsad_replay_error_count) instead of blocking. */
+int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const float* reward, const uint8_t* terminal,
+                    const float* bootstrap, const float* seq_len, const float* priority, const int32_t* n_dev,
+                    void* stream);
+
+/* PrioritizedReplay::sample (+ makeBatch): stratified draw of `batch` sequences (duplicates possible),
+ * out_fields[k] -> [T, batch, width_k], reward/bootstrap float32 [T,batch], terminal uint8 [T,batch],
+ * seq_len float32 [batch], weight float32 [batch] = (N*w/sum)^-beta / max; evicts the oldest entries when
+ * size > capacity.  Must alternate with hsad_replay_update_priority like the reference (prioritized_replay.h:209-212). */
+int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float* reward, uint8_t* terminal,
+                       float* bootstrap, float* seq_len, float* weight, void* stream);
+int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch, void* stream);
+/* size() / numAdd(): synchronise the stream the producers used, then read the device counters. */
+int hsad_replay_size(hsad_replay* r, int32_t* size, int32_t* num_add);
+/* get(idx): element idx counted from the ring head; out_fields[k] -> [T, width_k] */
+int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* reward, uint8_t* terminal,
+                    float* bootstrap, float* seq_len, void* stream);
+/* physical ring slots of the last sample (device int32 [batch]); debugging / tests */
+int hsad_replay_last_ids(hsad_replay* r, int32_t* out, int batch, void* stream);
+int hsad_replay_error_count(hsad_replay* r, int32_t* count);
+
+typedef struct hsad_seqwriter hsad_seqwriter;
+
+/* MultiStepBuffer(multi_step, num_envs, gamma) + R2D2Buffer(num_envs, ., multi_step, seq_len) for one actor. */
+int hsad_seqwriter_create(int num_envs, int multi_step, float gamma, int seq_len, int n_fields,
+                          const hsad_field* fields, int device, hsad_seqwriter** out);
+void hsad_seqwriter_destroy(hsad_seqwriter* w);
+/* MultiStepBuffer::pushObsAndAction: fields[k] -> [E, width_k] of the current step */
+int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields, void* stream);
+/* MultiStepBuffer::pushRewardAndTerminal: reward float32 [E], terminal uint8 [E] */
+int hsad_seqwriter_push_reward_terminal(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, void* stream);
+/* MultiStepBuffer::canPop (host-side count, no synchronisation) */
+int hsad_seqwriter_can_pop(const hsad_seqwriter* w);
+/* MultiStepBuffer::popTransition: n-step return / bootstrap / terminal of the oldest step -> float32/uint8 [E];
+ * out_fields / out_next_fields (either may be NULL): obs+action of that step and obs of step +n, [E, width_k]. */
+int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, void* const* out_next_fields,
+                                  float* reward, uint8_t* terminal, float* bootstrap, void* stream);
+/* R2D2Buffer::push of the transition just popped, with its per-env priority float32 [E]; pads finished sequences. */
+int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream);
+/* R2D2Buffer::popTransition + aggregatePriority + PrioritizedReplay::add for every finished env (ascending env
+ * order), entirely on the device; n_finished_dev (may be NULL) receives the count. */
+int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta, int32_t* n_finished_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
