@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip")]
 _lib = None
 
 
@@ -75,6 +75,13 @@ SIGNATURES = {
     "hsad_seqwriter_pop_transition": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P]),
     "hsad_seqwriter_push_sequence": (C.c_int, [_P, _P, _P]),
     "hsad_seqwriter_flush_to_replay": (C.c_int, [_P, _P, C.c_float, _P, _P]),
+    "hsad_gemm_nt_bf16": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
+                                    C.c_int, C.c_int, _P]),
+    "hsad_cast_pad_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "hsad_transpose_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "hsad_lstm_layer_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "hsad_td_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
 }
 
 

@@ -1,0 +1,536 @@
+// hsad_r2d2.hip — hand-written CDNA4 kernels for the R2D2 recurrent Q-network (forward part).
+// Implements hsad_gemm_nt_bf16, hsad_cast_pad_bf16, hsad_transpose_bf16, hsad_lstm_layer_forward,
+// hsad_q_head and hsad_td_loss of include/hsad.h.
+//
+// Reference math (PyTorch eager / cuDNN on the reference's GPU): R2D2Net (pyhanabi/r2d2.py:13-157) =
+// Linear+ReLU -> 2-layer LSTM(512) -> dueling heads, and R2D2Agent.td_error / loss (:383-499).
+//
+// MI355X mapping
+//  * Every contraction runs on the matrix cores: bf16 operands, fp32 accumulation
+//    (v_mfma_f32_32x32x16_bf16), operands staged through LDS in 16-byte units with a padded row stride
+//    that keeps ds_read_b128 conflict-free, next tile prefetched into registers while the current one is
+//    multiplied.  Master weights, gate pre-activations, cell state and all loss arithmetic stay fp32.
+//  * Weights use nn.Linear's [N, K] layout, so y = x W^T is an "NT" product with both operands
+//    K-contiguous — the layout MFMA fragments want.  Backward products are brought to NT form with
+//    explicit (cheap, HBM-bound) transposes instead of slower transposed-operand GEMMs.
+//  * The LSTM recurrence h_{t-1} W_hh^T is fused with the whole cell update in one kernel per time step.
+//    W_hh / W_ih rows are permuted once per weight update into blocks of [i|f|g|o] x 32 hidden units, so the
+//    four MFMA accumulators of a lane hold the four gates of the SAME (row, unit) and the cell update is
+//    pure per-lane fp32 math in the epilogue (no shuffles, no extra pass over HBM).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "hsad.h"
+
+extern "C" int hsad_internal_set_error(int code, const char* msg);
+
+namespace {
+
+int nfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return hsad_internal_set_error(code, buf);
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return nfail(HSAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+typedef unsigned short bf16_t;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+constexpr int kBK = 32;            // K per LDS tile
+constexpr int kLdsStride = 40;     // bf16 elements per LDS row: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+
+// A-operand / B-operand fragment of v_mfma_f32_32x32x16_bf16 from an LDS tile stored [rows][kLdsStride]:
+// lane l holds row (l & 31), k = 8*(l >> 5) .. +7 of the 16-wide k block kk.
+__device__ __forceinline__ bf16x8 lds_frag(const bf16_t* tile, int row0, int kk, int lane) {
+  const bf16_t* p = tile + (row0 + (lane & 31)) * kLdsStride + kk * 16 + (lane >> 5) * 8;
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (ReLU) ; A,B bf16 row-major (lda/ldb in elements, multiples of 8;
+// K multiple of 32, buffers zero-padded by the caller).  Block = 256 threads = 4 waves in a 2x2 grid, each
+// wave owning a (BM/2)x(BN/2) sub-tile made of 32x32 MFMA tiles.
+// ---------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* B;
+  const float* bias;
+  float* C32;     // optional fp32 output [M, ldc]
+  bf16_t* C16;    // optional bf16 output [M, ldc16]
+  int M, N, K, lda, ldb, ldc, ldc16;
+  int relu, accumulate;  // accumulate: C32 += result
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
+  constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
+  __shared__ __attribute__((aligned(16))) bf16_t sA[BM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) bf16_t sB[BN * kLdsStride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // global -> register staging: each thread moves 16 B (8 bf16); a tile row is 4 such chunks
+  constexpr int A_ITERS = BM * 4 / 256, B_ITERS = BN * 4 / 256;
+  uint4 ra[A_ITERS], rb[B_ITERS];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int gr = m0 + r;
+      ra[it] = (gr < g.M) ? *reinterpret_cast<const uint4*>(g.A + (size_t)gr * g.lda + k0 + q * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int gr = n0 + r;
+      rb[it] = (gr < g.N) ? *reinterpret_cast<const uint4*>(g.B + (size_t)gr * g.ldb + k0 + q * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_ITERS; ++it) {
+      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      *reinterpret_cast<uint4*>(sA + r * kLdsStride + q * 8) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < B_ITERS; ++it) {
+      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      *reinterpret_cast<uint4*>(sB + r * kLdsStride + q * 8) = rb[it];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / kBK;
+  load_tile(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile((kt + 1) * kBK);  // in flight while this tile is multiplied
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = lds_frag(sA, wm * WM + i * 32, kk, lane);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = lds_frag(sB, wn * WN + j * 32, kk, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + (lane & 31);
+      const float b = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r] + b;
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (g.C32) {
+            float* p = g.C32 + (size_t)row * g.ldc + col;
+            *p = g.accumulate ? (*p + v) : v;
+          }
+          if (g.C16) g.C16[(size_t)row * g.ldc16 + col] = f2bf(v);
+        }
+      }
+    }
+}
+
+// fp32 [M, K] -> bf16 [M, Kp] zero padded (Kp >= K)
+__global__ void cast_pad_bf16_kernel(const float* __restrict__ src, int M, int K, int lds, bf16_t* __restrict__ dst,
+                                     int Kp) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * Kp) return;
+  const int r = (int)(idx / Kp), c = (int)(idx - (size_t)r * Kp);
+  dst[idx] = c < K ? f2bf(src[(size_t)r * lds + c]) : (bf16_t)0;
+}
+
+// bf16 [R, C] (ld = lds) -> [C, R] (ld = ldd), 32x32 tiles through LDS
+__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int C, int lds, bf16_t* __restrict__ dst,
+                                      int ldd) {
+  __shared__ bf16_t tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused LSTM step: gates = gx (+ bias already folded in) + h_prev W_hh^T ; cell update in the epilogue.
+// Column layout ("gate-blocked"): for hidden-unit block nb (32 units) the 128 columns nb*128 + g*32 + u are
+// gate g in {i,f,g,o} of unit nb*32+u.  gx / W_hh rows are given in that layout.
+// Block = BM rows x 128 columns; each of the 4 waves handles BM/4 rows (BM = 128) or a quarter of K (BM = 32).
+// ---------------------------------------------------------------------------------------------------
+struct LstmStepArgs {
+  const bf16_t* h_prev;  // [Bn, H] bf16 (ld = H)
+  const bf16_t* Whh;     // [4H, H] bf16, gate-blocked rows
+  float* gates;          // [Bn, 4H] fp32: in = x-projection (+bias), out = activated gates i,f,g,o (for backward)
+  const float* c_prev;   // [Bn, H]
+  float* c_out;          // [Bn, H]
+  bf16_t* h_out16;       // [Bn, H]
+  float* h_out32;        // optional [Bn, H]
+  int Bn, H;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+template <int BM>
+__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
+  // BM == 128: wave w owns rows [32w, 32w+32) of the block, full K.   (big batches: actors)
+  // BM == 32 : all waves share the 32 rows, wave w reduces K-quarter w; partial sums meet in LDS. (learner, B=128)
+  __shared__ __attribute__((aligned(16))) bf16_t sA[BM * kLdsStride];
+  __shared__ __attribute__((aligned(16))) bf16_t sB[128 * kLdsStride];
+  __shared__ float sRed[BM == 32 ? 3 * 4 * 16 * 64 : 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, nb = blockIdx.x;  // nb: block of 32 hidden units
+  const int H = a.H;
+  constexpr int A_ITERS = (BM * 4 + 255) / 256;
+  uint4 ra[A_ITERS], rb[2];
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  if (BM == 128) {
+    auto load_tile = [&](int k0) {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        const int gr = m0 + r;
+        ra[it] = (gr < a.Bn) ? *reinterpret_cast<const uint4*>(a.h_prev + (size_t)gr * H + k0 + q * 8) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        rb[it] = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + k0 + q * 8);
+      }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+      for (int it = 0; it < A_ITERS; ++it) {
+        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        *reinterpret_cast<uint4*>(sA + r * kLdsStride + q * 8) = ra[it];
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        *reinterpret_cast<uint4*>(sB + r * kLdsStride + q * 8) = rb[it];
+      }
+    };
+    const int nk = H / kBK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      store_tile();
+      __syncthreads();
+      if (kt + 1 < nk) load_tile((kt + 1) * kBK);
+#pragma unroll
+      for (int kk = 0; kk < kBK / 16; ++kk) {
+        const bf16x8 fa = lds_frag(sA, wave * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, lds_frag(sB, j * 32, kk, lane), acc[j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  } else {
+    // BM == 32: operands are read straight from global/L2 (h_prev is 32 x H, the W slice 128 x H); wave w
+    // multiplies k in [w*H/4, (w+1)*H/4)
+    const int kq = H / 4;
+    for (int k0 = wave * kq; k0 < (wave + 1) * kq; k0 += 16) {
+      const int row = m0 + (lane & 31);
+      bf16x8 fa;
+      if (row < a.Bn) {
+        fa = *reinterpret_cast<const bf16x8*>(a.h_prev + (size_t)row * H + k0 + (lane >> 5) * 8);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[e] = (__bf16)0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(a.Whh + (size_t)(nb * 128 + j * 32 + (lane & 31)) * H + k0 + (lane >> 5) * 8);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+      }
+    }
+    // reduce the four K-quarters into wave 0
+    if (wave > 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sRed[(((wave - 1) * 4 + j) * 16 + r) * 64 + lane] = acc[j][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += sRed[((w * 4 + j) * 16 + r) * 64 + lane];
+  }
+
+  // epilogue: this lane holds gates i,f,g,o (acc[0..3]) of unit u for 16 rows
+  const int u = nb * 32 + (lane & 31);
+  const int rbase = m0 + (BM == 128 ? wave * 32 : 0) + 4 * (lane >> 5);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    if (row >= a.Bn) continue;
+    float* gp = a.gates + (size_t)row * 4 * H + (size_t)nb * 128 + (lane & 31);
+    const float gi = sigmoidf_(acc[0][r] + gp[0]);
+    const float gf = sigmoidf_(acc[1][r] + gp[32]);
+    const float gg = tanhf(acc[2][r] + gp[64]);
+    const float go = sigmoidf_(acc[3][r] + gp[96]);
+    const float c = gf * a.c_prev[(size_t)row * H + u] + gi * gg;
+    const float h = go * tanhf(c);
+    gp[0] = gi;
+    gp[32] = gf;
+    gp[64] = gg;
+    gp[96] = go;
+    a.c_out[(size_t)row * H + u] = c;
+    a.h_out16[(size_t)row * H + u] = f2bf(h);
+    if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Dueling head + masked argmax (R2D2Net.forward tail, r2d2.py:106-115; _duel :124-131).
+// heads fp32 [M, ldh]: columns [0, A) = advantage, column A = value.  legal fp32 [M, A].
+// pass 1: q = v + a*legal - mean_A(a*legal), qa = q[action], per-block min(q);  pass 2: greedy with the GLOBAL min.
+// ---------------------------------------------------------------------------------------------------
+__global__ void q_head_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
+                              const int64_t* __restrict__ action, int M, int A, float* __restrict__ q,
+                              float* __restrict__ qa, float* __restrict__ block_min) {
+  __shared__ float smin[256];
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  float mn = 3.4e38f;
+  if (m < M) {
+    const float* h = heads + (size_t)m * ldh;
+    const float* lg = legal + (size_t)m * A;
+    const float v = h[A];
+    float mean = 0.f;
+    for (int j = 0; j < A; ++j) mean += h[j] * lg[j];
+    mean /= (float)A;
+    const int act = action ? (int)action[m] : 0;
+    for (int j = 0; j < A; ++j) {
+      const float qq = v + h[j] * lg[j] - mean;
+      q[(size_t)m * A + j] = qq;
+      mn = fminf(mn, qq);
+      if (action && j == act) qa[m] = qq;
+    }
+  }
+  smin[threadIdx.x] = mn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_min[blockIdx.x] = smin[0];
+}
+
+__global__ void min_reduce_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float s[256];
+  float m = 3.4e38f;
+  for (int i = threadIdx.x; i < n; i += 256) m = fminf(m, v[i]);
+  s[threadIdx.x] = m;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) s[threadIdx.x] = fminf(s[threadIdx.x], s[threadIdx.x + k]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// greedy = argmax_j (1 + q - qmin) * legal (first maximal index, like torch.argmax on CPU);
+// optionally gathers q at the greedy action (target-net pass of double DQN)
+__global__ void greedy_kernel(const float* __restrict__ q, const float* __restrict__ legal, const float* __restrict__ qmin,
+                              int M, int A, int64_t* __restrict__ greedy) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const float mn = qmin[0];
+  float best = -3.4e38f;
+  int bi = 0;
+  for (int j = 0; j < A; ++j) {
+    const float s = (1.f + q[(size_t)m * A + j] - mn) * legal[(size_t)m * A + j];
+    if (s > best) {
+      best = s;
+      bi = j;
+    }
+  }
+  greedy[m] = bi;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// n-step double-DQN TD error, Huber loss and priorities (R2D2Agent.td_error / loss, r2d2.py:403-428,472-478).
+// online_qa, target_qa [T,B]; target is shifted by n steps and zero for the last n.
+// ---------------------------------------------------------------------------------------------------
+__global__ void td_loss_kernel(const float* __restrict__ online_qa, const float* __restrict__ target_qa,
+                               const float* __restrict__ reward, const float* __restrict__ bootstrap,
+                               const float* __restrict__ seq_len, int T, int B, int n, float gamma_n,
+                               float* __restrict__ err, float* __restrict__ priority, float* __restrict__ loss,
+                               float* __restrict__ dqa, const float* __restrict__ weight) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float len = seq_len[b];
+  float sum = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float tq = (t + n < T) ? target_qa[(size_t)(t + n) * B + b] : 0.f;
+    const float target = reward[(size_t)t * B + b] + bootstrap[(size_t)t * B + b] * gamma_n * tq;
+    const float mask = (float)t < len ? 1.f : 0.f;
+    const float e = (target - online_qa[(size_t)t * B + b]) * mask;
+    const float ae = fabsf(e);
+    err[(size_t)t * B + b] = e;
+    priority[(size_t)t * B + b] = ae;
+    sum += ae < 1.f ? 0.5f * e * e : ae - 0.5f;  // smooth_l1(err, 0), beta = 1
+    if (dqa) {
+      // d/d(online_qa) of mean_b(weight_b * sum_t huber(err)) : -clamp(e,-1,1) * mask * weight / B
+      const float g = fminf(fmaxf(e, -1.f), 1.f);
+      dqa[(size_t)t * B + b] = -g * mask * (weight ? weight[b] : 1.f) / (float)B;
+    }
+  }
+  loss[b] = sum;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                      float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream) {
+  if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
+  if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 32 and lda/ldb of 8");
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate};
+  hipStream_t s = (hipStream_t)stream;
+  if (N <= 64) {
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((N + 63) / 64, (M + 127) / 128), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, s, g);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream) {
+  if (!src || !dst || Kp < K) return nfail(HSAD_ERR_INVALID, "cast_pad: bad arguments");
+  const size_t n = (size_t)M * Kp;
+  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, M, K,
+                     ld_src, (bf16_t*)dst, Kp);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, void* stream) {
+  if (!src || !dst) return nfail(HSAD_ERR_INVALID, "transpose: null");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, R, C, ld_src, (bf16_t*)dst, ld_dst);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
+                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT, void* stream) {
+  if (!gates || !Whh_blocked || !c0 || !hseq16 || !cseq || !h0_16_scratch)
+    return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: null argument");
+  if (H % 64 || T < 1 || Bn < 1) return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: H must be a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  // h0 -> bf16
+  if (h0) {
+    const size_t n = (size_t)Bn * H;
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h0, Bn, H, H,
+                       (bf16_t*)h0_16_scratch, H);
+  } else {
+    HIP_TRY(hipMemsetAsync(h0_16_scratch, 0, (size_t)Bn * H * 2, s));
+  }
+  for (int t = 0; t < T; ++t) {
+    LstmStepArgs a;
+    a.h_prev = t == 0 ? (const bf16_t*)h0_16_scratch : (const bf16_t*)hseq16 + (size_t)(t - 1) * Bn * H;
+    a.Whh = (const bf16_t*)Whh_blocked;
+    a.gates = gates + (size_t)t * Bn * 4 * H;
+    a.c_prev = t == 0 ? c0 : cseq + (size_t)(t - 1) * Bn * H;
+    a.c_out = cseq + (size_t)t * Bn * H;
+    a.h_out16 = (bf16_t*)hseq16 + (size_t)t * Bn * H;
+    a.h_out32 = (t == T - 1) ? hT : nullptr;
+    a.Bn = Bn;
+    a.H = H;
+    if (Bn >= 1024)
+      hipLaunchKernelGGL(lstm_step_kernel<128>, dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(lstm_step_kernel<32>, dim3(H / 32, (Bn + 31) / 32), dim3(256), 0, s, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_q_head(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* q,
+                float* qa, int64_t* greedy, float* scratch, void* stream) {
+  if (!heads || !legal || !q || !scratch) return nfail(HSAD_ERR_INVALID, "q_head: null argument");
+  if (action && !qa) return nfail(HSAD_ERR_INVALID, "q_head: qa output required with actions");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (M + 255) / 256;
+  hipLaunchKernelGGL(q_head_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, legal, action, M, A, q, qa, scratch + 1);
+  hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
+  if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3(nb), dim3(256), 0, s, q, legal, scratch, M, A, greedy);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_td_loss(const float* online_qa, const float* target_qa, const float* reward, const float* bootstrap,
+                 const float* seq_len, int T, int B, int multi_step, double gamma, float* err, float* priority,
+                 float* loss, float* dqa, const float* weight, void* stream) {
+  if (!online_qa || !target_qa || !reward || !bootstrap || !seq_len || !err || !priority || !loss)
+    return nfail(HSAD_ERR_INVALID, "td_loss: null argument");
+  float gamma_n = 1.f;
+  {
+    double g = 1.0;  // python: gamma ** multi_step in double, then a float32 tensor multiply
+    for (int i = 0; i < multi_step; ++i) g *= gamma;
+    gamma_n = (float)g;
+  }
+  hipLaunchKernelGGL(td_loss_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, online_qa, target_qa,
+                     reward, bootstrap, seq_len, T, B, multi_step, gamma_n, err, priority, loss, dqa, weight);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+}  // extern "C"

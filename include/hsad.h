@@ -216,6 +216,37 @@ int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void*
  * order), entirely on the device; n_finished_dev (may be NULL) receives the count. */
 int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta, int32_t* n_finished_dev, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * R2D2 recurrent Q-network kernels (bf16 MFMA operands, fp32 accumulation / state / loss).
+ * Replace what the reference gets from PyTorch + cuDNN for R2D2Net / R2D2Agent
+ * (pyhanabi/r2d2.py:13-157, 383-499).  All pointers are device pointers; bf16 buffers are raw uint16.
+ * ------------------------------------------------------------------------------------------ */
+/* C[M,N] = A[M,K] * B[N,K]^T (+bias[N]) (ReLU): A,B bf16 row-major (lda/ldb multiples of 8, K multiple of 32,
+ * zero padded), outputs fp32 C32 (optionally accumulated into) and/or bf16 C16.  nn.Linear forward. */
+int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                      float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream);
+/* fp32 [M,K] (row stride ld_src) -> bf16 [M,Kp] zero padded */
+int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream);
+/* bf16 [R,C] -> [C,R] */
+int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, void* stream);
+/* One LSTM layer over T steps (nn.LSTM semantics, gate order i,f,g,o).  gates fp32 [T,Bn,4H] holds the input
+ * projection x W_ih^T + b_ih + b_hh on entry and the activated gates on exit, both in the gate-blocked column
+ * layout (block nb of 32 units: columns nb*128 + gate*32 + u); Whh_blocked bf16 [4H,H] has its rows in the same
+ * order.  h0/c0 fp32 [Bn,H] (h0 NULL = zeros).  Outputs hseq16 bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]
+ * (optional).  h0_16_scratch: bf16 [Bn,H]. */
+int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
+                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT, void* stream);
+/* Dueling head + masked argmax (r2d2.py:106-131): heads fp32 [M,ldh] = [advantage(A) | value(1) | ...],
+ * legal fp32 [M,A], action int64 [M] (may be NULL) -> q [M,A], qa [M], greedy int64 [M] (may be NULL).
+ * scratch: fp32 [2 + ceil(M/256)]. */
+int hsad_q_head(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* q,
+                float* qa, int64_t* greedy, float* scratch, void* stream);
+/* n-step double-DQN TD error, Huber loss, priorities (r2d2.py:403-428,472-478); all [T,B] fp32 except
+ * seq_len/loss/weight [B].  dqa (may be NULL) receives d mean_b(weight_b*loss_b) / d online_qa. */
+int hsad_td_loss(const float* online_qa, const float* target_qa, const float* reward, const float* bootstrap,
+                 const float* seq_len, int T, int B, int multi_step, double gamma, float* err, float* priority,
+                 float* loss, float* dqa, const float* weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

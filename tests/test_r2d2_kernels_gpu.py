@@ -1,0 +1,141 @@
+"""GPU tests of the hand-written R2D2 network kernels.
+
+Two kinds of reference: (1) a torch computation that rounds operands to bf16 at exactly the points the kernels
+do (tight tolerance: checks MFMA fragment layouts, tiling, epilogues); (2) the fp32 restatement pinned by the
+reference's golden vectors (bf16 tolerance, stated per quantity)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import r2d2_torch_ref as ref
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 96), (1024, 512, 864), (257, 37, 512), (10240, 2048, 512)])
+def test_gemm_nt_bf16(M, N, K):
+    from hanabi_sad_amd.r2d2 import gemm_nt
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    B = torch.randn(N, K, generator=g).to(DEV)   # asymmetric, non-identity: catches transposed C layouts
+    bias = torch.randn(N, generator=g).to(DEV)
+    A16, B16 = A.to(torch.bfloat16), B.to(torch.bfloat16)
+    want = A16.float() @ B16.float().t() + bias
+    out32 = torch.zeros(M, N, device=DEV)
+    out16 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    gemm_nt(A16, B16, M, N, K, bias=bias, out32=out32, out16=out16)
+    assert torch.allclose(out32, want, rtol=1e-3, atol=1e-3 * K ** 0.5)
+    assert torch.allclose(out16.float(), want, rtol=1e-2, atol=0.1)
+    relu = torch.zeros(M, N, device=DEV)
+    gemm_nt(A16, B16, M, N, K, bias=bias, out32=relu, relu=True)
+    assert torch.allclose(relu, want.clamp(min=0), rtol=1e-3, atol=1e-3 * K ** 0.5)
+    gemm_nt(A16, B16, M, N, K, out32=relu, accumulate=True)
+    assert torch.allclose(relu, want.clamp(min=0) + want - bias, rtol=1e-3, atol=2e-3 * K ** 0.5)
+
+
+def test_cast_and_transpose():
+    from hanabi_sad_amd.r2d2 import cast_pad_bf16, transpose_bf16
+    x = torch.randn(77, 838, device=DEV)
+    y = cast_pad_bf16(x, 864)
+    assert torch.equal(y[:, :838], x.to(torch.bfloat16)) and (y[:, 838:] == 0).all()
+    assert torch.equal(transpose_bf16(y), y.t().contiguous())
+
+
+@pytest.mark.parametrize("T,Bn,H", [(5, 128, 512), (3, 40, 64), (2, 1500, 256)])
+def test_lstm_layer_forward_matches_bf16_emulated_torch(T, Bn, H):
+    from hanabi_sad_amd.r2d2 import gate_block_perm, lstm_layer_forward
+    g = torch.Generator(device="cpu").manual_seed(T * 7 + H)
+    Whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV)
+    gx = torch.randn(T, Bn, 4 * H, generator=g).to(DEV)          # x W_ih^T + biases, original gate order
+    h0 = (torch.randn(Bn, H, generator=g) * 0.5).to(DEV)
+    c0 = (torch.randn(Bn, H, generator=g) * 0.5).to(DEV)
+    perm = gate_block_perm(H, DEV)
+    gates = gx[:, :, perm].contiguous()
+    hseq, cseq, hT = lstm_layer_forward(gates, Whh[perm].to(torch.bfloat16).contiguous(), h0, c0)
+    # reference with the same rounding points: h fed back as bf16, weights bf16, everything else fp32
+    h, c = bf(h0), c0
+    W = bf(Whh)
+    for t in range(T):
+        pre = gx[t] + h @ W.t()
+        i, f, gg, o = pre.chunk(4, 1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        hf = torch.sigmoid(o) * torch.tanh(c)
+        assert torch.allclose(cseq[t], c, rtol=2e-3, atol=2e-3), t
+        assert torch.allclose(hseq[t].float(), hf, rtol=1e-2, atol=1e-2), t
+        act = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], 1)[:, perm]
+        assert torch.allclose(gates[t], act, rtol=2e-3, atol=2e-3), t
+        h = hseq[t].float()      # continue from the kernel's bf16 state so the per-step check stays tight
+        c = cseq[t]
+    assert torch.allclose(hT, hf, rtol=2e-3, atol=2e-3)
+
+
+def test_forward_td_loss_against_golden_weights():
+    """Whole forward + TD/Huber/priority with the reference's (small) golden weights and batch."""
+    from hanabi_sad_amd.r2d2 import R2D2NetKernels, td_loss
+    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
+    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
+    t = lambda k: torch.tensor(z[k]).to(DEV)
+    priv, legal, a = t("loss.priv_s"), t("loss.legal_move"), t("loss.a")
+    online, target = R2D2NetKernels(Won, DEV), R2D2NetKernels(Wtg, DEV)
+    qa, greedy, q, o = online.forward(priv, legal, a)
+    # fp32 reference of the same nets
+    Wd = {k: v.to(DEV) for k, v in Won.items()}
+    T, B = a.shape
+    h0 = torch.zeros(2, B, online.H, device=DEV)
+    rqa, rgreedy, rq, ro = ref.net_forward(Wd, priv, legal, a, h0, h0.clone())
+    assert torch.allclose(q, rq, atol=2e-2, rtol=2e-2), (q - rq).abs().max()
+    assert torch.allclose(qa, rqa, atol=2e-2, rtol=2e-2)
+    assert torch.allclose(o.float(), ro, atol=2e-2, rtol=2e-2)
+    # greedy actions may only differ where the top-2 legal q are within the bf16 tolerance
+    diff = greedy != rgreedy
+    if diff.any():
+        top2 = ((1 + rq - rq.min()) * legal).topk(2, dim=2).values
+        assert ((top2[..., 0] - top2[..., 1])[diff] < 5e-2).all()
+    tqa, _, _, _ = target.forward(priv, legal, rgreedy)
+    err, prio, loss, dqa = td_loss(qa, tqa, t("loss.reward"), t("loss.bootstrap"), t("loss.seq_len"), int(z["meta"][8]),
+                                   float(z["gamma"][0]), weight=t("loss.weight"), want_grad=True)
+    assert np.allclose(prio.cpu().numpy(), z["loss.rl.priority"], atol=4e-2, rtol=4e-2)
+    assert np.allclose(loss.cpu().numpy(), z["loss.rl.loss"], atol=6e-2, rtol=6e-2)
+    # the TD kernel itself is exact fp32 arithmetic: feed it the reference's q-values
+    Wt = {k: v.to(DEV) for k, v in Wtg.items()}
+    rtqa, _, _, _ = ref.net_forward(Wt, priv, legal, rgreedy, h0, h0.clone())
+    err2, prio2, loss2, _ = td_loss(rqa.contiguous(), rtqa.contiguous(), t("loss.reward"), t("loss.bootstrap"),
+                                    t("loss.seq_len"), int(z["meta"][8]), float(z["gamma"][0]))
+    assert np.allclose(prio2.cpu().numpy(), z["loss.rl.priority"], atol=2e-5, rtol=2e-5)
+    assert np.allclose(loss2.cpu().numpy(), z["loss.rl.loss"], atol=2e-5, rtol=2e-5)
+
+
+def test_forward_full_size_against_fp32_restatement():
+    """BASELINE configs[2] shapes: F=838, H=512, A=21, T=80, B=128, random-init nets."""
+    from hanabi_sad_amd.r2d2 import R2D2NetKernels
+    torch.manual_seed(0)
+    F, H, A, T, B = 838, 512, 21, 80, 128
+    lin = lambda o, i: (torch.rand(o, i) * 2 - 1) / i ** 0.5
+    W = {"net.0.weight": lin(H, F), "net.0.bias": lin(H, 1).squeeze(1) * 0.1, "fc_v.weight": lin(1, H),
+         "fc_v.bias": torch.zeros(1), "fc_a.weight": lin(A, H), "fc_a.bias": torch.zeros(A) + 0.01,
+         "pred.weight": lin(15, H), "pred.bias": torch.zeros(15)}
+    for l in range(2):
+        W["lstm.weight_ih_l%d" % l] = lin(4 * H, H)
+        W["lstm.weight_hh_l%d" % l] = lin(4 * H, H)
+        W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1)
+        W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
+    priv = (torch.rand(T, B, F) < 0.15).float().to(DEV)
+    legal = (torch.rand(T, B, A) < 0.4).float()
+    legal[..., 0] = 1
+    legal = legal.to(DEV)
+    a = torch.zeros(T, B, dtype=torch.int64, device=DEV)
+    net = R2D2NetKernels(W, DEV)
+    qa, greedy, q, o = net.forward(priv, legal, a)
+    Wd = {k: v.to(DEV) for k, v in W.items()}
+    h0 = torch.zeros(2, B, H, device=DEV)
+    rqa, rgreedy, rq, ro = ref.net_forward(Wd, priv, legal, a, h0, h0.clone())
+    assert torch.allclose(q, rq, atol=3e-2, rtol=3e-2), (q - rq).abs().max()
+    assert (greedy == rgreedy).float().mean() > 0.97
