@@ -81,6 +81,15 @@ SIGNATURES = {
     "hsad_transpose_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "hsad_lstm_layer_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "hsad_gemm_nt_bf16_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "hsad_lstm_layer_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_heads_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,
+                                      C.c_int, _P]),
+    "hsad_aux_xent": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "hsad_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "hsad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int, _P, _P]),
     "hsad_td_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
 }
 

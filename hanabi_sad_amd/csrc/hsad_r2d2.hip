@@ -19,6 +19,7 @@
 //    pure per-lane fp32 math in the epilogue (no shuffles, no extra pass over HBM).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -78,6 +79,9 @@ struct GemmArgs {
   bf16_t* C16;    // optional bf16 output [M, ldc16]
   int M, N, K, lda, ldb, ldc, ldc16;
   int relu, accumulate;  // accumulate: C32 += result
+  int k_chunk;           // split-K: block z multiplies k in [z*k_chunk, (z+1)*k_chunk) and atomically adds to C32
+  const bf16_t* mask16;  // optional [M, ldmask]: output is zeroed where mask <= 0 (ReLU backward)
+  int ldmask;
 };
 
 template <int BM, int BN>
@@ -128,12 +132,14 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / kBK;
-  load_tile(0);
+  const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
+  const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
+  const int nk = (kend - kbeg) / kBK;
+  load_tile(kbeg);
   for (int kt = 0; kt < nk; ++kt) {
     store_tile();
     __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * kBK);  // in flight while this tile is multiplied
+    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * kBK);  // in flight while this tile is multiplied
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 fa[TM], fb[TN];
@@ -160,11 +166,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < g.M && col < g.N) {
-          float v = acc[i][j][r] + b;
+          float v = acc[i][j][r] + ((g.k_chunk && blockIdx.z) ? 0.f : b);
           if (g.relu) v = fmaxf(v, 0.f);
+          if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col]) > 0.f)) v = 0.f;
           if (g.C32) {
             float* p = g.C32 + (size_t)row * g.ldc + col;
-            *p = g.accumulate ? (*p + v) : v;
+            if (g.k_chunk)
+              atomicAdd(p, v);
+            else
+              *p = g.accumulate ? (*p + v) : v;
           }
           if (g.C16) g.C16[(size_t)row * g.ldc16 + col] = f2bf(v);
         }
@@ -216,7 +226,7 @@ struct LstmStepArgs {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <int BM>
+template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
   // BM == 128: wave w owns rows [32w, 32w+32) of the block, full K.   (big batches: actors)
   // BM == 32 : all waves share the 32 rows, wave w reduces K-quarter w; partial sums meet in LDS. (learner, B=128)
@@ -275,24 +285,29 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
       __syncthreads();
     }
   } else {
-    // BM == 32: operands are read straight from global/L2 (h_prev is 32 x H, the W slice 128 x H); wave w
-    // multiplies k in [w*H/4, (w+1)*H/4)
-    const int kq = H / 4;
-    for (int k0 = wave * kq; k0 < (wave + 1) * kq; k0 += 16) {
-      const int row = m0 + (lane & 31);
-      bf16x8 fa;
+    // BM == 32: operands come straight from L2 (h_prev is 32 x H, the W slice 128 x H); wave w multiplies
+    // k in [w*H/4, (w+1)*H/4) = KIT blocks of 16.  Every fragment load is issued before the first MFMA.
+    const int kbase = wave * (KIT * 16);
+    const int row = m0 + (lane & 31);
+    bf16x8 fa[KIT], fb[4][KIT];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
       if (row < a.Bn) {
-        fa = *reinterpret_cast<const bf16x8*>(a.h_prev + (size_t)row * H + k0 + (lane >> 5) * 8);
+        fa[it] = *reinterpret_cast<const bf16x8*>(a.h_prev + (size_t)row * H + kbase + it * 16 + (lane >> 5) * 8);
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fa[e] = (__bf16)0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(a.Whh + (size_t)(nb * 128 + j * 32 + (lane & 31)) * H + k0 + (lane >> 5) * 8);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[j], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) fa[it][e] = (__bf16)0.f;
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int it = 0; it < KIT; ++it)
+        fb[j][it] = *reinterpret_cast<const bf16x8*>(a.Whh + (size_t)(nb * 128 + j * 32 + (lane & 31)) * H + kbase + it * 16 + (lane >> 5) * 8);
+#pragma unroll
+    for (int it = 0; it < KIT; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it], fb[j][it], acc[j], 0, 0, 0);
     // reduce the four K-quarters into wave 0
     if (wave > 0) {
 #pragma unroll
@@ -310,19 +325,112 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
         for (int r = 0; r < 16; ++r) acc[j][r] += sRed[((w * 4 + j) * 16 + r) * 64 + lane];
   }
 
-  // epilogue: this lane holds gates i,f,g,o (acc[0..3]) of unit u for 16 rows
+  // epilogue: this lane holds gates i,f,g,o (acc[0..3]) of unit u for 16 rows.  All loads are issued first
+  // (one HBM round trip instead of sixteen dependent ones), then the fp32 cell math, then the stores.
   const int u = nb * 32 + (lane & 31);
   const int rbase = m0 + (BM == 128 ? wave * 32 : 0) + 4 * (lane >> 5);
+  float* __restrict__ gates = a.gates;
+  const float* __restrict__ c_prev = a.c_prev;
+  float pre[16][4], cp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = min(rbase + (r & 3) + 8 * (r >> 2), a.Bn - 1);
+    const float* gp = gates + (size_t)row * 4 * H + (size_t)nb * 128 + (lane & 31);
+    pre[r][0] = gp[0];
+    pre[r][1] = gp[32];
+    pre[r][2] = gp[64];
+    pre[r][3] = gp[96];
+    cp[r] = c_prev[(size_t)row * H + u];
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = rbase + (r & 3) + 8 * (r >> 2);
     if (row >= a.Bn) continue;
-    float* gp = a.gates + (size_t)row * 4 * H + (size_t)nb * 128 + (lane & 31);
-    const float gi = sigmoidf_(acc[0][r] + gp[0]);
-    const float gf = sigmoidf_(acc[1][r] + gp[32]);
-    const float gg = tanhf(acc[2][r] + gp[64]);
-    const float go = sigmoidf_(acc[3][r] + gp[96]);
-    const float c = gf * a.c_prev[(size_t)row * H + u] + gi * gg;
+    float* gp = gates + (size_t)row * 4 * H + (size_t)nb * 128 + (lane & 31);
+    const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
+    const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
+    const float gg = tanhf(acc[2][r] + pre[r][2]);
+    const float go = sigmoidf_(acc[3][r] + pre[r][3]);
+    const float c = gf * cp[r] + gi * gg;
+    const float h = go * tanhf(c);
+    gp[0] = gi;
+    gp[32] = gf;
+    gp[64] = gg;
+    gp[96] = go;
+    a.c_out[(size_t)row * H + u] = c;
+    a.h_out16[(size_t)row * H + u] = f2bf(h);
+    if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
+  }
+}
+
+// Small-batch variant (learner: Bn = 128): block = 32 rows x 32 hidden units, 4 waves in a 2x2 grid, each wave
+// owning 16 rows x 16 units with FOUR 16x16 accumulators (i,f,g,o) over the full K — no cross-wave reduction and
+// the transcendental-heavy cell update is spread over all four waves.  v_mfma_f32_16x16x32_bf16: lane l holds
+// row/col (l & 15), k = 8*(l >> 4)..+7 of a 32-wide k block; C: col = l & 15, row = 4*(l >> 4) + reg.
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int KB>  // KB = H / 32 k-blocks
+__global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int H = a.H, nb = blockIdx.x;
+  const int row_l = blockIdx.y * 32 + wr * 16 + (lane & 15);   // A row this lane loads
+  const int kofs = (lane >> 4) * 8;
+  const bf16_t* __restrict__ hp = a.h_prev;
+  const bf16_t* __restrict__ W = a.Whh;
+  f32x4 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int CH = KB < 8 ? KB : 8;   // k-blocks whose fragments are in flight together
+#pragma unroll 1
+  for (int c0 = 0; c0 < KB; c0 += CH) {
+    bf16x8 fa[CH], fb[4][CH];
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      if (row_l < a.Bn) {
+        fa[it] = *reinterpret_cast<const bf16x8*>(hp + (size_t)row_l * H + (c0 + it) * 32 + kofs);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[it][e] = (__bf16)0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int it = 0; it < CH; ++it)
+        fb[j][it] = *reinterpret_cast<const bf16x8*>(W + (size_t)(nb * 128 + j * 32 + wu * 16 + (lane & 15)) * H + (c0 + it) * 32 + kofs);
+#pragma unroll
+    for (int it = 0; it < CH; ++it)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[j][it], acc[j], 0, 0, 0);
+  }
+  // epilogue: lane holds 4 rows x 1 unit x 4 gates
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = blockIdx.y * 32 + wr * 16 + 4 * (lane >> 4);
+  float* __restrict__ gates = a.gates;
+  const float* __restrict__ c_prev = a.c_prev;
+  float pre[4][4], cp[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(rbase + r, a.Bn - 1);
+    const float* gp = gates + (size_t)row * 4 * H + ucol;
+    pre[r][0] = gp[0];
+    pre[r][1] = gp[32];
+    pre[r][2] = gp[64];
+    pre[r][3] = gp[96];
+    cp[r] = c_prev[(size_t)row * H + u];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rbase + r;
+    if (row >= a.Bn) continue;
+    float* gp = gates + (size_t)row * 4 * H + ucol;
+    const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
+    const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
+    const float gg = tanhf(acc[2][r] + pre[r][2]);
+    const float go = sigmoidf_(acc[3][r] + pre[r][3]);
+    const float c = gf * cp[r] + gi * gg;
     const float h = go * tanhf(c);
     gp[0] = gi;
     gp[32] = gf;
@@ -432,24 +540,245 @@ __global__ void td_loss_kernel(const float* __restrict__ online_qa, const float*
   loss[b] = sum;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused BPTT step (small batch): dh_rec = dG[t+1] * W_hh   (A = dG[t+1] bf16 [Bn,4H] gate-blocked columns,
+// B = W_hh^T bf16 [H,4H]), then for every (row, unit) of the output tile the whole LSTM cell backward:
+//   dh = dO[t] + dh_rec; do = dh*tanh(c); dct = dc + dh*o*(1-tanh(c)^2); di = dct*g; dg = dct*i; df = dct*c_prev;
+//   dc <- dct*f;  pre-activation grads da_i = di*i(1-i), da_f = df*f(1-f), da_g = dg*(1-g^2), da_o = do*o(1-o)
+// written as dG[t] (bf16, gate-blocked) for the next step and for the weight-gradient GEMMs.
+// Block = 32 rows x 32 units, 2x2 waves of 16x16 tiles (one accumulator per wave, K = 4H).
+// ---------------------------------------------------------------------------------------------------
+struct LstmBwdArgs {
+  const bf16_t* dG_next;  // [Bn,4H] bf16 (zeros at t = T-1)
+  const bf16_t* WhhT;     // [H,4H] bf16 = (gate-blocked W_hh)^T
+  const float* dO;        // [Bn,H] fp32 gradient from the layer above at step t (may be NULL)
+  const float* gates;     // [Bn,4H] activated gates of step t (gate-blocked)
+  const float* c;         // [Bn,H] c_t
+  const float* c_prev;    // [Bn,H] c_{t-1} (NULL = zeros)
+  float* dc;              // [Bn,H] running dc (in/out)
+  bf16_t* dG;             // [Bn,4H] out
+  int Bn, H;
+};
+
+template <int KB>  // KB = 4H / 32
+__global__ __launch_bounds__(256) void lstm_bwd_step_small_kernel(LstmBwdArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int H = a.H, K = 4 * H, nb = blockIdx.x;
+  const int row_l = blockIdx.y * 32 + wr * 16 + (lane & 15);
+  const int kofs = (lane >> 4) * 8;
+  const bf16_t* __restrict__ Ap = a.dG_next;
+  const bf16_t* __restrict__ W = a.WhhT;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int CH = KB < 16 ? KB : 16;
+#pragma unroll 1
+  for (int c0 = 0; c0 < KB; c0 += CH) {
+    bf16x8 fa[CH], fb[CH];
+#pragma unroll
+    for (int it = 0; it < CH; ++it) {
+      if (row_l < a.Bn) {
+        fa[it] = *reinterpret_cast<const bf16x8*>(Ap + (size_t)row_l * K + (c0 + it) * 32 + kofs);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fa[it][e] = (__bf16)0.f;
+      }
+      fb[it] = *reinterpret_cast<const bf16x8*>(W + (size_t)(nb * 32 + wu * 16 + (lane & 15)) * K + (c0 + it) * 32 + kofs);
+    }
+#pragma unroll
+    for (int it = 0; it < CH; ++it) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], fb[it], acc, 0, 0, 0);
+  }
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = blockIdx.y * 32 + wr * 16 + 4 * (lane >> 4);
+  float g4[4][4], cc[4], cpv[4], dov[4], dcv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(rbase + r, a.Bn - 1);
+    const float* gp = a.gates + (size_t)row * K + ucol;
+    g4[r][0] = gp[0];
+    g4[r][1] = gp[32];
+    g4[r][2] = gp[64];
+    g4[r][3] = gp[96];
+    cc[r] = a.c[(size_t)row * H + u];
+    cpv[r] = a.c_prev ? a.c_prev[(size_t)row * H + u] : 0.f;
+    dov[r] = a.dO ? a.dO[(size_t)row * H + u] : 0.f;
+    dcv[r] = a.dc[(size_t)row * H + u];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = rbase + r;
+    if (row >= a.Bn) continue;
+    const float gi = g4[r][0], gf = g4[r][1], gg = g4[r][2], go = g4[r][3];
+    const float dh = dov[r] + acc[r];
+    const float tc = tanhf(cc[r]);
+    const float d_o = dh * tc;
+    const float dct = dcv[r] + dh * go * (1.f - tc * tc);
+    const float dai = dct * gg * gi * (1.f - gi);
+    const float daf = dct * cpv[r] * gf * (1.f - gf);
+    const float dag = dct * gi * (1.f - gg * gg);
+    const float dao = d_o * go * (1.f - go);
+    a.dc[(size_t)row * H + u] = dct * gf;
+    bf16_t* dp = a.dG + (size_t)row * K + ucol;
+    dp[0] = f2bf(dai);
+    dp[32] = f2bf(daf);
+    dp[64] = f2bf(dag);
+    dp[96] = f2bf(dao);
+  }
+}
+
+// Gradient wrt the head outputs [advantage(A) | value | aux logits(NP)] (r2d2.py:124-131 _duel, :133-153 xent):
+//   q_j = v + a_j l_j - mean_k(a_k l_k), qa = q[action]  =>  da_j = dqa l_j (delta_{j,act} - 1/A), dv = dqa
+//   aux: d logit = (softmax - target) * slot_mask / max(sum slot_mask, 1e-6) * pred_weight * weight_b / B
+// Output bf16 [M, ldo] (columns beyond A+1+NP zero).  heads fp32 [M, ldh] provides the aux logits.
+__global__ void heads_bwd_kernel(const float* __restrict__ dqa, const float* __restrict__ legal,
+                                 const int64_t* __restrict__ action, const float* __restrict__ heads, int ldh,
+                                 const float* __restrict__ own_hand, const float* __restrict__ weight, int M, int Bsz, int A,
+                                 int NP, float pred_scale, bf16_t* __restrict__ out, int ldo) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  bf16_t* o = out + (size_t)m * ldo;
+  const float d = dqa[m];
+  const int act = (int)action[m];
+  const float invA = 1.f / (float)A;
+  for (int j = 0; j < A; ++j) o[j] = f2bf(d * legal[(size_t)m * A + j] * ((j == act ? 1.f : 0.f) - invA));
+  o[A] = f2bf(d);
+  int col = A + 1;
+  if (own_hand && pred_scale != 0.f) {
+    const int b = m % Bsz;
+    const float* tg = own_hand + (size_t)m * NP;
+    const float* lg = heads + (size_t)m * ldh + A + 1;
+    const int slots = NP / 3;
+    float nmask = 0.f;
+    for (int sidx = 0; sidx < slots; ++sidx) nmask += tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+    const float scale = pred_scale * weight[b] / fmaxf(nmask, 1e-6f);
+    for (int sidx = 0; sidx < slots; ++sidx) {
+      const float l0 = lg[3 * sidx], l1 = lg[3 * sidx + 1], l2 = lg[3 * sidx + 2];
+      const float mx = fmaxf(l0, fmaxf(l1, l2));
+      const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
+      const float inv = 1.f / (e0 + e1 + e2);
+      const float sm = tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+      // d/dlogit of -(sum_k t_k log softmax_k) * mask = (softmax * sum_k t_k - t) * mask ; targets are one-hot or zero
+      o[col + 3 * sidx + 0] = f2bf((e0 * inv * sm - tg[3 * sidx + 0]) * sm * scale);
+      o[col + 3 * sidx + 1] = f2bf((e1 * inv * sm - tg[3 * sidx + 1]) * sm * scale);
+      o[col + 3 * sidx + 2] = f2bf((e2 * inv * sm - tg[3 * sidx + 2]) * sm * scale);
+    }
+    col += NP;
+  }
+  for (int j = col; j < ldo; ++j) o[j] = 0;
+}
+
+// aux cross-entropy forward (cross_entropy, r2d2.py:133-153): per (t,b) xent summed over t into loss_aux[b]
+__global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ own_hand, int T, int Bsz,
+                                int A, int NP, float* __restrict__ xent_sum) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= Bsz) return;
+  const int slots = NP / 3;
+  float total = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const size_t m = (size_t)t * Bsz + b;
+    const float* tg = own_hand + m * NP;
+    const float* lg = heads + m * ldh + A + 1;
+    float nmask = 0.f, acc = 0.f;
+    for (int sidx = 0; sidx < slots; ++sidx) {
+      const float sm = tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+      const float l0 = lg[3 * sidx], l1 = lg[3 * sidx + 1], l2 = lg[3 * sidx + 2];
+      const float mx = fmaxf(l0, fmaxf(l1, l2));
+      const float lse = mx + __logf(__expf(l0 - mx) + __expf(l1 - mx) + __expf(l2 - mx));
+      const float plogq = tg[3 * sidx] * (l0 - lse) + tg[3 * sidx + 1] * (l1 - lse) + tg[3 * sidx + 2] * (l2 - lse);
+      acc += plogq * sm;
+      nmask += sm;
+    }
+    total += -acc / fmaxf(nmask, 1e-6f);
+  }
+  xent_sum[b] = total;
+}
+
+// column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients)
+template <typename TIn>
+__global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld, float* __restrict__ out) {
+  __shared__ float s[8][33];
+  const int col = blockIdx.x * 32 + threadIdx.x;
+  float acc = 0.f;
+  if (col < N)
+    for (int r = threadIdx.y; r < M; r += 8) {
+      if constexpr (sizeof(TIn) == 2)
+        acc += bf2f(src[(size_t)r * ld + col]);
+      else
+        acc += src[(size_t)r * ld + col];
+    }
+  s[threadIdx.y][threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.y == 0 && col < N) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x];
+    out[col] = t;
+  }
+}
+
+// sum of squares of a flat fp32 buffer (one atomic per block), then Adam with global-norm clipping
+__global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
+  __shared__ float s[256];
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += g[i] * g[i];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) s[threadIdx.x] += s[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, s[0]);
+}
+
+// torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (selfplay.py:231-235)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, const float* __restrict__ sumsq, float max_norm, float lr, float beta1, float beta2,
+                            float eps, float bc1, float bc2_sqrt) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float total_norm = sqrtf(sumsq[0]);
+  const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.f);
+  const float gi = g[i] * coef;
+  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] -= (lr / bc1) * (mi / denom);
+}
+
 }  // namespace
 
 extern "C" {
 
-int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                      float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream) {
+int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                         float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
+                         const void* relu_mask16, int ldmask, void* stream) {
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
   if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 32 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
-  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate};
+  if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
+    return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
+  GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
+             0, (const bf16_t*)relu_mask16, ldmask};
+  int gz = 1;
+  if (split_k > 1) {
+    int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
+    g.k_chunk = chunk;
+    gz = (K + chunk - 1) / chunk;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (N <= 64) {
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((N + 63) / 64, (M + 127) / 128), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((N + 63) / 64, (M + 127) / 128, gz), dim3(256), 0, s, g);
   } else {
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((N + 127) / 128, (M + 127) / 128, gz), dim3(256), 0, s, g);
   }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
+}
+
+int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                      float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream) {
+  return hsad_gemm_nt_bf16_ex(A, lda, B, ldb, M, N, K, bias, C32, ldc, C16, ldc16, relu, accumulate, 1, nullptr, 0, stream);
 }
 
 int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream) {
@@ -494,10 +823,21 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     a.h_out32 = (t == T - 1) ? hT : nullptr;
     a.Bn = Bn;
     a.H = H;
+    const dim3 gs(H / 32, (Bn + 31) / 32);
     if (Bn >= 1024)
-      hipLaunchKernelGGL(lstm_step_kernel<128>, dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
+    else if (H == 64)
+      hipLaunchKernelGGL(lstm_step_small_kernel<2>, gs, dim3(256), 0, s, a);
+    else if (H == 128)
+      hipLaunchKernelGGL(lstm_step_small_kernel<4>, gs, dim3(256), 0, s, a);
+    else if (H == 256)
+      hipLaunchKernelGGL(lstm_step_small_kernel<8>, gs, dim3(256), 0, s, a);
+    else if (H == 512)
+      hipLaunchKernelGGL(lstm_step_small_kernel<16>, gs, dim3(256), 0, s, a);
+    else if (H == 1024)
+      hipLaunchKernelGGL(lstm_step_small_kernel<32>, gs, dim3(256), 0, s, a);
     else
-      hipLaunchKernelGGL(lstm_step_kernel<32>, dim3(H / 32, (Bn + 31) / 32), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
   }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -529,6 +869,94 @@ int hsad_td_loss(const float* online_qa, const float* target_qa, const float* re
   }
   hipLaunchKernelGGL(td_loss_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, online_qa, target_qa,
                      reward, bootstrap, seq_len, T, B, multi_step, gamma_n, err, priority, loss, dqa, weight);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const float* cseq, const float* c0,
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch, void* stream) {
+  if (!gates || !cseq || !WhhT_blocked || !dG16 || !dc_scratch) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: null");
+  if (H != 64 && H != 128 && H != 256 && H != 512) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: H must be 64/128/256/512");
+  if (Bn >= 4096) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: intended for learner batches (Bn < 4096)");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t step4 = (size_t)Bn * 4 * H, step1 = (size_t)Bn * H;
+  bf16_t* dG = (bf16_t*)dG16;  // [T+1][Bn][4H]; slot T is the zero gradient entering the last step
+  HIP_TRY(hipMemsetAsync(dG + (size_t)T * step4, 0, step4 * 2, s));
+  HIP_TRY(hipMemsetAsync(dc_scratch, 0, step1 * 4, s));
+  for (int t = T - 1; t >= 0; --t) {
+    LstmBwdArgs a;
+    a.dG_next = dG + (size_t)(t + 1) * step4;
+    a.WhhT = (const bf16_t*)WhhT_blocked;
+    a.dO = dO ? dO + (size_t)t * step1 : nullptr;
+    a.gates = gates + (size_t)t * step4;
+    a.c = cseq + (size_t)t * step1;
+    a.c_prev = t > 0 ? cseq + (size_t)(t - 1) * step1 : c0;
+    a.dc = dc_scratch;
+    a.dG = dG + (size_t)t * step4;
+    a.Bn = Bn;
+    a.H = H;
+    const dim3 gs(H / 32, (Bn + 31) / 32);
+    if (H == 64)
+      hipLaunchKernelGGL(lstm_bwd_step_small_kernel<8>, gs, dim3(256), 0, s, a);
+    else if (H == 128)
+      hipLaunchKernelGGL(lstm_bwd_step_small_kernel<16>, gs, dim3(256), 0, s, a);
+    else if (H == 256)
+      hipLaunchKernelGGL(lstm_bwd_step_small_kernel<32>, gs, dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL(lstm_bwd_step_small_kernel<64>, gs, dim3(256), 0, s, a);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_heads_backward(const float* dqa, const float* legal, const int64_t* action, const float* heads, int ldh,
+                        const float* own_hand, const float* weight, int M, int B, int A, int NP, float pred_scale,
+                        void* out16, int ldo, void* stream) {
+  if (!dqa || !legal || !action || !out16) return nfail(HSAD_ERR_INVALID, "heads_backward: null");
+  if (ldo < A + 1 + (own_hand ? NP : 0)) return nfail(HSAD_ERR_INVALID, "heads_backward: ldo too small");
+  if (own_hand && (!heads || !weight)) return nfail(HSAD_ERR_INVALID, "heads_backward: aux gradient needs heads and weight");
+  hipLaunchKernelGGL(heads_bwd_kernel, dim3((M + 127) / 128), dim3(128), 0, (hipStream_t)stream, dqa, legal, action, heads,
+                     ldh, own_hand, weight, M, B, A, NP, pred_scale, (bf16_t*)out16, ldo);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int B, int A, int NP, float* xent_sum,
+                  void* stream) {
+  if (!heads || !own_hand || !xent_sum) return nfail(HSAD_ERR_INVALID, "aux_xent: null");
+  hipLaunchKernelGGL(aux_xent_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, heads, ldh, own_hand, T, B,
+                     A, NP, xent_sum);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream) {
+  if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum: null");
+  if (is_bf16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, (const bf16_t*)src, M,
+                       N, ld, out);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, (const float*)src, M, N,
+                       ld, out);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
+                   float lr, float beta1, float beta2, float eps, int step, float* scratch, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !scratch || n < 1 || step < 1)
+    return nfail(HSAD_ERR_INVALID, "adam_step: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(scratch, 0, 4, s));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad, (size_t)n, scratch);
+  double b1p = 1.0, b2p = 1.0;
+  for (int i = 0; i < step; ++i) {
+    b1p *= (double)beta1;
+    b2p *= (double)beta2;
+  }
+  const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
+                     (size_t)n, scratch, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

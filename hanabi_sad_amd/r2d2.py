@@ -179,3 +179,178 @@ def td_loss(online_qa, target_qa, reward, bootstrap, seq_len, multi_step, gamma,
                                 prio.data_ptr(), loss.data_ptr(), None if dqa is None else dqa.data_ptr(),
                                 None if weight is None else weight.contiguous().data_ptr(), _s(d)))
     return err, prio, loss, dqa
+
+
+# ---------------------------------------------------------------------------------------------------------
+# learner: forward with saved activations -> backward (BPTT on the HIP kernels) -> clip + Adam
+# ---------------------------------------------------------------------------------------------------------
+PARAM_ORDER = ["net.0.weight", "net.0.bias",
+               "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+               "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1",
+               "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias", "pred.weight", "pred.bias"]
+
+
+def gemm_nt_ex(A16, B16, M, N, K, out32=None, out16=None, split_k=1, relu_mask=None, accumulate=False):
+    lib = _lib.load_library()
+    _lib.check(lib.hsad_gemm_nt_bf16_ex(
+        A16.data_ptr(), A16.stride(0), B16.data_ptr(), B16.stride(0), M, N, K, None,
+        None if out32 is None else out32.data_ptr(), 0 if out32 is None else out32.stride(0),
+        None if out16 is None else out16.data_ptr(), 0 if out16 is None else out16.stride(0),
+        0, int(accumulate), int(split_k),
+        None if relu_mask is None else relu_mask.data_ptr(), 0 if relu_mask is None else relu_mask.stride(0),
+        _s(A16.device)))
+
+
+def transpose_pad(src16, Kp):
+    """bf16 [R, C] -> [C, Kp] with the R dimension zero-padded to Kp (the contraction dim of the next GEMM)"""
+    lib = _lib.load_library()
+    R, Cc = src16.shape
+    dst = torch.zeros(Cc, Kp, dtype=torch.bfloat16, device=src16.device) if Kp != R else \
+        torch.empty(Cc, R, dtype=torch.bfloat16, device=src16.device)
+    _lib.check(lib.hsad_transpose_bf16(src16.data_ptr(), R, Cc, src16.stride(0), dst.data_ptr(), dst.stride(0),
+                                       _s(src16.device)))
+    return dst
+
+
+def colsum(x):
+    lib = _lib.load_library()
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    _lib.check(lib.hsad_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, x.stride(0), out.data_ptr(),
+                               _s(x.device)))
+    return out
+
+
+class R2D2Learner:
+    """IQL learner step of selfplay.py:208-244 on the HIP kernels: loss(), backward(), Adam step, target sync."""
+
+    def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0,
+                 device="cuda:0"):
+        self.device = torch.device(device)
+        self.multi_step, self.gamma = int(multi_step), float(gamma)
+        self.lr, self.eps, self.grad_clip = float(lr), float(eps), float(grad_clip)
+        # flat fp32 master parameters with named views (same names / shapes as R2D2Net.state_dict())
+        sizes = [online_weights[k].numel() for k in PARAM_ORDER]
+        self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
+        self.gflat = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.scratch = torch.zeros(4, dtype=torch.float32, device=self.device)
+        views, gviews, off = {}, {}, 0
+        for k, n in zip(PARAM_ORDER, sizes):
+            shape = online_weights[k].shape
+            views[k] = self.flat[off:off + n].view(shape)
+            gviews[k] = self.gflat[off:off + n].view(shape)
+            views[k].copy_(online_weights[k])
+            off += n
+        self.online = R2D2NetKernels(views, device)
+        self.online.w = views           # the kernels' fp32 master weights ARE the flat buffer
+        self.online.refresh()
+        self.grad = gviews
+        self.target = R2D2NetKernels(target_weights, device)
+        self.step_count = 0
+        self._refresh_transposes()
+
+    def _refresh_transposes(self):
+        n = self.online
+        H = n.H
+        self.WhhT = [transpose_bf16(n.Whh[l]) for l in range(2)]     # [H, 4H]
+        self.WihT = [transpose_bf16(n.Wih[l]) for l in range(2)]     # [H, 4H]
+        NHp = _pad32(n.NH)
+        wh = torch.zeros(NHp, H, dtype=torch.bfloat16, device=self.device)
+        wh[:n.NH] = n.Wheads
+        self.WheadsT = transpose_bf16(wh)                             # [H, NHp]
+        self.NHp = NHp
+        self.inv_perm = torch.argsort(n.perm)
+
+    def sync_target_with_online(self):
+        for k in PARAM_ORDER:
+            self.target.w[k].copy_(self.online.w[k])
+        self.target.refresh()
+
+    def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
+        """batch: dict priv_s [T,B,F], legal_move [T,B,A], a [T,B] i64, reward/bootstrap [T,B], seq_len [B],
+        own_hand [T,B,3*hand].  Returns per-sequence loss [B] and priority [T,B]; fills self.grad."""
+        lib = _lib.load_library()
+        on, tg, d = self.online, self.target, self.device
+        priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]
+        T, B, _ = priv.shape
+        M, H, A = T * B, on.H, on.A
+        keep = {}
+        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep)
+        tqa, _, _, _ = tg.forward(priv, legal, greedy)
+        err, prio, loss, dqa = td_loss(qa, tqa, batch["reward"], batch["bootstrap"], batch["seq_len"], self.multi_step,
+                                       self.gamma, weight=weight, want_grad=compute_grad)
+        heads = keep["heads"]
+        own = batch.get("own_hand") if pred_weight > 0 else None
+        if own is not None:
+            own = own.contiguous()
+            xs = torch.empty(B, dtype=torch.float32, device=d)
+            _lib.check(lib.hsad_aux_xent(heads.data_ptr(), heads.stride(0), own.data_ptr(), T, B, A, on.NP,
+                                         xs.data_ptr(), _s(d)))
+            loss = loss + pred_weight * xs
+        if not compute_grad:
+            return loss, prio
+        # ---- backward ----
+        Mp = _pad32(M)
+        dheads = torch.empty(M, self.NHp, dtype=torch.bfloat16, device=d)
+        _lib.check(lib.hsad_heads_backward(dqa.data_ptr(), legal.contiguous().data_ptr(), a.contiguous().data_ptr(),
+                                           heads.data_ptr(), heads.stride(0),
+                                           None if own is None else own.data_ptr(), weight.contiguous().data_ptr(), M, B,
+                                           A, on.NP, float(pred_weight) / B if own is not None else 0.0,
+                                           dheads.data_ptr(), dheads.stride(0), _s(d)))
+        hseq = [h.view(M, H) for h in keep["hseq"]]
+        zero_h = torch.zeros(B, H, dtype=torch.bfloat16, device=d)
+        hprevT = [transpose_pad(torch.cat([zero_h, h[:M - B]], 0), Mp) for h in hseq]   # h_{t-1} (h_{-1} = 0)
+        # heads: dW = dheads^T @ o ; db = colsum ; dO1 = dheads @ Wheads
+        dheadsT = transpose_pad(dheads, Mp)                                              # [NHp, Mp]
+        o1T = transpose_pad(hseq[1], Mp)                                                 # [H, Mp]
+        dWh = torch.zeros(self.NHp, H, dtype=torch.float32, device=d)
+        gemm_nt_ex(dheadsT, o1T, self.NHp, H, Mp, out32=dWh, split_k=8)
+        dbh = colsum(dheads)
+        g = self.grad
+        g["fc_a.weight"].copy_(dWh[:A]); g["fc_v.weight"].copy_(dWh[A:A + 1]); g["pred.weight"].copy_(dWh[A + 1:on.NH])
+        g["fc_a.bias"].copy_(dbh[:A]); g["fc_v.bias"].copy_(dbh[A:A + 1]); g["pred.bias"].copy_(dbh[A + 1:on.NH])
+        dO = torch.empty(M, H, dtype=torch.float32, device=d)
+        gemm_nt_ex(dheads, self.WheadsT, M, H, self.NHp, out32=dO)
+        layer_in_T = [transpose_pad(keep["x1"], Mp), transpose_pad(hseq[0], Mp)]         # inputs of layer 0 / 1, [H, Mp]
+        for l in (1, 0):
+            dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
+            dc = torch.empty(B, H, dtype=torch.float32, device=d)
+            _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
+                                                    self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
+                                                    _s(d)))
+            dG2 = dG[:T].view(M, 4 * H)
+            dGT = transpose_pad(dG2, Mp)                                                 # [4H, Mp]
+            dWih = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
+            dWhh = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
+            gemm_nt_ex(dGT, layer_in_T[l], 4 * H, H, Mp, out32=dWih, split_k=8)
+            gemm_nt_ex(dGT, hprevT[l], 4 * H, H, Mp, out32=dWhh, split_k=8)
+            db = colsum(dG2)
+            g["lstm.weight_ih_l%d" % l].copy_(dWih[self.inv_perm])
+            g["lstm.weight_hh_l%d" % l].copy_(dWhh[self.inv_perm])
+            g["lstm.bias_ih_l%d" % l].copy_(db[self.inv_perm])
+            g["lstm.bias_hh_l%d" % l].copy_(db[self.inv_perm])
+            if l == 1:
+                dO = torch.empty(M, H, dtype=torch.float32, device=d)
+                gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
+            else:
+                dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+                gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
+        dx1T = transpose_pad(dx1, Mp)                                                    # [H, Mp]
+        a16T = transpose_pad(keep["a16"], Mp)                                            # [Fp, Mp]
+        dW1 = torch.zeros(H, on.Fp, dtype=torch.float32, device=d)
+        gemm_nt_ex(dx1T, a16T, H, on.Fp, Mp, out32=dW1, split_k=8)
+        g["net.0.weight"].copy_(dW1[:, :on.F])
+        g["net.0.bias"].copy_(colsum(dx1))
+        return loss, prio
+
+    def optimizer_step(self, beta1=0.9, beta2=0.999):
+        lib = _lib.load_library()
+        self.step_count += 1
+        _lib.check(lib.hsad_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                      self.flat.numel(), self.grad_clip, self.lr, beta1, beta2, self.eps, self.step_count,
+                                      self.scratch.data_ptr(), _s(self.device)))
+        self.online.refresh()
+        self._refresh_transposes()
+        return torch.sqrt(self.scratch[0])   # pre-clip global grad norm (stat "grad_norm")

@@ -246,6 +246,31 @@ int hsad_q_head(const float* heads, int ldh, const float* legal, const int64_t* 
 int hsad_td_loss(const float* online_qa, const float* target_qa, const float* reward, const float* bootstrap,
                  const float* seq_len, int T, int B, int multi_step, double gamma, float* err, float* priority,
                  float* loss, float* dqa, const float* weight, void* stream);
+/* hsad_gemm_nt_bf16 with split-K (fp32 atomic accumulation into a pre-zeroed / running C32; for weight
+ * gradients whose contraction dimension is T*B) and an optional ReLU-backward mask (output zeroed where
+ * relu_mask16 <= 0). */
+int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                         float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
+                         const void* relu_mask16, int ldmask, void* stream);
+/* BPTT through one LSTM layer (learner batches).  gates/cseq: saved by hsad_lstm_layer_forward; c0 (may be NULL =
+ * zeros); WhhT_blocked bf16 [H,4H] = transpose of the gate-blocked W_hh; dO fp32 [T,Bn,H] (may be NULL).
+ * Output dG16 bf16 [T+1,Bn,4H] (slot T is scratch): gradient wrt the gate pre-activations, gate-blocked. */
+int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const float* cseq, const float* c0,
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch, void* stream);
+/* Gradient wrt the head outputs [advantage | value | aux logits] from d(loss)/d(qa) and the aux cross-entropy
+ * (r2d2.py:124-153); pred_scale = pred_weight / B (0 disables the aux part).  out16 bf16 [M, ldo]. */
+int hsad_heads_backward(const float* dqa, const float* legal, const int64_t* action, const float* heads, int ldh,
+                        const float* own_hand, const float* weight, int M, int B, int A, int NP, float pred_scale,
+                        void* out16, int ldo, void* stream);
+/* aux own-hand cross-entropy summed over time (cross_entropy, r2d2.py:133-153): xent_sum fp32 [B] */
+int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int B, int A, int NP, float* xent_sum,
+                  void* stream);
+/* column sums (bias gradients) of a bf16 / fp32 [M, ld] matrix -> fp32 [N] */
+int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream);
+/* clip_grad_norm_(max_grad_norm) + Adam step over flat fp32 buffers (selfplay.py:231-235); step counts from 1;
+ * scratch: fp32 [1]. */
+int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
+                   float lr, float beta1, float beta2, float eps, int step, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -139,3 +139,49 @@ def test_forward_full_size_against_fp32_restatement():
     rqa, rgreedy, rq, ro = ref.net_forward(Wd, priv, legal, a, h0, h0.clone())
     assert torch.allclose(q, rq, atol=3e-2, rtol=3e-2), (q - rq).abs().max()
     assert (greedy == rgreedy).float().mean() > 0.97
+
+
+def relerr(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+@pytest.mark.parametrize("tag,pw", [("rl", 0.0), ("aux", 0.25)])
+def test_learner_gradients_against_reference_golden(tag, pw):
+    """loss / priority / every parameter gradient of (loss*weight).mean() vs the reference's autograd
+    (tests/golden, small net).  bf16 GEMM operands => tolerances are relative Frobenius errors."""
+    from hanabi_sad_amd.r2d2 import R2D2Learner
+    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
+    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
+    lr = R2D2Learner(Won, Wtg, int(z["meta"][8]), float(z["gamma"][0]), device=DEV)
+    t = lambda k: torch.tensor(z[k]).to(DEV)
+    batch = {k: t("loss." + k) for k in ("priv_s", "legal_move", "a", "reward", "bootstrap", "seq_len", "own_hand")}
+    loss, prio = lr.loss(batch, t("loss.weight"), pw)
+    assert np.allclose(loss.cpu().numpy(), z["loss.%s.loss" % tag], atol=8e-2, rtol=8e-2)
+    assert np.allclose(prio.cpu().numpy(), z["loss.%s.priority" % tag], atol=4e-2, rtol=4e-2)
+    worst = {}
+    for k, g in lr.grad.items():
+        want = torch.tensor(z["loss.%s.grad.%s" % (tag, k)]).to(DEV)
+        if want.abs().max() == 0:
+            assert g.abs().max() < 1e-6, k
+            continue
+        worst[k] = (relerr(g, want), float((g * want).sum() / (g.norm() * want.norm())))
+    assert all(np.isfinite(e) and e < 0.08 and c > 0.995 for e, c in worst.values()), worst
+
+
+def test_adam_step_matches_torch():
+    from hanabi_sad_amd.r2d2 import R2D2Learner
+    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
+    Won = ref.weights_from_npz(z, "online_net.")
+    lr = R2D2Learner(Won, Won, 3, 0.999, lr=1e-3, eps=1.5e-5, grad_clip=0.5, device=DEV)
+    p = torch.nn.Parameter(lr.flat.clone())
+    opt = torch.optim.Adam([p], lr=1e-3, eps=1.5e-5)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for step in range(3):
+        grad = torch.randn(lr.flat.numel(), generator=g).to(DEV) * 0.01
+        lr.gflat.copy_(grad)
+        p.grad = grad.clone()
+        want_norm = torch.nn.utils.clip_grad_norm_([p], 0.5)
+        opt.step()
+        got_norm = lr.optimizer_step()
+        assert torch.allclose(got_norm, want_norm, rtol=1e-5)
+        assert torch.allclose(lr.flat, p.data, rtol=1e-5, atol=1e-7)
