@@ -225,6 +225,8 @@ struct LstmStepArgs {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// tanh via one exp: 1 - 2/(1+e^{2x}); exact limits at +-inf, abs error ~1e-7 — the library tanhf costs ~3x the issue slots
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
 
 template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
@@ -349,10 +351,10 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     float* gp = gates + (size_t)row * 4 * H + (size_t)nb * 128 + (lane & 31);
     const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
     const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
-    const float gg = tanhf(acc[2][r] + pre[r][2]);
+    const float gg = tanhf_(acc[2][r] + pre[r][2]);
     const float go = sigmoidf_(acc[3][r] + pre[r][3]);
     const float c = gf * cp[r] + gi * gg;
-    const float h = go * tanhf(c);
+    const float h = go * tanhf_(c);
     gp[0] = gi;
     gp[32] = gf;
     gp[64] = gg;
@@ -428,10 +430,10 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
     float* gp = gates + (size_t)row * 4 * H + ucol;
     const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
     const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
-    const float gg = tanhf(acc[2][r] + pre[r][2]);
+    const float gg = tanhf_(acc[2][r] + pre[r][2]);
     const float go = sigmoidf_(acc[3][r] + pre[r][3]);
     const float c = gf * cp[r] + gi * gg;
-    const float h = go * tanhf(c);
+    const float h = go * tanhf_(c);
     gp[0] = gi;
     gp[32] = gf;
     gp[64] = gg;
@@ -439,6 +441,158 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
     a.c_out[(size_t)row * H + u] = c;
     a.h_out16[(size_t)row * H + u] = f2bf(h);
     if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent, weight-stationary LSTM layer (learner batches): ONE launch runs all T steps.
+// Grid = (H/32 unit blocks) x (Bn/32 row blocks), 256 threads each.  A workgroup keeps its gate-blocked W_hh
+// slice (128 rows x H, bf16, 133 KB for H = 512) in LDS for the whole sequence and the cell state c in
+// registers; per step it only needs the 32 x H tile h_{t-1} of ITS row block, which the H/32 workgroups of
+// that row block exchange through L2:
+//   producer: h tile staged in LDS -> 8-byte agent-scope (write-through, sc1) stores -> s_waitcnt vmcnt(0) ->
+//             __syncthreads -> one relaxed agent-scope atomicAdd on counter[t][row block]
+//   consumer: one lane polls that counter (relaxed, s_sleep), __syncthreads, then 8-byte agent-scope loads of
+//             h_{t-1} (bypass the non-coherent per-CU L1) feed the MFMA A fragments.
+// No grid-wide barrier, no release fence (nothing but the write-through h tile is shared), every spin bounded.
+// All workgroups must be co-resident: grid <= 256 CUs with one workgroup per CU (LDS-limited) — checked by the host.
+// ---------------------------------------------------------------------------------------------------
+struct LstmSeqArgs {
+  const bf16_t* Whh;       // [4H,H] gate-blocked
+  float* gates;            // [T,Bn,4H] in: x-projection + bias; out: activated gates
+  const float* c0;         // [Bn,H] or NULL
+  const bf16_t* h0_16;     // [Bn,H] bf16
+  bf16_t* hseq16;          // [T,Bn,H]
+  float* cseq;             // [T,Bn,H]
+  float* hT;               // optional [Bn,H]
+  unsigned* counters;      // [T][Bn/32] zeroed before launch
+  unsigned* timeout;       // [1] set to 1 if a spin gave up
+  int T, Bn, H;
+};
+
+typedef unsigned long long u64_t;
+
+template <int KB>  // KB = H / 32
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int H = KB * 32;
+  constexpr int WS = H + 8;                      // padded LDS row stride (elements)
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                 // [128][WS]
+  bf16_t* sH = sW + 128 * WS;                                        // [32][40] h tile staging
+  int* s_okp = reinterpret_cast<int*>(sH + 32 * 40);                 // keep ALL LDS in the dynamic region (16-B base)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int nb = blockIdx.x, rb = blockIdx.y, nrb = gridDim.y, nunit_blocks = gridDim.x;
+  const int kofs = (lane >> 4) * 8;
+  // W slice -> LDS (coalesced 16-byte loads)
+  for (int c = tid; c < 128 * (H / 8); c += 256) {
+    const int r = c / (H / 8), q = c - r * (H / 8);
+    *reinterpret_cast<uint4*>(sW + r * WS + q * 8) = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + q * 8);
+  }
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
+  const int row_l = rb * 32 + wr * 16 + (lane & 15);
+  float cst[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = min(rbase + r, a.Bn - 1);
+    cst[r] = a.c0 ? a.c0[(size_t)row * H + u] : 0.f;
+  }
+  __syncthreads();
+
+  for (int t = 0; t < a.T; ++t) {
+    // x-projection of this step: independent of h, so these HBM loads overlap the wait below
+    float* gt = a.gates + (size_t)t * a.Bn * 4 * H;
+    float pre[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(rbase + r, a.Bn - 1);
+      const float* gp = gt + (size_t)row * 4 * H + ucol;
+      pre[r][0] = gp[0];
+      pre[r][1] = gp[32];
+      pre[r][2] = gp[64];
+      pre[r][3] = gp[96];
+    }
+    const bf16_t* hprev = t == 0 ? a.h0_16 : a.hseq16 + (size_t)(t - 1) * a.Bn * H;
+    if (t > 0) {
+      if (tid == 0) {
+        unsigned* ctr = a.counters + (size_t)(t - 1) * nrb + rb;
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nunit_blocks) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 4000000u) {
+            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+        *s_okp = ok;
+      }
+      __syncthreads();
+      if (!*s_okp) return;
+    }
+    // A fragments of h_{t-1}: agent-scope 8-byte loads (h was written by other CUs during this launch)
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const u64_t* hrow = reinterpret_cast<const u64_t*>(hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs);
+    union Frag {
+      u64_t q[2];
+      bf16x8 v;
+    };
+    Frag fa[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      fa[kb].q[0] = __hip_atomic_load(hrow + kb * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fa[kb].q[1] = __hip_atomic_load(hrow + kb * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (j * 32 + wu * 16 + (lane & 15)) * WS + kb * 32 + kofs);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb].v, fb, acc[j], 0, 0, 0);
+      }
+    }
+    // cell update (fp32), h tile staged in LDS for wide write-through stores
+    float* ct = a.cseq + (size_t)t * a.Bn * H;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r;
+      const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
+      const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
+      const float gg = tanhf_(acc[2][r] + pre[r][2]);
+      const float go = sigmoidf_(acc[3][r] + pre[r][3]);
+      const float c = gf * cst[r] + gi * gg;
+      const float h = go * tanhf_(c);
+      cst[r] = c;
+      sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
+      if (row < a.Bn) {
+        float* gp = gt + (size_t)row * 4 * H + ucol;
+        gp[0] = gi;
+        gp[32] = gf;
+        gp[64] = gg;
+        gp[96] = go;
+        ct[(size_t)row * H + u] = c;
+        if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = h;
+      }
+    }
+    __syncthreads();
+    {  // 32 rows x 32 units bf16 = 256 x 8 bytes
+      const int r = tid >> 3, q = tid & 7;
+      const int row = rb * 32 + r;
+      if (row < a.Bn) {
+        const u64_t v = *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
+        __hip_atomic_store(reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4), v,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && t + 1 < a.T)
+      __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -610,7 +764,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_small_kernel(LstmBwdArgs a)
     if (row >= a.Bn) continue;
     const float gi = g4[r][0], gf = g4[r][1], gg = g4[r][2], go = g4[r][3];
     const float dh = dov[r] + acc[r];
-    const float tc = tanhf(cc[r]);
+    const float tc = tanhf_(cc[r]);
     const float d_o = dh * tc;
     const float dct = dcv[r] + dh * go * (1.f - tc * tc);
     const float dai = dct * gg * gi * (1.f - gi);
@@ -693,14 +847,16 @@ __global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const 
   xent_sum[b] = total;
 }
 
-// column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients)
+// column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients).  Grid = (N/64, row chunks of 512);
+// block 64x4: coalesced 64-column row segments, LDS reduce, one atomicAdd per column per block (out pre-zeroed).
 template <typename TIn>
 __global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld, float* __restrict__ out) {
-  __shared__ float s[8][33];
-  const int col = blockIdx.x * 32 + threadIdx.x;
+  __shared__ float s[4][65];
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int r0 = blockIdx.y * 512, r1 = min(M, r0 + 512);
   float acc = 0.f;
   if (col < N)
-    for (int r = threadIdx.y; r < M; r += 8) {
+    for (int r = r0 + threadIdx.y; r < r1; r += 4) {
       if constexpr (sizeof(TIn) == 2)
         acc += bf2f(src[(size_t)r * ld + col]);
       else
@@ -708,11 +864,7 @@ __global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld,
     }
   s[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.y == 0 && col < N) {
-    float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += s[k][threadIdx.x];
-    out[col] = t;
-  }
+  if (threadIdx.y == 0 && col < N) atomicAdd(out + col, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
 }
 
 // sum of squares of a flat fp32 buffer (one atomic per block), then Adam with global-norm clipping
@@ -799,7 +951,8 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
 }
 
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
-                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT, void* stream) {
+                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
+                            void* sync_scratch, void* stream) {
   if (!gates || !Whh_blocked || !c0 || !hseq16 || !cseq || !h0_16_scratch)
     return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: null argument");
   if (H % 64 || T < 1 || Bn < 1) return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: H must be a multiple of 64");
@@ -811,6 +964,38 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
                        (bf16_t*)h0_16_scratch, H);
   } else {
     HIP_TRY(hipMemsetAsync(h0_16_scratch, 0, (size_t)Bn * H * 2, s));
+  }
+  // persistent weight-stationary path (one launch for the whole sequence)
+  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
+    const int nrb = (Bn + 31) / 32;
+    unsigned* counters = (unsigned*)sync_scratch;
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb + 4), s));
+    LstmSeqArgs q;
+    q.Whh = (const bf16_t*)Whh_blocked;
+    q.gates = gates;
+    q.c0 = c0;
+    q.h0_16 = (const bf16_t*)h0_16_scratch;
+    q.hseq16 = (bf16_t*)hseq16;
+    q.cseq = cseq;
+    q.hT = hT;
+    q.counters = counters;
+    q.timeout = counters + (size_t)T * nrb;
+    q.T = T;
+    q.Bn = Bn;
+    q.H = H;
+    const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
+    const dim3 grid(H / 32, nrb);
+    if (H == 512) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, q);
+    } else {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(lstm_seq_fwd_kernel<8>, grid, dim3(256), lds, s, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return HSAD_OK;
   }
   for (int t = 0; t < T; ++t) {
     LstmStepArgs a;
@@ -840,6 +1025,15 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
       hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
   }
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* timed_out) {
+  if (!sync_scratch || !timed_out) return nfail(HSAD_ERR_INVALID, "null argument");
+  unsigned v = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&v, (const unsigned*)sync_scratch + (size_t)T * ((Bn + 31) / 32), 4, hipMemcpyDeviceToHost));
+  *timed_out = (int32_t)v;
   return HSAD_OK;
 }
 
@@ -932,12 +1126,13 @@ int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int
 
 int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream) {
   if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum: null");
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * N, s));
+  const dim3 grid((N + 63) / 64, (M + 511) / 512), block(64, 4);
   if (is_bf16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3((N + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, (const bf16_t*)src, M,
-                       N, ld, out);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, out);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3((N + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, (const float*)src, M, N,
-                       ld, out);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)src, M, N, ld, out);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -56,7 +56,7 @@ def transpose_bf16(src):
     return dst
 
 
-def lstm_layer_forward(gates, Whh_blocked16, h0, c0):
+def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
     """gates fp32 [T,Bn,4H] (x-projection + biases, gate-blocked; overwritten with the activated gates).
     -> hseq bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]"""
     lib = _lib.load_library()
@@ -69,10 +69,12 @@ def lstm_layer_forward(gates, Whh_blocked16, h0, c0):
     scratch = torch.empty(Bn, H, dtype=torch.bfloat16, device=d)
     if c0 is None:
         c0 = torch.zeros(Bn, H, dtype=torch.float32, device=d)
+    sync = torch.empty(T * ((Bn + 31) // 32) + 4, dtype=torch.int32, device=d) if persistent else None
     _lib.check(lib.hsad_lstm_layer_forward(T, Bn, H, gates.data_ptr(), Whh_blocked16.data_ptr(),
                                            None if h0 is None else h0.contiguous().data_ptr(),
                                            c0.contiguous().data_ptr(), hseq.data_ptr(), cseq.data_ptr(),
-                                           scratch.data_ptr(), hT.data_ptr(), _s(d)))
+                                           scratch.data_ptr(), hT.data_ptr(),
+                                           None if sync is None else sync.data_ptr(), _s(d)))
     return hseq, cseq, hT
 
 

@@ -233,9 +233,15 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
  * projection x W_ih^T + b_ih + b_hh on entry and the activated gates on exit, both in the gate-blocked column
  * layout (block nb of 32 units: columns nb*128 + gate*32 + u); Whh_blocked bf16 [4H,H] has its rows in the same
  * order.  h0/c0 fp32 [Bn,H] (h0 NULL = zeros).  Outputs hseq16 bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]
- * (optional).  h0_16_scratch: bf16 [Bn,H]. */
+ * (optional).  h0_16_scratch: bf16 [Bn,H].  sync_scratch (may be NULL): uint32 [T*ceil(Bn/32)+4]; when given and
+ * the shape allows (H in {256,512}, Bn <= 512) the whole sequence runs as ONE persistent launch that keeps the
+ * W_hh slices in LDS and exchanges h_t tiles through L2 (csrc/hsad_r2d2.hip); otherwise one launch per step.
+ * hsad_lstm_sync_timed_out() reports a bounded spin that gave up. */
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
-                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT, void* stream);
+                            const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
+                            void* sync_scratch, void* stream);
+/* reads the timeout word of a sync_scratch buffer used with T steps / Bn rows (synchronises the device) */
+int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* timed_out);
 /* Dueling head + masked argmax (r2d2.py:106-131): heads fp32 [M,ldh] = [advantage(A) | value(1) | ...],
  * legal fp32 [M,A], action int64 [M] (may be NULL) -> q [M,A], qa [M], greedy int64 [M] (may be NULL).
  * scratch: fp32 [2 + ceil(M/256)]. */

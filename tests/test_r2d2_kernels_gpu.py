@@ -49,8 +49,10 @@ def test_cast_and_transpose():
     assert torch.equal(transpose_bf16(y), y.t().contiguous())
 
 
-@pytest.mark.parametrize("T,Bn,H", [(5, 128, 512), (3, 40, 64), (2, 1500, 256)])
-def test_lstm_layer_forward_matches_bf16_emulated_torch(T, Bn, H):
+@pytest.mark.parametrize("T,Bn,H,persistent", [(5, 128, 512, True), (5, 128, 512, False), (3, 40, 64, True),
+                                               (2, 1500, 256, True), (80, 128, 512, True), (9, 70, 256, True)])
+def test_lstm_layer_forward_matches_bf16_emulated_torch(T, Bn, H, persistent):
+    """persistent=True takes the one-launch weight-stationary kernel when the shape allows (H in {256,512}, Bn<=512)."""
     from hanabi_sad_amd.r2d2 import gate_block_perm, lstm_layer_forward
     g = torch.Generator(device="cpu").manual_seed(T * 7 + H)
     Whh = (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV)
@@ -59,7 +61,8 @@ def test_lstm_layer_forward_matches_bf16_emulated_torch(T, Bn, H):
     c0 = (torch.randn(Bn, H, generator=g) * 0.5).to(DEV)
     perm = gate_block_perm(H, DEV)
     gates = gx[:, :, perm].contiguous()
-    hseq, cseq, hT = lstm_layer_forward(gates, Whh[perm].to(torch.bfloat16).contiguous(), h0, c0)
+    hseq, cseq, hT = lstm_layer_forward(gates, Whh[perm].to(torch.bfloat16).contiguous(), h0, c0, persistent=persistent)
+    torch.cuda.synchronize()
     # reference with the same rounding points: h fed back as bf16, weights bf16, everything else fp32
     h, c = bf(h0), c0
     W = bf(Whh)

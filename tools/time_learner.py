@@ -1,0 +1,56 @@
+"""Developer tool: R2D2 learner update time at BASELINE configs[2] (2p SAD IQL, H=512, B=128, T=80)."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hanabi_sad_amd.r2d2 import R2D2Learner
+DEV = "cuda:0"
+torch.manual_seed(0)
+F, H, A, T, B = 838, 512, 21, 80, 128
+lin = lambda o, i: (torch.rand(o, i) * 2 - 1) / i ** 0.5
+W = {"net.0.weight": lin(H, F), "net.0.bias": lin(H, 1).squeeze(1), "fc_v.weight": lin(1, H), "fc_v.bias": torch.zeros(1),
+     "fc_a.weight": lin(A, H), "fc_a.bias": torch.zeros(A), "pred.weight": lin(15, H), "pred.bias": torch.zeros(15)}
+for l in range(2):
+    W["lstm.weight_ih_l%d" % l] = lin(4 * H, H); W["lstm.weight_hh_l%d" % l] = lin(4 * H, H)
+    W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1); W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
+lr = R2D2Learner(W, W, 3, 0.999, device=DEV)
+seq_len = torch.randint(40, 81, (B,)).float().to(DEV)
+mask = (torch.arange(T, device=DEV).unsqueeze(1) < seq_len.unsqueeze(0)).float()
+legal = (torch.rand(T, B, A, device=DEV) < 0.4).float(); legal[..., 0] = 1
+batch = {"priv_s": (torch.rand(T, B, F, device=DEV) < 0.15).float() * mask.unsqueeze(2), "legal_move": legal * mask.unsqueeze(2),
+         "a": torch.zeros(T, B, dtype=torch.int64, device=DEV), "reward": (torch.rand(T, B, device=DEV) < 0.05).float() * mask,
+         "bootstrap": mask.clone(), "seq_len": seq_len, "own_hand": torch.zeros(T, B, 15, device=DEV)}
+weight = torch.ones(B, device=DEV)
+def upd():
+    loss, prio = lr.loss(batch, weight, 0.0)
+    lr.optimizer_step()
+for _ in range(3): upd()
+torch.cuda.synchronize(); t0 = time.perf_counter(); n = 10
+for _ in range(n): upd()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print("HIP learner update: %.2f ms  -> %.0f sequences/s  (%.1f TFLOP/s of 380.3 GFLOP/update)" % (dt * 1e3, B / dt, 380.3e9 / dt / 1e12))
+t0 = time.perf_counter()
+for _ in range(n): lr.loss(batch, weight, 0.0, compute_grad=False)
+torch.cuda.synchronize(); print("  forward only (online+target+TD): %.2f ms" % ((time.perf_counter() - t0) / n * 1e3))
+# torch eager baseline of the same math (nn.LSTM / MIOpen fp32) -- "what you get without hand-written kernels"
+import torch.nn as nn
+class Net(nn.Module):
+    def __init__(s):
+        super().__init__(); s.net = nn.Sequential(nn.Linear(F, H), nn.ReLU()); s.lstm = nn.LSTM(H, H, 2); s.fc_v = nn.Linear(H, 1); s.fc_a = nn.Linear(H, A)
+    def forward(s, priv, legal, a):
+        o, _ = s.lstm(s.net(priv)); av = s.fc_a(o); v = s.fc_v(o); la = av * legal; q = v + la - la.mean(2, keepdim=True)
+        return q.gather(2, a.unsqueeze(2)).squeeze(2), ((1 + q - q.min()) * legal).argmax(2)
+on, tg = Net().to(DEV), Net().to(DEV)
+opt = torch.optim.Adam(on.parameters(), lr=6.25e-5, eps=1.5e-5)
+def upd_t():
+    qa, g = on(batch["priv_s"], legal, batch["a"])
+    with torch.no_grad():
+        tq, _ = tg(batch["priv_s"], legal, g); tq = torch.cat([tq[3:], tq[:3]], 0); tq[-3:] = 0
+        target = batch["reward"] + batch["bootstrap"] * 0.997 * tq
+    err = (target - qa) * mask
+    l = (nn.functional.smooth_l1_loss(err, torch.zeros_like(err), reduction="none").sum(0) * weight).mean()
+    opt.zero_grad(); l.backward(); nn.utils.clip_grad_norm_(on.parameters(), 5); opt.step()
+for _ in range(3): upd_t()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(n): upd_t()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print("torch eager fp32 (MIOpen LSTM) update: %.2f ms -> %.0f sequences/s" % (dt * 1e3, B / dt))
