@@ -84,7 +84,7 @@ SIGNATURES = {
     "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "hsad_gemm_nt_bf16_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
                                        C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
-    "hsad_lstm_layer_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_lstm_layer_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_heads_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,
                                       C.c_int, _P]),
     "hsad_aux_xent": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

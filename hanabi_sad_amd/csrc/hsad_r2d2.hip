@@ -537,6 +537,8 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 8-byte agent-scope (sc1) loads: served by L2, bypassing the per-CU L1 that other CUs' stores never refresh
+    // (measured faster here than 16-byte non-temporal loads: 694 vs 760 us per 80-step layer)
     const u64_t* hrow = reinterpret_cast<const u64_t*>(hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs);
     union Frag {
       u64_t q[2];
@@ -593,6 +595,126 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     __syncthreads();
     if (tid == 0 && t + 1 < a.T)
       __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Persistent BPTT through one LSTM layer: same workgroup grid / exchange protocol as lstm_seq_fwd_kernel.
+// Workgroup (nb, rb) owns dh/dc of 32 rows x 32 units; its slice of W_hh^T (32 x 4H bf16, 131 KB) stays in LDS.
+// Per step it reads the 32 x 4H gradient tile dG[t+1] of its row block (written by the H/32 workgroups of that row
+// block one iteration earlier), multiplies, runs the cell backward and publishes its 32 x 128 slice of dG[t].
+// ---------------------------------------------------------------------------------------------------
+struct LstmSeqBwdArgs {
+  const bf16_t* WhhT;  // [H,4H]
+  const float* gates;  // [T,Bn,4H] activated
+  const float* cseq;   // [T,Bn,H]
+  const float* c0;     // [Bn,H] or NULL
+  const float* dO;     // [T,Bn,H] or NULL
+  bf16_t* dG;          // [T+1,Bn,4H]
+  unsigned* counters;  // [T][Bn/32] zeroed before launch
+  unsigned* timeout;
+  int T, Bn, H;
+};
+
+template <int KB>  // KB = 4H / 32
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int K = KB * 32, H = K / 4;
+  constexpr int WS = K + 8;
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);  // [32][WS]
+  bf16_t* sG = sW + 32 * WS;                          // [32][136] dG tile staging
+  int* s_okp = reinterpret_cast<int*>(sG + 32 * 136);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int nb = blockIdx.x, rb = blockIdx.y, nrb = gridDim.y, nunit_blocks = gridDim.x;
+  const int kofs = (lane >> 4) * 8;
+  for (int c = tid; c < 32 * (K / 8); c += 256) {
+    const int r = c / (K / 8), q = c - r * (K / 8);
+    *reinterpret_cast<uint4*>(sW + r * WS + q * 8) = *reinterpret_cast<const uint4*>(a.WhhT + (size_t)(nb * 32 + r) * K + q * 8);
+  }
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
+  const int row_l = rb * 32 + wr * 16 + (lane & 15);
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  for (int t = a.T - 1; t >= 0; --t) {
+    // everything the cell backward needs from this block's own saved activations (overlaps the wait)
+    float g4[4][4], cc[4], cpv[4], dov[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(rbase + r, a.Bn - 1);
+      const float* gp = a.gates + ((size_t)t * a.Bn + row) * K + ucol;
+      g4[r][0] = gp[0];
+      g4[r][1] = gp[32];
+      g4[r][2] = gp[64];
+      g4[r][3] = gp[96];
+      cc[r] = a.cseq[((size_t)t * a.Bn + row) * H + u];
+      cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
+      dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
+    }
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < a.T - 1) {
+      if (tid == 0) {
+        unsigned* ctr = a.counters + (size_t)(t + 1) * nrb + rb;
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nunit_blocks) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > 4000000u) {
+            __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = 0;
+            break;
+          }
+        }
+        *s_okp = ok;
+      }
+      __syncthreads();
+      if (!*s_okp) return;
+      const bf16x8* grow = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + min(row_l, a.Bn - 1)) * K + kofs);
+      const bf16_t* wrow = sW + (wu * 16 + (lane & 15)) * WS + kofs;
+      constexpr int CH = 16;
+#pragma unroll 1
+      for (int c0 = 0; c0 < KB; c0 += CH) {
+        bf16x8 fa[CH];
+#pragma unroll
+        for (int it = 0; it < CH; ++it) fa[it] = __builtin_nontemporal_load(grow + (c0 + it) * 4);
+#pragma unroll
+        for (int it = 0; it < CH; it += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], *reinterpret_cast<const bf16x8*>(wrow + (c0 + it) * 32), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it + 1], *reinterpret_cast<const bf16x8*>(wrow + (c0 + it + 1) * 32), acc1, 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = g4[r][0], gf = g4[r][1], gg = g4[r][2], go = g4[r][3];
+      const float dh = dov[r] + acc0[r] + acc1[r];
+      const float tc = tanhf_(cc[r]);
+      const float d_o = dh * tc;
+      const float dct = dcs[r] + dh * go * (1.f - tc * tc);
+      dcs[r] = dct * gf;
+      bf16_t* sp = sG + (wr * 16 + 4 * (lane >> 4) + r) * 136 + wu * 16 + (lane & 15);
+      sp[0] = f2bf(dct * gg * gi * (1.f - gi));
+      sp[32] = f2bf(dct * cpv[r] * gf * (1.f - gf));
+      sp[64] = f2bf(dct * gi * (1.f - gg * gg));
+      sp[96] = f2bf(d_o * go * (1.f - go));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // 32 rows x 128 columns bf16 = 1024 x 8 bytes
+      const int c = tid + it * 256, r = c >> 5, q = c & 31;
+      const int row = rb * 32 + r;
+      if (row < a.Bn) {
+        const u64_t v = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+        __hip_atomic_store(reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4), v, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && t > 0) __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1068,13 +1190,33 @@ int hsad_td_loss(const float* online_qa, const float* target_qa, const float* re
 }
 
 int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const float* cseq, const float* c0,
-                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch, void* stream) {
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch,
+                             void* sync_scratch, void* stream) {
   if (!gates || !cseq || !WhhT_blocked || !dG16 || !dc_scratch) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: null");
   if (H != 64 && H != 128 && H != 256 && H != 512) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: H must be 64/128/256/512");
   if (Bn >= 4096) return nfail(HSAD_ERR_INVALID, "lstm_layer_backward: intended for learner batches (Bn < 4096)");
   hipStream_t s = (hipStream_t)stream;
   const size_t step4 = (size_t)Bn * 4 * H, step1 = (size_t)Bn * H;
   bf16_t* dG = (bf16_t*)dG16;  // [T+1][Bn][4H]; slot T is the zero gradient entering the last step
+  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
+    const int nrb = (Bn + 31) / 32;
+    unsigned* counters = (unsigned*)sync_scratch;
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb + 4), s));
+    LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H};
+    const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16;
+    const dim3 grid(H / 32, nrb);
+    if (H == 512) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, q);
+    } else {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, grid, dim3(256), lds, s, q);
+    }
+    HIP_TRY(hipGetLastError());
+    return HSAD_OK;
+  }
   HIP_TRY(hipMemsetAsync(dG + (size_t)T * step4, 0, step4 * 2, s));
   HIP_TRY(hipMemsetAsync(dc_scratch, 0, step1 * 4, s));
   for (int t = T - 1; t >= 0; --t) {

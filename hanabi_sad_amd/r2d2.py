@@ -251,6 +251,8 @@ class R2D2Learner:
         self.grad = gviews
         self.target = R2D2NetKernels(target_weights, device)
         self.step_count = 0
+        self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
+        self.side = torch.cuda.Stream(device=self.device)
         self._refresh_transposes()
 
     def _refresh_transposes(self):
@@ -279,8 +281,19 @@ class R2D2Learner:
         T, B, _ = priv.shape
         M, H, A = T * B, on.H, on.A
         keep = {}
+        # the target trunk does not depend on the online net: run it on a side stream (the persistent LSTM kernels
+        # occupy 64 CUs each, so both nets' recurrences overlap); join before the target q-head needs `greedy`
+        main = torch.cuda.current_stream(d)
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            to, _, _ = tg.trunk(priv)
+            thd = tg.heads(to.reshape(M, H))
         qa, greedy, q, o = on.forward(priv, legal, a, keep=keep)
-        tqa, _, _, _ = tg.forward(priv, legal, greedy)
+        main.wait_stream(self.side)
+        _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
+        tqa = tqa.view(T, B)
+        to.record_stream(main)
+        thd.record_stream(main)
         err, prio, loss, dqa = td_loss(qa, tqa, batch["reward"], batch["bootstrap"], batch["seq_len"], self.multi_step,
                                        self.gamma, weight=weight, want_grad=compute_grad)
         heads = keep["heads"]
@@ -319,9 +332,10 @@ class R2D2Learner:
         for l in (1, 0):
             dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
             dc = torch.empty(B, H, dtype=torch.float32, device=d)
+            sync = torch.empty(T * ((B + 31) // 32) + 4, dtype=torch.int32, device=d)
             _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
                                                     self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
-                                                    _s(d)))
+                                                    sync.data_ptr() if self.persistent else None, _s(d)))
             dG2 = dG[:T].view(M, 4 * H)
             dGT = transpose_pad(dG2, Mp)                                                 # [4H, Mp]
             dWih = torch.zeros(4 * H, H, dtype=torch.float32, device=d)

@@ -260,9 +260,11 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
                          const void* relu_mask16, int ldmask, void* stream);
 /* BPTT through one LSTM layer (learner batches).  gates/cseq: saved by hsad_lstm_layer_forward; c0 (may be NULL =
  * zeros); WhhT_blocked bf16 [H,4H] = transpose of the gate-blocked W_hh; dO fp32 [T,Bn,H] (may be NULL).
- * Output dG16 bf16 [T+1,Bn,4H] (slot T is scratch): gradient wrt the gate pre-activations, gate-blocked. */
+ * Output dG16 bf16 [T+1,Bn,4H] (slot T is scratch): gradient wrt the gate pre-activations, gate-blocked.
+ * sync_scratch: as for hsad_lstm_layer_forward (NULL = one launch per step). */
 int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const float* cseq, const float* c0,
-                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch, void* stream);
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_scratch,
+                             void* sync_scratch, void* stream);
 /* Gradient wrt the head outputs [advantage | value | aux logits] from d(loss)/d(qa) and the aux cross-entropy
  * (r2d2.py:124-153); pred_scale = pred_weight / B (0 disables the aux part).  out16 bf16 [M, ldo]. */
 int hsad_heads_backward(const float* dqa, const float* legal, const int64_t* action, const float* heads, int ldh,

@@ -188,3 +188,70 @@ def test_adam_step_matches_torch():
         got_norm = lr.optimizer_step()
         assert torch.allclose(got_norm, want_norm, rtol=1e-5)
         assert torch.allclose(lr.flat, p.data, rtol=1e-5, atol=1e-7)
+
+
+def _rand_net(F, H, A, NP=15, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lin = lambda o, i: (torch.rand(o, i, generator=g) * 2 - 1) / i ** 0.5
+    W = {"net.0.weight": lin(H, F), "net.0.bias": lin(H, 1).squeeze(1), "fc_v.weight": lin(1, H), "fc_v.bias": torch.zeros(1),
+         "fc_a.weight": lin(A, H), "fc_a.bias": torch.zeros(A), "pred.weight": lin(NP, H), "pred.bias": torch.zeros(NP)}
+    for l in range(2):
+        W["lstm.weight_ih_l%d" % l] = lin(4 * H, H)
+        W["lstm.weight_hh_l%d" % l] = lin(4 * H, H)
+        W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1)
+        W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
+    return W
+
+
+def _rand_batch(T, B, F, A, seed=1):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    seq_len = torch.randint(T // 2, T + 1, (B,), generator=g).float()
+    mask = (torch.arange(T).unsqueeze(1) < seq_len.unsqueeze(0)).float()
+    legal = (torch.rand(T, B, A, generator=g) < 0.4).float()
+    legal[..., 0] = 1
+    a = torch.multinomial(legal.view(-1, A), 1, generator=g).view(T, B)
+    own = torch.zeros(T, B, 5, 3)
+    own.scatter_(3, torch.randint(0, 3, (T, B, 5, 1), generator=g), 1.0)
+    batch = {"priv_s": (torch.rand(T, B, F, generator=g) < 0.15).float() * mask.unsqueeze(2),
+             "legal_move": legal * mask.unsqueeze(2), "a": a * mask.long(),
+             "reward": (torch.rand(T, B, generator=g) < 0.2).float() * mask,
+             "bootstrap": (torch.arange(T).unsqueeze(1) + 3 < seq_len.unsqueeze(0)).float(), "seq_len": seq_len,
+             "own_hand": own.view(T, B, 15) * mask.unsqueeze(2)}
+    return {k: v.to(DEV) for k, v in batch.items()}, (torch.rand(B, generator=g) * 0.5 + 0.5).to(DEV)
+
+
+@pytest.mark.parametrize("H,T,B", [(256, 20, 64), (512, 80, 128)])
+def test_persistent_recurrences_match_per_step_kernels_and_fp32_autograd(H, T, B):
+    """One-launch weight-stationary forward/backward vs the per-step kernels (same math, different schedule) and vs
+    torch autograd on the fp32 restatement."""
+    from hanabi_sad_amd.r2d2 import R2D2Learner
+    F, A = 838, 21
+    W, Wt = _rand_net(F, H, A, seed=3), _rand_net(F, H, A, seed=4)
+    batch, weight = _rand_batch(T, B, F, A)
+    res = {}
+    for persistent in (True, False):
+        lr = R2D2Learner(W, Wt, 3, 0.999, device=DEV)
+        lr.persistent = persistent
+        if not persistent:
+            import hanabi_sad_amd.r2d2 as mod
+            orig = mod.lstm_layer_forward
+            mod.lstm_layer_forward = lambda *a, **k: orig(*a, persistent=False)
+        try:
+            loss, prio = lr.loss(batch, weight, 0.25)
+        finally:
+            if not persistent:
+                mod.lstm_layer_forward = orig
+        torch.cuda.synchronize()
+        res[persistent] = (loss.clone(), prio.clone(), {k: v.clone() for k, v in lr.grad.items()})
+    assert torch.allclose(res[True][0], res[False][0], rtol=2e-3, atol=2e-3)
+    assert torch.allclose(res[True][1], res[False][1], rtol=2e-3, atol=2e-3)
+    for k in res[True][2]:
+        assert relerr(res[True][2][k], res[False][2][k]) < 2e-2, k
+    # fp32 autograd reference
+    Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
+    Wtd = {k: v.to(DEV) for k, v in Wt.items()}
+    rloss, rprio = ref.loss(Wd, Wtd, batch, 3, 0.999, 0.25)
+    (rloss * weight).mean().backward()
+    assert torch.allclose(res[True][0], rloss.detach(), rtol=8e-2, atol=8e-2)
+    bad = {k: relerr(res[True][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[True][2][k], Wd[k].grad) > 0.1}
+    assert not bad, bad
