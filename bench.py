@@ -48,6 +48,72 @@ def measured_traffic_bytes(G):
         return None
 
 
+def learner_bench(dev, updates=20, warmup=3):
+    """Second half of BASELINE.json's metric: R2D2 learner samples/sec at configs[2] (2p SAD IQL, F=838, A=21,
+    H=512, 2-layer LSTM, B=128, T=80, n=3): sample-shaped synthetic batch -> loss fwd (online+target) -> BPTT ->
+    clip+Adam, all on the hand-written HIP kernels (bf16 MFMA operands, fp32 accumulate/state)."""
+    from hanabi_sad_amd.r2d2 import R2D2Learner, gemm_nt
+    torch.manual_seed(0)
+    F, H, A, T, B = 838, 512, 21, 80, 128
+    lin = lambda o, i: (torch.rand(o, i) * 2 - 1) / i ** 0.5
+    W = {"net.0.weight": lin(H, F), "net.0.bias": lin(H, 1).squeeze(1), "fc_v.weight": lin(1, H),
+         "fc_v.bias": torch.zeros(1), "fc_a.weight": lin(A, H), "fc_a.bias": torch.zeros(A),
+         "pred.weight": lin(15, H), "pred.bias": torch.zeros(15)}
+    for l in range(2):
+        W["lstm.weight_ih_l%d" % l] = lin(4 * H, H)
+        W["lstm.weight_hh_l%d" % l] = lin(4 * H, H)
+        W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1)
+        W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
+    lr = R2D2Learner(W, W, 3, 0.999, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device=dev)
+    seq_len = torch.randint(40, 81, (B,)).float().to(dev)
+    mask = (torch.arange(T, device=dev).unsqueeze(1) < seq_len.unsqueeze(0)).float()
+    legal = (torch.rand(T, B, A, device=dev) < 0.4).float()
+    legal[..., 0] = 1
+    a = torch.multinomial(legal.view(-1, A), 1).view(T, B)
+    batch = {"priv_s": (torch.rand(T, B, F, device=dev) < 0.15).float() * mask.unsqueeze(2),
+             "legal_move": legal * mask.unsqueeze(2), "a": a * mask.long(),
+             "reward": (torch.rand(T, B, device=dev) < 0.05).float() * mask, "bootstrap": mask.clone(),
+             "seq_len": seq_len, "own_hand": torch.zeros(T, B, 15, device=dev)}
+    weight = torch.ones(B, device=dev)
+
+    def upd():
+        lr.loss(batch, weight, 0.0)
+        lr.optimizer_step()
+    for _ in range(warmup):
+        upd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(updates):
+        upd()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / updates
+    flop = 380.3e9  # SURVEY.md §8(d): online fwd + target fwd + online bwd
+    # the time-batched LSTM input-projection GEMM (M=T*B, N=4H, K=H), timed live with events on the launch stream
+    M, N, K = T * B, 4 * H, H
+    A16 = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    B16 = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    C = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        gemm_nt(A16, B16, M, N, K, out32=C)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        gemm_nt(A16, B16, M, N, K, out32=C)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / 20
+    gemm_tf = 2.0 * M * N * K / (gemm_ms * 1e-3) / 1e12
+    return {
+        "value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate",
+        "config": {"workload": "BASELINE configs[2]: 2p SAD IQL learner update, F=838 A=21 H=512 L=2 B=128 T=80 n=3, "
+                               "synthetic batch, random-init nets, loss fwd + BPTT + clip + Adam"},
+        "update_tflops": flop / dt / 1e12,
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d)" % (M, N, K),
+                     "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0, "traffic": None,
+                     "avg_launch_ms": gemm_ms},
+    }
+
+
 def cpu_baseline(seconds=8.0):
     """The CPU oracle (port of the reference algorithm; the reference binary is unbuildable here: HLE
     submodule absent) in the reference's config-1 shape: 1 thread, 80 games, max_len 80, random policy."""
@@ -89,6 +155,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-learner", action="store_true", help="skip the R2D2 learner samples/sec measurement")
     ap.add_argument("--kernel-samples", type=int, default=50)
     ap.add_argument("--partitions", type=int, default=1, help="stream partitions for the rollout (hsad_env_set_partitions)")
     args = ap.parse_args()
@@ -175,6 +242,8 @@ def main():
                 "algorithmic_bytes_per_env_step": bytes_per_step, "avg_launch_ms": step_ms,
             },
         }
+        if world == 1 and not args.no_learner:
+            out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
