@@ -1020,6 +1020,86 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] -= (lr / bc1) * (mi / denom);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// R2D2Agent.act tail (r2d2.py:235-277): greedy by ADVANTAGE only, legal_adv = (1 + adv - min(adv)) * legal with the
+// global min, uniform-random legal action, eps-greedy mix.  Randomness: counter-based hash keyed (seed, row, counter)
+// (the reference draws from torch's global generator, which no implementation can reproduce bit-for-bit).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long act_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ void adv_min_kernel(const float* __restrict__ heads, int ldh, int N, int A, float* __restrict__ block_min) {
+  __shared__ float smin[256];
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  float mn = 3.4e38f;
+  if (m < N)
+    for (int j = 0; j < A; ++j) mn = fminf(mn, heads[(size_t)m * ldh + j]);
+  smin[threadIdx.x] = mn;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_min[blockIdx.x] = smin[0];
+}
+
+__global__ void act_select_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
+                                  const float* __restrict__ eps, const float* __restrict__ advmin, int N, int A,
+                                  unsigned long long seed, unsigned long long counter, int64_t* __restrict__ a_out,
+                                  int64_t* __restrict__ greedy_out) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= N) return;
+  const float mn = advmin[0];
+  float best = -3.4e38f;
+  int bi = 0, nlegal = 0;
+  for (int j = 0; j < A; ++j) {
+    const float l = legal[(size_t)m * A + j];
+    const float sc = (1.f + heads[(size_t)m * ldh + j] - mn) * l;
+    if (sc > best) {
+      best = sc;
+      bi = j;
+    }
+    nlegal += l != 0.f;
+  }
+  greedy_out[m] = bi;
+  int act = bi;
+  const float e = eps ? eps[m] : 0.f;
+  if (e > 0.f && nlegal > 0) {
+    const unsigned long long h = act_mix64(act_mix64(seed ^ (0xD1342543DE82EF95ull * (unsigned long long)m)) + counter);
+    const float u = (float)((h >> 40) & 0xFFFFFFull) * (1.f / 16777216.f);
+    if (u < e) {
+      int k = (int)(((h & 0xFFFFFFFFull) * (unsigned long long)nlegal) >> 32);
+      for (int j = 0; j < A; ++j)
+        if (legal[(size_t)m * A + j] != 0.f && k-- == 0) {
+          act = j;
+          break;
+        }
+    }
+  }
+  a_out[m] = act;
+}
+
+// R2D2Agent.compute_priority tail (r2d2.py:355-360): |reward + bootstrap * gamma^n * target_qa - online_qa|
+__global__ void nstep_priority_kernel(const float* __restrict__ qa, const float* __restrict__ tqa, const float* __restrict__ reward,
+                                      const float* __restrict__ bootstrap, float gamma_n, int N, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) out[i] = fabsf(reward[i] + bootstrap[i] * gamma_n * tqa[i] - qa[i]);
+}
+
+// zero the rows of fp32 [L, N, H] state whose env terminated (R2D2Actor::postAct, r2d2_actor.h:109-126)
+__global__ void zero_rows_kernel(float* __restrict__ x, const unsigned char* __restrict__ flag, int N, int H, int rows_per_flag) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)gridDim.y * N * H;
+  const size_t i = idx + (size_t)blockIdx.y * N * H;
+  if (idx >= (size_t)N * H || i >= total) return;
+  const int row = (int)(idx / H);
+  if (flag[row / rows_per_flag]) x[i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1294,6 +1374,39 @@ int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
   const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
                      (size_t)n, scratch, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_act_select(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
+                    uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* scratch, void* stream) {
+  if (!heads || !legal || !a_out || !greedy_out || !scratch) return nfail(HSAD_ERR_INVALID, "act_select: null");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (N + 255) / 256;
+  hipLaunchKernelGGL(adv_min_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, N, A, scratch + 1);
+  hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
+  hipLaunchKernelGGL(act_select_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, legal, eps, scratch, N, A,
+                     (unsigned long long)seed, (unsigned long long)counter, a_out, greedy_out);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_nstep_priority(const float* qa, const float* target_qa, const float* reward, const float* bootstrap,
+                        int multi_step, double gamma, int N, float* out, void* stream) {
+  if (!qa || !target_qa || !reward || !bootstrap || !out) return nfail(HSAD_ERR_INVALID, "nstep_priority: null");
+  double g = 1.0;
+  for (int i = 0; i < multi_step; ++i) g *= gamma;
+  hipLaunchKernelGGL(nstep_priority_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, qa, target_qa, reward,
+                     bootstrap, (float)g, N, out);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream) {
+  if (!x || !flag || rows_per_flag < 1) return nfail(HSAD_ERR_INVALID, "zero_rows: bad arguments");
+  const size_t n = (size_t)N * H;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, (hipStream_t)stream, x, flag, N, H,
+                     rows_per_flag);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

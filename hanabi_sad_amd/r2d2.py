@@ -370,3 +370,69 @@ class R2D2Learner:
         self.online.refresh()
         self._refresh_transposes()
         return torch.sqrt(self.scratch[0])   # pre-clip global grad norm (stat "grad_norm")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# agent: act / compute_priority for the actors (IQL row layout: one row per (game, player))
+# ---------------------------------------------------------------------------------------------------------
+class R2D2Agent:
+    """R2D2Agent.act / compute_priority (pyhanabi/r2d2.py:247-361) on the HIP kernels, IQL layout: every tensor has a
+    leading row dimension N (= games x players), hidden state is fp32 [L, N, H]."""
+
+    def __init__(self, online: R2D2NetKernels, target: R2D2NetKernels, multi_step, gamma, seed=0):
+        self.online, self.target = online, target
+        self.multi_step, self.gamma = int(multi_step), float(gamma)
+        self.seed, self.counter = int(seed), 0
+        self.device = online.device
+
+    def get_h0(self, n):
+        z = torch.zeros(self.online.L, n, self.online.H, dtype=torch.float32, device=self.device)
+        return {"h0": z, "c0": z.clone()}
+
+    def _adv(self, net, priv_s, h0, c0):
+        o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
+        return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
+
+    def act(self, obs, hid):
+        """obs: priv_s [N,F], legal_move [N,A], eps [N]; hid: h0,c0 [L,N,H] -> {a, greedy_a}, new hid"""
+        lib = _lib.load_library()
+        n = obs["priv_s"].shape[0]
+        hd, h, c = self._adv(self.online, obs["priv_s"], hid["h0"], hid["c0"])
+        a = torch.empty(n, dtype=torch.int64, device=self.device)
+        g = torch.empty(n, dtype=torch.int64, device=self.device)
+        scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=self.device)
+        eps = obs.get("eps")
+        _lib.check(lib.hsad_act_select(hd.data_ptr(), hd.stride(0), obs["legal_move"].contiguous().data_ptr(),
+                                       None if eps is None else eps.contiguous().data_ptr(), n, self.online.A, self.seed,
+                                       self.counter, a.data_ptr(), g.data_ptr(), scratch.data_ptr(), _s(self.device)))
+        self.counter += 1
+        return {"a": a, "greedy_a": g}, {"h0": h, "c0": c}
+
+    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap):
+        """|r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|  -> fp32 [N]"""
+        lib = _lib.load_library()
+        on, tg, d = self.online, self.target, self.device
+        n = a.shape[0]
+        hd, _, _ = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"])
+        _, qa, _ = on.q_head(hd, obs["legal_move"], a, want_greedy=False)
+        nhd, _, _ = self._adv(on, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
+        na = torch.empty(n, dtype=torch.int64, device=d)
+        junk = torch.empty(n, dtype=torch.int64, device=d)
+        scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=d)
+        _lib.check(lib.hsad_act_select(nhd.data_ptr(), nhd.stride(0), next_obs["legal_move"].contiguous().data_ptr(), None, n,
+                                       on.A, 0, 0, junk.data_ptr(), na.data_ptr(), scratch.data_ptr(), _s(d)))
+        thd, _, _ = self._adv(tg, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
+        _, tqa, _ = tg.q_head(thd, next_obs["legal_move"], na, want_greedy=False)
+        out = torch.empty(n, dtype=torch.float32, device=d)
+        _lib.check(lib.hsad_nstep_priority(qa.data_ptr(), tqa.data_ptr(), reward.contiguous().data_ptr(),
+                                           bootstrap.contiguous().data_ptr(), self.multi_step, self.gamma, n, out.data_ptr(),
+                                           _s(d)))
+        return out
+
+
+def zero_hidden_rows(hid, terminal_u8, rows_per_flag):
+    lib = _lib.load_library()
+    for k in ("h0", "c0"):
+        x = hid[k]
+        L, N, H = x.shape
+        _lib.check(lib.hsad_zero_rows(x.data_ptr(), terminal_u8.data_ptr(), L, N, H, rows_per_flag, _s(x.device)))

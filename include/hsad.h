@@ -279,6 +279,16 @@ int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, 
  * scratch: fp32 [1]. */
 int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
                    float lr, float beta1, float beta2, float eps, int step, float* scratch, void* stream);
+/* R2D2Agent.act tail (r2d2.py:235-277): heads fp32 [N,ldh] (advantage in columns [0,A)), legal fp32 [N,A], eps fp32 [N]
+ * (NULL = greedy) -> a, greedy_a int64 [N].  scratch fp32 [2 + ceil(N/256)].  Exploration draws come from a counter-based
+ * hash of (seed, row, counter). */
+int hsad_act_select(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
+                    uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* scratch, void* stream);
+/* |reward + bootstrap * gamma^n * target_qa - online_qa| (R2D2Agent.compute_priority, r2d2.py:355-360), all fp32 [N] */
+int hsad_nstep_priority(const float* qa, const float* target_qa, const float* reward, const float* bootstrap,
+                        int multi_step, double gamma, int N, float* out, void* stream);
+/* zero rows r of fp32 x[L,N,H] where flag[r / rows_per_flag] != 0 (hidden-state reset on terminal, r2d2_actor.h:109-126) */
+int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);
 
 #ifdef __cplusplus
 }

@@ -255,3 +255,36 @@ def test_persistent_recurrences_match_per_step_kernels_and_fp32_autograd(H, T, B
     assert torch.allclose(res[True][0], rloss.detach(), rtol=8e-2, atol=8e-2)
     bad = {k: relerr(res[True][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[True][2][k], Wd[k].grad) > 0.1}
     assert not bad, bad
+
+
+def test_agent_act_and_compute_priority_against_reference_golden():
+    from hanabi_sad_amd.r2d2 import R2D2Agent, R2D2NetKernels
+    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
+    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
+    agent = R2D2Agent(R2D2NetKernels(Won, DEV), R2D2NetKernels(Wtg, DEV), int(z["meta"][8]), float(z["gamma"][0]))
+    flat = lambda k: torch.tensor(z[k]).flatten(0, 1).to(DEV)
+
+    def hid(hk, ck):
+        f = lambda h: torch.tensor(h).reshape(h.shape[0] * h.shape[1], 2, -1).transpose(0, 1).contiguous().to(DEV)
+        return {"h0": f(z[hk]), "c0": f(z[ck])}
+    obs = {"priv_s": flat("act.priv_s"), "legal_move": flat("act.legal_move"), "eps": torch.zeros(flat("act.priv_s").shape[0], device=DEV)}
+    reply, new_hid = agent.act(obs, hid("act.h0", "act.c0"))
+    want = torch.tensor(z["act.out_greedy_a"].reshape(-1)).to(DEV)
+    # with eps = 0 both outputs are the greedy action; bf16 may only flip near-ties
+    assert torch.equal(reply["a"], reply["greedy_a"])
+    assert (reply["greedy_a"] == want).float().mean() >= 0.9
+    G = want.shape[0]
+    assert np.allclose(new_hid["h0"].transpose(0, 1).cpu().numpy(), z["act.out_h0"].reshape(G, 2, -1), atol=2e-2)
+    assert np.allclose(new_hid["c0"].transpose(0, 1).cpu().numpy(), z["act.out_c0"].reshape(G, 2, -1), atol=3e-2)
+    nobs = {"priv_s": flat("prio.next_priv_s"), "legal_move": flat("prio.next_legal_move")}
+    p = agent.compute_priority(obs, flat("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
+                               flat("prio.reward"), flat("prio.bootstrap"))
+    assert np.allclose(p.cpu().numpy(), z["prio.out"].reshape(-1), atol=4e-2, rtol=4e-2)
+    # exploration: eps = 1 must pick uniformly among legal moves, deterministic in (seed, counter)
+    obs["eps"] = torch.ones_like(obs["eps"])
+    agent.counter = 5
+    r1, _ = agent.act(obs, hid("act.h0", "act.c0"))
+    agent.counter = 5
+    r2, _ = agent.act(obs, hid("act.h0", "act.c0"))
+    assert torch.equal(r1["a"], r2["a"])
+    assert (obs["legal_move"].gather(1, r1["a"].unsqueeze(1)) == 1).all()
