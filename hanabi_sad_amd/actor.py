@@ -1,0 +1,66 @@
+"""Device-resident actor: the reference's R2D2Actor + HanabiThreadLoop (rela/r2d2_actor.h:23-172,
+cpp/thread_loop.h:42-88) for ALL games in lock-step on one GPU — no threads, no batcher, no host copies.
+
+IQL layout (reference create.py:115-131: one actor per player): every (game, player) pair is one "env row"
+of the agent / sequence writer; reward and terminal are shared by the players of a game."""
+from collections import deque
+
+import torch
+
+from .env import BatchedHanabiEnv
+from .r2d2 import R2D2Agent, zero_hidden_rows
+from .replay import DeviceReplay, SequenceWriter
+
+
+def transition_fields(env):
+    """per-step fields of an IQL RNNTransition: obs {priv_s, legal_move, eps, own_hand} + action {a, greedy_a}
+    (cpp/hanabi_env.cc:197-204; pyhanabi/r2d2.py:296-303)"""
+    return [("priv_s", env.F, torch.float32), ("legal_move", env.A, torch.float32), ("eps", 1, torch.float32),
+            ("own_hand", 3 * env.H, torch.float32), ("a", 1, torch.int64), ("greedy_a", 1, torch.int64)]
+
+
+class DeviceActor:
+    def __init__(self, env: BatchedHanabiEnv, agent: R2D2Agent, replay: DeviceReplay, multi_step, gamma, eta, seq_len):
+        self.env, self.agent, self.replay = env, agent, replay
+        self.G, self.P = env.G, env.P
+        self.N = self.G * self.P
+        self.eta = float(eta)
+        self.multi_step = int(multi_step)
+        self.writer = SequenceWriter(self.N, multi_step, gamma, seq_len, transition_fields(env), env.device)
+        self.hid = agent.get_h0(self.N)
+        self.history_hid = deque()
+        self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
+        self.n_finished = torch.zeros(1, dtype=torch.int32, device=env.device)
+
+    def _rows(self):
+        e, N = self.env, self.N
+        return {"priv_s": e.priv_s.view(N, e.F), "legal_move": e.legal_move.view(N, e.A), "eps": e.eps.view(N),
+                "own_hand": e.own_hand.view(N, 3 * e.H)}
+
+    def step(self):
+        """one iteration of the thread-loop body: reset-terminated -> act -> step -> postAct"""
+        env, agent, P = self.env, self.agent, self.P
+        env.reset()
+        obs = self._rows()
+        self.history_hid.append({k: v.clone() for k, v in self.hid.items()})        # historyHidden_.push_back(hidden_)
+        reply, self.hid = agent.act(obs, self.hid)
+        fields = dict(obs)
+        fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
+        self.writer.push_obs_action(fields)
+        env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))
+        self.num_act += self.N
+        # postAct: reward / terminal of the game go to each of its players' rows
+        r = env.reward.repeat_interleave(P)
+        t = env.terminal.repeat_interleave(P)
+        self.writer.push_reward_terminal(r, t)
+        zero_hidden_rows(self.hid, env.terminal, P)                                    # r2d2_actor.h:109-126
+        if not self.writer.can_pop():
+            return
+        cur, nxt, rew, term, boot = self.writer.pop_transition()
+        hid_s = self.history_hid.popleft()
+        hid_next = self.history_hid[-1]
+        cur_obs = {"priv_s": cur["priv_s"], "legal_move": cur["legal_move"]}
+        nxt_obs = {"priv_s": nxt["priv_s"], "legal_move": nxt["legal_move"]}
+        prio = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, hid_next, rew, boot)
+        self.writer.push_sequence(prio)
+        self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)

@@ -1,0 +1,167 @@
+"""selfplay-style driver on the device pipeline (reference pyhanabi/selfplay.py:89-281, IQL path):
+build env / agent / replay / actor, burn in, then alternate rollout and learner updates.
+
+    python -m hanabi_sad_amd.selfplay --num_game 4096 --num_update 200
+
+Single GPU: actors and learner share the device and alternate in lock-step.  Multi-GPU
+(torchrun, one rank per GPU): every rank rolls out its shard of games into its own replay shard; rank 0 is
+the learner and broadcasts the online/target parameters over RCCL every --actor_sync_freq updates
+ — see hanabi_sad_amd/dist.py."""
+import argparse
+import time
+
+import numpy as np
+import torch
+
+from .actor import DeviceActor, transition_fields
+from .env import BatchedHanabiEnv
+from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2Learner, R2D2NetKernels
+from .replay import DeviceReplay, aggregate_priority
+
+
+def generate_explore_eps(base_eps, alpha, num_env):
+    """pyhanabi/utils.py:367-379"""
+    if num_env == 1:
+        return [0.0 if base_eps < 1e-6 else base_eps]
+    out = []
+    for i in range(num_env):
+        e = base_eps ** (1 + i / (num_env - 1) * alpha)
+        out.append(0.0 if e < 1e-6 else e)
+    return out
+
+
+def init_weights(in_dim, hid_dim, out_dim, hand_size, seed):
+    """random-init R2D2Net parameters with nn.Linear / nn.LSTM's default U(-1/sqrt(fan), 1/sqrt(fan)) init,
+    keyed like the reference state_dict (so `.pthw` checkpoints are interchangeable)"""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    u = lambda shape, fan: (torch.rand(*shape, generator=g) * 2 - 1) / fan ** 0.5
+    H = hid_dim
+    W = {"net.0.weight": u((H, in_dim), in_dim), "net.0.bias": u((H,), in_dim),
+         "fc_v.weight": u((1, H), H), "fc_v.bias": u((1,), H), "fc_a.weight": u((out_dim, H), H),
+         "fc_a.bias": u((out_dim,), H), "pred.weight": u((hand_size * 3, H), H), "pred.bias": u((hand_size * 3,), H)}
+    for l in range(2):
+        for k in ("weight_ih", "weight_hh"):
+            W["lstm.%s_l%d" % (k, l)] = u((4 * H, H), H)
+        for k in ("bias_ih", "bias_hh"):
+            W["lstm.%s_l%d" % (k, l)] = u((4 * H,), H)
+    return W
+
+
+class Trainer:
+    def __init__(self, args, device="cuda:0", rank=0, world=1):
+        self.args, self.device, self.rank, self.world = args, torch.device(device), rank, world
+        eps = generate_explore_eps(args.act_base_eps, args.act_eps_alpha, args.num_eps)
+        self.env = BatchedHanabiEnv(args.num_game, players=args.num_player, hand_size=args.hand_size,
+                                    seed=args.seed + rank * args.num_game, bomb=args.train_bomb, eps_list=eps,
+                                    max_len=args.max_len, sad=bool(args.sad), shuffle_color=bool(args.shuffle_color),
+                                    device=device, track_deck_history=False)
+        W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed)
+        self.learner = R2D2Learner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
+                                   device=device)
+        # the actors run their own copies of the agent, refreshed every actor_sync_freq updates
+        # (ActGroup.update_model / BatchRunner::updateModel, create.py:143-145)
+        self.act_online = R2D2NetKernels(W, device)
+        self.act_target = R2D2NetKernels(W, device)
+        self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
+        fields = transition_fields(self.env)
+        self.replay = DeviceReplay(args.replay_buffer_size, args.seed + rank, args.priority_exponent,
+                                   args.priority_weight, args.prefetch, args.max_len, fields, device)
+        self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len)
+        self.num_update = 0
+
+    def update_actor_model(self):
+        for k in PARAM_ORDER:
+            self.act_online.w[k].copy_(self.learner.online.w[k])
+            self.act_target.w[k].copy_(self.learner.target.w[k])
+        if self.world > 1:
+            from .dist import broadcast_params
+            broadcast_params([self.act_online.w[k] for k in PARAM_ORDER] + [self.act_target.w[k] for k in PARAM_ORDER], src=0)
+        self.act_online.refresh()
+        self.act_target.refresh()
+
+    def learner_update(self):
+        a = self.args
+        if self.num_update % a.num_update_between_sync == 0:
+            self.learner.sync_target_with_online()
+        if self.num_update % a.actor_sync_freq == 0:
+            self.update_actor_model()
+        (f, reward, terminal, bootstrap, seq_len), weight = self.replay.sample(a.batchsize)
+        batch = {"priv_s": f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
+                 "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
+        loss, priority = self.learner.loss(batch, weight, a.pred_weight)
+        prio = aggregate_priority(priority, seq_len, a.eta)
+        g_norm = self.learner.optimizer_step()
+        self.replay.update_priority(prio)
+        self.num_update += 1
+        return (loss * weight).mean(), g_norm
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="R2D2 self-play on the device pipeline (flags as in pyhanabi/selfplay.py)")
+    p.add_argument("--seed", type=int, default=10001)
+    p.add_argument("--gamma", type=float, default=0.999)
+    p.add_argument("--eta", type=float, default=0.9)
+    p.add_argument("--train_bomb", type=int, default=0)
+    p.add_argument("--sad", type=int, default=1)
+    p.add_argument("--shuffle_color", type=int, default=0)
+    p.add_argument("--pred_weight", type=float, default=0.0)
+    p.add_argument("--num_player", type=int, default=2)
+    p.add_argument("--hand_size", type=int, default=5)
+    p.add_argument("--lr", type=float, default=6.25e-5)
+    p.add_argument("--eps", type=float, default=1.5e-5)
+    p.add_argument("--grad_clip", type=float, default=5.0)
+    p.add_argument("--rnn_hid_dim", type=int, default=512)
+    p.add_argument("--batchsize", type=int, default=128)
+    p.add_argument("--num_update", type=int, default=100)
+    p.add_argument("--num_update_between_sync", type=int, default=2500)
+    p.add_argument("--multi_step", type=int, default=3)
+    p.add_argument("--burn_in_frames", type=int, default=2000)
+    p.add_argument("--replay_buffer_size", type=int, default=32768)
+    p.add_argument("--priority_exponent", type=float, default=0.9)
+    p.add_argument("--priority_weight", type=float, default=0.6)
+    p.add_argument("--max_len", type=int, default=80)
+    p.add_argument("--prefetch", type=int, default=3)
+    p.add_argument("--num_game", type=int, default=4096, help="concurrent games on this GPU (num_thread*num_game_per_thread)")
+    p.add_argument("--num_eps", type=int, default=80)
+    p.add_argument("--act_base_eps", type=float, default=0.1)
+    p.add_argument("--act_eps_alpha", type=float, default=7)
+    p.add_argument("--actor_sync_freq", type=int, default=10)
+    p.add_argument("--act_steps_per_update", type=int, default=1)
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    from .dist import rank_world
+    args = parse_args(argv)
+    rank, world = rank_world()
+    if world > 1:
+        import os
+        import torch.distributed as dist
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl")
+    dev = "cuda:%d" % torch.cuda.current_device()
+    tr = Trainer(args, dev, rank, world)
+    t0 = time.time()
+    while tr.replay.size() < args.burn_in_frames:
+        for _ in range(10):
+            tr.actor.step()
+    tr.env.check_errors()
+    print("burn-in done: replay %d sequences after %d acts in %.1fs" % (tr.replay.size(), tr.actor.num_act, time.time() - t0))
+    t0, acts0 = time.time(), tr.actor.num_act
+    for u in range(args.num_update):
+        for _ in range(args.act_steps_per_update):
+            tr.actor.step()
+        loss, g_norm = tr.learner_update()
+        if u % 20 == 0:
+            print("update %d loss %.4f grad_norm %.3f replay %d" % (u, float(loss), float(g_norm), tr.replay.size()))
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    tr.env.check_errors()
+    tr.replay.check_errors()
+    # Tachometer definitions (pyhanabi/utils.py:229-240)
+    print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt,
+                                                             (tr.actor.num_act - acts0) / dt, tr.replay.size()))
+
+
+if __name__ == "__main__":
+    main()
