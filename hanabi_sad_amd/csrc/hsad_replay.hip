@@ -167,15 +167,38 @@ struct ReplayDev {
 
 // PrioritizedReplay::add bookkeeping (ConcurrentQueue::blockAppend): weights = priority^alpha stored at
 // tail.., sequential float block sum added to the running double, tail/size/num_add advanced.
-__global__ void replay_add_ctl_kernel(ReplayDev rd, int n, const int* __restrict__ n_dev,
-                                      const float* __restrict__ priority) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n, const int* __restrict__ n_dev,
+                                                             const float* __restrict__ priority) {
+  __shared__ double s_red[256];
+  const int tid = threadIdx.x;
   ReplayCtl c = *rd.ctl;
   int cnt = n_dev ? min(*n_dev, n) : n;
-  if (c.size + cnt > rd.ring) {  // the reference would block here until sample() pops
-    c.err += 1;
+  int err = 0;
+  if (cnt > rd.ring) {  // cannot be stored at all
+    err = 1;
     cnt = 0;
   }
+  // The reference blocks the producer thread while size + cnt > ring until sample() pops the oldest entries
+  // (ConcurrentQueue::blockAppend).  A lock-step device pipeline cannot block, so it performs that pop itself:
+  // evict exactly as many of the oldest entries as are needed to make room (same bookkeeping as blockPop).
+  const int npop = max(0, c.size + cnt - rd.ring);
+  double local = 0.0;
+  for (int k = tid; k < npop; k += 256) {
+    const int j = (c.head + k) % rd.ring;
+    local += (double)rd.weights[j];
+    rd.evicted[j] = 1;
+  }
+  s_red[tid] = local;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) s_red[tid] += s_red[tid + s];
+    __syncthreads();
+  }
+  if (tid != 0) return;
+  c.sum -= s_red[0];
+  c.head = (c.head + npop) % rd.ring;
+  c.size -= npop;
+  c.err += err;
   float sum = 0.f;
   for (int i = 0; i < cnt; ++i) {
     const float w = powf(priority[i], rd.alpha);
@@ -642,7 +665,7 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
   if (n < 1) return HSAD_OK;
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(1), 0, s, r->rd, n, n_dev, priority);
+  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, n, n_dev, priority);
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
   // payload rows; add_n (<= n) from the control block bounds the copy
@@ -866,7 +889,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   const SeqDev& sd = w->sd;
   const float c1m = (float)(1.0 - (double)eta);
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
-  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(1), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
+  hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
   hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min(sd.E * sd.T, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);
   hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl);

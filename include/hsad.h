@@ -173,7 +173,8 @@ int64_t hsad_replay_bytes(const hsad_replay* r);
 /* PrioritizedReplay::add(vector<RNNTransition>, priority): n sequences, fields[k] -> [n, T, width_k],
  * reward/bootstrap float32 [n,T], terminal uint8 [n,T], seq_len/priority float32 [n].  Weight = priority^alpha.
  * n_dev (may be NULL): device int32 holding the actual count (<= n) for sync-free producers.
- * Unlike the reference, a full ring is an error (HSAD_ERR_STATE via hsad_replay_error_count) instead of blocking. */
+ * Where the reference would block the producer on a full ring (blockAppend) until sample() pops, add() evicts the
+ * oldest entries itself to make room (same bookkeeping as blockPop); only n > ring is an error. */
 int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const float* reward, const uint8_t* terminal,
                     const float* bootstrap, const float* seq_len, const float* priority, const int32_t* n_dev,
                     void* stream);

@@ -181,15 +181,29 @@ def test_prioritized_sampling_eviction_and_updates_match_reference(alpha, beta, 
         assert np.array_equal(f["s"].cpu().numpy(), o) and float(sl_g.item()) == sl
 
 
-def test_contract_violations_are_reported():
+def test_full_ring_evicts_oldest_instead_of_blocking():
+    """Where the reference blocks the producer (blockAppend on a full ring) the device replay makes room by popping
+    the oldest entries — the same pop sample() would have done.  A single add larger than the ring is an error."""
     from hanabi_sad_amd import HsadError
     from hanabi_sad_amd.replay import DeviceReplay
     fields = [("s", 4, torch.float32)]
     rep = DeviceReplay(8, 1, 0.9, 0.6, 0, 4, fields, DEV)   # ring = 10
     z = lambda *s: torch.zeros(*s, device=DEV)
-    for _ in range(2):
-        rep.add({"s": z(5, 4, 4)}, z(5, 4), z(5, 4).to(torch.uint8), z(5, 4), z(5) + 4, z(5) + 1)
+
+    def add(first, n):
+        obs = z(n, 4, 4)
+        obs[:, 0, 0] = torch.arange(first, first + n, device=DEV)
+        rep.add({"s": obs}, z(n, 4), z(n, 4).to(torch.uint8), z(n, 4), z(n) + 4, z(n) + 1)
+    add(0, 5)
+    add(5, 5)
     assert rep.size() == 10
-    rep.add({"s": z(1, 4, 4)}, z(1, 4), z(1, 4).to(torch.uint8), z(1, 4), z(1) + 4, z(1) + 1)  # the reference would block
+    add(10, 3)                                     # the reference would block here
+    assert rep.size() == 10 and rep.num_add() == 13
+    assert float(rep.get(0)[0]["s"][0, 0]) == 3.0   # entries 0..2 were evicted
+    rep.check_errors()
+    (f, *_), w = rep.sample(4)
+    rep.update_priority(torch.ones(4, device=DEV))
+    assert rep.size() == 8
+    add(100, 11)                                    # larger than the whole ring
     with pytest.raises(HsadError):
         rep.check_errors()
