@@ -111,3 +111,34 @@ def test_world_size_2_gloo(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "rank0.ok").exists() and (tmp_path / "rank1.ok").exists()
+
+
+BCAST_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from hanabi_sad_amd.dist import rank_world, broadcast_params
+rank, world = rank_world()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.manual_seed(rank)
+params = [torch.randn(7, 3), torch.randn(11), torch.randn(2, 2, 2)]
+want = None
+torch.manual_seed(0)
+want = [torch.randn(7, 3), torch.randn(11), torch.randn(2, 2, 2)]
+broadcast_params(params, src=0)          # rank-0 learner -> every actor rank
+assert all(torch.equal(a, b) for a, b in zip(params, want)), rank
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(%r, "bcast%%d.ok" %% rank), "w").write("ok")
+'''
+
+
+def test_param_broadcast_world_size_2_gloo(tmp_path):
+    """rank-0 learner -> actor ranks parameter broadcast (RCCL on the GPU box; gloo here)."""
+    script = tmp_path / "bworker.py"
+    script.write_text(BCAST_WORKER % (ROOT, str(tmp_path)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (tmp_path / "bcast0.ok").exists() and (tmp_path / "bcast1.ok").exists()

@@ -44,3 +44,31 @@ def test_actor_fills_replay_with_well_formed_sequences_and_learner_trains():
     tr.replay.check_errors()
     assert not torch.equal(w0, tr.learner.flat)
     assert torch.equal(tr.act_online.w["fc_a.weight"], tr.learner.online.w["fc_a.weight"]) or tr.num_update % 2 != 1
+
+
+def test_reference_named_mirrors():
+    """hanalearn.HanabiEnv / rela.RNNPrioritizedReplay / rela.aggregate_priority keep the reference call surface."""
+    from hanabi_sad_amd import hanalearn, rela
+    from oracle.oracle import OracleEnv, policy_random
+    params = {"players": "2", "hand_size": "5", "seed": "77", "bomb": "0"}
+    env = hanalearn.HanabiEnv(params, [0.1, 0.2], 80, True, False, False, False)
+    ref = OracleEnv(players=2, hand_size=5, seed=77, eps_list=[0.1, 0.2], max_len=80, sad=True)
+    assert (env.feature_size(), env.num_action(), env.hand_feature_size()) == (838, 21, 125)
+    assert env.terminated()
+    o, ro = env.reset(), ref.reset()
+    n = 0
+    while not ref.terminated():
+        assert np.array_equal(o["priv_s"].cpu().numpy(), ro["priv_s"]) and env.get_current_player() == ref.cur_player()
+        a, g = policy_random(ro["legal_move"], 3, 0, n)
+        assert all(env.move_is_legal(int(u)) == ref.move_is_legal(int(u)) for u in range(20))
+        o, r, t = env.step({"a": torch.tensor(a), "greedy_a": torch.tensor(g)})
+        ro, rr, rt = ref.step(a, g)
+        assert (r, t) == (rr, rt)
+        n += 1
+    assert env.terminated() and env.get_score() == ref.get("score") and env.last_score() == ref.get("last_score")
+    assert env.get_fireworks() == ref.fireworks() and env.get_life() == ref.get("life") and env.get_info() == ref.get("info")
+    assert len(env.deck_history()) == len(ref.deck_history())
+    p = torch.tensor([[1., 2], [3, 4], [5, 6]])
+    assert np.allclose(rela.aggregate_priority(p, torch.tensor([2., 3]), 0.9).numpy(), [2.9, 5.8], rtol=1e-6)
+    rep = rela.RNNPrioritizedReplay(64, 1, 0.9, 0.6, 3)
+    assert rep.size() == 0 and rep.num_add() == 0
