@@ -538,6 +538,44 @@ __device__ __forceinline__ uint64_t encode_last_action(int P, int H, uint32_t re
   return m;
 }
 
+// legal-move mask of player p in the current state (uids colour-permuted for that observer); noop iff nothing
+// else is legal (HanabiState::LegalMoves + cpp/hanabi_env.cc:171-191)
+template <int TH>
+__device__ __forceinline__ uint64_t legal_mask_of(int P, int H, int A, const uint32_t* s_st, int lane, int p, uint32_t pm) {
+  const uint32_t board = ST(PL_BOARD);
+  const int cur = board_cur(board), info = board_info(board);
+  uint64_t lm = 0;
+  if (p == cur) {
+    const uint32_t hw = ST(PLH(p));
+    const int len = (hw >> 25) & 7;
+    const uint64_t lenmask = (1ull << len) - 1ull;
+    if (info < 8) lm |= lenmask;
+    lm |= lenmask << H;
+    if (info > 0) {
+      for (int o = 1; o < P; ++o) {
+        int q = p + o;
+        if (q >= P) q -= P;
+        const uint32_t thw = ST(PLH(q));
+        const int tl = (thw >> 25) & 7;
+        uint32_t cm = 0, rm = 0;
+#pragma unroll
+        for (int i = 0; i < (TH ? TH : 5); ++i) {
+          const int card = (thw >> (5 * i)) & 31;
+          const int c = (card * 13) >> 6, r = card - 5 * c;
+          if (i < tl) {
+            cm |= 1u << perm_c(pm, c);
+            rm |= 1u << r;
+          }
+        }
+        lm |= (uint64_t)cm << (2 * H + (o - 1) * 5);
+        lm |= (uint64_t)rm << (2 * H + (P - 1) * 5 + (o - 1) * 5);
+      }
+    }
+  }
+  if (!lm) lm = 1ull << (A - 1);
+  return lm;
+}
+
 // Build the observation / legal-move / own-hand bit rows of this lane's game for every observer
 // (HanabiEnv::computeFeatureAndLegalMove, cpp/hanabi_env.cc:115-205, on top of the canonical encoder).
 template <int TP, int TH>
@@ -615,36 +653,7 @@ __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* 
     or_bits64(s_obs, base + (uint32_t)ep.OL, encode_last_action(P, H, lastmv, p, pm));
     if (ep.sad) or_bits64(s_obs, base + (uint32_t)ep.F0, encode_last_action(P, H, greedy_rec, p, pm));
 
-    // legal moves (uids colour-permuted for this observer), noop iff nothing else is legal
-    uint64_t lm = 0;
-    if (p == cur) {
-      const uint32_t hw = ST(PLH(p));
-      const int len = (hw >> 25) & 7;
-      const uint64_t lenmask = (1ull << len) - 1ull;
-      if (info < 8) lm |= lenmask;
-      lm |= lenmask << H;
-      if (info > 0) {
-        for (int o = 1; o < P; ++o) {
-          int q = p + o;
-          if (q >= P) q -= P;
-          const uint32_t thw = ST(PLH(q));
-          const int tl = (thw >> 25) & 7;
-          uint32_t cm = 0, rm = 0;
-#pragma unroll
-          for (int i = 0; i < (TH ? TH : 5); ++i) {
-            const int card = (thw >> (5 * i)) & 31;
-            const int c = (card * 13) >> 6, r = card - 5 * c;
-            if (i < tl) {
-              cm |= 1u << perm_c(pm, c);
-              rm |= 1u << r;
-            }
-          }
-          lm |= (uint64_t)cm << (2 * H + (o - 1) * 5);
-          lm |= (uint64_t)rm << (2 * H + (P - 1) * 5 + (o - 1) * 5);
-        }
-      }
-    }
-    if (!lm) lm = 1ull << (ep.A - 1);
+    const uint64_t lm = legal_mask_of<TH>(P, H, ep.A, s_st, lane, p, pm);
     or_bits64(s_legal, (uint32_t)(lane * P + p) * (uint32_t)ep.A, lm);
     ep.legal_bits[(size_t)g * P + p] = lm;
 
@@ -751,8 +760,11 @@ __device__ __forceinline__ int policy_pick(uint64_t seed, uint64_t game, uint64_
 // =================================================================================================
 // MODE 0: VectorEnv::reset — (re)start every finished/not-started game, rewrite only their rows.
 // MODE 1: VectorEnv::step  — apply a[g][cur] (and the SAD greedy move), deal, observe all games.
-// MODE 2: MODE 1 with the random-legal policy evaluated in-kernel (hsad_env_rollout_random); the sampled
-//         actions are also written to a_out/g_out so the trajectory matches policy kernel + MODE 1.
+// MODE 2: MODE 1 with the random-legal policy evaluated in-kernel; the sampled actions are also written to
+//         a_out/g_out so the trajectory matches policy kernel + MODE 1.
+// MODE 3: the whole thread-loop body in one launch (hsad_env_rollout_random): reset-if-terminated -> policy -> step.
+//         Same trajectories as MODE 0 + MODE 2; the observation of a freshly reset state is not materialised
+//         (nothing consumes it in the random-policy rollout).
 // TP/TH: compile-time players / hand size (0 = run-time values from EnvParams).
 // =================================================================================================
 template <int MODE, int TP, int TH>
@@ -775,12 +787,14 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   STAMP(0);
   const uint32_t misc0 = ep.planes[(size_t)PL_MISC * ep.Gpad + g];
   bool active;
+  const bool needs_reset = valid && (!((misc0 >> 15) & 1u) || ((misc0 >> 14) & 1u));
   if (MODE == 0) {
-    active = valid && (!((misc0 >> 15) & 1u) || ((misc0 >> 14) & 1u));
+    active = needs_reset;
     if (__ballot(active) == 0ull) return;
   } else {
     active = valid;
   }
+  const bool do_reset = (MODE == 0 || MODE == 3) && needs_reset;
   // stage all state planes in LDS; loads issued in batches of 8 so they overlap
   for (int pl0 = 0; pl0 < ep.npl; pl0 += 8) {
     uint32_t v[8];
@@ -812,13 +826,13 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   float reward = 0.f;
   bool term = false;
 
-  if (MODE == 0) {
+  if (MODE == 0 || MODE == 3) {
     // ---- prefetch window: every mt19937 word this reset will regenerate, in one round trip ----
     const int W = ep.win_w;
     uint32_t* winA = s_win + lane;                   // x[wbase + k],       k in [0, W]
     uint32_t* winB = s_win + (W + 1) * kWave + lane;  // x[wbase + k + 397], k in [0, W) -> new words
     const uint32_t wbase = rng.spos;
-    if (active) {
+    if (do_reset) {
       for (int k0 = 0; k0 <= W; k0 += 16) {
         uint32_t va[16], vb[16];
 #pragma unroll
@@ -893,7 +907,8 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       if (rng.w_c < rng.w_n) rng.spos = (wbase + (uint32_t)rng.w_c) % (uint32_t)kMtN;
       rng.w_n = rng.w_c;
     }
-  } else {
+  }
+  if (MODE != 0) {
     if (active) {
       uint32_t misc = ST(PL_MISC);
       const bool started = (misc >> 15) & 1u, was_term = (misc >> 14) & 1u;
@@ -904,12 +919,16 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
         log_error(ep, g, 3);  // assert(!terminated()) in HanabiEnv::step
       } else {
         int uid, guid = 0;
-        if (MODE == 2) {
+        if (MODE >= 2) {
           const uint32_t counter = ep.act_count[g];
           ep.act_count[g] = counter + 1u;
           uid = guid = 0;
           for (int p = 0; p < P; ++p) {
-            const uint64_t mask = ep.legal_bits[(size_t)g * P + p];
+            // legal bits of the state the policy acts on: the stored side output, or (MODE 3, game restarted a
+            // moment ago in this very launch) recomputed from the fresh state
+            const uint64_t mask = do_reset ? legal_mask_of<TH>(P, H, ep.A, s_st, lane, p,
+                                                               ep.shuffle_color ? (ST(PLPERM(p)) & 0x7fffu) : kIdentityPerm)
+                                           : ep.legal_bits[(size_t)g * P + p];
             const int pa = policy_pick(ep.policy_seed, (uint64_t)g, (uint64_t)counter, p, 0, mask);
             const int pg = policy_pick(ep.policy_seed, (uint64_t)g, (uint64_t)counter, p, 1, mask);
             ep.a_out[(size_t)g * P + p] = pa;
@@ -1234,6 +1253,12 @@ __global__ void export_state_kernel(EnvParams ep, int32_t* __restrict__ out, int
   }
 }
 
+// busy-wait of `ticks` x 10 ns (constant 100 MHz wall clock) used to offset partition chains
+__global__ void delay_kernel(long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 thread_local std::string g_last_error;
 
@@ -1265,6 +1290,7 @@ struct hsad_env {
   int device;
   // rollout partitions: independent game ranges on private streams so that one partition's
   // latency-bound phases overlap another partition's HBM-bound observation streaming
+  long long stagger_ns;  // initial offset between consecutive partition chains
   int n_part;         // streams created so far
   int n_part_active;  // partitions used by hsad_env_rollout_random (1 = caller's stream only)
   hipStream_t part_stream[16];
@@ -1278,13 +1304,25 @@ typedef void (*EnvKernelFn)(EnvParams, const int64_t*, const int64_t*);
 
 // compile-time (players, hand) specialisations; anything else runs the generic <0,0> instance
 EnvKernelFn pick_env_kernel(int mode, int P, int H) {
-  if (P == 2 && H == 5) return mode == 0 ? env_kernel<0, 2, 5> : (mode == 1 ? env_kernel<1, 2, 5> : env_kernel<2, 2, 5>);
-  return mode == 0 ? env_kernel<0, 0, 0> : (mode == 1 ? env_kernel<1, 0, 0> : env_kernel<2, 0, 0>);
+  if (P == 2 && H == 5) {
+    switch (mode) {
+      case 0: return env_kernel<0, 2, 5>;
+      case 1: return env_kernel<1, 2, 5>;
+      case 2: return env_kernel<2, 2, 5>;
+      default: return env_kernel<3, 2, 5>;
+    }
+  }
+  switch (mode) {
+    case 0: return env_kernel<0, 0, 0>;
+    case 1: return env_kernel<1, 0, 0>;
+    case 2: return env_kernel<2, 0, 0>;
+    default: return env_kernel<3, 0, 0>;
+  }
 }
 
 int configure_env_kernels(hsad_env* e) {
-  for (int mode = 0; mode < 3; ++mode) {
-    const size_t lds = mode ? e->lds_bytes : e->lds_bytes_reset;
+  for (int mode = 0; mode < 4; ++mode) {
+    const size_t lds = (mode == 1 || mode == 2) ? e->lds_bytes : e->lds_bytes_reset;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_env_kernel(mode, e->ep.P, e->ep.H)),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -1294,7 +1332,7 @@ int configure_env_kernels(hsad_env* e) {
 // launch one env kernel over games [g_begin, g_begin + g_count) (g_begin multiple of 64)
 void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipStream_t stream, int g_begin,
                 int g_count, uint64_t policy_seed = 0, int64_t* a_out = nullptr, int64_t* g_out = nullptr) {
-  const size_t lds = mode ? e->lds_bytes : e->lds_bytes_reset;
+  const size_t lds = (mode == 1 || mode == 2) ? e->lds_bytes : e->lds_bytes_reset;
   EnvParams ep = e->ep;
   ep.g_begin = g_begin;
   ep.g_count = g_count;
@@ -1373,6 +1411,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   e->device = cfg->device;
   e->bound = false;
   e->n_part = 0;
+  e->stagger_ns = 0;
   e->n_part_active = 1;
   e->fork = nullptr;
   if (e->lds_bytes_reset > 160 * 1024) {
@@ -1516,22 +1555,23 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
   const int K = e->n_part_active;
   const int blocks = e->ep.Gpad / kWave;
   if (K <= 1) {
-    for (int i = 0; i < n_iter; ++i) {
-      launch_env(e, 0, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad);
-      launch_env(e, 2, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a);
-    }
+    for (int i = 0; i < n_iter; ++i)
+      launch_env(e, 3, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a);
     HIP_TRY(hipGetLastError());
     return HSAD_OK;
   }
   // fork: every partition stream waits for the work already queued on the caller's stream
   HIP_TRY(hipEventRecord(e->fork, (hipStream_t)stream));
   for (int k = 0; k < K; ++k) HIP_TRY(hipStreamWaitEvent(e->part_stream[k], e->fork, 0));
+  // stagger the chains so that one partition's latency-bound logic overlaps another's HBM streaming
+  if (e->stagger_ns > 0)
+    for (int k = 1; k < K; ++k)
+      hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, e->part_stream[k], (long long)e->stagger_ns * k / 10);
   for (int i = 0; i < n_iter; ++i) {
     for (int k = 0; k < K; ++k) {
       const int b0 = (int)((long long)blocks * k / K), b1 = (int)((long long)blocks * (k + 1) / K);
       if (b1 <= b0) continue;
-      launch_env(e, 0, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave);
-      launch_env(e, 2, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a);
+      launch_env(e, 3, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1540,6 +1580,12 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
     HIP_TRY(hipEventRecord(e->part_done[k], e->part_stream[k]));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, e->part_done[k], 0));
   }
+  return HSAD_OK;
+}
+
+int hsad_env_set_rollout_stagger(hsad_env* e, int microseconds) {
+  if (!e || microseconds < 0) return set_error(HSAD_ERR_INVALID, "bad argument");
+  e->stagger_ns = (long long)microseconds * 1000;
   return HSAD_OK;
 }
 

@@ -97,6 +97,9 @@ class BatchedHanabiEnv:
         """Number of independent game ranges rollout_random overlaps on private HIP streams."""
         _lib.check(self.lib.hsad_env_set_partitions(self.h, int(n_part)))
 
+    def set_rollout_stagger(self, microseconds):
+        _lib.check(self.lib.hsad_env_set_rollout_stagger(self.h, int(microseconds)))
+
     def query(self):
         out = torch.zeros(self.G, 16, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.hsad_env_query(self.h, out.data_ptr(), self._stream()))

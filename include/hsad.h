@@ -96,8 +96,9 @@ int hsad_env_step(hsad_env* env, const int64_t* a, const int64_t* greedy_a, void
 int hsad_env_policy_random(hsad_env* env, uint64_t policy_seed, int64_t* a, int64_t* greedy_a, void* stream);
 
 /* n_iter iterations of the reference thread loop body (cpp/thread_loop.h:46-72) for all games:
- * reset-terminated -> random policy -> step (policy evaluated inside the step kernel; the sampled
- * a / greedy_a are still written to the given tensors).  Launch-only; returns before the GPU finishes. */
+ * reset-terminated -> random policy -> step, fused into ONE launch per iteration (the sampled a / greedy_a are
+ * still written to the given tensors; trajectories are identical to hsad_env_reset + hsad_env_policy_random +
+ * hsad_env_step).  Launch-only; returns before the GPU finishes. */
 int hsad_env_rollout_random(hsad_env* env, int n_iter, uint64_t policy_seed, int64_t* a, int64_t* greedy_a,
                             void* stream);
 
@@ -106,6 +107,9 @@ int hsad_env_rollout_random(hsad_env* env, int n_iter, uint64_t policy_seed, int
  * overlap another range's HBM-bound observation streaming.  Results are unaffected (games are
  * independent).  Default 1 = everything on the caller's stream. */
 int hsad_env_set_partitions(hsad_env* env, int n_part);
+
+/* initial offset (microseconds) between consecutive partition chains of hsad_env_rollout_random */
+int hsad_env_set_rollout_stagger(hsad_env* env, int microseconds);
 
 /* Per-game scalars, device int32 [G, HSAD_QUERY_WORDS]:
  * terminated(), getCurrentPlayer(), getScore(), getLife(), getInfo(), lastScore(), numStep,
