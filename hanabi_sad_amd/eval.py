@@ -1,0 +1,67 @@
+"""Batched evaluation and checkpoints.
+
+`evaluate` = pyhanabi/eval.py:19-66: `num_game` fresh games (seed+game_idx, max_len = -1, eps = 0), every player
+acts greedily, score = last_score(); the reference spins one thread per game, here all games advance in
+lock-step on the GPU and finished games simply stop acting.
+`save_weights` / `load_weights` keep the reference's `.pthw` format: torch.save(online_net.state_dict())
+with the key names net.0.*, lstm.*_l{0,1}, fc_v.*, fc_a.*, pred.* (common_utils/saver.py:17-61; utils.py:278-299)."""
+import numpy as np
+import torch
+
+from .env import BatchedHanabiEnv
+from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2NetKernels, zero_hidden_rows
+
+
+def evaluate(weights, num_game, seed, bomb, sad, *, num_player=2, hand_size=5, device="cuda:0", max_steps=200):
+    """-> (mean score, fraction of perfect games, scores list, num perfect) like eval.evaluate"""
+    env = BatchedHanabiEnv(num_game, players=num_player, hand_size=hand_size, seed=seed, bomb=bomb, eps_list=[0.0],
+                           max_len=-1, sad=bool(sad), device=device, track_deck_history=False)
+    net = R2D2NetKernels(weights, device)
+    agent = R2D2Agent(net, net, 1, 0.99)
+    N = num_game * num_player
+    hid = agent.get_h0(N)
+    env.reset()
+    done = torch.zeros(num_game, dtype=torch.bool, device=device)
+    noop = env.A - 1
+    for _ in range(max_steps):
+        obs = {"priv_s": env.priv_s.view(N, env.F), "legal_move": env.legal_move.view(N, env.A), "eps": env.eps.view(N)}
+        reply, hid = agent.act(obs, hid)
+        a = reply["a"].view(num_game, num_player)
+        # finished games may not be stepped again (HanabiEnv::step asserts !terminated()): park them on a copy that
+        # the kernel ignores by keeping their state untouched -> step only the live ones through a masked action
+        q = env.query()
+        done = q[:, 0] == 1
+        if bool(done.all()):
+            break
+        live = ~done
+        if bool(live.all()):
+            env.step(a.contiguous(), reply["greedy_a"].view(num_game, num_player).contiguous())
+        else:
+            # lock-step with stragglers: finished games receive an (ignored) illegal noop and are skipped by the
+            # error log below; their last_score is already latched
+            aa = torch.where(live.unsqueeze(1), a, torch.full_like(a, noop)).contiguous()
+            env.step(aa, aa)
+            n, g, c = _drain_errors(env)
+    scores = env.query()[:, 5].cpu().numpy().astype(np.int64)
+    perfect = int((scores == 25).sum())
+    return float(scores.mean()), perfect / num_game, scores.tolist(), perfect
+
+
+def _drain_errors(env):
+    import ctypes as C
+    n, g, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    env.lib.hsad_env_error_count(env.h, C.byref(n), C.byref(g), C.byref(c))
+    return n.value, g.value, c.value
+
+
+def save_weights(weights, path):
+    """online_net.state_dict() in the reference's key names -> `.pthw`"""
+    torch.save({k: weights[k].detach().cpu().clone() for k in PARAM_ORDER}, path)
+
+
+def load_weights(path, device="cpu"):
+    sd = torch.load(path, map_location=device)
+    missing = [k for k in PARAM_ORDER if k not in sd]
+    if missing:
+        raise KeyError("checkpoint lacks %s (expected R2D2Net.state_dict() keys)" % missing)
+    return {k: sd[k].float() for k in PARAM_ORDER}

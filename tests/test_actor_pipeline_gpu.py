@@ -72,3 +72,20 @@ def test_reference_named_mirrors():
     assert np.allclose(rela.aggregate_priority(p, torch.tensor([2., 3]), 0.9).numpy(), [2.9, 5.8], rtol=1e-6)
     rep = rela.RNNPrioritizedReplay(64, 1, 0.9, 0.6, 3)
     assert rep.size() == 0 and rep.num_add() == 0
+
+
+def test_batched_greedy_evaluation_and_checkpoint_roundtrip(tmp_path):
+    """eval.evaluate semantics (fresh games, eps = 0, max_len = -1, greedy) + `.pthw` key compatibility."""
+    from hanabi_sad_amd.eval import evaluate, load_weights, save_weights
+    from hanabi_sad_amd.selfplay import init_weights
+    W = init_weights(838, 64, 21, 5, seed=3)
+    path = str(tmp_path / "model0.pthw")
+    save_weights(W, path)
+    sd = torch.load(path)
+    assert list(sd.keys())[:2] == ["net.0.weight", "net.0.bias"] and sd["lstm.weight_hh_l1"].shape == (256, 64)
+    W2 = load_weights(path)
+    assert all(torch.equal(W[k], W2[k]) for k in W)
+    mean, perfect, scores, n_perfect = evaluate(W2, 200, seed=9917, bomb=0, sad=True, device="cuda:0")
+    assert len(scores) == 200 and all(0 <= s <= 25 for s in scores) and 0 <= mean <= 25
+    mean2, _, scores2, _ = evaluate(W2, 200, seed=9917, bomb=0, sad=True, device="cuda:0")
+    assert scores == scores2                      # deterministic: greedy policy, fixed seeds
