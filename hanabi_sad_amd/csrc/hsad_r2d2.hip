@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
       dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
     }
-    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < a.T - 1) {
       if (tid == 0) {
         unsigned* ctr = a.counters + (size_t)(t + 1) * nrb + rb;
@@ -672,25 +672,51 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       }
       __syncthreads();
       if (!*s_okp) return;
-      const bf16x8* grow = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + min(row_l, a.Bn - 1)) * K + kofs);
-      const bf16_t* wrow = sW + (wu * 16 + (lane & 15)) * WS + kofs;
-      constexpr int CH = 16;
-#pragma unroll 1
-      for (int c0 = 0; c0 < KB; c0 += CH) {
-        bf16x8 fa[CH];
+      // K-split: wave w multiplies k-blocks [w*KB/4, (w+1)*KB/4) for the whole 32x32 block tile (2x2 MFMA tiles),
+      // so every dG fragment is fetched from L2 exactly once per workgroup; partial tiles meet in LDS.
+      constexpr int KQ = KB / 4;
+      const int row0 = min(rb * 32 + (lane & 15), a.Bn - 1), row1 = min(rb * 32 + 16 + (lane & 15), a.Bn - 1);
+      const bf16x8* g0 = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row0) * K + kofs);
+      const bf16x8* g1 = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row1) * K + kofs);
+      const bf16_t* w0 = sW + (lane & 15) * WS + kofs;
+      const bf16_t* w1 = sW + (16 + (lane & 15)) * WS + kofs;
+      f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+      bf16x8 fa0[KQ], fa1[KQ];
 #pragma unroll
-        for (int it = 0; it < CH; ++it) fa[it] = __builtin_nontemporal_load(grow + (c0 + it) * 4);
+      for (int it = 0; it < KQ; ++it) {
+        fa0[it] = __builtin_nontemporal_load(g0 + (wave * KQ + it) * 4);
+        fa1[it] = __builtin_nontemporal_load(g1 + (wave * KQ + it) * 4);
+      }
 #pragma unroll
-        for (int it = 0; it < CH; it += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it], *reinterpret_cast<const bf16x8*>(wrow + (c0 + it) * 32), acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[it + 1], *reinterpret_cast<const bf16x8*>(wrow + (c0 + it + 1) * 32), acc1, 0, 0, 0);
-        }
+      for (int it = 0; it < KQ; ++it) {
+        const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (wave * KQ + it) * 32);
+        const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (wave * KQ + it) * 32);
+        p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[it], fb0, p00, 0, 0, 0);
+        p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[it], fb1, p01, 0, 0, 0);
+        p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[it], fb0, p10, 0, 0, 0);
+        p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[it], fb1, p11, 0, 0, 0);
+      }
+      // sRed[wave][tile][lane] (f32x4): tile = wr*2 + wu
+      f32x4* sRed = reinterpret_cast<f32x4*>(s_okp + 4);
+      sRed[(wave * 4 + 0) * 64 + lane] = p00;
+      sRed[(wave * 4 + 1) * 64 + lane] = p01;
+      sRed[(wave * 4 + 2) * 64 + lane] = p10;
+      sRed[(wave * 4 + 3) * 64 + lane] = p11;
+      __syncthreads();
+      const int tile = wr * 2 + wu;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const f32x4 v = sRed[(w * 4 + tile) * 64 + lane];
+        accf[0] += v[0];
+        accf[1] += v[1];
+        accf[2] += v[2];
+        accf[3] += v[3];
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float gi = g4[r][0], gf = g4[r][1], gg = g4[r][2], go = g4[r][3];
-      const float dh = dov[r] + acc0[r] + acc1[r];
+      const float dh = dov[r] + accf[r];
       const float tc = tanhf_(cc[r]);
       const float d_o = dh * tc;
       const float dct = dcs[r] + dh * go * (1.f - tc * tc);
@@ -1283,7 +1309,7 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
     unsigned* counters = (unsigned*)sync_scratch;
     HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb + 4), s));
     LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H};
-    const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16;
+    const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
     const dim3 grid(H / 32, nrb);
     if (H == 512) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>),

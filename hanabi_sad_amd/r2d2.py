@@ -315,20 +315,34 @@ class R2D2Learner:
                                            A, on.NP, float(pred_weight) / B if own is not None else 0.0,
                                            dheads.data_ptr(), dheads.stride(0), _s(d)))
         hseq = [h.view(M, H) for h in keep["hseq"]]
-        zero_h = torch.zeros(B, H, dtype=torch.bfloat16, device=d)
-        hprevT = [transpose_pad(torch.cat([zero_h, h[:M - B]], 0), Mp) for h in hseq]   # h_{t-1} (h_{-1} = 0)
-        # heads: dW = dheads^T @ o ; db = colsum ; dO1 = dheads @ Wheads
-        dheadsT = transpose_pad(dheads, Mp)                                              # [NHp, Mp]
-        o1T = transpose_pad(hseq[1], Mp)                                                 # [H, Mp]
-        dWh = torch.zeros(self.NHp, H, dtype=torch.float32, device=d)
-        gemm_nt_ex(dheadsT, o1T, self.NHp, H, Mp, out32=dWh, split_k=8)
-        dbh = colsum(dheads)
         g = self.grad
-        g["fc_a.weight"].copy_(dWh[:A]); g["fc_v.weight"].copy_(dWh[A:A + 1]); g["pred.weight"].copy_(dWh[A + 1:on.NH])
-        g["fc_a.bias"].copy_(dbh[:A]); g["fc_v.bias"].copy_(dbh[A:A + 1]); g["pred.bias"].copy_(dbh[A + 1:on.NH])
+        side = self.side
+        held = []   # tensors consumed on the side stream (kept alive / stream-recorded until the join)
+
+        def on_side(fn):
+            """weight-gradient work is off the critical path: run it on the side stream while the main stream
+            continues with the next layer's BPTT (the persistent recurrence kernels only occupy 64 CUs)"""
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fn()
+
+        # heads: dO1 = dheads @ Wheads on the main stream; dW / db on the side stream
         dO = torch.empty(M, H, dtype=torch.float32, device=d)
         gemm_nt_ex(dheads, self.WheadsT, M, H, self.NHp, out32=dO)
-        layer_in_T = [transpose_pad(keep["x1"], Mp), transpose_pad(hseq[0], Mp)]         # inputs of layer 0 / 1, [H, Mp]
+
+        def heads_wgrad():
+            dheadsT = transpose_pad(dheads, Mp)                                          # [NHp, Mp]
+            o1T = transpose_pad(hseq[1], Mp)                                             # [H, Mp]
+            dWh = torch.zeros(self.NHp, H, dtype=torch.float32, device=d)
+            gemm_nt_ex(dheadsT, o1T, self.NHp, H, Mp, out32=dWh, split_k=8)
+            dbh = colsum(dheads)
+            g["fc_a.weight"].copy_(dWh[:A]); g["fc_v.weight"].copy_(dWh[A:A + 1]); g["pred.weight"].copy_(dWh[A + 1:on.NH])
+            g["fc_a.bias"].copy_(dbh[:A]); g["fc_v.bias"].copy_(dbh[A:A + 1]); g["pred.bias"].copy_(dbh[A + 1:on.NH])
+            held.extend([dheadsT, o1T, dWh, dbh])
+        on_side(heads_wgrad)
+        zero_h = torch.zeros(B, H, dtype=torch.bfloat16, device=d)
+        layer_in = [keep["x1"], hseq[0]]                                                 # inputs of layer 0 / 1
+        dx1 = None
         for l in (1, 0):
             dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
             dc = torch.empty(B, H, dtype=torch.float32, device=d)
@@ -337,28 +351,41 @@ class R2D2Learner:
                                                     self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
                                                     sync.data_ptr() if self.persistent else None, _s(d)))
             dG2 = dG[:T].view(M, 4 * H)
-            dGT = transpose_pad(dG2, Mp)                                                 # [4H, Mp]
-            dWih = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
-            dWhh = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
-            gemm_nt_ex(dGT, layer_in_T[l], 4 * H, H, Mp, out32=dWih, split_k=8)
-            gemm_nt_ex(dGT, hprevT[l], 4 * H, H, Mp, out32=dWhh, split_k=8)
-            db = colsum(dG2)
-            g["lstm.weight_ih_l%d" % l].copy_(dWih[self.inv_perm])
-            g["lstm.weight_hh_l%d" % l].copy_(dWhh[self.inv_perm])
-            g["lstm.bias_ih_l%d" % l].copy_(db[self.inv_perm])
-            g["lstm.bias_hh_l%d" % l].copy_(db[self.inv_perm])
             if l == 1:
                 dO = torch.empty(M, H, dtype=torch.float32, device=d)
                 gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
             else:
                 dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
                 gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
-        dx1T = transpose_pad(dx1, Mp)                                                    # [H, Mp]
-        a16T = transpose_pad(keep["a16"], Mp)                                            # [Fp, Mp]
-        dW1 = torch.zeros(H, on.Fp, dtype=torch.float32, device=d)
-        gemm_nt_ex(dx1T, a16T, H, on.Fp, Mp, out32=dW1, split_k=8)
-        g["net.0.weight"].copy_(dW1[:, :on.F])
-        g["net.0.bias"].copy_(colsum(dx1))
+
+            def layer_wgrad(l=l, dG2=dG2, dG=dG):
+                dGT = transpose_pad(dG2, Mp)                                             # [4H, Mp]
+                inT = transpose_pad(layer_in[l], Mp)                                     # [H, Mp]
+                hprevT = transpose_pad(torch.cat([zero_h, hseq[l][:M - B]], 0), Mp)      # h_{t-1} (h_{-1} = 0)
+                dWih = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
+                dWhh = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
+                gemm_nt_ex(dGT, inT, 4 * H, H, Mp, out32=dWih, split_k=8)
+                gemm_nt_ex(dGT, hprevT, 4 * H, H, Mp, out32=dWhh, split_k=8)
+                db = colsum(dG2)
+                g["lstm.weight_ih_l%d" % l].copy_(dWih[self.inv_perm])
+                g["lstm.weight_hh_l%d" % l].copy_(dWhh[self.inv_perm])
+                g["lstm.bias_ih_l%d" % l].copy_(db[self.inv_perm])
+                g["lstm.bias_hh_l%d" % l].copy_(db[self.inv_perm])
+                held.extend([dGT, inT, hprevT, dWih, dWhh, db, dG])
+            on_side(layer_wgrad)
+
+        def input_wgrad():
+            dx1T = transpose_pad(dx1, Mp)                                                # [H, Mp]
+            a16T = transpose_pad(keep["a16"], Mp)                                        # [Fp, Mp]
+            dW1 = torch.zeros(H, on.Fp, dtype=torch.float32, device=d)
+            gemm_nt_ex(dx1T, a16T, H, on.Fp, Mp, out32=dW1, split_k=8)
+            g["net.0.weight"].copy_(dW1[:, :on.F])
+            g["net.0.bias"].copy_(colsum(dx1))
+            held.extend([dx1T, a16T, dW1])
+        on_side(input_wgrad)
+        main.wait_stream(side)
+        for t_ in held:
+            t_.record_stream(main)
         return loss, prio
 
     def optimizer_step(self, beta1=0.9, beta2=0.999):
