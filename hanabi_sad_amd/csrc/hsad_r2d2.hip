@@ -558,11 +558,13 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb].v, fb, acc[j], 0, 0, 0);
       }
     }
-    // cell update (fp32), h tile staged in LDS for wide write-through stores
+    // cell update (fp32), h tile staged in LDS for wide write-through stores.  Only the h tile is on the other
+    // workgroups' critical path: it is published first; the block-local gate / cell-state stores (22 KB headed
+    // for HBM) are issued after the signal so their latency hides behind the next step's wait.
     float* ct = a.cseq + (size_t)t * a.Bn * H;
+    float keep_g[4][4], keep_h[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = rbase + r;
       const float gi = sigmoidf_(acc[0][r] + pre[r][0]);
       const float gf = sigmoidf_(acc[1][r] + pre[r][1]);
       const float gg = tanhf_(acc[2][r] + pre[r][2]);
@@ -570,16 +572,12 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
       const float c = gf * cst[r] + gi * gg;
       const float h = go * tanhf_(c);
       cst[r] = c;
+      keep_g[r][0] = gi;
+      keep_g[r][1] = gf;
+      keep_g[r][2] = gg;
+      keep_g[r][3] = go;
+      keep_h[r] = h;
       sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
-      if (row < a.Bn) {
-        float* gp = gt + (size_t)row * 4 * H + ucol;
-        gp[0] = gi;
-        gp[32] = gf;
-        gp[64] = gg;
-        gp[96] = go;
-        ct[(size_t)row * H + u] = c;
-        if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = h;
-      }
     }
     __syncthreads();
     {  // 32 rows x 32 units bf16 = 256 x 8 bytes
@@ -595,8 +593,22 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
     __syncthreads();
     if (tid == 0 && t + 1 < a.T)
       __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r;
+      if (row < a.Bn) {
+        float* gp = gt + (size_t)row * 4 * H + ucol;
+        gp[0] = keep_g[r][0];
+        gp[32] = keep_g[r][1];
+        gp[64] = keep_g[r][2];
+        gp[96] = keep_g[r][3];
+        ct[(size_t)row * H + u] = cst[r];
+        if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = keep_h[r];
+      }
+    }
   }
 }
+
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent BPTT through one LSTM layer: same workgroup grid / exchange protocol as lstm_seq_fwd_kernel.
