@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -62,7 +63,7 @@ struct EnvParams {
   int G, Gpad, P, H, A, F, F0, LAL, OB, OD, OL, OK, DECKW;
   int max_len, sad, shuffle_color, bomb, kmode, n_eps, track_dh, npl;
   int obs_words, legal_words, own_words, win_w;
-  int seed0, deal_mode;
+  int seed0, deal_mode, nt_stores;
   int g_begin, g_count;            // launch covers games [g_begin, g_begin + g_count); g_begin % 64 == 0
   unsigned long long policy_seed;  // MODE 2 (step with built-in random-legal policy)
   int64_t* a_out;                  // MODE 2: where the sampled actions are recorded ([G,P] each)
@@ -499,10 +500,21 @@ __device__ __forceinline__ void stream_bits_f32(const uint32_t* bits, uint32_t b
 
 // Same, for the wave-wide aligned case (bit0 == 0, out 16-byte aligned): every lane reads one 32-bit word
 // of bits and emits 8 consecutive float4 — 128 B per lane per iteration, 8 KiB per wave-iteration.
-__device__ __forceinline__ void stream_bits_f32_aligned(const uint32_t* bits, float* out, uint32_t n, int lane) {
+template <bool NT>
+__device__ __forceinline__ void stream_bits_f32_aligned(const uint32_t* bits, float* out, uint32_t n, int lane,
+                                                        int nthreads = kWave) {
   float4* o4 = reinterpret_cast<float4*>(out);
   const uint32_t nch = n >> 2;
-  for (uint32_t k = lane; k < nch; k += kWave) o4[k] = nib_to_f4((bits[k >> 3] >> ((k & 7u) * 4u)) & 15u);
+  for (uint32_t k = lane; k < nch; k += nthreads) {
+    const float4 v = nib_to_f4((bits[k >> 3] >> ((k & 7u) * 4u)) & 15u);
+    if (NT) {
+      typedef float nt_f4 __attribute__((ext_vector_type(4)));
+      nt_f4 w = {v.x, v.y, v.z, v.w};
+      __builtin_nontemporal_store(w, reinterpret_cast<nt_f4*>(o4 + k));
+    } else {
+      o4[k] = v;
+    }
+  }
   const uint32_t done = nch << 2;
   if ((uint32_t)lane < n - done) out[done + lane] = get1(bits, done + lane) ? 1.f : 0.f;
 }
@@ -580,7 +592,8 @@ __device__ __forceinline__ uint64_t legal_mask_of(int P, int H, int A, const uin
 // (HanabiEnv::computeFeatureAndLegalMove, cpp/hanabi_env.cc:115-205, on top of the canonical encoder).
 template <int TP, int TH>
 __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* s_st, int lane, int g, uint32_t* s_obs,
-                                           uint32_t* s_legal, uint32_t* s_own, uint32_t greedy_rec) {
+                                           uint32_t* s_legal, uint32_t* s_own, uint32_t greedy_rec, int p_begin,
+                                           int p_step) {
   const int P = TP ? TP : ep.P, H = TH ? TH : ep.H;
   const uint32_t board = ST(PL_BOARD);
   const uint32_t misc = ST(PL_MISC);
@@ -591,9 +604,7 @@ __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* 
   const int info = board_info(board), life = board_life(board);
   const uint32_t F = (uint32_t)ep.F;
 
-#pragma unroll
-  for (int p = 0; p < (TP ? TP : 5); ++p) {
-    if (p >= P) break;
+  for (int p = p_begin; p < P; p += p_step) {
     const uint32_t base = (uint32_t)(lane * P + p) * F;
     const uint32_t pm = ep.shuffle_color ? (ST(PLPERM(p)) & 0x7fffu) : kIdentityPerm;
     uint32_t miss = 0;
@@ -767,17 +778,22 @@ __device__ __forceinline__ int policy_pick(uint64_t seed, uint64_t game, uint64_
 //         (nothing consumes it in the random-policy rollout).
 // TP/TH: compile-time players / hand size (0 = run-time values from EnvParams).
 // =================================================================================================
+constexpr int kEnvThreads = 2 * kWave;  // wave 0: game logic; wave 1: LDS zeroing; both: row building + streaming
+
 template <int MODE, int TP, int TH>
-__global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t* __restrict__ a_in,
-                                                    const int64_t* __restrict__ g_in) {
+__global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const int64_t* __restrict__ a_in,
+                                                          const int64_t* __restrict__ g_in) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* s_st = smem;
   uint32_t* s_obs = s_st + ep.npl * kWave;
   uint32_t* s_legal = s_obs + ep.obs_words;
   uint32_t* s_own = s_legal + ep.legal_words;
   uint32_t* s_win = s_own + ep.own_words;  // reset kernel only: [2*win_w+1][kWave]
+  uint32_t* s_grec = s_win + (MODE == 0 || MODE == 3 ? (2 * ep.win_w + 1) * kWave : 0);  // [kWave] SAD greedy records
 
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
   const int g0 = ep.g_begin + blockIdx.x * kWave;
   const int g = g0 + lane;
   const bool valid = g < ep.G;
@@ -795,16 +811,18 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
     active = valid;
   }
   const bool do_reset = (MODE == 0 || MODE == 3) && needs_reset;
-  // stage all state planes in LDS; loads issued in batches of 8 so they overlap
-  for (int pl0 = 0; pl0 < ep.npl; pl0 += 8) {
-    uint32_t v[8];
+  // wave 0 stages all state planes in LDS (loads issued in batches of 8 so they overlap);
+  // wave 1 meanwhile clears the bit-row buffers
+  if (wave == 0) {
+    for (int pl0 = 0; pl0 < ep.npl; pl0 += 8) {
+      uint32_t v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = ep.planes[(size_t)min(pl0 + j, ep.npl - 1) * ep.Gpad + g];
+      for (int j = 0; j < 8; ++j) v[j] = ep.planes[(size_t)min(pl0 + j, ep.npl - 1) * ep.Gpad + g];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (pl0 + j < ep.npl) ST(pl0 + j) = v[j];
-  }
-  {
+      for (int j = 0; j < 8; ++j)
+        if (pl0 + j < ep.npl) ST(pl0 + j) = v[j];
+    }
+  } else {
     const int nz = ep.obs_words + ep.legal_words + ep.own_words;
     uint4* z4 = reinterpret_cast<uint4*>(s_obs);
     for (int k = lane; k < (nz >> 2); k += kWave) z4[k] = make_uint4(0u, 0u, 0u, 0u);
@@ -826,6 +844,7 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   float reward = 0.f;
   bool term = false;
 
+  if (wave == 0) {
   if (MODE == 0 || MODE == 3) {
     // ---- prefetch window: every mt19937 word this reset will regenerate, in one round trip ----
     const int W = ep.win_w;
@@ -1045,14 +1064,18 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
       }
     }
   }
+    s_grec[lane] = greedy_rec;
+  }
+  __syncthreads();
   STAMP(2);
 
-  // look-ahead refill: loads go out now and are consumed after the rows are built
+  // look-ahead refill (wave 0): loads go out now and are consumed after the rows are built
   Refill rf;
-  refill_issue(rf, rng, active);
-  if (active) build_rows<TP, TH>(ep, s_st, lane, g, s_obs, s_legal, s_own, greedy_rec);
+  refill_issue(rf, rng, active && wave == 0);
+  // both waves build rows: wave w takes observers w, w+2, ...
+  if (active) build_rows<TP, TH>(ep, s_st, lane, g, s_obs, s_legal, s_own, s_grec[lane], wave, 2);
   STAMP(3);
-  if (active) {
+  if (active && wave == 0) {
     refill_finish(rf, rng);
     ST(PL_DRAWS) = rng.draws;
     ST(PL_LA0) = rng.la0;
@@ -1067,19 +1090,24 @@ __global__ __launch_bounds__(kWave) void env_kernel(EnvParams ep, const int64_t*
   const size_t PF = (size_t)P * ep.F, PA = (size_t)P * ep.A, PO = (size_t)P * 3 * H;
   if (MODE >= 1) {
     // all ng games of the wave: one contiguous, 16-byte aligned range per output tensor
-    stream_bits_f32_aligned(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), lane);
-    stream_bits_f32_aligned(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), lane);
-    stream_bits_f32_aligned(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), lane);
-    if (valid) {
+    if (ep.nt_stores) {
+      stream_bits_f32_aligned<true>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
+    } else {
+      stream_bits_f32_aligned<false>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
+    }
+    stream_bits_f32_aligned<false>(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), tid, kEnvThreads);
+    stream_bits_f32_aligned<false>(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), tid, kEnvThreads);
+    if (valid && wave == 0) {
       for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(PLEPS(p)));
       ep.reward[g] = reward;
       ep.terminal[g] = term ? 1 : 0;
     }
     if (ep.kmode == 1) {
       __syncthreads();
-      v0_fixup(ep, s_st, s_obs, __ballot(valid), g0, lane);
+      if (wave == 0) v0_fixup(ep, s_st, s_obs, __ballot(valid), g0, lane);
     }
   } else {
+    if (wave != 0) return;  // the reset kernel streams a handful of games per block: one wave is plenty
     uint64_t todo = __ballot(active);
     const uint64_t todo_all = todo;
     while (todo) {
@@ -1339,8 +1367,8 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
   ep.policy_seed = policy_seed;
   ep.a_out = a_out;
   ep.g_out = g_out;
-  hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kWave), lds, stream,
-                     ep, a, g);
+  hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds,
+                     stream, ep, a, g);
 }
 
 }  // namespace
@@ -1394,7 +1422,8 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   ep.track_dh = cfg->track_deck_history ? 1 : 0;
   ep.npl = PL_FIXED + 6 * P;
   ep.seed0 = cfg->seed0;
-  ep.deal_mode = cfg->deal_mode ? 1 : 0;  // 1 = always take the literal fp64 discrete_distribution path
+  ep.deal_mode = cfg->deal_mode ? 1 : 0;
+  ep.nt_stores = getenv("HSAD_NT_STORES") ? atoi(getenv("HSAD_NT_STORES")) : 1;  // write-once obs stream: bypass L2 residency  // 1 = always take the literal fp64 discrete_distribution path
   {
     const int n_static = 2 * P * H + P + (ep.shuffle_color ? 1 + 2 * (P - 1) : 0);
     ep.win_w = n_static + 2 < 64 ? n_static + 2 : 64;
@@ -1406,7 +1435,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   ep.obs_words = (ep.obs_words + 3) & ~3;
   ep.legal_words = (ep.legal_words + 3) & ~3;
   ep.own_words = (ep.own_words + 3) & ~3;
-  e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words);
+  e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words + kWave);
   e->lds_bytes_reset = e->lds_bytes + sizeof(uint32_t) * (size_t)(2 * ep.win_w + 1) * kWave;
   e->device = cfg->device;
   e->bound = false;
