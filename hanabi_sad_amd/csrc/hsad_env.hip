@@ -790,6 +790,7 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   uint32_t* s_own = s_legal + ep.legal_words;
   uint32_t* s_win = s_own + ep.own_words;  // reset kernel only: [2*win_w+1][kWave]
   uint32_t* s_grec = s_win + (MODE == 0 || MODE == 3 ? (2 * ep.win_w + 1) * kWave : 0);  // [kWave] SAD greedy records
+  float* s_eps = reinterpret_cast<float*>(s_grec + kWave);  // [min(n_eps, 128)] copy of the eps list (reset only)
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -827,6 +828,8 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
     uint4* z4 = reinterpret_cast<uint4*>(s_obs);
     for (int k = lane; k < (nz >> 2); k += kWave) z4[k] = make_uint4(0u, 0u, 0u, 0u);
     for (int k = (nz & ~3) + lane; k < nz; k += kWave) s_obs[k] = 0u;
+    if (MODE == 0 || MODE == 3)
+      for (int k = lane; k < min(ep.n_eps, 128); k += kWave) s_eps[k] = ep.eps_list[k];
   }
   __syncthreads();
   STAMP(1);
@@ -852,22 +855,35 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
     uint32_t* winB = s_win + (W + 1) * kWave + lane;  // x[wbase + k + 397], k in [0, W) -> new words
     const uint32_t wbase = rng.spos;
     if (do_reset) {
-      for (int k0 = 0; k0 <= W; k0 += 16) {
-        uint32_t va[16], vb[16];
+      if (W <= 32) {
+        // one batch: all 2W+1 words in flight together, regenerated in registers, only the new words go to LDS
+        uint32_t va[33], vb[32];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const uint32_t k = (uint32_t)min(k0 + j, W);
-          va[j] = rng.mt[(wbase + k) % (uint32_t)kMtN];
-          vb[j] = rng.mt[(wbase + k + kMtM) % (uint32_t)kMtN];
-        }
+        for (int j = 0; j < 33; ++j) va[j] = rng.mt[(wbase + (uint32_t)min(j, W)) % (uint32_t)kMtN];
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (k0 + j <= W) {
-            winA[(k0 + j) * kWave] = va[j];
-            if (k0 + j < W) winB[(k0 + j) * kWave] = vb[j];
+        for (int j = 0; j < 32; ++j) vb[j] = rng.mt[(wbase + (uint32_t)min(j, W) + kMtM) % (uint32_t)kMtN];
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+          if (j < W) winB[j * kWave] = mt_twist(va[j], va[j + 1], vb[j]);
+      } else {
+        for (int k0 = 0; k0 <= W; k0 += 16) {
+          uint32_t va[16], vb[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const uint32_t k = (uint32_t)min(k0 + j, W);
+            va[j] = rng.mt[(wbase + k) % (uint32_t)kMtN];
+            vb[j] = rng.mt[(wbase + k + kMtM) % (uint32_t)kMtN];
           }
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (k0 + j <= W) {
+              winA[(k0 + j) * kWave] = va[j];
+              if (k0 + j < W) winB[(k0 + j) * kWave] = vb[j];
+            }
+        }
+        for (int k = 0; k < W; ++k) winB[k * kWave] = mt_twist(winA[k * kWave], winA[(k + 1) * kWave], winB[k * kWave]);
       }
-      for (int k = 0; k < W; ++k) winB[k * kWave] = mt_twist(winA[k * kWave], winA[(k + 1) * kWave], winB[k * kWave]);
+      STAMP(6);
       rng.win = winB;
       rng.w_n = W;
       rng.spos = (wbase + (uint32_t)W) % (uint32_t)kMtN;
@@ -881,16 +897,37 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
       ST(PL_BOARD) = (8u << 15) | (3u << 19) | ((uint32_t)P << 21) | (0u << 24) | (0u << 27);
       ST(PL_MISC) = (ST(PL_MISC) & (63u << 16)) | (50u << 8) | (1u << 15);  // keep last_score; started
       ST(PL_LASTMV) = 0;
-      for (int p = 0; p < P; ++p) {
-        ST(PLH(p)) = 0;
-        ST(PLKCP(p)) = 0;
-        ST(PLKRP(p)) = 0;
-        ST(PLKH(p)) = 0;
+      {
+        // initial deal (ApplyRandomChance until every hand is full: players in seat order, H cards each) with the
+        // deck and the hand being filled held in registers — one LDS store per plane at the end instead of ~35
+        // dependent LDS round trips per card
+        uint64_t dk = deck;
+        int dsize = 50;
+        const uint32_t full_k = (H >= 5) ? 0x1ffffffu : ((1u << (5 * H)) - 1u);
+        for (int p = 0; p < P; ++p) {
+          uint32_t hw = 0;
+          for (int i = 0; i < H; ++i) {
+            const int t = deal_pick(ep.deal_mode, dk, dsize, rng);
+            dk -= (uint64_t)1 << (2 * t);
+            if (ep.track_dh) ep.deck_hist[(size_t)g * 52 + (50 - dsize)] = (uint8_t)t;
+            dsize -= 1;
+            hw |= (uint32_t)t << (5 * i);
+          }
+          ST(PLH(p)) = hw | ((uint32_t)H << 25);
+          ST(PLKCP(p)) = full_k;
+          ST(PLKRP(p)) = full_k;
+          ST(PLKH(p)) = 0;
+        }
+        ST(PL_DECK_LO) = (uint32_t)dk;
+        ST(PL_DECK_HI) = (uint32_t)(dk >> 32);
+        ST(PL_MISC) = (ST(PL_MISC) & ~(63u << 8)) | ((uint32_t)dsize << 8);
+        // all hands full -> AdvanceToNextPlayer leaves the chance node: cur = 0, next = 1 % P
+        ST(PL_BOARD) = board_set(board_set(ST(PL_BOARD), 24, 7u, 1u), 27, 7u, (uint32_t)(1 % P));
       }
-      for (int k = 0; k < P * H; ++k) deal_one(ep, P, H, s_st, lane, rng, g);
+      STAMP(7);
       for (int p = 0; p < P; ++p) {
-        const uint32_t r = rng_next(rng);
-        ST(PLEPS(p)) = __float_as_uint(ep.eps_list[r % (uint32_t)ep.n_eps]);
+        const uint32_t r = rng_next(rng) % (uint32_t)ep.n_eps;
+        ST(PLEPS(p)) = __float_as_uint(r < 128u ? s_eps[r] : ep.eps_list[r]);
       }
       if (ep.shuffle_color) {
         const int fix = (int)(rng_next(rng) % (uint32_t)P);
@@ -1435,7 +1472,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   ep.obs_words = (ep.obs_words + 3) & ~3;
   ep.legal_words = (ep.legal_words + 3) & ~3;
   ep.own_words = (ep.own_words + 3) & ~3;
-  e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words + kWave);
+  e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words + kWave + 128);
   e->lds_bytes_reset = e->lds_bytes + sizeof(uint32_t) * (size_t)(2 * ep.win_w + 1) * kWave;
   e->device = cfg->device;
   e->bound = false;

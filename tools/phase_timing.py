@@ -24,3 +24,7 @@ for name in ("reset", "step"):
     print("  phase mean us: load %.1f logic %.1f build %.1f writeback %.1f stream %.1f" % tuple(d.mean(0)))
     print("  phase max  us: load %.1f logic %.1f build %.1f writeback %.1f stream %.1f" % tuple(d.max(0)))
     print("  start spread %.1f us  end mean %.1f us" % ((b[:, 0] - t0).max(), (b[:, 5] - t0).mean()))
+    if name == "reset":
+        ok = (b[:, 6] > 0) & (b[:, 7] > 0)
+        print("  reset logic split us: window prefetch %.1f, initial deal %.1f, eps/perm/LA/publish %.1f" % (
+            (b[ok, 6] - b[ok, 1]).mean(), (b[ok, 7] - b[ok, 6]).mean(), (b[ok, 2] - b[ok, 7]).mean()))
