@@ -56,8 +56,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
 
-constexpr int kBK = 32;            // K per LDS tile
-constexpr int kLdsStride = 40;     // bf16 elements per LDS row: 32 + 8 pad (80 B: conflict-free ds_read_b128)
+constexpr int kBK = 64;            // K per LDS tile (one barrier pair per 64-deep step)
+constexpr int kLdsStride = 72;     // bf16 elements per LDS row: 64 + 8 pad (144 B: conflict-free ds_read_b128)
 
 // A-operand / B-operand fragment of v_mfma_f32_32x32x16_bf16 from an LDS tile stored [rows][kLdsStride]:
 // lane l holds row (l & 31), k = 8*(l >> 5) .. +7 of the 16-wide k block kk.
@@ -94,19 +94,20 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  // global -> register staging: each thread moves 16 B (8 bf16); a tile row is 4 such chunks
-  constexpr int A_ITERS = BM * 4 / 256, B_ITERS = BN * 4 / 256;
+  // global -> register staging: each thread moves 16 B (8 bf16); a tile row is kBK/8 such chunks
+  constexpr int CPR = kBK / 8;  // chunks per row
+  constexpr int A_ITERS = BM * CPR / 256, B_ITERS = BN * CPR / 256;
   uint4 ra[A_ITERS], rb[B_ITERS];
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
       const int gr = m0 + r;
       ra[it] = (gr < g.M) ? *reinterpret_cast<const uint4*>(g.A + (size_t)gr * g.lda + k0 + q * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
       const int gr = n0 + r;
       rb[it] = (gr < g.N) ? *reinterpret_cast<const uint4*>(g.B + (size_t)gr * g.ldb + k0 + q * 8) : make_uint4(0, 0, 0, 0);
     }
@@ -114,12 +115,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   auto store_tile = [&]() {
 #pragma unroll
     for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
       *reinterpret_cast<uint4*>(sA + r * kLdsStride + q * 8) = ra[it];
     }
 #pragma unroll
     for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
       *reinterpret_cast<uint4*>(sB + r * kLdsStride + q * 8) = rb[it];
     }
   };
@@ -238,8 +239,9 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, nb = blockIdx.x;  // nb: block of 32 hidden units
   const int H = a.H;
-  constexpr int A_ITERS = (BM * 4 + 255) / 256;
-  uint4 ra[A_ITERS], rb[2];
+  constexpr int CPR = kBK / 8;
+  constexpr int A_ITERS = (BM * CPR + 255) / 256, B_ITERS = 128 * CPR / 256;
+  uint4 ra[A_ITERS], rb[B_ITERS];
   f32x16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -250,25 +252,25 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     auto load_tile = [&](int k0) {
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) {
-        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        const int c = tid + it * 256, r = c / CPR, q = c % CPR;
         const int gr = m0 + r;
         ra[it] = (gr < a.Bn) ? *reinterpret_cast<const uint4*>(a.h_prev + (size_t)gr * H + k0 + q * 8) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      for (int it = 0; it < B_ITERS; ++it) {
+        const int c = tid + it * 256, r = c / CPR, q = c % CPR;
         rb[it] = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + k0 + q * 8);
       }
     };
     auto store_tile = [&]() {
 #pragma unroll
       for (int it = 0; it < A_ITERS; ++it) {
-        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+        const int c = tid + it * 256, r = c / CPR, q = c % CPR;
         *reinterpret_cast<uint4*>(sA + r * kLdsStride + q * 8) = ra[it];
       }
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int c = tid + it * 256, r = c >> 2, q = c & 3;
+      for (int it = 0; it < B_ITERS; ++it) {
+        const int c = tid + it * 256, r = c / CPR, q = c % CPR;
         *reinterpret_cast<uint4*>(sB + r * kLdsStride + q * 8) = rb[it];
       }
     };
@@ -1146,7 +1148,7 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
                          float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
                          const void* relu_mask16, int ldmask, void* stream) {
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
-  if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 32 and lda/ldb of 8");
+  if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 64 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");

@@ -16,7 +16,8 @@ def _s(dev):
 
 
 def _pad32(k):
-    return (k + 31) // 32 * 32
+    """GEMM contraction dims are padded to the kernels' K tile (64)"""
+    return (k + 63) // 64 * 64
 
 
 def gate_block_perm(H, device):

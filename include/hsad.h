@@ -226,7 +226,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
  * Replace what the reference gets from PyTorch + cuDNN for R2D2Net / R2D2Agent
  * (pyhanabi/r2d2.py:13-157, 383-499).  All pointers are device pointers; bf16 buffers are raw uint16.
  * ------------------------------------------------------------------------------------------ */
-/* C[M,N] = A[M,K] * B[N,K]^T (+bias[N]) (ReLU): A,B bf16 row-major (lda/ldb multiples of 8, K multiple of 32,
+/* C[M,N] = A[M,K] * B[N,K]^T (+bias[N]) (ReLU): A,B bf16 row-major (lda/ldb multiples of 8, K multiple of 64,
  * zero padded), outputs fp32 C32 (optionally accumulated into) and/or bf16 C16.  nn.Linear forward. */
 int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream);
