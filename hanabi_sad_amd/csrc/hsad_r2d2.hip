@@ -628,6 +628,8 @@ struct LstmSeqBwdArgs {
   unsigned* counters;  // [T][Bn/32] zeroed before launch
   unsigned* timeout;
   int T, Bn, H;
+  float* dc_io;        // optional [Bn,H]: running dc entering the last step of this chunk (in) / leaving its first (out)
+  int has_next;        // dG slot T holds a real gradient (produced by an earlier launch for the following chunk)
 };
 
 template <int KB>  // KB = 4H / 32
@@ -651,6 +653,10 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
   const int row_l = rb * 32 + wr * 16 + (lane & 15);
   float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.dc_io) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dcs[r] = a.dc_io[(size_t)min(rbase + r, a.Bn - 1) * H + u];
+  }
   __syncthreads();
 
   for (int t = a.T - 1; t >= 0; --t) {
@@ -669,8 +675,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
     }
     f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t < a.T - 1) {
-      if (tid == 0) {
+    if (t < a.T - 1 || a.has_next) {
+      if (tid == 0 && t < a.T - 1) {
         unsigned* ctr = a.counters + (size_t)(t + 1) * nrb + rb;
         unsigned spins = 0;
         int ok = 1;
@@ -683,6 +689,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
           }
         }
         *s_okp = ok;
+      } else if (tid == 0) {
+        *s_okp = 1;
       }
       __syncthreads();
       if (!*s_okp) return;
@@ -755,6 +763,11 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t > 0) __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (a.dc_io) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (rbase + r < a.Bn) a.dc_io[(size_t)(rbase + r) * H + u] = dcs[r];
   }
 }
 
@@ -1211,7 +1224,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
   if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
     const int nrb = (Bn + 31) / 32;
     unsigned* counters = (unsigned*)sync_scratch;
-    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb + 4), s));
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb), s));  // the timeout word after the counters is sticky
     LstmSeqArgs q;
     q.Whh = (const bf16_t*)Whh_blocked;
     q.gates = gates;
@@ -1321,8 +1334,8 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
   if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
     const int nrb = (Bn + 31) / 32;
     unsigned* counters = (unsigned*)sync_scratch;
-    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb + 4), s));
-    LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H};
+    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb), s));  // the timeout word after the counters is sticky
+    LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H, nullptr, 0};
     const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
     const dim3 grid(H / 32, nrb);
     if (H == 512) {
@@ -1447,6 +1460,70 @@ int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_
   const size_t n = (size_t)N * H;
   hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((n + 255) / 256), L), dim3(256), 0, (hipStream_t)stream, x, flag, N, H,
                      rows_per_flag);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// Chunked variants for layer pipelining: one persistent launch per chunk of Tc steps with the recurrent state carried
+// across launches (h as bf16 [Bn,H] = the previous chunk's last hseq row, c as fp32 = its last cseq row).
+int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
+                            const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream) {
+  if (!gates || !Whh_blocked || !h_prev16 || !hseq16 || !cseq || !sync_scratch) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk: null");
+  if (!((H == 256 || H == 512) && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk: needs H in {256,512}, Bn <= 512");
+  hipStream_t s = (hipStream_t)stream;
+  const int nrb = (Bn + 31) / 32;
+  unsigned* counters = (unsigned*)sync_scratch;
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)Tc * nrb), s));
+  LstmSeqArgs q;
+  q.Whh = (const bf16_t*)Whh_blocked;
+  q.gates = gates;
+  q.c0 = c_prev;
+  q.h0_16 = (const bf16_t*)h_prev16;
+  q.hseq16 = (bf16_t*)hseq16;
+  q.cseq = cseq;
+  q.hT = hT;
+  q.counters = counters;
+  q.timeout = counters + (size_t)Tc * nrb;
+  q.T = Tc;
+  q.Bn = Bn;
+  q.H = H;
+  const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
+  const dim3 grid(H / 32, nrb);
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, q);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel<8>, grid, dim3(256), lds, s, q);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// gates / cseq / dO / dG16 point at the chunk's first step; dG16 slot Tc must hold the gradient of the following
+// chunk's first step when has_next != 0 (zeros are written there otherwise); c_before = c of the step preceding the
+// chunk (NULL = zeros); dc_io carries dc across chunks (zero it before the last-in-time chunk).
+int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
+                             void* sync_scratch, void* stream) {
+  if (!gates || !cseq || !WhhT_blocked || !dG16 || !dc_io || !sync_scratch) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk: null");
+  if (!((H == 256 || H == 512) && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk: needs H in {256,512}, Bn <= 512");
+  hipStream_t s = (hipStream_t)stream;
+  const int nrb = (Bn + 31) / 32;
+  bf16_t* dG = (bf16_t*)dG16;
+  if (!has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
+  unsigned* counters = (unsigned*)sync_scratch;
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)Tc * nrb), s));
+  LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c_before, dO, dG, counters, counters + (size_t)Tc * nrb, Tc, Bn, H, dc_io, has_next};
+  const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
+  const dim3 grid(H / 32, nrb);
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, q);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, grid, dim3(256), lds, s, q);
+  }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -57,6 +57,27 @@ def transpose_bf16(src):
     return dst
 
 
+_SYNC = {}
+
+
+def sync_scratch(device, T, Bn, tag="fwd"):
+    """cached zero-initialised counter block for a persistent recurrence launch of (T, Bn) on the CURRENT stream (one
+    block per stream: launches on one stream are ordered, concurrent streams must not share counters)"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, int(T), int(Bn))
+    buf = _SYNC.get(key)
+    if buf is None:
+        buf = torch.zeros(T * ((Bn + 31) // 32) + 4, dtype=torch.int32, device=device)
+        _SYNC[key] = buf
+    return buf
+
+
+def check_sync():
+    """raise if any persistent recurrence launch gave up waiting for a sibling workgroup (synchronises)"""
+    bad = [k for k, b in _SYNC.items() if int(b[k[3] * ((k[4] + 31) // 32)].item()) != 0]
+    if bad:
+        raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup: %s" % (bad,))
+
+
 def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
     """gates fp32 [T,Bn,4H] (x-projection + biases, gate-blocked; overwritten with the activated gates).
     -> hseq bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]"""
@@ -70,7 +91,7 @@ def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
     scratch = torch.empty(Bn, H, dtype=torch.bfloat16, device=d)
     if c0 is None:
         c0 = torch.zeros(Bn, H, dtype=torch.float32, device=d)
-    sync = torch.empty(T * ((Bn + 31) // 32) + 4, dtype=torch.int32, device=d) if persistent else None
+    sync = sync_scratch(d, T, Bn) if persistent else None
     _lib.check(lib.hsad_lstm_layer_forward(T, Bn, H, gates.data_ptr(), Whh_blocked16.data_ptr(),
                                            None if h0 is None else h0.contiguous().data_ptr(),
                                            c0.contiguous().data_ptr(), hseq.data_ptr(), cseq.data_ptr(),
@@ -113,10 +134,57 @@ class R2D2NetKernels:
         self.Wheads = torch.cat([w["fc_a.weight"], w["fc_v.weight"], w["pred.weight"]], 0).to(torch.bfloat16).contiguous()
         self.bheads = torch.cat([w["fc_a.bias"], w["fc_v.bias"], w["pred.bias"]], 0).contiguous()
 
-    def trunk(self, priv_s, h0=None, c0=None, keep=None):
+    def _trunk_pipelined(self, priv_s, keep, chunks):
+        """zero-initial-state trunk with the two LSTM layers software-pipelined over `chunks` time chunks: layer 1's
+        input projection + recurrence for chunk c run on a second stream while layer 0 works on chunk c+1."""
+        lib = self.lib
+        T, N, F = priv_s.shape
+        M, H, d = T * N, self.H, self.device
+        Tc = T // chunks
+        s0 = torch.cuda.current_stream(d)
+        if getattr(self, "_s1", None) is None:
+            self._s1 = torch.cuda.Stream(device=d)
+        s1 = self._s1
+        a16 = cast_pad_bf16(priv_s.reshape(M, F), self.Fp)
+        x1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+        gemm_nt(a16, self.W1, M, H, self.Fp, bias=self.b1, out16=x1, relu=True)
+        gates = [torch.empty(T, N, 4 * H, dtype=torch.float32, device=d) for _ in range(2)]
+        hseq = [torch.empty(T, N, H, dtype=torch.bfloat16, device=d) for _ in range(2)]
+        cseq = [torch.empty(T, N, H, dtype=torch.float32, device=d) for _ in range(2)]
+        hT = [torch.empty(N, H, dtype=torch.float32, device=d) for _ in range(2)]
+        zero16 = torch.zeros(N, H, dtype=torch.bfloat16, device=d)
+        gemm_nt(x1, self.Wih[0], M, 4 * H, H, bias=self.bg[0], out32=gates[0].view(M, 4 * H))
+        s1.wait_stream(s0)
+
+        def chunk(l, c):
+            t0 = c * Tc
+            _lib.check(lib.hsad_lstm_forward_chunk(
+                Tc, N, H, gates[l][t0].data_ptr(), self.Whh[l].data_ptr(),
+                (zero16 if c == 0 else hseq[l][t0 - 1]).data_ptr(), None if c == 0 else cseq[l][t0 - 1].data_ptr(),
+                hseq[l][t0].data_ptr(), cseq[l][t0].data_ptr(), hT[l].data_ptr(),
+                sync_scratch(d, Tc, N, "fwdc").data_ptr(), _s(d)))
+
+        for c in range(chunks):
+            chunk(0, c)
+            ev = torch.cuda.Event()
+            ev.record(s0)
+            with torch.cuda.stream(s1):
+                s1.wait_event(ev)
+                t0 = c * Tc
+                gemm_nt(hseq[0][t0:t0 + Tc].view(Tc * N, H), self.Wih[1], Tc * N, 4 * H, H, bias=self.bg[1],
+                        out32=gates[1][t0:t0 + Tc].view(Tc * N, 4 * H))
+                chunk(1, c)
+        s0.wait_stream(s1)
+        if keep is not None:
+            keep.update({"a16": a16, "x1": x1, "gates": [g.view(M, 4 * H) for g in gates], "hseq": hseq, "cseq": cseq})
+        return hseq[1], torch.stack(hT, 0), torch.stack([cseq[0][T - 1], cseq[1][T - 1]], 0)
+
+    def trunk(self, priv_s, h0=None, c0=None, keep=None, chunks=1):
         """priv_s fp32 [T,N,F]; h0/c0 fp32 [L,N,H] or None -> lstm output bf16 [T,N,H], new h [L,N,H], new c."""
         T, N, F = priv_s.shape
         M, H = T * N, self.H
+        if chunks > 1 and h0 is None and c0 is None and T % chunks == 0 and H in (256, 512) and N <= 512:
+            return self._trunk_pipelined(priv_s, keep, chunks)
         a16 = cast_pad_bf16(priv_s.reshape(M, F), self.Fp)
         x1 = torch.empty(M, H, dtype=torch.bfloat16, device=self.device)
         gemm_nt(a16, self.W1, M, H, self.Fp, bias=self.b1, out16=x1, relu=True)
@@ -157,10 +225,10 @@ class R2D2NetKernels:
                                         None if greedy is None else greedy.data_ptr(), scratch.data_ptr(), _s(d)))
         return q, qa, greedy
 
-    def forward(self, priv_s, legal_move, action, h0=None, c0=None, keep=None):
+    def forward(self, priv_s, legal_move, action, h0=None, c0=None, keep=None, chunks=1):
         """R2D2Net.forward (r2d2.py:80-122) on [T,N,*]: qa [T,N], greedy [T,N], q [T,N,A], lstm_o bf16 [T,N,H]."""
         T, N, _ = priv_s.shape
-        o, _, _ = self.trunk(priv_s, h0, c0, keep)
+        o, _, _ = self.trunk(priv_s, h0, c0, keep, chunks=chunks)
         hd = self.heads(o.reshape(T * N, self.H))
         q, qa, greedy = self.q_head(hd, legal_move.reshape(T * N, self.A), action.reshape(-1))
         if keep is not None:
@@ -253,6 +321,8 @@ class R2D2Learner:
         self.target = R2D2NetKernels(target_weights, device)
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
+        self.chunks = 4          # time chunks for the layer pipeline (1 = layers strictly one after the other)
+        self.bwd_stream = torch.cuda.Stream(device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
         self._refresh_transposes()
 
@@ -267,6 +337,12 @@ class R2D2Learner:
         self.WheadsT = transpose_bf16(wh)                             # [H, NHp]
         self.NHp = NHp
         self.inv_perm = torch.argsort(n.perm)
+
+    def _nchunks(self, T, B):
+        c = self.chunks if (self.persistent and self.online.H in (256, 512) and B <= 512) else 1
+        while c > 1 and T % c:
+            c -= 1
+        return c
 
     def sync_target_with_online(self):
         for k in PARAM_ORDER:
@@ -287,9 +363,9 @@ class R2D2Learner:
         main = torch.cuda.current_stream(d)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
-            to, _, _ = tg.trunk(priv)
+            to, _, _ = tg.trunk(priv, chunks=self._nchunks(T, B))
             thd = tg.heads(to.reshape(M, H))
-        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep)
+        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep, chunks=self._nchunks(T, B))
         main.wait_stream(self.side)
         _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
         tqa = tqa.view(T, B)
@@ -320,10 +396,10 @@ class R2D2Learner:
         side = self.side
         held = []   # tensors consumed on the side stream (kept alive / stream-recorded until the join)
 
-        def on_side(fn):
+        def on_side(fn, after=None):
             """weight-gradient work is off the critical path: run it on the side stream while the main stream
             continues with the next layer's BPTT (the persistent recurrence kernels only occupy 64 CUs)"""
-            side.wait_stream(main)
+            side.wait_stream(main if after is None else after)
             with torch.cuda.stream(side):
                 fn()
 
@@ -344,20 +420,57 @@ class R2D2Learner:
         zero_h = torch.zeros(B, H, dtype=torch.bfloat16, device=d)
         layer_in = [keep["x1"], hseq[0]]                                                 # inputs of layer 0 / 1
         dx1 = None
+        nch = self._nchunks(T, B)
+        if nch > 1:
+            # layer pipeline, mirrored: layer 1 walks the chunks from the end on a second stream; as soon as chunk c's
+            # dG1 exists the main stream turns it into dO0 for that chunk and runs layer 0's recurrence over it
+            Tc = T // nch
+            sb = self.bwd_stream
+            dGs = [torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d) for _ in range(2)]
+            dcs = [torch.zeros(B, H, dtype=torch.float32, device=d) for _ in range(2)]
+            dO0 = torch.empty(M, H, dtype=torch.float32, device=d)
+            dOs = [dO0, dO]
+
+            def bchunk(l, c):
+                t0 = c * Tc
+                _lib.check(lib.hsad_lstm_backward_chunk(
+                    Tc, B, H, keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
+                    None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
+                    dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
+                    int(c != nch - 1), sync_scratch(d, Tc, B, "bwdc").data_ptr(), _s(d)))
+
+            sb.wait_stream(main)
+            for c in reversed(range(nch)):
+                with torch.cuda.stream(sb):
+                    bchunk(1, c)
+                    ev = torch.cuda.Event()
+                    ev.record(sb)
+                main.wait_event(ev)
+                t0 = c * Tc
+                gemm_nt_ex(dGs[1][t0:t0 + Tc].view(Tc * B, 4 * H), self.WihT[1], Tc * B, H, 4 * H,
+                           out32=dO0[t0 * B:(t0 + Tc) * B])
+                bchunk(0, c)
+            dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+            gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
+            held.extend(dGs + dcs + [dO0])
         for l in (1, 0):
-            dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
-            dc = torch.empty(B, H, dtype=torch.float32, device=d)
-            sync = torch.empty(T * ((B + 31) // 32) + 4, dtype=torch.int32, device=d)
-            _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
-                                                    self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
-                                                    sync.data_ptr() if self.persistent else None, _s(d)))
-            dG2 = dG[:T].view(M, 4 * H)
-            if l == 1:
-                dO = torch.empty(M, H, dtype=torch.float32, device=d)
-                gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
+            if nch > 1:
+                dG = dGs[l]
+                dG2 = dG[:T].view(M, 4 * H)
             else:
-                dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
-                gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
+                dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
+                dc = torch.empty(B, H, dtype=torch.float32, device=d)
+                sync = sync_scratch(d, T, B, "bwd")
+                _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
+                                                        self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
+                                                        sync.data_ptr() if self.persistent else None, _s(d)))
+                dG2 = dG[:T].view(M, 4 * H)
+                if l == 1:
+                    dO = torch.empty(M, H, dtype=torch.float32, device=d)
+                    gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
+                else:
+                    dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+                    gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
 
             def layer_wgrad(l=l, dG2=dG2, dG=dG):
                 dGT = transpose_pad(dG2, Mp)                                             # [4H, Mp]
@@ -373,7 +486,7 @@ class R2D2Learner:
                 g["lstm.bias_ih_l%d" % l].copy_(db[self.inv_perm])
                 g["lstm.bias_hh_l%d" % l].copy_(db[self.inv_perm])
                 held.extend([dGT, inT, hprevT, dWih, dWhh, db, dG])
-            on_side(layer_wgrad)
+            on_side(layer_wgrad, after=self.bwd_stream if (nch > 1 and l == 1) else None)
 
         def input_wgrad():
             dx1T = transpose_pad(dx1, Mp)                                                # [H, Mp]

@@ -241,7 +241,8 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
  * (optional).  h0_16_scratch: bf16 [Bn,H].  sync_scratch (may be NULL): uint32 [T*ceil(Bn/32)+4]; when given and
  * the shape allows (H in {256,512}, Bn <= 512) the whole sequence runs as ONE persistent launch that keeps the
  * W_hh slices in LDS and exchanges h_t tiles through L2 (csrc/hsad_r2d2.hip); otherwise one launch per step.
- * hsad_lstm_sync_timed_out() reports a bounded spin that gave up. */
+ * The word after the counters is a STICKY timeout flag (zero the scratch once when allocating it; launches only
+ * clear the counters); hsad_lstm_sync_timed_out() reports a bounded spin that gave up. */
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
                             const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
                             void* sync_scratch, void* stream);
@@ -294,6 +295,16 @@ int hsad_nstep_priority(const float* qa, const float* target_qa, const float* re
                         int multi_step, double gamma, int N, float* out, void* stream);
 /* zero rows r of fp32 x[L,N,H] where flag[r / rows_per_flag] != 0 (hidden-state reset on terminal, r2d2_actor.h:109-126) */
 int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);
+/* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
+ * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
+int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
+                            const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream);
+/* all sequence pointers address the chunk's first step; dG16 slot Tc = gradient of the following chunk's first step
+ * (has_next) or scratch that is zeroed; c_before = c of the step before the chunk (NULL = zeros); dc_io fp32 [Bn,H]
+ * carries dc between chunks (caller zeroes it before the last-in-time chunk). */
+int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
+                             const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
+                             void* sync_scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ for l in range(2):
     W["lstm.weight_ih_l%d" % l] = lin(4 * H, H); W["lstm.weight_hh_l%d" % l] = lin(4 * H, H)
     W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1); W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
 lr = R2D2Learner(W, W, 3, 0.999, device=DEV)
+lr.chunks = int(os.environ.get("CHUNKS", lr.chunks))
 seq_len = torch.randint(40, 81, (B,)).float().to(DEV)
 mask = (torch.arange(T, device=DEV).unsqueeze(1) < seq_len.unsqueeze(0)).float()
 legal = (torch.rand(T, B, A, device=DEV) < 0.4).float(); legal[..., 0] = 1
@@ -27,10 +28,12 @@ for _ in range(3): upd()
 torch.cuda.synchronize(); t0 = time.perf_counter(); n = 10
 for _ in range(n): upd()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print("HIP learner update: %.2f ms  -> %.0f sequences/s  (%.1f TFLOP/s of 380.3 GFLOP/update)" % (dt * 1e3, B / dt, 380.3e9 / dt / 1e12))
+print("chunks=%d" % lr.chunks, end="  "); print("HIP learner update: %.2f ms  -> %.0f sequences/s  (%.1f TFLOP/s of 380.3 GFLOP/update)" % (dt * 1e3, B / dt, 380.3e9 / dt / 1e12))
 t0 = time.perf_counter()
 for _ in range(n): lr.loss(batch, weight, 0.0, compute_grad=False)
 torch.cuda.synchronize(); print("  forward only (online+target+TD): %.2f ms" % ((time.perf_counter() - t0) / n * 1e3))
+from hanabi_sad_amd.r2d2 import check_sync; check_sync()
+if os.environ.get("NO_TORCH"): sys.exit(0)
 # torch eager baseline of the same math (nn.LSTM / MIOpen fp32) -- "what you get without hand-written kernels"
 import torch.nn as nn
 class Net(nn.Module):
