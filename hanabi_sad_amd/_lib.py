@@ -79,17 +79,20 @@ SIGNATURES = {
     "hsad_gemm_nt_bf16": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
                                     C.c_int, C.c_int, _P]),
     "hsad_cast_pad_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "hsad_prepare_weight": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "hsad_bias_sum_perm": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "hsad_transpose_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "hsad_lstm_layer_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_sync_timed_out": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "hsad_gemm_nt_bf16_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
-                                       C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+                                       C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "hsad_lstm_layer_backward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_heads_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,
                                       C.c_int, _P]),
     "hsad_aux_xent": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "hsad_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "hsad_colsum_acc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, _P, _P]),
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),

@@ -82,6 +82,7 @@ struct GemmArgs {
   int k_chunk;           // split-K: block z multiplies k in [z*k_chunk, (z+1)*k_chunk) and atomically adds to C32
   const bf16_t* mask16;  // optional [M, ldmask]: output is zeroed where mask <= 0 (ReLU backward)
   int ldmask;
+  const int32_t* row_map;  // optional [M]: result row r is written to row row_map[r] of C32 / C16
 };
 
 template <int BM, int BN>
@@ -170,14 +171,15 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
           float v = acc[i][j][r] + ((g.k_chunk && blockIdx.z) ? 0.f : b);
           if (g.relu) v = fmaxf(v, 0.f);
           if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col]) > 0.f)) v = 0.f;
+          const int orow = g.row_map ? g.row_map[row] : row;
           if (g.C32) {
-            float* p = g.C32 + (size_t)row * g.ldc + col;
+            float* p = g.C32 + (size_t)orow * g.ldc + col;
             if (g.k_chunk)
               atomicAdd(p, v);
             else
               *p = g.accumulate ? (*p + v) : v;
           }
-          if (g.C16) g.C16[(size_t)row * g.ldc16 + col] = f2bf(v);
+          if (g.C16) g.C16[(size_t)orow * g.ldc16 + col] = f2bf(v);
         }
       }
     }
@@ -205,6 +207,38 @@ __global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int
   for (int i = threadIdx.y; i < 32; i += blockDim.y) {
     const int c = c0 + i, r = r0 + threadIdx.x;
     if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
+  }
+}
+
+// fp32 master weight [R, C] -> the kernels' bf16 operands in one pass: dst16[r][c] = src[perm ? perm[r] : r][c] and the
+// transposed copy dstT16[c][r] (either may be NULL).  Padding columns of the destinations are left untouched.
+__global__ void prepare_weight_kernel(const float* __restrict__ src, int R, int C, int lds, const int32_t* __restrict__ perm,
+                                      bf16_t* __restrict__ dst, int ldd, bf16_t* __restrict__ dstT, int ldt) {
+  __shared__ bf16_t tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    bf16_t v = (bf16_t)0;
+    if (r < R && c < C) {
+      v = f2bf(src[(size_t)(perm ? perm[r] : r) * lds + c]);
+      if (dst) dst[(size_t)r * ldd + c] = v;
+    }
+    tile[i][threadIdx.x] = v;
+  }
+  if (!dstT) return;
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (c < C && r < R) dstT[(size_t)c * ldt + r] = tile[threadIdx.x][i];
+  }
+}
+
+// out[i] = a[perm[i]] + b[perm[i]]  (gate bias b_ih + b_hh in the gate-blocked order)
+__global__ void bias_sum_perm_kernel(const float* a, const float* b, const int32_t* perm, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int j = perm ? perm[i] : i;
+    out[i] = a[j] + (b ? b[j] : 0.f);
   }
 }
 
@@ -1025,7 +1059,8 @@ __global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const 
 // column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients).  Grid = (N/64, row chunks of 512);
 // block 64x4: coalesced 64-column row segments, LDS reduce, one atomicAdd per column per block (out pre-zeroed).
 template <typename TIn>
-__global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld, float* __restrict__ out) {
+__global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld, float* __restrict__ out,
+                              float* __restrict__ out2 = nullptr, const int32_t* __restrict__ col_map = nullptr) {
   __shared__ float s[4][65];
   const int col = blockIdx.x * 64 + threadIdx.x;
   const int r0 = blockIdx.y * 512, r1 = min(M, r0 + 512);
@@ -1039,7 +1074,12 @@ __global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld,
     }
   s[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
-  if (threadIdx.y == 0 && col < N) atomicAdd(out + col, s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]);
+  if (threadIdx.y == 0 && col < N) {
+    const float v = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+    const int oc = col_map ? col_map[col] : col;
+    atomicAdd(out + oc, v);
+    if (out2) atomicAdd(out2 + oc, v);
+  }
 }
 
 // sum of squares of a flat fp32 buffer (one atomic per block), then Adam with global-norm clipping
@@ -1159,14 +1199,14 @@ extern "C" {
 
 int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                          float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
-                         const void* relu_mask16, int ldmask, void* stream) {
+                         const void* relu_mask16, int ldmask, const int32_t* row_map, void* stream) {
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
   if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 64 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
-             0, (const bf16_t*)relu_mask16, ldmask};
+             0, (const bf16_t*)relu_mask16, ldmask, row_map};
   int gz = 1;
   if (split_k > 1) {
     int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
@@ -1185,7 +1225,7 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
 
 int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream) {
-  return hsad_gemm_nt_bf16_ex(A, lda, B, ldb, M, N, K, bias, C32, ldc, C16, ldc16, relu, accumulate, 1, nullptr, 0, stream);
+  return hsad_gemm_nt_bf16_ex(A, lda, B, ldb, M, N, K, bias, C32, ldc, C16, ldc16, relu, accumulate, 1, nullptr, 0, nullptr, stream);
 }
 
 int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream) {
@@ -1193,6 +1233,22 @@ int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, in
   const size_t n = (size_t)M * Kp;
   hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, M, K,
                      ld_src, (bf16_t*)dst, Kp);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_prepare_weight(const float* src, int R, int C, int ld_src, const int32_t* perm, void* dst16, int ld_dst,
+                        void* dstT16, int ld_dstT, void* stream) {
+  if (!src || (!dst16 && !dstT16) || R <= 0 || C <= 0) return nfail(HSAD_ERR_INVALID, "prepare_weight: bad arguments");
+  hipLaunchKernelGGL(prepare_weight_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream, src, R, C,
+                     ld_src, perm, (bf16_t*)dst16, ld_dst, (bf16_t*)dstT16, ld_dstT);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_bias_sum_perm(const float* a, const float* b, const int32_t* perm, float* out, int n, void* stream) {
+  if (!a || !out || n <= 0) return nfail(HSAD_ERR_INVALID, "bias_sum_perm: bad arguments");
+  hipLaunchKernelGGL(bias_sum_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, perm, out, n);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1412,6 +1468,19 @@ int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, 
   return HSAD_OK;
 }
 
+int hsad_colsum_acc(const void* src, int is_bf16, int M, int N, int ld, float* out, float* out2, const int32_t* col_map,
+                    void* stream) {
+  if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum_acc: null");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((N + 63) / 64, (M + 511) / 512), block(64, 4);
+  if (is_bf16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, out, out2, col_map);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)src, M, N, ld, out, out2, col_map);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
 int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
                    float lr, float beta1, float beta2, float eps, int step, float* scratch, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !scratch || n < 1 || step < 1)
@@ -1419,11 +1488,7 @@ int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(scratch, 0, 4, s));
   hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad, (size_t)n, scratch);
-  double b1p = 1.0, b2p = 1.0;
-  for (int i = 0; i < step; ++i) {
-    b1p *= (double)beta1;
-    b2p *= (double)beta2;
-  }
+  const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);  // torch: beta ** step
   const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
                      (size_t)n, scratch, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);

@@ -103,7 +103,7 @@ def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
 class R2D2NetKernels:
     """Forward pass of R2D2Net on the HIP kernels.  `weights`: dict keyed like R2D2Net.state_dict()."""
 
-    def __init__(self, weights, device="cuda:0"):
+    def __init__(self, weights, device="cuda:0", with_transposes=False):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.HsadError("R2D2NetKernels needs a ROCm device; there is no CPU path")
@@ -116,23 +116,49 @@ class R2D2NetKernels:
         self.L = 2
         self.Fp = _pad32(self.F)
         self.perm = gate_block_perm(self.H, self.device)
+        self.perm32 = self.perm.to(torch.int32).contiguous()
+        H, d, bf = self.H, self.device, torch.bfloat16
+        self.NH = self.A + 1 + self.NP
+        self.NHp = _pad32(self.NH)
+        # kernel operands live in fixed buffers that refresh() re-fills in place (pad regions stay zero)
+        self.W1 = torch.zeros(H, self.Fp, dtype=bf, device=d)
+        self.Wih = [torch.empty(4 * H, H, dtype=bf, device=d) for _ in range(self.L)]
+        self.Whh = [torch.empty(4 * H, H, dtype=bf, device=d) for _ in range(self.L)]
+        self.bg = [torch.empty(4 * H, dtype=torch.float32, device=d) for _ in range(self.L)]
+        self.Wheads = torch.empty(self.NH, H, dtype=bf, device=d)
+        self.bheads = torch.empty(self.NH, dtype=torch.float32, device=d)
+        self.WihT = self.WhhT = self.WheadsT = None
+        if with_transposes:   # backward operands (learner only)
+            self.WihT = [torch.empty(H, 4 * H, dtype=bf, device=d) for _ in range(self.L)]
+            self.WhhT = [torch.empty(H, 4 * H, dtype=bf, device=d) for _ in range(self.L)]
+            self.WheadsT = torch.zeros(H, self.NHp, dtype=bf, device=d)
         self.refresh()
 
+    def _prep(self, src, perm, dst, dstT):
+        R, C = src.shape
+        _lib.check(self.lib.hsad_prepare_weight(src.data_ptr(), R, C, src.stride(0), None if perm is None else perm.data_ptr(),
+                                                None if dst is None else dst.data_ptr(), 0 if dst is None else dst.stride(0),
+                                                None if dstT is None else dstT.data_ptr(),
+                                                0 if dstT is None else dstT.stride(0), _s(self.device)))
+
     def refresh(self):
-        """Re-derive the bf16 / blocked kernel operands from the fp32 master weights."""
-        w, H = self.w, self.H
-        W1 = torch.zeros(H, self.Fp, dtype=torch.float32, device=self.device)
-        W1[:, :self.F] = w["net.0.weight"]
-        self.W1 = W1.to(torch.bfloat16)
+        """Re-derive the bf16 / gate-blocked (and, for the learner, transposed) kernel operands from the fp32 master
+        weights: one small HIP launch per weight, no temporaries."""
+        w, H, T_ = self.w, self.H, self.WihT is not None
+        self._prep(w["net.0.weight"], None, self.W1, None)
         self.b1 = w["net.0.bias"]
-        self.Wih, self.Whh, self.bg = [], [], []
         for l in range(self.L):
-            self.Wih.append(w["lstm.weight_ih_l%d" % l][self.perm].to(torch.bfloat16).contiguous())
-            self.Whh.append(w["lstm.weight_hh_l%d" % l][self.perm].to(torch.bfloat16).contiguous())
-            self.bg.append((w["lstm.bias_ih_l%d" % l] + w["lstm.bias_hh_l%d" % l])[self.perm].contiguous())
-        self.NH = self.A + 1 + self.NP
-        self.Wheads = torch.cat([w["fc_a.weight"], w["fc_v.weight"], w["pred.weight"]], 0).to(torch.bfloat16).contiguous()
-        self.bheads = torch.cat([w["fc_a.bias"], w["fc_v.bias"], w["pred.bias"]], 0).contiguous()
+            self._prep(w["lstm.weight_ih_l%d" % l], self.perm32, self.Wih[l], self.WihT[l] if T_ else None)
+            self._prep(w["lstm.weight_hh_l%d" % l], self.perm32, self.Whh[l], self.WhhT[l] if T_ else None)
+            _lib.check(self.lib.hsad_bias_sum_perm(w["lstm.bias_ih_l%d" % l].data_ptr(), w["lstm.bias_hh_l%d" % l].data_ptr(),
+                                                   self.perm32.data_ptr(), self.bg[l].data_ptr(), 4 * H, _s(self.device)))
+        r0 = 0
+        for wk, bk in (("fc_a.weight", "fc_a.bias"), ("fc_v.weight", "fc_v.bias"), ("pred.weight", "pred.bias")):
+            n = w[wk].shape[0]
+            self._prep(w[wk], None, self.Wheads[r0:r0 + n], self.WheadsT[:, r0:r0 + n] if T_ else None)
+            _lib.check(self.lib.hsad_bias_sum_perm(w[bk].data_ptr(), None, None, self.bheads[r0:r0 + n].data_ptr(), n,
+                                                   _s(self.device)))
+            r0 += n
 
     def _trunk_pipelined(self, priv_s, keep, chunks):
         """zero-initial-state trunk with the two LSTM layers software-pipelined over `chunks` time chunks: layer 1's
@@ -258,10 +284,10 @@ def td_loss(online_qa, target_qa, reward, bootstrap, seq_len, multi_step, gamma,
 PARAM_ORDER = ["net.0.weight", "net.0.bias",
                "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
                "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1",
-               "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias", "pred.weight", "pred.bias"]
+               "fc_a.weight", "fc_v.weight", "pred.weight", "fc_a.bias", "fc_v.bias", "pred.bias"]   # heads contiguous
 
 
-def gemm_nt_ex(A16, B16, M, N, K, out32=None, out16=None, split_k=1, relu_mask=None, accumulate=False):
+def gemm_nt_ex(A16, B16, M, N, K, out32=None, out16=None, split_k=1, relu_mask=None, accumulate=False, row_map=None):
     lib = _lib.load_library()
     _lib.check(lib.hsad_gemm_nt_bf16_ex(
         A16.data_ptr(), A16.stride(0), B16.data_ptr(), B16.stride(0), M, N, K, None,
@@ -269,7 +295,7 @@ def gemm_nt_ex(A16, B16, M, N, K, out32=None, out16=None, split_k=1, relu_mask=N
         None if out16 is None else out16.data_ptr(), 0 if out16 is None else out16.stride(0),
         0, int(accumulate), int(split_k),
         None if relu_mask is None else relu_mask.data_ptr(), 0 if relu_mask is None else relu_mask.stride(0),
-        _s(A16.device)))
+        None if row_map is None else row_map.data_ptr(), _s(A16.device)))
 
 
 def transpose_pad(src16, Kp):
@@ -283,10 +309,12 @@ def transpose_pad(src16, Kp):
     return dst
 
 
-def colsum(x):
+def colsum(x, out=None, ncols=None):
     lib = _lib.load_library()
     M, N = x.shape
-    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    N = N if ncols is None else ncols
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=x.device)
     _lib.check(lib.hsad_colsum(x.data_ptr(), int(x.dtype == torch.bfloat16), M, N, x.stride(0), out.data_ptr(),
                                _s(x.device)))
     return out
@@ -314,10 +342,15 @@ class R2D2Learner:
             gviews[k] = self.gflat[off:off + n].view(shape)
             views[k].copy_(online_weights[k])
             off += n
-        self.online = R2D2NetKernels(views, device)
+        self.online = R2D2NetKernels(views, device, with_transposes=True)
         self.online.w = views           # the kernels' fp32 master weights ARE the flat buffer
         self.online.refresh()
         self.grad = gviews
+        # contiguous [NH, H] / [NH] views over the three heads (PARAM_ORDER keeps them adjacent)
+        o0 = sum(sizes[:PARAM_ORDER.index("fc_a.weight")])
+        NH, Hh = self.online.NH, self.online.H
+        self.g_wheads = self.gflat[o0:o0 + NH * Hh].view(NH, Hh)
+        self.g_bheads = self.gflat[o0 + NH * Hh:o0 + NH * Hh + NH]
         self.target = R2D2NetKernels(target_weights, device)
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
@@ -328,19 +361,11 @@ class R2D2Learner:
 
     def _refresh_transposes(self):
         n = self.online
-        H = n.H
-        self.WhhT = [transpose_bf16(n.Whh[l]) for l in range(2)]     # [H, 4H]
-        self.WihT = [transpose_bf16(n.Wih[l]) for l in range(2)]     # [H, 4H]
-        NHp = _pad32(n.NH)
-        wh = torch.zeros(NHp, H, dtype=torch.bfloat16, device=self.device)
-        wh[:n.NH] = n.Wheads
-        self.WheadsT = transpose_bf16(wh)                             # [H, NHp]
-        self.NHp = NHp
-        self.inv_perm = torch.argsort(n.perm)
+        self.WhhT, self.WihT, self.WheadsT, self.NHp = n.WhhT, n.WihT, n.WheadsT, n.NHp   # filled by online.refresh()
 
     def _nchunks(self, T, B):
-        c = self.chunks if (self.persistent and self.online.H in (256, 512) and B <= 512) else 1
-        while c > 1 and T % c:
+        c = self.chunks if (self.persistent and self.online.H in (256, 512) and B <= 512 and B % 8 == 0) else 1
+        while c > 1 and (T % c or (T // c * B) % 64):   # chunk rows are the contraction dim of the chunked wgrad GEMMs
             c -= 1
         return c
 
@@ -362,10 +387,10 @@ class R2D2Learner:
         # occupy 64 CUs each, so both nets' recurrences overlap); join before the target q-head needs `greedy`
         main = torch.cuda.current_stream(d)
         self.side.wait_stream(main)
+        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep, chunks=self._nchunks(T, B))
         with torch.cuda.stream(self.side):
             to, _, _ = tg.trunk(priv, chunks=self._nchunks(T, B))
             thd = tg.heads(to.reshape(M, H))
-        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep, chunks=self._nchunks(T, B))
         main.wait_stream(self.side)
         _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
         tqa = tqa.view(T, B)
@@ -407,100 +432,146 @@ class R2D2Learner:
         dO = torch.empty(M, H, dtype=torch.float32, device=d)
         gemm_nt_ex(dheads, self.WheadsT, M, H, self.NHp, out32=dO)
 
+        self.gflat.zero_()   # the split-K weight-gradient GEMMs accumulate atomically into the flat gradient
+        if self._nchunks(T, B) > 1:
+            self._backward_pipelined(keep, dheads, dO, T, B)
+            return loss, prio
+
         def heads_wgrad():
             dheadsT = transpose_pad(dheads, Mp)                                          # [NHp, Mp]
             o1T = transpose_pad(hseq[1], Mp)                                             # [H, Mp]
-            dWh = torch.zeros(self.NHp, H, dtype=torch.float32, device=d)
-            gemm_nt_ex(dheadsT, o1T, self.NHp, H, Mp, out32=dWh, split_k=8)
-            dbh = colsum(dheads)
-            g["fc_a.weight"].copy_(dWh[:A]); g["fc_v.weight"].copy_(dWh[A:A + 1]); g["pred.weight"].copy_(dWh[A + 1:on.NH])
-            g["fc_a.bias"].copy_(dbh[:A]); g["fc_v.bias"].copy_(dbh[A:A + 1]); g["pred.bias"].copy_(dbh[A + 1:on.NH])
-            held.extend([dheadsT, o1T, dWh, dbh])
+            gemm_nt_ex(dheadsT, o1T, on.NH, H, Mp, out32=self.g_wheads, split_k=8)
+            colsum(dheads, out=self.g_bheads, ncols=on.NH)
+            held.extend([dheadsT, o1T])
         on_side(heads_wgrad)
         zero_h = torch.zeros(B, H, dtype=torch.bfloat16, device=d)
         layer_in = [keep["x1"], hseq[0]]                                                 # inputs of layer 0 / 1
         dx1 = None
-        nch = self._nchunks(T, B)
-        if nch > 1:
-            # layer pipeline, mirrored: layer 1 walks the chunks from the end on a second stream; as soon as chunk c's
-            # dG1 exists the main stream turns it into dO0 for that chunk and runs layer 0's recurrence over it
-            Tc = T // nch
-            sb = self.bwd_stream
-            dGs = [torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d) for _ in range(2)]
-            dcs = [torch.zeros(B, H, dtype=torch.float32, device=d) for _ in range(2)]
-            dO0 = torch.empty(M, H, dtype=torch.float32, device=d)
-            dOs = [dO0, dO]
-
-            def bchunk(l, c):
-                t0 = c * Tc
-                _lib.check(lib.hsad_lstm_backward_chunk(
-                    Tc, B, H, keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
-                    None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
-                    dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
-                    int(c != nch - 1), sync_scratch(d, Tc, B, "bwdc").data_ptr(), _s(d)))
-
-            sb.wait_stream(main)
-            for c in reversed(range(nch)):
-                with torch.cuda.stream(sb):
-                    bchunk(1, c)
-                    ev = torch.cuda.Event()
-                    ev.record(sb)
-                main.wait_event(ev)
-                t0 = c * Tc
-                gemm_nt_ex(dGs[1][t0:t0 + Tc].view(Tc * B, 4 * H), self.WihT[1], Tc * B, H, 4 * H,
-                           out32=dO0[t0 * B:(t0 + Tc) * B])
-                bchunk(0, c)
-            dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
-            gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
-            held.extend(dGs + dcs + [dO0])
         for l in (1, 0):
-            if nch > 1:
-                dG = dGs[l]
-                dG2 = dG[:T].view(M, 4 * H)
+            dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
+            dc = torch.empty(B, H, dtype=torch.float32, device=d)
+            sync = sync_scratch(d, T, B, "bwd")
+            _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
+                                                    self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
+                                                    sync.data_ptr() if self.persistent else None, _s(d)))
+            dG2 = dG[:T].view(M, 4 * H)
+            if l == 1:
+                dO = torch.empty(M, H, dtype=torch.float32, device=d)
+                gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
             else:
-                dG = torch.empty(T + 1, B, 4 * H, dtype=torch.bfloat16, device=d)
-                dc = torch.empty(B, H, dtype=torch.float32, device=d)
-                sync = sync_scratch(d, T, B, "bwd")
-                _lib.check(lib.hsad_lstm_layer_backward(T, B, H, keep["gates"][l].data_ptr(), keep["cseq"][l].data_ptr(), None,
-                                                        self.WhhT[l].data_ptr(), dO.data_ptr(), dG.data_ptr(), dc.data_ptr(),
-                                                        sync.data_ptr() if self.persistent else None, _s(d)))
-                dG2 = dG[:T].view(M, 4 * H)
-                if l == 1:
-                    dO = torch.empty(M, H, dtype=torch.float32, device=d)
-                    gemm_nt_ex(dG2, self.WihT[1], M, H, 4 * H, out32=dO)
-                else:
-                    dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
-                    gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
+                dx1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+                gemm_nt_ex(dG2, self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
 
             def layer_wgrad(l=l, dG2=dG2, dG=dG):
                 dGT = transpose_pad(dG2, Mp)                                             # [4H, Mp]
                 inT = transpose_pad(layer_in[l], Mp)                                     # [H, Mp]
                 hprevT = transpose_pad(torch.cat([zero_h, hseq[l][:M - B]], 0), Mp)      # h_{t-1} (h_{-1} = 0)
-                dWih = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
-                dWhh = torch.zeros(4 * H, H, dtype=torch.float32, device=d)
-                gemm_nt_ex(dGT, inT, 4 * H, H, Mp, out32=dWih, split_k=8)
-                gemm_nt_ex(dGT, hprevT, 4 * H, H, Mp, out32=dWhh, split_k=8)
+                gemm_nt_ex(dGT, inT, 4 * H, H, Mp, out32=g["lstm.weight_ih_l%d" % l], split_k=8, row_map=on.perm32)
+                gemm_nt_ex(dGT, hprevT, 4 * H, H, Mp, out32=g["lstm.weight_hh_l%d" % l], split_k=8, row_map=on.perm32)
                 db = colsum(dG2)
-                g["lstm.weight_ih_l%d" % l].copy_(dWih[self.inv_perm])
-                g["lstm.weight_hh_l%d" % l].copy_(dWhh[self.inv_perm])
-                g["lstm.bias_ih_l%d" % l].copy_(db[self.inv_perm])
-                g["lstm.bias_hh_l%d" % l].copy_(db[self.inv_perm])
-                held.extend([dGT, inT, hprevT, dWih, dWhh, db, dG])
-            on_side(layer_wgrad, after=self.bwd_stream if (nch > 1 and l == 1) else None)
+                g["lstm.bias_ih_l%d" % l].index_copy_(0, on.perm, db)
+                g["lstm.bias_hh_l%d" % l].index_copy_(0, on.perm, db)
+                held.extend([dGT, inT, hprevT, db, dG])
+            on_side(layer_wgrad)
 
         def input_wgrad():
             dx1T = transpose_pad(dx1, Mp)                                                # [H, Mp]
             a16T = transpose_pad(keep["a16"], Mp)                                        # [Fp, Mp]
-            dW1 = torch.zeros(H, on.Fp, dtype=torch.float32, device=d)
-            gemm_nt_ex(dx1T, a16T, H, on.Fp, Mp, out32=dW1, split_k=8)
-            g["net.0.weight"].copy_(dW1[:, :on.F])
-            g["net.0.bias"].copy_(colsum(dx1))
-            held.extend([dx1T, a16T, dW1])
+            gemm_nt_ex(dx1T, a16T, H, on.F, Mp, out32=g["net.0.weight"], split_k=8)
+            colsum(dx1, out=g["net.0.bias"])
+            held.extend([dx1T, a16T])
         on_side(input_wgrad)
         main.wait_stream(side)
         for t_ in held:
             t_.record_stream(main)
         return loss, prio
+
+    def _backward_pipelined(self, keep, dheads, dO1, T, B):
+        """BPTT with the two layers software-pipelined over time chunks (mirror image of the forward pipeline).
+          bwd stream : layer-1 recurrence, chunks last -> first
+          main       : dO0[chunk] = dG1[chunk] W_ih1, then the layer-0 recurrence over that chunk; finally dx1 / dW1
+          side       : operand transposes + heads wgrad up front; each layer's dW_ih / dW_hh / db once that layer's
+                       recurrence is complete (layer 1's overlaps the rest of layer 0's recurrence)
+        Weight gradients are deliberately NOT chunked: bulk GEMM workgroups landing on every CU between chunk launches
+        delay the persistent kernels' (all-or-nothing) residency -- measured 4.4 vs 3.9 ms/update; restricting them
+        with stream priorities or CU masks measured worse still (7.8-11 ms).
+        """
+        lib, on, d, g = _lib.load_library(), self.online, self.device, self.grad
+        H, M = on.H, T * B
+        nch = self._nchunks(T, B)
+        Tc = T // nch
+        Mc = Tc * B
+        main, sb, side = torch.cuda.current_stream(d), self.bwd_stream, self.side
+        hseq = [h.view(M, H) for h in keep["hseq"]]
+        bf = torch.bfloat16
+        dGs = [torch.empty(T + 1, B, 4 * H, dtype=bf, device=d) for _ in range(2)]
+        dcs = [torch.zeros(B, H, dtype=torch.float32, device=d) for _ in range(2)]
+        dO0 = torch.empty(M, H, dtype=torch.float32, device=d)
+        dOs = [dO0, dO1]
+        dx1 = torch.empty(M, H, dtype=bf, device=d)
+        # transposed operands [*, B + M]: columns B.. hold x^T, so [:, :M] is the one-step-delayed copy (h_{t-1}, zeros
+        # for t = 0) and one transpose serves both the input-weight and the recurrent-weight gradient
+        hsT = [torch.empty(H, B + M, dtype=bf, device=d) for _ in range(2)]
+        x1T = torch.empty(H, M, dtype=bf, device=d)
+        a16T = torch.empty(on.Fp, M, dtype=bf, device=d)
+        dGT = torch.empty(4 * H, M, dtype=bf, device=d)      # reused by both layers (side stream order)
+        dx1T = torch.empty(H, M, dtype=bf, device=d)
+        dheadsT = torch.empty(self.NHp, M, dtype=bf, device=d)
+
+        def tr(src, dst):   # bf16 [R, C] -> dst [C, R] view
+            _lib.check(lib.hsad_transpose_bf16(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(),
+                                               dst.stride(0), _s(d)))
+
+        def csum(x, out, out2=None, col_map=None, ncols=None):
+            _lib.check(lib.hsad_colsum_acc(x.data_ptr(), 1, x.shape[0], x.shape[1] if ncols is None else ncols, x.stride(0),
+                                           out.data_ptr(), None if out2 is None else out2.data_ptr(),
+                                           None if col_map is None else col_map.data_ptr(), _s(d)))
+
+        def bchunk(l, c):
+            t0 = c * Tc
+            _lib.check(lib.hsad_lstm_backward_chunk(
+                Tc, B, H, keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
+                None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
+                dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
+                int(c != nch - 1), sync_scratch(d, Tc, B, "bwdc").data_ptr(), _s(d)))
+
+        def layer_wgrad(l, inT):
+            dG2 = dGs[l][:T].view(M, 4 * H)
+            tr(dG2, dGT)
+            gemm_nt_ex(dGT, inT, 4 * H, H, M, out32=g["lstm.weight_ih_l%d" % l], split_k=8, row_map=on.perm32)
+            gemm_nt_ex(dGT, hsT[l][:, :M], 4 * H, H, M, out32=g["lstm.weight_hh_l%d" % l], split_k=8, row_map=on.perm32)
+            csum(dG2, g["lstm.bias_ih_l%d" % l], g["lstm.bias_hh_l%d" % l], on.perm32)
+
+        sb.wait_stream(main)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for l in range(2):
+                hsT[l][:, :B].zero_()
+                tr(hseq[l], hsT[l][:, B:])
+            tr(keep["x1"], x1T)
+            tr(keep["a16"], a16T)
+            tr(dheads, dheadsT)
+            gemm_nt_ex(dheadsT, hsT[1][:, B:], on.NH, H, M, out32=self.g_wheads, split_k=8)
+            csum(dheads, self.g_bheads, ncols=on.NH)
+        for c in reversed(range(nch)):
+            r0 = c * Mc
+            with torch.cuda.stream(sb):
+                bchunk(1, c)
+                e1 = torch.cuda.Event()
+                e1.record(sb)
+            main.wait_event(e1)
+            gemm_nt_ex(dGs[1][c * Tc:(c + 1) * Tc].view(Mc, 4 * H), self.WihT[1], Mc, H, 4 * H, out32=dO0[r0:r0 + Mc])
+            bchunk(0, c)
+        with torch.cuda.stream(side):
+            side.wait_event(e1)                       # layer 1 complete
+            layer_wgrad(1, hsT[0][:, B:])
+            side.wait_stream(main)                    # layer 0 complete
+            layer_wgrad(0, x1T)
+        gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
+        tr(dx1, dx1T)
+        gemm_nt_ex(dx1T, a16T, H, on.F, M, out32=g["net.0.weight"], split_k=8)
+        csum(dx1, g["net.0.bias"])
+        main.wait_stream(side)
 
     def optimizer_step(self, beta1=0.9, beta2=0.999):
         lib = _lib.load_library()

@@ -263,7 +263,15 @@ int hsad_td_loss(const float* online_qa, const float* target_qa, const float* re
  * relu_mask16 <= 0). */
 int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                          float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
-                         const void* relu_mask16, int ldmask, void* stream);
+                         const void* relu_mask16, int ldmask, const int32_t* row_map, void* stream);
+/* (row_map, may be NULL: result row r lands in output row row_map[r] -- un-blocks the gate-blocked weight gradients) */
+/* fp32 master weight [R,C] -> bf16 kernel operands in one pass: dst16[r][:] = src[perm ? perm[r] : r][:] and/or its
+ * transpose dstT16[c][r] (either may be NULL; padding of the destinations is left untouched).  Replaces
+ * `weight[perm].to(bfloat16)` + transpose after every optimizer step. */
+int hsad_prepare_weight(const float* src, int R, int C, int ld_src, const int32_t* perm, void* dst16, int ld_dst,
+                        void* dstT16, int ld_dstT, void* stream);
+/* out[i] = a[perm[i]] + b[perm[i]] (b / perm may be NULL): the gate bias b_ih + b_hh in gate-blocked order */
+int hsad_bias_sum_perm(const float* a, const float* b, const int32_t* perm, float* out, int n, void* stream);
 /* BPTT through one LSTM layer (learner batches).  gates/cseq: saved by hsad_lstm_layer_forward; c0 (may be NULL =
  * zeros); WhhT_blocked bf16 [H,4H] = transpose of the gate-blocked W_hh; dO fp32 [T,Bn,H] (may be NULL).
  * Output dG16 bf16 [T+1,Bn,4H] (slot T is scratch): gradient wrt the gate pre-activations, gate-blocked.
@@ -281,6 +289,10 @@ int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int
                   void* stream);
 /* column sums (bias gradients) of a bf16 / fp32 [M, ld] matrix -> fp32 [N] */
 int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream);
+/* accumulating variant (no zeroing): out[col_map ? col_map[c] : c] += column sum c, and the same into out2 when given
+ * (the two LSTM bias gradients are both the un-blocked column sums of dG) */
+int hsad_colsum_acc(const void* src, int is_bf16, int M, int N, int ld, float* out, float* out2, const int32_t* col_map,
+                    void* stream);
 /* clip_grad_norm_(max_grad_norm) + Adam step over flat fp32 buffers (selfplay.py:231-235); step counts from 1;
  * scratch: fp32 [1]. */
 int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
