@@ -30,6 +30,18 @@ class Field(C.Structure):
 
 # every symbol include/hsad.h declares: (restype, argtypes)
 _P = C.c_void_p
+class LstmFwdRec(C.Structure):
+    """hsad_lstm_fwd_rec (include/hsad.h)"""
+    _fields_ = [("gates", C.c_void_p), ("Whh_blocked", C.c_void_p), ("h_prev16", C.c_void_p), ("c_prev", C.c_void_p),
+                ("hseq16", C.c_void_p), ("cseq", C.c_void_p), ("hT", C.c_void_p)]
+
+
+class LstmBwdRec(C.Structure):
+    """hsad_lstm_bwd_rec (include/hsad.h)"""
+    _fields_ = [("gates", C.c_void_p), ("cseq", C.c_void_p), ("c_before", C.c_void_p), ("WhhT_blocked", C.c_void_p),
+                ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int)]
+
+
 SIGNATURES = {
     "hsad_last_error": (C.c_char_p, []),
     "hsad_version": (C.c_char_p, []),
@@ -98,6 +110,8 @@ SIGNATURES = {
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "hsad_nstep_priority": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "hsad_zero_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "hsad_lstm_forward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "hsad_lstm_backward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_td_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),

@@ -509,7 +509,7 @@ struct LstmSeqArgs {
 typedef unsigned long long u64_t;
 
 template <int KB>  // KB = H / 32
-__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+__device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int H = KB * 32;
   constexpr int WS = H + 8;                      // padded LDS row stride (elements)
@@ -518,7 +518,6 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   int* s_okp = reinterpret_cast<int*>(sH + 32 * 40);                 // keep ALL LDS in the dynamic region (16-B base)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wu = wave & 1;
-  const int nb = blockIdx.x, rb = blockIdx.y, nrb = gridDim.y, nunit_blocks = gridDim.x;
   const int kofs = (lane >> 4) * 8;
   // W slice -> LDS (coalesced 16-byte loads)
   for (int c = tid; c < 128 * (H / 8); c += 256) {
@@ -645,6 +644,19 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
   }
 }
 
+// Up to four independent recurrences (layers of the pipeline x nets) in ONE launch: blockIdx.z picks the recurrence.
+// This is how the layer pipeline (and the online/target pair) overlap without depending on how HIP streams happen to
+// be multiplexed onto hardware queues.
+struct LstmSeqArgsN {
+  LstmSeqArgs r[4];
+};
+
+template <int KB>
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgsN m) {
+  lstm_seq_fwd_body<KB>(m.r[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.y, gridDim.x);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------------
 // Persistent BPTT through one LSTM layer: same workgroup grid / exchange protocol as lstm_seq_fwd_kernel.
@@ -667,7 +679,7 @@ struct LstmSeqBwdArgs {
 };
 
 template <int KB>  // KB = 4H / 32
-__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
+__device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = KB * 32, H = K / 4;
   constexpr int WS = K + 8;
@@ -676,7 +688,6 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
   int* s_okp = reinterpret_cast<int*>(sG + 32 * 136);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wu = wave & 1;
-  const int nb = blockIdx.x, rb = blockIdx.y, nrb = gridDim.y, nunit_blocks = gridDim.x;
   const int kofs = (lane >> 4) * 8;
   for (int c = tid; c < 32 * (K / 8); c += 256) {
     const int r = c / (K / 8), q = c - r * (K / 8);
@@ -804,6 +815,16 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgs a) {
       if (rbase + r < a.Bn) a.dc_io[(size_t)(rbase + r) * H + u] = dcs[r];
   }
 }
+
+struct LstmSeqBwdArgsN {
+  LstmSeqBwdArgs r[2];
+};
+
+template <int KB>
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgsN m) {
+  lstm_seq_bwd_body<KB>(m.r[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.y, gridDim.x);
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Dueling head + masked argmax (R2D2Net.forward tail, r2d2.py:106-115; _duel :124-131).
@@ -1195,6 +1216,35 @@ __global__ void zero_rows_kernel(float* __restrict__ x, const unsigned char* __r
 
 }  // namespace
 
+// ---- launch helpers for the persistent recurrences (nrec independent recurrences per launch) ----
+static int launch_seq_fwd(const LstmSeqArgsN& m, int nrec, int H, int nrb, hipStream_t s) {
+  const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
+  const dim3 grid(H / 32, nrb, nrec);
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, m);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_fwd_kernel<8>, grid, dim3(256), lds, s, m);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+static int launch_seq_bwd(const LstmSeqBwdArgsN& m, int nrec, int H, int nrb, hipStream_t s) {
+  const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
+  const dim3 grid(H / 32, nrb, nrec);
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, m);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, grid, dim3(256), lds, s, m);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
 extern "C" {
 
 int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
@@ -1294,19 +1344,9 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     q.T = T;
     q.Bn = Bn;
     q.H = H;
-    const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
-    const dim3 grid(H / 32, nrb);
-    if (H == 512) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, q);
-    } else {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(lstm_seq_fwd_kernel<8>, grid, dim3(256), lds, s, q);
-    }
-    HIP_TRY(hipGetLastError());
-    return HSAD_OK;
+    LstmSeqArgsN m{};
+    m.r[0] = q;
+    return launch_seq_fwd(m, 1, H, nrb, s);
   }
   for (int t = 0; t < T; ++t) {
     LstmStepArgs a;
@@ -1392,19 +1432,9 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
     unsigned* counters = (unsigned*)sync_scratch;
     HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb), s));  // the timeout word after the counters is sticky
     LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H, nullptr, 0};
-    const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
-    const dim3 grid(H / 32, nrb);
-    if (H == 512) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, q);
-    } else {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, grid, dim3(256), lds, s, q);
-    }
-    HIP_TRY(hipGetLastError());
-    return HSAD_OK;
+    LstmSeqBwdArgsN m{};
+    m.r[0] = q;
+    return launch_seq_bwd(m, 1, H, nrb, s);
   }
   HIP_TRY(hipMemsetAsync(dG + (size_t)T * step4, 0, step4 * 2, s));
   HIP_TRY(hipMemsetAsync(dc_scratch, 0, step1 * 4, s));
@@ -1529,68 +1559,72 @@ int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_
   return HSAD_OK;
 }
 
-// Chunked variants for layer pipelining: one persistent launch per chunk of Tc steps with the recurrent state carried
-// across launches (h as bf16 [Bn,H] = the previous chunk's last hseq row, c as fp32 = its last cseq row).
-int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
-                            const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream) {
-  if (!gates || !Whh_blocked || !h_prev16 || !hseq16 || !cseq || !sync_scratch) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk: null");
-  if (!((H == 256 || H == 512) && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk: needs H in {256,512}, Bn <= 512");
+// Chunked variants for the layer pipeline: one persistent launch runs up to four (forward) / two (backward) independent
+// recurrences over a chunk of Tc steps each, with the recurrent state carried across launches (h as bf16 [Bn,H] = the
+// previous chunk's last hseq row, c as fp32 = its last cseq row).  sync_scratch: uint32 [nrec*Tc*ceil(Bn/32) + 4].
+int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_fwd_rec* recs, void* sync_scratch,
+                                  void* stream) {
+  if (nrec < 1 || nrec > 4 || !recs || !sync_scratch || Tc < 1) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: bad arguments");
+  if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: needs H in {256,512}, Bn <= 512");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32;
   unsigned* counters = (unsigned*)sync_scratch;
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)Tc * nrb), s));
-  LstmSeqArgs q;
-  q.Whh = (const bf16_t*)Whh_blocked;
-  q.gates = gates;
-  q.c0 = c_prev;
-  q.h0_16 = (const bf16_t*)h_prev16;
-  q.hseq16 = (bf16_t*)hseq16;
-  q.cseq = cseq;
-  q.hT = hT;
-  q.counters = counters;
-  q.timeout = counters + (size_t)Tc * nrb;
-  q.T = Tc;
-  q.Bn = Bn;
-  q.H = H;
-  const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
-  const dim3 grid(H / 32, nrb);
-  if (H == 512) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, q);
-  } else {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lstm_seq_fwd_kernel<8>, grid, dim3(256), lds, s, q);
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)nrec * Tc * nrb), s));
+  LstmSeqArgsN m{};
+  for (int i = 0; i < nrec; ++i) {
+    const hsad_lstm_fwd_rec& r = recs[i];
+    if (!r.gates || !r.Whh_blocked || !r.h_prev16 || !r.hseq16 || !r.cseq) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: null pointer in record");
+    LstmSeqArgs& q = m.r[i];
+    q.Whh = (const bf16_t*)r.Whh_blocked;
+    q.gates = r.gates;
+    q.c0 = r.c_prev;
+    q.h0_16 = (const bf16_t*)r.h_prev16;
+    q.hseq16 = (bf16_t*)r.hseq16;
+    q.cseq = r.cseq;
+    q.hT = r.hT;
+    q.counters = counters + (size_t)i * Tc * nrb;
+    q.timeout = counters + (size_t)nrec * Tc * nrb;
+    q.T = Tc;
+    q.Bn = Bn;
+    q.H = H;
   }
-  HIP_TRY(hipGetLastError());
-  return HSAD_OK;
+  return launch_seq_fwd(m, nrec, H, nrb, s);
 }
 
-// gates / cseq / dO / dG16 point at the chunk's first step; dG16 slot Tc must hold the gradient of the following
-// chunk's first step when has_next != 0 (zeros are written there otherwise); c_before = c of the step preceding the
-// chunk (NULL = zeros); dc_io carries dc across chunks (zero it before the last-in-time chunk).
+int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
+                            const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream) {
+  hsad_lstm_fwd_rec r{gates, Whh_blocked, h_prev16, c_prev, hseq16, cseq, hT};
+  return hsad_lstm_forward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
+}
+
+// All sequence pointers address the chunk's first step; dG16 slot Tc must hold the gradient of the following chunk's
+// first step when has_next != 0 (it is zeroed otherwise); c_before = c of the step preceding the chunk (NULL = zeros);
+// dc_io carries dc across chunks (zero it before the last-in-time chunk).
+int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
+                                   void* stream) {
+  if (nrec < 1 || nrec > 2 || !recs || !sync_scratch || Tc < 1) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: bad arguments");
+  if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: needs H in {256,512}, Bn <= 512");
+  hipStream_t s = (hipStream_t)stream;
+  const int nrb = (Bn + 31) / 32;
+  unsigned* counters = (unsigned*)sync_scratch;
+  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)nrec * Tc * nrb), s));
+  LstmSeqBwdArgsN m{};
+  for (int i = 0; i < nrec; ++i) {
+    const hsad_lstm_bwd_rec& r = recs[i];
+    if (!r.gates || !r.cseq || !r.WhhT_blocked || !r.dG16 || !r.dc_io) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: null pointer in record");
+    bf16_t* dG = (bf16_t*)r.dG16;
+    if (!r.has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
+    m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
+                            counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next};
+  }
+  return launch_seq_bwd(m, nrec, H, nrb, s);
+}
+
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream) {
-  if (!gates || !cseq || !WhhT_blocked || !dG16 || !dc_io || !sync_scratch) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk: null");
-  if (!((H == 256 || H == 512) && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk: needs H in {256,512}, Bn <= 512");
-  hipStream_t s = (hipStream_t)stream;
-  const int nrb = (Bn + 31) / 32;
-  bf16_t* dG = (bf16_t*)dG16;
-  if (!has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
-  unsigned* counters = (unsigned*)sync_scratch;
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)Tc * nrb), s));
-  LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c_before, dO, dG, counters, counters + (size_t)Tc * nrb, Tc, Bn, H, dc_io, has_next};
-  const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
-  const dim3 grid(H / 32, nrb);
-  if (H == 512) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, q);
-  } else {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(lstm_seq_bwd_kernel<32>, grid, dim3(256), lds, s, q);
-  }
-  HIP_TRY(hipGetLastError());
-  return HSAD_OK;
+  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next};
+  return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
 }
 
 }  // extern "C"

@@ -60,20 +60,22 @@ def transpose_bf16(src):
 _SYNC = {}
 
 
-def sync_scratch(device, T, Bn, tag="fwd"):
-    """cached zero-initialised counter block for a persistent recurrence launch of (T, Bn) on the CURRENT stream (one
-    block per stream: launches on one stream are ordered, concurrent streams must not share counters)"""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, int(T), int(Bn))
+def sync_scratch(device, T, Bn, tag="fwd", nrec=1):
+    """cached zero-initialised counter block for a persistent recurrence launch (nrec recurrences of T steps, Bn rows) on
+    the CURRENT stream (one block per stream: launches on one stream are ordered, concurrent streams must not share
+    counters).  The word after the counters is the sticky timeout flag."""
+    n = int(nrec) * int(T) * ((int(Bn) + 31) // 32)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, n)
     buf = _SYNC.get(key)
     if buf is None:
-        buf = torch.zeros(T * ((Bn + 31) // 32) + 4, dtype=torch.int32, device=device)
+        buf = torch.zeros(n + 4, dtype=torch.int32, device=device)
         _SYNC[key] = buf
     return buf
 
 
 def check_sync():
     """raise if any persistent recurrence launch gave up waiting for a sibling workgroup (synchronises)"""
-    bad = [k for k, b in _SYNC.items() if int(b[k[3] * ((k[4] + 31) // 32)].item()) != 0]
+    bad = [k for k, b in _SYNC.items() if int(b[k[3]].item()) != 0]
     if bad:
         raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup: %s" % (bad,))
 
@@ -98,6 +100,58 @@ def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
                                            scratch.data_ptr(), hT.data_ptr(),
                                            None if sync is None else sync.data_ptr(), _s(d)))
     return hseq, cseq, hT
+
+
+def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
+    """Zero-initial-state trunks of up to two nets of identical shape on the same input, with the two LSTM layers
+    software-pipelined over `chunks` time chunks: stage s runs layer 0 on chunk s and layer 1 on chunk s-1 -- for every
+    net -- as ONE multi-recurrence persistent launch (hsad_lstm_forward_chunk_multi), everything in stream order.
+    Returns [(lstm_o bf16 [T,N,H], h [L,N,H], c [L,N,H])] per net; fills keeps[i] (may be None) for the backward pass."""
+    n0 = nets[0]
+    lib, d, H = n0.lib, n0.device, n0.H
+    T, N, F = priv_s.shape
+    M, Tc = T * N, T // chunks
+    assert len(nets) * 2 <= 4 and T % chunks == 0
+    a16 = cast_pad_bf16(priv_s.reshape(M, F), n0.Fp)
+    st = []
+    for net in nets:
+        x1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
+        gemm_nt(a16, net.W1, M, H, net.Fp, bias=net.b1, out16=x1, relu=True)
+        gates = [torch.empty(T, N, 4 * H, dtype=torch.float32, device=d) for _ in range(2)]
+        gemm_nt(x1, net.Wih[0], M, 4 * H, H, bias=net.bg[0], out32=gates[0].view(M, 4 * H))
+        st.append({"x1": x1, "gates": gates,
+                   "hseq": [torch.empty(T, N, H, dtype=torch.bfloat16, device=d) for _ in range(2)],
+                   "cseq": [torch.empty(T, N, H, dtype=torch.float32, device=d) for _ in range(2)],
+                   "hT": [torch.empty(N, H, dtype=torch.float32, device=d) for _ in range(2)]})
+    zero16 = torch.zeros(N, H, dtype=torch.bfloat16, device=d)
+
+    def rec(net, q, l, c):
+        t0 = c * Tc
+        return _lib.LstmFwdRec(q["gates"][l][t0].data_ptr(), net.Whh[l].data_ptr(),
+                               (zero16 if c == 0 else q["hseq"][l][t0 - 1]).data_ptr(),
+                               None if c == 0 else q["cseq"][l][t0 - 1].data_ptr(),
+                               q["hseq"][l][t0].data_ptr(), q["cseq"][l][t0].data_ptr(), q["hT"][l].data_ptr())
+
+    for s_ in range(chunks + 1):
+        recs = []
+        for net, q in zip(nets, st):
+            if s_ < chunks:
+                recs.append(rec(net, q, 0, s_))
+            if s_ >= 1:
+                t0 = (s_ - 1) * Tc
+                gemm_nt(q["hseq"][0][t0:t0 + Tc].view(Tc * N, H), net.Wih[1], Tc * N, 4 * H, H, bias=net.bg[1],
+                        out32=q["gates"][1][t0:t0 + Tc].view(Tc * N, 4 * H))
+                recs.append(rec(net, q, 1, s_ - 1))
+        arr = (_lib.LstmFwdRec * len(recs))(*recs)
+        _lib.check(lib.hsad_lstm_forward_chunk_multi(len(recs), Tc, N, H, arr,
+                                                     sync_scratch(d, Tc, N, "fwdm", len(recs)).data_ptr(), _s(d)))
+    out = []
+    for q, keep in zip(st, keeps):
+        if keep is not None:
+            keep.update({"a16": a16, "x1": q["x1"], "gates": [g.view(M, 4 * H) for g in q["gates"]], "hseq": q["hseq"],
+                         "cseq": q["cseq"]})
+        out.append((q["hseq"][1], torch.stack(q["hT"], 0), torch.stack([q["cseq"][0][T - 1], q["cseq"][1][T - 1]], 0)))
+    return out
 
 
 class R2D2NetKernels:
@@ -161,49 +215,7 @@ class R2D2NetKernels:
             r0 += n
 
     def _trunk_pipelined(self, priv_s, keep, chunks):
-        """zero-initial-state trunk with the two LSTM layers software-pipelined over `chunks` time chunks: layer 1's
-        input projection + recurrence for chunk c run on a second stream while layer 0 works on chunk c+1."""
-        lib = self.lib
-        T, N, F = priv_s.shape
-        M, H, d = T * N, self.H, self.device
-        Tc = T // chunks
-        s0 = torch.cuda.current_stream(d)
-        if getattr(self, "_s1", None) is None:
-            self._s1 = torch.cuda.Stream(device=d)
-        s1 = self._s1
-        a16 = cast_pad_bf16(priv_s.reshape(M, F), self.Fp)
-        x1 = torch.empty(M, H, dtype=torch.bfloat16, device=d)
-        gemm_nt(a16, self.W1, M, H, self.Fp, bias=self.b1, out16=x1, relu=True)
-        gates = [torch.empty(T, N, 4 * H, dtype=torch.float32, device=d) for _ in range(2)]
-        hseq = [torch.empty(T, N, H, dtype=torch.bfloat16, device=d) for _ in range(2)]
-        cseq = [torch.empty(T, N, H, dtype=torch.float32, device=d) for _ in range(2)]
-        hT = [torch.empty(N, H, dtype=torch.float32, device=d) for _ in range(2)]
-        zero16 = torch.zeros(N, H, dtype=torch.bfloat16, device=d)
-        gemm_nt(x1, self.Wih[0], M, 4 * H, H, bias=self.bg[0], out32=gates[0].view(M, 4 * H))
-        s1.wait_stream(s0)
-
-        def chunk(l, c):
-            t0 = c * Tc
-            _lib.check(lib.hsad_lstm_forward_chunk(
-                Tc, N, H, gates[l][t0].data_ptr(), self.Whh[l].data_ptr(),
-                (zero16 if c == 0 else hseq[l][t0 - 1]).data_ptr(), None if c == 0 else cseq[l][t0 - 1].data_ptr(),
-                hseq[l][t0].data_ptr(), cseq[l][t0].data_ptr(), hT[l].data_ptr(),
-                sync_scratch(d, Tc, N, "fwdc").data_ptr(), _s(d)))
-
-        for c in range(chunks):
-            chunk(0, c)
-            ev = torch.cuda.Event()
-            ev.record(s0)
-            with torch.cuda.stream(s1):
-                s1.wait_event(ev)
-                t0 = c * Tc
-                gemm_nt(hseq[0][t0:t0 + Tc].view(Tc * N, H), self.Wih[1], Tc * N, 4 * H, H, bias=self.bg[1],
-                        out32=gates[1][t0:t0 + Tc].view(Tc * N, 4 * H))
-                chunk(1, c)
-        s0.wait_stream(s1)
-        if keep is not None:
-            keep.update({"a16": a16, "x1": x1, "gates": [g.view(M, 4 * H) for g in gates], "hseq": hseq, "cseq": cseq})
-        return hseq[1], torch.stack(hT, 0), torch.stack([cseq[0][T - 1], cseq[1][T - 1]], 0)
+        return trunk_pipelined_multi([self], priv_s, [keep], chunks)[0]
 
     def trunk(self, priv_s, h0=None, c0=None, keep=None, chunks=1):
         """priv_s fp32 [T,N,F]; h0/c0 fp32 [L,N,H] or None -> lstm output bf16 [T,N,H], new h [L,N,H], new c."""
@@ -355,7 +367,6 @@ class R2D2Learner:
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
         self.chunks = 4          # time chunks for the layer pipeline (1 = layers strictly one after the other)
-        self.bwd_stream = torch.cuda.Stream(device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
         self._refresh_transposes()
 
@@ -386,16 +397,27 @@ class R2D2Learner:
         # the target trunk does not depend on the online net: run it on a side stream (the persistent LSTM kernels
         # occupy 64 CUs each, so both nets' recurrences overlap); join before the target q-head needs `greedy`
         main = torch.cuda.current_stream(d)
-        self.side.wait_stream(main)
-        qa, greedy, q, o = on.forward(priv, legal, a, keep=keep, chunks=self._nchunks(T, B))
-        with torch.cuda.stream(self.side):
-            to, _, _ = tg.trunk(priv, chunks=self._nchunks(T, B))
+        nch = self._nchunks(T, B)
+        if nch > 1:
+            # online and target trunks share every persistent launch (4 recurrences = 256 workgroups): no side stream
+            (o, _, _), (to, _, _) = trunk_pipelined_multi([on, tg], priv, [keep, None], nch)
+            hd = on.heads(o.reshape(M, H))
+            keep["heads"] = hd
+            q, qa, greedy = on.q_head(hd, legal.reshape(M, A), a.reshape(-1))
+            qa, greedy = qa.view(T, B), greedy.view(T, B)
             thd = tg.heads(to.reshape(M, H))
-        main.wait_stream(self.side)
+        else:
+            # the target trunk does not depend on the online net: run it on a side stream
+            self.side.wait_stream(main)
+            qa, greedy, q, o = on.forward(priv, legal, a, keep=keep)
+            with torch.cuda.stream(self.side):
+                to, _, _ = tg.trunk(priv)
+                thd = tg.heads(to.reshape(M, H))
+            main.wait_stream(self.side)
+            to.record_stream(main)
+            thd.record_stream(main)
         _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
         tqa = tqa.view(T, B)
-        to.record_stream(main)
-        thd.record_stream(main)
         err, prio, loss, dqa = td_loss(qa, tqa, batch["reward"], batch["bootstrap"], batch["seq_len"], self.multi_step,
                                        self.gamma, weight=weight, want_grad=compute_grad)
         heads = keep["heads"]
@@ -488,8 +510,8 @@ class R2D2Learner:
 
     def _backward_pipelined(self, keep, dheads, dO1, T, B):
         """BPTT with the two layers software-pipelined over time chunks (mirror image of the forward pipeline).
-          bwd stream : layer-1 recurrence, chunks last -> first
-          main       : dO0[chunk] = dG1[chunk] W_ih1, then the layer-0 recurrence over that chunk; finally dx1 / dW1
+          main       : stage s = [dO0 of chunk nch-s = dG1 W_ih1] then ONE persistent launch running layer 1 on chunk
+                       nch-1-s next to layer 0 on chunk nch-s (hsad_lstm_backward_chunk_multi); finally dx1 / dW1
           side       : operand transposes + heads wgrad up front; each layer's dW_ih / dW_hh / db once that layer's
                        recurrence is complete (layer 1's overlaps the rest of layer 0's recurrence)
         Weight gradients are deliberately NOT chunked: bulk GEMM workgroups landing on every CU between chunk launches
@@ -501,7 +523,7 @@ class R2D2Learner:
         nch = self._nchunks(T, B)
         Tc = T // nch
         Mc = Tc * B
-        main, sb, side = torch.cuda.current_stream(d), self.bwd_stream, self.side
+        main, side = torch.cuda.current_stream(d), self.side
         hseq = [h.view(M, H) for h in keep["hseq"]]
         bf = torch.bfloat16
         dGs = [torch.empty(T + 1, B, 4 * H, dtype=bf, device=d) for _ in range(2)]
@@ -527,13 +549,12 @@ class R2D2Learner:
                                            out.data_ptr(), None if out2 is None else out2.data_ptr(),
                                            None if col_map is None else col_map.data_ptr(), _s(d)))
 
-        def bchunk(l, c):
+        def brec(l, c):
             t0 = c * Tc
-            _lib.check(lib.hsad_lstm_backward_chunk(
-                Tc, B, H, keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
-                None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
-                dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
-                int(c != nch - 1), sync_scratch(d, Tc, B, "bwdc").data_ptr(), _s(d)))
+            return _lib.LstmBwdRec(keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
+                                   None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
+                                   dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
+                                   int(c != nch - 1))
 
         def layer_wgrad(l, inT):
             dG2 = dGs[l][:T].view(M, 4 * H)
@@ -542,7 +563,6 @@ class R2D2Learner:
             gemm_nt_ex(dGT, hsT[l][:, :M], 4 * H, H, M, out32=g["lstm.weight_hh_l%d" % l], split_k=8, row_map=on.perm32)
             csum(dG2, g["lstm.bias_ih_l%d" % l], g["lstm.bias_hh_l%d" % l], on.perm32)
 
-        sb.wait_stream(main)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for l in range(2):
@@ -553,19 +573,27 @@ class R2D2Learner:
             tr(dheads, dheadsT)
             gemm_nt_ex(dheadsT, hsT[1][:, B:], on.NH, H, M, out32=self.g_wheads, split_k=8)
             csum(dheads, self.g_bheads, ncols=on.NH)
-        for c in reversed(range(nch)):
-            r0 = c * Mc
-            with torch.cuda.stream(sb):
-                bchunk(1, c)
+        # stage s: layer 1 on chunk nch-1-s next to layer 0 on chunk nch-s, one persistent launch per stage
+        e1 = None
+        for s_ in range(nch + 1):
+            recs = []
+            if s_ < nch:
+                recs.append(brec(1, nch - 1 - s_))
+            if s_ >= 1:
+                c0 = nch - s_
+                r0 = c0 * Mc
+                gemm_nt_ex(dGs[1][c0 * Tc:(c0 + 1) * Tc].view(Mc, 4 * H), self.WihT[1], Mc, H, 4 * H, out32=dO0[r0:r0 + Mc])
+                recs.append(brec(0, c0))
+            arr = (_lib.LstmBwdRec * len(recs))(*recs)
+            _lib.check(lib.hsad_lstm_backward_chunk_multi(len(recs), Tc, B, H, arr,
+                                                          sync_scratch(d, Tc, B, "bwdm", len(recs)).data_ptr(), _s(d)))
+            if s_ == nch - 1:
                 e1 = torch.cuda.Event()
-                e1.record(sb)
-            main.wait_event(e1)
-            gemm_nt_ex(dGs[1][c * Tc:(c + 1) * Tc].view(Mc, 4 * H), self.WihT[1], Mc, H, 4 * H, out32=dO0[r0:r0 + Mc])
-            bchunk(0, c)
+                e1.record(main)                           # layer 1 complete
         with torch.cuda.stream(side):
-            side.wait_event(e1)                       # layer 1 complete
+            side.wait_event(e1)
             layer_wgrad(1, hsT[0][:, B:])
-            side.wait_stream(main)                    # layer 0 complete
+            side.wait_stream(main)                        # layer 0 complete
             layer_wgrad(0, x1T)
         gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
         tr(dx1, dx1T)

@@ -307,6 +307,34 @@ int hsad_nstep_priority(const float* qa, const float* target_qa, const float* re
                         int multi_step, double gamma, int N, float* out, void* stream);
 /* zero rows r of fp32 x[L,N,H] where flag[r / rows_per_flag] != 0 (hidden-state reset on terminal, r2d2_actor.h:109-126) */
 int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);
+/* One recurrence of a multi-recurrence chunk launch (see hsad_lstm_forward_chunk for the field meanings) */
+typedef struct hsad_lstm_fwd_rec {
+  float* gates;
+  const void* Whh_blocked;
+  const void* h_prev16;
+  const float* c_prev;
+  void* hseq16;
+  float* cseq;
+  float* hT; /* optional */
+} hsad_lstm_fwd_rec;
+typedef struct hsad_lstm_bwd_rec {
+  const float* gates;
+  const float* cseq;
+  const float* c_before;
+  const void* WhhT_blocked;
+  const float* dO;
+  void* dG16;
+  float* dc_io;
+  int has_next;
+} hsad_lstm_bwd_rec;
+/* nrec (<= 4 forward, <= 2 backward) independent recurrences of identical shape in ONE persistent launch, e.g. layer 0
+ * on chunk c+1 next to layer 1 on chunk c, for the online and the target net at once.  The overlap is inside the launch,
+ * so it does not depend on how HIP streams are multiplexed onto hardware queues.  Needs nrec * (H/32) * ceil(Bn/32)
+ * co-resident workgroups (one per CU).  sync_scratch: uint32 [nrec*Tc*ceil(Bn/32) + 4], sticky timeout word last. */
+int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_fwd_rec* recs, void* sync_scratch,
+                                  void* stream);
+int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
+                                   void* stream);
 /* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
  * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,

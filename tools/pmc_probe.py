@@ -10,6 +10,8 @@ EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
 env = BatchedHanabiEnv(G, seed=1, eps_list=EPS, device="cuda:0", track_deck_history=False)
 env.rollout_random(20, 5)
 torch.cuda.synchronize()
+env.rollout_random(10, 5)   # the fused kernel (env_kernel<3,...>) the benchmark's timed region launches
+torch.cuda.synchronize()
 for _ in range(10):
     env.reset(); a, g = env.policy_random(5); env.step(a, g)
 torch.cuda.synchronize()
