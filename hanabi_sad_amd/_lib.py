@@ -74,6 +74,9 @@ SIGNATURES = {
     "hsad_replay_bytes": (C.c_int64, [_P]),
     "hsad_replay_add": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P, _P, _P]),
     "hsad_replay_sample": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P, _P]),
+    "hsad_replay_priority_sum": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "hsad_replay_draw_canonical": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float)]),
+    "hsad_replay_sample_at": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(_P), _P, _P, _P, _P, _P, _P]),
     "hsad_replay_update_priority": (C.c_int, [_P, _P, C.c_int, _P]),
     "hsad_replay_size": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hsad_replay_get": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P]),

@@ -232,8 +232,12 @@ __global__ void replay_add_scalars_kernel(ReplayDev rd, int n, int T, const floa
 }
 
 // PrioritizedReplay::sample_ (rela/prioritized_replay.h:274-345) as one block.
+// targets == nullptr: the reference's stratified draw from canonical uniforms.  targets != nullptr (sharded replay): B
+// explicit positions in THIS shard's cumulative-weight space (the global stratified positions minus the weight of the
+// shards before it); weight_out then receives the raw weights w_i and the caller forms the global IS weights.
 __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B, const float* __restrict__ canon,
-                                                             float* __restrict__ weight_out) {
+                                                             float* __restrict__ weight_out,
+                                                             const float* __restrict__ targets = nullptr) {
   __shared__ double s_incl[1024];
   __shared__ double s_red[1024];
   __shared__ float s_rand[kMaxBatch];
@@ -245,10 +249,14 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   const ReplayCtl c = *rd.ctl;
   const int N = c.size, head = c.head, ring = rd.ring;
   const float sum = (float)c.sum;
-  const float segment = sum / B;
+  const float segment = sum / (B > 0 ? B : 1);
   if (tid < B) {
-    float r = canon[tid] * segment + tid * segment;  // uniform_real_distribution(0, segment)(rng) + i * segment
-    s_rand[tid] = fminf(sum - 0.1f, r);
+    if (targets) {
+      s_rand[tid] = fminf(fmaxf(targets[tid], 0.f), sum * (1.f - 1e-6f));
+    } else {
+      float r = canon[tid] * segment + tid * segment;  // uniform_real_distribution(0, segment)(rng) + i * segment
+      s_rand[tid] = fminf(sum - 0.1f, r);
+    }
   }
   // chunked prefix sums of the weights in ring order, accumulated in double like the reference's accSum
   const int C = (N + 1023) / 1024;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   }
   __syncthreads();
   if (tid == 0) {
-    float m = s_y[0];
+    float m = B > 0 ? s_y[0] : 1.f;
     for (int i = 1; i < B; ++i) m = fmaxf(m, s_y[i]);
     s_max = m;
     ReplayCtl cc = *rd.ctl;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     *rd.ctl = cc;
   }
   __syncthreads();
-  if (tid < B) weight_out[tid] = s_y[tid] / s_max;
+  if (tid < B) weight_out[tid] = targets ? s_w[tid] : s_y[tid] / s_max;
 }
 
 // PrioritizedReplay::updatePriority -> ConcurrentQueue::update (sequential: duplicates see earlier writes)
@@ -695,6 +703,44 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
                      r->rd.sampled_ids, 0);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((batch * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
                      r->bootstrap, r->seq_len, r->rd.sampled_ids, batch, r->T, reward, terminal, bootstrap, seq_len);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// ---- sharded replay (one shard per GPU): the stratified draw is done over the concatenation of all
+// shards; each shard serves the positions that fall into its own slice of the cumulative weight. ----
+int hsad_replay_priority_sum(hsad_replay* r, double* sum, int32_t* size) {
+  if (!r || !sum) return rfail(HSAD_ERR_INVALID, "null argument");
+  ReplayCtl c;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&c, r->rd.ctl, sizeof(c), hipMemcpyDeviceToHost));
+  *sum = c.sum;
+  if (size) *size = c.size;
+  return HSAD_OK;
+}
+
+int hsad_replay_draw_canonical(hsad_replay* r, int n, float* out_host) {
+  if (!r || !out_host || n < 0 || n > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad argument");
+  for (int i = 0; i < n; ++i) out_host[i] = std::generate_canonical<float, 24>(r->rng);
+  return HSAD_OK;
+}
+
+int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void* const* out_fields, float* reward,
+                          uint8_t* terminal, float* bootstrap, float* seq_len, float* raw_weight, void* stream) {
+  if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (n < 0 || n > kMaxBatch || (n > 0 && (!targets_host || !raw_weight))) return rfail(HSAD_ERR_INVALID, "bad batch");
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  for (int i = 0; i < n; ++i) r->h_canon[i] = targets_host[i];
+  if (n > 0) HIP_TRY(hipMemcpyAsync(r->d_canon, r->h_canon.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon);
+  if (n > 0) {
+    FieldPtrsMut fp;
+    for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0);
+    hipLaunchKernelGGL(gather_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
+                       r->bootstrap, r->seq_len, r->rd.sampled_ids, n, r->T, reward, terminal, bootstrap, seq_len);
+  }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

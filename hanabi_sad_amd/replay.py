@@ -115,6 +115,38 @@ class DeviceReplay:
         fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
         return (fields, reward, terminal.bool(), bootstrap, seq_len), weight
 
+    # ---- shard interface used by hanabi_sad_amd.dist.ShardedReplay (one DeviceReplay per GPU) ----
+    def priority_sum(self):
+        """(running weight sum as float, size) of this shard; synchronises the device"""
+        sm, sz = C.c_double(0.0), C.c_int32(0)
+        _lib.check(self.lib.hsad_replay_priority_sum(self.h, C.byref(sm), C.byref(sz)))
+        return sm.value, sz.value
+
+    def draw_canonical(self, n):
+        """the next n canonical uniforms of this replay's std::mt19937 stream (what sample(n) would consume), float32"""
+        import numpy as np
+        out = (C.c_float * n)()
+        _lib.check(self.lib.hsad_replay_draw_canonical(self.h, int(n), out))
+        return np.frombuffer(out, dtype=np.float32).copy()
+
+    def sample_at(self, targets):
+        """targets: host float32 positions in this shard's cumulative-weight space (len may be 0).
+        -> (fields dict [T,n,w], reward, terminal(bool), bootstrap [T,n], seq_len [n]), raw_weight [n]"""
+        import numpy as np
+        targets = np.ascontiguousarray(targets, dtype=np.float32)
+        n, d, T = int(targets.shape[0]), self.device, self.T
+        outs = [torch.empty(T, n, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d) for _, w, dt in self.fields]
+        reward = torch.empty(T, n, dtype=torch.float32, device=d)
+        terminal = torch.empty(T, n, dtype=torch.uint8, device=d)
+        bootstrap = torch.empty(T, n, dtype=torch.float32, device=d)
+        seq_len = torch.empty(n, dtype=torch.float32, device=d)
+        raw_w = torch.empty(n, dtype=torch.float32, device=d)
+        _lib.check(self.lib.hsad_replay_sample_at(self.h, n, targets.ctypes.data_as(C.POINTER(C.c_float)), _ptr_array(outs),
+                                                  reward.data_ptr(), terminal.data_ptr(), bootstrap.data_ptr(),
+                                                  seq_len.data_ptr(), raw_w.data_ptr(), _stream(d)))
+        fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
+        return (fields, reward, terminal.bool(), bootstrap, seq_len), raw_w
+
     def update_priority(self, priority):
         priority = priority.to(self.device, torch.float32).contiguous()
         _lib.check(self.lib.hsad_replay_update_priority(self.h, priority.data_ptr(), int(priority.numel()),

@@ -5,7 +5,8 @@ build env / agent / replay / actor, burn in, then alternate rollout and learner 
 
 Single GPU: actors and learner share the device and alternate in lock-step.  Multi-GPU
 (torchrun, one rank per GPU): every rank rolls out its shard of games into its own replay shard; rank 0 is
-the learner and broadcasts the online/target parameters over RCCL every --actor_sync_freq updates
+the learner: its batches are assembled from ALL shards (stratified over their concatenation), the new priorities go
+back to the owning shards, and the online/target parameters are broadcast over RCCL every --actor_sync_freq updates
  — see hanabi_sad_amd/dist.py."""
 import argparse
 import time
@@ -56,23 +57,28 @@ class Trainer:
                                     max_len=args.max_len, sad=bool(args.sad), shuffle_color=bool(args.shuffle_color),
                                     device=device, track_deck_history=False)
         W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed)
+        # only the learner rank holds optimizer state; actor ranks receive parameters by broadcast
         self.learner = R2D2Learner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
-                                   device=device)
+                                   device=device) if rank == 0 else None
         # the actors run their own copies of the agent, refreshed every actor_sync_freq updates
         # (ActGroup.update_model / BatchRunner::updateModel, create.py:143-145)
         self.act_online = R2D2NetKernels(W, device)
         self.act_target = R2D2NetKernels(W, device)
         self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
         fields = transition_fields(self.env)
-        self.replay = DeviceReplay(args.replay_buffer_size, args.seed + rank, args.priority_exponent,
-                                   args.priority_weight, args.prefetch, args.max_len, fields, device)
+        # the reference's capacity is split evenly over the per-GPU shards
+        self.replay = DeviceReplay(max(args.batchsize, args.replay_buffer_size // world), args.seed + rank,
+                                   args.priority_exponent, args.priority_weight, args.prefetch, args.max_len, fields, device)
+        from .dist import ShardedReplay
+        self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0)
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len)
         self.num_update = 0
 
     def update_actor_model(self):
-        for k in PARAM_ORDER:
-            self.act_online.w[k].copy_(self.learner.online.w[k])
-            self.act_target.w[k].copy_(self.learner.target.w[k])
+        if self.learner is not None:
+            for k in PARAM_ORDER:
+                self.act_online.w[k].copy_(self.learner.online.w[k])
+                self.act_target.w[k].copy_(self.learner.target.w[k])
         if self.world > 1:
             from .dist import broadcast_params
             broadcast_params([self.act_online.w[k] for k in PARAM_ORDER] + [self.act_target.w[k] for k in PARAM_ORDER], src=0)
@@ -80,18 +86,26 @@ class Trainer:
         self.act_target.refresh()
 
     def learner_update(self):
+        """one learner iteration; collective when world > 1 (every rank calls it in lock-step: actor ranks serve their
+        share of the batch, receive the new priorities of the rows they contributed and, every actor_sync_freq updates,
+        the parameters)"""
         a = self.args
-        if self.num_update % a.num_update_between_sync == 0:
+        if self.learner is not None and self.num_update % a.num_update_between_sync == 0:
             self.learner.sync_target_with_online()
         if self.num_update % a.actor_sync_freq == 0:
             self.update_actor_model()
-        (f, reward, terminal, bootstrap, seq_len), weight = self.replay.sample(a.batchsize)
+        res = self.sharded.sample(a.batchsize)
+        if self.learner is None:
+            self.sharded.update_priority()
+            self.num_update += 1
+            return None, None
+        (f, reward, terminal, bootstrap, seq_len), weight = res
         batch = {"priv_s": f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
                  "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)
         g_norm = self.learner.optimizer_step()
-        self.replay.update_priority(prio)
+        self.sharded.update_priority(prio)
         self.num_update += 1
         return (loss * weight).mean(), g_norm
 
@@ -127,6 +141,8 @@ def parse_args(argv=None):
     p.add_argument("--act_eps_alpha", type=float, default=7)
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
+    p.add_argument("--dist_backend", type=str, default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (smoke runs "
+                   "with several ranks sharing a GPU: tensors are staged through host memory)")
     return p.parse_args(argv)
 
 
@@ -137,12 +153,13 @@ def main(argv=None):
     if world > 1:
         import os
         import torch.distributed as dist
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.dist_backend)
     dev = "cuda:%d" % torch.cuda.current_device()
     tr = Trainer(args, dev, rank, world)
     t0 = time.time()
-    while tr.replay.size() < args.burn_in_frames:
+    while tr.replay.size() < max(args.batchsize, args.burn_in_frames // world):   # per-shard share of the burn-in
         for _ in range(10):
             tr.actor.step()
     tr.env.check_errors()
@@ -152,7 +169,7 @@ def main(argv=None):
         for _ in range(args.act_steps_per_update):
             tr.actor.step()
         loss, g_norm = tr.learner_update()
-        if u % 20 == 0:
+        if u % 20 == 0 and loss is not None:
             print("update %d loss %.4f grad_norm %.3f replay %d" % (u, float(loss), float(g_norm), tr.replay.size()))
     torch.cuda.synchronize()
     dt = time.time() - t0

@@ -190,6 +190,18 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
 int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float* reward, uint8_t* terminal,
                        float* bootstrap, float* seq_len, float* weight, void* stream);
 int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch, void* stream);
+/* Sharded replay (one shard per GPU).  The reference's stratified draw (prioritized_replay.h:291-334) is
+ * taken over the CONCATENATION of the shards: rank-0's generator supplies the canonical uniforms
+ * (hsad_replay_draw_canonical = the generate_canonical<float,24> stream sample() would consume), every shard reports its
+ * running weight sum / size (hsad_replay_priority_sum; synchronises), and serves the positions that fall inside its own
+ * slice with hsad_replay_sample_at: targets_host[i] = global position - weight of the shards before this one (host float32,
+ * n may be 0: only the eviction bookkeeping of sample() runs).  raw_weight [n] receives w_i = priority^alpha of the drawn
+ * elements; the caller forms (N*w/sum)^-beta / max over the assembled batch.  Alternates with
+ * hsad_replay_update_priority(n) like hsad_replay_sample.  Host-side choreography: hanabi_sad_amd/dist.py. */
+int hsad_replay_priority_sum(hsad_replay* r, double* sum, int32_t* size);
+int hsad_replay_draw_canonical(hsad_replay* r, int n, float* out_host);
+int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void* const* out_fields, float* reward,
+                          uint8_t* terminal, float* bootstrap, float* seq_len, float* raw_weight, void* stream);
 /* size() / numAdd(): synchronise the stream the producers used, then read the device counters. */
 int hsad_replay_size(hsad_replay* r, int32_t* size, int32_t* num_add);
 /* get(idx): element idx counted from the ring head; out_fields[k] -> [T, width_k] */
