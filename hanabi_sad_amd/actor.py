@@ -2,7 +2,9 @@
 cpp/thread_loop.h:42-88) for ALL games in lock-step on one GPU — no threads, no batcher, no host copies.
 
 IQL layout (reference create.py:115-131: one actor per player): every (game, player) pair is one "env row"
-of the agent / sequence writer; reward and terminal are shared by the players of a game."""
+of the agent / sequence writer; reward and terminal are shared by the players of a game.
+VDN layout (create.py:98-113: one actor sees [E, P, ·]): the agent still acts on (game, player) rows, but a transition
+is one GAME (fields of width P·w, one reward / terminal / priority per game) and priorities sum Q over the players."""
 from collections import deque
 
 import torch
@@ -12,21 +14,26 @@ from .r2d2 import R2D2Agent, zero_hidden_rows
 from .replay import DeviceReplay, SequenceWriter
 
 
-def transition_fields(env):
-    """per-step fields of an IQL RNNTransition: obs {priv_s, legal_move, eps, own_hand} + action {a, greedy_a}
-    (cpp/hanabi_env.cc:197-204; pyhanabi/r2d2.py:296-303)"""
-    return [("priv_s", env.F, torch.float32), ("legal_move", env.A, torch.float32), ("eps", 1, torch.float32),
-            ("own_hand", 3 * env.H, torch.float32), ("a", 1, torch.int64), ("greedy_a", 1, torch.int64)]
+def transition_fields(env, vdn=False):
+    """per-step fields of an RNNTransition: obs {priv_s, legal_move, eps, own_hand} + action {a, greedy_a}
+    (cpp/hanabi_env.cc:197-204; pyhanabi/r2d2.py:296-303).  IQL: one transition per (game, player); VDN: one per
+    game with the players' rows concatenated ([P, w] flattened)."""
+    m = env.P if vdn else 1
+    return [("priv_s", m * env.F, torch.float32), ("legal_move", m * env.A, torch.float32), ("eps", m, torch.float32),
+            ("own_hand", m * 3 * env.H, torch.float32), ("a", m, torch.int64), ("greedy_a", m, torch.int64)]
 
 
 class DeviceActor:
-    def __init__(self, env: BatchedHanabiEnv, agent: R2D2Agent, replay: DeviceReplay, multi_step, gamma, eta, seq_len):
+    def __init__(self, env: BatchedHanabiEnv, agent: R2D2Agent, replay: DeviceReplay, multi_step, gamma, eta, seq_len,
+                 vdn=False):
         self.env, self.agent, self.replay = env, agent, replay
         self.G, self.P = env.G, env.P
-        self.N = self.G * self.P
+        self.N = self.G * self.P              # agent rows (hidden state [L, N, H]) in both layouts
+        self.vdn = bool(vdn)
+        self.E = self.G if self.vdn else self.N   # transitions per step
         self.eta = float(eta)
         self.multi_step = int(multi_step)
-        self.writer = SequenceWriter(self.N, multi_step, gamma, seq_len, transition_fields(env), env.device)
+        self.writer = SequenceWriter(self.E, multi_step, gamma, seq_len, transition_fields(env, self.vdn), env.device)
         self.hid = agent.get_h0(self.N)
         self.history_hid = deque()
         self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
@@ -48,10 +55,10 @@ class DeviceActor:
         fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
         self.writer.push_obs_action(fields)
         env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))
-        self.num_act += self.N
-        # postAct: reward / terminal of the game go to each of its players' rows
-        r = env.reward.repeat_interleave(P)
-        t = env.terminal.repeat_interleave(P)
+        self.num_act += self.N               # Tachometer counts P acts per game step in both layouts (utils.py:229-236)
+        # postAct: reward / terminal of the game go to each of its players' rows (IQL) or to the game's row (VDN)
+        r = env.reward if self.vdn else env.reward.repeat_interleave(P)
+        t = env.terminal if self.vdn else env.terminal.repeat_interleave(P)
         self.writer.push_reward_terminal(r, t)
         zero_hidden_rows(self.hid, env.terminal, P)                                    # r2d2_actor.h:109-126
         if not self.writer.can_pop():
@@ -59,8 +66,10 @@ class DeviceActor:
         cur, nxt, rew, term, boot = self.writer.pop_transition()
         hid_s = self.history_hid.popleft()
         hid_next = self.history_hid[-1]
-        cur_obs = {"priv_s": cur["priv_s"], "legal_move": cur["legal_move"]}
-        nxt_obs = {"priv_s": nxt["priv_s"], "legal_move": nxt["legal_move"]}
-        prio = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, hid_next, rew, boot)
+        N, F, A = self.N, env.F, env.A       # VDN rows [G, P*w] are the same memory as [G*P, w]
+        cur_obs = {"priv_s": cur["priv_s"].view(N, F), "legal_move": cur["legal_move"].view(N, A)}
+        nxt_obs = {"priv_s": nxt["priv_s"].view(N, F), "legal_move": nxt["legal_move"].view(N, A)}
+        prio = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, hid_next, rew, boot,
+                                      num_player=P if self.vdn else 1)
         self.writer.push_sequence(prio)
         self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)

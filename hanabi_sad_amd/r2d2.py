@@ -132,6 +132,10 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
                                None if c == 0 else q["cseq"][l][t0 - 1].data_ptr(),
                                q["hseq"][l][t0].data_ptr(), q["cseq"][l][t0].data_ptr(), q["hT"][l].data_ptr())
 
+    # every workgroup of a launch must be resident at once (they spin on each other): at most CUs // (64 * row blocks)
+    # recurrences per launch (4 at B = 128 on a 256-CU MI355X, 2 at 256 rows)
+    cus = torch.cuda.get_device_properties(d).multi_processor_count
+    per_launch = max(1, min(4, cus // ((H // 32) * ((N + 31) // 32))))
     for s_ in range(chunks + 1):
         recs = []
         for net, q in zip(nets, st):
@@ -142,9 +146,11 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
                 gemm_nt(q["hseq"][0][t0:t0 + Tc].view(Tc * N, H), net.Wih[1], Tc * N, 4 * H, H, bias=net.bg[1],
                         out32=q["gates"][1][t0:t0 + Tc].view(Tc * N, 4 * H))
                 recs.append(rec(net, q, 1, s_ - 1))
-        arr = (_lib.LstmFwdRec * len(recs))(*recs)
-        _lib.check(lib.hsad_lstm_forward_chunk_multi(len(recs), Tc, N, H, arr,
-                                                     sync_scratch(d, Tc, N, "fwdm", len(recs)).data_ptr(), _s(d)))
+        for i in range(0, len(recs), per_launch):
+            part = recs[i:i + per_launch]
+            arr = (_lib.LstmFwdRec * len(part))(*part)
+            _lib.check(lib.hsad_lstm_forward_chunk_multi(len(part), Tc, N, H, arr,
+                                                         sync_scratch(d, Tc, N, "fwdm", len(part)).data_ptr(), _s(d)))
     out = []
     for q, keep in zip(st, keeps):
         if keep is not None:
@@ -367,6 +373,7 @@ class R2D2Learner:
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
         self.chunks = 4          # time chunks for the layer pipeline (1 = layers strictly one after the other)
+        self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self.side = torch.cuda.Stream(device=self.device)
         self._refresh_transposes()
 
@@ -391,7 +398,16 @@ class R2D2Learner:
         lib = _lib.load_library()
         on, tg, d = self.online, self.target, self.device
         priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]
-        T, B, _ = priv.shape
+        NPL = 1
+        if priv.dim() == 4:
+            # VDN (td_error / flat_4d, r2d2.py:363-412): [T,B,P,*] -> B*P rows; Q-values are summed over the players of a
+            # game before the TD error, so d loss / d qa of a row is that of its game
+            if pred_weight > 0:
+                raise _lib.HsadError("VDN with the auxiliary task is broken in the reference (aux_task_vdn, SURVEY F6b) "
+                                     "and therefore has no defined behaviour to reproduce")
+            NPL = priv.shape[2]
+            priv, legal, a = priv.flatten(1, 2), legal.flatten(1, 2), a.flatten(1, 2)
+        T, B, _ = priv.shape        # B = rows per step (games x players for VDN)
         M, H, A = T * B, on.H, on.A
         keep = {}
         # the target trunk does not depend on the online net: run it on a side stream (the persistent LSTM kernels
@@ -418,6 +434,8 @@ class R2D2Learner:
             thd.record_stream(main)
         _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
         tqa = tqa.view(T, B)
+        if NPL > 1:
+            qa, tqa = qa.view(T, B // NPL, NPL).sum(-1), tqa.view(T, B // NPL, NPL).sum(-1)
         err, prio, loss, dqa = td_loss(qa, tqa, batch["reward"], batch["bootstrap"], batch["seq_len"], self.multi_step,
                                        self.gamma, weight=weight, want_grad=compute_grad)
         heads = keep["heads"]
@@ -430,6 +448,9 @@ class R2D2Learner:
             loss = loss + pred_weight * xs
         if not compute_grad:
             return loss, prio
+        if NPL > 1:
+            dqa = dqa.repeat_interleave(NPL, dim=1)      # every player's Q enters its game's sum with weight 1
+            weight = weight.repeat_interleave(NPL)
         # ---- backward ----
         Mp = _pad32(M)
         dheads = torch.empty(M, self.NHp, dtype=torch.bfloat16, device=d)
@@ -584,9 +605,12 @@ class R2D2Learner:
                 r0 = c0 * Mc
                 gemm_nt_ex(dGs[1][c0 * Tc:(c0 + 1) * Tc].view(Mc, 4 * H), self.WihT[1], Mc, H, 4 * H, out32=dO0[r0:r0 + Mc])
                 recs.append(brec(0, c0))
-            arr = (_lib.LstmBwdRec * len(recs))(*recs)
-            _lib.check(lib.hsad_lstm_backward_chunk_multi(len(recs), Tc, B, H, arr,
-                                                          sync_scratch(d, Tc, B, "bwdm", len(recs)).data_ptr(), _s(d)))
+            per_launch = max(1, min(2, self._cus // ((H // 32) * ((B + 31) // 32))))
+            for i in range(0, len(recs), per_launch):
+                part = recs[i:i + per_launch]
+                arr = (_lib.LstmBwdRec * len(part))(*part)
+                _lib.check(lib.hsad_lstm_backward_chunk_multi(len(part), Tc, B, H, arr,
+                                                              sync_scratch(d, Tc, B, "bwdm", len(part)).data_ptr(), _s(d)))
             if s_ == nch - 1:
                 e1 = torch.cuda.Event()
                 e1.record(main)                           # layer 1 complete
@@ -648,8 +672,10 @@ class R2D2Agent:
         self.counter += 1
         return {"a": a, "greedy_a": g}, {"h0": h, "c0": c}
 
-    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap):
-        """|r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|  -> fp32 [N]"""
+    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap, num_player=1):
+        """|r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|  -> fp32 [N]
+        num_player > 1 = VDN (r2d2.py:341-345): rows are (game, player) pairs, Q-values are summed over the players of
+        a game and reward / bootstrap / the result are per game [N / num_player]."""
         lib = _lib.load_library()
         on, tg, d = self.online, self.target, self.device
         n = a.shape[0]
@@ -663,6 +689,9 @@ class R2D2Agent:
                                        on.A, 0, 0, junk.data_ptr(), na.data_ptr(), scratch.data_ptr(), _s(d)))
         thd, _, _ = self._adv(tg, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
         _, tqa, _ = tg.q_head(thd, next_obs["legal_move"], na, want_greedy=False)
+        if num_player > 1:
+            qa, tqa = qa.view(-1, num_player).sum(1), tqa.view(-1, num_player).sum(1)
+            n = n // num_player
         out = torch.empty(n, dtype=torch.float32, device=d)
         _lib.check(lib.hsad_nstep_priority(qa.data_ptr(), tqa.data_ptr(), reward.contiguous().data_ptr(),
                                            bootstrap.contiguous().data_ptr(), self.multi_step, self.gamma, n, out.data_ptr(),

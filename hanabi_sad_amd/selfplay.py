@@ -65,13 +65,15 @@ class Trainer:
         self.act_online = R2D2NetKernels(W, device)
         self.act_target = R2D2NetKernels(W, device)
         self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
-        fields = transition_fields(self.env)
+        self.vdn = args.method == "vdn"
+        fields = transition_fields(self.env, self.vdn)
         # the reference's capacity is split evenly over the per-GPU shards
         self.replay = DeviceReplay(max(args.batchsize, args.replay_buffer_size // world), args.seed + rank,
                                    args.priority_exponent, args.priority_weight, args.prefetch, args.max_len, fields, device)
         from .dist import ShardedReplay
         self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0)
-        self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len)
+        self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
+                                 vdn=self.vdn)
         self.num_update = 0
 
     def update_actor_model(self):
@@ -100,8 +102,13 @@ class Trainer:
             self.num_update += 1
             return None, None
         (f, reward, terminal, bootstrap, seq_len), weight = res
-        batch = {"priv_s": f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
-                 "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
+        if self.vdn:    # [T, B, P*w] -> [T, B, P, w]
+            P_, v4 = self.env.P, lambda t: t.view(t.shape[0], t.shape[1], self.env.P, -1)
+            batch = {"priv_s": v4(f["priv_s"]), "legal_move": v4(f["legal_move"]), "a": f["a"], "reward": reward,
+                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": v4(f["own_hand"])}
+        else:
+            batch = {"priv_s": f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
+                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)
         g_norm = self.learner.optimizer_step()
@@ -112,6 +119,7 @@ class Trainer:
 
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="R2D2 self-play on the device pipeline (flags as in pyhanabi/selfplay.py)")
+    p.add_argument("--method", type=str, default="iql", choices=["iql", "vdn"])
     p.add_argument("--seed", type=int, default=10001)
     p.add_argument("--gamma", type=float, default=0.999)
     p.add_argument("--eta", type=float, default=0.9)

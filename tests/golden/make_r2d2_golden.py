@@ -167,4 +167,4 @@ def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, p
 
 if __name__ == "__main__":
     run_case("r2d2_iql_sad_small", False, 838, 21, 64, 12, 6, 10, seed=1)
-    run_case("r2d2_vdn_small", True, 783, 21, 32, 9, 4, 5, seed=2)
+    run_case("r2d2_vdn_small", True, 783, 21, 64, 9, 4, 5, seed=2)

@@ -73,12 +73,20 @@ def zeros_hid(W, n, like):
 
 
 def td_error(Won, Wtg, priv_s, legal_move, action, reward, bootstrap, seq_len, multi_step, gamma):
-    """R2D2Agent.td_error for IQL layouts [T,B,*] (r2d2.py:383-428)."""
+    """R2D2Agent.td_error (r2d2.py:383-428): IQL layouts [T,B,*]; VDN layouts [T,B,P,*] are flattened to B*P rows
+    (flat_4d, r2d2.py:363-381) and the Q-values summed over the players of a game."""
     T, B = priv_s.shape[:2]
-    h0, c0 = zeros_hid(Won, B, priv_s)
+    P = 0
+    if priv_s.dim() == 4:
+        P = priv_s.shape[2]
+        priv_s, legal_move, action = priv_s.flatten(1, 2), legal_move.flatten(1, 2), action.flatten(1, 2)
+    h0, c0 = zeros_hid(Won, priv_s.shape[1], priv_s)
     online_qa, greedy_a, _, lstm_o = net_forward(Won, priv_s, legal_move, action, h0, c0)
     with torch.no_grad():
         target_qa, _, _, _ = net_forward(Wtg, priv_s, legal_move, greedy_a, h0, c0)
+    if P:
+        online_qa, target_qa = online_qa.view(T, B, P).sum(-1), target_qa.view(T, B, P).sum(-1)
+    with torch.no_grad():
         target_qa = torch.cat([target_qa[multi_step:], target_qa[:multi_step]], 0)
         target_qa[-multi_step:] = 0
         target = reward + bootstrap * (gamma ** multi_step) * target_qa
@@ -110,11 +118,14 @@ def loss(Won, Wtg, batch, multi_step, gamma, pred_weight):
 
 
 def compute_priority(Won, Wtg, priv_s, legal_move, a, next_priv_s, next_legal_move, h0, c0, next_h0, next_c0, reward,
-                     bootstrap, multi_step, gamma):
+                     bootstrap, multi_step, gamma, num_player=1):
     """R2D2Agent.compute_priority, IQL, flat [N,*] inputs with hidden [L,N,H] (r2d2.py:305-361)."""
     qa, _, _, _ = net_forward(Won, priv_s.unsqueeze(0), legal_move.unsqueeze(0), a.unsqueeze(0), h0, c0)
     next_a, _, _ = greedy_act(Won, next_priv_s, next_legal_move, next_h0, next_c0)
     tqa, _, _, _ = net_forward(Wtg, next_priv_s.unsqueeze(0), next_legal_move.unsqueeze(0), next_a.unsqueeze(0), next_h0,
                                next_c0)
-    target = reward + bootstrap * (gamma ** multi_step) * tqa.squeeze(0)
-    return (target - qa.squeeze(0)).abs()
+    qa, tqa = qa.squeeze(0), tqa.squeeze(0)
+    if num_player > 1:                                                        # VDN: sum over the players of a game
+        qa, tqa = qa.view(-1, num_player).sum(1), tqa.view(-1, num_player).sum(1)
+    target = reward + bootstrap * (gamma ** multi_step) * tqa
+    return (target - qa).abs()

@@ -64,3 +64,32 @@ def test_loss_priority_and_gradients_match_reference_iql(tag, pw):
         g = v.grad if v.grad is not None else torch.zeros_like(v)
         want = z["loss.%s.grad.%s" % (tag, k)]
         assert np.allclose(g.numpy(), want, rtol=1e-4, atol=1e-6), k
+
+
+def test_vdn_act_priority_loss_and_gradients_match_reference():
+    """VDN layouts ([.., P, ..], Q summed over the players of a game; r2d2.py:254-258,316-345,386-412)"""
+    z = load("r2d2_vdn_small")
+    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
+    meta = z["meta"]
+    assert int(meta[0]) == 1
+    P = z["act.priv_s"].shape[2]
+    f2 = lambda k: torch.tensor(z[k]).flatten(0, 2)
+    g, h, c = ref.greedy_act(Won, f2("act.priv_s"), f2("act.legal_move"), hid_to_LNH(z["act.h0"]), hid_to_LNH(z["act.c0"]))
+    assert np.array_equal(g.numpy(), z["act.out_greedy_a"].reshape(-1))
+    p = ref.compute_priority(Won, Wtg, f2("act.priv_s"), f2("act.legal_move"), f2("prio.a"), f2("prio.next_priv_s"),
+                             f2("prio.next_legal_move"), hid_to_LNH(z["act.h0"]), hid_to_LNH(z["act.c0"]),
+                             hid_to_LNH(z["prio.next_h0"]), hid_to_LNH(z["prio.next_c0"]),
+                             torch.tensor(z["prio.reward"]).flatten(), torch.tensor(z["prio.bootstrap"]).flatten(),
+                             int(meta[8]), float(z["gamma"][0]), num_player=P)
+    assert np.allclose(p.numpy(), z["prio.out"].reshape(-1), **TOL)
+    for v in Won.values():
+        v.requires_grad_(True)
+    batch = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("loss.") and k.count(".") == 1}
+    assert batch["priv_s"].dim() == 4
+    loss, prio = ref.loss(Won, Wtg, batch, int(meta[8]), float(z["gamma"][0]), 0.0)
+    assert np.allclose(loss.detach().numpy(), z["loss.rl.loss"], **TOL)
+    assert np.allclose(prio.detach().numpy(), z["loss.rl.priority"], **TOL)
+    (loss * batch["weight"]).mean().backward()
+    for k, v in Won.items():
+        g_ = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert np.allclose(g_.numpy(), z["loss.rl.grad.%s" % k], rtol=1e-4, atol=1e-6), k
