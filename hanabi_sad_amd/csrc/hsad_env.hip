@@ -1369,14 +1369,20 @@ typedef void (*EnvKernelFn)(EnvParams, const int64_t*, const int64_t*);
 
 // compile-time (players, hand) specialisations; anything else runs the generic <0,0> instance
 EnvKernelFn pick_env_kernel(int mode, int P, int H) {
-  if (P == 2 && H == 5) {
-    switch (mode) {
-      case 0: return env_kernel<0, 2, 5>;
-      case 1: return env_kernel<1, 2, 5>;
-      case 2: return env_kernel<2, 2, 5>;
-      default: return env_kernel<3, 2, 5>;
-    }
+#define HSAD_ENV_SPECIALISE(PP, HH)                 \
+  if (P == PP && H == HH) {                         \
+    switch (mode) {                                 \
+      case 0: return env_kernel<0, PP, HH>;         \
+      case 1: return env_kernel<1, PP, HH>;         \
+      case 2: return env_kernel<2, PP, HH>;         \
+      default: return env_kernel<3, PP, HH>;        \
+    }                                               \
   }
+  HSAD_ENV_SPECIALISE(2, 5)   // BASELINE configs[1..3]
+  HSAD_ENV_SPECIALISE(5, 4)   // BASELINE configs[4] (5-player Other-Play)
+  HSAD_ENV_SPECIALISE(3, 5)
+  HSAD_ENV_SPECIALISE(4, 4)
+#undef HSAD_ENV_SPECIALISE
   switch (mode) {
     case 0: return env_kernel<0, 0, 0>;
     case 1: return env_kernel<1, 0, 0>;
