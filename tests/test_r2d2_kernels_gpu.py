@@ -41,6 +41,30 @@ def test_gemm_nt_bf16(M, N, K):
     assert torch.allclose(relu, want.clamp(min=0) + want - bias, rtol=1e-3, atol=2e-3 * K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K,split_k,use_map", [(10240, 2048, 512, 1, False), (7000, 2040, 320, 1, False),
+                                                   (2048, 512, 10240, 8, True), (4100, 1000, 2560, 4, True)])
+def test_gemm_big_tile_kernel(M, N, K, split_k, use_map):
+    """shapes whose grid fills the chip take the 256x256 / 256x128 one-workgroup-per-CU kernel (fp32 output, bias,
+    split-K atomics, output row map); ragged edges included"""
+    from hanabi_sad_amd.r2d2 import gemm_nt, gemm_nt_ex
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A16 = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    B16 = torch.randn(N, K, generator=g).to(DEV).to(torch.bfloat16)
+    want = A16.float() @ B16.float().t()
+    if split_k == 1:
+        bias = torch.randn(N, generator=g).to(DEV)
+        out = torch.full((M, N), 7.0, device=DEV)
+        gemm_nt(A16, B16, M, N, K, bias=bias, out32=out)
+        assert torch.allclose(out, want + bias, rtol=1e-3, atol=1e-3 * K ** 0.5)
+    else:
+        perm = torch.randperm(M, generator=g).to(DEV)
+        out = torch.zeros(M, N, device=DEV)
+        gemm_nt_ex(A16, B16, M, N, K, out32=out, split_k=split_k, row_map=perm.to(torch.int32) if use_map else None)
+        ref_out = torch.zeros(M, N, device=DEV)
+        ref_out[perm] = want
+        assert torch.allclose(out, ref_out, rtol=1e-3, atol=2e-3 * K ** 0.5)
+
+
 def test_cast_and_transpose():
     from hanabi_sad_amd.r2d2 import cast_pad_bf16, transpose_bf16
     x = torch.randn(77, 838, device=DEV)
