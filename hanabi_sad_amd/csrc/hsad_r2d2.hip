@@ -689,6 +689,54 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
 // No grid-wide barrier, no release fence (nothing but the write-through h tile is shared), every spin bounded.
 // All workgroups must be co-resident: grid <= 256 CUs with one workgroup per CU (LDS-limited) — checked by the host.
 // ---------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------
+// Persistent recurrences: XCD-aware placement.  The workgroups that exchange tiles every step (the H/32 unit blocks of
+// one row block) are mapped to linear block ids that are congruent mod 8, which the dispatcher (observed, not promised)
+// places on ONE XCD.  At kernel start they check it: every workgroup adds 1 to the 6-bit field of its own XCC id in a
+// shared 64-bit word; once all have arrived, "one field holds everybody" means the group shares an L2.  Then the
+// exchange can stay inside that L2 -- plain stores + L2 atomics instead of write-through stores + memory-side atomics
+// (`fast`).  A group that is NOT co-located keeps the cross-XCD protocol: correctness never depends on placement.
+// ---------------------------------------------------------------------------------------------------
+typedef unsigned long long u64_t;
+
+__device__ __forceinline__ int xcd_group_is_colocated(u64_t* word, int nmember, unsigned* timeout) {
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  __hip_atomic_fetch_add(word, 1ull << (6 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  unsigned spins = 0;
+  for (;;) {
+    const u64_t v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int total = 0, best = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int f = (int)((v >> (6 * i)) & 63u);
+      total += f;
+      best = max(best, f);
+    }
+    if (total >= nmember) return best == nmember ? 1 : 0;
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > 4000000u) {
+      __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return -1;
+    }
+  }
+}
+
+// tile hand-off primitives in the two protocols
+__device__ __forceinline__ void xchg_store8(u64_t* p, u64_t v, int fast) {
+  if (fast)
+    *p = v;                                                                       // stays in the XCD's L2
+  else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // sc1: written through
+}
+__device__ __forceinline__ void xchg_signal(unsigned* ctr, int fast) {
+  if (fast)
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // executed in the L2
+  else
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct LstmSeqArgs {
   const bf16_t* Whh;       // [4H,H] gate-blocked
   float* gates;            // [T,Bn,4H] in: x-projection + bias; out: activated gates
@@ -702,10 +750,9 @@ struct LstmSeqArgs {
   int T, Bn, H;
 };
 
-typedef unsigned long long u64_t;
-
 template <int KB>  // KB = H / 32
-__device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks) {
+__device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks,
+                                                  u64_t* group_word) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int H = KB * 32;
   constexpr int WS = H + 8;                      // padded LDS row stride (elements)
@@ -730,7 +777,10 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     const int row = min(rbase + r, a.Bn - 1);
     cst[r] = a.c0 ? a.c0[(size_t)row * H + u] : 0.f;
   }
+  if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nunit_blocks, a.timeout);
   __syncthreads();
+  const int fast = s_okp[1];
+  if (fast < 0) return;
 
   for (int t = 0; t < a.T; ++t) {
     // x-projection of this step: independent of h, so these HBM loads overlap the wait below
@@ -816,14 +866,12 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
       const int row = rb * 32 + r;
       if (row < a.Bn) {
         const u64_t v = *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
-        __hip_atomic_store(reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4), v,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xchg_store8(reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4), v, fast);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && t + 1 < a.T)
-      __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && t + 1 < a.T) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r;
@@ -845,11 +893,23 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
 // be multiplexed onto hardware queues.
 struct LstmSeqArgsN {
   LstmSeqArgs r[4];
+  int nrec, nrb, nunit;
+  u64_t* group_words;   // [nrec * nrb], zeroed before launch
 };
+
+// linear block id L -> XCD x = L % 8 (observed dispatch order), slot s = L / 8; group G = x + 8 * (s / nunit) is the
+// (recurrence, row block) pair whose nunit unit-block workgroups all land on XCD x
+#define HSAD_SEQ_PLACE(m)                                         \
+  const int L_ = blockIdx.x, s_ = L_ >> 3;                        \
+  const int p_ = s_ / (m).nunit, nb_ = s_ - p_ * (m).nunit;       \
+  const int G_ = (L_ & 7) + 8 * p_;                               \
+  if (G_ >= (m).nrec * (m).nrb) return;                           \
+  const int rec_ = G_ / (m).nrb, rb_ = G_ - rec_ * (m).nrb;
 
 template <int KB>
 __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgsN m) {
-  lstm_seq_fwd_body<KB>(m.r[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.y, gridDim.x);
+  HSAD_SEQ_PLACE(m)
+  lstm_seq_fwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_);
 }
 
 
@@ -875,7 +935,8 @@ struct LstmSeqBwdArgs {
 };
 
 template <int KB>  // KB = 4H / 32
-__device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks) {
+__device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks,
+                                                  u64_t* group_word) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = KB * 32, H = K / 4;
   constexpr int WS = K + 8;
@@ -898,7 +959,10 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) dcs[r] = a.dc_io[(size_t)min(rbase + r, a.Bn - 1) * H + u];
   }
+  if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nunit_blocks, a.timeout);
   __syncthreads();
+  const int fast = s_okp[1];
+  if (fast < 0) return;
 
   for (int t = a.T - 1; t >= 0; --t) {
     // everything the cell backward needs from this block's own saved activations (overlaps the wait)
@@ -997,13 +1061,12 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       const int row = rb * 32 + r;
       if (row < a.Bn) {
         const u64_t v = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
-        __hip_atomic_store(reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4), v, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        xchg_store8(reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4), v, fast);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && t > 0) __hip_atomic_fetch_add(a.counters + (size_t)t * nrb + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && t > 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
   }
   if (a.dc_io) {
 #pragma unroll
@@ -1014,11 +1077,14 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
 
 struct LstmSeqBwdArgsN {
   LstmSeqBwdArgs r[2];
+  int nrec, nrb, nunit;
+  u64_t* group_words;
 };
 
 template <int KB>
 __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgsN m) {
-  lstm_seq_bwd_body<KB>(m.r[blockIdx.z], blockIdx.y, blockIdx.x, gridDim.y, gridDim.x);
+  HSAD_SEQ_PLACE(m)
+  lstm_seq_bwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_);
 }
 
 
@@ -1413,9 +1479,17 @@ __global__ void zero_rows_kernel(float* __restrict__ x, const unsigned char* __r
 }  // namespace
 
 // ---- launch helpers for the persistent recurrences (nrec independent recurrences per launch) ----
-static int launch_seq_fwd(const LstmSeqArgsN& m, int nrec, int H, int nrb, hipStream_t s) {
+// sync_scratch layout (uint32 words): [2 * nrec * nrb: one 64-bit placement word per (recurrence, row block)]
+// [nrec * T * nrb step counters] [sticky timeout word] -- everything before the timeout word is zeroed per launch
+static inline size_t seq_sync_words(int nrec, int T, int nrb) { return (size_t)nrec * nrb * (T + 2); }
+
+static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s) {
   const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
-  const dim3 grid(H / 32, nrb, nrec);
+  m.nrec = nrec;
+  m.nrb = nrb;
+  m.nunit = H / 32;
+  m.group_words = reinterpret_cast<u64_t*>(sync);
+  const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, m);
@@ -1427,9 +1501,13 @@ static int launch_seq_fwd(const LstmSeqArgsN& m, int nrec, int H, int nrb, hipSt
   return HSAD_OK;
 }
 
-static int launch_seq_bwd(const LstmSeqBwdArgsN& m, int nrec, int H, int nrb, hipStream_t s) {
+static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s) {
   const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
-  const dim3 grid(H / 32, nrb, nrec);
+  m.nrec = nrec;
+  m.nrb = nrb;
+  m.nunit = H / 32;
+  m.group_words = reinterpret_cast<u64_t*>(sync);
+  const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, m);
@@ -1555,8 +1633,9 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
   // persistent weight-stationary path (one launch for the whole sequence)
   if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
     const int nrb = (Bn + 31) / 32;
-    unsigned* counters = (unsigned*)sync_scratch;
-    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb), s));  // the timeout word after the counters is sticky
+    unsigned* sync = (unsigned*)sync_scratch;
+    unsigned* counters = sync + 2 * nrb;
+    HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(1, T, nrb), s));  // the timeout word after it is sticky
     LstmSeqArgs q;
     q.Whh = (const bf16_t*)Whh_blocked;
     q.gates = gates;
@@ -1572,7 +1651,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     q.H = H;
     LstmSeqArgsN m{};
     m.r[0] = q;
-    return launch_seq_fwd(m, 1, H, nrb, s);
+    return launch_seq_fwd(m, 1, H, nrb, sync, s);
   }
   for (int t = 0; t < T; ++t) {
     LstmStepArgs a;
@@ -1609,7 +1688,7 @@ int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* t
   if (!sync_scratch || !timed_out) return nfail(HSAD_ERR_INVALID, "null argument");
   unsigned v = 0;
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(&v, (const unsigned*)sync_scratch + (size_t)T * ((Bn + 31) / 32), 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(&v, (const unsigned*)sync_scratch + seq_sync_words(1, T, (Bn + 31) / 32), 4, hipMemcpyDeviceToHost));
   *timed_out = (int32_t)v;
   return HSAD_OK;
 }
@@ -1655,12 +1734,13 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
   bf16_t* dG = (bf16_t*)dG16;  // [T+1][Bn][4H]; slot T is the zero gradient entering the last step
   if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
     const int nrb = (Bn + 31) / 32;
-    unsigned* counters = (unsigned*)sync_scratch;
-    HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)T * nrb), s));  // the timeout word after the counters is sticky
+    unsigned* sync = (unsigned*)sync_scratch;
+    unsigned* counters = sync + 2 * nrb;
+    HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(1, T, nrb), s));
     LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H, nullptr, 0};
     LstmSeqBwdArgsN m{};
     m.r[0] = q;
-    return launch_seq_bwd(m, 1, H, nrb, s);
+    return launch_seq_bwd(m, 1, H, nrb, sync, s);
   }
   HIP_TRY(hipMemsetAsync(dG + (size_t)T * step4, 0, step4 * 2, s));
   HIP_TRY(hipMemsetAsync(dc_scratch, 0, step1 * 4, s));
@@ -1794,8 +1874,9 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
   if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: needs H in {256,512}, Bn <= 512");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32;
-  unsigned* counters = (unsigned*)sync_scratch;
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)nrec * Tc * nrb), s));
+  unsigned* sync = (unsigned*)sync_scratch;
+  unsigned* counters = sync + 2 * nrec * nrb;
+  HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
   LstmSeqArgsN m{};
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fwd_rec& r = recs[i];
@@ -1814,7 +1895,7 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
     q.Bn = Bn;
     q.H = H;
   }
-  return launch_seq_fwd(m, nrec, H, nrb, s);
+  return launch_seq_fwd(m, nrec, H, nrb, sync, s);
 }
 
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
@@ -1832,8 +1913,9 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
   if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: needs H in {256,512}, Bn <= 512");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32;
-  unsigned* counters = (unsigned*)sync_scratch;
-  HIP_TRY(hipMemsetAsync(counters, 0, sizeof(unsigned) * ((size_t)nrec * Tc * nrb), s));
+  unsigned* sync = (unsigned*)sync_scratch;
+  unsigned* counters = sync + 2 * nrec * nrb;
+  HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
   LstmSeqBwdArgsN m{};
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_bwd_rec& r = recs[i];
@@ -1843,7 +1925,7 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
     m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
                             counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next};
   }
-  return launch_seq_bwd(m, nrec, H, nrb, s);
+  return launch_seq_bwd(m, nrec, H, nrb, sync, s);
 }
 
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,

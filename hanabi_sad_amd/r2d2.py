@@ -64,7 +64,7 @@ def sync_scratch(device, T, Bn, tag="fwd", nrec=1):
     """cached zero-initialised counter block for a persistent recurrence launch (nrec recurrences of T steps, Bn rows) on
     the CURRENT stream (one block per stream: launches on one stream are ordered, concurrent streams must not share
     counters).  The word after the counters is the sticky timeout flag."""
-    n = int(nrec) * int(T) * ((int(Bn) + 31) // 32)
+    n = int(nrec) * ((int(Bn) + 31) // 32) * (int(T) + 2)   # placement words + step counters (include/hsad.h)
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, n)
     buf = _SYNC.get(key)
     if buf is None:

@@ -250,7 +250,7 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
  * projection x W_ih^T + b_ih + b_hh on entry and the activated gates on exit, both in the gate-blocked column
  * layout (block nb of 32 units: columns nb*128 + gate*32 + u); Whh_blocked bf16 [4H,H] has its rows in the same
  * order.  h0/c0 fp32 [Bn,H] (h0 NULL = zeros).  Outputs hseq16 bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]
- * (optional).  h0_16_scratch: bf16 [Bn,H].  sync_scratch (may be NULL): uint32 [T*ceil(Bn/32)+4]; when given and
+ * (optional).  h0_16_scratch: bf16 [Bn,H].  sync_scratch (may be NULL): uint32 [(T+2)*ceil(Bn/32)+4]; when given and
  * the shape allows (H in {256,512}, Bn <= 512) the whole sequence runs as ONE persistent launch that keeps the
  * W_hh slices in LDS and exchanges h_t tiles through L2 (csrc/hsad_r2d2.hip); otherwise one launch per step.
  * The word after the counters is a STICKY timeout flag (zero the scratch once when allocating it; launches only
@@ -342,7 +342,10 @@ typedef struct hsad_lstm_bwd_rec {
 /* nrec (<= 4 forward, <= 2 backward) independent recurrences of identical shape in ONE persistent launch, e.g. layer 0
  * on chunk c+1 next to layer 1 on chunk c, for the online and the target net at once.  The overlap is inside the launch,
  * so it does not depend on how HIP streams are multiplexed onto hardware queues.  Needs nrec * (H/32) * ceil(Bn/32)
- * co-resident workgroups (one per CU).  sync_scratch: uint32 [nrec*Tc*ceil(Bn/32) + 4], sticky timeout word last. */
+ * co-resident workgroups (one per CU).  sync_scratch: uint32 [nrec*(Tc+2)*ceil(Bn/32) + 4]: one 64-bit XCD-placement word
+ * per (recurrence, row block), the step counters, then the sticky timeout word.  Workgroups that exchange tiles are
+ * mapped to block ids that share an XCD; a start-up handshake verifies it and only then uses the L2-local hand-off
+ * (plain stores + L2 atomics), otherwise the cross-XCD protocol (write-through stores + device-scope atomics). */
 int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_fwd_rec* recs, void* sync_scratch,
                                   void* stream);
 int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,

@@ -34,7 +34,12 @@ print("chunks=%d" % lr.chunks, end="  "); print("HIP learner update: %.2f ms  ->
 t0 = time.perf_counter()
 for _ in range(n): lr.loss(batch, weight, 0.0, compute_grad=False)
 torch.cuda.synchronize(); print("  forward only (online+target+TD): %.2f ms" % ((time.perf_counter() - t0) / n * 1e3))
-from hanabi_sad_amd.r2d2 import check_sync; check_sync()
+from hanabi_sad_amd.r2d2 import check_sync, _SYNC; check_sync()
+for k, b in _SYNC.items():   # XCD placement words of the last launch on each buffer: how many groups were co-located?
+    if not k[2].endswith("m"): continue
+    words = b[:64].cpu().numpy().view("uint64")
+    groups = [[int((w >> (6 * i)) & 63) for i in range(8)] for w in words[:16] if w]
+    print("  %s: %d/%d groups on one XCD" % (k[2], sum(max(g) == sum(g) for g in groups), len(groups)), groups[:2])
 if os.environ.get("NO_TORCH"): sys.exit(0)
 # torch eager baseline of the same math (nn.LSTM / MIOpen fp32) -- "what you get without hand-written kernels"
 import torch.nn as nn
