@@ -49,6 +49,7 @@ int nfail(int code, const char* fmt, ...) {
 typedef unsigned short bf16_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
   uint32_t u = __float_as_uint(f);
@@ -699,6 +700,16 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
 // ---------------------------------------------------------------------------------------------------
 typedef unsigned long long u64_t;
 
+// developer phase timers of the persistent recurrences (hsad_lstm_debug_timing): wall-clock ticks (100 MHz) summed over
+// the steps of ONE workgroup (row block 0, unit block 0); slots 0-7 forward, 8-15 backward
+__device__ u64_t g_lstm_dbg[16];
+#define LSTM_STAMP(slot)                                      \
+  if (dbg_on) {                                               \
+    const u64_t now_ = wall_clock64();                        \
+    atomicAdd(&g_lstm_dbg[slot], now_ - stamp_);              \
+    stamp_ = now_;                                            \
+  }
+
 __device__ __forceinline__ int xcd_group_is_colocated(u64_t* word, int nmember, unsigned* timeout) {
   unsigned xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -781,6 +792,8 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
   __syncthreads();
   const int fast = s_okp[1];
   if (fast < 0) return;
+  const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
+  u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
   for (int t = 0; t < a.T; ++t) {
     // x-projection of this step: independent of h, so these HBM loads overlap the wait below
@@ -814,23 +827,39 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
       __syncthreads();
       if (!*s_okp) return;
     }
+    LSTM_STAMP(0)   // issue x-projection loads + wait for h_{t-1}
     // A fragments of h_{t-1}: agent-scope 8-byte loads (h was written by other CUs during this launch)
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // 8-byte agent-scope (sc1) loads: served by L2, bypassing the per-CU L1 that other CUs' stores never refresh
-    // (measured faster here than 16-byte non-temporal loads: 694 vs 760 us per 80-step layer)
-    const u64_t* hrow = reinterpret_cast<const u64_t*>(hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs);
+    // L1-bypassing loads of h_{t-1} (other CUs wrote it during this launch; this CU's L1 is never refreshed by them).
+    // Co-located groups: 16-byte sc1 loads, one full 64-byte segment per row and instruction, served by the shared L2.
+    // Cross-XCD groups keep the 8-byte agent-scope atomics (measured faster there than 16-byte nt loads: 694 vs 760 us
+    // per 80-step layer).
+    const bf16_t* hrow16 = hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs;
+    const u64_t* hrow = reinterpret_cast<const u64_t*>(hrow16);
     union Frag {
       u64_t q[2];
+      u32x4 w;
       bf16x8 v;
     };
     Frag fa[KB];
+    if (fast) {
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      fa[kb].q[0] = __hip_atomic_load(hrow + kb * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fa[kb].q[1] = __hip_atomic_load(hrow + kb * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int kb = 0; kb < KB; ++kb)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fa[kb].w) : "v"(hrow16), "n"(kb * 64));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(fa[kb].w));   // values are defined only from here on
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        fa[kb].q[0] = __hip_atomic_load(hrow + kb * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fa[kb].q[1] = __hip_atomic_load(hrow + kb * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
+    if (dbg_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LSTM_STAMP(1)   // h tile loads (timed workgroup only: drained here)
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
@@ -842,6 +871,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     // cell update (fp32), h tile staged in LDS for wide write-through stores.  Only the h tile is on the other
     // workgroups' critical path: it is published first; the block-local gate / cell-state stores (22 KB headed
     // for HBM) are issued after the signal so their latency hides behind the next step's wait.
+    LSTM_STAMP(2)   // MFMAs (W from LDS)
     float* ct = a.cseq + (size_t)t * a.Bn * H;
     float keep_g[4][4], keep_h[4];
 #pragma unroll
@@ -861,6 +891,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
       sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
     }
     __syncthreads();
+    LSTM_STAMP(3)   // cell update + h tile to LDS
     {  // 32 rows x 32 units bf16 = 256 x 8 bytes
       const int r = tid >> 3, q = tid & 7;
       const int row = rb * 32 + r;
@@ -872,6 +903,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t + 1 < a.T) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    LSTM_STAMP(4)   // publish: stores, drain, signal
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + r;
@@ -885,6 +917,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
         if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = keep_h[r];
       }
     }
+    LSTM_STAMP(5)   // issue gate / cell-state stores
   }
 }
 
@@ -963,6 +996,8 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
   __syncthreads();
   const int fast = s_okp[1];
   if (fast < 0) return;
+  const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
+  u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
   for (int t = a.T - 1; t >= 0; --t) {
     // everything the cell backward needs from this block's own saved activations (overlaps the wait)
@@ -999,6 +1034,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       }
       __syncthreads();
       if (!*s_okp) return;
+      LSTM_STAMP(8)   // own-activation loads issued + wait for dG_{t+1}
       // K-split: wave w multiplies k-blocks [w*KB/4, (w+1)*KB/4) for the whole 32x32 block tile (2x2 MFMA tiles),
       // so every dG fragment is fetched from L2 exactly once per workgroup; partial tiles meet in LDS.
       constexpr int KQ = KB / 4;
@@ -1008,21 +1044,42 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       const bf16_t* w0 = sW + (lane & 15) * WS + kofs;
       const bf16_t* w1 = sW + (16 + (lane & 15)) * WS + kofs;
       f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
-      bf16x8 fa0[KQ], fa1[KQ];
+      union Frag {
+        u32x4 w;
+        bf16x8 v;
+      };
+      Frag fr0[KQ], fr1[KQ];
+      if (fast) {   // shared L2: 16-byte sc1 loads (L1 bypass, L2 hit)
+        const bf16x8* b0 = g0 + wave * KQ * 4;
+        const bf16x8* b1 = g1 + wave * KQ * 4;
 #pragma unroll
-      for (int it = 0; it < KQ; ++it) {
-        fa0[it] = __builtin_nontemporal_load(g0 + (wave * KQ + it) * 4);
-        fa1[it] = __builtin_nontemporal_load(g1 + (wave * KQ + it) * 4);
+        for (int it = 0; it < KQ; ++it) {
+          asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr0[it].w) : "v"(b0), "n"(it * 64));
+          asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr1[it].w) : "v"(b1), "n"(it * 64));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < KQ; ++it) {
+          asm volatile("" : "+v"(fr0[it].w));
+          asm volatile("" : "+v"(fr1[it].w));
+        }
+      } else {
+#pragma unroll
+        for (int it = 0; it < KQ; ++it) {
+          fr0[it].v = __builtin_nontemporal_load(g0 + (wave * KQ + it) * 4);
+          fr1[it].v = __builtin_nontemporal_load(g1 + (wave * KQ + it) * 4);
+        }
       }
 #pragma unroll
       for (int it = 0; it < KQ; ++it) {
         const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (wave * KQ + it) * 32);
         const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (wave * KQ + it) * 32);
-        p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[it], fb0, p00, 0, 0, 0);
-        p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[it], fb1, p01, 0, 0, 0);
-        p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[it], fb0, p10, 0, 0, 0);
-        p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[it], fb1, p11, 0, 0, 0);
+        p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb0, p00, 0, 0, 0);
+        p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb1, p01, 0, 0, 0);
+        p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb0, p10, 0, 0, 0);
+        p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb1, p11, 0, 0, 0);
       }
+      LSTM_STAMP(9)   // dG tile loads + MFMAs
       // sRed[wave][tile][lane] (f32x4): tile = wr*2 + wu
       f32x4* sRed = reinterpret_cast<f32x4*>(s_okp + 4);
       sRed[(wave * 4 + 0) * 64 + lane] = p00;
@@ -1055,6 +1112,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       sp[96] = f2bf(d_o * go * (1.f - go));
     }
     __syncthreads();
+    LSTM_STAMP(10)  // K-split reduction + cell backward + dG tile to LDS
 #pragma unroll
     for (int it = 0; it < 4; ++it) {  // 32 rows x 128 columns bf16 = 1024 x 8 bytes
       const int c = tid + it * 256, r = c >> 5, q = c & 31;
@@ -1067,6 +1125,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t > 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    LSTM_STAMP(11)  // publish: stores, drain, signal
   }
   if (a.dc_io) {
 #pragma unroll
@@ -1681,6 +1740,15 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
       hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
   }
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_debug_timing(uint64_t* out16, int reset) {
+  if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lstm_dbg), sizeof(uint64_t) * 16));
+  if (reset) {
+    const uint64_t z[16] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_dbg), z, sizeof(z)));
+  }
   return HSAD_OK;
 }
 

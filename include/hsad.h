@@ -258,6 +258,10 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
                             const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
                             void* sync_scratch, void* stream);
+/* developer phase timers of the persistent recurrences (100 MHz ticks summed over the steps of one workgroup; slots
+ * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
+ * publish); out16 may be NULL; reset != 0 clears them */
+int hsad_lstm_debug_timing(uint64_t* out16, int reset);
 /* reads the timeout word of a sync_scratch buffer used with T steps / Bn rows (synchronises the device) */
 int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* timed_out);
 /* Dueling head + masked argmax (r2d2.py:106-131): heads fp32 [M,ldh] = [advantage(A) | value(1) | ...],
