@@ -844,33 +844,46 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
       bf16x8 v;
     };
     Frag fa[KB];
+    auto mfma_range = [&](int k0, int k1) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb < k0 || kb >= k1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (j * 32 + wu * 16 + (lane & 15)) * WS + kb * 32 + kofs);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb].v, fb, acc[j], 0, 0, 0);
+        }
+      }
+    };
     if (fast) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
         asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fa[kb].w) : "v"(hrow16), "n"(kb * 64));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // loads return in order: once at most KB - n are outstanding the first n k-blocks are here, so the MFMAs of each
+      // quarter of K start while the rest of the tile is still in flight
+      constexpr int QK = KB / 4;
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) asm volatile("" : "+v"(fa[kb].w));   // values are defined only from here on
+      for (int qd = 0; qd < 4; ++qd) {
+        if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QK) : "memory");
+        if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QK) : "memory");
+        if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QK) : "memory");
+        if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          if (kb >= qd * QK && kb < (qd + 1) * QK) asm volatile("" : "+v"(fa[kb].w));   // defined only from here on
+        if (qd == 3) { LSTM_STAMP(1) }   // h tile loads (+ three quarters of the MFMAs)
+        mfma_range(qd * QK, (qd + 1) * QK);
+      }
     } else {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
         fa[kb].q[0] = __hip_atomic_load(hrow + kb * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         fa[kb].q[1] = __hip_atomic_load(hrow + kb * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      if (dbg_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      LSTM_STAMP(1)
+      mfma_range(0, KB);
     }
-    if (dbg_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LSTM_STAMP(1)   // h tile loads (timed workgroup only: drained here)
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (j * 32 + wu * 16 + (lane & 15)) * WS + kb * 32 + kofs);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kb].v, fb, acc[j], 0, 0, 0);
-      }
-    }
-    // cell update (fp32), h tile staged in LDS for wide write-through stores.  Only the h tile is on the other
-    // workgroups' critical path: it is published first; the block-local gate / cell-state stores (22 KB headed
-    // for HBM) are issued after the signal so their latency hides behind the next step's wait.
     LSTM_STAMP(2)   // MFMAs (W from LDS)
     float* ct = a.cseq + (size_t)t * a.Bn * H;
     float keep_g[4][4], keep_h[4];
@@ -1057,27 +1070,43 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
           asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr0[it].w) : "v"(b0), "n"(it * 64));
           asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr1[it].w) : "v"(b1), "n"(it * 64));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < KQ; ++it) {
-          asm volatile("" : "+v"(fr0[it].w));
-          asm volatile("" : "+v"(fr1[it].w));
-        }
-      } else {
+      } else {      // cross-XCD: 16-byte non-temporal loads (L1 bypass)
 #pragma unroll
         for (int it = 0; it < KQ; ++it) {
           fr0[it].v = __builtin_nontemporal_load(g0 + (wave * KQ + it) * 4);
           fr1[it].v = __builtin_nontemporal_load(g1 + (wave * KQ + it) * 4);
         }
       }
+      auto mfma_range = [&](int i0, int i1) {
 #pragma unroll
-      for (int it = 0; it < KQ; ++it) {
-        const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (wave * KQ + it) * 32);
-        const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (wave * KQ + it) * 32);
-        p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb0, p00, 0, 0, 0);
-        p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb1, p01, 0, 0, 0);
-        p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb0, p10, 0, 0, 0);
-        p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb1, p11, 0, 0, 0);
+        for (int it = 0; it < KQ; ++it) {
+          if (it < i0 || it >= i1) continue;
+          const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (wave * KQ + it) * 32);
+          const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (wave * KQ + it) * 32);
+          p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb0, p00, 0, 0, 0);
+          p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb1, p01, 0, 0, 0);
+          p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb0, p10, 0, 0, 0);
+          p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb1, p11, 0, 0, 0);
+        }
+      };
+      if (fast) {   // loads return in order: a quarter of the k-blocks at a time, MFMAs overlap the rest of the tile
+        constexpr int QI = KQ / 4;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * QI) : "memory");
+          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QI) : "memory");
+          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QI) : "memory");
+          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int it = 0; it < KQ; ++it)
+            if (it >= qd * QI && it < (qd + 1) * QI) {
+              asm volatile("" : "+v"(fr0[it].w));
+              asm volatile("" : "+v"(fr1[it].w));
+            }
+          mfma_range(qd * QI, (qd + 1) * QI);
+        }
+      } else {
+        mfma_range(0, KQ);
       }
       LSTM_STAMP(9)   // dG tile loads + MFMAs
       // sRed[wave][tile][lane] (f32x4): tile = wr*2 + wu
