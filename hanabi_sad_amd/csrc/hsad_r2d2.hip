@@ -391,19 +391,44 @@ __global__ void cast_pad_bf16_kernel(const float* __restrict__ src, int M, int K
   dst[idx] = c < K ? f2bf(src[(size_t)r * lds + c]) : (bf16_t)0;
 }
 
-// bf16 [R, C] (ld = lds) -> [C, R] (ld = ldd), 32x32 tiles through LDS
-__global__ void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int C, int lds, bf16_t* __restrict__ dst,
-                                      int ldd) {
-  __shared__ bf16_t tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
-    const int r = r0 + i, c = c0 + threadIdx.x;
-    tile[i][threadIdx.x] = (r < R && c < C) ? src[(size_t)r * lds + c] : (bf16_t)0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
-    const int c = c0 + i, r = r0 + threadIdx.x;
-    if (c < C && r < R) dst[(size_t)c * ldd + r] = tile[threadIdx.x][i];
+// bf16 [R, C] (ld = lds) -> [C, R] (ld = ldd).  64x64 tiles through LDS, 256 threads: 8-byte global loads and stores
+// when both leading dimensions / bases allow it (the weight-gradient operands: 10-40 MB per call), scalar otherwise.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int C, int lds,
+                                                             bf16_t* __restrict__ dst, int ldd, int vec) {
+  __shared__ bf16_t tile[64][66];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+  if (vec) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 4) + 16 * i, c = (tid & 15) * 4;
+      uint2 v = make_uint2(0, 0);
+      if (r0 + r < R && c0 + c < C) v = *reinterpret_cast<const uint2*>(src + (size_t)(r0 + r) * lds + c0 + c);   // C % 4 == 0
+      tile[r][c + 0] = (bf16_t)(v.x & 0xffff);
+      tile[r][c + 1] = (bf16_t)(v.x >> 16);
+      tile[r][c + 2] = (bf16_t)(v.y & 0xffff);
+      tile[r][c + 3] = (bf16_t)(v.y >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = (tid >> 4) + 16 * i, r = (tid & 15) * 4;      // output row c0 + c, output columns r0 + r .. +3
+      if (c0 + c < C && r0 + r < R) {
+        uint2 v;
+        v.x = (uint32_t)tile[r + 0][c] | ((uint32_t)tile[r + 1][c] << 16);
+        v.y = (uint32_t)tile[r + 2][c] | ((uint32_t)tile[r + 3][c] << 16);
+        *reinterpret_cast<uint2*>(dst + (size_t)(c0 + c) * ldd + r0 + r) = v;                                      // R % 4 == 0
+      }
+    }
+  } else {
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(size_t)(r0 + r) * lds + c0 + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = tid; i < 64 * 64; i += 256) {
+      const int c = i >> 6, r = i & 63;
+      if (c0 + c < C && r0 + r < R) dst[(size_t)(c0 + c) * ldd + r0 + r] = tile[r][c];
+    }
   }
 }
 
@@ -1696,9 +1721,10 @@ int hsad_bias_sum_perm(const float* a, const float* b, const int32_t* perm, floa
 }
 
 int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, void* stream) {
-  if (!src || !dst) return nfail(HSAD_ERR_INVALID, "transpose: null");
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, R, C, ld_src, (bf16_t*)dst, ld_dst);
+  if (!src || !dst || R <= 0 || C <= 0) return nfail(HSAD_ERR_INVALID, "transpose: bad arguments");
+  const int vec = !(R & 3) && !(C & 3) && !(ld_src & 3) && !(ld_dst & 3) && !(((uintptr_t)src | (uintptr_t)dst) & 7);
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, R, C, ld_src, (bf16_t*)dst, ld_dst, vec);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

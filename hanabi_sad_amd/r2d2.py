@@ -372,6 +372,7 @@ class R2D2Learner:
         self.target = R2D2NetKernels(target_weights, device)
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
+        self.wgrad_split = 8     # split-K factor of the weight-gradient GEMMs (contraction over T*B)
         self.chunks = 4          # time chunks for the layer pipeline (1 = layers strictly one after the other)
         self._cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self.side = torch.cuda.Stream(device=self.device)
@@ -483,7 +484,7 @@ class R2D2Learner:
         def heads_wgrad():
             dheadsT = transpose_pad(dheads, Mp)                                          # [NHp, Mp]
             o1T = transpose_pad(hseq[1], Mp)                                             # [H, Mp]
-            gemm_nt_ex(dheadsT, o1T, on.NH, H, Mp, out32=self.g_wheads, split_k=8)
+            gemm_nt_ex(dheadsT, o1T, on.NH, H, Mp, out32=self.g_wheads, split_k=self.wgrad_split)
             colsum(dheads, out=self.g_bheads, ncols=on.NH)
             held.extend([dheadsT, o1T])
         on_side(heads_wgrad)
@@ -509,8 +510,8 @@ class R2D2Learner:
                 dGT = transpose_pad(dG2, Mp)                                             # [4H, Mp]
                 inT = transpose_pad(layer_in[l], Mp)                                     # [H, Mp]
                 hprevT = transpose_pad(torch.cat([zero_h, hseq[l][:M - B]], 0), Mp)      # h_{t-1} (h_{-1} = 0)
-                gemm_nt_ex(dGT, inT, 4 * H, H, Mp, out32=g["lstm.weight_ih_l%d" % l], split_k=8, row_map=on.perm32)
-                gemm_nt_ex(dGT, hprevT, 4 * H, H, Mp, out32=g["lstm.weight_hh_l%d" % l], split_k=8, row_map=on.perm32)
+                gemm_nt_ex(dGT, inT, 4 * H, H, Mp, out32=g["lstm.weight_ih_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
+                gemm_nt_ex(dGT, hprevT, 4 * H, H, Mp, out32=g["lstm.weight_hh_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
                 db = colsum(dG2)
                 g["lstm.bias_ih_l%d" % l].index_copy_(0, on.perm, db)
                 g["lstm.bias_hh_l%d" % l].index_copy_(0, on.perm, db)
@@ -520,7 +521,7 @@ class R2D2Learner:
         def input_wgrad():
             dx1T = transpose_pad(dx1, Mp)                                                # [H, Mp]
             a16T = transpose_pad(keep["a16"], Mp)                                        # [Fp, Mp]
-            gemm_nt_ex(dx1T, a16T, H, on.F, Mp, out32=g["net.0.weight"], split_k=8)
+            gemm_nt_ex(dx1T, a16T, H, on.F, Mp, out32=g["net.0.weight"], split_k=self.wgrad_split)
             colsum(dx1, out=g["net.0.bias"])
             held.extend([dx1T, a16T])
         on_side(input_wgrad)
@@ -580,8 +581,8 @@ class R2D2Learner:
         def layer_wgrad(l, inT):
             dG2 = dGs[l][:T].view(M, 4 * H)
             tr(dG2, dGT)
-            gemm_nt_ex(dGT, inT, 4 * H, H, M, out32=g["lstm.weight_ih_l%d" % l], split_k=8, row_map=on.perm32)
-            gemm_nt_ex(dGT, hsT[l][:, :M], 4 * H, H, M, out32=g["lstm.weight_hh_l%d" % l], split_k=8, row_map=on.perm32)
+            gemm_nt_ex(dGT, inT, 4 * H, H, M, out32=g["lstm.weight_ih_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
+            gemm_nt_ex(dGT, hsT[l][:, :M], 4 * H, H, M, out32=g["lstm.weight_hh_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
             csum(dG2, g["lstm.bias_ih_l%d" % l], g["lstm.bias_hh_l%d" % l], on.perm32)
 
         side.wait_stream(main)
@@ -592,7 +593,7 @@ class R2D2Learner:
             tr(keep["x1"], x1T)
             tr(keep["a16"], a16T)
             tr(dheads, dheadsT)
-            gemm_nt_ex(dheadsT, hsT[1][:, B:], on.NH, H, M, out32=self.g_wheads, split_k=8)
+            gemm_nt_ex(dheadsT, hsT[1][:, B:], on.NH, H, M, out32=self.g_wheads, split_k=self.wgrad_split)
             csum(dheads, self.g_bheads, ncols=on.NH)
         # stage s: layer 1 on chunk nch-1-s next to layer 0 on chunk nch-s, one persistent launch per stage
         e1 = None
@@ -621,7 +622,7 @@ class R2D2Learner:
             layer_wgrad(0, x1T)
         gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
         tr(dx1, dx1T)
-        gemm_nt_ex(dx1T, a16T, H, on.F, M, out32=g["net.0.weight"], split_k=8)
+        gemm_nt_ex(dx1T, a16T, H, on.F, M, out32=g["net.0.weight"], split_k=self.wgrad_split)
         csum(dx1, g["net.0.bias"])
         main.wait_stream(side)
 

@@ -71,6 +71,14 @@ def test_cast_and_transpose():
     y = cast_pad_bf16(x, 896)
     assert torch.equal(y[:, :838], x.to(torch.bfloat16)) and (y[:, 838:] == 0).all()
     assert torch.equal(transpose_bf16(y), y.t().contiguous())
+    # vectorised path (all dims / strides multiples of 4) into a column slice of a wider destination, ragged tiles
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    src = torch.randn(1000, 264, device=DEV).to(torch.bfloat16)[:, :260]
+    dst = torch.full((260, 1128), 3.0, dtype=torch.bfloat16, device=DEV)
+    _lib.check(_lib.load_library().hsad_transpose_bf16(src.data_ptr(), 1000, 260, src.stride(0), dst[:, 128:].data_ptr(),
+                                                       dst.stride(0), _s(torch.device(DEV))))
+    assert torch.equal(dst[:, 128:], src.t()) and (dst[:, :128] == 3).all()
 
 
 @pytest.mark.parametrize("T,Bn,H,persistent", [(5, 128, 512, True), (5, 128, 512, False), (3, 40, 64, True),

@@ -14,6 +14,7 @@ for l in range(2):
     W["lstm.bias_ih_l%d" % l] = lin(4 * H, 1).squeeze(1); W["lstm.bias_hh_l%d" % l] = lin(4 * H, 1).squeeze(1)
 lr = R2D2Learner(W, W, 3, 0.999, device=DEV)
 lr.chunks = int(os.environ.get("CHUNKS", lr.chunks))
+lr.wgrad_split = int(os.environ.get("WSPLIT", lr.wgrad_split))
 seq_len = torch.randint(40, 81, (B,)).float().to(DEV)
 mask = (torch.arange(T, device=DEV).unsqueeze(1) < seq_len.unsqueeze(0)).float()
 legal = (torch.rand(T, B, A, device=DEV) < 0.4).float(); legal[..., 0] = 1
