@@ -194,17 +194,34 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
     if (tid < s) s_red[tid] += s_red[tid + s];
     __syncthreads();
   }
+  const double popped = s_red[0];
+  // weights = priority^alpha: computed and stored by all threads; the running sum is the reference's sequential float
+  // accumulation (prioritized_replay.h add -> blockAppend), so it is added up by ONE thread, in order, out of LDS
+  __shared__ float s_w[4096];
+  __shared__ float s_sum;
+  if (tid == 0) s_sum = 0.f;
+  for (int base = 0; base < cnt; base += 4096) {
+    const int m = min(4096, cnt - base);
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) {
+      const float w = powf(priority[base + i], rd.alpha);
+      rd.weights[(c.tail + base + i) % rd.ring] = w;
+      s_w[i] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float sum = s_sum;
+      for (int i = 0; i < m; ++i) sum += s_w[i];
+      s_sum = sum;
+    }
+  }
+  __syncthreads();
   if (tid != 0) return;
-  c.sum -= s_red[0];
+  const float sum = s_sum;
+  c.sum -= popped;
   c.head = (c.head + npop) % rd.ring;
   c.size -= npop;
   c.err += err;
-  float sum = 0.f;
-  for (int i = 0; i < cnt; ++i) {
-    const float w = powf(priority[i], rd.alpha);
-    rd.weights[(c.tail + i) % rd.ring] = w;
-    sum += w;
-  }
   c.add_start = c.tail;
   c.add_n = cnt;
   c.tail = (c.tail + cnt) % rd.ring;
@@ -508,19 +525,33 @@ __global__ __launch_bounds__(1024) void seq_collect_kernel(SeqDev sd, float eta,
   __syncthreads();
   int k = s_cnt[tid];
   for (int e = e0; e < e1; ++e) {
-    const int L = sd.len[e];
-    if (L <= 0) continue;
-    float mx = 0.f;
-    double sum = 0.0;
-    for (int t = 0; t < sd.T; ++t) {
-      const float p = sd.st_prio[(size_t)e * sd.T + t] * (t < L ? 1.f : 0.f);
-      sum += p;
-      mx = t == 0 ? p : fmaxf(mx, p);
-    }
+    if (sd.len[e] <= 0) continue;
     sd.fin_env[k] = e;
+    ++k;
+  }
+}
+
+// rela::aggregatePriority (r2d2_actor.h:10-21) of the finished sequences, one wavefront per sequence: coalesced reads
+// of the T step priorities, max / sum reduced across the lanes (sum in double like the collect loop it replaces)
+__global__ __launch_bounds__(256) void seq_aggregate_kernel(SeqDev sd, float eta, float c1m) {
+  const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (k >= sd.n_fin[0]) return;
+  const int e = sd.fin_env[k];
+  const int L = sd.len[e];
+  float mx = 0.f;
+  double sum = 0.0;
+  for (int t = lane; t < sd.T; t += 64) {
+    const float p = sd.st_prio[(size_t)e * sd.T + t] * (t < L ? 1.f : 0.f);
+    sum += p;
+    mx = fmaxf(mx, p);      // priorities are absolute TD errors (>= 0), as is the padding
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 64);
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  if (lane == 0) {
     sd.fin_len[k] = (float)L;
     sd.fin_prio[k] = eta * mx + c1m * ((float)sum / (float)L);
-    ++k;
   }
 }
 
@@ -935,6 +966,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   const SeqDev& sd = w->sd;
   const float c1m = (float)(1.0 - (double)eta);
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
+  hipLaunchKernelGGL(seq_aggregate_kernel, dim3((sd.E + 3) / 4), dim3(256), 0, s, sd, eta, c1m);
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
   hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min(sd.E * sd.T, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);

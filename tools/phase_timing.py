@@ -11,9 +11,11 @@ env.rollout_random(30, 5)
 nb = (G + 63) // 64
 buf = torch.zeros(nb, 8, dtype=torch.int64, device="cuda:0")
 _lib.check(env.lib.hsad_env_debug_timing(env.h, buf.data_ptr()))
-for name in ("reset", "step"):
+for name in ("reset", "step", "fused"):
     if name == "reset":
         buf.zero_(); env.reset(); torch.cuda.synchronize()
+    elif name == "fused":
+        buf.zero_(); env.rollout_random(1, 7); torch.cuda.synchronize()
     else:
         a, g = env.policy_random(5); buf.zero_(); env.step(a, g); torch.cuda.synchronize()
     b = buf.cpu().numpy().astype(np.float64)
@@ -24,7 +26,7 @@ for name in ("reset", "step"):
     print("  phase mean us: load %.1f logic %.1f build %.1f writeback %.1f stream %.1f" % tuple(d.mean(0)))
     print("  phase max  us: load %.1f logic %.1f build %.1f writeback %.1f stream %.1f" % tuple(d.max(0)))
     print("  start spread %.1f us  end mean %.1f us" % ((b[:, 0] - t0).max(), (b[:, 5] - t0).mean()))
-    if name == "reset":
+    if name in ("reset", "fused"):
         ok = (b[:, 6] > 0) & (b[:, 7] > 0)
         print("  reset logic split us: window prefetch %.1f, initial deal %.1f, eps/perm/LA/publish %.1f" % (
             (b[ok, 6] - b[ok, 1]).mean(), (b[ok, 7] - b[ok, 6]).mean(), (b[ok, 2] - b[ok, 7]).mean()))
