@@ -479,6 +479,7 @@ struct LstmStepArgs {
   bf16_t* h_out16;       // [Bn, H]
   float* h_out32;        // optional [Bn, H]
   int Bn, H;
+  int keep_gates;        // 0 = inference: the activated gates are not written back (no backward pass will read them)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -613,10 +614,12 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     const float go = sigmoidf_(acc[3][r] + pre[r][3]);
     const float c = gf * cp[r] + gi * gg;
     const float h = go * tanhf_(c);
-    gp[0] = gi;
-    gp[32] = gf;
-    gp[64] = gg;
-    gp[96] = go;
+    if (a.keep_gates) {
+      gp[0] = gi;
+      gp[32] = gf;
+      gp[64] = gg;
+      gp[96] = go;
+    }
     a.c_out[(size_t)row * H + u] = c;
     a.h_out16[(size_t)row * H + u] = f2bf(h);
     if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
@@ -692,10 +695,12 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
     const float go = sigmoidf_(acc[3][r] + pre[r][3]);
     const float c = gf * cp[r] + gi * gg;
     const float h = go * tanhf_(c);
-    gp[0] = gi;
-    gp[32] = gf;
-    gp[64] = gg;
-    gp[96] = go;
+    if (a.keep_gates) {
+      gp[0] = gi;
+      gp[32] = gf;
+      gp[64] = gg;
+      gp[96] = go;
+    }
     a.c_out[(size_t)row * H + u] = c;
     a.h_out16[(size_t)row * H + u] = f2bf(h);
     if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
@@ -1731,7 +1736,7 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
 
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
                             const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
-                            void* sync_scratch, void* stream) {
+                            void* sync_scratch, int keep_gates, void* stream) {
   if (!gates || !Whh_blocked || !c0 || !hseq16 || !cseq || !h0_16_scratch)
     return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: null argument");
   if (H % 64 || T < 1 || Bn < 1) return nfail(HSAD_ERR_INVALID, "lstm_layer_forward: H must be a multiple of 64");
@@ -1778,6 +1783,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     a.h_out32 = (t == T - 1) ? hT : nullptr;
     a.Bn = Bn;
     a.H = H;
+    a.keep_gates = keep_gates;
     const dim3 gs(H / 32, (Bn + 31) / 32);
     if (Bn >= 1024)
       hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);

@@ -80,16 +80,16 @@ def check_sync():
         raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup: %s" % (bad,))
 
 
-def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
+def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True, hT_out=None, cseq_out=None, keep_gates=True):
     """gates fp32 [T,Bn,4H] (x-projection + biases, gate-blocked; overwritten with the activated gates).
-    -> hseq bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]"""
+    -> hseq bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]  (hT_out / cseq_out: caller-provided destinations)"""
     lib = _lib.load_library()
     T, Bn, H4 = gates.shape
     H = H4 // 4
     d = gates.device
     hseq = torch.empty(T, Bn, H, dtype=torch.bfloat16, device=d)
-    cseq = torch.empty(T, Bn, H, dtype=torch.float32, device=d)
-    hT = torch.empty(Bn, H, dtype=torch.float32, device=d)
+    cseq = torch.empty(T, Bn, H, dtype=torch.float32, device=d) if cseq_out is None else cseq_out
+    hT = torch.empty(Bn, H, dtype=torch.float32, device=d) if hT_out is None else hT_out
     scratch = torch.empty(Bn, H, dtype=torch.bfloat16, device=d)
     if c0 is None:
         c0 = torch.zeros(Bn, H, dtype=torch.float32, device=d)
@@ -98,7 +98,7 @@ def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True):
                                            None if h0 is None else h0.contiguous().data_ptr(),
                                            c0.contiguous().data_ptr(), hseq.data_ptr(), cseq.data_ptr(),
                                            scratch.data_ptr(), hT.data_ptr(),
-                                           None if sync is None else sync.data_ptr(), _s(d)))
+                                           None if sync is None else sync.data_ptr(), int(keep_gates), _s(d)))
     return hseq, cseq, hT
 
 
@@ -232,14 +232,20 @@ class R2D2NetKernels:
         a16 = cast_pad_bf16(priv_s.reshape(M, F), self.Fp)
         x1 = torch.empty(M, H, dtype=torch.bfloat16, device=self.device)
         gemm_nt(a16, self.W1, M, H, self.Fp, bias=self.b1, out16=x1, relu=True)
-        inp, hs, cs = x1, [], []
+        inp = x1
         saved = {"a16": a16, "x1": x1, "gates": [], "hseq": [], "cseq": []}
+        # new hidden state written in place by the kernels (no stack / cat copies: at T = 1 with tens of thousands of rows
+        # those copies cost as much as a GEMM)
+        h_new = torch.empty(self.L, N, H, dtype=torch.float32, device=self.device)
+        c_new = torch.empty(self.L, N, H, dtype=torch.float32, device=self.device) if T == 1 else None
+        cs = []
         for l in range(self.L):
             gates = torch.empty(M, 4 * H, dtype=torch.float32, device=self.device)
             gemm_nt(inp, self.Wih[l], M, 4 * H, H, bias=self.bg[l], out32=gates)
             hseq, cseq, hT = lstm_layer_forward(gates.view(T, N, 4 * H), self.Whh[l],
-                                                None if h0 is None else h0[l], None if c0 is None else c0[l])
-            hs.append(hT)
+                                                None if h0 is None else h0[l], None if c0 is None else c0[l],
+                                                hT_out=h_new[l], cseq_out=None if c_new is None else c_new[l].view(1, N, H),
+                                                keep_gates=keep is not None)
             cs.append(cseq[T - 1])
             saved["gates"].append(gates)
             saved["hseq"].append(hseq)
@@ -247,7 +253,7 @@ class R2D2NetKernels:
             inp = hseq.view(M, H)
         if keep is not None:
             keep.update(saved)
-        return inp.view(T, N, H), torch.stack(hs, 0), torch.stack(cs, 0)
+        return inp.view(T, N, H), h_new, (c_new if c_new is not None else torch.stack(cs, 0))
 
     def heads(self, o16):
         """bf16 [M,H] -> fp32 [M, NH] = [advantage | value | aux logits]"""

@@ -253,11 +253,12 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
  * (optional).  h0_16_scratch: bf16 [Bn,H].  sync_scratch (may be NULL): uint32 [(T+2)*ceil(Bn/32)+4]; when given and
  * the shape allows (H in {256,512}, Bn <= 512) the whole sequence runs as ONE persistent launch that keeps the
  * W_hh slices in LDS and exchanges h_t tiles through L2 (csrc/hsad_r2d2.hip); otherwise one launch per step.
+ * keep_gates = 0 (inference; per-step kernels only): the activated gates are not written back.
  * The word after the counters is a STICKY timeout flag (zero the scratch once when allocating it; launches only
  * clear the counters); hsad_lstm_sync_timed_out() reports a bounded spin that gave up. */
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
                             const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
-                            void* sync_scratch, void* stream);
+                            void* sync_scratch, int keep_gates, void* stream);
 /* developer phase timers of the persistent recurrences (100 MHz ticks summed over the steps of one workgroup; slots
  * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
  * publish); out16 may be NULL; reset != 0 clears them */
