@@ -86,7 +86,6 @@ struct GemmArgs {
   const bf16_t* mask16;  // optional [M, ldmask]: output is zeroed where mask <= 0 (ReLU backward)
   int ldmask;
   const int32_t* row_map;  // optional [M]: result row r is written to row row_map[r] of C32 / C16
-  int dbg;                 // developer experiments (HSAD_GEMM_DBG)
   int gz;                  // number of K splits (1 = none)
 };
 
@@ -161,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 
   const int kbeg = g.k_chunk ? bz * g.k_chunk : 0;
   const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
-  const int nk = (g.dbg & 2) ? 1 : (kend - kbeg) / kBK;
+  const int nk = (kend - kbeg) / kBK;
   store_tile(0);                                            // first k tile of this output tile: loaded ahead
   if (nk > 1) load_tile(kbeg + kBK);
   __syncthreads();
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   // stride WN + 8 floats: the two half-waves of a ds_write hit disjoint banks) and streams it out as 16-byte
   // non-temporal stores, 256 contiguous bytes per output row -- the output is write-once, read by a later kernel.
   const bool staged = g.C32 && !g.C16 && !g.k_chunk && !g.accumulate && !g.row_map && !g.mask16 && !(g.ldc & 3) &&
-                      !((uintptr_t)g.C32 & 15) && !(g.dbg & 4);
+                      !((uintptr_t)g.C32 & 15);
   if (staged) {
     constexpr int CS = WN + 8;
     float* sC = reinterpret_cast<float*>(smem_gemm) + wave * (WM * CS);
@@ -225,7 +224,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
     for (int it = 0; it < WM / RPI; ++it) {
       const int rl = it * RPI + rw;
       const int row = cm0 + wm * WM + rl;
-      if ((g.dbg & 1) && it) continue;
       if (row < g.M) {
         const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
         float* p = g.C32 + (size_t)row * g.ldc + col;
@@ -248,7 +246,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = cm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if ((g.dbg & 1) && r) continue;
         if (row < g.M && col < g.N) {
           float v = acc[i][j][r] + ((g.k_chunk && cbz) ? 0.f : b);
           if (g.relu) v = fmaxf(v, 0.f);
@@ -268,118 +265,6 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   }
   __syncthreads();   // the staged C (and the last operand tiles) are dead before the next tile overwrites LDS
   }
-}
-
-// epilogue of one 32x32 MFMA tile of the big-tile kernel (C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) +
-// 4 * (lane >> 5)): fp32 output only -- plain store, or atomic accumulation for split-K, optional output row map.
-// (bf16 outputs / ReLU / masks stay on the 128x128 kernel; keeping this body small lets the compiler unroll all 16
-// tiles and keep the 256 accumulators in registers.)
-__device__ __forceinline__ void gemm_store_tile32(const GemmArgs& g, const f32x16 c, const int row0, const int col,
-                                                  const float bias) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = row0 + (r & 3) + 8 * (r >> 2);
-    if (row < g.M && col < g.N) {
-      float* p = g.C32 + (size_t)(g.row_map ? g.row_map[row] : row) * g.ldc + col;
-      if (g.k_chunk)
-        atomicAdd(p, c[r] + bias);
-      else
-        *p = c[r] + bias;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Big-tile variant for large GEMMs: block tile 256 x (64*TNW) (TNW = 4 or 2), four waves in a 2x2 grid, each wave a
-// 128 x (32*TNW) sub-tile of 4 x TNW 32x32 MFMA tiles whose accumulators live in the AGPR half of the register file
-// (256 / 128 registers), ONE workgroup per CU.  Why: with 128x128 tiles every operand byte is re-read from L2 M/128
-// resp. N/128 times (328 MB for the 10240x2048x512 LSTM projection) and every MFMA needs a full ds_read_b128 of
-// operand -- both halve here.  LDS is double-buffered ([2][rows][72] bf16 per operand, 147 KB at TNW = 4) so one
-// barrier per 64-deep step suffices, and the global loads of step k+2 are in flight during the MFMAs of step k.
-// ---------------------------------------------------------------------------------------------------
-template <int TNW>
-__global__ __launch_bounds__(256, 1) void gemm_nt_bf16_big_kernel(GemmArgs g) {
-  constexpr int BM = 256, BN = 64 * TNW;
-  constexpr int TM = 4, TN = TNW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_big[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_big);               // [2][BM][kLdsStride]
-  bf16_t* sB = sA + 2 * BM * kLdsStride;                           // [2][BN][kLdsStride]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  constexpr int CPR = kBK / 8;
-  constexpr int A_ITERS = BM * CPR / 256, B_ITERS = BN * CPR / 256;
-  uint4 ra[A_ITERS], rb[B_ITERS];
-  auto load_tile = [&](int k0) {
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      const int gr = m0 + r;
-      ra[it] = (gr < g.M) ? *reinterpret_cast<const uint4*>(g.A + (size_t)gr * g.lda + k0 + q * 8) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      const int gr = n0 + r;
-      rb[it] = (gr < g.N) ? *reinterpret_cast<const uint4*>(g.B + (size_t)gr * g.ldb + k0 + q * 8) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    bf16_t* a = sA + buf * BM * kLdsStride;
-    bf16_t* b = sB + buf * BN * kLdsStride;
-#pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      *reinterpret_cast<uint4*>(a + r * kLdsStride + q * 8) = ra[it];
-    }
-#pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      *reinterpret_cast<uint4*>(b + r * kLdsStride + q * 8) = rb[it];
-    }
-  };
-
-  f32x16 acc[TM][TN] = {};
-
-  const int kbeg = g.k_chunk ? blockIdx.z * g.k_chunk : 0;
-  const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
-  const int nk = (kend - kbeg) / kBK;
-  load_tile(kbeg);
-  store_tile(0);
-  if (nk > 1) load_tile(kbeg + kBK);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      store_tile(cur ^ 1);                                  // tile kt+1: its buffer was last read in step kt-1
-      if (kt + 2 < nk) load_tile(kbeg + (kt + 2) * kBK);    // in flight during this step's MFMAs
-    }
-    const bf16_t* a = sA + cur * BM * kLdsStride;
-    const bf16_t* b = sB + cur * BN * kLdsStride;
-#pragma unroll
-    for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = lds_frag(a, wm * 128 + i * 32, kk, lane);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = lds_frag(b, wn * (32 * TN) + j * 32, kk, lane);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-    {
-      const int col = n0 + wn * (32 * TN) + j * 32 + (lane & 31);
-      const float bias = (g.bias && col < g.N && !(g.k_chunk && blockIdx.z)) ? g.bias[col] : 0.f;
-      gemm_store_tile32(g, acc[i][j], m0 + wm * 128 + i * 32 + 4 * (lane >> 5), col, bias);
-    }
 }
 
 // fp32 [M, K] -> bf16 [M, Kp] zero padded (Kp >= K)
@@ -1648,7 +1533,7 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
-             0, (const bf16_t*)relu_mask16, ldmask, row_map, getenv("HSAD_GEMM_DBG") ? atoi(getenv("HSAD_GEMM_DBG")) : 0};
+             0, (const bf16_t*)relu_mask16, ldmask, row_map, 1};
   int gz = 1;
   if (split_k > 1) {
     int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
@@ -1663,24 +1548,7 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  // tile choice: the 256x256 (or 256x128) one-workgroup-per-CU kernel once its grid fills the chip
-  static const int force = getenv("HSAD_GEMM_TILE") ? atoi(getenv("HSAD_GEMM_TILE")) : 0;   // developer override
-  const long t256 = (long)((N + 255) / 256) * ((M + 255) / 256) * gz, t128 = (long)((N + 127) / 128) * ((M + 255) / 256) * gz;
-  int big = 0;
-  const bool big_ok = C32 && !C16 && !relu && !relu_mask16 && !accumulate;   // what the big-tile epilogue supports
-  if (force == 256 && t256 >= 1) big = 4;
-  else if (force == 1128 && t128 >= 1) big = 2;
-  if (force == 128 || !big_ok) big = 0;
-  if (big) {
-    const size_t lds = (size_t)2 * (256 + 64 * big) * kLdsStride * sizeof(bf16_t);
-    if (big == 4) {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gemm_nt_bf16_big_kernel<4>, dim3((N + 255) / 256, (M + 255) / 256, gz), dim3(256), lds, s, g);
-    } else {
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_big_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(gemm_nt_bf16_big_kernel<2>, dim3((N + 127) / 128, (M + 255) / 256, gz), dim3(256), lds, s, g);
-    }
-  } else if (N <= 64) {
+  if (N <= 64) {
     const size_t lds = (size_t)2 * (128 + 64) * kLdsStride * sizeof(bf16_t);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz;

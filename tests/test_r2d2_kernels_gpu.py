@@ -43,9 +43,9 @@ def test_gemm_nt_bf16(M, N, K):
 
 @pytest.mark.parametrize("M,N,K,split_k,use_map", [(10240, 2048, 512, 1, False), (7000, 2040, 320, 1, False),
                                                    (2048, 512, 10240, 8, True), (4100, 1000, 2560, 4, True)])
-def test_gemm_big_tile_kernel(M, N, K, split_k, use_map):
-    """shapes whose grid fills the chip take the 256x256 / 256x128 one-workgroup-per-CU kernel (fp32 output, bias,
-    split-K atomics, output row map); ragged edges included"""
+def test_gemm_large_shapes_split_k_and_row_map(M, N, K, split_k, use_map):
+    """learner-sized GEMMs through the persistent tile loop (more tiles than workgroups): LDS-staged fp32 epilogue with
+    bias, split-K atomics with an output row map, ragged edges"""
     from hanabi_sad_amd.r2d2 import gemm_nt, gemm_nt_ex
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     A16 = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
