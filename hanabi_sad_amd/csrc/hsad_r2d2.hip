@@ -373,11 +373,10 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __e
 
 template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
-  // BM == 128: wave w owns rows [32w, 32w+32) of the block, full K.   (big batches: actors)
-  // BM == 32 : all waves share the 32 rows, wave w reduces K-quarter w; partial sums meet in LDS. (learner, B=128)
+  // big batches (actors): wave w owns rows [32w, 32w+32) of the block, full K; small batches use lstm_step_small_kernel
+  static_assert(BM == 128 && KIT == 1, "only the 128-row variant is instantiated");
   __shared__ __attribute__((aligned(16))) bf16_t sA[BM * kLdsStride];
   __shared__ __attribute__((aligned(16))) bf16_t sB[128 * kLdsStride];
-  __shared__ float sRed[BM == 32 ? 3 * 4 * 16 * 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, nb = blockIdx.x;  // nb: block of 32 hidden units
   const int H = a.H;
@@ -430,45 +429,6 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
       }
       __syncthreads();
     }
-  } else {
-    // BM == 32: operands come straight from L2 (h_prev is 32 x H, the W slice 128 x H); wave w multiplies
-    // k in [w*H/4, (w+1)*H/4) = KIT blocks of 16.  Every fragment load is issued before the first MFMA.
-    const int kbase = wave * (KIT * 16);
-    const int row = m0 + (lane & 31);
-    bf16x8 fa[KIT], fb[4][KIT];
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      if (row < a.Bn) {
-        fa[it] = *reinterpret_cast<const bf16x8*>(a.h_prev + (size_t)row * H + kbase + it * 16 + (lane >> 5) * 8);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) fa[it][e] = (__bf16)0.f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int it = 0; it < KIT; ++it)
-        fb[j][it] = *reinterpret_cast<const bf16x8*>(a.Whh + (size_t)(nb * 128 + j * 32 + (lane & 31)) * H + kbase + it * 16 + (lane >> 5) * 8);
-#pragma unroll
-    for (int it = 0; it < KIT; ++it)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it], fb[j][it], acc[j], 0, 0, 0);
-    // reduce the four K-quarters into wave 0
-    if (wave > 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sRed[(((wave - 1) * 4 + j) * 16 + r) * 64 + lane] = acc[j][r];
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll
-    for (int w = 0; w < 3; ++w)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += sRed[((w * 4 + j) * 16 + r) * 64 + lane];
   }
 
   // epilogue: this lane holds gates i,f,g,o (acc[0..3]) of unit u for 16 rows.  All loads are issued first
