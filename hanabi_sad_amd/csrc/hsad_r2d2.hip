@@ -638,7 +638,7 @@ struct LstmSeqArgs {
 
 template <int KB>  // KB = H / 32
 __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks,
-                                                  u64_t* group_word) {
+                                                  u64_t* group_word, const int force_cross_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int H = KB * 32;
   constexpr int WS = H + 8;                      // padded LDS row stride (elements)
@@ -665,8 +665,8 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
   }
   if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nunit_blocks, a.timeout);
   __syncthreads();
-  const int fast = s_okp[1];
-  if (fast < 0) return;
+  if (s_okp[1] < 0) return;
+  const int fast = force_cross_xcd ? 0 : s_okp[1];
   const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
   u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
@@ -816,6 +816,7 @@ struct LstmSeqArgsN {
   LstmSeqArgs r[4];
   int nrec, nrb, nunit;
   u64_t* group_words;   // [nrec * nrb], zeroed before launch
+  int force_cross_xcd;  // testing: use the cross-XCD protocol even for co-located groups
 };
 
 // linear block id L -> XCD x = L % 8 (observed dispatch order), slot s = L / 8; group G = x + 8 * (s / nunit) is the
@@ -830,7 +831,7 @@ struct LstmSeqArgsN {
 template <int KB>
 __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgsN m) {
   HSAD_SEQ_PLACE(m)
-  lstm_seq_fwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_);
+  lstm_seq_fwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_, m.force_cross_xcd);
 }
 
 
@@ -857,7 +858,7 @@ struct LstmSeqBwdArgs {
 
 template <int KB>  // KB = 4H / 32
 __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks,
-                                                  u64_t* group_word) {
+                                                  u64_t* group_word, const int force_cross_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int K = KB * 32, H = K / 4;
   constexpr int WS = K + 8;
@@ -882,8 +883,8 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
   }
   if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nunit_blocks, a.timeout);
   __syncthreads();
-  const int fast = s_okp[1];
-  if (fast < 0) return;
+  if (s_okp[1] < 0) return;
+  const int fast = force_cross_xcd ? 0 : s_okp[1];
   const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
   u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
@@ -1042,12 +1043,13 @@ struct LstmSeqBwdArgsN {
   LstmSeqBwdArgs r[2];
   int nrec, nrb, nunit;
   u64_t* group_words;
+  int force_cross_xcd;
 };
 
 template <int KB>
 __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgsN m) {
   HSAD_SEQ_PLACE(m)
-  lstm_seq_bwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_);
+  lstm_seq_bwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_, m.force_cross_xcd);
 }
 
 
@@ -1445,6 +1447,7 @@ __global__ void zero_rows_kernel(float* __restrict__ x, const unsigned char* __r
 // sync_scratch layout (uint32 words): [2 * nrec * nrb: one 64-bit placement word per (recurrence, row block)]
 // [nrec * T * nrb step counters] [sticky timeout word] -- everything before the timeout word is zeroed per launch
 static inline size_t seq_sync_words(int nrec, int T, int nrb) { return (size_t)nrec * nrb * (T + 2); }
+static int g_force_cross_xcd = 0;   // hsad_lstm_set_exchange_mode
 
 static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s) {
   const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
@@ -1452,6 +1455,7 @@ static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sy
   m.nrb = nrb;
   m.nunit = H / 32;
   m.group_words = reinterpret_cast<u64_t*>(sync);
+  m.force_cross_xcd = g_force_cross_xcd;
   const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1470,6 +1474,7 @@ static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned*
   m.nrb = nrb;
   m.nunit = H / 32;
   m.group_words = reinterpret_cast<u64_t*>(sync);
+  m.force_cross_xcd = g_force_cross_xcd;
   const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1629,6 +1634,11 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
       hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
   }
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_set_exchange_mode(int force_cross_xcd) {
+  g_force_cross_xcd = force_cross_xcd ? 1 : 0;
   return HSAD_OK;
 }
 

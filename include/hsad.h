@@ -259,6 +259,9 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
 int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_blocked, const float* h0,
                             const float* c0, void* hseq16, float* cseq, void* h0_16_scratch, float* hT,
                             void* sync_scratch, int keep_gates, void* stream);
+/* testing: force_cross_xcd != 0 makes every persistent recurrence use the cross-XCD hand-off protocol even when its
+ * workgroups are co-located (the default, 0, picks per group at start-up); results must not depend on it */
+int hsad_lstm_set_exchange_mode(int force_cross_xcd);
 /* developer phase timers of the persistent recurrences (100 MHz ticks summed over the steps of one workgroup; slots
  * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
  * publish); out16 may be NULL; reset != 0 clears them */

@@ -337,6 +337,31 @@ def test_prepare_weight_casts_permutes_and_transposes_in_one_pass():
     assert (dst[:, C:] == 7).all() and (dstT[:, R:] == 7).all()           # padding untouched
 
 
+def test_exchange_protocol_does_not_change_results():
+    """co-located workgroups hand tiles over inside their XCD's L2, others through memory: the arithmetic is the same, so
+    forcing the cross-XCD protocol everywhere must reproduce loss and priorities bit for bit"""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import R2D2Learner, check_sync
+    lib = _lib.load_library()
+    F, A, H, T, B = 838, 21, 512, 80, 128
+    W, Wt = _rand_net(F, H, A, seed=9), _rand_net(F, H, A, seed=10)
+    batch, weight = _rand_batch(T, B, F, A)
+    res = []
+    try:
+        for mode in (0, 1):
+            _lib.check(lib.hsad_lstm_set_exchange_mode(mode))
+            lr = R2D2Learner(W, Wt, 3, 0.999, device=DEV)
+            loss, prio = lr.loss(batch, weight, 0.25)
+            torch.cuda.synchronize()
+            res.append((loss.clone(), prio.clone(), {k: v.clone() for k, v in lr.grad.items()}))
+    finally:
+        lib.hsad_lstm_set_exchange_mode(0)
+    check_sync()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert relerr(res[0][2][k], res[1][2][k]) < 1e-4, k
+
+
 def test_agent_act_and_compute_priority_against_reference_golden():
     from hanabi_sad_amd.r2d2 import R2D2Agent, R2D2NetKernels
     z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
