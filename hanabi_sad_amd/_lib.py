@@ -94,6 +94,8 @@ SIGNATURES = {
     "hsad_gemm_nt_bf16": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
                                     C.c_int, C.c_int, _P]),
     "hsad_cast_pad_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "hsad_gemm_nt_bf16_splitk": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "hsad_transpose_bf16_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "hsad_prepare_weight": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "hsad_bias_sum_perm": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
     "hsad_transpose_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),

@@ -87,6 +87,7 @@ struct GemmArgs {
   int ldmask;
   const int32_t* row_map;  // optional [M]: result row r is written to row row_map[r] of C32 / C16
   int gz;                  // number of K splits (1 = none)
+  size_t slab_stride;      // split-K without atomics: split z writes its partial result to C32 + z * slab_stride
 };
 
 template <int BM, int BN>
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   // Fast path (plain fp32 output, the big activation-producing GEMMs): the wave stages its WM x WN block in LDS (row
   // stride WN + 8 floats: the two half-waves of a ds_write hit disjoint banks) and streams it out as 16-byte
   // non-temporal stores, 256 contiguous bytes per output row -- the output is write-once, read by a later kernel.
-  const bool staged = g.C32 && !g.C16 && !g.k_chunk && !g.accumulate && !g.row_map && !g.mask16 && !(g.ldc & 3) &&
+  const bool staged = g.C32 && !g.C16 && (!g.k_chunk || g.slab_stride) && !g.accumulate && !g.row_map && !g.mask16 && !(g.ldc & 3) &&
                       !((uintptr_t)g.C32 & 15);
   if (staged) {
     constexpr int CS = WN + 8;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = cn0 + wn * WN + j * 32 + (lane & 31);
-        const float bias = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+        const float bias = (g.bias && col < g.N && !cbz) ? g.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = acc[i][j][r] + bias;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       const int row = cm0 + wm * WM + rl;
       if (row < g.M) {
         const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
-        float* p = g.C32 + (size_t)row * g.ldc + col;
+        float* p = g.C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
         if (col + 3 < g.N) {
           __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(p));
         } else {
@@ -278,8 +279,12 @@ __global__ void cast_pad_bf16_kernel(const float* __restrict__ src, int M, int K
 
 // bf16 [R, C] (ld = lds) -> [C, R] (ld = ldd).  64x64 tiles through LDS, 256 threads: 8-byte global loads and stores
 // when both leading dimensions / bases allow it (the weight-gradient operands: 10-40 MB per call), scalar otherwise.
+// Optionally also accumulates the column sums of src (bias gradients: the tile is in LDS anyway) into
+// csum[col_map ? col_map[c] : c] (and csum2).
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, int R, int C, int lds,
-                                                             bf16_t* __restrict__ dst, int ldd, int vec) {
+                                                             bf16_t* __restrict__ dst, int ldd, int vec,
+                                                             float* __restrict__ csum = nullptr, float* __restrict__ csum2 = nullptr,
+                                                             const int32_t* __restrict__ col_map = nullptr) {
   __shared__ bf16_t tile[64][66];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   if (vec) {
@@ -294,6 +299,21 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
       tile[r][c + 3] = (bf16_t)(v.y >> 16);
     }
     __syncthreads();
+    if (csum) {   // 4 threads per column, 16 rows each (rows beyond R were loaded as zeros)
+      __shared__ float s_part[4][64];
+      const int c = tid & 63, q = tid >> 6;
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += bf2f(tile[q * 16 + r][c]);
+      s_part[q][c] = a;
+      __syncthreads();
+      if (tid < 64 && c0 + tid < C) {
+        const float v = s_part[0][tid] + s_part[1][tid] + s_part[2][tid] + s_part[3][tid];
+        const int oc = col_map ? col_map[c0 + tid] : c0 + tid;
+        atomicAdd(csum + oc, v);
+        if (csum2) atomicAdd(csum2 + oc, v);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = (tid >> 4) + 16 * i, r = (tid & 15) * 4;      // output row c0 + c, output columns r0 + r .. +3
@@ -1129,11 +1149,12 @@ __global__ void td_loss_kernel(const float* __restrict__ online_qa, const float*
                                const float* __restrict__ seq_len, int T, int B, int n, float gamma_n,
                                float* __restrict__ err, float* __restrict__ priority, float* __restrict__ loss,
                                float* __restrict__ dqa, const float* __restrict__ weight) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  // one block per sequence, one thread per time step (a single thread walking T dependent loads took 51 us)
+  __shared__ float s_sum[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
   const float len = seq_len[b];
   float sum = 0.f;
-  for (int t = 0; t < T; ++t) {
+  for (int t = tid; t < T; t += blockDim.x) {
     const float tq = (t + n < T) ? target_qa[(size_t)(t + n) * B + b] : 0.f;
     const float target = reward[(size_t)t * B + b] + bootstrap[(size_t)t * B + b] * gamma_n * tq;
     const float mask = (float)t < len ? 1.f : 0.f;
@@ -1148,7 +1169,13 @@ __global__ void td_loss_kernel(const float* __restrict__ online_qa, const float*
       dqa[(size_t)t * B + b] = -g * mask * (weight ? weight[b] : 1.f) / (float)B;
     }
   }
-  loss[b] = sum;
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int k = blockDim.x / 2; k > 0; k >>= 1) {   // fixed-order tree: deterministic
+    if (tid < k) s_sum[tid] += s_sum[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) loss[b] = s_sum[0];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1302,6 +1329,28 @@ __global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const 
     total += -acc / fmaxf(nmask, 1e-6f);
   }
   xent_sum[b] = total;
+}
+
+// out[row_map ? row_map[r] : r][:] = sum over the n split-K slabs of ws[z][r][:]   (N % 4 == 0, 16-byte aligned rows)
+__global__ void sum_slabs_kernel(const float* __restrict__ ws, int n, int M, int N, float* __restrict__ out, int ldc,
+                                 const int32_t* __restrict__ row_map) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int n4 = N / 4;
+  if (i4 >= (size_t)M * n4) return;
+  const int r = (int)(i4 / n4), c = (int)(i4 - (size_t)r * n4) * 4;
+  float4 a = *reinterpret_cast<const float4*>(ws + (size_t)r * N + c);
+  for (int z = 1; z < n; ++z) {
+    const float4 b = *reinterpret_cast<const float4*>(ws + ((size_t)z * M + r) * N + c);
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    a.w += b.w;
+  }
+  float* p = out + (size_t)(row_map ? row_map[r] : r) * ldc + c;
+  p[0] = a.x;
+  p[1] = a.y;
+  p[2] = a.z;
+  p[3] = a.w;
 }
 
 // column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients).  Grid = (N/64, row chunks of 512);
@@ -1489,16 +1538,16 @@ static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned*
 
 extern "C" {
 
-int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
-                         float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
-                         const void* relu_mask16, int ldmask, const int32_t* row_map, void* stream) {
+static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* C32,
+                       int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k, const void* relu_mask16,
+                       int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream) {
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
   if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 64 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
-             0, (const bf16_t*)relu_mask16, ldmask, row_map, 1};
+             0, (const bf16_t*)relu_mask16, ldmask, row_map, 1, 0};
   int gz = 1;
   if (split_k > 1) {
     int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
@@ -1506,6 +1555,8 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
     gz = (K + chunk - 1) / chunk;
   }
   g.gz = gz;
+  g.slab_stride = gz > 1 ? slab_stride : 0;
+  if (n_split_out) *n_split_out = gz;
   hipStream_t s = (hipStream_t)stream;
   static int n_cu = 0;
   if (!n_cu) {
@@ -1524,6 +1575,28 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
     const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, s, g);
   }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
+                         float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
+                         const void* relu_mask16, int ldmask, const int32_t* row_map, void* stream) {
+  return gemm_launch(A, lda, B, ldb, M, N, K, bias, C32, ldc, C16, ldc16, relu, accumulate, split_k, relu_mask16, ldmask, row_map,
+                     0, nullptr, stream);
+}
+
+int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                             float* C32, int ldc, const int32_t* row_map, void* stream) {
+  if (!workspace || !C32 || split_k < 1 || (N & 3) || (ldc & 3) || ((uintptr_t)workspace & 15))
+    return nfail(HSAD_ERR_INVALID, "gemm_splitk: needs a workspace, N and ldc multiples of 4");
+  int n_split = 1;
+  const int rc = gemm_launch(A, lda, B, ldb, M, N, K, nullptr, workspace, N, nullptr, 0, 0, 0, split_k, nullptr, 0, nullptr,
+                             (size_t)M * N, &n_split, stream);
+  if (rc) return rc;
+  const size_t n4 = (size_t)M * (N / 4);
+  hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, M,
+                     N, C32, ldc, row_map);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1563,6 +1636,17 @@ int hsad_transpose_bf16(const void* src, int R, int C, int ld_src, void* dst, in
   const int vec = !(R & 3) && !(C & 3) && !(ld_src & 3) && !(ld_dst & 3) && !(((uintptr_t)src | (uintptr_t)dst) & 7);
   hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, R, C, ld_src, (bf16_t*)dst, ld_dst, vec);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_transpose_bf16_colsum(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, float* colsum, float* colsum2,
+                               const int32_t* col_map, void* stream) {
+  if (!src || !dst || !colsum || R <= 0 || C <= 0) return nfail(HSAD_ERR_INVALID, "transpose_colsum: bad arguments");
+  if ((R & 3) || (C & 3) || (ld_src & 3) || (ld_dst & 3) || (((uintptr_t)src | (uintptr_t)dst) & 7))
+    return nfail(HSAD_ERR_INVALID, "transpose_colsum: R, C and the leading dimensions must be multiples of 4, bases 8-byte aligned");
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, R, C, ld_src, (bf16_t*)dst, ld_dst, 1, colsum, colsum2, col_map);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1684,7 +1768,7 @@ int hsad_td_loss(const float* online_qa, const float* target_qa, const float* re
     for (int i = 0; i < multi_step; ++i) g *= gamma;
     gamma_n = (float)g;
   }
-  hipLaunchKernelGGL(td_loss_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, online_qa, target_qa,
+  hipLaunchKernelGGL(td_loss_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, online_qa, target_qa,
                      reward, bootstrap, seq_len, T, B, multi_step, gamma_n, err, priority, loss, dqa, weight);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;

@@ -388,6 +388,13 @@ class R2D2Learner:
         n = self.online
         self.WhhT, self.WihT, self.WheadsT, self.NHp = n.WhhT, n.WihT, n.WheadsT, n.NHp   # filled by online.refresh()
 
+    def _wgrad_ws(self, n_out):
+        """fp32 workspace for the split-K slabs of one weight gradient (reused: the wgrad GEMMs run in side-stream order)"""
+        n = self.wgrad_split * n_out
+        if getattr(self, "_ws", None) is None or self._ws.numel() < n:
+            self._ws = torch.empty(n, dtype=torch.float32, device=self.device)
+        return self._ws
+
     def _nchunks(self, T, B):
         c = self.chunks if (self.persistent and self.online.H in (256, 512) and B <= 512 and B % 8 == 0) else 1
         while c > 1 and (T % c or (T // c * B) % 64):   # chunk rows are the contraction dim of the chunked wgrad GEMMs
@@ -568,14 +575,27 @@ class R2D2Learner:
         dx1T = torch.empty(H, M, dtype=bf, device=d)
         dheadsT = torch.empty(self.NHp, M, dtype=bf, device=d)
 
-        def tr(src, dst):   # bf16 [R, C] -> dst [C, R] view
-            _lib.check(lib.hsad_transpose_bf16(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(),
-                                               dst.stride(0), _s(d)))
+        def tr(src, dst, csum=None, csum2=None, col_map=None):
+            """bf16 [R, C] -> dst [C, R] view; optionally the column sums of src (a bias gradient) on the way"""
+            if csum is None:
+                _lib.check(lib.hsad_transpose_bf16(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0), dst.data_ptr(),
+                                                   dst.stride(0), _s(d)))
+            else:
+                _lib.check(lib.hsad_transpose_bf16_colsum(src.data_ptr(), src.shape[0], src.shape[1], src.stride(0),
+                                                          dst.data_ptr(), dst.stride(0), csum.data_ptr(),
+                                                          None if csum2 is None else csum2.data_ptr(),
+                                                          None if col_map is None else col_map.data_ptr(), _s(d)))
 
-        def csum(x, out, out2=None, col_map=None, ncols=None):
-            _lib.check(lib.hsad_colsum_acc(x.data_ptr(), 1, x.shape[0], x.shape[1] if ncols is None else ncols, x.stride(0),
-                                           out.data_ptr(), None if out2 is None else out2.data_ptr(),
-                                           None if col_map is None else col_map.data_ptr(), _s(d)))
+        def csum(x, out, ncols):
+            _lib.check(lib.hsad_colsum_acc(x.data_ptr(), 1, x.shape[0], ncols, x.stride(0), out.data_ptr(), None, None, _s(d)))
+
+        ws = self._wgrad_ws(4 * H * H)
+
+        def wgrad(AT, BT, Mo, No, out, row_map=None):
+            """out[row_map[r]] = AT[Mo, M] . BT[No, M]^T as split-K over the T*B contraction, partial slabs + one reduction"""
+            _lib.check(lib.hsad_gemm_nt_bf16_splitk(AT.data_ptr(), AT.stride(0), BT.data_ptr(), BT.stride(0), Mo, No, M,
+                                                    self.wgrad_split, ws.data_ptr(), out.data_ptr(), out.stride(0),
+                                                    None if row_map is None else row_map.data_ptr(), _s(d)))
 
         def brec(l, c):
             t0 = c * Tc
@@ -586,10 +606,9 @@ class R2D2Learner:
 
         def layer_wgrad(l, inT):
             dG2 = dGs[l][:T].view(M, 4 * H)
-            tr(dG2, dGT)
-            gemm_nt_ex(dGT, inT, 4 * H, H, M, out32=g["lstm.weight_ih_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
-            gemm_nt_ex(dGT, hsT[l][:, :M], 4 * H, H, M, out32=g["lstm.weight_hh_l%d" % l], split_k=self.wgrad_split, row_map=on.perm32)
-            csum(dG2, g["lstm.bias_ih_l%d" % l], g["lstm.bias_hh_l%d" % l], on.perm32)
+            tr(dG2, dGT, g["lstm.bias_ih_l%d" % l], g["lstm.bias_hh_l%d" % l], on.perm32)   # + both bias gradients
+            wgrad(dGT, inT, 4 * H, H, g["lstm.weight_ih_l%d" % l], on.perm32)
+            wgrad(dGT, hsT[l][:, :M], 4 * H, H, g["lstm.weight_hh_l%d" % l], on.perm32)
 
         side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -600,7 +619,7 @@ class R2D2Learner:
             tr(keep["a16"], a16T)
             tr(dheads, dheadsT)
             gemm_nt_ex(dheadsT, hsT[1][:, B:], on.NH, H, M, out32=self.g_wheads, split_k=self.wgrad_split)
-            csum(dheads, self.g_bheads, ncols=on.NH)
+            csum(dheads, self.g_bheads, on.NH)
         # stage s: layer 1 on chunk nch-1-s next to layer 0 on chunk nch-s, one persistent launch per stage
         e1 = None
         for s_ in range(nch + 1):
@@ -627,9 +646,8 @@ class R2D2Learner:
             side.wait_stream(main)                        # layer 0 complete
             layer_wgrad(0, x1T)
         gemm_nt_ex(dGs[0][:T].view(M, 4 * H), self.WihT[0], M, H, 4 * H, out16=dx1, relu_mask=keep["x1"])
-        tr(dx1, dx1T)
+        tr(dx1, dx1T, g["net.0.bias"])
         gemm_nt_ex(dx1T, a16T, H, on.F, M, out32=g["net.0.weight"], split_k=self.wgrad_split)
-        csum(dx1, g["net.0.bias"])
         main.wait_stream(side)
 
     def optimizer_step(self, beta1=0.9, beta2=0.999):

@@ -285,6 +285,15 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
                          float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k,
                          const void* relu_mask16, int ldmask, const int32_t* row_map, void* stream);
 /* (row_map, may be NULL: result row r lands in output row row_map[r] -- un-blocks the gate-blocked weight gradients) */
+/* split-K without atomics (weight gradients: contraction over T*B): every K split writes its partial [M,N] into its own slab
+ * of `workspace` (fp32 [split_k, M, N]) through the fast epilogue, then one pass sums the slabs into
+ * C32[row_map ? row_map[r] : r] (overwritten).  N and ldc multiples of 4. */
+int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                             float* C32, int ldc, const int32_t* row_map, void* stream);
+/* hsad_transpose_bf16 that also accumulates (atomically) the column sums of src into colsum[col_map ? col_map[c] : c]
+ * (and colsum2): the bias gradients come for free while the weight-gradient operand is transposed */
+int hsad_transpose_bf16_colsum(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, float* colsum, float* colsum2,
+                               const int32_t* col_map, void* stream);
 /* fp32 master weight [R,C] -> bf16 kernel operands in one pass: dst16[r][:] = src[perm ? perm[r] : r][:] and/or its
  * transpose dstT16[c][r] (either may be NULL; padding of the destinations is left untouched).  Replaces
  * `weight[perm].to(bfloat16)` + transpose after every optimizer step. */
