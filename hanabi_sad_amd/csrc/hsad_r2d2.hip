@@ -197,9 +197,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   // Fast path (plain fp32 output, the big activation-producing GEMMs): the wave stages its WM x WN block in LDS (row
   // stride WN + 8 floats: the two half-waves of a ds_write hit disjoint banks) and streams it out as 16-byte
   // non-temporal stores, 256 contiguous bytes per output row -- the output is write-once, read by a later kernel.
-  const bool staged = g.C32 && !g.C16 && (!g.k_chunk || g.slab_stride) && !g.accumulate && !g.row_map && !g.mask16 && !(g.ldc & 3) &&
-                      !((uintptr_t)g.C32 & 15);
-  if (staged) {
+  const bool staged32 = g.C32 && !g.C16 && (!g.k_chunk || g.slab_stride) && !g.accumulate && !g.row_map && !g.mask16 &&
+                        !(g.ldc & 3) && !((uintptr_t)g.C32 & 15);
+  // bf16-only output (activations / activation gradients, optional ReLU-backward mask): same staging, 8-byte stores
+  const bool staged16 = !g.C32 && g.C16 && !g.k_chunk && !g.row_map && !(g.ldc16 & 3) && !((uintptr_t)g.C16 & 7) &&
+                        (!g.mask16 || (!(g.ldmask & 3) && !((uintptr_t)g.mask16 & 7)));
+  if (staged32 || staged16) {
     constexpr int CS = WN + 8;
     float* sC = reinterpret_cast<float*>(smem_gemm) + wave * (WM * CS);
 #pragma unroll
@@ -225,7 +228,30 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
     for (int it = 0; it < WM / RPI; ++it) {
       const int rl = it * RPI + rw;
       const int row = cm0 + wm * WM + rl;
-      if (row < g.M) {
+      if (row < g.M && staged16) {
+        nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
+        if (col + 3 < g.N) {
+          if (g.mask16) {
+            const uint2 mk = *reinterpret_cast<const uint2*>(g.mask16 + (size_t)row * g.ldmask + col);
+            if (!(bf2f((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+            if (!(bf2f((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+            if (!(bf2f((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+            if (!(bf2f((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+          }
+          uint2 o;
+          o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+          o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (col + e < g.N) {
+              float x = v[e];
+              if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col + e]) > 0.f)) x = 0.f;
+              g.C16[(size_t)row * g.ldc16 + col + e] = f2bf(x);
+            }
+        }
+      } else if (row < g.M) {
         const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
         float* p = g.C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
         if (col + 3 < g.N) {
@@ -1564,7 +1590,9 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
-  if (N <= 64) {
+  // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
+  const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
+  if (N <= 64 || tiles128 < n_cu) {
     const size_t lds = (size_t)2 * (128 + 64) * kLdsStride * sizeof(bf16_t);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz;

@@ -65,6 +65,24 @@ def test_gemm_large_shapes_split_k_and_row_map(M, N, K, split_k, use_map):
         assert torch.allclose(out, ref_out, rtol=1e-3, atol=2e-3 * K ** 0.5)
 
 
+@pytest.mark.parametrize("M,N,K", [(10240, 512, 2048), (300, 200, 192), (1000, 130, 64)])
+def test_gemm_bf16_only_output_with_relu_and_backward_mask(M, N, K):
+    """bf16-only outputs take the LDS-staged epilogue (8-byte stores) when strides allow it, the scalar one otherwise"""
+    from hanabi_sad_amd.r2d2 import gemm_nt, gemm_nt_ex
+    g = torch.Generator(device="cpu").manual_seed(M * 3 + N)
+    A16 = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    B16 = torch.randn(N, K, generator=g).to(DEV).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(DEV)
+    want = A16.float() @ B16.float().t()
+    out = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=DEV)
+    gemm_nt(A16, B16, M, N, K, bias=bias, out16=out, relu=True)
+    assert torch.allclose(out.float(), (want + bias).clamp(min=0), rtol=1e-2, atol=0.1)
+    mask = (torch.rand(M, N, generator=g) < 0.5).to(DEV).to(torch.bfloat16)
+    out2 = torch.full((M, N), 5.0, dtype=torch.bfloat16, device=DEV)
+    gemm_nt_ex(A16, B16, M, N, K, out16=out2, relu_mask=mask)
+    assert torch.allclose(out2.float(), want * mask.float(), rtol=1e-2, atol=0.1)
+
+
 def test_cast_and_transpose():
     from hanabi_sad_amd.r2d2 import cast_pad_bf16, transpose_bf16
     x = torch.randn(77, 838, device=DEV)
