@@ -3,7 +3,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["NO_TORCH"] = "1"
-src = open(os.path.join(os.path.dirname(__file__), "time_learner.py")).read().split("for _ in range(3): upd()")[0]
+src = open(os.path.join(os.path.dirname(__file__), "time_learner.py")).read().split("for _ in range(5): upd()")[0]
 exec(src)
 for _ in range(3): upd()
 torch.cuda.synchronize()
@@ -14,20 +14,3 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("issue %.2f ms/update, total %.2f ms/update" % ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
-# graph capture of the whole update
-g = torch.cuda.CUDAGraph()
-s = torch.cuda.Stream()
-s.wait_stream(torch.cuda.current_stream())
-with torch.cuda.stream(s):
-    upd()
-torch.cuda.current_stream().wait_stream(s)
-torch.cuda.synchronize()
-try:
-    with torch.cuda.graph(g):
-        upd()
-    for _ in range(3): g.replay()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n): g.replay()
-    torch.cuda.synchronize(); print("graph replay: %.2f ms/update" % ((time.perf_counter() - t0) / n * 1e3))
-except Exception as e:
-    print("graph capture failed:", repr(e)[:400])
