@@ -33,7 +33,7 @@ _P = C.c_void_p
 class LstmFwdRec(C.Structure):
     """hsad_lstm_fwd_rec (include/hsad.h)"""
     _fields_ = [("gates", C.c_void_p), ("Whh_blocked", C.c_void_p), ("h_prev16", C.c_void_p), ("c_prev", C.c_void_p),
-                ("hseq16", C.c_void_p), ("cseq", C.c_void_p), ("hT", C.c_void_p)]
+                ("hseq16", C.c_void_p), ("cseq", C.c_void_p), ("hT", C.c_void_p), ("xchg", C.c_void_p)]
 
 
 class LstmBwdRec(C.Structure):

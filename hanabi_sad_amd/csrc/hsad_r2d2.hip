@@ -677,6 +677,7 @@ struct LstmSeqArgs {
   bf16_t* hseq16;          // [T,Bn,H]
   float* cseq;             // [T,Bn,H]
   float* hT;               // optional [Bn,H]
+  bf16_t* xchg;            // optional [T][ceil(Bn/32)][H/32][32 rows][32 units]: h tiles in hand-off order (see below)
   unsigned* counters;      // [T][Bn/32] zeroed before launch
   unsigned* timeout;       // [1] set to 1 if a spin gave up
   int T, Bn, H;
@@ -757,7 +758,14 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     // Co-located groups: 16-byte sc1 loads, one full 64-byte segment per row and instruction, served by the shared L2.
     // Cross-XCD groups keep the 8-byte agent-scope atomics (measured faster there than 16-byte nt loads: 694 vs 760 us
     // per 80-step layer).
-    const bf16_t* hrow16 = hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs;
+    // Hand-off layout (a.xchg, steps t >= 1): the tile a workgroup publishes -- 32 rows x its 32 units -- is ONE contiguous
+    // 2 KB block [32 rows][32 units], blocks ordered [t][row block][unit block].  The producer's stores are then linear and
+    // a consumer wave instruction (16 rows x 64 B of one k block) reads 1 KB contiguous instead of sixteen 64-byte pieces
+    // 1 KB apart.  hseq16 keeps the row-major copy for the kernels downstream.
+    const bool use_x = a.xchg != nullptr && t > 0;
+    const bf16_t* hrow16 = use_x ? a.xchg + ((size_t)(t - 1) * nrb + rb) * (size_t)KB * 1024 + (wr * 16 + (lane & 15)) * 32 + kofs
+                                 : hprev + (size_t)min(row_l, a.Bn - 1) * H + kofs;
+    const int kstride = use_x ? 1024 : 32;   // elements between consecutive k blocks of this lane's fragment
     const u64_t* hrow = reinterpret_cast<const u64_t*>(hrow16);
     union Frag {
       u64_t q[2];
@@ -779,7 +787,7 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     if (fast) {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fa[kb].w) : "v"(hrow16), "n"(kb * 64));
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fa[kb].w) : "v"(hrow16 + (size_t)kb * kstride));
       // loads return in order: once at most KB - n are outstanding the first n k-blocks are here, so the MFMAs of each
       // quarter of K start while the rest of the tile is still in flight
       constexpr int QK = KB / 4;
@@ -798,8 +806,8 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
     } else {
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) {
-        fa[kb].q[0] = __hip_atomic_load(hrow + kb * 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        fa[kb].q[1] = __hip_atomic_load(hrow + kb * 8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fa[kb].q[0] = __hip_atomic_load(hrow + (size_t)kb * (kstride / 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fa[kb].q[1] = __hip_atomic_load(hrow + (size_t)kb * (kstride / 4) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       if (dbg_on) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       LSTM_STAMP(1)
@@ -831,12 +839,22 @@ __device__ __forceinline__ void lstm_seq_fwd_body(const LstmSeqArgs& a, const in
       const int row = rb * 32 + r;
       if (row < a.Bn) {
         const u64_t v = *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
-        xchg_store8(reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4), v, fast);
+        if (a.xchg)   // hand-off copy: linear 2 KB block (thread tid -> bytes [8 tid, 8 tid + 8))
+          xchg_store8(reinterpret_cast<u64_t*>(a.xchg + (((size_t)t * nrb + rb) * KB + nb) * 1024 + r * 32 + q * 4), v, fast);
+        else
+          xchg_store8(reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4), v, fast);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t + 1 < a.T) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    if (a.xchg) {   // row-major copy for the kernels downstream: off the other workgroups' critical path
+      const int r = tid >> 3, q = tid & 7;
+      const int row = rb * 32 + r;
+      if (row < a.Bn)
+        *reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4) =
+            *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
+    }
     LSTM_STAMP(4)   // publish: stores, drain, signal
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1708,6 +1726,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     q.hseq16 = (bf16_t*)hseq16;
     q.cseq = cseq;
     q.hT = hT;
+    q.xchg = nullptr;
     q.counters = counters;
     q.timeout = counters + (size_t)T * nrb;
     q.T = T;
@@ -1968,6 +1987,7 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
     q.hseq16 = (bf16_t*)r.hseq16;
     q.cseq = r.cseq;
     q.hT = r.hT;
+    q.xchg = (bf16_t*)r.xchg;
     q.counters = counters + (size_t)i * Tc * nrb;
     q.timeout = counters + (size_t)nrec * Tc * nrb;
     q.T = Tc;
@@ -1979,7 +1999,7 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
 
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
                             const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream) {
-  hsad_lstm_fwd_rec r{gates, Whh_blocked, h_prev16, c_prev, hseq16, cseq, hT};
+  hsad_lstm_fwd_rec r{gates, Whh_blocked, h_prev16, c_prev, hseq16, cseq, hT, nullptr};
   return hsad_lstm_forward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
 }
 

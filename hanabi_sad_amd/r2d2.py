@@ -122,7 +122,9 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
         st.append({"x1": x1, "gates": gates,
                    "hseq": [torch.empty(T, N, H, dtype=torch.bfloat16, device=d) for _ in range(2)],
                    "cseq": [torch.empty(T, N, H, dtype=torch.float32, device=d) for _ in range(2)],
-                   "hT": [torch.empty(N, H, dtype=torch.float32, device=d) for _ in range(2)]})
+                   "hT": [torch.empty(N, H, dtype=torch.float32, device=d) for _ in range(2)],
+                   # hand-off scratch of the persistent kernels (h tiles as contiguous 2 KB blocks), one per layer
+                   "xchg": [torch.empty(Tc * ((N + 31) // 32) * 32 * H, dtype=torch.bfloat16, device=d) for _ in range(2)]})
     zero16 = torch.zeros(N, H, dtype=torch.bfloat16, device=d)
 
     def rec(net, q, l, c):
@@ -130,7 +132,8 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
         return _lib.LstmFwdRec(q["gates"][l][t0].data_ptr(), net.Whh[l].data_ptr(),
                                (zero16 if c == 0 else q["hseq"][l][t0 - 1]).data_ptr(),
                                None if c == 0 else q["cseq"][l][t0 - 1].data_ptr(),
-                               q["hseq"][l][t0].data_ptr(), q["cseq"][l][t0].data_ptr(), q["hT"][l].data_ptr())
+                               q["hseq"][l][t0].data_ptr(), q["cseq"][l][t0].data_ptr(), q["hT"][l].data_ptr(),
+                               q["xchg"][l].data_ptr())
 
     # every workgroup of a launch must be resident at once (they spin on each other): at most CUs // (64 * row blocks)
     # recurrences per launch (4 at B = 128 on a 256-CU MI355X, 2 at 256 rows)

@@ -344,7 +344,8 @@ typedef struct hsad_lstm_fwd_rec {
   const float* c_prev;
   void* hseq16;
   float* cseq;
-  float* hT; /* optional */
+  float* hT;  /* optional */
+  void* xchg; /* optional bf16 scratch [Tc * 32*ceil(Bn/32) * H]: h tiles in hand-off order (contiguous 2 KB blocks) */
 } hsad_lstm_fwd_rec;
 typedef struct hsad_lstm_bwd_rec {
   const float* gates;
