@@ -39,7 +39,7 @@ class LstmFwdRec(C.Structure):
 class LstmBwdRec(C.Structure):
     """hsad_lstm_bwd_rec (include/hsad.h)"""
     _fields_ = [("gates", C.c_void_p), ("cseq", C.c_void_p), ("c_before", C.c_void_p), ("WhhT_blocked", C.c_void_p),
-                ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int)]
+                ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p)]
 
 
 SIGNATURES = {

@@ -918,6 +918,7 @@ struct LstmSeqBwdArgs {
   int T, Bn, H;
   float* dc_io;        // optional [Bn,H]: running dc entering the last step of this chunk (in) / leaving its first (out)
   int has_next;        // dG slot T holds a real gradient (produced by an earlier launch for the following chunk)
+  bf16_t* xchg;        // optional [T][ceil(Bn/32)][4H/32][32 rows][32 cols]: dG tiles in hand-off order
 };
 
 template <int KB>  // KB = 4H / 32
@@ -992,8 +993,16 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       // so every dG fragment is fetched from L2 exactly once per workgroup; partial tiles meet in LDS.
       constexpr int KQ = KB / 4;
       const int row0 = min(rb * 32 + (lane & 15), a.Bn - 1), row1 = min(rb * 32 + 16 + (lane & 15), a.Bn - 1);
-      const bf16x8* g0 = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row0) * K + kofs);
-      const bf16x8* g1 = reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row1) * K + kofs);
+      // Hand-off layout (a.xchg, tiles produced in THIS launch, i.e. t + 1 < T): k block kbi (32 gate columns) of a row
+      // block is one contiguous 2 KB slab [32 rows][32 cols]; a producer's 128 columns are 4 adjacent slabs (8 KB linear
+      // store) and a consumer wave instruction (16 rows of one k block) reads 1 KB contiguous.
+      const bool use_x = a.xchg != nullptr && t < a.T - 1;
+      const bf16_t* xb = use_x ? a.xchg + ((size_t)(t + 1) * nrb + rb) * (size_t)KB * 1024 + kofs : nullptr;
+      const bf16x8* g0 = use_x ? reinterpret_cast<const bf16x8*>(xb + (lane & 15) * 32)
+                               : reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row0) * K + kofs);
+      const bf16x8* g1 = use_x ? reinterpret_cast<const bf16x8*>(xb + (16 + (lane & 15)) * 32)
+                               : reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row1) * K + kofs);
+      const int kstep = use_x ? 128 : 4;     // bf16x8 units between consecutive k blocks of this lane's fragment
       const bf16_t* w0 = sW + (lane & 15) * WS + kofs;
       const bf16_t* w1 = sW + (16 + (lane & 15)) * WS + kofs;
       f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
@@ -1003,18 +1012,18 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       };
       Frag fr0[KQ], fr1[KQ];
       if (fast) {   // shared L2: 16-byte sc1 loads (L1 bypass, L2 hit)
-        const bf16x8* b0 = g0 + wave * KQ * 4;
-        const bf16x8* b1 = g1 + wave * KQ * 4;
+        const bf16x8* b0 = g0 + (size_t)wave * KQ * kstep;
+        const bf16x8* b1 = g1 + (size_t)wave * KQ * kstep;
 #pragma unroll
         for (int it = 0; it < KQ; ++it) {
-          asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr0[it].w) : "v"(b0), "n"(it * 64));
-          asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc1" : "=v"(fr1[it].w) : "v"(b1), "n"(it * 64));
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr0[it].w) : "v"(b0 + (size_t)it * kstep));
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr1[it].w) : "v"(b1 + (size_t)it * kstep));
         }
       } else {      // cross-XCD: 16-byte non-temporal loads (L1 bypass)
 #pragma unroll
         for (int it = 0; it < KQ; ++it) {
-          fr0[it].v = __builtin_nontemporal_load(g0 + (wave * KQ + it) * 4);
-          fr1[it].v = __builtin_nontemporal_load(g1 + (wave * KQ + it) * 4);
+          fr0[it].v = __builtin_nontemporal_load(g0 + (size_t)(wave * KQ + it) * kstep);
+          fr1[it].v = __builtin_nontemporal_load(g1 + (size_t)(wave * KQ + it) * kstep);
         }
       }
       auto mfma_range = [&](int i0, int i1) {
@@ -1082,18 +1091,38 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
     }
     __syncthreads();
     LSTM_STAMP(10)  // K-split reduction + cell backward + dG tile to LDS
+    if (a.xchg && t > 0) {
+      // hand-off copy: 4 slabs [32 rows][32 cols] = 8 KB linear (piece c -> bytes [8c, 8c + 8)); consumed by step t - 1
+      bf16_t* xo = a.xchg + (((size_t)t * nrb + rb) * KB + 4 * nb) * 1024;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {  // 32 rows x 128 columns bf16 = 1024 x 8 bytes
-      const int c = tid + it * 256, r = c >> 5, q = c & 31;
-      const int row = rb * 32 + r;
-      if (row < a.Bn) {
-        const u64_t v = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
-        xchg_store8(reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4), v, fast);
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 256, r = (c >> 3) & 31, qq = c & 7;   // slab it, row r, 8-byte piece qq
+        xchg_store8(reinterpret_cast<u64_t*>(xo + c * 4), *reinterpret_cast<const u64_t*>(sG + r * 136 + it * 32 + qq * 4), fast);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {  // 32 rows x 128 columns bf16 = 1024 x 8 bytes
+        const int c = tid + it * 256, r = c >> 5, q = c & 31;
+        const int row = rb * 32 + r;
+        if (row < a.Bn) {
+          const u64_t v = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+          xchg_store8(reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4), v, fast);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0 && t > 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    if (a.xchg && t > 0) {   // row-major copy for the weight-gradient GEMMs: off the other workgroups' critical path
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 256, r = c >> 5, q = c & 31;
+        const int row = rb * 32 + r;
+        if (row < a.Bn)
+          *reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + row) * K + nb * 128 + q * 4) =
+              *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+      }
+    }
     LSTM_STAMP(11)  // publish: stores, drain, signal
   }
   if (a.dc_io) {
@@ -1835,7 +1864,7 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
     unsigned* sync = (unsigned*)sync_scratch;
     unsigned* counters = sync + 2 * nrb;
     HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(1, T, nrb), s));
-    LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H, nullptr, 0};
+    LstmSeqBwdArgs q{(const bf16_t*)WhhT_blocked, gates, cseq, c0, dO, dG, counters, counters + (size_t)T * nrb, T, Bn, H, nullptr, 0, nullptr};
     LstmSeqBwdArgsN m{};
     m.r[0] = q;
     return launch_seq_bwd(m, 1, H, nrb, sync, s);
@@ -2022,7 +2051,7 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
     bf16_t* dG = (bf16_t*)r.dG16;
     if (!r.has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
     m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
-                            counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next};
+                            counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg};
   }
   return launch_seq_bwd(m, nrec, H, nrb, sync, s);
 }
@@ -2030,7 +2059,7 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream) {
-  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next};
+  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr};
   return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
 }
 

@@ -600,12 +600,14 @@ class R2D2Learner:
                                                     self.wgrad_split, ws.data_ptr(), out.data_ptr(), out.stride(0),
                                                     None if row_map is None else row_map.data_ptr(), _s(d)))
 
+        xchg = [torch.empty(Tc * ((B + 31) // 32) * 32 * 4 * H, dtype=bf, device=d) for _ in range(2)]   # hand-off scratch
+
         def brec(l, c):
             t0 = c * Tc
             return _lib.LstmBwdRec(keep["gates"][l].view(T, B, 4 * H)[t0].data_ptr(), keep["cseq"][l][t0].data_ptr(),
                                    None if c == 0 else keep["cseq"][l][t0 - 1].data_ptr(), self.WhhT[l].data_ptr(),
                                    dOs[l].view(T, B, H)[t0].data_ptr(), dGs[l][t0].data_ptr(), dcs[l].data_ptr(),
-                                   int(c != nch - 1))
+                                   int(c != nch - 1), xchg[l].data_ptr())
 
         def layer_wgrad(l, inT):
             dG2 = dGs[l][:T].view(M, 4 * H)

@@ -356,6 +356,7 @@ typedef struct hsad_lstm_bwd_rec {
   void* dG16;
   float* dc_io;
   int has_next;
+  void* xchg; /* optional bf16 scratch [Tc * 32*ceil(Bn/32) * 4H]: dG tiles in hand-off order */
 } hsad_lstm_bwd_rec;
 /* nrec (<= 4 forward, <= 2 backward) independent recurrences of identical shape in ONE persistent launch, e.g. layer 0
  * on chunk c+1 next to layer 1 on chunk c, for the online and the target net at once.  The overlap is inside the launch,
