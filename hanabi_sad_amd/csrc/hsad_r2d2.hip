@@ -881,11 +881,15 @@ struct LstmSeqArgsN {
   int nrec, nrb, nunit;
   u64_t* group_words;   // [nrec * nrb], zeroed before launch
   int force_cross_xcd;  // testing: use the cross-XCD protocol even for co-located groups
+  unsigned* zero_ptr;   // optional: the NEXT launch's sync scratch, zeroed by this launch (saves a memset per launch)
+  int zero_words;
 };
 
 // linear block id L -> XCD x = L % 8 (observed dispatch order), slot s = L / 8; group G = x + 8 * (s / nunit) is the
 // (recurrence, row block) pair whose nunit unit-block workgroups all land on XCD x
 #define HSAD_SEQ_PLACE(m)                                         \
+  if (blockIdx.x == 0 && (m).zero_ptr)                            \
+    for (int i_ = threadIdx.x; i_ < (m).zero_words; i_ += 256) (m).zero_ptr[i_] = 0u; \
   const int L_ = blockIdx.x, s_ = L_ >> 3;                        \
   const int p_ = s_ / (m).nunit, nb_ = s_ - p_ * (m).nunit;       \
   const int G_ = (L_ & 7) + 8 * p_;                               \
@@ -1137,6 +1141,8 @@ struct LstmSeqBwdArgsN {
   int nrec, nrb, nunit;
   u64_t* group_words;
   int force_cross_xcd;
+  unsigned* zero_ptr;
+  int zero_words;
 };
 
 template <int KB>
@@ -1571,13 +1577,16 @@ __global__ void zero_rows_kernel(float* __restrict__ x, const unsigned char* __r
 static inline size_t seq_sync_words(int nrec, int T, int nrb) { return (size_t)nrec * nrb * (T + 2); }
 static int g_force_cross_xcd = 0;   // hsad_lstm_set_exchange_mode
 
-static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s) {
+static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s, unsigned* next = nullptr,
+                          int next_words = 0) {
   const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
   m.nrec = nrec;
   m.nrb = nrb;
   m.nunit = H / 32;
   m.group_words = reinterpret_cast<u64_t*>(sync);
   m.force_cross_xcd = g_force_cross_xcd;
+  m.zero_ptr = next;
+  m.zero_words = next_words;
   const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1590,13 +1599,16 @@ static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sy
   return HSAD_OK;
 }
 
-static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s) {
+static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s, unsigned* next = nullptr,
+                          int next_words = 0) {
   const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
   m.nrec = nrec;
   m.nrb = nrb;
   m.nunit = H / 32;
   m.group_words = reinterpret_cast<u64_t*>(sync);
   m.force_cross_xcd = g_force_cross_xcd;
+  m.zero_ptr = next;
+  m.zero_words = next_words;
   const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1996,14 +2008,16 @@ int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_
 // recurrences over a chunk of Tc steps each, with the recurrent state carried across launches (h as bf16 [Bn,H] = the
 // previous chunk's last hseq row, c as fp32 = its last cseq row).  sync_scratch: uint32 [nrec*Tc*ceil(Bn/32) + 4].
 int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_fwd_rec* recs, void* sync_scratch,
-                                  void* stream) {
+                                  void* next_sync_scratch, void* stream) {
   if (nrec < 1 || nrec > 4 || !recs || !sync_scratch || Tc < 1) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: bad arguments");
   if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_forward_chunk_multi: needs H in {256,512}, Bn <= 512");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32;
   unsigned* sync = (unsigned*)sync_scratch;
   unsigned* counters = sync + 2 * nrec * nrb;
-  HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
+  // ping-pong scratch: with a partner buffer the caller guarantees `sync_scratch` is zero (fresh, or zeroed by the previous
+  // launch of the pair) and this launch zeroes the partner -- no memset kernel between the stages of the pipeline
+  if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
   LstmSeqArgsN m{};
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fwd_rec& r = recs[i];
@@ -2023,27 +2037,27 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
     q.Bn = Bn;
     q.H = H;
   }
-  return launch_seq_fwd(m, nrec, H, nrb, sync, s);
+  return launch_seq_fwd(m, nrec, H, nrb, sync, s, (unsigned*)next_sync_scratch, (int)seq_sync_words(nrec, Tc, nrb));
 }
 
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
                             const float* c_prev, void* hseq16, float* cseq, float* hT, void* sync_scratch, void* stream) {
   hsad_lstm_fwd_rec r{gates, Whh_blocked, h_prev16, c_prev, hseq16, cseq, hT, nullptr};
-  return hsad_lstm_forward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
+  return hsad_lstm_forward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, nullptr, stream);
 }
 
 // All sequence pointers address the chunk's first step; dG16 slot Tc must hold the gradient of the following chunk's
 // first step when has_next != 0 (it is zeroed otherwise); c_before = c of the step preceding the chunk (NULL = zeros);
 // dc_io carries dc across chunks (zero it before the last-in-time chunk).
 int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
-                                   void* stream) {
+                                   void* next_sync_scratch, void* stream) {
   if (nrec < 1 || nrec > 2 || !recs || !sync_scratch || Tc < 1) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: bad arguments");
   if (!((H == 256 || H == 512) && Bn >= 1 && Bn <= 512)) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: needs H in {256,512}, Bn <= 512");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32;
   unsigned* sync = (unsigned*)sync_scratch;
   unsigned* counters = sync + 2 * nrec * nrb;
-  HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
+  if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * seq_sync_words(nrec, Tc, nrb), s));
   LstmSeqBwdArgsN m{};
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_bwd_rec& r = recs[i];
@@ -2053,14 +2067,14 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
     m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
                             counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg};
   }
-  return launch_seq_bwd(m, nrec, H, nrb, sync, s);
+  return launch_seq_bwd(m, nrec, H, nrb, sync, s, (unsigned*)next_sync_scratch, (int)seq_sync_words(nrec, Tc, nrb));
 }
 
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream) {
   hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr};
-  return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, stream);
+  return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, nullptr, stream);
 }
 
 }  // extern "C"

@@ -65,12 +65,25 @@ def sync_scratch(device, T, Bn, tag="fwd", nrec=1):
     the CURRENT stream (one block per stream: launches on one stream are ordered, concurrent streams must not share
     counters).  The word after the counters is the sticky timeout flag."""
     n = int(nrec) * ((int(Bn) + 31) // 32) * (int(T) + 2)   # placement words + step counters (include/hsad.h)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, n)
+    # keyed by the full launch shape: ping-pong pairs (sync_scratch_pair) must never share a block with another shape
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, n, int(nrec), int(T), int(Bn))
     buf = _SYNC.get(key)
     if buf is None:
         buf = torch.zeros(n + 4, dtype=torch.int32, device=device)
         _SYNC[key] = buf
     return buf
+
+
+_PAIR = {}
+
+
+def sync_scratch_pair(device, T, Bn, tag, nrec):
+    """(current, partner) counter blocks for a ping-pong sequence of persistent launches: the launch that uses `current`
+    zeroes `partner`, which the next launch with the same key then uses"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, int(nrec), int(T), int(Bn))
+    flip = _PAIR.get(key, 0)
+    _PAIR[key] = flip ^ 1
+    return (sync_scratch(device, T, Bn, tag + "/%d" % flip, nrec), sync_scratch(device, T, Bn, tag + "/%d" % (flip ^ 1), nrec))
 
 
 def check_sync():
@@ -152,8 +165,8 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
         for i in range(0, len(recs), per_launch):
             part = recs[i:i + per_launch]
             arr = (_lib.LstmFwdRec * len(part))(*part)
-            _lib.check(lib.hsad_lstm_forward_chunk_multi(len(part), Tc, N, H, arr,
-                                                         sync_scratch(d, Tc, N, "fwdm", len(part)).data_ptr(), _s(d)))
+            cur, nxt = sync_scratch_pair(d, Tc, N, "fwdm", len(part))
+            _lib.check(lib.hsad_lstm_forward_chunk_multi(len(part), Tc, N, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d)))
     out = []
     for q, keep in zip(st, keeps):
         if keep is not None:
@@ -640,8 +653,8 @@ class R2D2Learner:
             for i in range(0, len(recs), per_launch):
                 part = recs[i:i + per_launch]
                 arr = (_lib.LstmBwdRec * len(part))(*part)
-                _lib.check(lib.hsad_lstm_backward_chunk_multi(len(part), Tc, B, H, arr,
-                                                              sync_scratch(d, Tc, B, "bwdm", len(part)).data_ptr(), _s(d)))
+                cur, nxt = sync_scratch_pair(d, Tc, B, "bwdm", len(part))
+                _lib.check(lib.hsad_lstm_backward_chunk_multi(len(part), Tc, B, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d)))
             if s_ == nch - 1:
                 e1 = torch.cuda.Event()
                 e1.record(main)                           # layer 1 complete

@@ -364,11 +364,14 @@ typedef struct hsad_lstm_bwd_rec {
  * co-resident workgroups (one per CU).  sync_scratch: uint32 [nrec*(Tc+2)*ceil(Bn/32) + 4]: one 64-bit XCD-placement word
  * per (recurrence, row block), the step counters, then the sticky timeout word.  Workgroups that exchange tiles are
  * mapped to block ids that share an XCD; a start-up handshake verifies it and only then uses the L2-local hand-off
- * (plain stores + L2 atomics), otherwise the cross-XCD protocol (write-through stores + device-scope atomics). */
+ * (plain stores + L2 atomics), otherwise the cross-XCD protocol (write-through stores + device-scope atomics).
+ * next_sync_scratch (may be NULL): ping-pong partner of the same size -- when given, sync_scratch must already be zero
+ * (freshly zero-allocated, or zeroed by the previous launch of the pair) and this launch zeroes the partner instead of a
+ * memset kernel in front of every launch. */
 int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_fwd_rec* recs, void* sync_scratch,
-                                  void* stream);
+                                  void* next_sync_scratch, void* stream);
 int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
-                                   void* stream);
+                                   void* next_sync_scratch, void* stream);
 /* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
  * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,

@@ -45,7 +45,7 @@ names = ["wait", "h loads", "mfma", "cell", "publish", "state stores", "", "", "
 print("  fwd per step (us):", ", ".join("%s %.2f" % (names[i], buf[i] / 100.0 / 640) for i in range(6)), " sum %.2f" % (sum(buf[:6]) / 100.0 / 640))
 print("  bwd per step (us):", ", ".join("%s %.2f" % (names[i], buf[i] / 100.0 / 320) for i in range(8, 12)), " sum %.2f" % (sum(buf[8:12]) / 100.0 / 320))
 for k, b in _SYNC.items():   # XCD placement words of the last launch on each buffer: how many groups were co-located?
-    if not k[2].endswith("m"): continue
+    if "m/" not in k[2]: continue
     words = b[:64].cpu().numpy().view("uint64")
     groups = [[int((w >> (6 * i)) & 63) for i in range(8)] for w in words[:16] if w]
     print("  %s: %d/%d groups on one XCD" % (k[2], sum(max(g) == sum(g) for g in groups), len(groups)), groups[:2])
