@@ -159,7 +159,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learner", action="store_true", help="skip the R2D2 learner samples/sec measurement")
     ap.add_argument("--kernel-samples", type=int, default=50)
-    ap.add_argument("--partitions", type=int, default=1, help="stream partitions for the rollout (hsad_env_set_partitions)")
+    ap.add_argument("--partitions", type=int, default=3,
+                    help="independent game ranges the rollout runs on private HIP streams (hsad_env_set_partitions); results "
+                         "are bit-identical for any value")
+    ap.add_argument("--lock-us", type=int, default=30,
+                    help="phase lock between the partition chains (hsad_env_set_rollout_stagger): partition k starts each "
+                         "launch this long after partition k-1, so one partition's logic phase overlaps the others' HBM stream")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -182,6 +187,7 @@ def main():
     env = BatchedHanabiEnv(G, players=PLAYERS, hand_size=HAND, seed=shard_seed(1, begin), eps_list=EPS, max_len=80,
                            sad=False, device=dev, track_deck_history=False)
     env.set_partitions(args.partitions)
+    env.set_rollout_stagger(args.lock_us if args.partitions > 1 else 0)
     policy_seed = 12345 + rank
 
     def barrier():
@@ -192,8 +198,9 @@ def main():
 
     env.rollout_random(args.warmup, policy_seed)
     barrier()
-    # the timed region launches ONE fused kernel per iteration (env_kernel<3,P,H>: reset-terminated + random-legal policy
-    # + step + observe); HIP events on the launch stream give its average duration over exactly this region
+    # the timed region launches the fused kernel (env_kernel<3,P,H>: reset-terminated + random-legal policy + step +
+    # observe) once per iteration and partition; HIP events on the launch stream(s) give its average duration over exactly
+    # this region
     k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     k0.record()
@@ -201,7 +208,10 @@ def main():
     k1.record()
     barrier()
     elapsed = time.perf_counter() - t0
-    fused_ms = k0.elapsed_time(k1) / args.steps
+    iter_ms = k0.elapsed_time(k1) / args.steps                      # all partitions of one iteration (they overlap)
+    K = max(1, args.partitions)
+    part_ms = env.last_rollout_ms() if K > 1 else [iter_ms]         # events on the partition streams themselves
+    fused_ms = sum(part_ms) / len(part_ms)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -222,7 +232,8 @@ def main():
     step_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
     bytes_per_step = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, False)
     achieved_step = bytes_per_step * G / (step_ms * 1e-3) / 1e9
-    achieved = bytes_per_step * G / (fused_ms * 1e-3) / 1e9
+    achieved = bytes_per_step * G / (iter_ms * 1e-3) / 1e9        # all concurrent launches together = the chip's rate
+    per_launch = bytes_per_step * (G / K) / (fused_ms * 1e-3) / 1e9
 
     if rank == 0:
         out = {
@@ -239,18 +250,24 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1]: %d concurrent 2-player Hanabi games per GPU, random-legal policy, one "
-                            "fused reset-terminated + policy + step + observe kernel per iteration, fp32 obs [G,2,783] "
-                            "written to HBM" % G,
+                "workload": "BASELINE configs[1]: %d concurrent 2-player Hanabi games per GPU, random-legal policy, fused "
+                            "reset-terminated + policy + step + observe kernel, %d phase-locked stream partition(s) per "
+                            "iteration, fp32 obs [G,2,783] written to HBM" % (G, K),
+                "partitions": K, "phase_lock_us": args.lock_us if K > 1 else 0,
                 "games_per_gpu": G, "players": PLAYERS, "hand_size": HAND, "feature_size": env.F,
                 "num_action": env.A, "max_len": 80, "sharding": "games sharded across ranks, no collective",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "env_kernel<3,2,5> (fused reset-terminated + policy + step + observe; the only "
-                                          "kernel in the timed region, one launch per iteration)",
+                "bound": "hbm",
+                "kernel": "env_kernel<3,2,5> (fused reset-terminated + policy + step + observe; the only kernel in the timed "
+                          "region: %d launch(es) per iteration on %d stream partition(s), overlapping in time)" % (K, K),
+                # achieved = algorithmic bytes of the K concurrent launches of an iteration / the iteration's duration (HIP
+                # events on the caller's stream, fork/join included); per_launch_* = one launch against its own duration
+                # (HIP events on its partition stream) -- the number rocprofv3's AverageNs for this kernel must agree with
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic_bytes(G, 3), "algorithmic_bytes_per_env_step": bytes_per_step,
-                "algorithmic_bytes_per_launch": bytes_per_step * G, "avg_launch_ms": fused_ms,
+                "algorithmic_bytes_per_launch": bytes_per_step * G / K, "avg_launch_ms": fused_ms,
+                "launches_per_iteration": K, "iteration_ms": iter_ms, "per_launch_achieved": per_launch,
             },
             "roofline_step_kernel": {
                 "bound": "hbm", "kernel": "env_kernel<1,2,5> (HanabiEnv::step + observe with actions from HBM, the "

@@ -82,6 +82,12 @@ struct EnvParams {
   float* reward;
   uint8_t* terminal;
   unsigned long long* dbg;  // optional per-wave phase timestamps [grid][8] (hsad_env_debug_timing)
+  // phase lock of stream partitions (hsad_env_rollout_random with K > 1): partition p > 0 starts its launch `lock_ticks`
+  // (10 ns units) after partition p-1 started the launch with the same tag, so that one partition's latency-bound logic
+  // phase keeps overlapping the other's HBM stream.  Timing only: a bounded wait, results never depend on it.
+  unsigned long long* phase;  // [16][2]: {tag, wall_clock64 at launch start} per partition, or NULL
+  int part, n_part, lock_ticks;
+  unsigned long long launch_tag, first_tag;   // first_tag: tag of the first iteration of this rollout call
 };
 
 constexpr uint32_t kIdentityPerm = (0u) | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12);
@@ -801,6 +807,31 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   const int ng = min(kWave, ep.G - g0);
   const int P = TP ? TP : ep.P, H = TH ? TH : ep.H;
 
+  if (MODE == 3 && ep.phase) {
+    if (blockIdx.x == 0 && tid == 0) {   // announce this launch (time first, then the tag that validates it)
+      __hip_atomic_store(ep.phase + 2 * ep.part + 1, (unsigned long long)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ep.phase + 2 * ep.part, ep.launch_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ep.n_part > 1 && ep.lock_ticks > 0 && lane == 0) {
+      // ring order A(i), B(i), ..., A(i+1): wait for the predecessor's launch (same iteration, or the previous one for
+      // partition 0) to have STARTED lock_ticks ago.  If the predecessor is already further along, or silent for 200 us,
+      // just go: the lock is an optimisation, never a dependency.
+      const int pred = (ep.part + ep.n_part - 1) % ep.n_part;
+      const unsigned long long want = ep.part > 0 ? ep.launch_tag : ep.launch_tag - 1ull;
+      const unsigned long long t_in = wall_clock64();
+      while (want >= ep.first_tag && wall_clock64() - t_in < 20000ull) {
+        const unsigned long long tg = __hip_atomic_load(ep.phase + 2 * pred, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tg > want) break;                        // predecessor already ahead: nothing to align with
+        if (tg == want) {
+          const unsigned long long ref = __hip_atomic_load(ep.phase + 2 * pred + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while ((long long)(wall_clock64() - ref) < (long long)ep.lock_ticks && wall_clock64() - t_in < 20000ull)
+            __builtin_amdgcn_s_sleep(8);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+  }
   STAMP(0);
   const uint32_t misc0 = ep.planes[(size_t)PL_MISC * ep.Gpad + g];
   bool active;
@@ -1318,12 +1349,6 @@ __global__ void export_state_kernel(EnvParams ep, int32_t* __restrict__ out, int
   }
 }
 
-// busy-wait of `ticks` x 10 ns (constant 100 MHz wall clock) used to offset partition chains
-__global__ void delay_kernel(long long ticks) {
-  const unsigned long long t0 = wall_clock64();
-  while ((long long)(wall_clock64() - t0) < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
 // ---- host side ---------------------------------------------------------------------------------
 thread_local std::string g_last_error;
 
@@ -1355,11 +1380,15 @@ struct hsad_env {
   int device;
   // rollout partitions: independent game ranges on private streams so that one partition's
   // latency-bound phases overlap another partition's HBM-bound observation streaming
-  long long stagger_ns;  // initial offset between consecutive partition chains
+  long long stagger_ns;  // offset kept between consecutive partition chains (phase lock)
+  unsigned long long* d_phase;     // [16][2] device words of the phase lock
+  unsigned long long launch_seq;   // tag of the next locked launch
   int n_part;         // streams created so far
   int n_part_active;  // partitions used by hsad_env_rollout_random (1 = caller's stream only)
   hipStream_t part_stream[16];
   hipEvent_t part_done[16];
+  hipEvent_t part_begin[16];   // timing-enabled pair with part_done: per-partition chain time of the last rollout
+  int last_rollout_iters, last_rollout_parts;
   hipEvent_t fork;
 };
 
@@ -1402,9 +1431,16 @@ int configure_env_kernels(hsad_env* e) {
 
 // launch one env kernel over games [g_begin, g_begin + g_count) (g_begin multiple of 64)
 void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipStream_t stream, int g_begin,
-                int g_count, uint64_t policy_seed = 0, int64_t* a_out = nullptr, int64_t* g_out = nullptr) {
+                int g_count, uint64_t policy_seed = 0, int64_t* a_out = nullptr, int64_t* g_out = nullptr, int part = -1,
+                unsigned long long tag = 0, unsigned long long first_tag = 0, int n_part = 1) {
   const size_t lds = (mode == 1 || mode == 2) ? e->lds_bytes : e->lds_bytes_reset;
   EnvParams ep = e->ep;
+  ep.phase = part >= 0 ? e->d_phase : nullptr;
+  ep.part = part < 0 ? 0 : part;
+  ep.lock_ticks = (int)(e->stagger_ns / 10);
+  ep.launch_tag = tag;
+  ep.first_tag = first_tag;
+  ep.n_part = n_part;
   ep.g_begin = g_begin;
   ep.g_count = g_count;
   ep.policy_seed = policy_seed;
@@ -1484,6 +1520,10 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   e->bound = false;
   e->n_part = 0;
   e->stagger_ns = 0;
+  e->d_phase = nullptr;
+  e->launch_seq = 0;
+  e->last_rollout_iters = 0;
+  e->last_rollout_parts = 0;
   e->n_part_active = 1;
   e->fork = nullptr;
   if (e->lds_bytes_reset > 160 * 1024) {
@@ -1531,6 +1571,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
 void hsad_env_destroy(hsad_env* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  if (e->d_phase) (void)hipFree(e->d_phase);
   if (e->ep.planes) (void)hipFree(e->ep.planes);
   if (e->ep.mt) (void)hipFree(e->ep.mt);
   if (e->ep.deck_hist) (void)hipFree(e->ep.deck_hist);
@@ -1541,6 +1582,7 @@ void hsad_env_destroy(hsad_env* e) {
   for (int k = 0; k < e->n_part; ++k) {
     (void)hipStreamDestroy(e->part_stream[k]);
     (void)hipEventDestroy(e->part_done[k]);
+    (void)hipEventDestroy(e->part_begin[k]);
   }
   if (e->fork) (void)hipEventDestroy(e->fork);
   delete e;
@@ -1610,7 +1652,8 @@ int hsad_env_set_partitions(hsad_env* e, int n_part) {
   HIP_TRY(hipSetDevice(e->device));
   for (int k = e->n_part; k < n_part; ++k) {
     HIP_TRY(hipStreamCreateWithFlags(&e->part_stream[k], hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&e->part_done[k], hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&e->part_done[k]));
+    HIP_TRY(hipEventCreate(&e->part_begin[k]));
   }
   if (!e->fork) HIP_TRY(hipEventCreateWithFlags(&e->fork, hipEventDisableTiming));
   if (n_part > e->n_part) e->n_part = n_part;
@@ -1634,16 +1677,26 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
   }
   // fork: every partition stream waits for the work already queued on the caller's stream
   HIP_TRY(hipEventRecord(e->fork, (hipStream_t)stream));
-  for (int k = 0; k < K; ++k) HIP_TRY(hipStreamWaitEvent(e->part_stream[k], e->fork, 0));
-  // stagger the chains so that one partition's latency-bound logic overlaps another's HBM streaming
-  if (e->stagger_ns > 0)
-    for (int k = 1; k < K; ++k)
-      hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, e->part_stream[k], (long long)e->stagger_ns * k / 10);
+  for (int k = 0; k < K; ++k) {
+    HIP_TRY(hipStreamWaitEvent(e->part_stream[k], e->fork, 0));
+    HIP_TRY(hipEventRecord(e->part_begin[k], e->part_stream[k]));
+  }
+  e->last_rollout_iters = n_iter;
+  e->last_rollout_parts = K;
+  // the chains are phase-locked in the kernel (EnvParams::phase): partition k starts each launch stagger_ns after
+  // partition k-1 started the launch of the same iteration
+  if (!e->d_phase) {
+    HIP_TRY(hipMalloc((void**)&e->d_phase, sizeof(unsigned long long) * 32));
+    HIP_TRY(hipMemset(e->d_phase, 0, sizeof(unsigned long long) * 32));
+  }
+  const unsigned long long first_tag = e->launch_seq + 1;
   for (int i = 0; i < n_iter; ++i) {
+    const unsigned long long tag = ++e->launch_seq;
     for (int k = 0; k < K; ++k) {
       const int b0 = (int)((long long)blocks * k / K), b1 = (int)((long long)blocks * (k + 1) / K);
       if (b1 <= b0) continue;
-      launch_env(e, 3, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a);
+      launch_env(e, 3, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a, k, tag,
+                 first_tag, K);
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1651,6 +1704,20 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
   for (int k = 0; k < K; ++k) {
     HIP_TRY(hipEventRecord(e->part_done[k], e->part_stream[k]));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, e->part_done[k], 0));
+  }
+  return HSAD_OK;
+}
+
+int hsad_env_last_rollout_ms(hsad_env* e, float* ms_per_launch, int* n_part) {
+  if (!e || !ms_per_launch) return set_error(HSAD_ERR_INVALID, "null argument");
+  const int K = e->last_rollout_parts;
+  if (n_part) *n_part = K;
+  if (K < 2 || e->last_rollout_iters < 1) return set_error(HSAD_ERR_STATE, "no partitioned rollout has run");
+  for (int k = 0; k < K; ++k) {
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(e->part_done[k]));
+    HIP_TRY(hipEventElapsedTime(&ms, e->part_begin[k], e->part_done[k]));
+    ms_per_launch[k] = ms / (float)e->last_rollout_iters;
   }
   return HSAD_OK;
 }

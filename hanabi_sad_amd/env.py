@@ -98,7 +98,15 @@ class BatchedHanabiEnv:
         _lib.check(self.lib.hsad_env_set_partitions(self.h, int(n_part)))
 
     def set_rollout_stagger(self, microseconds):
+        """phase lock between the partition chains (see include/hsad.h); timing only"""
         _lib.check(self.lib.hsad_env_set_rollout_stagger(self.h, int(microseconds)))
+
+    def last_rollout_ms(self):
+        """average launch duration (ms) on each partition stream of the last partitioned rollout_random"""
+        import ctypes as C
+        ms, n = (C.c_float * 16)(), C.c_int(0)
+        _lib.check(self.lib.hsad_env_last_rollout_ms(self.h, ms, C.byref(n)))
+        return [float(ms[k]) for k in range(n.value)]
 
     def query(self):
         out = torch.zeros(self.G, 16, dtype=torch.int32, device=self.device)

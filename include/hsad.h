@@ -108,8 +108,14 @@ int hsad_env_rollout_random(hsad_env* env, int n_iter, uint64_t policy_seed, int
  * independent).  Default 1 = everything on the caller's stream. */
 int hsad_env_set_partitions(hsad_env* env, int n_part);
 
-/* initial offset (microseconds) between consecutive partition chains of hsad_env_rollout_random */
+/* Phase lock of the partition chains of hsad_env_rollout_random: partition k starts each launch `microseconds` after
+ * partition k-1 started the launch of the same iteration (bounded in-kernel wait on a device timestamp), so that one
+ * partition's latency-bound logic phase keeps overlapping another's HBM stream.  Timing only -- results are identical
+ * for any value; 0 lets the chains drift. */
 int hsad_env_set_rollout_stagger(hsad_env* env, int microseconds);
+/* average launch duration (ms) on each partition stream of the last partitioned hsad_env_rollout_random (HIP events on
+ * the streams the kernels were launched on; synchronises those events); ms_per_launch [n_part <= 16] */
+int hsad_env_last_rollout_ms(hsad_env* env, float* ms_per_launch, int* n_part);
 
 /* Per-game scalars, device int32 [G, HSAD_QUERY_WORDS]:
  * terminated(), getCurrentPlayer(), getScore(), getLife(), getInfo(), lastScore(), numStep,

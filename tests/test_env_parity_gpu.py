@@ -125,14 +125,16 @@ def test_illegal_move_is_reported_not_applied():
         dev2.check_errors()
 
 
-@pytest.mark.parametrize("parts", [1, 3, 8])
-def test_rollout_random_matches_oracle(parts):
-    """hsad_env_rollout_random (fused policy, optional multi-stream partitions) == oracle thread-loop."""
+@pytest.mark.parametrize("parts,lock_us", [(1, 0), (3, 0), (3, 30), (2, 45), (8, 0), (8, 5)])
+def test_rollout_random_matches_oracle(parts, lock_us):
+    """hsad_env_rollout_random (fused policy, optional multi-stream partitions, optional phase lock between the partition
+    chains -- timing only) == oracle thread-loop."""
     from hanabi_sad_amd import BatchedHanabiEnv
     from oracle.oracle import OracleVecEnv
     G, iters, seed, pseed = 64 * 9 + 5, 60, 4242, 11
     dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, sad=True, shuffle_color=True, device="cuda:0")
     dev.set_partitions(parts)
+    dev.set_rollout_stagger(lock_us)
     ref = OracleVecEnv(G, seed, players=2, hand_size=5, eps_list=EPS, sad=True, shuffle_color=True, max_len=80)
     for chunk in range(3):
         dev.rollout_random(iters // 3, pseed)
@@ -145,6 +147,9 @@ def test_rollout_random_matches_oracle(parts):
         _cmp("eps", dev.eps, ref.eps, chunk)
         _cmp("reward", dev.reward, ref.reward, chunk)
         _cmp("terminal", dev.terminal, ref.terminal, chunk)
+    if parts > 1:
+        ms = dev.last_rollout_ms()
+        assert len(ms) == parts and all(m > 0 for m in ms)
         _cmp("a", dev.a, ref.a, chunk)
         _cmp("greedy_a", dev.greedy_a, ref.g, chunk)
     r_state = np.stack([e.export_state() for e in ref.envs])

@@ -8,9 +8,9 @@ from hanabi_sad_amd import BatchedHanabiEnv
 G = 65536
 EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
 env = BatchedHanabiEnv(G, seed=1, eps_list=EPS, device="cuda:0", track_deck_history=False)
-env.rollout_random(20, 5)
-torch.cuda.synchronize()
-env.rollout_random(10, 5)   # the fused kernel (env_kernel<3,...>) the benchmark's timed region launches
+env.set_partitions(3); env.set_rollout_stagger(30)   # as bench.py launches it: every env_kernel<3,...> dispatch covers G/3 games
+env.rollout_random(30, 5)   # the fused kernel the benchmark's timed region launches
+env.set_partitions(1)
 torch.cuda.synchronize()
 for _ in range(10):
     env.reset(); a, g = env.policy_random(5); env.step(a, g)
