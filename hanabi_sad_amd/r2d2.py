@@ -361,7 +361,9 @@ def colsum(x, out=None, ncols=None):
 
 
 class R2D2Learner:
-    """IQL learner step of selfplay.py:208-244 on the HIP kernels: loss(), backward(), Adam step, target sync."""
+    """Learner step of selfplay.py:208-244 on the HIP kernels: loss() (forward of online + target net, n-step double-DQN
+    TD error, Huber loss, priorities, optional aux task, full BPTT into the flat gradient), optimizer_step() (global-norm
+    clip + Adam), sync_target_with_online().  IQL batches [T,B,*] and VDN batches [T,B,P,*] (Q summed over players)."""
 
     def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0,
                  device="cuda:0"):
@@ -440,8 +442,6 @@ class R2D2Learner:
         T, B, _ = priv.shape        # B = rows per step (games x players for VDN)
         M, H, A = T * B, on.H, on.A
         keep = {}
-        # the target trunk does not depend on the online net: run it on a side stream (the persistent LSTM kernels
-        # occupy 64 CUs each, so both nets' recurrences overlap); join before the target q-head needs `greedy`
         main = torch.cuda.current_stream(d)
         nch = self._nchunks(T, B)
         if nch > 1:
