@@ -10,12 +10,20 @@ from .env import BatchedHanabiEnv
 
 class HanabiEnv:
     def __init__(self, params, eps_list, max_len, sad, shuffle_obs, shuffle_color, verbose, device="cuda:0"):
-        self.impl = BatchedHanabiEnv(1, players=int(params["players"]), hand_size=int(params.get("hand_size", 5)),
-                                     seed=int(params.get("seed", 1)), bomb=int(params.get("bomb", 0)),
-                                     eps_list=list(eps_list), max_len=max_len, sad=sad, shuffle_obs=shuffle_obs,
-                                     shuffle_color=shuffle_color, device=device)
+        self.cfg = dict(players=int(params["players"]), hand_size=int(params.get("hand_size", 5)),
+                        seed=int(params.get("seed", 1)), bomb=int(params.get("bomb", 0)), eps_list=tuple(eps_list),
+                        max_len=int(max_len), sad=bool(sad), shuffle_obs=bool(shuffle_obs), shuffle_color=bool(shuffle_color))
+        self.device = device
+        self._impl = None      # a 1-game device env, created on first standalone use
+        self._vec = None       # (HanabiVecEnv, index) once appended to a vector env: the game then lives in ITS batch
         if verbose:
             print("Hanabi game created, with parameters:", dict(params))
+
+    @property
+    def impl(self):
+        if self._impl is None:
+            self._impl = BatchedHanabiEnv(1, device=self.device, **self.cfg)
+        return self._impl
 
     def feature_size(self):
         return self.impl.feature_size()
@@ -44,8 +52,15 @@ class HanabiEnv:
         self.impl.check_errors()
         return self._obs(), float(self.impl.reward[0]), bool(self.impl.terminal[0])
 
+    def _src(self):
+        """(device env, row) holding this game: its vector env's batch once that exists, else the private 1-game env"""
+        if self._vec is not None and self._vec[0].impl is not None:
+            return self._vec[0].impl, self._vec[1]
+        return self.impl, 0
+
     def _q(self, i):
-        return int(self.impl.query()[0, i])
+        env, r = self._src()
+        return int(env.query()[r, i])
 
     def terminated(self):
         return bool(self._q(0))
@@ -66,12 +81,106 @@ class HanabiEnv:
         return self._q(5)
 
     def get_fireworks(self):
-        return [int(x) for x in self.impl.query()[0, 8:13]]
+        env, r = self._src()
+        return [int(x) for x in env.query()[r, 8:13]]
 
     def move_is_legal(self, uid):
-        return bool(self.impl.move_is_legal(torch.tensor([uid]))[0])
+        env, r = self._src()
+        return bool(env.move_is_legal(torch.full((env.G,), int(uid)))[r])
 
     def deck_history(self):
         """dealt cards of the episode as strings like "R1" (colour letter + rank), cpp/hanabi_env.h:112-114"""
         cards, n = self.impl.deck_history()
         return ["RYGWB"[int(c) // 5] + str(int(c) % 5 + 1) for c in cards[0, :int(n[0])]]
+
+
+class HanabiVecEnv:
+    """hanalearn.HanabiVecEnv (cpp/pybind.cc:40-43, rela/env.h:29-108): `append(env)` collects per-game `HanabiEnv`s; the
+    games then live in ONE batched device env (created when a thread loop attaches).  The appended games must differ only in
+    their seed, and the seeds must be consecutive (what create.py:36-53 builds: seed + game_idx)."""
+
+    def __init__(self):
+        self.envs, self.impl = [], None
+
+    def append(self, env):
+        if self.impl is not None:
+            raise RuntimeError("HanabiVecEnv.append after the device env was built")
+        env._vec = (self, len(self.envs))
+        self.envs.append(env)
+
+    def size(self):
+        return len(self.envs)
+
+    def batched(self, device):
+        if self.impl is None:
+            if not self.envs:
+                raise RuntimeError("empty HanabiVecEnv")
+            c0 = self.envs[0].cfg
+            for i, e in enumerate(self.envs):
+                want = dict(c0, seed=c0["seed"] + i)
+                if e.cfg != want:
+                    raise ValueError("HanabiVecEnv: game %d differs from game 0 by more than seed = seed0 + index: %s vs %s"
+                                     % (i, e.cfg, want))
+            self.impl = BatchedHanabiEnv(len(self.envs), device=device, track_deck_history=False, **c0)
+        return self.impl
+
+
+class HanabiThreadLoop:
+    """hanalearn.HanabiThreadLoop(actor | [actor per player], vec_env, eval) (cpp/thread_loop.h:14-88).  There is no thread:
+    `step()` is one iteration of the loop body for all games of the vector env, driven by rela.Context.  Training mode =
+    actor.DeviceActor (IQL when given a list of per-player actors, VDN for a single actor with num_player = P); eval mode =
+    every player acts greedily until each game has finished once."""
+
+    def __init__(self, actors, vec_env, eval_mode):
+        from .actor import DeviceActor, transition_fields
+        from .r2d2 import R2D2Agent
+        self.actors = list(actors) if isinstance(actors, (list, tuple)) else [actors]
+        a0 = self.actors[0]
+        self.eval_mode = bool(eval_mode)
+        run = a0.runner
+        self.env = vec_env.batched(run.device)
+        self.vdn = not isinstance(actors, (list, tuple)) and a0.num_player > 1
+        if self.eval_mode:
+            self.agent = R2D2Agent(run.online, run.online, 1, 0.99)
+            self.hid = self.agent.get_h0(self.env.G * self.env.P)
+            self.env.reset()
+            self.done = False
+            self.impl = None
+        else:
+            self.agent = R2D2Agent(run.online, run.target, a0.multi_step, a0.gamma, seed=self.env.G)
+            fields = transition_fields(self.env, self.vdn)
+            replay = a0.replay.bind_schema(fields, a0.seq_len, run.device)
+            self.impl = DeviceActor(self.env, self.agent, replay, a0.multi_step, a0.gamma, a0.eta, a0.seq_len, vdn=self.vdn)
+
+    def step(self):
+        if not self.eval_mode:
+            before = self.impl.num_act
+            self.impl.step()
+            per_actor = (self.impl.num_act - before) // len(self.actors)   # R2D2Actor::numAct_ += num_envs per act()
+            for a in self.actors:
+                a._num_act += per_actor
+            return
+        if self.done:
+            return
+        env, N = self.env, self.env.G * self.env.P
+        done = env.query()[:, 0] == 1
+        if bool(done.all()):
+            self.done = True
+            return
+        obs = {"priv_s": env.priv_s.view(N, env.F), "legal_move": env.legal_move.view(N, env.A),
+               "eps": torch.zeros(N, device=env.device)}
+        reply, self.hid = self.agent.act(obs, self.hid)
+        a = reply["greedy_a"].view(env.G, env.P)
+        a = torch.where(done.unsqueeze(1), torch.full_like(a, env.A - 1), a).contiguous()   # finished games: ignored noop
+        env.step(a, a)
+        if bool(done.any()):
+            import ctypes as C
+            n, g, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            env.lib.hsad_env_error_count(env.h, C.byref(n), C.byref(g), C.byref(c))   # drain the "finished game" notes
+
+    def finished(self):
+        return self.eval_mode and self.done
+
+    def scores(self):
+        """lastScore() of every game (eval.py:57-66)"""
+        return self.env.query()[:, 5].cpu().tolist()

@@ -2,9 +2,11 @@
 
 `RNNPrioritizedReplay(capacity, seed, alpha, beta, prefetch)` keeps the reference signature; the transition
 schema and sequence length are taken from the first `bind_schema()` / actor that attaches to it.  The thread
-machinery (`Context`, `ThreadLoop`, `BatchRunner`, `R2D2Actor`) has no counterpart by design: all games advance
-in lock-step on the GPU (hanabi_sad_amd.actor.DeviceActor), so `Context` only keeps the start/pause/terminate
-surface for drivers written against the reference."""
+machinery has no counterpart by design: all games advance in lock-step on the GPU (hanabi_sad_amd.actor.DeviceActor).
+`BatchRunner` / `R2D2Actor` keep the constructor signatures and carry configuration; `Context.start()` runs the attached
+`hanalearn.HanabiThreadLoop`s from ONE background Python thread (ctypes releases the GIL during launches), so a driver
+written against the reference -- create_envs / create_threads / ActGroup / context.start() / replay.sample() -- works
+unchanged; `Context.step()` is there for drivers that prefer to interleave rollout and learning themselves."""
 import torch
 
 from .replay import DeviceReplay, aggregate_priority as _aggregate_priority
@@ -64,34 +66,125 @@ def aggregate_priority(priority, seq_len, eta):
     return out if priority.device.type == "cuda" else out.cpu()
 
 
-class Context:
-    """rela.Context surface (rela/context.h:18-80) over lock-step actors: start/pause/resume/terminate flags
-    that a driver loop polls; there are no threads to manage."""
+class BatchRunner:
+    """rela.BatchRunner(py_model, device, max_batchsize, methods) (rela/batch_runner.h:17-130): holds the acting copy of the
+    agent.  `py_model` is anything with state_dict() carrying `online_net.*` / `target_net.*` (the reference R2D2Agent) or a
+    plain dict of such tensors.  There is nothing to batch across threads, so start()/stop() are no-ops."""
 
-    def __init__(self):
-        self.actors, self._started, self._paused, self._terminated = [], False, False, False
+    def __init__(self, py_model, device, max_batchsize=100, methods=None):
+        self.device = device
+        self.online = self.target = None
+        self.update_model(py_model)
 
-    def push_env_thread(self, actor):
-        self.actors.append(actor)
-        return len(self.actors)
+    @staticmethod
+    def _split(py_model):
+        sd = py_model.state_dict() if hasattr(py_model, "state_dict") else dict(py_model)
+        on = {k[len("online_net."):]: v for k, v in sd.items() if k.startswith("online_net.")}
+        tg = {k[len("target_net."):]: v for k, v in sd.items() if k.startswith("target_net.")}
+        if not on:
+            raise KeyError("BatchRunner: state_dict has no online_net.* entries")
+        return on, (tg or on)
+
+    def update_model(self, py_model):
+        """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
+        from .r2d2 import R2D2NetKernels
+        on, tg = self._split(py_model)
+        if self.online is None:
+            self.online, self.target = R2D2NetKernels(on, self.device), R2D2NetKernels(tg, self.device)
+            return
+        for net, sd in ((self.online, on), (self.target, tg)):
+            for k, v in sd.items():
+                net.w[k].copy_(v)
+            net.refresh()
 
     def start(self):
-        self._started = True
+        pass
+
+    def stop(self):
+        pass
+
+
+class R2D2Actor:
+    """rela.R2D2Actor(runner, multi_step, num_envs, gamma, eta, seq_len, num_player, replay) and the 2-argument eval form
+    R2D2Actor(runner, num_player) (rela/pybind.cc:72-84): configuration for hanalearn.HanabiThreadLoop."""
+
+    def __init__(self, runner, *args):
+        self.runner, self._num_act = runner, 0
+        if len(args) == 1:
+            self.num_player, self.replay = int(args[0]), None
+            self.multi_step = self.num_envs = self.gamma = self.eta = self.seq_len = None
+        elif len(args) == 7:
+            self.multi_step, self.num_envs, self.gamma, self.eta, self.seq_len, self.num_player, self.replay = args
+        else:
+            raise TypeError("R2D2Actor(runner, num_player) or R2D2Actor(runner, multi_step, num_envs, gamma, eta, seq_len, "
+                            "num_player, replay)")
+
+    def num_act(self):
+        return self._num_act
+
+
+class Context:
+    """rela.Context (rela/context.h:18-80): push_env_thread / start / pause / resume / terminate / terminated.
+    start() runs every attached loop from one background thread until terminate(); eval loops end by themselves, and
+    terminated() turns True once all attached loops have finished (what eval.py:47-51 polls)."""
+
+    def __init__(self):
+        self.loops, self._thread, self._paused, self._stop, self._error = [], None, False, False, None
+
+    def push_env_thread(self, loop):
+        self.loops.append(loop)
+        return len(self.loops)
+
+    def _run(self):
+        import time
+        try:
+            while not self._stop:
+                if self._paused:
+                    time.sleep(0.001)
+                    continue
+                busy = False
+                for lp in self.loops:
+                    if not (hasattr(lp, "finished") and lp.finished()):
+                        lp.step()
+                        busy = True
+                if not busy:
+                    break
+        except Exception as e:   # surfaced by the next Context call from the driver's thread
+            self._error = e
+
+    def _check(self):
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
+
+    def start(self):
+        import threading
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def step(self):
+        """advance every attached loop by one lock-step iteration from the caller's thread (alternative to start())"""
+        for lp in self.loops:
+            if not (hasattr(lp, "finished") and lp.finished()):
+                lp.step()
 
     def pause(self):
+        self._check()
         self._paused = True
 
     def resume(self):
+        self._check()
         self._paused = False
 
     def terminate(self):
-        self._terminated = True
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+        self._check()
 
     def terminated(self):
-        return self._terminated
-
-    def step(self):
-        """advance every attached actor by one lock-step iteration (what the reference's threads do on their own)"""
-        if self._started and not self._paused and not self._terminated:
-            for a in self.actors:
-                a.step()
+        self._check()
+        if self._thread is not None and not self._thread.is_alive():
+            return True
+        return self._stop or (bool(self.loops) and all(hasattr(lp, "finished") and lp.finished() for lp in self.loops))

@@ -1,0 +1,114 @@
+"""A driver written against the reference's `hanalearn` / `rela` names (the calls of pyhanabi/create.py:24-76,98-145,
+selfplay.py:152-245 and eval.py:25-66, in the same order) running on the device pipeline through the mirror modules."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+DEV = "cuda:0"
+
+
+class TinyAgent:
+    """stands in for the reference's torch R2D2Agent: all the mirrors need is state_dict() with online_net.* / target_net.*"""
+
+    def __init__(self, in_dim, hid, out_dim, hand, seed):
+        from hanabi_sad_amd.selfplay import init_weights
+        W = init_weights(in_dim, hid, out_dim, hand, seed)
+        self.sd = {"online_net." + k: v for k, v in W.items()}
+        self.sd.update({"target_net." + k: v.clone() for k, v in W.items()})
+
+    def state_dict(self):
+        return self.sd
+
+
+def create_envs(hanalearn, num_env, seed, num_player, hand_size, bomb, eps, max_len, sad):
+    games = []
+    for i in range(num_env):
+        params = {"players": str(num_player), "hand_size": str(hand_size), "seed": str(seed + i), "bomb": str(bomb)}
+        games.append(hanalearn.HanabiEnv(params, eps, max_len, sad, False, False, False))
+    return games
+
+
+@pytest.mark.parametrize("method", ["iql", "vdn"])
+def test_reference_shaped_training_driver(method):
+    from hanabi_sad_amd import hanalearn, rela
+    from hanabi_sad_amd.r2d2 import R2D2Learner
+    from hanabi_sad_amd.selfplay import generate_explore_eps
+    num_thread, per_thread, P, hand, n, gamma, eta, T, B = 2, 96, 2, 5, 3, 0.999, 0.9, 80, 32
+    eps = generate_explore_eps(0.1, 7, 80)
+    games = create_envs(hanalearn, num_thread * per_thread, 7, P, hand, 0, eps, T, True)
+    F, A = games[0].feature_size(), games[0].num_action()
+    assert (F, A) == (838, 21)
+    agent = TinyAgent(F, 256, A, hand, 3)
+    replay = rela.RNNPrioritizedReplay(4096, 1, 0.9, 0.6, 3)
+    runner = rela.BatchRunner(agent, DEV, 100, ["act", "compute_priority"])
+    runner.start()
+    context, threads, actors = rela.Context(), [], []
+    for t in range(num_thread):
+        if method == "vdn":
+            acts = rela.R2D2Actor(runner, n, per_thread, gamma, eta, T, P, replay)
+            actors.append(acts)
+        else:
+            acts = [rela.R2D2Actor(runner, n, per_thread, gamma, eta, T, 1, replay) for _ in range(P)]
+            actors.extend(acts)
+        env = hanalearn.HanabiVecEnv()
+        for g in range(per_thread):
+            env.append(games[t * per_thread + g])
+        th = hanalearn.HanabiThreadLoop(acts, env, False)
+        threads.append(th)
+        context.push_env_thread(th)
+    context.start()
+    t0 = time.time()
+    while replay.size() < 4 * B:                       # burn in (selfplay.py:182-186)
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    on = {k[len("online_net."):]: v for k, v in agent.state_dict().items() if k.startswith("online_net.")}
+    learner = R2D2Learner(on, on, n, gamma, device=DEV)
+    for it in range(4):                                 # train-loop body (selfplay.py:208-244)
+        batch, weight = replay.sample(B, DEV)
+        obs, act = batch.obs, batch.action
+        if method == "vdn":
+            v4 = lambda x: x.view(x.shape[0], x.shape[1], P, -1)
+            b = {"priv_s": v4(obs["priv_s"]), "legal_move": v4(obs["legal_move"]), "a": act["a"], "own_hand": v4(obs["own_hand"])}
+        else:
+            b = {"priv_s": obs["priv_s"], "legal_move": obs["legal_move"], "a": act["a"].squeeze(-1) if act["a"].dim() == 3 else act["a"],
+                 "own_hand": obs["own_hand"]}
+        b.update(reward=batch.reward, bootstrap=batch.bootstrap, seq_len=batch.seq_len)
+        loss, priority = learner.loss(b, weight, 0.0)
+        learner.optimizer_step()
+        replay.update_priority(rela.aggregate_priority(priority, batch.seq_len, eta))
+        assert torch.isfinite(loss).all()
+    context.pause()
+    n_act = sum(a.num_act() for a in actors)
+    assert n_act > 0 and replay.num_add() >= replay.size() > 0
+    context.terminate()
+    assert context.terminated()
+    for th in threads:
+        th.env.check_errors()
+
+
+def test_reference_shaped_eval_driver():
+    """eval.py:25-66: one game per env, greedy actors, poll context.terminated(), read game.last_score()"""
+    from hanabi_sad_amd import hanalearn, rela
+    num_game, P = 40, 2
+    games = create_envs(hanalearn, num_game, 11, P, 5, 0, [0.0], -1, True)
+    agent = TinyAgent(games[0].feature_size(), 256, games[0].num_action(), 5, 5)
+    runner = rela.BatchRunner(agent, DEV, 1000, ["act"])
+    runner.start()
+    context = rela.Context()
+    env = hanalearn.HanabiVecEnv()
+    for g in games:
+        env.append(g)
+    context.push_env_thread(hanalearn.HanabiThreadLoop([rela.R2D2Actor(runner, 1) for _ in range(P)], env, True))
+    context.start()
+    t0 = time.time()
+    while not context.terminated():
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    context.terminate()
+    runner.stop()
+    scores = [g.last_score() for g in games]
+    assert len(scores) == num_game and all(0 <= s <= 25 for s in scores)
+    assert all(g.terminated() for g in games)
