@@ -57,6 +57,22 @@ def test_host_mirror_fails_loudly_without_gpu():
         BatchedHanabiEnv(4, device="cpu")
     with pytest.raises((HsadError, RuntimeError, AssertionError)):
         BatchedHanabiEnv(4, device="cuda:0")
+    # the rela / hanalearn mirrors have no CPU path either: building the acting nets or a vector env must raise
+    from hanabi_sad_amd import hanalearn, rela
+    from hanabi_sad_amd.selfplay import init_weights
+    W = init_weights(838, 64, 21, 5, 0)
+    sd = {"online_net." + k: v for k, v in W.items()}
+    with pytest.raises((HsadError, RuntimeError, AssertionError)):
+        rela.BatchRunner(sd, "cpu", 100, ["act"])
+    env = hanalearn.HanabiVecEnv()
+    env.append(hanalearn.HanabiEnv({"players": "2", "seed": "1"}, [0.0], 80, True, False, False, False))
+    with pytest.raises((HsadError, RuntimeError, AssertionError)):
+        env.batched("cpu")
+    with pytest.raises(ValueError):   # games of one vector env must differ by consecutive seeds only
+        bad = hanalearn.HanabiVecEnv()
+        bad.append(hanalearn.HanabiEnv({"players": "2", "seed": "1"}, [0.0], 80, True, False, False, False))
+        bad.append(hanalearn.HanabiEnv({"players": "2", "seed": "5"}, [0.0], 80, True, False, False, False))
+        bad.batched("cuda:0")
 
 
 def test_product_package_never_imports_the_oracle():
