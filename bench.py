@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learner", action="store_true", help="skip the R2D2 learner samples/sec measurement")
     ap.add_argument("--kernel-samples", type=int, default=50)
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL, one GPU per rank; what the driver uses) | gloo (smoke-testing the multi-rank path with "
+                         "several ranks sharing one GPU)")
     ap.add_argument("--partitions", type=int, default=3,
                     help="independent game ranges the rollout runs on private HIP streams (hsad_env_set_partitions); results "
                          "are bit-identical for any value")
@@ -172,13 +175,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
+    local_dev = local_rank % max(1, torch.cuda.device_count()) if args.dist_backend != "nccl" else local_rank
+    torch.cuda.set_device(local_dev)
+    dev = "cuda:%d" % local_dev
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from hanabi_sad_amd import BatchedHanabiEnv
     from hanabi_sad_amd.dist import shard_range, shard_seed
@@ -213,7 +220,7 @@ def main():
     part_ms = env.last_rollout_ms() if K > 1 else [iter_ms]         # events on the partition streams themselves
     fused_ms = sum(part_ms) / len(part_ms)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     env.check_errors()
