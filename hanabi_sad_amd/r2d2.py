@@ -190,6 +190,10 @@ class R2D2NetKernels:
         self.A = self.w["fc_a.weight"].shape[0]
         self.NP = self.w["pred.weight"].shape[0]
         self.L = 2
+        extra = [k for k in self.w if k.startswith("lstm.") and k[-1] not in "01"] + [k for k in self.w if k.startswith("net.") and not k.startswith("net.0.")]
+        if extra:
+            raise _lib.HsadError("R2D2NetKernels supports the reference default shape only (1 fc layer, 2 LSTM layers); "
+                                 "unexpected parameters: %s" % extra)
         self.Fp = _pad32(self.F)
         self.perm = gate_block_perm(self.H, self.device)
         self.perm32 = self.perm.to(torch.int32).contiguous()
