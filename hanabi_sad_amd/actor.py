@@ -70,6 +70,6 @@ class DeviceActor:
         cur_obs = {"priv_s": cur["priv_s"].view(N, F), "legal_move": cur["legal_move"].view(N, A)}
         nxt_obs = {"priv_s": nxt["priv_s"].view(N, F), "legal_move": nxt["legal_move"].view(N, A)}
         prio = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, hid_next, rew, boot,
-                                      num_player=P if self.vdn else 1)
+                                      num_player=P if self.vdn else 1, next_greedy_a=reply["greedy_a"])
         self.writer.push_sequence(prio)
         self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)

@@ -303,6 +303,41 @@ __global__ void cast_pad_bf16_kernel(const float* __restrict__ src, int M, int K
   dst[idx] = c < K ? f2bf(src[(size_t)r * lds + c]) : (bf16_t)0;
 }
 
+// same, eight outputs (one 16-byte store) per thread: Kp % 8 == 0, dst 16-byte aligned; 8-byte source loads when src and lds
+// allow them (the observation rows: 838 floats = 3352 B per row, 8- but not 16-byte aligned).  HBM-bound: 6 B per element.
+template <int SRC_VEC2>
+__global__ __launch_bounds__(256) void cast_pad_bf16_vec8_kernel(const float* __restrict__ src, int M, int K, int lds,
+                                                                 bf16_t* __restrict__ dst, int Kp) {
+  const int cpr = Kp >> 3;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)M * cpr) return;
+  const int r = (int)(idx / cpr), c = (int)(idx - (size_t)r * cpr) * 8;
+  const float* sp = src + (size_t)r * lds + c;
+  float v[8];
+  if (c + 8 <= K) {
+    if (SRC_VEC2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float2 t = reinterpret_cast<const float2*>(sp)[e];
+        v[2 * e] = t.x;
+        v[2 * e + 1] = t.y;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = sp[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = c + e < K ? sp[e] : 0.f;
+  }
+  uint4 o;
+  o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(dst + (size_t)r * Kp + c) = o;
+}
+
 // bf16 [R, C] (ld = lds) -> [C, R] (ld = ldd).  64x64 tiles through LDS, 256 threads: 8-byte global loads and stores
 // when both leading dimensions / bases allow it (the weight-gradient operands: 10-40 MB per call), scalar otherwise.
 // Optionally also accumulates the column sums of src (bias gradients: the tile is in LDS anyway) into
@@ -514,6 +549,153 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
     a.c_out[(size_t)row * H + u] = c;
     a.h_out16[(size_t)row * H + u] = f2bf(h);
     if (a.h_out32) a.h_out32[(size_t)row * H + u] = h;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Single-step LSTM cell for inference at GEMM speed (actors: tens of thousands of rows, T = 1):
+//   gates = [x | h_prev] [W_ih | W_hh]^T + bias,   cell update in the epilogue
+// -- one kernel per layer, both projections share the K loop (K = Kx + H), the gate pre-activations never reach HBM and
+// h_prev comes as the bf16 cast of the fp32 state (in the K loop the fp32 state would double the A traffic and its
+// registers cost the second wave per SIMD).  Same pipeline as gemm_nt_bf16_kernel<128,128> (double-buffered
+// LDS, persistent tile loop).  Column layout "gate16": output columns come in groups of 64 = [i(16) f(16) g(16) o(16)] of
+// 16 hidden units, so a wave's 64 columns hold every gate of its 16 units: lanes l and l ^ 16 own {i,g} resp. {f,o} of
+// the same unit and swap eight accumulator rows each (`__shfl_xor 16`), then each finishes 8 of the 16 rows.
+// ---------------------------------------------------------------------------------------------------
+struct LstmCellArgs {
+  const bf16_t* x;       // [Bn, Kx] bf16 (ld = ldx)
+  const bf16_t* h_prev16;  // [Bn, H] bf16 (the fp32 state cast by the caller; MAY NOT alias h_out16)
+  const bf16_t* Wcat;    // [4H, Kx + H] bf16, rows in gate16 order, columns [W_ih | W_hh]
+  const float* bias;     // [4H] gate16 order (b_ih + b_hh)
+  const float* c_prev;   // [Bn, H]
+  float* c_out;          // [Bn, H]
+  float* h_out32;        // [Bn, H]
+  bf16_t* h_out16;       // optional [Bn, H]
+  int Bn, H, Kx, ldx;
+};
+
+__global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
+  constexpr int BM = 128, BN = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_cell);   // [2][BM][kLdsStride]
+  bf16_t* sB = sA + 2 * BM * kLdsStride;                // [2][BN][kLdsStride]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int H = a.H, K = a.Kx + H, N4 = 4 * H;
+  const int tiles_n = N4 / BN, tiles_m = (a.Bn + BM - 1) / BM, n_tiles = tiles_n * tiles_m;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int t) {
+    n0 = (t % tiles_n) * BN;
+    m0 = (t / tiles_n) * BM;
+  };
+  constexpr int CPR = kBK / 8;
+  constexpr int ITERS = BM * CPR / 256;
+  static_assert(ITERS == 4, "staging registers below are written out for four 16-byte chunks per operand");
+  // named registers, not arrays: with arrays here the compiler kept the staging values in scratch memory (load -> wait ->
+  // scratch store), which serialises the whole pipeline
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const int sr = tid / CPR, sq = tid % CPR;                 // chunk it covers tile row sr + 32 * it
+  auto load_tile = [&](int k0) {
+    const bool part2 = k0 >= a.Kx;
+    const bf16_t* abase = (part2 ? a.h_prev16 + (k0 - a.Kx) : a.x + k0) + sq * 8;
+    const size_t lda = part2 ? H : a.ldx;
+    const bf16_t* bbase = a.Wcat + (size_t)(n0 + sr) * K + k0 + sq * 8;
+    const int last = a.Bn - 1;                              // rows past the end repeat the last row (never stored)
+    ra0 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr, last) * lda);
+    ra1 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 32, last) * lda);
+    ra2 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 64, last) * lda);
+    ra3 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 96, last) * lda);
+    rb0 = *reinterpret_cast<const uint4*>(bbase);
+    rb1 = *reinterpret_cast<const uint4*>(bbase + (size_t)32 * K);
+    rb2 = *reinterpret_cast<const uint4*>(bbase + (size_t)64 * K);
+    rb3 = *reinterpret_cast<const uint4*>(bbase + (size_t)96 * K);
+  };
+  auto store_tile = [&](int buf) {
+    bf16_t* pa = sA + (buf * BM + sr) * kLdsStride + sq * 8;
+    bf16_t* pb = sB + (buf * BN + sr) * kLdsStride + sq * 8;
+    *reinterpret_cast<uint4*>(pa) = ra0;
+    *reinterpret_cast<uint4*>(pa + 32 * kLdsStride) = ra1;
+    *reinterpret_cast<uint4*>(pa + 64 * kLdsStride) = ra2;
+    *reinterpret_cast<uint4*>(pa + 96 * kLdsStride) = ra3;
+    *reinterpret_cast<uint4*>(pb) = rb0;
+    *reinterpret_cast<uint4*>(pb + 32 * kLdsStride) = rb1;
+    *reinterpret_cast<uint4*>(pb + 64 * kLdsStride) = rb2;
+    *reinterpret_cast<uint4*>(pb + 96 * kLdsStride) = rb3;
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  set_tile(tile);
+  load_tile(0);
+  const int nk = K / kBK;
+  for (; tile < n_tiles; tile += gridDim.x) {
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    store_tile(0);
+    if (nk > 1) load_tile(kBK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) {
+        store_tile(cur ^ 1);
+        if (kt + 2 < nk) load_tile((kt + 2) * kBK);
+      }
+      const bf16_t* pa = sA + cur * BM * kLdsStride;
+      const bf16_t* pb = sB + cur * BN * kLdsStride;
+#pragma unroll
+      for (int kk = 0; kk < kBK / 16; ++kk) {
+        bf16x8 fa[2], fb[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = lds_frag(pa, wm * 64 + i * 32, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = lds_frag(pb, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    const int cm0 = m0, cn0 = n0;
+    if (tile + (int)gridDim.x < n_tiles) {   // next tile's first operand loads fly during the epilogue
+      set_tile(tile + gridDim.x);
+      load_tile(0);
+    }
+    // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+    const bool hi = (lane & 16) != 0;                       // lo lanes hold {i, g}, hi lanes {f, o} of unit (lane & 15)
+    const int unit = (cn0 + wn * 64) / 4 + (lane & 15);     // 64 gate columns = 16 units
+    const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
+    const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      // swap: lo keeps rows r < 8 and receives {f, o} for them, hi keeps rows r >= 8 and receives {i, g}
+      float g0[8], g1[8];                                   // partner's tile-0 / tile-1 values for MY eight rows
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        g0[k] = __shfl_xor(hi ? acc[i][0][k] : acc[i][0][8 + k], 16, 64);
+        g1[k] = __shfl_xor(hi ? acc[i][1][k] : acc[i][1][8 + k], 16, 64);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rr = (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);          // C row of accumulator register k ...
+        const int row = cm0 + wm * 64 + i * 32 + rr + (hi ? 16 : 0);     // ... and of register 8 + k (two rows of 8 further on)
+        if (row >= a.Bn) continue;
+        const float m0v = hi ? acc[i][0][8 + k] : acc[i][0][k], m1v = hi ? acc[i][1][8 + k] : acc[i][1][k];
+        const float pi = hi ? g0[k] : m0v, pg = hi ? g1[k] : m1v;
+        const float pf = hi ? m0v : g0[k], po = hi ? m1v : g1[k];
+        const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
+        const float c = gf * a.c_prev[(size_t)row * H + unit] + gi * gg;
+        const float h = go * tanhf_(c);
+        a.c_out[(size_t)row * H + unit] = c;
+        a.h_out32[(size_t)row * H + unit] = h;
+        if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
+      }
+    }
   }
 }
 
@@ -1696,8 +1878,18 @@ int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int
 int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream) {
   if (!src || !dst || Kp < K) return nfail(HSAD_ERR_INVALID, "cast_pad: bad arguments");
   const size_t n = (size_t)M * Kp;
-  hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, M, K,
-                     ld_src, (bf16_t*)dst, Kp);
+  if (n == 0) return HSAD_OK;
+  if (Kp % 8 == 0 && ((uintptr_t)dst & 15) == 0) {
+    const size_t nv = n / 8;
+    const dim3 grid((unsigned)((nv + 255) / 256));
+    if (ld_src % 2 == 0 && ((uintptr_t)src & 7) == 0)
+      hipLaunchKernelGGL(cast_pad_bf16_vec8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, M, K, ld_src, (bf16_t*)dst, Kp);
+    else
+      hipLaunchKernelGGL(cast_pad_bf16_vec8_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, M, K, ld_src, (bf16_t*)dst, Kp);
+  } else {
+    hipLaunchKernelGGL(cast_pad_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, M, K,
+                       ld_src, (bf16_t*)dst, Kp);
+  }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1805,6 +1997,31 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     else
       hipLaunchKernelGGL((lstm_step_kernel<128, 1>), dim3(H / 32, (Bn + 127) / 128), dim3(256), 0, s, a);
   }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
+                         const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
+                         void* stream) {
+  if (!x16 || !h_prev16 || !Wcat_gate16 || !bias_gate16 || !c_prev || !c_out || !h_out32)
+    return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: null argument");
+  if (Bn < 1 || H < 64 || (H % kBK) || Kx < kBK || (Kx % kBK) || (ldx % 8) || ((4 * H) % 128))
+    return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: H and Kx must be multiples of 64, ldx of 8");
+  if ((((uintptr_t)x16 | (uintptr_t)Wcat_gate16 | (uintptr_t)h_prev16) & 15))
+    return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands must be 16-byte aligned");
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  LstmCellArgs a{(const bf16_t*)x16, (const bf16_t*)h_prev16, (const bf16_t*)Wcat_gate16, bias_gate16, c_prev, c_out, h_out32, (bf16_t*)h_out16,
+                 Bn, H, Kx, ldx};
+  const size_t lds = (size_t)2 * (128 + 128) * kLdsStride * sizeof(bf16_t);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const long tiles = (long)(4 * H / 128) * ((Bn + 127) / 128);
+  hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -28,6 +28,14 @@ def gate_block_perm(H, device):
     return (g * H + nb * 32 + u).reshape(-1)
 
 
+def gate16_perm(H, device):
+    """row order of the fused inference cell (hsad_lstm_cell_fused): 64 rows = [i f g o] x 16 units"""
+    ub = torch.arange(H // 16).view(-1, 1, 1)
+    gate = torch.arange(4).view(1, -1, 1)
+    u = torch.arange(16).view(1, 1, -1)
+    return (gate * H + ub * 16 + u).reshape(-1).to(device)
+
+
 def gemm_nt(A16, B16, M, N, K, bias=None, out32=None, out16=None, relu=False, accumulate=False):
     lib = _lib.load_library()
     _lib.check(lib.hsad_gemm_nt_bf16(
@@ -207,6 +215,12 @@ class R2D2NetKernels:
         self.bg = [torch.empty(4 * H, dtype=torch.float32, device=d) for _ in range(self.L)]
         self.Wheads = torch.empty(self.NH, H, dtype=bf, device=d)
         self.bheads = torch.empty(self.NH, dtype=torch.float32, device=d)
+        # single-step inference operands (actors): [W_ih | W_hh] and the bias in gate16 row order
+        self.Wcat16 = self.bias16 = None
+        if H % 64 == 0:
+            self.perm16 = gate16_perm(H, d).to(torch.int32).contiguous()
+            self.Wcat16 = [torch.empty(4 * H, 2 * H, dtype=bf, device=d) for _ in range(self.L)]
+            self.bias16 = [torch.empty(4 * H, dtype=torch.float32, device=d) for _ in range(self.L)]
         self.WihT = self.WhhT = self.WheadsT = None
         if with_transposes:   # backward operands (learner only)
             self.WihT = [torch.empty(H, 4 * H, dtype=bf, device=d) for _ in range(self.L)]
@@ -232,6 +246,11 @@ class R2D2NetKernels:
             self._prep(w["lstm.weight_hh_l%d" % l], self.perm32, self.Whh[l], self.WhhT[l] if T_ else None)
             _lib.check(self.lib.hsad_bias_sum_perm(w["lstm.bias_ih_l%d" % l].data_ptr(), w["lstm.bias_hh_l%d" % l].data_ptr(),
                                                    self.perm32.data_ptr(), self.bg[l].data_ptr(), 4 * H, _s(self.device)))
+            if self.Wcat16 is not None and not T_:   # acting copies only (the learner's net never steps one row at a time)
+                self._prep(w["lstm.weight_ih_l%d" % l], self.perm16, self.Wcat16[l][:, :H], None)
+                self._prep(w["lstm.weight_hh_l%d" % l], self.perm16, self.Wcat16[l][:, H:], None)
+                _lib.check(self.lib.hsad_bias_sum_perm(w["lstm.bias_ih_l%d" % l].data_ptr(), w["lstm.bias_hh_l%d" % l].data_ptr(),
+                                                       self.perm16.data_ptr(), self.bias16[l].data_ptr(), 4 * H, _s(self.device)))
         r0 = 0
         for wk, bk in (("fc_a.weight", "fc_a.bias"), ("fc_v.weight", "fc_v.bias"), ("pred.weight", "pred.bias")):
             n = w[wk].shape[0]
@@ -274,6 +293,25 @@ class R2D2NetKernels:
         if keep is not None:
             keep.update(saved)
         return inp.view(T, N, H), h_new, (c_new if c_new is not None else torch.stack(cs, 0))
+
+    def step(self, priv_s, h0, c0):
+        """one recurrent step for inference (R2D2Net.act, r2d2.py:65-78): priv_s fp32 [N,F], h0/c0 fp32 [L,N,H] (contiguous)
+        -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]).  One fused GEMM + cell kernel per layer."""
+        N, F = priv_s.shape
+        H, d = self.H, self.device
+        a16 = cast_pad_bf16(priv_s, self.Fp)
+        x = torch.empty(N, H, dtype=torch.bfloat16, device=d)
+        gemm_nt(a16, self.W1, N, H, self.Fp, bias=self.b1, out16=x, relu=True)
+        h = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
+        c = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
+        h16 = cast_pad_bf16(h0.reshape(self.L * N, H), H).view(self.L, N, H)
+        for l in range(self.L):
+            x_next = torch.empty(N, H, dtype=torch.bfloat16, device=d)
+            _lib.check(self.lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), x.stride(0), h16[l].data_ptr(),
+                                                     self.Wcat16[l].data_ptr(), self.bias16[l].data_ptr(), c0[l].data_ptr(),
+                                                     c[l].data_ptr(), h[l].data_ptr(), x_next.data_ptr(), _s(d)))
+            x = x_next
+        return x, h, c
 
     def heads(self, o16):
         """bf16 [M,H] -> fp32 [M, NH] = [advantage | value | aux logits]"""
@@ -701,6 +739,9 @@ class R2D2Agent:
         return {"h0": z, "c0": z.clone()}
 
     def _adv(self, net, priv_s, h0, c0):
+        if net.Wcat16 is not None and net.WihT is None and priv_s.shape[0] >= 1024 and h0.is_contiguous() and c0.is_contiguous():
+            o, h, c = net.step(priv_s, h0, c0)           # big batches: fused GEMM + cell kernel per layer
+            return net.heads(o), h, c
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
 
@@ -719,21 +760,28 @@ class R2D2Agent:
         self.counter += 1
         return {"a": a, "greedy_a": g}, {"h0": h, "c0": c}
 
-    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap, num_player=1):
+    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap, num_player=1, next_greedy_a=None):
         """|r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|  -> fp32 [N]
         num_player > 1 = VDN (r2d2.py:341-345): rows are (game, player) pairs, Q-values are summed over the players of
-        a game and reward / bootstrap / the result are per game [N / num_player]."""
+        a game and reward / bootstrap / the result are per game [N / num_player].
+        next_greedy_a: argmax_a' adv_online(s') when the caller already has it.  In the actor loop (r2d2_actor.h:128-150)
+        next_obs / next_hid of the popped transition ARE the inputs of the act() call of the same iteration, so its
+        greedy_a is this argmax and the third network pass of the reference is a recomputation; None computes it here."""
         lib = _lib.load_library()
         on, tg, d = self.online, self.target, self.device
         n = a.shape[0]
         hd, _, _ = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"])
         _, qa, _ = on.q_head(hd, obs["legal_move"], a, want_greedy=False)
-        nhd, _, _ = self._adv(on, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
-        na = torch.empty(n, dtype=torch.int64, device=d)
-        junk = torch.empty(n, dtype=torch.int64, device=d)
-        scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=d)
-        _lib.check(lib.hsad_act_select(nhd.data_ptr(), nhd.stride(0), next_obs["legal_move"].contiguous().data_ptr(), None, n,
-                                       on.A, 0, 0, junk.data_ptr(), na.data_ptr(), scratch.data_ptr(), _s(d)))
+        if next_greedy_a is not None:
+            na = next_greedy_a.contiguous().view(-1)
+            assert na.dtype == torch.int64 and na.shape[0] == n
+        else:
+            nhd, _, _ = self._adv(on, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
+            na = torch.empty(n, dtype=torch.int64, device=d)
+            junk = torch.empty(n, dtype=torch.int64, device=d)
+            scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=d)
+            _lib.check(lib.hsad_act_select(nhd.data_ptr(), nhd.stride(0), next_obs["legal_move"].contiguous().data_ptr(), None,
+                                           n, on.A, 0, 0, junk.data_ptr(), na.data_ptr(), scratch.data_ptr(), _s(d)))
         thd, _, _ = self._adv(tg, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
         _, tqa, _ = tg.q_head(thd, next_obs["legal_move"], na, want_greedy=False)
         if num_player > 1:

@@ -46,6 +46,30 @@ def test_actor_fills_replay_with_well_formed_sequences_and_learner_trains():
     assert torch.equal(tr.act_online.w["fc_a.weight"], tr.learner.online.w["fc_a.weight"]) or tr.num_update % 2 != 1
 
 
+@pytest.mark.parametrize("method", ["iql", "vdn"])
+def test_actor_hands_over_exactly_the_greedy_action_the_reference_recomputes(method):
+    """DeviceActor passes its act() reply as next_greedy_a; compute_priority without it (the reference's third network
+    pass on next_obs / next_hid, r2d2.py:305-361) must give the same priorities bit for bit, every step"""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    args = parse_args(["--num_game", "64", "--rnn_hid_dim", "64", "--batchsize", "16", "--replay_buffer_size", "1024",
+                       "--burn_in_frames", "64", "--max_len", "40", "--act_base_eps", "0.4", "--sad", "1",
+                       "--method", method])
+    tr = Trainer(args, "cuda:0")
+    agent, seen = tr.actor.agent, []
+    plain = agent.compute_priority
+
+    def spy(*a, **kw):
+        assert kw.get("next_greedy_a") is not None
+        got = plain(*a, **kw)
+        kw2 = dict(kw, next_greedy_a=None)
+        seen.append(bool(torch.equal(got, plain(*a, **kw2))))
+        return got
+    agent.compute_priority = spy
+    for _ in range(50):
+        tr.actor.step()
+    assert len(seen) >= 40 and all(seen)
+
+
 def test_reference_named_mirrors():
     """hanalearn.HanabiEnv / rela.RNNPrioritizedReplay / rela.aggregate_priority keep the reference call surface."""
     from hanabi_sad_amd import hanalearn, rela

@@ -380,6 +380,31 @@ def test_exchange_protocol_does_not_change_results():
         assert relerr(res[0][2][k], res[1][2][k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("N,H", [(3000, 512), (1025, 256)])
+def test_fused_inference_cell_matches_the_two_kernel_path(N, H):
+    """net.step (one fused [x|h][W_ih|W_hh]^T GEMM + cell kernel per layer, gate16 column order) vs net.trunk at T = 1
+    (projection GEMM + per-step LSTM kernel): the same bf16 operands and fp32 accumulation, different summation order"""
+    from hanabi_sad_amd.r2d2 import R2D2NetKernels
+    F, A = 838, 21
+    net = R2D2NetKernels(_rand_net(F, H, A, seed=12), DEV)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    priv = (torch.rand(N, F, generator=g) < 0.15).float().to(DEV)
+    h0 = (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)
+    c0 = (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)
+    o1, h1, c1 = net.step(priv, h0, c0)
+    o2, h2, c2 = net.trunk(priv.unsqueeze(0), h0, c0)
+    assert torch.allclose(h1, h2, atol=2e-3, rtol=2e-3) and torch.allclose(c1, c2, atol=2e-3, rtol=2e-3)
+    assert torch.allclose(o1.float(), o2.reshape(N, H).float(), atol=1e-2, rtol=1e-2)
+    # against fp32 torch on the bf16-rounded operands of layer 0 (transposition / gate-order mistakes cannot hide here)
+    w = net.w
+    x = torch.relu(bf(priv) @ bf(w["net.0.weight"]).t() + w["net.0.bias"])
+    gates = bf(x) @ bf(w["lstm.weight_ih_l0"]).t() + bf(h0[0]) @ bf(w["lstm.weight_hh_l0"]).t() + w["lstm.bias_ih_l0"] + w["lstm.bias_hh_l0"]
+    i, f, gg, o = gates.chunk(4, 1)
+    c = torch.sigmoid(f) * c0[0] + torch.sigmoid(i) * torch.tanh(gg)
+    assert torch.allclose(c1[0], c, atol=2e-3, rtol=2e-3)
+    assert torch.allclose(h1[0], torch.sigmoid(o) * torch.tanh(c), atol=2e-3, rtol=2e-3)
+
+
 def test_agent_act_and_compute_priority_against_reference_golden():
     from hanabi_sad_amd.r2d2 import R2D2Agent, R2D2NetKernels
     z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
@@ -403,6 +428,12 @@ def test_agent_act_and_compute_priority_against_reference_golden():
     p = agent.compute_priority(obs, flat("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
                                flat("prio.reward"), flat("prio.bootstrap"))
     assert np.allclose(p.cpu().numpy(), z["prio.out"].reshape(-1), atol=4e-2, rtol=4e-2)
+    # the actor loop hands over the greedy action of its own act() on (next_obs, next_hid) instead of a third pass
+    nobs["eps"] = torch.zeros_like(obs["eps"])
+    nreply, _ = agent.act(nobs, hid("prio.next_h0", "prio.next_c0"))
+    p2 = agent.compute_priority(obs, flat("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
+                                flat("prio.reward"), flat("prio.bootstrap"), next_greedy_a=nreply["greedy_a"])
+    assert torch.equal(p, p2)
     # exploration: eps = 1 must pick uniformly among legal moves, deterministic in (seed, counter)
     obs["eps"] = torch.ones_like(obs["eps"])
     agent.counter = 5
