@@ -69,6 +69,24 @@ __device__ __forceinline__ bf16x8 lds_frag(const bf16_t* tile, int row0, int kk,
   return *reinterpret_cast<const bf16x8*>(p);
 }
 
+// LDS-DMA operand tiles: rows of exactly 64 bf16 (128 B), no padding -- global_load_lds writes wave-uniform base + lane * 16,
+// so a wave instruction fills 8 consecutive rows and the image cannot be padded.  Bank conflicts are avoided instead by
+// storing the 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): the 16 lanes ds_read_b128 serves per LDS cycle
+// (rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} of a fragment, one chunk column) then cover all 16 slots of the 256-byte
+// bank row.  The permutation is applied on the SOURCE side (which global chunk a lane fetches; still one 128-byte line per
+// row) and again when reading fragments.
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void glds16(const bf16_t* gsrc_lane, bf16_t* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag_swz(const bf16_t* tile, int row0, int kk, int lane) {
+  const int r = row0 + (lane & 31);
+  return *reinterpret_cast<const bf16x8*>(tile + r * kBK + swz_chunk(r, kk * 2 + (lane >> 5)) * 8);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // C[M,N] = A[M,K] * B[N,K]^T (+ bias[N]) (ReLU) ; A,B bf16 row-major (lda/ldb in elements, multiples of 8;
 // K multiple of 32, buffers zero-padded by the caller).  Block = 256 threads = 4 waves in a 2x2 grid, each
@@ -448,9 +466,11 @@ struct LstmStepArgs {
   int keep_gates;        // 0 = inference: the activated gates are not written back (no backward pass will read them)
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
-// tanh via one exp: 1 - 2/(1+e^{2x}); exact limits at +-inf, abs error ~1e-7 — the library tanhf costs ~3x the issue slots
-__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f / (1.f + __expf(2.f * x)); }
+// 1/(1+e^-x) and tanh with one v_exp_f32 and one v_rcp_f32 each (both 1 ulp): a true division costs ten more issue slots
+// per gate, in kernels whose cell updates are VALU-bound (actors) or on the critical path of every time step (learner).
+// tanh = 1 - 2/(1+e^{2x}): exact limits at +-inf, abs error ~1e-7.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
 template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
@@ -577,58 +597,64 @@ struct LstmCellArgs {
 __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
   constexpr int BM = 128, BN = 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_cell);   // [2][BM][kLdsStride]
-  bf16_t* sB = sA + 2 * BM * kLdsStride;                // [2][BN][kLdsStride]
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_cell);   // [2][BM][64] swizzled (see glds16 / lds_frag_swz)
+  bf16_t* sB = sA + 2 * BM * kBK;                       // [2][BN][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int H = a.H, K = a.Kx + H, N4 = 4 * H;
-  const int tiles_n = N4 / BN, tiles_m = (a.Bn + BM - 1) / BM, n_tiles = tiles_n * tiles_m;
+  const int tiles_n = N4 / BN, tiles_m = (a.Bn + BM - 1) / BM;
+  // Tile order.  Workgroup b runs on XCD b % 8 and every XCD has its own L2: XCD x owns the row tiles m = x, x + 8, ... and
+  // its workgroups walk them with the column tile fastest, so a row tile of [x | h] is fetched into ONE L2 and re-used by
+  // the 4H / 128 column tiles there while the (small) weight matrix is what every L2 holds.  (Row tiles spread over all
+  // XCDs made each L2 fetch every activation row: 4.8x the algorithmic HBM/fabric traffic.)
+  const bool xcd_order = (gridDim.x % 8) == 0;
+  const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
+  const int per_xcd = gridDim.x / n_xcd;
+  int seq = blockIdx.x / n_xcd;                          // position in this XCD's tile sequence
   int m0 = 0, n0 = 0;
-  auto set_tile = [&](int t) {
-    n0 = (t % tiles_n) * BN;
-    m0 = (t / tiles_n) * BM;
+  auto set_tile = [&](int sq) -> bool {
+    const int mt = (sq / tiles_n) * n_xcd + xcd;
+    n0 = (sq % tiles_n) * BN;
+    m0 = mt * BM;
+    return mt < tiles_m;
   };
-  constexpr int CPR = kBK / 8;
-  constexpr int ITERS = BM * CPR / 256;
-  static_assert(ITERS == 4, "staging registers below are written out for four 16-byte chunks per operand");
-  // named registers, not arrays: with arrays here the compiler kept the staging values in scratch memory (load -> wait ->
-  // scratch store), which serialises the whole pipeline
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  const int sr = tid / CPR, sq = tid % CPR;                 // chunk it covers tile row sr + 32 * it
-  auto load_tile = [&](int k0) {
+  // operand tiles go L2 -> LDS by LDS-DMA (no staging registers, no ds_write pass): wave w moves the 8-row pieces w, w + 4,
+  // w + 8, w + 12 of each operand, one instruction per piece.  Per-lane source offsets (bytes, 32 bit) are computed once
+  // per tile (A) / once per kernel (B); a k step only moves the wave-uniform bases.
+  const int prow = lane >> 3;
+  uint32_t boff[4], aoff_x[4], aoff_h[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rl = (it * 4 + wave) * 8 + prow;
+    boff[it] = (uint32_t)(rl * K + swz_chunk(rl, lane & 7) * 8) * 2u;
+  }
+  auto set_rows = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (it * 4 + wave) * 8 + prow;
+      const int gr = min(m0 + rl, a.Bn - 1);              // rows past the end repeat the last row (never stored)
+      const int ch = swz_chunk(rl, lane & 7) * 8;
+      aoff_x[it] = (uint32_t)(gr * a.ldx + ch) * 2u;
+      aoff_h[it] = (uint32_t)(gr * H + ch) * 2u;
+    }
+  };
+  auto issue_tile = [&](int k0, int buf) {
     const bool part2 = k0 >= a.Kx;
-    const bf16_t* abase = (part2 ? a.h_prev16 + (k0 - a.Kx) : a.x + k0) + sq * 8;
-    const size_t lda = part2 ? H : a.ldx;
-    const bf16_t* bbase = a.Wcat + (size_t)(n0 + sr) * K + k0 + sq * 8;
-    const int last = a.Bn - 1;                              // rows past the end repeat the last row (never stored)
-    ra0 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr, last) * lda);
-    ra1 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 32, last) * lda);
-    ra2 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 64, last) * lda);
-    ra3 = *reinterpret_cast<const uint4*>(abase + (size_t)min(m0 + sr + 96, last) * lda);
-    rb0 = *reinterpret_cast<const uint4*>(bbase);
-    rb1 = *reinterpret_cast<const uint4*>(bbase + (size_t)32 * K);
-    rb2 = *reinterpret_cast<const uint4*>(bbase + (size_t)64 * K);
-    rb3 = *reinterpret_cast<const uint4*>(bbase + (size_t)96 * K);
-  };
-  auto store_tile = [&](int buf) {
-    bf16_t* pa = sA + (buf * BM + sr) * kLdsStride + sq * 8;
-    bf16_t* pb = sB + (buf * BN + sr) * kLdsStride + sq * 8;
-    *reinterpret_cast<uint4*>(pa) = ra0;
-    *reinterpret_cast<uint4*>(pa + 32 * kLdsStride) = ra1;
-    *reinterpret_cast<uint4*>(pa + 64 * kLdsStride) = ra2;
-    *reinterpret_cast<uint4*>(pa + 96 * kLdsStride) = ra3;
-    *reinterpret_cast<uint4*>(pb) = rb0;
-    *reinterpret_cast<uint4*>(pb + 32 * kLdsStride) = rb1;
-    *reinterpret_cast<uint4*>(pb + 64 * kLdsStride) = rb2;
-    *reinterpret_cast<uint4*>(pb + 96 * kLdsStride) = rb3;
+    const char* abase = reinterpret_cast<const char*>(part2 ? a.h_prev16 + (k0 - a.Kx) : a.x + k0);
+    const char* bbase = reinterpret_cast<const char*>(a.Wcat + (size_t)n0 * K + k0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = it * 4 + wave;
+      glds16(reinterpret_cast<const bf16_t*>(abase + (part2 ? aoff_h[it] : aoff_x[it])), sA + (buf * BM + piece * 8) * kBK);
+      glds16(reinterpret_cast<const bf16_t*>(bbase + boff[it]), sB + (buf * BN + piece * 8) * kBK);
+    }
   };
 
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-  set_tile(tile);
-  load_tile(0);
+  if (!set_tile(seq)) return;
+  set_rows();
+  issue_tile(0, 0);
   const int nk = K / kBK;
-  for (; tile < n_tiles; tile += gridDim.x) {
+  for (;;) {
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -636,66 +662,72 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    store_tile(0);
-    if (nk > 1) load_tile(kBK);
-    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
-      if (kt + 1 < nk) {
-        store_tile(cur ^ 1);
-        if (kt + 2 < nk) load_tile((kt + 2) * kBK);
-      }
-      const bf16_t* pa = sA + cur * BM * kLdsStride;
-      const bf16_t* pb = sB + cur * BN * kLdsStride;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k tile kt have landed in LDS ...
+      __syncthreads();                                   // ... everyone's have, and nobody still reads the other buffer
+      if (kt + 1 < nk) issue_tile((kt + 1) * kBK, cur ^ 1);   // in flight during this step's MFMAs
+      const bf16_t* pa = sA + cur * BM * kBK;
+      const bf16_t* pb = sB + cur * BN * kBK;
 #pragma unroll
       for (int kk = 0; kk < kBK / 16; ++kk) {
         bf16x8 fa[2], fb[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) fa[i] = lds_frag(pa, wm * 64 + i * 32, kk, lane);
+        for (int i = 0; i < 2; ++i) fa[i] = lds_frag_swz(pa, wm * 64 + i * 32, kk, lane);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = lds_frag(pb, wn * 64 + j * 32, kk, lane);
+        for (int j = 0; j < 2; ++j) fb[j] = lds_frag_swz(pb, wn * 64 + j * 32, kk, lane);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-      __syncthreads();
-    }
-    const int cm0 = m0, cn0 = n0;
-    if (tile + (int)gridDim.x < n_tiles) {   // next tile's first operand loads fly during the epilogue
-      set_tile(tile + gridDim.x);
-      load_tile(0);
     }
     // ---- epilogue: C/D layout col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
+    const int cm0 = m0, cn0 = n0;
     const bool hi = (lane & 16) != 0;                       // lo lanes hold {i, g}, hi lanes {f, o} of unit (lane & 15)
     const int unit = (cn0 + wn * 64) / 4 + (lane & 15);     // 64 gate columns = 16 units
     const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
     const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
+    float cp[2][8];                                         // c_prev of my eight rows of each 32-row block
+    int rowof[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int rr = (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);   // C row of accumulator register k; register 8 + k is
+        rowof[i][k] = cm0 + wm * 64 + i * 32 + rr + (hi ? 16 : 0);  // two rows-of-8 further on
+        cp[i][k] = rowof[i][k] < a.Bn ? a.c_prev[(size_t)rowof[i][k] * H + unit] : 0.f;
+      }
+    seq += per_xcd;
+    const bool more = set_tile(seq);
+    if (more) {                                // next tile's first k tile flies during the cell update (buffer 0: last read
+      if (nk & 1) __syncthreads();             // in step nk - 2 when nk is even, i.e. behind the barrier of step nk - 1)
+      set_rows();
+      issue_tile(0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      // swap: lo keeps rows r < 8 and receives {f, o} for them, hi keeps rows r >= 8 and receives {i, g}
-      float g0[8], g1[8];                                   // partner's tile-0 / tile-1 values for MY eight rows
+      // lo lanes finish accumulator rows k < 8 and receive {f, o} for them, hi lanes rows 8 + k and receive {i, g}
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        g0[k] = __shfl_xor(hi ? acc[i][0][k] : acc[i][0][8 + k], 16, 64);
-        g1[k] = __shfl_xor(hi ? acc[i][1][k] : acc[i][1][8 + k], 16, 64);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int rr = (k & 3) + 8 * (k >> 2) + 4 * (lane >> 5);          // C row of accumulator register k ...
-        const int row = cm0 + wm * 64 + i * 32 + rr + (hi ? 16 : 0);     // ... and of register 8 + k (two rows of 8 further on)
+        float l0 = acc[i][0][k], h0 = acc[i][0][8 + k], l1 = acc[i][1][k], h1 = acc[i][1][8 + k];
+        asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));   // keeps "hi ? x[k] : x[8 + k]" a select of two registers
+        const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);           // (as a select of the INDEX it becomes a 16-way chain)
+        const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
+        const int row = rowof[i][k];
         if (row >= a.Bn) continue;
-        const float m0v = hi ? acc[i][0][8 + k] : acc[i][0][k], m1v = hi ? acc[i][1][8 + k] : acc[i][1][k];
-        const float pi = hi ? g0[k] : m0v, pg = hi ? g1[k] : m1v;
-        const float pf = hi ? m0v : g0[k], po = hi ? m1v : g1[k];
+        const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
+        const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
+        const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
         const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
-        const float c = gf * a.c_prev[(size_t)row * H + unit] + gi * gg;
+        const float c = gf * cp[i][k] + gi * gg;
         const float h = go * tanhf_(c);
         a.c_out[(size_t)row * H + unit] = c;
         a.h_out32[(size_t)row * H + unit] = h;
         if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
       }
     }
+    if (!more) break;
   }
 }
 
@@ -2018,10 +2050,14 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
   }
   LstmCellArgs a{(const bf16_t*)x16, (const bf16_t*)h_prev16, (const bf16_t*)Wcat_gate16, bias_gate16, c_prev, c_out, h_out32, (bf16_t*)h_out16,
                  Bn, H, Kx, ldx};
-  const size_t lds = (size_t)2 * (128 + 128) * kLdsStride * sizeof(bf16_t);
+  const size_t lds = (size_t)2 * (128 + 128) * kBK * sizeof(bf16_t);
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  if ((size_t)Bn * (size_t)std::max(ldx, H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
+    return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands of 4 GB and more are not supported (32-bit offsets)");
   const long tiles = (long)(4 * H / 128) * ((Bn + 127) / 128);
-  hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, (hipStream_t)stream, a);
+  long grid = std::min<long>(tiles, 2L * n_cu);
+  if (grid >= 64) grid &= ~7L;       // a multiple of 8 switches the kernel to its XCD-aware tile order
+  hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
