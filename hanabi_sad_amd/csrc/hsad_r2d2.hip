@@ -108,66 +108,66 @@ struct GemmArgs {
   size_t slab_stride;      // split-K without atomics: split z writes its partial result to C32 + z * slab_stride
 };
 
+// LDS bytes of gemm_nt_bf16_kernel<BM,BN>: operand buffer 0 | operand buffer 1, the latter shared with the epilogue's output
+// staging (4 waves x 32 rows x (BN/2 + 8) floats), which may be the larger of the two
+constexpr size_t gemm_lds_bytes(int BM, int BN) {
+  const size_t oper = (size_t)(BM + BN) * kBK * sizeof(bf16_t), stage = (size_t)4 * 32 * (BN / 2 + 8) * sizeof(float);
+  return oper + (oper > stage ? oper : stage);
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
   constexpr int TM = WM / 32, TN = WN / 32;    // MFMA tiles per wave
-  // LDS: operand tiles double-buffered ([2][BM|BN][72] bf16) -> one barrier per 64-deep step, with the global loads of
-  // step k+2 in flight during the MFMAs of step k; the same memory is reused by the fp32 output staging of the epilogue
+  // LDS: [A0 | B0 | A1 | B1], operand tiles of 64-deep k steps, rows of exactly 128 B in the XOR-swizzled chunk order of
+  // glds16 / lds_frag_swz, filled by LDS-DMA (no staging registers, no ds_write pass; the per-lane source offsets are
+  // computed once per tile, a k step moves only wave-uniform bases): the DMA of step k+1 is in flight during the MFMAs of
+  // step k, one barrier per step.  The epilogue stages its output in the [A1 | B1] region.
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_gemm[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_gemm);   // [2][BM][kLdsStride]
-  bf16_t* sB = sA + 2 * BM * kLdsStride;                // [2][BN][kLdsStride]
+  constexpr int BUF = (BM + BN) * kBK;                  // bf16 elements per operand buffer
+  bf16_t* sOp = reinterpret_cast<bf16_t*>(smem_gemm);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // persistent over output tiles (grid = a couple of workgroups per CU): tile t -> (n tile fastest, then m, then k split),
-  // so that workgroups running together share the A panel in L2, and the first operand loads of the next tile are
-  // issued before the epilogue of the current one
+  // so that workgroups running together share the A panel in L2, and the first operand tile of the next output tile is
+  // requested before the epilogue of the current one
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int n_tiles = tiles_n * tiles_m * g.gz;
   int m0 = 0, n0 = 0, bz = 0;
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;        // 8-row pieces per wave and operand
+  uint32_t aoff[A_IT], boff[B_IT];                      // byte offsets of this lane's 16-byte chunk in each piece
+  const int prow = lane >> 3;
   auto set_tile = [&](int t) {
     n0 = (t % tiles_n) * BN;
     m0 = ((t / tiles_n) % tiles_m) * BM;
     bz = t / (tiles_n * tiles_m);
-  };
-
-  // global -> register staging: each thread moves 16 B (8 bf16); a tile row is kBK/8 such chunks
-  constexpr int CPR = kBK / 8;  // chunks per row
-  constexpr int A_ITERS = BM * CPR / 256, B_ITERS = BN * CPR / 256;
-  uint4 ra[A_ITERS], rb[B_ITERS];
-  auto load_tile = [&](int k0) {
+    // rows past the end of A / B repeat the last row: what they produce is never stored
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      const int gr = m0 + r;
-      ra[it] = (gr < g.M) ? *reinterpret_cast<const uint4*>(g.A + (size_t)gr * g.lda + k0 + q * 8) : make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < A_IT; ++it) {
+      const int rl = (it * 4 + wave) * 8 + prow;
+      aoff[it] = (uint32_t)(min(m0 + rl, g.M - 1) * g.lda + swz_chunk(rl, lane & 7) * 8) * 2u;
     }
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      const int gr = n0 + r;
-      rb[it] = (gr < g.N) ? *reinterpret_cast<const uint4*>(g.B + (size_t)gr * g.ldb + k0 + q * 8) : make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < B_IT; ++it) {
+      const int rl = (it * 4 + wave) * 8 + prow;
+      boff[it] = (uint32_t)(min(n0 + rl, g.N - 1) * g.ldb + swz_chunk(rl, lane & 7) * 8) * 2u;
     }
   };
-  auto store_tile = [&](int buf) {
-    bf16_t* a = sA + buf * BM * kLdsStride;
-    bf16_t* b = sB + buf * BN * kLdsStride;
+  auto issue_tile = [&](int k0, int buf) {
+    const char* abase = reinterpret_cast<const char*>(g.A + k0);
+    const char* bbase = reinterpret_cast<const char*>(g.B + k0);
+    bf16_t* da = sOp + buf * BUF;
+    bf16_t* db = da + BM * kBK;
 #pragma unroll
-    for (int it = 0; it < A_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      *reinterpret_cast<uint4*>(a + r * kLdsStride + q * 8) = ra[it];
-    }
+    for (int it = 0; it < A_IT; ++it) glds16(reinterpret_cast<const bf16_t*>(abase + aoff[it]), da + (it * 4 + wave) * 8 * kBK);
 #pragma unroll
-    for (int it = 0; it < B_ITERS; ++it) {
-      const int c = tid + it * 256, r = c / CPR, q = c % CPR;
-      *reinterpret_cast<uint4*>(b + r * kLdsStride + q * 8) = rb[it];
-    }
+    for (int it = 0; it < B_IT; ++it) glds16(reinterpret_cast<const bf16_t*>(bbase + boff[it]), db + (it * 4 + wave) * 8 * kBK);
   };
 
   int tile = blockIdx.x;
   if (tile >= n_tiles) return;
   set_tile(tile);
-  load_tile(g.k_chunk ? bz * g.k_chunk : 0);
+  issue_tile(g.k_chunk ? bz * g.k_chunk : 0, 0);
   for (; tile < n_tiles; tile += gridDim.x) {
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -180,36 +180,32 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   const int kbeg = g.k_chunk ? bz * g.k_chunk : 0;
   const int kend = g.k_chunk ? min(g.K, kbeg + g.k_chunk) : g.K;
   const int nk = (kend - kbeg) / kBK;
-  store_tile(0);                                            // first k tile of this output tile: loaded ahead
-  if (nk > 1) load_tile(kbeg + kBK);
-  __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      store_tile(cur ^ 1);                                  // tile kt+1 (its buffer was last read in step kt-1)
-      if (kt + 2 < nk) load_tile(kbeg + (kt + 2) * kBK);    // in flight during this step's MFMAs
-    }
-    const bf16_t* a = sA + cur * BM * kLdsStride;
-    const bf16_t* b = sB + cur * BN * kLdsStride;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k tile kt have landed in LDS ...
+    __syncthreads();                                   // ... everyone's have, and nobody still reads the other buffer
+    if (kt + 1 < nk) issue_tile(kbeg + (kt + 1) * kBK, cur ^ 1);   // in flight during this step's MFMAs
+    const bf16_t* a = sOp + cur * BUF;
+    const bf16_t* b = a + BM * kBK;
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = lds_frag(a, wm * WM + i * 32, kk, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = lds_frag_swz(a, wm * WM + i * 32, kk, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = lds_frag(b, wn * WN + j * 32, kk, lane);
+      for (int j = 0; j < TN; ++j) fb[j] = lds_frag_swz(b, wn * WN + j * 32, kk, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
   }
 
   const int cm0 = m0, cn0 = n0, cbz = bz;                   // this tile's coordinates for the epilogue
-  if (tile + (int)gridDim.x < n_tiles) {                    // next tile's first operand loads fly during the epilogue
+  __syncthreads();                                          // both operand buffers are dead: 0 may be refilled, 1 staged into
+  if (tile + (int)gridDim.x < n_tiles) {                    // next tile's first operand tile flies during the epilogue
     set_tile(tile + gridDim.x);
-    load_tile(g.k_chunk ? bz * g.k_chunk : 0);
+    issue_tile(g.k_chunk ? bz * g.k_chunk : 0, 0);
   }
   // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
   // Fast path (plain fp32 output, the big activation-producing GEMMs): the wave stages its WM x WN block in LDS (row
@@ -222,62 +218,65 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
                         (!g.mask16 || (!(g.ldmask & 3) && !((uintptr_t)g.mask16 & 7)));
   if (staged32 || staged16) {
     constexpr int CS = WN + 8;
-    float* sC = reinterpret_cast<float*>(smem_gemm) + wave * (WM * CS);
+    float* sC = reinterpret_cast<float*>(smem_gemm + (size_t)BUF * sizeof(bf16_t)) + wave * (32 * CS);
+    float bias[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = cn0 + wn * WN + j * 32 + (lane & 31);
-        const float bias = (g.bias && col < g.N && !cbz) ? g.bias[col] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = acc[i][j][r] + bias;
-          if (g.relu) v = fmaxf(v, 0.f);
-          sC[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + j * 32 + (lane & 31)] = v;
-        }
-      }
-    // no barrier: each wave reads back only what it wrote (wave-private region, in-order LDS)
+    for (int j = 0; j < TN; ++j) {
+      const int col = cn0 + wn * WN + j * 32 + (lane & 31);
+      bias[j] = (g.bias && col < g.N && !cbz) ? g.bias[col] : 0.f;
+    }
     typedef float nt_f4 __attribute__((ext_vector_type(4)));
     constexpr int LPR = WN / 4;          // lanes per output row
     constexpr int RPI = 64 / LPR;        // rows per instruction
     const int cw = (lane % LPR) * 4, rw = lane / LPR;
     const int col = cn0 + wn * WN + cw;
 #pragma unroll
-    for (int it = 0; it < WM / RPI; ++it) {
-      const int rl = it * RPI + rw;
-      const int row = cm0 + wm * WM + rl;
-      if (row < g.M && staged16) {
-        nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
-        if (col + 3 < g.N) {
-          if (g.mask16) {
-            const uint2 mk = *reinterpret_cast<const uint2*>(g.mask16 + (size_t)row * g.ldmask + col);
-            if (!(bf2f((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
-            if (!(bf2f((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
-            if (!(bf2f((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
-            if (!(bf2f((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
-          }
-          uint2 o;
-          o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = o;
-        } else {
+    for (int i = 0; i < TM; ++i) {       // 32 output rows per pass through the wave-private staging area (in-order LDS:
+#pragma unroll                           // no barrier between the passes)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < g.N) {
-              float x = v[e];
-              if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col + e]) > 0.f)) x = 0.f;
-              g.C16[(size_t)row * g.ldc16 + col + e] = f2bf(x);
-            }
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[i][j][r] + bias[j];
+          if (g.relu) v = fmaxf(v, 0.f);
+          sC[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * CS + j * 32 + (lane & 31)] = v;
         }
-      } else if (row < g.M) {
-        const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
-        float* p = g.C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
-        if (col + 3 < g.N) {
-          __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(p));
-        } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (col + e < g.N) p[e] = v[e];
+      for (int it = 0; it < 32 / RPI; ++it) {
+        const int rl = it * RPI + rw;
+        const int row = cm0 + wm * WM + i * 32 + rl;
+        if (row < g.M && staged16) {
+          nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
+          if (col + 3 < g.N) {
+            if (g.mask16) {
+              const uint2 mk = *reinterpret_cast<const uint2*>(g.mask16 + (size_t)row * g.ldmask + col);
+              if (!(bf2f((bf16_t)(mk.x & 0xffff)) > 0.f)) v[0] = 0.f;
+              if (!(bf2f((bf16_t)(mk.x >> 16)) > 0.f)) v[1] = 0.f;
+              if (!(bf2f((bf16_t)(mk.y & 0xffff)) > 0.f)) v[2] = 0.f;
+              if (!(bf2f((bf16_t)(mk.y >> 16)) > 0.f)) v[3] = 0.f;
+            }
+            uint2 o;
+            o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+            o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) {
+                float x = v[e];
+                if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col + e]) > 0.f)) x = 0.f;
+                g.C16[(size_t)row * g.ldc16 + col + e] = f2bf(x);
+              }
+          }
+        } else if (row < g.M) {
+          const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
+          float* p = g.C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
+          if (col + 3 < g.N) {
+            __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(p));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (col + e < g.N) p[e] = v[e];
+          }
         }
       }
     }
@@ -308,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
       }
     }
   }
-  __syncthreads();   // the staged C (and the last operand tiles) are dead before the next tile overwrites LDS
+  // no barrier here: the next tile's first k step opens with one, and only after it is buffer 1 (the staging area) refilled
   }
 }
 
@@ -1843,6 +1842,8 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
   if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 64 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
+  if (M < 1 || N < 1 || (size_t)M * lda * 2 >= ((size_t)1 << 32) || (size_t)N * ldb * 2 >= ((size_t)1 << 32))
+    return nfail(HSAD_ERR_INVALID, "gemm: empty operand, or one of 4 GB and more (32-bit offsets inside the kernel)");
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
@@ -1866,12 +1867,12 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
   // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
   const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
   if (N <= 64 || tiles128 < n_cu) {
-    const size_t lds = (size_t)2 * (128 + 64) * kLdsStride * sizeof(bf16_t);
+    const size_t lds = gemm_lds_bytes(128, 64);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, s, g);
   } else {
-    const size_t lds = (size_t)2 * (128 + 128) * kLdsStride * sizeof(bf16_t);
+    const size_t lds = gemm_lds_bytes(128, 128);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, s, g);
