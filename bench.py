@@ -116,6 +116,33 @@ def learner_bench(dev, updates=20, warmup=3):
     }
 
 
+def actor_bench(dev, games=16384, steps=40, warmup=30):
+    """The rollout with the agent in the loop (SURVEY.md §8 rows a/f; what the reference's actor threads + BatchRunner do):
+    one DeviceActor.step() = reset finished games -> observe -> R2D2 act (eps-greedy, SAD greedy action) -> env step ->
+    n-step pop -> compute_priority (online + target nets) -> sequence push -> flush finished sequences into the
+    prioritized replay.  2-player SAD IQL, H=512, 2-layer LSTM; acts = games x players per step (utils.py:229-236)."""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    args = parse_args(["--num_game", str(games), "--replay_buffer_size", "65536", "--sad", "1"])
+    tr = Trainer(args, str(dev))
+    for _ in range(warmup):
+        tr.actor.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.actor.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tr.env.check_errors()
+    tr.replay.check_errors()
+    out = {"value": games * 2 / dt, "unit": "acts/s", "ms_per_step": dt * 1e3, "game_steps_per_sec": games / dt,
+           "config": {"workload": "%d concurrent 2-player SAD games, IQL R2D2 agent (F=838 A=21 H=512 L=2) in the loop, n-step 3, "
+                                  "max_len 80, priorities from online+target nets, finished sequences flushed into a "
+                                  "65,536-sequence device replay" % games}}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(seconds=8.0):
     """The CPU oracle (port of the reference algorithm; the reference binary is unbuildable here: HLE
     submodule absent) in the reference's config-1 shape: 1 thread, 80 games, max_len 80, random policy."""
@@ -158,6 +185,7 @@ def main():
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learner", action="store_true", help="skip the R2D2 learner samples/sec measurement")
+    ap.add_argument("--no-actor", action="store_true", help="skip the agent-in-the-loop actor measurement")
     ap.add_argument("--kernel-samples", type=int, default=50)
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank; what the driver uses) | gloo (smoke-testing the multi-rank path with "
@@ -285,6 +313,8 @@ def main():
         }
         if world == 1 and not args.no_learner:
             out["learner"] = learner_bench(dev)
+        if world == 1 and not args.no_actor:
+            out["actor"] = actor_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -49,7 +49,9 @@ class DeviceActor:
         env, agent, P = self.env, self.agent, self.P
         env.reset()
         obs = self._rows()
-        self.history_hid.append({k: v.clone() for k, v in self.hid.items()})        # historyHidden_.push_back(hidden_)
+        # historyHidden_.push_back(hidden_): by reference -- R2D2Agent.act returns fresh state tensors and never writes the
+        # ones it is given, and zero_hidden_rows below only touches the new ones, which enter the history next step
+        self.history_hid.append(dict(self.hid))
         reply, self.hid = agent.act(obs, self.hid)
         fields = dict(obs)
         fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]

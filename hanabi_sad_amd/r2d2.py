@@ -746,7 +746,8 @@ class R2D2Agent:
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
 
     def act(self, obs, hid):
-        """obs: priv_s [N,F], legal_move [N,A], eps [N]; hid: h0,c0 [L,N,H] -> {a, greedy_a}, new hid"""
+        """obs: priv_s [N,F], legal_move [N,A], eps [N]; hid: h0,c0 [L,N,H] -> {a, greedy_a}, new hid
+        The new state is written to fresh tensors; the tensors in `hid` are read only (DeviceActor keeps them as history)."""
         lib = _lib.load_library()
         n = obs["priv_s"].shape[0]
         hd, h, c = self._adv(self.online, obs["priv_s"], hid["h0"], hid["c0"])
