@@ -48,7 +48,9 @@ for k, b in _SYNC.items():   # XCD placement words of the last launch on each bu
     if "m/" not in k[2]: continue
     words = b[:64].cpu().numpy().view("uint64")
     groups = [[int((w >> (6 * i)) & 63) for i in range(8)] for w in words[:16] if w]
-    print("  %s: %d/%d groups on one XCD" % (k[2], sum(max(g) == sum(g) for g in groups), len(groups)), groups[:2])
+    groups = [g for g in groups if sum(g) == 16]     # the words after the last group of a launch are step counters
+    ok = sum(max(g) == sum(g) for g in groups)
+    print("  %s: %d/%d groups on one XCD" % (k[2], ok, len(groups)), groups[:2] if ok == len(groups) else groups)
 if os.environ.get("NO_TORCH"): sys.exit(0)
 # torch eager baseline of the same math (nn.LSTM / MIOpen fp32) -- "what you get without hand-written kernels"
 import torch.nn as nn
