@@ -730,6 +730,137 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
   }
 }
 
+// 256 x 256 tile variant of lstm_cell_gemm_kernel for the big actor batches: 512 threads = 8 waves in a 2 (M) x 4 (N) grid,
+// each wave a 128 x 64 sub-tile (4 x 2 MFMA tiles, 128 accumulator registers), one workgroup per CU with both 64 KB operand
+// buffers in its LDS.  Per staged byte this does twice the MFMA work of the 128 x 128 kernel (whose k loop is bound by the
+// cost of moving operands into LDS, not by the matrix cores) and 0.75 instead of 1 fragment reads per MFMA.
+__global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) {
+  constexpr int BM = 256, BN = 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
+  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_cell);   // [2][BM][64] swizzled
+  bf16_t* sB = sA + 2 * BM * kBK;                       // [2][BN][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int H = a.H, K = a.Kx + H, N4 = 4 * H;
+  const int tiles_n = N4 / BN, tiles_m = (a.Bn + BM - 1) / BM;
+  const bool xcd_order = (gridDim.x % 8) == 0;           // see lstm_cell_gemm_kernel
+  const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
+  const int per_xcd = gridDim.x / n_xcd;
+  int seq = blockIdx.x / n_xcd;
+  int m0 = 0, n0 = 0;
+  auto set_tile = [&](int sq) -> bool {
+    const int mt = (sq / tiles_n) * n_xcd + xcd;
+    n0 = (sq % tiles_n) * BN;
+    m0 = mt * BM;
+    return mt < tiles_m;
+  };
+  // wave w moves the 8-row pieces w, w + 8, w + 16, w + 24 of each operand
+  const int prow = lane >> 3;
+  uint32_t boff[4], aoff_x[4], aoff_h[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rl = (it * 8 + wave) * 8 + prow;
+    boff[it] = (uint32_t)(rl * K + swz_chunk(rl, lane & 7) * 8) * 2u;
+  }
+  auto set_rows = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rl = (it * 8 + wave) * 8 + prow;
+      const int gr = min(m0 + rl, a.Bn - 1);
+      const int ch = swz_chunk(rl, lane & 7) * 8;
+      aoff_x[it] = (uint32_t)(gr * a.ldx + ch) * 2u;
+      aoff_h[it] = (uint32_t)(gr * H + ch) * 2u;
+    }
+  };
+  auto issue_tile = [&](int k0, int buf) {
+    const bool part2 = k0 >= a.Kx;
+    const char* abase = reinterpret_cast<const char*>(part2 ? a.h_prev16 + (k0 - a.Kx) : a.x + k0);
+    const char* bbase = reinterpret_cast<const char*>(a.Wcat + (size_t)n0 * K + k0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int piece = it * 8 + wave;
+      glds16(reinterpret_cast<const bf16_t*>(abase + (part2 ? aoff_h[it] : aoff_x[it])), sA + (buf * BM + piece * 8) * kBK);
+      glds16(reinterpret_cast<const bf16_t*>(bbase + boff[it]), sB + (buf * BN + piece * 8) * kBK);
+    }
+  };
+
+  if (!set_tile(seq)) return;
+  set_rows();
+  issue_tile(0, 0);
+  const int nk = K / kBK;
+  for (;;) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 1 < nk) issue_tile((kt + 1) * kBK, cur ^ 1);
+      const bf16_t* pa = sA + cur * BM * kBK;
+      const bf16_t* pb = sB + cur * BN * kBK;
+#pragma unroll
+      for (int kk = 0; kk < kBK / 16; ++kk) {
+        bf16x8 fa[4], fb[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = lds_frag_swz(pb, wn * 64 + j * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = lds_frag_swz(pa, wm * 128 + i * 32, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue (as lstm_cell_gemm_kernel: lo lanes hold {i, g}, hi lanes {f, o} of unit (lane & 15)) ----
+    const int cm0 = m0, cn0 = n0;
+    const bool hi = (lane & 16) != 0;
+    const int unit = (cn0 + wn * 64) / 4 + (lane & 15);
+    const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
+    const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
+    const int rsub = 4 * (lane >> 5) + (hi ? 16 : 0);
+    seq += per_xcd;
+    const bool more = set_tile(seq);
+    if (more) {                                // buffer 0 was last read in step nk - 2 when nk is even
+      if (nk & 1) __syncthreads();
+      set_rows();
+      issue_tile(0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float cp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int row = cm0 + wm * 128 + i * 32 + (k & 3) + 8 * (k >> 2) + rsub;
+        cp[k] = row < a.Bn ? a.c_prev[(size_t)row * H + unit] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float l0 = acc[i][0][k], h0 = acc[i][0][8 + k], l1 = acc[i][1][k], h1 = acc[i][1][8 + k];
+        asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
+        const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);
+        const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
+        const int row = cm0 + wm * 128 + i * 32 + (k & 3) + 8 * (k >> 2) + rsub;
+        if (row >= a.Bn) continue;
+        const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
+        const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
+        const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
+        const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
+        const float c = gf * cp[k] + gi * gg;
+        const float h = go * tanhf_(c);
+        a.c_out[(size_t)row * H + unit] = c;
+        a.h_out32[(size_t)row * H + unit] = h;
+        if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
+      }
+    }
+    if (!more) break;
+  }
+}
+
 // Small-batch variant (learner: Bn = 128): block = 32 rows x 32 hidden units, 4 waves in a 2x2 grid, each wave
 // owning 16 rows x 16 units with FOUR 16x16 accumulators (i,f,g,o) over the full K — no cross-wave reduction and
 // the transcendental-heavy cell update is spread over all four waves.  v_mfma_f32_16x16x32_bf16: lane l holds
@@ -2057,14 +2188,25 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
   }
   LstmCellArgs a{(const bf16_t*)x16, (const bf16_t*)h_prev16, (const bf16_t*)Wcat_gate16, bias_gate16, c_prev, c_out, h_out32, (bf16_t*)h_out16,
                  Bn, H, Kx, ldx};
-  const size_t lds = (size_t)2 * (128 + 128) * kBK * sizeof(bf16_t);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   if ((size_t)Bn * (size_t)std::max(ldx, H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands of 4 GB and more are not supported (32-bit offsets)");
-  const long tiles = (long)(4 * H / 128) * ((Bn + 127) / 128);
-  long grid = std::min<long>(tiles, 2L * n_cu);
-  if (grid >= 64) grid &= ~7L;       // a multiple of 8 switches the kernel to its XCD-aware tile order
-  hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+  static const int force_tile = getenv("HSAD_CELL_TILE") ? atoi(getenv("HSAD_CELL_TILE")) : 0;   // developer switch: 128 | 256
+  const bool big = force_tile ? force_tile == 256 : (Bn >= 4096 && (4 * H) % 256 == 0);
+  if (big && (4 * H) % 256 == 0) {
+    const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long tiles = (long)(4 * H / 256) * ((Bn + 255) / 256);
+    long grid = std::min<long>(tiles, (long)n_cu);
+    if (grid >= 64) grid &= ~7L;
+    hipLaunchKernelGGL(lstm_cell_gemm256_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+  } else {
+    const size_t lds = (size_t)2 * (128 + 128) * kBK * sizeof(bf16_t);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long tiles = (long)(4 * H / 128) * ((Bn + 127) / 128);
+    long grid = std::min<long>(tiles, 2L * n_cu);
+    if (grid >= 64) grid &= ~7L;       // a multiple of 8 switches the kernel to its XCD-aware tile order
+    hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
+  }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -411,7 +411,7 @@ def test_act_leaves_its_input_state_untouched():
             assert torch.equal(hid[k], keep[k]) and new[k].data_ptr() != hid[k].data_ptr()
 
 
-@pytest.mark.parametrize("N,H", [(3000, 512), (1025, 256)])
+@pytest.mark.parametrize("N,H", [(3000, 512), (1025, 256), (4200, 512), (4355, 256)])   # >= 4096 rows: 256x256 tiles
 def test_fused_inference_cell_matches_the_two_kernel_path(N, H):
     """net.step (one fused [x|h][W_ih|W_hh]^T GEMM + cell kernel per layer, gate16 column order) vs net.trunk at T = 1
     (projection GEMM + per-step LSTM kernel): the same bf16 operands and fp32 accumulation, different summation order"""
