@@ -116,11 +116,13 @@ def learner_bench(dev, updates=20, warmup=3):
     }
 
 
-def actor_bench(dev, games=16384, steps=40, warmup=30):
+def actor_bench(dev, games=16384, steps=160, warmup=120):
     """The rollout with the agent in the loop (SURVEY.md §8 rows a/f; what the reference's actor threads + BatchRunner do):
     one DeviceActor.step() = reset finished games -> observe -> R2D2 act (eps-greedy, SAD greedy action) -> env step ->
     n-step pop -> compute_priority (online + target nets) -> sequence push -> flush finished sequences into the
-    prioritized replay.  2-player SAD IQL, H=512, 2-layer LSTM; acts = games x players per step (utils.py:229-236)."""
+    prioritized replay.  2-player SAD IQL, H=512, 2-layer LSTM; acts = games x players per step (utils.py:229-236).
+    Warm-up runs past the first episode ends (all games start together) and the timed window spans two max-length
+    episodes, so the per-step average includes the steady-state rate of finished sequences being flushed."""
     from hanabi_sad_amd.selfplay import Trainer, parse_args
     args = parse_args(["--num_game", str(games), "--replay_buffer_size", "65536", "--sad", "1"])
     tr = Trainer(args, str(dev))

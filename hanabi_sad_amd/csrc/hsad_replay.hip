@@ -477,17 +477,8 @@ __global__ void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const f
   const int nq = row_bytes / 16;
   for (int j = threadIdx.x; j < nq; j += blockDim.x) dst[j] = src[j];
   const unsigned char term = sd.pend_terminal[e];
-  if (term) {  // pad the rest of the sequence: zeros, terminal = 1, bootstrap = 0, priority 0
-    uint4* pad = reinterpret_cast<uint4*>(sd.st_rows + ((size_t)e * sd.T + idx + 1) * row_bytes);
-    const size_t npad = (size_t)(sd.T - idx - 1) * nq;
-    for (size_t j = threadIdx.x; j < npad; j += blockDim.x) pad[j] = make_uint4(0, 0, 0, 0);
-    for (int t = idx + 1 + threadIdx.x; t < sd.T; t += blockDim.x) {
-      sd.st_reward[(size_t)e * sd.T + t] = 0.f;
-      sd.st_terminal[(size_t)e * sd.T + t] = 1;
-      sd.st_bootstrap[(size_t)e * sd.T + t] = 0.f;
-      sd.st_prio[(size_t)e * sd.T + t] = 0.f;
-    }
-  }
+  // the padding of a finished sequence (zeros, terminal = 1, bootstrap = 0, priority 0: transition.cc:29-40) is not written
+  // here: seq_flush_copy_kernel writes it straight into the replay ring, and nothing else reads staging rows past len[e]
   if (threadIdx.x == 0) {
     sd.st_reward[(size_t)e * sd.T + idx] = sd.pend_reward[e];
     sd.st_terminal[(size_t)e * sd.T + idx] = term;
@@ -541,7 +532,7 @@ __global__ __launch_bounds__(256) void seq_aggregate_kernel(SeqDev sd, float eta
   float mx = 0.f;
   double sum = 0.0;
   for (int t = lane; t < sd.T; t += 64) {
-    const float p = sd.st_prio[(size_t)e * sd.T + t] * (t < L ? 1.f : 0.f);
+    const float p = t < L ? sd.st_prio[(size_t)e * sd.T + t] : 0.f;   // padding priority 0; staging past L is stale
     sum += p;
     mx = fmaxf(mx, p);      // priorities are absolute TD errors (>= 0), as is the padding
   }
@@ -555,21 +546,41 @@ __global__ __launch_bounds__(256) void seq_aggregate_kernel(SeqDev sd, float eta
   }
 }
 
-// copy finished staging sequences into the replay ring (rows + scalars), then reset the env's cursor
-__global__ void seq_flush_copy_kernel(SeqDev sd, ReplayDev rd, int row_bytes, unsigned char* r_rows, float* r_reward,
-                                      unsigned char* r_terminal, float* r_bootstrap, float* r_seq_len) {
-  const int total = rd.ctl->add_n * sd.T;  // rows to move; grid-stride because the count only exists on the device
-  for (int row = blockIdx.x; row < total; row += gridDim.x) {
+// Finished staging sequences -> replay ring (rows + scalars).  One wavefront per (sequence, step) row, up to four 16-byte
+// chunks per lane in flight; steps past the sequence's length are not copied but written as the reference's padding
+// (R2D2Buffer::push -> padLike, transition_buffer.h:150-166 / transition.cc:29-40: zeros, terminal = 1, bootstrap = 0).
+__global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDev rd, int row_bytes, unsigned char* r_rows,
+                                                             float* r_reward, unsigned char* r_terminal, float* r_bootstrap,
+                                                             float* r_seq_len) {
+  const int n_add = rd.ctl->add_n, start = rd.ctl->add_start;   // the count only exists on the device: grid-stride
+  const int total = n_add * sd.T;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nq = row_bytes / 16;
+  for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
     const int k = row / sd.T, t = row - k * sd.T;
     const int e = sd.fin_env[k];
-    const int slot = (rd.ctl->add_start + k) % rd.ring;
-    const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
+    const int L = sd.len[e];
+    const int slot = (start + k) % rd.ring;
     uint4* dst = reinterpret_cast<uint4*>(r_rows + ((size_t)slot * sd.T + t) * row_bytes);
-    for (int j = threadIdx.x; j < row_bytes / 16; j += blockDim.x) dst[j] = src[j];
-    if (threadIdx.x == 0) {
-      r_reward[(size_t)slot * sd.T + t] = sd.st_reward[(size_t)e * sd.T + t];
-      r_terminal[(size_t)slot * sd.T + t] = sd.st_terminal[(size_t)e * sd.T + t];
-      r_bootstrap[(size_t)slot * sd.T + t] = sd.st_bootstrap[(size_t)e * sd.T + t];
+    if (t < L) {
+      const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
+      for (int j0 = lane; j0 < nq; j0 += 256) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + 64 * u < nq) v[u] = src[j0 + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + 64 * u < nq) dst[j0 + 64 * u] = v[u];
+      }
+    } else {
+      for (int j = lane; j < nq; j += 64) dst[j] = make_uint4(0, 0, 0, 0);
+    }
+    if (lane == 0) {
+      const size_t o = (size_t)slot * sd.T + t, i = (size_t)e * sd.T + t;
+      r_reward[o] = t < L ? sd.st_reward[i] : 0.f;
+      r_terminal[o] = t < L ? sd.st_terminal[i] : (unsigned char)1;
+      r_bootstrap[o] = t < L ? sd.st_bootstrap[i] : 0.f;
       if (t == 0) r_seq_len[slot] = sd.fin_len[k];
     }
   }
@@ -597,7 +608,12 @@ struct hsad_replay {
   float* bootstrap;
   float* seq_len;  // [ring]
   float* d_canon;  // [kMaxBatch] canonical uniforms for the sample in flight
-  std::vector<float> h_canon;  // pageable staging (hipMemcpyAsync copies it before returning)
+  // pinned staging ring for the uniforms: an async copy from PAGEABLE memory makes the host wait for everything queued on
+  // the stream before it (a whole actor step in the self-play loop); slot k is reused once the copy recorded in ev[k] is done
+  static constexpr int kCanonSlots = 8;
+  float* h_canon_ring = nullptr;   // [kCanonSlots][kMaxBatch], hipHostMalloc
+  hipEvent_t canon_ev[kCanonSlots] = {};
+  int canon_next = 0;
   int* d_tmp_id;
   std::mt19937 rng;
   hipStream_t last_stream;
@@ -675,7 +691,14 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
     hsad_replay_destroy(r);
     return HSAD_ERR_NOMEM;
   }
-  r->h_canon.resize(kMaxBatch);
+  he = hipHostMalloc((void**)&r->h_canon_ring, sizeof(float) * hsad_replay::kCanonSlots * kMaxBatch, hipHostMallocDefault);
+  for (int k = 0; k < hsad_replay::kCanonSlots && he == hipSuccess; ++k)
+    he = hipEventCreateWithFlags(&r->canon_ev[k], hipEventDisableTiming);
+  if (he != hipSuccess) {
+    rfail(HSAD_ERR_HIP, "pinned staging for the replay sampler: %s", hipGetErrorString(he));
+    hsad_replay_destroy(r);
+    return HSAD_ERR_HIP;
+  }
   HIP_TRY(hipMemset(rd.ctl, 0, sizeof(ReplayCtl)));
   HIP_TRY(hipMemset(rd.weights, 0, ring * 4));
   HIP_TRY(hipMemset(rd.evicted, 0, ring));
@@ -691,7 +714,22 @@ void hsad_replay_destroy(hsad_replay* r) {
                   r->rd.sampled_ids, r->rd.sampled_w, r->d_canon, r->d_tmp_id};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (hipEvent_t e : r->canon_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (r->h_canon_ring) (void)hipHostFree(r->h_canon_ring);
   delete r;
+}
+
+// next pinned staging slot for n uniforms; upload_canon queues the copy to d_canon and marks the slot busy until it is done
+static float* canon_slot(hsad_replay* r, int* slot) {
+  *slot = r->canon_next;
+  r->canon_next = (r->canon_next + 1) % hsad_replay::kCanonSlots;
+  (void)hipEventSynchronize(r->canon_ev[*slot]);   // returns at once for an event never recorded / long finished
+  return r->h_canon_ring + (size_t)*slot * kMaxBatch;
+}
+static hipError_t upload_canon(hsad_replay* r, int slot, int n, hipStream_t s) {
+  hipError_t e = hipMemcpyAsync(r->d_canon, r->h_canon_ring + (size_t)slot * kMaxBatch, sizeof(float) * n, hipMemcpyHostToDevice, s);
+  return e != hipSuccess ? e : hipEventRecord(r->canon_ev[slot], s);
 }
 
 int64_t hsad_replay_bytes(const hsad_replay* r) { return r ? r->bytes : 0; }
@@ -725,8 +763,10 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   // canonical uniforms exactly as std::uniform_real_distribution<float> would draw them (libstdc++:
   // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
   // the segment depends on the device-side running sum)
-  for (int i = 0; i < batch; ++i) r->h_canon[i] = std::generate_canonical<float, 24>(r->rng);
-  HIP_TRY(hipMemcpyAsync(r->d_canon, r->h_canon.data(), sizeof(float) * batch, hipMemcpyHostToDevice, s));
+  int slot;
+  float* hc = canon_slot(r, &slot);
+  for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
+  HIP_TRY(upload_canon(r, slot, batch, s));
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight);
   FieldPtrsMut fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
@@ -762,8 +802,12 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (n < 0 || n > kMaxBatch || (n > 0 && (!targets_host || !raw_weight))) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  for (int i = 0; i < n; ++i) r->h_canon[i] = targets_host[i];
-  if (n > 0) HIP_TRY(hipMemcpyAsync(r->d_canon, r->h_canon.data(), sizeof(float) * n, hipMemcpyHostToDevice, s));
+  if (n > 0) {
+    int slot;
+    float* hc = canon_slot(r, &slot);
+    for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
+    HIP_TRY(upload_canon(r, slot, n, s));
+  }
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon);
   if (n > 0) {
     FieldPtrsMut fp;
@@ -968,7 +1012,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
   hipLaunchKernelGGL(seq_aggregate_kernel, dim3((sd.E + 3) / 4), dim3(256), 0, s, sd, eta, c1m);
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
-  hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min(sd.E * sd.T, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
+  hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min((sd.E * sd.T + 3) / 4, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);
   hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl);
   HIP_TRY(hipGetLastError());

@@ -109,9 +109,10 @@ class ShardedReplay:
     `shard` needs priority_sum() -> (sum, size), draw_canonical(n), sample_at(targets) and update_priority(p) --
     hanabi_sad_amd.replay.DeviceReplay on a GPU, any stand-in with the same methods in the gloo CPU tests."""
 
-    def __init__(self, shard, beta, device, learner_rank=0):
+    def __init__(self, shard, beta, device, learner_rank=0, host_path=False):
         import torch.distributed as dist
         self.shard, self.beta, self.device, self.learner = shard, float(beta), torch.device(device), learner_rank
+        self.host_path = bool(host_path)   # tests: take the collective code path (host positions, sample_at) with one shard
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.rank = dist.get_rank() if self.on else 0
         self.world = dist.get_world_size() if self.on else 1
@@ -131,6 +132,11 @@ class ShardedReplay:
 
     def sample(self, batch):
         import numpy as np
+        if not self.on and not self.host_path and hasattr(self.shard, "sample"):
+            # one shard: the plain device-side sampler draws the same batch (tests/test_sharded_replay_gpu.py) without
+            # reading the priority sum back to the host, so the host keeps running ahead of the GPU
+            self._owner = np.full(batch, self.rank, dtype=np.int64)
+            return self.shard.sample(batch)
         sums, sizes = self._gather_sums()
         canon = torch.zeros(batch, dtype=torch.float32, device=self.comm)
         if self.rank == self.learner:

@@ -37,7 +37,7 @@ def test_one_shard_equals_plain_sample_including_eviction_and_updates():
     cap, B = 48, 16
     plain = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
     shard = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
-    sr = ShardedReplay(shard, 0.6, DEV)
+    sr = ShardedReplay(shard, 0.6, DEV, host_path=True)
     rng = np.random.default_rng(0)
     base = 0
     for it in range(6):
