@@ -112,10 +112,11 @@ __global__ void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows
 // rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
 // or, with ids == nullptr, row index base_row + b (T must be 1 then) .
 __global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldPtrsMut dst, int B, int T,
-                                   const int* __restrict__ ids, int base_row) {
+                                   const int* __restrict__ ids, int base_row, const int* __restrict__ valid_rows = nullptr) {
   const int row = blockIdx.x;  // = t*B + b
   const int t = row / B, b = row - t * B;
   const size_t src_row = ids ? ((size_t)ids[b] * T + t) : ((size_t)base_row + b);
+  const bool pad = valid_rows && ids && t >= valid_rows[ids[b]];   // a step after the stored ones: all-zero fields
   const unsigned char* s = rows + src_row * L.row_bytes;
   for (int k = 0; k < L.n_fields; ++k) {
     if (!dst.p[k]) continue;
@@ -124,9 +125,9 @@ __global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, Field
     if (L.esize[k] >= 4) {
       const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s + L.offset[k]);
       uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
-      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = s4[j];
+      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = pad ? 0u : s4[j];
     } else {
-      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) d[j] = s[L.offset[k] + j];
+      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) d[j] = pad ? (unsigned char)0 : s[L.offset[k] + j];
     }
   }
 }
@@ -135,14 +136,16 @@ __global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, Field
 __global__ void gather_scalars_kernel(const float* __restrict__ reward, const unsigned char* __restrict__ terminal,
                                       const float* __restrict__ bootstrap, const float* __restrict__ seq_len,
                                       const int* __restrict__ ids, int B, int T, float* o_reward,
-                                      unsigned char* o_terminal, float* o_bootstrap, float* o_seq_len) {
+                                      unsigned char* o_terminal, float* o_bootstrap, float* o_seq_len,
+                                      const int* __restrict__ valid_rows) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= T * B) return;
   const int t = idx / B, b = idx - t * B;
   const size_t s = (size_t)ids[b] * T + t;
-  if (o_reward) o_reward[idx] = reward[s];
-  if (o_terminal) o_terminal[idx] = terminal[s];
-  if (o_bootstrap) o_bootstrap[idx] = bootstrap[s];
+  const bool pad = t >= valid_rows[ids[b]];
+  if (o_reward) o_reward[idx] = pad ? 0.f : reward[s];
+  if (o_terminal) o_terminal[idx] = pad ? (unsigned char)1 : terminal[s];
+  if (o_bootstrap) o_bootstrap[idx] = pad ? 0.f : bootstrap[s];
   if (t == 0 && o_seq_len) o_seq_len[b] = seq_len[ids[b]];
 }
 
@@ -161,6 +164,9 @@ struct ReplayDev {
   unsigned char* evicted;
   int* sampled_ids;
   float* sampled_w;
+  int* valid_rows;   // [ring] steps of the slot's sequence that are stored; readers materialise the reference's padding
+                     // (zeros, terminal = 1, bootstrap = 0) for the steps after them.  T for hsad_replay_add, the episode
+                     // length for sequences flushed by the sequence writer (which therefore never writes padding)
   int ring, capacity;
   float alpha, beta;
 };
@@ -245,7 +251,10 @@ __global__ void replay_add_scalars_kernel(ReplayDev rd, int n, int T, const floa
   s_reward[d] = reward[idx];
   s_terminal[d] = terminal[idx];
   s_bootstrap[d] = bootstrap[idx];
-  if (t == 0) s_seq_len[(start + i) % rd.ring] = seq_len[i];
+  if (t == 0) {
+    s_seq_len[(start + i) % rd.ring] = seq_len[i];
+    rd.valid_rows[(start + i) % rd.ring] = T;
+  }
 }
 
 // PrioritizedReplay::sample_ (rela/prioritized_replay.h:274-345) as one block.
@@ -478,7 +487,7 @@ __global__ void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const f
   for (int j = threadIdx.x; j < nq; j += blockDim.x) dst[j] = src[j];
   const unsigned char term = sd.pend_terminal[e];
   // the padding of a finished sequence (zeros, terminal = 1, bootstrap = 0, priority 0: transition.cc:29-40) is not written
-  // here: seq_flush_copy_kernel writes it straight into the replay ring, and nothing else reads staging rows past len[e]
+  // here or anywhere: the replay's readers produce it (valid_rows), and nothing else reads staging rows past len[e]
   if (threadIdx.x == 0) {
     sd.st_reward[(size_t)e * sd.T + idx] = sd.pend_reward[e];
     sd.st_terminal[(size_t)e * sd.T + idx] = term;
@@ -547,8 +556,10 @@ __global__ __launch_bounds__(256) void seq_aggregate_kernel(SeqDev sd, float eta
 }
 
 // Finished staging sequences -> replay ring (rows + scalars).  One wavefront per (sequence, step) row, up to four 16-byte
-// chunks per lane in flight; steps past the sequence's length are not copied but written as the reference's padding
-// (R2D2Buffer::push -> padLike, transition_buffer.h:150-166 / transition.cc:29-40: zeros, terminal = 1, bootstrap = 0).
+// chunks per lane in flight.  Only the len stored steps move: the reference's padding (R2D2Buffer::push -> padLike,
+// transition_buffer.h:150-166 / transition.cc:29-40: zeros, terminal = 1, bootstrap = 0) is never written -- valid_rows
+// [slot] = len tells the readers (sample / sample_at / get) to produce it.  With untrained agents episodes last ~10 of the
+// 80 steps, so this is 8x less replay traffic per finished episode.
 __global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDev rd, int row_bytes, unsigned char* r_rows,
                                                              float* r_reward, unsigned char* r_terminal, float* r_bootstrap,
                                                              float* r_seq_len) {
@@ -561,27 +572,27 @@ __global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDe
     const int e = sd.fin_env[k];
     const int L = sd.len[e];
     const int slot = (start + k) % rd.ring;
+    if (t == 0 && lane == 0) {
+      r_seq_len[slot] = sd.fin_len[k];
+      rd.valid_rows[slot] = L;
+    }
+    if (t >= L) continue;
     uint4* dst = reinterpret_cast<uint4*>(r_rows + ((size_t)slot * sd.T + t) * row_bytes);
-    if (t < L) {
-      const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
-      for (int j0 = lane; j0 < nq; j0 += 256) {
-        uint4 v[4];
+    const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
+    for (int j0 = lane; j0 < nq; j0 += 256) {
+      uint4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + 64 * u < nq) v[u] = src[j0 + 64 * u];
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 64 * u < nq) v[u] = src[j0 + 64 * u];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (j0 + 64 * u < nq) dst[j0 + 64 * u] = v[u];
-      }
-    } else {
-      for (int j = lane; j < nq; j += 64) dst[j] = make_uint4(0, 0, 0, 0);
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 64 * u < nq) dst[j0 + 64 * u] = v[u];
     }
     if (lane == 0) {
       const size_t o = (size_t)slot * sd.T + t, i = (size_t)e * sd.T + t;
-      r_reward[o] = t < L ? sd.st_reward[i] : 0.f;
-      r_terminal[o] = t < L ? sd.st_terminal[i] : (unsigned char)1;
-      r_bootstrap[o] = t < L ? sd.st_bootstrap[i] : 0.f;
-      if (t == 0) r_seq_len[slot] = sd.fin_len[k];
+      r_reward[o] = sd.st_reward[i];
+      r_terminal[o] = sd.st_terminal[i];
+      r_bootstrap[o] = sd.st_bootstrap[i];
     }
   }
 }
@@ -685,6 +696,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
       (he = alloc((void**)&rd.ctl, sizeof(ReplayCtl))) != hipSuccess ||
       (he = alloc((void**)&rd.sampled_ids, kMaxBatch * 4)) != hipSuccess ||
       (he = alloc((void**)&rd.sampled_w, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&rd.valid_rows, ring * 4)) != hipSuccess ||
       (he = alloc((void**)&r->d_canon, kMaxBatch * 4)) != hipSuccess ||
       (he = alloc((void**)&r->d_tmp_id, 16)) != hipSuccess) {
     rfail(HSAD_ERR_NOMEM, "hipMalloc failed for the replay (%zu B so far): %s", total, hipGetErrorString(he));
@@ -702,6 +714,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
   HIP_TRY(hipMemset(rd.ctl, 0, sizeof(ReplayCtl)));
   HIP_TRY(hipMemset(rd.weights, 0, ring * 4));
   HIP_TRY(hipMemset(rd.evicted, 0, ring));
+  HIP_TRY(hipMemset(rd.valid_rows, 0, ring * 4));
   r->bytes = (int64_t)total;
   *out = r;
   return HSAD_OK;
@@ -711,7 +724,7 @@ void hsad_replay_destroy(hsad_replay* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   void* ptrs[] = {r->rows, r->reward, r->terminal, r->bootstrap, r->seq_len, r->rd.weights, r->rd.evicted, r->rd.ctl,
-                  r->rd.sampled_ids, r->rd.sampled_w, r->d_canon, r->d_tmp_id};
+                  r->rd.sampled_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : r->canon_ev)
@@ -771,9 +784,10 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   FieldPtrsMut fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
   hipLaunchKernelGGL(unpack_rows_kernel, dim3(batch * r->T), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
-                     r->rd.sampled_ids, 0);
+                     r->rd.sampled_ids, 0, r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((batch * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
-                     r->bootstrap, r->seq_len, r->rd.sampled_ids, batch, r->T, reward, terminal, bootstrap, seq_len);
+                     r->bootstrap, r->seq_len, r->rd.sampled_ids, batch, r->T, reward, terminal, bootstrap, seq_len,
+                     r->rd.valid_rows);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -812,9 +826,11 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (n > 0) {
     FieldPtrsMut fp;
     for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0);
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,
+                       r->rd.valid_rows);
     hipLaunchKernelGGL(gather_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
-                       r->bootstrap, r->seq_len, r->rd.sampled_ids, n, r->T, reward, terminal, bootstrap, seq_len);
+                       r->bootstrap, r->seq_len, r->rd.sampled_ids, n, r->T, reward, terminal, bootstrap, seq_len,
+                       r->rd.valid_rows);
   }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -855,9 +871,10 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
   hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
   FieldPtrsMut fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
-  hipLaunchKernelGGL(unpack_rows_kernel, dim3(r->T), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0);
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3(r->T), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
+                     r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
-                     r->bootstrap, r->seq_len, r->d_tmp_id, 1, r->T, reward, terminal, bootstrap, seq_len);
+                     r->bootstrap, r->seq_len, r->d_tmp_id, 1, r->T, reward, terminal, bootstrap, seq_len, r->rd.valid_rows);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

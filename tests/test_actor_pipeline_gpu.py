@@ -34,6 +34,15 @@ def test_actor_fills_replay_with_well_formed_sequences_and_learner_trains():
         assert (f["priv_s"][:L, :125] == 0).all()                                                   # own-hand block hidden
         assert bootstrap[:L].cpu().numpy()[max(0, L - args.multi_step):].sum() == 0                 # no bootstrap past the end
         assert ((f["own_hand"][:L].view(L, 5, 3).sum(2) <= 1).all())
+    # the same padding through the sampling path (the flush stores only the len real steps; readers materialise the rest)
+    (f, reward, terminal, bootstrap, seq_len), weight = tr.replay.sample(16)
+    for b in range(16):
+        L = int(seq_len[b].item())
+        assert 1 <= L <= T and f["priv_s"][L:, b].abs().sum() == 0 and f["legal_move"][L:, b].abs().sum() == 0
+        assert f["a"][L:, b].abs().sum() == 0 and reward[L:, b].abs().sum() == 0 and bootstrap[L:, b].sum() == 0
+        assert terminal[L:, b].all() and bool(terminal[L - 1, b]) and not terminal[:L - 1, b].any()
+        assert f["legal_move"][:L, b].sum(1).min() >= 1
+    tr.replay.update_priority(torch.ones(16, device="cuda:0"))
     w0 = tr.learner.flat.clone()
     losses = []
     for _ in range(6):
