@@ -255,18 +255,23 @@ def main():
         elapsed = float(t.item())
     env.check_errors()
 
-    # the API's separate step kernel (actions from HBM), timed the same way for reference
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.kernel_samples)]
-    for e0, e1 in ev:
-        env.reset()
-        a, g = env.policy_random(policy_seed)
-        e0.record()
-        env.step(a, g)
-        e1.record()
-    torch.cuda.synchronize()
+    # the API's separate step kernel (actions from HBM) for reference: one event pair per launch.  The two records put
+    # barrier / timestamp packets around the kernel; what an EMPTY pair measures under the same conditions is subtracted.
+    def pairs(with_step):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.kernel_samples)]
+        for e0, e1 in ev:
+            env.reset()
+            a, g = env.policy_random(policy_seed)
+            e0.record()
+            if with_step:
+                env.step(a, g)
+            e1.record()
+        torch.cuda.synchronize()
+        return sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
+    pairs(True)
+    step_raw_ms, pair_overhead_ms = pairs(True), pairs(False)
+    step_ms = step_raw_ms - pair_overhead_ms
     env.check_errors()
-    step_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / len(ev)
     bytes_per_step = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, False)
     achieved_step = bytes_per_step * G / (step_ms * 1e-3) / 1e9
     achieved = bytes_per_step * G / (iter_ms * 1e-3) / 1e9        # all concurrent launches together = the chip's rate
@@ -311,6 +316,7 @@ def main():
                                           "hsad_env_step entry point)",
                 "achieved": achieved_step, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_step / HBM_PEAK_GBS,
                 "traffic": measured_traffic_bytes(G, 1), "avg_launch_ms": step_ms,
+                "event_pair_ms": step_raw_ms, "empty_event_pair_ms": pair_overhead_ms,
             },
         }
         if world == 1 and not args.no_learner:
