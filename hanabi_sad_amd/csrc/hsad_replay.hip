@@ -82,15 +82,40 @@ struct FieldPtrsMut {
   void* p[kMaxFields];
 };
 
-// One block per row.  src element (i, t) of field k lives at ((i*src_T + t) * width_k); dst row index is
-// given by dst_row(i, t).  n_dev (optional) bounds i.
+// One WAVEFRONT per row (4 rows per 256-thread block).  src element (i, t) of field k lives at ((i*src_T + t) * width_k);
+// dst row index is given by dst_row(i, t).  n_dev (optional) bounds i.
 enum RowMap : int { MAP_RING = 0, MAP_LINEAR = 1 };
+
+// nbytes from s to d (or zeros) by one wavefront: 8-byte accesses when both ends allow (row offsets are 8-byte aligned by
+// make_layout; a field's own rows are when width * esize is a multiple of 8, e.g. the 838-float observation), four per
+// lane in flight so that a 3 KB row is two load rounds instead of a chain of thirteen dependent 4-byte ones
+template <typename W>
+__device__ __forceinline__ void copy_words_wave(unsigned char* d, const unsigned char* s, int n_words, int lane, bool zero) {
+  W* dw = reinterpret_cast<W*>(d);
+  const W* sw = reinterpret_cast<const W*>(s);
+  for (int j0 = lane; j0 < n_words; j0 += 256) {
+    W v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = (!zero && j0 + 64 * u < n_words) ? sw[j0 + 64 * u] : W{};
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + 64 * u < n_words) dw[j0 + 64 * u] = v[u];
+  }
+}
+__device__ __forceinline__ void copy_bytes_wave(unsigned char* d, const unsigned char* s, int nbytes, int lane, bool zero) {
+  const uintptr_t mix = (uintptr_t)d | (uintptr_t)s | (uintptr_t)nbytes;
+  if ((mix & 7) == 0) copy_words_wave<uint2>(d, s, nbytes / 8, lane, zero);
+  else if ((mix & 3) == 0) copy_words_wave<uint32_t>(d, s, nbytes / 4, lane, zero);
+  else copy_words_wave<unsigned char>(d, s, nbytes, lane, zero);
+}
 
 // fields [n][T][w]  ->  rows[(slot0 + i) % ring][t]     (replay add)
 // fields [E][w] (T=1) -> rows[base_row + e]             (history ring push)
-__global__ void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows, int n, int T, int map, int slot0,
-                                 int ring, const int* __restrict__ n_dev, const int* __restrict__ slot0_dev) {
-  const int row = blockIdx.x;
+__global__ __launch_bounds__(256) void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows, int n, int T, int map,
+                                                        int slot0, int ring, const int* __restrict__ n_dev,
+                                                        const int* __restrict__ slot0_dev) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n * T) return;
   const int i = row / T, t = row - i * T;
   if (n_dev && i >= *n_dev) return;
   const int s0 = slot0_dev ? *slot0_dev : slot0;
@@ -98,22 +123,17 @@ __global__ void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows
   unsigned char* dst = rows + dst_row * L.row_bytes;
   for (int k = 0; k < L.n_fields; ++k) {
     const int nbytes = L.width[k] * L.esize[k];
-    const unsigned char* s = static_cast<const unsigned char*>(src.p[k]) + (size_t)row * nbytes;
-    if (L.esize[k] >= 4) {
-      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s);
-      uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + L.offset[k]);
-      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = s4[j];
-    } else {
-      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) dst[L.offset[k] + j] = s[j];
-    }
+    copy_bytes_wave(dst + L.offset[k], static_cast<const unsigned char*>(src.p[k]) + (size_t)row * nbytes, nbytes, lane, false);
   }
 }
 
 // rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
 // or, with ids == nullptr, row index base_row + b (T must be 1 then) .
-__global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldPtrsMut dst, int B, int T,
-                                   const int* __restrict__ ids, int base_row, const int* __restrict__ valid_rows = nullptr) {
-  const int row = blockIdx.x;  // = t*B + b
+__global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldPtrsMut dst, int B, int T,
+                                                          const int* __restrict__ ids, int base_row,
+                                                          const int* __restrict__ valid_rows = nullptr) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // = t*B + b
+  if (row >= B * T) return;
   const int t = row / B, b = row - t * B;
   const size_t src_row = ids ? ((size_t)ids[b] * T + t) : ((size_t)base_row + b);
   const bool pad = valid_rows && ids && t >= valid_rows[ids[b]];   // a step after the stored ones: all-zero fields
@@ -121,14 +141,7 @@ __global__ void unpack_rows_kernel(RowLayout L, const unsigned char* rows, Field
   for (int k = 0; k < L.n_fields; ++k) {
     if (!dst.p[k]) continue;
     const int nbytes = L.width[k] * L.esize[k];
-    unsigned char* d = static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes;
-    if (L.esize[k] >= 4) {
-      const uint32_t* s4 = reinterpret_cast<const uint32_t*>(s + L.offset[k]);
-      uint32_t* d4 = reinterpret_cast<uint32_t*>(d);
-      for (int j = threadIdx.x; j < nbytes / 4; j += blockDim.x) d4[j] = pad ? 0u : s4[j];
-    } else {
-      for (int j = threadIdx.x; j < nbytes; j += blockDim.x) d[j] = pad ? (unsigned char)0 : s[L.offset[k] + j];
-    }
+    copy_bytes_wave(static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes, s + L.offset[k], nbytes, lane, pad);
   }
 }
 
@@ -759,7 +772,7 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
   // payload rows; add_n (<= n) from the control block bounds the copy
-  hipLaunchKernelGGL(pack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, fp, r->rows, n, r->T, (int)MAP_RING, 0,
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, fp, r->rows, n, r->T, (int)MAP_RING, 0,
                      r->rd.ring, &r->rd.ctl->add_n, &r->rd.ctl->add_start);
   hipLaunchKernelGGL(replay_add_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->rd, n, r->T, reward,
                      terminal, bootstrap, seq_len, r->reward, r->terminal, r->bootstrap, r->seq_len);
@@ -783,7 +796,7 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight);
   FieldPtrsMut fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
-  hipLaunchKernelGGL(unpack_rows_kernel, dim3(batch * r->T), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
                      r->rd.sampled_ids, 0, r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((batch * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
                      r->bootstrap, r->seq_len, r->rd.sampled_ids, batch, r->T, reward, terminal, bootstrap, seq_len,
@@ -826,7 +839,7 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (n > 0) {
     FieldPtrsMut fp;
     for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(n * r->T), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,
                        r->rd.valid_rows);
     hipLaunchKernelGGL(gather_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
                        r->bootstrap, r->seq_len, r->rd.sampled_ids, n, r->T, reward, terminal, bootstrap, seq_len,
@@ -871,7 +884,7 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
   hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
   FieldPtrsMut fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
-  hipLaunchKernelGGL(unpack_rows_kernel, dim3(r->T), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
+  hipLaunchKernelGGL(unpack_rows_kernel, dim3((r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
                      r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
                      r->bootstrap, r->seq_len, r->d_tmp_id, 1, r->T, reward, terminal, bootstrap, seq_len, r->rd.valid_rows);
@@ -961,7 +974,7 @@ int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields,
   const int slot = (w->head + w->count) % w->sd.depth;
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? fields[k] : nullptr;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3(w->sd.E), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((w->sd.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
                      w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr);
   HIP_TRY(hipGetLastError());
   w->count += 1;
@@ -996,7 +1009,7 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
     const int slot = pass == 0 ? w->head : (w->head + sd.n) % sd.depth;
     FieldPtrsMut fp;
     for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? of[k] : nullptr;
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3(sd.E), dim3(256), 0, s, w->L, sd.hist_rows, fp, sd.E, 1,
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((sd.E + 3) / 4), dim3(256), 0, s, w->L, sd.hist_rows, fp, sd.E, 1,
                        (const int*)nullptr, slot * sd.E);
   }
   HIP_TRY(hipGetLastError());
