@@ -36,6 +36,9 @@ class DeviceActor:
         self.writer = SequenceWriter(self.E, multi_step, gamma, seq_len, transition_fields(env, self.vdn), env.device)
         self.hid = agent.get_h0(self.N)
         self.history_hid = deque()
+        self.q_hist = deque()                 # (Q_online(s_t, a_t), online weight version) per step still in the n-step window
+        self.verify_cached_priority = False   # tests: also run compute_priority on the unpacked transition and compare
+        self.n_checked = self.n_checked_stale = 0
         self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
         self.n_finished = torch.zeros(1, dtype=torch.int32, device=env.device)
 
@@ -52,7 +55,12 @@ class DeviceActor:
         # historyHidden_.push_back(hidden_): by reference -- R2D2Agent.act returns fresh state tensors and never writes the
         # ones it is given, and zero_hidden_rows below only touches the new ones, which enter the history next step
         self.history_hid.append(dict(self.hid))
-        reply, self.hid = agent.act(obs, self.hid)
+        # with_q: Q_online(s_t, a_t) comes out of the pass that picks the action and Q_target(s_t, greedy_t) costs one target
+        # pass on the live observation -- exactly the two numbers compute_priority needs from time t (as `obs` n steps from
+        # now, as `next_obs` right now).  Two network passes per step instead of the reference's four, no observation ever
+        # read back from the n-step ring.
+        reply, self.hid = agent.act(obs, self.hid, with_q=True)
+        self.q_hist.append((reply["q_online_a"], reply["versions"][0]))
         fields = dict(obs)
         fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
         self.writer.push_obs_action(fields)
@@ -65,13 +73,24 @@ class DeviceActor:
         zero_hidden_rows(self.hid, env.terminal, P)                                    # r2d2_actor.h:109-126
         if not self.writer.can_pop():
             return
-        cur, nxt, rew, term, boot = self.writer.pop_transition()
         hid_s = self.history_hid.popleft()
-        hid_next = self.history_hid[-1]
-        N, F, A = self.N, env.F, env.A       # VDN rows [G, P*w] are the same memory as [G*P, w]
-        cur_obs = {"priv_s": cur["priv_s"].view(N, F), "legal_move": cur["legal_move"].view(N, A)}
-        nxt_obs = {"priv_s": nxt["priv_s"].view(N, F), "legal_move": nxt["legal_move"].view(N, A)}
-        prio = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, hid_next, rew, boot,
-                                      num_player=P if self.vdn else 1, next_greedy_a=reply["greedy_a"])
+        qa_s, version_s = self.q_hist.popleft()
+        stale = version_s != agent.online.version   # the online weights were synced since step t-n: the reference would
+        np_ = P if self.vdn else 1                  # evaluate Q_online(s_{t-n}, a) with the NEW weights, so redo that pass
+        N, F, A = self.N, env.F, env.A              # VDN rows [G, P*w] are the same memory as [G*P, w]
+        check = self.verify_cached_priority
+        cur, nxt, rew, term, boot = self.writer.pop_transition(want_fields=stale or check, want_next=check)
+        if stale or check:
+            cur_obs = {"priv_s": cur["priv_s"].view(N, F), "legal_move": cur["legal_move"].view(N, A)}
+        if stale:
+            qa_s = agent.q_of(agent.online, cur_obs, cur["a"].view(-1), hid_s)
+        prio = agent.priority_from_q(qa_s, reply["q_target_greedy"], rew, boot, num_player=np_)
+        if check:   # tests: the reference's call on the unpacked transition must give the same bits
+            nxt_obs = {"priv_s": nxt["priv_s"].view(N, F), "legal_move": nxt["legal_move"].view(N, A)}
+            full = agent.compute_priority(cur_obs, cur["a"].view(-1), nxt_obs, hid_s, self.history_hid[-1], rew, boot,
+                                          num_player=np_)
+            assert torch.equal(prio, full), "cached-Q priorities differ from compute_priority"
+            self.n_checked += 1
+            self.n_checked_stale += int(stale)
         self.writer.push_sequence(prio)
         self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)

@@ -239,6 +239,7 @@ class R2D2NetKernels:
         """Re-derive the bf16 / gate-blocked (and, for the learner, transposed) kernel operands from the fp32 master
         weights: one small HIP launch per weight, no temporaries."""
         w, H, T_ = self.w, self.H, self.WihT is not None
+        self.version = getattr(self, "version", 0) + 1      # consumers caching this net's outputs compare it (DeviceActor)
         self._prep(w["net.0.weight"], None, self.W1, None)
         self.b1 = w["net.0.bias"]
         for l in range(self.L):
@@ -745,9 +746,13 @@ class R2D2Agent:
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
 
-    def act(self, obs, hid):
+    def act(self, obs, hid, with_q=False):
         """obs: priv_s [N,F], legal_move [N,A], eps [N]; hid: h0,c0 [L,N,H] -> {a, greedy_a}, new hid
-        The new state is written to fresh tensors; the tensors in `hid` are read only (DeviceActor keeps them as history)."""
+        The new state is written to fresh tensors; the tensors in `hid` are read only (DeviceActor keeps them as history).
+        with_q: the reply also carries the two Q-values compute_priority needs from THIS (obs, hid) -- `q_online_a` =
+        Q_online(s, a) from the pass that was just run, and `q_target_greedy` = Q_target(s, greedy_a) from one target-net
+        pass -- so that an actor loop can form the n-step priorities from them (priority_from_q) instead of re-running both
+        nets n steps later; `versions` = (online.version, target.version) of the weights they were computed with."""
         lib = _lib.load_library()
         n = obs["priv_s"].shape[0]
         hd, h, c = self._adv(self.online, obs["priv_s"], hid["h0"], hid["c0"])
@@ -759,7 +764,30 @@ class R2D2Agent:
                                        None if eps is None else eps.contiguous().data_ptr(), n, self.online.A, self.seed,
                                        self.counter, a.data_ptr(), g.data_ptr(), scratch.data_ptr(), _s(self.device)))
         self.counter += 1
-        return {"a": a, "greedy_a": g}, {"h0": h, "c0": c}
+        reply = {"a": a, "greedy_a": g}
+        if with_q:
+            _, reply["q_online_a"], _ = self.online.q_head(hd, obs["legal_move"], a, want_greedy=False)
+            reply["q_target_greedy"] = self.q_of(self.target, obs, g, hid)
+            reply["versions"] = (self.online.version, self.target.version)
+        return reply, {"h0": h, "c0": c}
+
+    def q_of(self, net, obs, action, hid):
+        """Q_net(s, action) [N] for one step from the carried hidden state (one network pass)"""
+        hd, _, _ = self._adv(net, obs["priv_s"], hid["h0"], hid["c0"])
+        _, qa, _ = net.q_head(hd, obs["legal_move"], action, want_greedy=False)
+        return qa
+
+    def priority_from_q(self, qa, tqa, reward, bootstrap, num_player=1):
+        """|r + bootstrap * gamma^n * tqa - qa| (r2d2.py:341-361); num_player > 1 sums the Q-values over a game's players"""
+        n = qa.shape[0]
+        if num_player > 1:
+            qa, tqa = qa.view(-1, num_player).sum(1), tqa.view(-1, num_player).sum(1)
+            n = n // num_player
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.load_library().hsad_nstep_priority(qa.data_ptr(), tqa.data_ptr(), reward.contiguous().data_ptr(),
+                                                           bootstrap.contiguous().data_ptr(), self.multi_step, self.gamma, n,
+                                                           out.data_ptr(), _s(self.device)))
+        return out
 
     def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap, num_player=1, next_greedy_a=None):
         """|r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|  -> fp32 [N]
@@ -783,16 +811,8 @@ class R2D2Agent:
             scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=d)
             _lib.check(lib.hsad_act_select(nhd.data_ptr(), nhd.stride(0), next_obs["legal_move"].contiguous().data_ptr(), None,
                                            n, on.A, 0, 0, junk.data_ptr(), na.data_ptr(), scratch.data_ptr(), _s(d)))
-        thd, _, _ = self._adv(tg, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
-        _, tqa, _ = tg.q_head(thd, next_obs["legal_move"], na, want_greedy=False)
-        if num_player > 1:
-            qa, tqa = qa.view(-1, num_player).sum(1), tqa.view(-1, num_player).sum(1)
-            n = n // num_player
-        out = torch.empty(n, dtype=torch.float32, device=d)
-        _lib.check(lib.hsad_nstep_priority(qa.data_ptr(), tqa.data_ptr(), reward.contiguous().data_ptr(),
-                                           bootstrap.contiguous().data_ptr(), self.multi_step, self.gamma, n, out.data_ptr(),
-                                           _s(d)))
-        return out
+        tqa = self.q_of(tg, next_obs, na, next_hid)
+        return self.priority_from_q(qa, tqa, reward, bootstrap, num_player)
 
 
 def zero_hidden_rows(hid, terminal_u8, rows_per_flag):

@@ -230,12 +230,14 @@ class SequenceWriter:
     def can_pop(self):
         return bool(self.lib.hsad_seqwriter_can_pop(self.h))
 
-    def pop_transition(self, want_fields=True):
+    def pop_transition(self, want_fields=True, want_next=None):
+        """-> (obs/action fields of step t, of step t+n, n-step reward, terminal, bootstrap); want_fields / want_next = False
+        skip reading the respective rows back from the history ring (None)"""
         d, E = self.device, self.E
         mk = lambda: [torch.empty(E, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d)
                       for _, w, dt in self.fields]
         cur = mk() if want_fields else None
-        nxt = mk() if want_fields else None
+        nxt = mk() if (want_fields if want_next is None else want_next) else None
         reward = torch.empty(E, dtype=torch.float32, device=d)
         terminal = torch.empty(E, dtype=torch.uint8, device=d)
         bootstrap = torch.empty(E, dtype=torch.float32, device=d)

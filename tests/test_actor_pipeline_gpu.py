@@ -56,27 +56,35 @@ def test_actor_fills_replay_with_well_formed_sequences_and_learner_trains():
 
 
 @pytest.mark.parametrize("method", ["iql", "vdn"])
-def test_actor_hands_over_exactly_the_greedy_action_the_reference_recomputes(method):
-    """DeviceActor passes its act() reply as next_greedy_a; compute_priority without it (the reference's third network
-    pass on next_obs / next_hid, r2d2.py:305-361) must give the same priorities bit for bit, every step"""
+def test_actor_priorities_from_cached_q_equal_compute_priority_bit_for_bit(method):
+    """DeviceActor forms the n-step priorities from Q_online(s_t, a_t) / Q_target(s_t, greedy_t) computed when step t was
+    acted on; the reference's call (compute_priority on the transition read back from the n-step ring, four network
+    passes, r2d2.py:305-361 / r2d2_actor.h:128-150) must give the same bits every step -- also across actor weight syncs,
+    where the cached online value is stale and the actor redoes that one pass with the new weights."""
     from hanabi_sad_amd.selfplay import Trainer, parse_args
     args = parse_args(["--num_game", "64", "--rnn_hid_dim", "64", "--batchsize", "16", "--replay_buffer_size", "1024",
                        "--burn_in_frames", "64", "--max_len", "40", "--act_base_eps", "0.4", "--sad", "1",
                        "--method", method])
     tr = Trainer(args, "cuda:0")
-    agent, seen = tr.actor.agent, []
-    plain = agent.compute_priority
-
-    def spy(*a, **kw):
-        assert kw.get("next_greedy_a") is not None
-        got = plain(*a, **kw)
-        kw2 = dict(kw, next_greedy_a=None)
-        seen.append(bool(torch.equal(got, plain(*a, **kw2))))
-        return got
-    agent.compute_priority = spy
-    for _ in range(50):
+    tr.actor.verify_cached_priority = True
+    for it in range(60):
+        if it in (20, 21, 35):          # a weight sync (with really different weights) inside the n-step window
+            for net in (tr.act_online, tr.act_target):
+                net.w["fc_a.weight"].mul_(1.02)
+                net.w["lstm.weight_hh_l0"].mul_(0.99)
+                net.refresh()
         tr.actor.step()
-    assert len(seen) >= 40 and all(seen)
+    assert tr.actor.n_checked >= 50 and 6 <= tr.actor.n_checked_stale <= 9
+    # the greedy action act() hands out is the argmax compute_priority would recompute on (next_obs, next_hid)
+    agent = tr.actor.agent
+    obs = tr.actor._rows()
+    hid = {k: v.clone() for k, v in tr.actor.hid.items()}
+    reply, _ = agent.act(dict(obs, eps=torch.zeros_like(obs["eps"])), hid)
+    z = torch.zeros(tr.actor.E, device="cuda:0")
+    p1 = agent.compute_priority(obs, reply["a"], obs, hid, hid, z, z + 1, num_player=tr.actor.P if tr.actor.vdn else 1)
+    p2 = agent.compute_priority(obs, reply["a"], obs, hid, hid, z, z + 1, num_player=tr.actor.P if tr.actor.vdn else 1,
+                                next_greedy_a=reply["greedy_a"])
+    assert torch.equal(p1, p2)
 
 
 def test_reference_named_mirrors():
