@@ -295,17 +295,22 @@ class R2D2NetKernels:
             keep.update(saved)
         return inp.view(T, N, H), h_new, (c_new if c_new is not None else torch.stack(cs, 0))
 
-    def step(self, priv_s, h0, c0):
+    def precast(self, priv_s, h0):
+        """bf16 operands of step(): (observations zero-padded to Fp, hidden state); nets of the same shape can share them"""
+        return cast_pad_bf16(priv_s, self.Fp), cast_pad_bf16(h0.reshape(self.L * h0.shape[1], self.H), self.H).view(self.L, -1, self.H)
+
+    def step(self, priv_s, h0, c0, pre=None):
         """one recurrent step for inference (R2D2Net.act, r2d2.py:65-78): priv_s fp32 [N,F], h0/c0 fp32 [L,N,H] (contiguous)
-        -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]).  One fused GEMM + cell kernel per layer."""
+        -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]).  One fused GEMM + cell kernel per layer.
+        pre: precast(priv_s, h0) when the caller already has it (the online and the target net of an actor see the same
+        observation and hidden state)."""
         N, F = priv_s.shape
         H, d = self.H, self.device
-        a16 = cast_pad_bf16(priv_s, self.Fp)
+        a16, h16 = pre if pre is not None else self.precast(priv_s, h0)
         x = torch.empty(N, H, dtype=torch.bfloat16, device=d)
         gemm_nt(a16, self.W1, N, H, self.Fp, bias=self.b1, out16=x, relu=True)
         h = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
         c = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
-        h16 = cast_pad_bf16(h0.reshape(self.L * N, H), H).view(self.L, N, H)
         for l in range(self.L):
             x_next = torch.empty(N, H, dtype=torch.bfloat16, device=d)
             _lib.check(self.lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), x.stride(0), h16[l].data_ptr(),
@@ -739,9 +744,13 @@ class R2D2Agent:
         z = torch.zeros(self.online.L, n, self.online.H, dtype=torch.float32, device=self.device)
         return {"h0": z, "c0": z.clone()}
 
-    def _adv(self, net, priv_s, h0, c0):
-        if net.Wcat16 is not None and net.WihT is None and priv_s.shape[0] >= 1024 and h0.is_contiguous() and c0.is_contiguous():
-            o, h, c = net.step(priv_s, h0, c0)           # big batches: fused GEMM + cell kernel per layer
+    def _fused(self, net, priv_s, h0, c0):
+        return (net.Wcat16 is not None and net.WihT is None and priv_s.shape[0] >= 1024 and h0.is_contiguous()
+                and c0.is_contiguous())
+
+    def _adv(self, net, priv_s, h0, c0, pre=None):
+        if self._fused(net, priv_s, h0, c0):
+            o, h, c = net.step(priv_s, h0, c0, pre)      # big batches: fused GEMM + cell kernel per layer
             return net.heads(o), h, c
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
@@ -755,7 +764,11 @@ class R2D2Agent:
         nets n steps later; `versions` = (online.version, target.version) of the weights they were computed with."""
         lib = _lib.load_library()
         n = obs["priv_s"].shape[0]
-        hd, h, c = self._adv(self.online, obs["priv_s"], hid["h0"], hid["c0"])
+        on, tg = self.online, self.target
+        pre = None
+        if with_q and self._fused(on, obs["priv_s"], hid["h0"], hid["c0"]) and (on.Fp, on.H, on.L) == (tg.Fp, tg.H, tg.L):
+            pre = on.precast(obs["priv_s"], hid["h0"])   # both nets read the same bf16 observation / hidden state
+        hd, h, c = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"], pre)
         a = torch.empty(n, dtype=torch.int64, device=self.device)
         g = torch.empty(n, dtype=torch.int64, device=self.device)
         scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=self.device)
@@ -767,13 +780,13 @@ class R2D2Agent:
         reply = {"a": a, "greedy_a": g}
         if with_q:
             _, reply["q_online_a"], _ = self.online.q_head(hd, obs["legal_move"], a, want_greedy=False)
-            reply["q_target_greedy"] = self.q_of(self.target, obs, g, hid)
+            reply["q_target_greedy"] = self.q_of(self.target, obs, g, hid, pre)
             reply["versions"] = (self.online.version, self.target.version)
         return reply, {"h0": h, "c0": c}
 
-    def q_of(self, net, obs, action, hid):
+    def q_of(self, net, obs, action, hid, pre=None):
         """Q_net(s, action) [N] for one step from the carried hidden state (one network pass)"""
-        hd, _, _ = self._adv(net, obs["priv_s"], hid["h0"], hid["c0"])
+        hd, _, _ = self._adv(net, obs["priv_s"], hid["h0"], hid["c0"], pre)
         _, qa, _ = net.q_head(hd, obs["legal_move"], action, want_greedy=False)
         return qa
 
