@@ -387,31 +387,60 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   if (tid < B) weight_out[tid] = targets ? s_w[tid] : s_y[tid] / s_max;
 }
 
-// PrioritizedReplay::updatePriority -> ConcurrentQueue::update (sequential: duplicates see earlier writes)
-__global__ void replay_update_kernel(ReplayDev rd, int B, const float* __restrict__ priority) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// PrioritizedReplay::updatePriority -> ConcurrentQueue::update (prioritized_replay.h:110-131): for i = 0..B-1 in order,
+// diff += (w_i - weights[id_i]); weights[id_i] = w_i -- a duplicate id sees the earlier write.  One block: the ids, flags,
+// old weights and pow() are fetched / computed by B threads at once (the one-thread loop was 128 dependent global round
+// trips = 155 us); each element then finds the latest earlier occurrence of its id, which gives it the same "current
+// weight" the sequential loop would have read, so every float difference is the same, and thread 0 adds them in order.
+__global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B, const float* __restrict__ priority) {
+  __shared__ int s_id[kMaxBatch];
+  __shared__ float s_w[kMaxBatch];
+  __shared__ float s_diff[kMaxBatch];
+  __shared__ unsigned char s_live[kMaxBatch];
+  const int tid = threadIdx.x;
   ReplayCtl c = *rd.ctl;
-  if (B == 0) {
+  if (B == 0 || c.n_sampled != B) {
+    if (tid == 0) {
+      if (B != 0) c.err += 1;
+      else c.n_sampled = 0;
+      *rd.ctl = c;
+    }
+    return;
+  }
+  float old = 0.f;
+  if (tid < B) {
+    const int id = rd.sampled_ids[tid];
+    s_id[tid] = id;
+    s_live[tid] = !rd.evicted[id];
+    s_w[tid] = powf(priority[tid], rd.alpha);
+    old = rd.weights[id];
+  }
+  __syncthreads();
+  if (tid < B) {
+    float diff = 0.f;
+    if (s_live[tid]) {
+      const int id = s_id[tid];
+      float cur = old;
+      bool last = true;
+      for (int j = 0; j < B; ++j) {
+        if (s_id[j] != id) continue;          // (evicted[id] is per id: every occurrence of a live id is live)
+        if (j < tid) cur = s_w[j];            // ascending j: ends at the latest earlier occurrence
+        if (j > tid) last = false;
+      }
+      diff = s_w[tid] - cur;
+      if (last) rd.weights[id] = s_w[tid];    // the final value is the last occurrence's
+    }
+    s_diff[tid] = diff;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double diff = 0.0;
+    for (int i = 0; i < B; ++i)
+      if (s_live[i]) diff += s_diff[i];
+    c.sum += diff;
     c.n_sampled = 0;
     *rd.ctl = c;
-    return;
   }
-  if (c.n_sampled != B) {
-    c.err += 1;
-    *rd.ctl = c;
-    return;
-  }
-  double diff = 0.0;
-  for (int i = 0; i < B; ++i) {
-    const int id = rd.sampled_ids[i];
-    if (rd.evicted[id]) continue;
-    const float w = powf(priority[i], rd.alpha);
-    diff += (w - rd.weights[id]);
-    rd.weights[id] = w;
-  }
-  c.sum += diff;
-  c.n_sampled = 0;
-  *rd.ctl = c;
 }
 
 __global__ void ids_from_head_kernel(ReplayDev rd, int idx, int* out) {
@@ -853,7 +882,7 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
   if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
   if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
   r->last_stream = (hipStream_t)stream;
-  hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, r->rd, batch, priority);
+  hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
