@@ -63,6 +63,8 @@ struct EnvParams {
   int G, Gpad, P, H, A, F, F0, LAL, OB, OD, OL, OK, DECKW;
   int max_len, sad, shuffle_color, bomb, kmode, n_eps, track_dh, npl;
   int obs_words, legal_words, own_words, win_w;
+  int win_words;   // LDS words per lane of the mt19937 prefetch window: win_w when win_w <= 32 (old words stay in registers,
+                   // only the regenerated ones are stored), 2 * win_w + 1 otherwise
   int seed0, deal_mode, nt_stores;
   int g_begin, g_count;            // launch covers games [g_begin, g_begin + g_count); g_begin % 64 == 0
   unsigned long long policy_seed;  // MODE 2 (step with built-in random-legal policy)
@@ -794,8 +796,8 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   uint32_t* s_obs = s_st + ep.npl * kWave;
   uint32_t* s_legal = s_obs + ep.obs_words;
   uint32_t* s_own = s_legal + ep.legal_words;
-  uint32_t* s_win = s_own + ep.own_words;  // reset kernel only: [2*win_w+1][kWave]
-  uint32_t* s_grec = s_win + (MODE == 0 || MODE == 3 ? (2 * ep.win_w + 1) * kWave : 0);  // [kWave] SAD greedy records
+  uint32_t* s_win = s_own + ep.own_words;  // reset kernel only: [win_words][kWave]
+  uint32_t* s_grec = s_win + (MODE == 0 || MODE == 3 ? ep.win_words * kWave : 0);  // [kWave] SAD greedy records
   float* s_eps = reinterpret_cast<float*>(s_grec + kWave);  // [min(n_eps, 128)] copy of the eps list (reset only)
 
   const int tid = threadIdx.x;
@@ -882,8 +884,8 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   if (MODE == 0 || MODE == 3) {
     // ---- prefetch window: every mt19937 word this reset will regenerate, in one round trip ----
     const int W = ep.win_w;
-    uint32_t* winA = s_win + lane;                   // x[wbase + k],       k in [0, W]
-    uint32_t* winB = s_win + (W + 1) * kWave + lane;  // x[wbase + k + 397], k in [0, W) -> new words
+    uint32_t* winA = s_win + lane;                   // x[wbase + k],       k in [0, W]   (W > 32 only)
+    uint32_t* winB = s_win + (W <= 32 ? 0 : (W + 1) * kWave) + lane;  // x[wbase + k + 397], k in [0, W) -> new words
     const uint32_t wbase = rng.spos;
     if (do_reset) {
       if (W <= 32) {
@@ -1506,6 +1508,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   {
     const int n_static = 2 * P * H + P + (ep.shuffle_color ? 1 + 2 * (P - 1) : 0);
     ep.win_w = n_static + 2 < 64 ? n_static + 2 : 64;
+    ep.win_words = ep.win_w <= 32 ? ep.win_w : 2 * ep.win_w + 1;
   }
   // +3 words of slack: or_bits may touch up to two words past the last row
   ep.obs_words = (kWave * P * ep.F + 31) / 32 + 3;
@@ -1515,7 +1518,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   ep.legal_words = (ep.legal_words + 3) & ~3;
   ep.own_words = (ep.own_words + 3) & ~3;
   e->lds_bytes = sizeof(uint32_t) * ((size_t)ep.npl * kWave + ep.obs_words + ep.legal_words + ep.own_words + kWave + 128);
-  e->lds_bytes_reset = e->lds_bytes + sizeof(uint32_t) * (size_t)(2 * ep.win_w + 1) * kWave;
+  e->lds_bytes_reset = e->lds_bytes + sizeof(uint32_t) * (size_t)ep.win_words * kWave;
   e->device = cfg->device;
   e->bound = false;
   e->n_part = 0;
