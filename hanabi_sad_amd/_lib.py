@@ -60,6 +60,7 @@ SIGNATURES = {
     "hsad_env_rollout_random": (C.c_int, [_P, C.c_int, C.c_uint64, _P, _P, _P]),
     "hsad_env_set_partitions": (C.c_int, [_P, C.c_int]),
     "hsad_env_set_rollout_stagger": (C.c_int, [_P, C.c_int]),
+    "hsad_env_set_rollout_chunk": (C.c_int, [_P, C.c_int]),
     "hsad_env_last_rollout_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int)]),
     "hsad_env_query": (C.c_int, [_P, _P, _P]),
     "hsad_env_move_is_legal": (C.c_int, [_P, _P, _P, _P]),

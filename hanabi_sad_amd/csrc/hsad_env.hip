@@ -68,6 +68,8 @@ struct EnvParams {
   int seed0, deal_mode, nt_stores;
   int g_begin, g_count;            // launch covers games [g_begin, g_begin + g_count); g_begin % 64 == 0
   unsigned long long policy_seed;  // MODE 2 (step with built-in random-legal policy)
+  int n_iter;       // MODE 3: iterations this launch runs for its games (persistent rollout; 1 otherwise)
+  int stagger_ticks;  // MODE 3, n_iter > 1: workgroup b starts (b % 8) * stagger_ticks (100 MHz) late, see env_kernel
   int64_t* a_out;                  // MODE 2: where the sampled actions are recorded ([G,P] each)
   int64_t* g_out;
   uint32_t* planes;
@@ -789,8 +791,8 @@ __device__ __forceinline__ int policy_pick(uint64_t seed, uint64_t game, uint64_
 constexpr int kEnvThreads = 2 * kWave;  // wave 0: game logic; wave 1: LDS zeroing; both: row building + streaming
 
 template <int MODE, int TP, int TH>
-__global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const int64_t* __restrict__ a_in,
-                                                          const int64_t* __restrict__ g_in) {
+__device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __restrict__ a_in, const int64_t* __restrict__ g_in,
+                                         const int g_bias = 0) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint32_t* s_st = smem;
   uint32_t* s_obs = s_st + ep.npl * kWave;
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const int g0 = ep.g_begin + blockIdx.x * kWave;
+  const int g0 = ep.g_begin + blockIdx.x * kWave + g_bias;   // g_bias: always 0 (see env_rollout_kernel)
   const int g = g0 + lane;
   const bool valid = g < ep.G;
   const int ng = min(kWave, ep.G - g0);
@@ -1197,6 +1199,33 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
   STAMP(5);
 }
 
+template <int MODE, int TP, int TH>
+__global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const int64_t* __restrict__ a_in,
+                                                          const int64_t* __restrict__ g_in) {
+  env_body<MODE, TP, TH>(ep, a_in, g_in);
+}
+
+// Persistent rollout: games are independent, so a workgroup simply runs n_iter iterations (reset finished games + policy +
+// step + observe) for its 64 games without meeting the others at launch boundaries.  Workgroups that share a CU drift
+// apart (and are started apart: stagger_ticks), so one's game-logic phase overlaps the others' observation streams and HBM
+// sees a steady write stream -- what the phase-locked partitions approximate with three launches per iteration.
+// g_bias is an opaque zero: with a loop-invariant game index the compiler hoists every per-lane address of the body out of
+// the loop and ends up at 258 VGPRs (95 without the loop), i.e. one wave per SIMD instead of five.
+template <int TP, int TH>
+__global__ __launch_bounds__(kEnvThreads) __attribute__((amdgpu_waves_per_eu(4, 5))) void env_rollout_kernel(EnvParams ep) {
+  if (ep.stagger_ticks > 0) {
+    const unsigned long long t_in = wall_clock64(), wait = (unsigned long long)(blockIdx.x & 7u) * (unsigned long long)ep.stagger_ticks;
+    while (wall_clock64() - t_in < wait) __builtin_amdgcn_s_sleep(16);
+  }
+#pragma clang loop unroll(disable)
+  for (int iter = 0; iter < ep.n_iter; ++iter) {
+    if (iter) __syncthreads();   // the previous iteration's rows have left LDS before they are cleared again
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    env_body<3, TP, TH>(ep, nullptr, nullptr, zero);
+  }
+}
+
 // ---- init: zero planes, seed mt19937 (std::mt19937::seed: x0 = s; x_i = 1812433253*(x ^ x>>30) + i) ---
 __global__ void init_kernel(EnvParams ep) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1387,6 +1416,7 @@ struct hsad_env {
   unsigned long long launch_seq;   // tag of the next locked launch
   int n_part;         // streams created so far
   int n_part_active;  // partitions used by hsad_env_rollout_random (1 = caller's stream only)
+  int rollout_chunk;  // > 0: hsad_env_rollout_random runs persistent launches of this many iterations (hsad_env_set_rollout_chunk)
   hipStream_t part_stream[16];
   hipEvent_t part_done[16];
   hipEvent_t part_begin[16];   // timing-enabled pair with part_done: per-partition chain time of the last rollout
@@ -1422,7 +1452,18 @@ EnvKernelFn pick_env_kernel(int mode, int P, int H) {
   }
 }
 
+typedef void (*EnvRolloutFn)(EnvParams);
+EnvRolloutFn pick_rollout_kernel(int P, int H) {
+  if (P == 2 && H == 5) return env_rollout_kernel<2, 5>;
+  if (P == 5 && H == 4) return env_rollout_kernel<5, 4>;
+  if (P == 3 && H == 5) return env_rollout_kernel<3, 5>;
+  if (P == 4 && H == 4) return env_rollout_kernel<4, 4>;
+  return env_rollout_kernel<0, 0>;
+}
+
 int configure_env_kernels(hsad_env* e) {
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_rollout_kernel(e->ep.P, e->ep.H)),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->lds_bytes_reset));
   for (int mode = 0; mode < 4; ++mode) {
     const size_t lds = (mode == 1 || mode == 2) ? e->lds_bytes : e->lds_bytes_reset;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(pick_env_kernel(mode, e->ep.P, e->ep.H)),
@@ -1434,7 +1475,7 @@ int configure_env_kernels(hsad_env* e) {
 // launch one env kernel over games [g_begin, g_begin + g_count) (g_begin multiple of 64)
 void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipStream_t stream, int g_begin,
                 int g_count, uint64_t policy_seed = 0, int64_t* a_out = nullptr, int64_t* g_out = nullptr, int part = -1,
-                unsigned long long tag = 0, unsigned long long first_tag = 0, int n_part = 1) {
+                unsigned long long tag = 0, unsigned long long first_tag = 0, int n_part = 1, int n_iter = 1) {
   const size_t lds = (mode == 1 || mode == 2) ? e->lds_bytes : e->lds_bytes_reset;
   EnvParams ep = e->ep;
   ep.phase = part >= 0 ? e->d_phase : nullptr;
@@ -1446,10 +1487,15 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
   ep.g_begin = g_begin;
   ep.g_count = g_count;
   ep.policy_seed = policy_seed;
+  ep.n_iter = n_iter;
+  ep.stagger_ticks = n_iter > 1 ? (int)(e->stagger_ns / 10) : 0;
   ep.a_out = a_out;
   ep.g_out = g_out;
-  hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds,
-                     stream, ep, a, g);
+  if (mode == 3 && n_iter > 1)
+    hipLaunchKernelGGL(pick_rollout_kernel(ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds, stream, ep);
+  else
+    hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds,
+                       stream, ep, a, g);
 }
 
 }  // namespace
@@ -1528,6 +1574,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   e->last_rollout_iters = 0;
   e->last_rollout_parts = 0;
   e->n_part_active = 1;
+  e->rollout_chunk = 0;
   e->fork = nullptr;
   if (e->lds_bytes_reset > 160 * 1024) {
     const size_t need = e->lds_bytes_reset;
@@ -1672,6 +1719,13 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
   if (e->ep.sad && !greedy_a) return set_error(HSAD_ERR_INVALID, "sad=1 requires greedy_a");
   const int K = e->n_part_active;
   const int blocks = e->ep.Gpad / kWave;
+  if (e->rollout_chunk > 0) {   // persistent: one launch = rollout_chunk iterations of every game (the last one may be shorter)
+    for (int i = 0; i < n_iter; i += e->rollout_chunk)
+      launch_env(e, 3, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a, -1, 0, 0, 1,
+                 std::min(e->rollout_chunk, n_iter - i));
+    HIP_TRY(hipGetLastError());
+    return HSAD_OK;
+  }
   if (K <= 1) {
     for (int i = 0; i < n_iter; ++i)
       launch_env(e, 3, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a);
@@ -1722,6 +1776,12 @@ int hsad_env_last_rollout_ms(hsad_env* e, float* ms_per_launch, int* n_part) {
     HIP_TRY(hipEventElapsedTime(&ms, e->part_begin[k], e->part_done[k]));
     ms_per_launch[k] = ms / (float)e->last_rollout_iters;
   }
+  return HSAD_OK;
+}
+
+int hsad_env_set_rollout_chunk(hsad_env* e, int iterations_per_launch) {
+  if (!e || iterations_per_launch < 0) return set_error(HSAD_ERR_INVALID, "bad argument");
+  e->rollout_chunk = iterations_per_launch;
   return HSAD_OK;
 }
 

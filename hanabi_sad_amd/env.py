@@ -101,6 +101,10 @@ class BatchedHanabiEnv:
         """phase lock between the partition chains (see include/hsad.h); timing only"""
         _lib.check(self.lib.hsad_env_set_rollout_stagger(self.h, int(microseconds)))
 
+    def set_rollout_chunk(self, iterations_per_launch):
+        """persistent rollout: one launch runs this many iterations of every game (0 = one launch per iteration)"""
+        _lib.check(self.lib.hsad_env_set_rollout_chunk(self.h, int(iterations_per_launch)))
+
     def last_rollout_ms(self):
         """average launch duration (ms) on each partition stream of the last partitioned rollout_random"""
         import ctypes as C

@@ -108,6 +108,12 @@ int hsad_env_rollout_random(hsad_env* env, int n_iter, uint64_t policy_seed, int
  * independent).  Default 1 = everything on the caller's stream. */
 int hsad_env_set_partitions(hsad_env* env, int n_part);
 
+/* Persistent rollout: with iterations_per_launch > 0 hsad_env_rollout_random runs ONE launch per that many iterations
+ * (the last may be shorter); inside it every workgroup advances its 64 games independently -- games never interact, so
+ * nothing but the launch boundary ever synchronised them -- and workgroup b starts (b % 8) x the rollout stagger late so
+ * that the workgroups of a CU stream their observations at different times.  Takes precedence over partitions; 0 (the
+ * default) = one launch per iteration and partition.  Results are bit-identical either way. */
+int hsad_env_set_rollout_chunk(hsad_env* env, int iterations_per_launch);
 /* Phase lock of the partition chains of hsad_env_rollout_random: partition k starts each launch `microseconds` after
  * partition k-1 started the launch of the same iteration (bounded in-kernel wait on a device timestamp), so that one
  * partition's latency-bound logic phase keeps overlapping another's HBM stream.  Timing only -- results are identical

@@ -4,8 +4,9 @@ reference-bit-parity of a 1,024-game slice of the same run (SURVEY.md §8d confi
 * card conservation and token ranges in every game after every block of steps (deck + hands + discards + fireworks = the
   50-card deck; 0 <= info <= 8; 0 <= life <= 3; score = sum of fireworks),
 * the observation tensors are pure 0/1 with the own-hand block zero, exactly one legal noop iff nothing else is legal,
-* partition / phase-lock invariance: the run as 3 phase-locked stream partitions equals the single-launch run bit for bit
-  (compared through per-tensor checksums AND a full equality on the observation tensor),
+* scheduling invariance: the run as 3 phase-locked stream partitions, and the run as PERSISTENT launches (every workgroup
+  advancing its games 30 iterations per launch, staggered starts), equal the launch-per-iteration run bit for bit (compared
+  through per-tensor checksums AND a full equality on the observation tensor),
 * determinism: running the same seeds twice gives the same state dump,
 * the first 1,024 games equal the CPU oracle driven with the same seeds and the same counter-based policy."""
 import numpy as np
@@ -19,11 +20,12 @@ EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
 FULL_DECK = np.array([3, 2, 2, 2, 1] * 5, dtype=np.int64)
 
 
-def make(parts, lock):
+def make(parts, lock, chunk=0):
     from hanabi_sad_amd import BatchedHanabiEnv
     e = BatchedHanabiEnv(G, seed=SEED, eps_list=EPS, max_len=80, device=DEV, track_deck_history=False)
     e.set_partitions(parts)
     e.set_rollout_stagger(lock)
+    e.set_rollout_chunk(chunk)
     return e
 
 
@@ -55,18 +57,21 @@ def checksum(t):
 
 
 def test_full_size_rollout_properties_and_partition_invariance():
-    a, b = make(1, 0), make(3, 30)
+    a, b, pers = make(1, 0), make(3, 30), make(1, 5, 30)
     for blk in range(3):
         a.rollout_random(ITERS // 3, PSEED)
         b.rollout_random(ITERS // 3, PSEED)
+        pers.rollout_random(ITERS // 3, PSEED)
         torch.cuda.synchronize()
         a.check_errors()
         b.check_errors()
+        pers.check_errors()
         sa = invariants(a)
-        assert np.array_equal(sa, b.export_state().cpu().numpy())
-        for name in ("priv_s", "legal_move", "own_hand", "eps", "reward", "terminal"):
-            assert checksum(getattr(a, name)) == checksum(getattr(b, name)), (name, blk)
-        assert torch.equal(a.priv_s, b.priv_s)
+        for other in (b, pers):
+            assert np.array_equal(sa, other.export_state().cpu().numpy())
+            for name in ("priv_s", "legal_move", "own_hand", "eps", "reward", "terminal", "a", "greedy_a"):
+                assert checksum(getattr(a, name)) == checksum(getattr(other, name)), (name, blk)
+            assert torch.equal(a.priv_s, other.priv_s)
         # observation tensors: 0/1 valued, own-hand block (first hand_size*25 features) zero, legal rows well formed
         assert bool(((a.priv_s == 0) | (a.priv_s == 1)).all())
         assert float(a.priv_s[:, :, :a.H * 25].abs().sum()) == 0.0
@@ -85,7 +90,7 @@ def test_full_size_rollout_properties_and_partition_invariance():
 def test_first_1024_games_of_the_full_size_run_equal_the_oracle():
     from oracle.oracle import OracleVecEnv
     n = 1024
-    dev = make(3, 30)
+    dev = make(1, 5, 45)      # persistent launches: what bench.py times
     ref = OracleVecEnv(n, SEED, players=2, hand_size=5, eps_list=EPS, max_len=80)
     for blk in range(2):
         dev.rollout_random(45, PSEED)

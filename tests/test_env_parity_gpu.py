@@ -125,16 +125,19 @@ def test_illegal_move_is_reported_not_applied():
         dev2.check_errors()
 
 
-@pytest.mark.parametrize("parts,lock_us", [(1, 0), (3, 0), (3, 30), (2, 45), (8, 0), (8, 5)])
-def test_rollout_random_matches_oracle(parts, lock_us):
-    """hsad_env_rollout_random (fused policy, optional multi-stream partitions, optional phase lock between the partition
-    chains -- timing only) == oracle thread-loop."""
+@pytest.mark.parametrize("parts,lock_us,chunk_iters", [(1, 0, 0), (3, 0, 0), (3, 30, 0), (2, 45, 0), (8, 0, 0), (8, 5, 0),
+                                                        (1, 0, 7), (1, 10, 20), (3, 5, 50), (1, 0, 1)])
+def test_rollout_random_matches_oracle(parts, lock_us, chunk_iters):
+    """hsad_env_rollout_random (fused policy; optional multi-stream partitions with a phase lock between the partition
+    chains; or PERSISTENT launches that run chunk_iters iterations of every game each, workgroups started staggered --
+    scheduling only) == oracle thread-loop."""
     from hanabi_sad_amd import BatchedHanabiEnv
     from oracle.oracle import OracleVecEnv
     G, iters, seed, pseed = 64 * 9 + 5, 60, 4242, 11
     dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, sad=True, shuffle_color=True, device="cuda:0")
     dev.set_partitions(parts)
     dev.set_rollout_stagger(lock_us)
+    dev.set_rollout_chunk(chunk_iters)
     ref = OracleVecEnv(G, seed, players=2, hand_size=5, eps_list=EPS, sad=True, shuffle_color=True, max_len=80)
     for chunk in range(3):
         dev.rollout_random(iters // 3, pseed)
@@ -147,7 +150,7 @@ def test_rollout_random_matches_oracle(parts, lock_us):
         _cmp("eps", dev.eps, ref.eps, chunk)
         _cmp("reward", dev.reward, ref.reward, chunk)
         _cmp("terminal", dev.terminal, ref.terminal, chunk)
-    if parts > 1:
+    if parts > 1 and not chunk_iters:
         ms = dev.last_rollout_ms()
         assert len(ms) == parts and all(m > 0 for m in ms)
         _cmp("a", dev.a, ref.a, chunk)
