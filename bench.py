@@ -36,13 +36,18 @@ def algorithmic_bytes_per_step(P, F, A, H, sad):
     return P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 * (1 + int(sad)) + 2 * 128
 
 
-def measured_traffic_bytes(G, mode):
-    """HBM bytes per launch of env_kernel<mode,2,5> from the committed rocprofv3 PMC passes (profiles/, collected with
-    separate --pmc WRITE_SIZE / FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py).
-    Only valid for the configuration it was measured at; None otherwise."""
+def measured_traffic_bytes(G, mode, chunk=0):
+    """HBM bytes per launch of env_kernel<mode,2,5> (chunk > 0: of the persistent env_rollout_kernel<2,5> running `chunk`
+    iterations per launch) from the committed rocprofv3 PMC passes (profiles/, collected with separate --pmc WRITE_SIZE /
+    FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py).  Only valid for the configuration
+    it was measured at; None otherwise."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     try:
         for k, rec in json.load(open(path)).items():
+            if chunk > 0:
+                if k.startswith("env_rollout_kernel<2,5>"):
+                    return rec["hbm_bytes_per_iteration"] * chunk if G == 65536 else None
+                continue
             if k.startswith("env_kernel<%d,2,5>" % mode):
                 return rec["hbm_bytes_per_launch"] if G == 65536 else None
     except Exception:
@@ -183,7 +188,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-learner", action="store_true", help="skip the R2D2 learner samples/sec measurement")
@@ -192,6 +197,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL, one GPU per rank; what the driver uses) | gloo (smoke-testing the multi-rank path with "
                          "several ranks sharing one GPU)")
+    ap.add_argument("--chunk", type=int, default=50,
+                    help="persistent rollout: iterations of every game per launch (hsad_env_set_rollout_chunk); 0 = one launch "
+                         "per iteration and partition (--partitions / --lock-us).  Results are bit-identical either way")
     ap.add_argument("--partitions", type=int, default=3,
                     help="independent game ranges the rollout runs on private HIP streams (hsad_env_set_partitions); results "
                          "are bit-identical for any value")
@@ -223,8 +231,13 @@ def main():
     begin, _ = shard_range(G * world, rank, world)
     env = BatchedHanabiEnv(G, players=PLAYERS, hand_size=HAND, seed=shard_seed(1, begin), eps_list=EPS, max_len=80,
                            sad=False, device=dev, track_deck_history=False)
-    env.set_partitions(args.partitions)
-    env.set_rollout_stagger(args.lock_us if args.partitions > 1 else 0)
+    persistent = args.chunk > 0
+    if persistent:
+        env.set_rollout_chunk(args.chunk)
+        env.set_rollout_stagger(0)
+    else:
+        env.set_partitions(args.partitions)
+        env.set_rollout_stagger(args.lock_us if args.partitions > 1 else 0)
     policy_seed = 12345 + rank
 
     def barrier():
@@ -246,9 +259,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     iter_ms = k0.elapsed_time(k1) / args.steps                      # all partitions of one iteration (they overlap)
-    K = max(1, args.partitions)
-    part_ms = env.last_rollout_ms() if K > 1 else [iter_ms]         # events on the partition streams themselves
-    fused_ms = sum(part_ms) / len(part_ms)
+    if persistent:
+        # one launch = args.chunk iterations of all G games (the last one shorter if steps is not a multiple), back to back
+        # on the caller's stream between the two events: average launch duration = region / launches
+        K = 1
+        n_launch = (args.steps + args.chunk - 1) // args.chunk
+        fused_ms = k0.elapsed_time(k1) / n_launch
+        iters_per_launch = args.steps / n_launch
+    else:
+        K = max(1, args.partitions)
+        part_ms = env.last_rollout_ms() if K > 1 else [iter_ms]     # events on the partition streams themselves
+        fused_ms = sum(part_ms) / len(part_ms)
+        n_launch, iters_per_launch = args.steps * K, 1.0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -275,7 +297,7 @@ def main():
     bytes_per_step = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, False)
     achieved_step = bytes_per_step * G / (step_ms * 1e-3) / 1e9
     achieved = bytes_per_step * G / (iter_ms * 1e-3) / 1e9        # all concurrent launches together = the chip's rate
-    per_launch = bytes_per_step * (G / K) / (fused_ms * 1e-3) / 1e9
+    per_launch = bytes_per_step * (G / K) * iters_per_launch / (fused_ms * 1e-3) / 1e9
 
     if rank == 0:
         out = {
@@ -293,23 +315,30 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[1]: %d concurrent 2-player Hanabi games per GPU, random-legal policy, fused "
-                            "reset-terminated + policy + step + observe kernel, %d phase-locked stream partition(s) per "
-                            "iteration, fp32 obs [G,2,783] written to HBM" % (G, K),
-                "partitions": K, "phase_lock_us": args.lock_us if K > 1 else 0,
+                            "reset-terminated + policy + step + observe kernel, %s, fp32 obs [G,2,783] written to HBM every "
+                            "step" % (G, ("persistent launches of %d iterations each" % args.chunk) if persistent else
+                                      ("%d phase-locked stream partition(s) per iteration" % K)),
+                "rollout_chunk": args.chunk if persistent else 0,
+                "partitions": K, "phase_lock_us": args.lock_us if (K > 1 and not persistent) else 0,
                 "games_per_gpu": G, "players": PLAYERS, "hand_size": HAND, "feature_size": env.F,
                 "num_action": env.A, "max_len": 80, "sharding": "games sharded across ranks, no collective",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "env_kernel<3,2,5> (fused reset-terminated + policy + step + observe; the only kernel in the timed "
-                          "region: %d launch(es) per iteration on %d stream partition(s), overlapping in time)" % (K, K),
-                # achieved = algorithmic bytes of the K concurrent launches of an iteration / the iteration's duration (HIP
-                # events on the caller's stream, fork/join included); per_launch_* = one launch against its own duration
-                # (HIP events on its partition stream) -- the number rocprofv3's AverageNs for this kernel must agree with
+                "kernel": ("env_rollout_kernel<2,5> (persistent fused reset-terminated + policy + step + observe; the only kernel "
+                           "in the timed region: one launch = %d iterations of all %d games)" % (args.chunk, G)) if persistent else
+                          ("env_kernel<3,2,5> (fused reset-terminated + policy + step + observe; the only kernel in the timed "
+                           "region: %d launch(es) per iteration on %d stream partition(s), overlapping in time)" % (K, K)),
+                # achieved = algorithmic bytes of the timed region / its duration (HIP events on the caller's stream) = what the
+                # chip sustains; per_launch_* = one launch against its own duration -- the number rocprofv3's AverageNs for
+                # this kernel must agree with (persistent: the same thing, launches run back to back on one stream)
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic_bytes(G, 3), "algorithmic_bytes_per_env_step": bytes_per_step,
-                "algorithmic_bytes_per_launch": bytes_per_step * G / K, "avg_launch_ms": fused_ms,
-                "launches_per_iteration": K, "iteration_ms": iter_ms, "per_launch_achieved": per_launch,
+                "traffic": measured_traffic_bytes(G, 3, args.chunk if persistent else 0),
+                "algorithmic_bytes_per_env_step": bytes_per_step,
+                "algorithmic_bytes_per_launch": bytes_per_step * G / K * iters_per_launch, "avg_launch_ms": fused_ms,
+                "launches": n_launch, "iterations_per_launch": iters_per_launch,
+                "launches_per_iteration": K if not persistent else 1.0 / iters_per_launch, "iteration_ms": iter_ms,
+                "per_launch_achieved": per_launch,
             },
             "roofline_step_kernel": {
                 "bound": "hbm", "kernel": "env_kernel<1,2,5> (HanabiEnv::step + observe with actions from HBM, the "

@@ -8,8 +8,12 @@ from hanabi_sad_amd import BatchedHanabiEnv
 G = 65536
 EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
 env = BatchedHanabiEnv(G, seed=1, eps_list=EPS, device="cuda:0", track_deck_history=False)
-env.set_partitions(3); env.set_rollout_stagger(30)   # as bench.py launches it: every env_kernel<3,...> dispatch covers G/3 games
-env.rollout_random(30, 5)   # the fused kernel the benchmark's timed region launches
+CHUNK = 50
+env.set_rollout_chunk(CHUNK)   # as bench.py launches it: one env_rollout_kernel dispatch = CHUNK iterations of all G games
+env.rollout_random(4 * CHUNK, 5)
+env.set_rollout_chunk(0)
+env.set_partitions(3); env.set_rollout_stagger(30)   # the launch-per-iteration path: every env_kernel<3,...> dispatch covers G/3 games
+env.rollout_random(30, 5)
 env.set_partitions(1)
 torch.cuda.synchronize()
 for _ in range(10):

@@ -45,7 +45,17 @@ out = {
                     "note": "factors = known bytes / counter; MI355X_MICROARCH.md §HBM: WRITE_SIZE exact in KiB, "
                             "FETCH_SIZE undercounts wide coalesced reads 2x on gfx950"},
 }
-PARTS = 3    # bench.py runs the fused rollout kernel as 3 stream partitions: one launch covers G/3 games
+PARTS = 3    # the launch-per-iteration rollout runs as 3 stream partitions: one launch covers G/3 games
+CHUNK = 50   # the persistent rollout kernel: one launch = CHUNK iterations of all G games (tools/pmc_probe.py)
+wk, fk = mean(pick(w, r"env_rollout_kernel<2, 5>")), mean(pick(f, r"env_rollout_kernel<2, 5>"))
+if wk is not None:
+    wf = write_factor if write_factor and abs(write_factor - 1) < 0.05 else 1.0
+    ff = fetch_factor if fetch_factor and 1.5 < fetch_factor < 2.5 else 2.0
+    hbm = (wk * wf + (fk or 0.0) * ff) * 1024.0
+    out["env_rollout_kernel<2,5> persistent fused reset+policy+step+observe, G=65536, %d iterations per launch" % CHUNK] = {
+        "WRITE_SIZE_KiB": wk, "FETCH_SIZE_KiB_raw": fk, "dispatches": len(pick(w, r"env_rollout_kernel<2, 5>")),
+        "iterations_per_launch": CHUNK, "hbm_bytes_per_launch": hbm, "hbm_bytes_per_iteration": hbm / CHUNK,
+        "algorithmic_bytes_per_launch": ALGO * CHUNK, "traffic_over_algorithmic": hbm / (ALGO * CHUNK)}
 for mode, label in ((3, "env_kernel<3,2,5> fused reset+policy+step+observe (rollout), G=65536 in 3 partition launches"),
                     (1, "env_kernel<1,2,5> step+observe, G=65536"),
                     (0, "env_kernel<0,2,5> reset-terminated, G=65536")):
@@ -63,4 +73,4 @@ for mode, label in ((3, "env_kernel<3,2,5> fused reset+policy+step+observe (roll
         rec["traffic_over_algorithmic"] = hbm / algo
     out[label] = rec
 json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k.startswith("env_kernel")}, indent=1))
+print(json.dumps({k: v for k, v in out.items() if k.startswith("env_")}, indent=1))
