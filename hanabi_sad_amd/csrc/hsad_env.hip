@@ -1212,7 +1212,7 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
 // g_bias is an opaque zero: with a loop-invariant game index the compiler hoists every per-lane address of the body out of
 // the loop and ends up at 258 VGPRs (95 without the loop), i.e. one wave per SIMD instead of five.
 template <int TP, int TH>
-__global__ __launch_bounds__(kEnvThreads) __attribute__((amdgpu_waves_per_eu(4, 5))) void env_rollout_kernel(EnvParams ep) {
+__global__ __launch_bounds__(kEnvThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void env_rollout_kernel(EnvParams ep) {
   if (ep.stagger_ticks > 0) {
     const unsigned long long t_in = wall_clock64(), wait = (unsigned long long)(blockIdx.x & 7u) * (unsigned long long)ep.stagger_ticks;
     while (wall_clock64() - t_in < wait) __builtin_amdgcn_s_sleep(16);
