@@ -164,11 +164,19 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
     for (int it = 0; it < B_IT; ++it) glds16(reinterpret_cast<const bf16_t*>(bbase + boff[it]), db + (it * 4 + wave) * 8 * kBK);
   };
 
-  int tile = blockIdx.x;
-  if (tile >= n_tiles) return;
-  set_tile(tile);
+  // Which tiles this workgroup walks.  Workgroup b runs on XCD b % 8 and every XCD has its own L2: XCD x takes the CONTIGUOUS
+  // eighth [x * tpx, (x + 1) * tpx) of the tile order, so the tiles that share an A panel (same m, consecutive n) run on
+  // one XCD and the panel is fetched into one L2 instead of up to eight (round-robin tiles made the weight-gradient GEMMs
+  // read their 42 MB A operand four times).  Grids that are not a multiple of 8 keep the plain order.
+  const bool xcd_order = (gridDim.x % 8) == 0 && n_tiles >= 16;
+  const int tpx = xcd_order ? (n_tiles + 7) / 8 : n_tiles;                    // tiles per XCD
+  const int tbase = xcd_order ? (int)(blockIdx.x & 7) * tpx : 0;
+  const int qstep = xcd_order ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  int q = xcd_order ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;               // position inside this XCD's range
+  if (q >= tpx || tbase + q >= n_tiles) return;
+  set_tile(tbase + q);
   issue_tile(g.k_chunk ? bz * g.k_chunk : 0, 0);
-  for (; tile < n_tiles; tile += gridDim.x) {
+  for (; q < tpx && tbase + q < n_tiles; q += qstep) {
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -203,8 +211,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 
   const int cm0 = m0, cn0 = n0, cbz = bz;                   // this tile's coordinates for the epilogue
   __syncthreads();                                          // both operand buffers are dead: 0 may be refilled, 1 staged into
-  if (tile + (int)gridDim.x < n_tiles) {                    // next tile's first operand tile flies during the epilogue
-    set_tile(tile + gridDim.x);
+  if (q + qstep < tpx && tbase + q + qstep < n_tiles) {     // next tile's first operand tile flies during the epilogue
+    set_tile(tbase + q + qstep);
     issue_tile(g.k_chunk ? bz * g.k_chunk : 0, 0);
   }
   // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) ----
@@ -1973,6 +1981,14 @@ static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned*
 
 extern "C" {
 
+// persistent grid: up to two workgroups per CU; a multiple of 8 (when there is enough work) switches the kernel to its
+// XCD-aware tile order, and every XCD's share must be covered: 8 * ceil(tiles / 8) workgroups at most
+static long gemm_grid(long tiles, int n_cu) {
+  if (tiles < 16) return tiles;
+  const long want = std::min<long>(((tiles + 7) / 8) * 8, 2L * n_cu);
+  return want & ~7L;
+}
+
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* C32,
                        int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k, const void* relu_mask16,
                        int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream) {
@@ -2007,12 +2023,12 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     const size_t lds = gemm_lds_bytes(128, 64);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((unsigned)gemm_grid(tiles, n_cu)), dim3(256), lds, s, g);
   } else {
     const size_t lds = gemm_lds_bytes(128, 128);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((unsigned)std::min<long>(tiles, 2L * n_cu)), dim3(256), lds, s, g);
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((unsigned)gemm_grid(tiles, n_cu)), dim3(256), lds, s, g);
   }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
