@@ -125,6 +125,38 @@ def test_illegal_move_is_reported_not_applied():
         dev2.check_errors()
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(players=5, hand_size=4, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80),    # <5,4>
+    dict(players=3, hand_size=5, sad=False, shuffle_color=True, knowledge_mode=1, bomb=0, max_len=30),   # <3,5>, V0 fix-up
+    dict(players=4, hand_size=4, sad=False, shuffle_color=False, knowledge_mode=0, bomb=1, max_len=80),  # <4,4>
+    dict(players=5, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80),    # generic <0,0>
+    dict(players=2, hand_size=5, sad=False, shuffle_color=False, knowledge_mode=0, bomb=0, max_len=12),  # <2,5>, short games
+], ids=lambda c: "p%dh%d" % (c["players"], c["hand_size"]))
+def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg):
+    """the persistent rollout kernel (hsad_env_set_rollout_chunk) has its own (players, hand) instantiations"""
+    from hanabi_sad_amd import BatchedHanabiEnv
+    from oracle.oracle import OracleVecEnv
+    G, seed, pseed = 64 * 2 + 11, 777, 3
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", **cfg)
+    dev.set_rollout_chunk(13)
+    ref = OracleVecEnv(G, seed, eps_list=EPS, **cfg)
+    for blk in range(2):
+        dev.rollout_random(40, pseed)      # launches of 13, 13, 13, 1 iterations
+        ref.rollout(40, pseed)
+        torch.cuda.synchronize()
+        dev.check_errors()
+        _cmp("priv_s", dev.priv_s, ref.priv_s, blk)
+        _cmp("legal_move", dev.legal_move, ref.legal, blk)
+        _cmp("own_hand", dev.own_hand, ref.own_hand, blk)
+        _cmp("eps", dev.eps, ref.eps, blk)
+        _cmp("reward", dev.reward, ref.reward, blk)
+        _cmp("terminal", dev.terminal, ref.terminal, blk)
+        _cmp("a", dev.a, ref.a, blk)
+    for e in ref.envs:
+        e.terminated()
+    _cmp("state dump", dev.export_state(), np.stack([e.export_state() for e in ref.envs]), 0)
+
+
 @pytest.mark.parametrize("parts,lock_us,chunk_iters", [(1, 0, 0), (3, 0, 0), (3, 30, 0), (2, 45, 0), (8, 0, 0), (8, 5, 0),
                                                         (1, 0, 7), (1, 10, 20), (3, 5, 50), (1, 0, 1)])
 def test_rollout_random_matches_oracle(parts, lock_us, chunk_iters):
