@@ -295,13 +295,17 @@ class R2D2NetKernels:
             keep.update(saved)
         return inp.view(T, N, H), h_new, (c_new if c_new is not None else torch.stack(cs, 0))
 
-    def precast(self, priv_s, h0):
-        """bf16 operands of step(): (observations zero-padded to Fp, hidden state); nets of the same shape can share them"""
-        return cast_pad_bf16(priv_s, self.Fp), cast_pad_bf16(h0.reshape(self.L * h0.shape[1], self.H), self.H).view(self.L, -1, self.H)
+    def precast(self, priv_s, h0, h16=None):
+        """bf16 operands of step(): (observations zero-padded to Fp, hidden state); nets of the same shape can share them.
+        h16: the bf16 copy of h0 a previous step() wrote next to it (same values: bf16(h0)), which saves the cast"""
+        if h16 is None or h16.shape != h0.shape or h16.dtype != torch.bfloat16 or not h16.is_contiguous():
+            h16 = cast_pad_bf16(h0.reshape(self.L * h0.shape[1], self.H), self.H).view(self.L, -1, self.H)
+        return cast_pad_bf16(priv_s, self.Fp), h16
 
     def step(self, priv_s, h0, c0, pre=None):
         """one recurrent step for inference (R2D2Net.act, r2d2.py:65-78): priv_s fp32 [N,F], h0/c0 fp32 [L,N,H] (contiguous)
-        -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]).  One fused GEMM + cell kernel per layer.
+        -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]), new h rounded to bf16 [L,N,H] (layer l's slice is what layer
+        l + 1 consumed; the next step's precast takes it instead of casting h again).  One fused GEMM + cell kernel per layer.
         pre: precast(priv_s, h0) when the caller already has it (the online and the target net of an actor see the same
         observation and hidden state)."""
         N, F = priv_s.shape
@@ -311,13 +315,13 @@ class R2D2NetKernels:
         gemm_nt(a16, self.W1, N, H, self.Fp, bias=self.b1, out16=x, relu=True)
         h = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
         c = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
+        h16_new = torch.empty(self.L, N, H, dtype=torch.bfloat16, device=d)
         for l in range(self.L):
-            x_next = torch.empty(N, H, dtype=torch.bfloat16, device=d)
             _lib.check(self.lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), x.stride(0), h16[l].data_ptr(),
                                                      self.Wcat16[l].data_ptr(), self.bias16[l].data_ptr(), c0[l].data_ptr(),
-                                                     c[l].data_ptr(), h[l].data_ptr(), x_next.data_ptr(), _s(d)))
-            x = x_next
-        return x, h, c
+                                                     c[l].data_ptr(), h[l].data_ptr(), h16_new[l].data_ptr(), _s(d)))
+            x = h16_new[l]
+        return x, h, c, h16_new
 
     def heads(self, o16):
         """bf16 [M,H] -> fp32 [M, NH] = [advantage | value | aux logits]"""
@@ -749,8 +753,9 @@ class R2D2Agent:
                 and c0.is_contiguous())
 
     def _adv(self, net, priv_s, h0, c0, pre=None):
+        self._h16 = None
         if self._fused(net, priv_s, h0, c0):
-            o, h, c = net.step(priv_s, h0, c0, pre)      # big batches: fused GEMM + cell kernel per layer
+            o, h, c, self._h16 = net.step(priv_s, h0, c0, pre)      # big batches: fused GEMM + cell kernel per layer
             return net.heads(o), h, c
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
@@ -767,8 +772,11 @@ class R2D2Agent:
         on, tg = self.online, self.target
         pre = None
         if with_q and self._fused(on, obs["priv_s"], hid["h0"], hid["c0"]) and (on.Fp, on.H, on.L) == (tg.Fp, tg.H, tg.L):
-            pre = on.precast(obs["priv_s"], hid["h0"])   # both nets read the same bf16 observation / hidden state
+            pre = on.precast(obs["priv_s"], hid["h0"], hid.get("h0_16"))   # both nets read the same bf16 operands
         hd, h, c = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"], pre)
+        new_hid = {"h0": h, "c0": c}
+        if self._h16 is not None:
+            new_hid["h0_16"] = self._h16     # bf16(h0), written by the cell kernels anyway; zero_hidden_rows keeps it in step
         a = torch.empty(n, dtype=torch.int64, device=self.device)
         g = torch.empty(n, dtype=torch.int64, device=self.device)
         scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=self.device)
@@ -782,7 +790,7 @@ class R2D2Agent:
             _, reply["q_online_a"], _ = self.online.q_head(hd, obs["legal_move"], a, want_greedy=False)
             reply["q_target_greedy"] = self.q_of(self.target, obs, g, hid, pre)
             reply["versions"] = (self.online.version, self.target.version)
-        return reply, {"h0": h, "c0": c}
+        return reply, new_hid
 
     def q_of(self, net, obs, action, hid, pre=None):
         """Q_net(s, action) [N] for one step from the carried hidden state (one network pass)"""
@@ -834,3 +842,8 @@ def zero_hidden_rows(hid, terminal_u8, rows_per_flag):
         x = hid[k]
         L, N, H = x.shape
         _lib.check(lib.hsad_zero_rows(x.data_ptr(), terminal_u8.data_ptr(), L, N, H, rows_per_flag, _s(x.device)))
+    x = hid.get("h0_16")                   # the bf16 copy of h0 an acting step carries along: rows of H/2 32-bit words
+    if x is not None:
+        L, N, H = x.shape
+        assert H % 2 == 0 and x.is_contiguous()
+        _lib.check(lib.hsad_zero_rows(x.data_ptr(), terminal_u8.data_ptr(), L, N, H // 2, rows_per_flag, _s(x.device)))

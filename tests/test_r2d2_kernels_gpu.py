@@ -409,6 +409,12 @@ def test_act_leaves_its_input_state_untouched():
         _, new = agent.act(obs, hid)
         for k in hid:
             assert torch.equal(hid[k], keep[k]) and new[k].data_ptr() != hid[k].data_ptr()
+        if N >= 1024:     # fused path: the state carries its bf16 copy along, and a second step that uses it gives the same bits
+            assert torch.equal(new["h0_16"], new["h0"].to(torch.bfloat16))
+            r1, n1 = agent.act(obs, new)
+            agent.counter -= 1
+            r2, n2 = agent.act(obs, {"h0": new["h0"], "c0": new["c0"]})
+            assert torch.equal(r1["a"], r2["a"]) and torch.equal(n1["h0"], n2["h0"]) and torch.equal(n1["c0"], n2["c0"])
 
 
 @pytest.mark.parametrize("N,H", [(3000, 512), (1025, 256), (4200, 512), (4355, 256)])   # >= 4096 rows: 256x256 tiles
@@ -422,7 +428,8 @@ def test_fused_inference_cell_matches_the_two_kernel_path(N, H):
     priv = (torch.rand(N, F, generator=g) < 0.15).float().to(DEV)
     h0 = (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)
     c0 = (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)
-    o1, h1, c1 = net.step(priv, h0, c0)
+    o1, h1, c1, h16 = net.step(priv, h0, c0)
+    assert torch.equal(h16, h1.to(torch.bfloat16)) and torch.equal(o1, h16[-1])   # the bf16 copy the next step reuses
     o2, h2, c2 = net.trunk(priv.unsqueeze(0), h0, c0)
     assert torch.allclose(h1, h2, atol=2e-3, rtol=2e-3) and torch.allclose(c1, c2, atol=2e-3, rtol=2e-3)
     assert torch.allclose(o1.float(), o2.reshape(N, H).float(), atol=1e-2, rtol=1e-2)
