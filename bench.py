@@ -46,7 +46,7 @@ def measured_traffic_bytes(G, mode, chunk=0):
         for k, rec in json.load(open(path)).items():
             if chunk > 0:
                 if k.startswith("env_rollout_kernel<2,5>"):
-                    return rec["hbm_bytes_per_iteration"] * chunk if G == 65536 else None
+                    return rec["hbm_bytes_per_iteration"] * chunk if G == 65536 else None   # chunk = iterations per launch
                 continue
             if k.startswith("env_kernel<%d,2,5>" % mode):
                 return rec["hbm_bytes_per_launch"] if G == 65536 else None
@@ -333,7 +333,7 @@ def main():
                 # chip sustains; per_launch_* = one launch against its own duration -- the number rocprofv3's AverageNs for
                 # this kernel must agree with (persistent: the same thing, launches run back to back on one stream)
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic_bytes(G, 3, args.chunk if persistent else 0),
+                "traffic": measured_traffic_bytes(G, 3, iters_per_launch if persistent else 0),
                 "algorithmic_bytes_per_env_step": bytes_per_step,
                 "algorithmic_bytes_per_launch": bytes_per_step * G / K * iters_per_launch, "avg_launch_ms": fused_ms,
                 "launches": n_launch, "iterations_per_launch": iters_per_launch,
