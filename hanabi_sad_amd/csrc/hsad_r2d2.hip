@@ -729,8 +729,8 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
         const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
         const float c = gf * cp[i][k] + gi * gg;
         const float h = go * tanhf_(c);
-        a.c_out[(size_t)row * H + unit] = c;
-        a.h_out32[(size_t)row * H + unit] = h;
+        if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
+        if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
         if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
       }
     }
@@ -860,8 +860,8 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
         const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
         const float c = gf * cp[k] + gi * gg;
         const float h = go * tanhf_(c);
-        a.c_out[(size_t)row * H + unit] = c;
-        a.h_out32[(size_t)row * H + unit] = h;
+        if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
+        if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
         if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
       }
     }
@@ -2190,7 +2190,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream) {
-  if (!x16 || !h_prev16 || !Wcat_gate16 || !bias_gate16 || !c_prev || !c_out || !h_out32)
+  if (!x16 || !h_prev16 || !Wcat_gate16 || !bias_gate16 || !c_prev || (!c_out && !h_out32 && !h_out16))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: null argument");
   if (Bn < 1 || H < 64 || (H % kBK) || Kx < kBK || (Kx % kBK) || (ldx % 8) || ((4 * H) % 128))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: H and Kx must be multiples of 64, ldx of 8");

@@ -302,24 +302,26 @@ class R2D2NetKernels:
             h16 = cast_pad_bf16(h0.reshape(self.L * h0.shape[1], self.H), self.H).view(self.L, -1, self.H)
         return cast_pad_bf16(priv_s, self.Fp), h16
 
-    def step(self, priv_s, h0, c0, pre=None):
+    def step(self, priv_s, h0, c0, pre=None, want_state=True):
         """one recurrent step for inference (R2D2Net.act, r2d2.py:65-78): priv_s fp32 [N,F], h0/c0 fp32 [L,N,H] (contiguous)
         -> lstm output bf16 [N,H], new h, new c (fp32 [L,N,H]), new h rounded to bf16 [L,N,H] (layer l's slice is what layer
         l + 1 consumed; the next step's precast takes it instead of casting h again).  One fused GEMM + cell kernel per layer.
         pre: precast(priv_s, h0) when the caller already has it (the online and the target net of an actor see the same
-        observation and hidden state)."""
+        observation and hidden state).  want_state=False: only the output is needed (h, c come back as None and the cell
+        kernels skip 134 MB of state stores per layer at 32,768 rows)."""
         N, F = priv_s.shape
         H, d = self.H, self.device
         a16, h16 = pre if pre is not None else self.precast(priv_s, h0)
         x = torch.empty(N, H, dtype=torch.bfloat16, device=d)
         gemm_nt(a16, self.W1, N, H, self.Fp, bias=self.b1, out16=x, relu=True)
-        h = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
-        c = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
+        h = torch.empty(self.L, N, H, dtype=torch.float32, device=d) if want_state else None
+        c = torch.empty(self.L, N, H, dtype=torch.float32, device=d) if want_state else None
         h16_new = torch.empty(self.L, N, H, dtype=torch.bfloat16, device=d)
         for l in range(self.L):
             _lib.check(self.lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), x.stride(0), h16[l].data_ptr(),
                                                      self.Wcat16[l].data_ptr(), self.bias16[l].data_ptr(), c0[l].data_ptr(),
-                                                     c[l].data_ptr(), h[l].data_ptr(), h16_new[l].data_ptr(), _s(d)))
+                                                     c[l].data_ptr() if want_state else None,
+                                                     h[l].data_ptr() if want_state else None, h16_new[l].data_ptr(), _s(d)))
             x = h16_new[l]
         return x, h, c, h16_new
 
@@ -752,10 +754,10 @@ class R2D2Agent:
         return (net.Wcat16 is not None and net.WihT is None and priv_s.shape[0] >= 1024 and h0.is_contiguous()
                 and c0.is_contiguous())
 
-    def _adv(self, net, priv_s, h0, c0, pre=None):
+    def _adv(self, net, priv_s, h0, c0, pre=None, want_state=True):
         self._h16 = None
         if self._fused(net, priv_s, h0, c0):
-            o, h, c, self._h16 = net.step(priv_s, h0, c0, pre)      # big batches: fused GEMM + cell kernel per layer
+            o, h, c, self._h16 = net.step(priv_s, h0, c0, pre, want_state)   # big batches: fused GEMM + cell kernel per layer
             return net.heads(o), h, c
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
@@ -794,7 +796,7 @@ class R2D2Agent:
 
     def q_of(self, net, obs, action, hid, pre=None):
         """Q_net(s, action) [N] for one step from the carried hidden state (one network pass)"""
-        hd, _, _ = self._adv(net, obs["priv_s"], hid["h0"], hid["c0"], pre)
+        hd, _, _ = self._adv(net, obs["priv_s"], hid["h0"], hid["c0"], pre, want_state=False)
         _, qa, _ = net.q_head(hd, obs["legal_move"], action, want_greedy=False)
         return qa
 

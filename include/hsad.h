@@ -275,7 +275,8 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
  * [W_ih | W_hh]^T + bias with the cell update in the epilogue -- the gate pre-activations never reach HBM.  h_prev16 is
  * the bf16 cast [Bn,H] of the fp32 state (hsad_cast_pad_bf16) and may not alias h_out16.  Column order "gate16": rows of Wcat_gate16 bf16 [4H, Kx+H] and bias_gate16 [4H]
  * come in groups of 64 = [i(16) f(16) g(16) o(16)] of 16 hidden units (row 64*ub + 16*gate + u <- nn.LSTM row gate*H +
- * 16*ub + u); x16 bf16 [Bn,Kx] (ld = ldx); c_prev / c_out / h_out32 fp32 [Bn,H] (c_out may be c_prev); h_out16 bf16 [Bn,H] optional
+ * 16*ub + u); x16 bf16 [Bn,Kx] (ld = ldx); c_prev / c_out / h_out32 fp32 [Bn,H] (c_out may be c_prev; c_out, h_out32 and
+ * h_out16 are each optional -- a caller that only wants the layer's output, e.g. the target net of an actor, skips the state); h_out16 bf16 [Bn,H] optional
  * (the next layer's x). */
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
