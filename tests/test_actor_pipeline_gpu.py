@@ -55,6 +55,27 @@ def test_actor_fills_replay_with_well_formed_sequences_and_learner_trains():
     assert torch.equal(tr.act_online.w["fc_a.weight"], tr.learner.online.w["fc_a.weight"]) or tr.num_update % 2 != 1
 
 
+@pytest.mark.parametrize("games", [1024, 4096])
+def test_cached_q_priorities_on_the_fused_cell_kernels(games):
+    """the same bit-for-bit check at batch sizes that take the fused GEMM + cell kernels (2,048 rows: 128 x 128 tiles;
+    8,192 rows: 256 x 256 tiles), where the hidden state also carries its bf16 copy from step to step"""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    args = parse_args(["--num_game", str(games), "--batchsize", "16", "--replay_buffer_size", "4096", "--burn_in_frames", "64",
+                       "--act_base_eps", "0.4", "--sad", "1"])
+    tr = Trainer(args, "cuda:0")
+    tr.actor.verify_cached_priority = True
+    for it in range(24):
+        if it in (9, 10):
+            for net in (tr.act_online, tr.act_target):
+                net.w["fc_a.weight"].mul_(1.02)
+                net.w["lstm.weight_hh_l0"].mul_(0.99)
+                net.refresh()
+        tr.actor.step()
+    assert "h0_16" in tr.actor.hid and tr.actor.n_checked >= 18 and tr.actor.n_checked_stale >= 3
+    tr.env.check_errors()
+    tr.replay.check_errors()
+
+
 @pytest.mark.parametrize("method", ["iql", "vdn"])
 def test_actor_priorities_from_cached_q_equal_compute_priority_bit_for_bit(method):
     """DeviceActor forms the n-step priorities from Q_online(s_t, a_t) / Q_target(s_t, greedy_t) computed when step t was
