@@ -62,6 +62,8 @@ enum : int {
 struct EnvParams {
   int G, Gpad, P, H, A, F, F0, LAL, OB, OD, OL, OK, DECKW;
   int max_len, sad, shuffle_color, bomb, kmode, n_eps, track_dh, npl;
+  int gpw;         // games per workgroup: 64 (one per lane of the logic wave) or 32 (lanes 32-63 idle in the logic phase, half
+                   // the LDS bit rows): twice the workgroups when 64-game ones would leave most CUs with a single one
   int obs_words, legal_words, own_words, win_w;
   int win_words;   // LDS words per lane of the mt19937 prefetch window: win_w when win_w <= 32 (old words stay in registers,
                    // only the regenerated ones are stored), 2 * win_w + 1 otherwise
@@ -805,10 +807,11 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
-  const int g0 = ep.g_begin + blockIdx.x * kWave + g_bias;   // g_bias: always 0 (see env_rollout_kernel)
+  const int g0 = ep.g_begin + blockIdx.x * ep.gpw + g_bias;   // g_bias: always 0 (see env_rollout_kernel)
   const int g = g0 + lane;
-  const bool valid = g < ep.G;
-  const int ng = min(kWave, ep.G - g0);
+  const bool valid = lane < ep.gpw && g < ep.G;
+  const int ng = min(ep.gpw, ep.G - g0);
+  if (ng <= 0) return;   // 32-game workgroups: the padded game count (a multiple of 64) may add a whole empty workgroup
   const int P = TP ? TP : ep.P, H = TH ? TH : ep.H;
 
   if (MODE == 3 && ep.phase) {
@@ -1492,9 +1495,9 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
   ep.a_out = a_out;
   ep.g_out = g_out;
   if (mode == 3 && n_iter > 1)
-    hipLaunchKernelGGL(pick_rollout_kernel(ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds, stream, ep);
+    hipLaunchKernelGGL(pick_rollout_kernel(ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(kEnvThreads), lds, stream, ep);
   else
-    hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + kWave - 1) / kWave), dim3(kEnvThreads), lds,
+    hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(kEnvThreads), lds,
                        stream, ep, a, g);
 }
 
@@ -1557,9 +1560,18 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
     ep.win_words = ep.win_w <= 32 ? ep.win_w : 2 * ep.win_w + 1;
   }
   // +3 words of slack: or_bits may touch up to two words past the last row
-  ep.obs_words = (kWave * P * ep.F + 31) / 32 + 3;
-  ep.legal_words = (kWave * P * ep.A + 31) / 32 + 3;
-  ep.own_words = (kWave * P * 3 * H + 31) / 32 + 3;
+  {
+    // 32-game workgroups when 64-game ones would not even give every CU two (the persistent / fused kernels overlap one
+    // workgroup's game logic with another's observation stream): 2-player games up to 32,768 per GPU, and the 5-player
+    // configurations, whose 64-game bit rows need 60 KB of LDS
+    int dev_cus = 256;
+    (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+    const int forced = getenv("HSAD_ENV_GPW") ? atoi(getenv("HSAD_ENV_GPW")) : 0;
+    ep.gpw = (forced == 32 || forced == 64) ? forced : ((ep.G + kWave - 1) / kWave < 2 * dev_cus ? 32 : 64);
+  }
+  ep.obs_words = (ep.gpw * P * ep.F + 31) / 32 + 3;
+  ep.legal_words = (ep.gpw * P * ep.A + 31) / 32 + 3;
+  ep.own_words = (ep.gpw * P * 3 * H + 31) / 32 + 3;
   ep.obs_words = (ep.obs_words + 3) & ~3;
   ep.legal_words = (ep.legal_words + 3) & ~3;
   ep.own_words = (ep.own_words + 3) & ~3;
@@ -1582,7 +1594,8 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
     return set_error(HSAD_ERR_INVALID, "configuration needs %zu B of LDS per wave (> 160 KiB)", need);
   }
 
-  const size_t planes_b = sizeof(uint32_t) * (size_t)ep.npl * ep.Gpad;
+  // + 64: with 32-game workgroups the idle lanes 32-63 of the last workgroup still LOAD their plane words
+  const size_t planes_b = sizeof(uint32_t) * ((size_t)ep.npl * ep.Gpad + 64);
   const size_t mt_b = sizeof(uint32_t) * (size_t)ep.Gpad * kMtN;
   const size_t dh_b = (size_t)ep.Gpad * 52;
   hipError_t he;
@@ -1595,9 +1608,9 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   if ((he = hipMalloc(&ep.mt, mt_b)) != hipSuccess) return fail("mt19937 state");
   if ((he = hipMalloc(&ep.deck_hist, dh_b)) != hipSuccess) return fail("deck history");
   if ((he = hipMalloc(&ep.err, 16)) != hipSuccess) return fail("error log");
-  if ((he = hipMalloc(&ep.act_count, sizeof(uint32_t) * ep.Gpad)) != hipSuccess) return fail("act counters");
-  if ((he = hipMalloc(&ep.legal_bits, sizeof(uint64_t) * (size_t)ep.Gpad * P)) != hipSuccess) return fail("legal bits");
-  HIP_TRY(hipMemset(ep.legal_bits, 0, sizeof(uint64_t) * (size_t)ep.Gpad * P));
+  if ((he = hipMalloc(&ep.act_count, sizeof(uint32_t) * (ep.Gpad + 64))) != hipSuccess) return fail("act counters");
+  if ((he = hipMalloc(&ep.legal_bits, sizeof(uint64_t) * (size_t)(ep.Gpad + 64) * P)) != hipSuccess) return fail("legal bits");
+  HIP_TRY(hipMemset(ep.legal_bits, 0, sizeof(uint64_t) * (size_t)(ep.Gpad + 64) * P));
   if ((he = hipMalloc(&e->d_eps_list, sizeof(float) * cfg->n_eps)) != hipSuccess) return fail("eps list");
   ep.eps_list = e->d_eps_list;
   e->state_bytes = planes_b + mt_b + dh_b;
@@ -1697,7 +1710,7 @@ int hsad_env_policy_random(hsad_env* e, uint64_t policy_seed, int64_t* a, int64_
 int hsad_env_set_partitions(hsad_env* e, int n_part) {
   if (!e) return set_error(HSAD_ERR_INVALID, "null env");
   if (n_part < 1 || n_part > 16) return set_error(HSAD_ERR_INVALID, "n_part must be 1..16");
-  const int blocks = e->ep.Gpad / kWave;
+  const int blocks = e->ep.Gpad / e->ep.gpw;
   if (n_part > blocks) n_part = blocks;
   HIP_TRY(hipSetDevice(e->device));
   for (int k = e->n_part; k < n_part; ++k) {
@@ -1718,7 +1731,7 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
   if (!a) return set_error(HSAD_ERR_INVALID, "action tensor is null");
   if (e->ep.sad && !greedy_a) return set_error(HSAD_ERR_INVALID, "sad=1 requires greedy_a");
   const int K = e->n_part_active;
-  const int blocks = e->ep.Gpad / kWave;
+  const int blocks = e->ep.Gpad / e->ep.gpw;
   if (e->rollout_chunk > 0) {   // persistent: one launch = rollout_chunk iterations of every game (the last one may be shorter)
     for (int i = 0; i < n_iter; i += e->rollout_chunk)
       launch_env(e, 3, nullptr, nullptr, (hipStream_t)stream, 0, e->ep.Gpad, policy_seed, a, greedy_a, -1, 0, 0, 1,
@@ -1752,7 +1765,7 @@ int hsad_env_rollout_random(hsad_env* e, int n_iter, uint64_t policy_seed, int64
     for (int k = 0; k < K; ++k) {
       const int b0 = (int)((long long)blocks * k / K), b1 = (int)((long long)blocks * (k + 1) / K);
       if (b1 <= b0) continue;
-      launch_env(e, 3, nullptr, nullptr, e->part_stream[k], b0 * kWave, (b1 - b0) * kWave, policy_seed, a, greedy_a, k, tag,
+      launch_env(e, 3, nullptr, nullptr, e->part_stream[k], b0 * e->ep.gpw, (b1 - b0) * e->ep.gpw, policy_seed, a, greedy_a, k, tag,
                  first_tag, K);
     }
   }
