@@ -20,7 +20,8 @@ class EnvConfig(C.Structure):
         ("num_games", C.c_int32), ("players", C.c_int32), ("hand_size", C.c_int32), ("bomb", C.c_int32),
         ("seed0", C.c_int32), ("max_len", C.c_int32), ("sad", C.c_int32), ("shuffle_obs", C.c_int32),
         ("shuffle_color", C.c_int32), ("knowledge_mode", C.c_int32), ("n_eps", C.c_int32), ("device", C.c_int32),
-        ("track_deck_history", C.c_int32), ("deal_mode", C.c_int32), ("eps_list", C.POINTER(C.c_float)),
+        ("track_deck_history", C.c_int32), ("deal_mode", C.c_int32), ("games_per_workgroup", C.c_int32),
+        ("eps_list", C.POINTER(C.c_float)),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "hsad_env_hand_feature_size": (C.c_int, [_P]),
     "hsad_env_num_games": (C.c_int, [_P]),
     "hsad_env_num_players": (C.c_int, [_P]),
+    "hsad_env_games_per_workgroup": (C.c_int, [_P]),
     "hsad_env_state_bytes": (C.c_int64, [_P]),
     "hsad_env_bind_outputs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "hsad_env_reset": (C.c_int, [_P, _P]),

@@ -1523,6 +1523,8 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   if (cfg->n_eps < 1 || !cfg->eps_list) return set_error(HSAD_ERR_INVALID, "eps_list must hold >= 1 value");
   if (cfg->knowledge_mode != 0 && cfg->knowledge_mode != 1) return set_error(HSAD_ERR_INVALID, "knowledge_mode 0|1");
   if (cfg->max_len > 255) return set_error(HSAD_ERR_INVALID, "max_len must be <= 255");
+  if (cfg->games_per_workgroup != 0 && cfg->games_per_workgroup != 32 && cfg->games_per_workgroup != 64)
+    return set_error(HSAD_ERR_INVALID, "games_per_workgroup must be 0 (auto), 32 or 64");
   HIP_TRY(hipSetDevice(cfg->device));
 
   hsad_env* e = new (std::nothrow) hsad_env();
@@ -1566,7 +1568,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
     // configurations, whose 64-game bit rows need 60 KB of LDS
     int dev_cus = 256;
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
-    const int forced = getenv("HSAD_ENV_GPW") ? atoi(getenv("HSAD_ENV_GPW")) : 0;
+    const int forced = getenv("HSAD_ENV_GPW") ? atoi(getenv("HSAD_ENV_GPW")) : cfg->games_per_workgroup;
     ep.gpw = (forced == 32 || forced == 64) ? forced : ((ep.G + kWave - 1) / kWave < 2 * dev_cus ? 32 : 64);
   }
   ep.obs_words = (ep.gpw * P * ep.F + 31) / 32 + 3;
@@ -1656,6 +1658,7 @@ int hsad_env_num_action(const hsad_env* e) { return e ? e->ep.A : 0; }
 int hsad_env_hand_feature_size(const hsad_env* e) { return e ? e->ep.H * 25 : 0; }
 int hsad_env_num_games(const hsad_env* e) { return e ? e->ep.G : 0; }
 int hsad_env_num_players(const hsad_env* e) { return e ? e->ep.P : 0; }
+int hsad_env_games_per_workgroup(const hsad_env* e) { return e ? e->ep.gpw : 0; }
 int64_t hsad_env_state_bytes(const hsad_env* e) { return e ? (int64_t)e->state_bytes : 0; }
 int hsad_env_state_words(const hsad_env* e) { return e ? 80 + e->ep.P * e->ep.H * 6 + e->ep.P * 10 : 0; }
 

@@ -1935,8 +1935,22 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ x, c
 static inline size_t seq_sync_words(int nrec, int T, int nrb) { return (size_t)nrec * nrb * (T + 2); }
 static int g_force_cross_xcd = 0;   // hsad_lstm_set_exchange_mode
 
+// CUs of the current device: the persistent recurrences spin on sibling workgroups, so a launch must fit the chip with one
+// workgroup per CU (their LDS footprint allows no second one)
+static int device_cus() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+  }
+  return n_cu > 0 ? n_cu : 256;
+}
+static inline int seq_grid(int nrec, int H, int nrb) { return 8 * (H / 32) * ((nrec * nrb + 7) / 8); }
+
 static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s, unsigned* next = nullptr,
                           int next_words = 0) {
+  if (seq_grid(nrec, H, nrb) > device_cus())
+    return nfail(HSAD_ERR_INVALID, "persistent LSTM launch needs %d co-resident workgroups, the device has %d CUs", seq_grid(nrec, H, nrb), device_cus());
   const size_t lds = (size_t)(128 * (H + 8) + 32 * 40) * sizeof(bf16_t) + 16;
   m.nrec = nrec;
   m.nrb = nrb;
@@ -1945,7 +1959,7 @@ static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sy
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = next;
   m.zero_words = next_words;
-  const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
+  const dim3 grid(seq_grid(nrec, H, nrb));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_seq_fwd_kernel<16>, grid, dim3(256), lds, s, m);
@@ -1959,6 +1973,8 @@ static int launch_seq_fwd(LstmSeqArgsN m, int nrec, int H, int nrb, unsigned* sy
 
 static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned* sync, hipStream_t s, unsigned* next = nullptr,
                           int next_words = 0) {
+  if (seq_grid(nrec, H, nrb) > device_cus())
+    return nfail(HSAD_ERR_INVALID, "persistent LSTM launch needs %d co-resident workgroups, the device has %d CUs", seq_grid(nrec, H, nrb), device_cus());
   const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
   m.nrec = nrec;
   m.nrb = nrb;
@@ -1967,7 +1983,7 @@ static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned*
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = next;
   m.zero_words = next_words;
-  const dim3 grid(8 * (H / 32) * ((nrec * nrb + 7) / 8));
+  const dim3 grid(seq_grid(nrec, H, nrb));
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_seq_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, grid, dim3(256), lds, s, m);
@@ -2132,7 +2148,7 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
     HIP_TRY(hipMemsetAsync(h0_16_scratch, 0, (size_t)Bn * H * 2, s));
   }
   // persistent weight-stationary path (one launch for the whole sequence)
-  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
+  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && seq_grid(1, H, (Bn + 31) / 32) <= device_cus()) {
     const int nrb = (Bn + 31) / 32;
     unsigned* sync = (unsigned*)sync_scratch;
     unsigned* counters = sync + 2 * nrb;
@@ -2289,7 +2305,7 @@ int hsad_lstm_layer_backward(int T, int Bn, int H, const float* gates, const flo
   hipStream_t s = (hipStream_t)stream;
   const size_t step4 = (size_t)Bn * 4 * H, step1 = (size_t)Bn * H;
   bf16_t* dG = (bf16_t*)dG16;  // [T+1][Bn][4H]; slot T is the zero gradient entering the last step
-  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && (H / 32) * ((Bn + 31) / 32) <= 256) {
+  if (sync_scratch && (H == 256 || H == 512) && Bn <= 512 && seq_grid(1, H, (Bn + 31) / 32) <= device_cus()) {
     const int nrb = (Bn + 31) / 32;
     unsigned* sync = (unsigned*)sync_scratch;
     unsigned* counters = sync + 2 * nrb;

@@ -12,7 +12,7 @@ from . import _lib
 class BatchedHanabiEnv:
     def __init__(self, num_games, players=2, hand_size=5, seed=1, bomb=0, eps_list=(0.0,), max_len=80, sad=False,
                  shuffle_obs=False, shuffle_color=False, knowledge_mode=0, device="cuda:0", track_deck_history=True,
-                 deal_mode=0):
+                 deal_mode=0, games_per_workgroup=0):
         self.lib = _lib.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -21,7 +21,7 @@ class BatchedHanabiEnv:
         eps = (C.c_float * len(eps_list))(*[float(e) for e in eps_list])
         cfg = _lib.EnvConfig(num_games, players, hand_size, int(bomb), int(seed), int(max_len), int(bool(sad)),
                              int(bool(shuffle_obs)), int(bool(shuffle_color)), int(knowledge_mode), len(eps_list),
-                             dev_index, int(bool(track_deck_history)), int(deal_mode), eps)
+                             dev_index, int(bool(track_deck_history)), int(deal_mode), int(games_per_workgroup), eps)
         self.h = C.c_void_p()
         _lib.check(self.lib.hsad_env_create(C.byref(cfg), C.byref(self.h)))
         L = self.lib
@@ -29,6 +29,7 @@ class BatchedHanabiEnv:
         self.F = L.hsad_env_feature_size(self.h)
         self.A = L.hsad_env_num_action(self.h)
         self.sad = bool(sad)
+        self.games_per_workgroup = L.hsad_env_games_per_workgroup(self.h)   # kernel shape in use (32 | 64)
         d = self.device
         self.priv_s = torch.zeros(self.G, self.P, self.F, dtype=torch.float32, device=d)
         self.legal_move = torch.zeros(self.G, self.P, self.A, dtype=torch.float32, device=d)

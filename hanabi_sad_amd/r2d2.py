@@ -15,7 +15,7 @@ def _s(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
-def _pad32(k):
+def _pad64(k):
     """GEMM contraction dims are padded to the kernels' K tile (64)"""
     return (k + 63) // 64 * 64
 
@@ -90,8 +90,30 @@ def sync_scratch_pair(device, T, Bn, tag, nrec):
     zeroes `partner`, which the next launch with the same key then uses"""
     key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, int(nrec), int(T), int(Bn))
     flip = _PAIR.get(key, 0)
-    _PAIR[key] = flip ^ 1
     return (sync_scratch(device, T, Bn, tag + "/%d" % flip, nrec), sync_scratch(device, T, Bn, tag + "/%d" % (flip ^ 1), nrec))
+
+
+def sync_scratch_pair_commit(device, T, Bn, tag, nrec, ok):
+    """after the launch that used sync_scratch_pair's blocks: on success the roles swap (the partner was zeroed by the
+    launch); on failure nothing was enqueued, so both blocks are re-zeroed and the order kept"""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream, tag, int(nrec), int(T), int(Bn))
+    if ok:
+        _PAIR[key] = _PAIR.get(key, 0) ^ 1
+    else:
+        for f in (0, 1):
+            b = sync_scratch(device, T, Bn, tag + "/%d" % f, nrec)
+            b[:b.numel() - 4].zero_()      # the sticky timeout word (and its padding) stays
+
+
+def _launch_pair(fn, device, T, Bn, tag, nrec):
+    """run fn(cur, nxt) = one ping-pong persistent launch; the pair only flips once the launch was enqueued"""
+    cur, nxt = sync_scratch_pair(device, T, Bn, tag, nrec)
+    try:
+        fn(cur, nxt)
+    except Exception:
+        sync_scratch_pair_commit(device, T, Bn, tag, nrec, False)
+        raise
+    sync_scratch_pair_commit(device, T, Bn, tag, nrec, True)
 
 
 def check_sync():
@@ -173,8 +195,8 @@ def trunk_pipelined_multi(nets, priv_s, keeps, chunks):
         for i in range(0, len(recs), per_launch):
             part = recs[i:i + per_launch]
             arr = (_lib.LstmFwdRec * len(part))(*part)
-            cur, nxt = sync_scratch_pair(d, Tc, N, "fwdm", len(part))
-            _lib.check(lib.hsad_lstm_forward_chunk_multi(len(part), Tc, N, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d)))
+            _launch_pair(lambda cur, nxt: _lib.check(lib.hsad_lstm_forward_chunk_multi(
+                len(part), Tc, N, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d))), d, Tc, N, "fwdm", len(part))
     out = []
     for q, keep in zip(st, keeps):
         if keep is not None:
@@ -192,7 +214,9 @@ class R2D2NetKernels:
         if self.device.type != "cuda":
             raise _lib.HsadError("R2D2NetKernels needs a ROCm device; there is no CPU path")
         self.lib = _lib.load_library()
-        self.w = {k: v.detach().to(self.device, torch.float32).contiguous() for k, v in weights.items()}
+        # always OWN the fp32 masters (.to() alone aliases a caller's fp32 tensors that already live on this GPU: nets built
+        # from one dict would then share storage and update_actor_model / sync_target_with_online would write through)
+        self.w = {k: v.detach().to(self.device, torch.float32).clone().contiguous() for k, v in weights.items()}
         self.H = self.w["fc_v.weight"].shape[1]
         self.F = self.w["net.0.weight"].shape[1]
         self.A = self.w["fc_a.weight"].shape[0]
@@ -202,12 +226,12 @@ class R2D2NetKernels:
         if extra:
             raise _lib.HsadError("R2D2NetKernels supports the reference default shape only (1 fc layer, 2 LSTM layers); "
                                  "unexpected parameters: %s" % extra)
-        self.Fp = _pad32(self.F)
+        self.Fp = _pad64(self.F)
         self.perm = gate_block_perm(self.H, self.device)
         self.perm32 = self.perm.to(torch.int32).contiguous()
         H, d, bf = self.H, self.device, torch.bfloat16
         self.NH = self.A + 1 + self.NP
-        self.NHp = _pad32(self.NH)
+        self.NHp = _pad64(self.NH)
         # kernel operands live in fixed buffers that refresh() re-fills in place (pad regions stay zero)
         self.W1 = torch.zeros(H, self.Fp, dtype=bf, device=d)
         self.Wih = [torch.empty(4 * H, H, dtype=bf, device=d) for _ in range(self.L)]
@@ -507,15 +531,21 @@ class R2D2Learner:
             qa, greedy = qa.view(T, B), greedy.view(T, B)
             thd = tg.heads(to.reshape(M, H))
         else:
-            # the target trunk does not depend on the online net: run it on a side stream
-            self.side.wait_stream(main)
+            # the target trunk does not depend on the online net: run it on a side stream -- unless both trunks would run
+            # persistent recurrences that cannot be co-resident (each spins on its own sibling workgroups, one per CU)
+            wgs = 8 * (H // 32) * (((B + 31) // 32 + 7) // 8)
+            concurrent = not (self.persistent and H in (256, 512) and B <= 512 and 2 * wgs > self._cus)
+            side_ = self.side if concurrent else main
+            if concurrent:
+                self.side.wait_stream(main)
             qa, greedy, q, o = on.forward(priv, legal, a, keep=keep)
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(side_):
                 to, _, _ = tg.trunk(priv)
                 thd = tg.heads(to.reshape(M, H))
-            main.wait_stream(self.side)
-            to.record_stream(main)
-            thd.record_stream(main)
+            if concurrent:
+                main.wait_stream(self.side)
+                to.record_stream(main)
+                thd.record_stream(main)
         _, tqa, _ = tg.q_head(thd, legal.reshape(M, A), greedy.reshape(-1), want_greedy=False)
         tqa = tqa.view(T, B)
         if NPL > 1:
@@ -536,7 +566,7 @@ class R2D2Learner:
             dqa = dqa.repeat_interleave(NPL, dim=1)      # every player's Q enters its game's sum with weight 1
             weight = weight.repeat_interleave(NPL)
         # ---- backward ----
-        Mp = _pad32(M)
+        Mp = _pad64(M)
         dheads = torch.empty(M, self.NHp, dtype=torch.bfloat16, device=d)
         _lib.check(lib.hsad_heads_backward(dqa.data_ptr(), legal.contiguous().data_ptr(), a.contiguous().data_ptr(),
                                            heads.data_ptr(), heads.stride(0),
@@ -707,8 +737,8 @@ class R2D2Learner:
             for i in range(0, len(recs), per_launch):
                 part = recs[i:i + per_launch]
                 arr = (_lib.LstmBwdRec * len(part))(*part)
-                cur, nxt = sync_scratch_pair(d, Tc, B, "bwdm", len(part))
-                _lib.check(lib.hsad_lstm_backward_chunk_multi(len(part), Tc, B, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d)))
+                _launch_pair(lambda cur, nxt: _lib.check(lib.hsad_lstm_backward_chunk_multi(
+                    len(part), Tc, B, H, arr, cur.data_ptr(), nxt.data_ptr(), _s(d))), d, Tc, B, "bwdm", len(part))
             if s_ == nch - 1:
                 e1 = torch.cuda.Event()
                 e1.record(main)                           # layer 1 complete

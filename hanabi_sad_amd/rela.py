@@ -7,9 +7,16 @@ machinery has no counterpart by design: all games advance in lock-step on the GP
 `hanalearn.HanabiThreadLoop`s from ONE background Python thread (ctypes releases the GIL during launches), so a driver
 written against the reference -- create_envs / create_threads / ActGroup / context.start() / replay.sample() -- works
 unchanged; `Context.step()` is there for drivers that prefer to interleave rollout and learning themselves."""
+import threading
+
 import torch
 
 from .replay import DeviceReplay, aggregate_priority as _aggregate_priority
+
+# BatchRunner's mtxUpdate_ (rela/batch_runner.h:74-77,106-109): a weight update never interleaves with a rollout step that
+# the Context thread is enqueueing (both sides enqueue on the same stream; a refresh() between two layers of an act() would
+# run one step on mixed weights)
+_MODEL_LOCK = threading.RLock()
 
 
 class RNNTransition:
@@ -89,13 +96,14 @@ class BatchRunner:
         """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
         from .r2d2 import R2D2NetKernels
         on, tg = self._split(py_model)
-        if self.online is None:
-            self.online, self.target = R2D2NetKernels(on, self.device), R2D2NetKernels(tg, self.device)
-            return
-        for net, sd in ((self.online, on), (self.target, tg)):
-            for k, v in sd.items():
-                net.w[k].copy_(v)
-            net.refresh()
+        with _MODEL_LOCK:
+            if self.online is None:
+                self.online, self.target = R2D2NetKernels(on, self.device), R2D2NetKernels(tg, self.device)
+                return
+            for net, sd in ((self.online, on), (self.target, tg)):
+                for k, v in sd.items():
+                    net.w[k].copy_(v)
+                net.refresh()
 
     def start(self):
         pass
@@ -130,6 +138,7 @@ class Context:
 
     def __init__(self):
         self.loops, self._thread, self._paused, self._stop, self._error = [], None, False, False, None
+        self._parked = threading.Event()      # set by the loop thread while it sits between two steps with _paused seen
 
     def push_env_thread(self, loop):
         self.loops.append(loop)
@@ -140,17 +149,24 @@ class Context:
         try:
             while not self._stop:
                 if self._paused:
+                    self._parked.set()
                     time.sleep(0.001)
                     continue
+                self._parked.clear()
                 busy = False
                 for lp in self.loops:
+                    if self._paused or self._stop:
+                        break
                     if not (hasattr(lp, "finished") and lp.finished()):
-                        lp.step()
+                        with _MODEL_LOCK:
+                            lp.step()
                         busy = True
-                if not busy:
+                if not busy and not self._paused:
                     break
         except Exception as e:   # surfaced by the next Context call from the driver's thread
             self._error = e
+        finally:
+            self._parked.set()
 
     def _check(self):
         if self._error is not None:
@@ -167,14 +183,21 @@ class Context:
         """advance every attached loop by one lock-step iteration from the caller's thread (alternative to start())"""
         for lp in self.loops:
             if not (hasattr(lp, "finished") and lp.finished()):
-                lp.step()
+                with _MODEL_LOCK:
+                    lp.step()
 
     def pause(self):
+        """blocks until the loop thread is parked between two steps, like the reference's pause (rela/context.h:52-60 waits
+        for every ThreadLoop to reach waitUntilResume)"""
         self._check()
         self._paused = True
+        if self._thread is not None and self._thread.is_alive():
+            self._parked.wait()
+        self._check()
 
     def resume(self):
         self._check()
+        self._parked.clear()
         self._paused = False
 
     def terminate(self):

@@ -16,7 +16,7 @@ import torch
 
 from .actor import DeviceActor, transition_fields
 from .env import BatchedHanabiEnv
-from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2Learner, R2D2NetKernels
+from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2Learner, R2D2NetKernels, check_sync
 from .replay import DeviceReplay, aggregate_priority
 
 
@@ -165,6 +165,11 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend)
     dev = "cuda:%d" % torch.cuda.current_device()
+    if args.method == "vdn":
+        # selfplay.py:103-106: a VDN transition holds every player's row, so batch / replay / burn-in count games
+        args.batchsize = int(np.round(args.batchsize / args.num_player))
+        args.replay_buffer_size //= args.num_player
+        args.burn_in_frames //= args.num_player
     tr = Trainer(args, dev, rank, world)
     t0 = time.time()
     while tr.replay.size() < max(args.batchsize, args.burn_in_frames // world):   # per-shard share of the burn-in
@@ -179,10 +184,13 @@ def main(argv=None):
         loss, g_norm = tr.learner_update()
         if u % 20 == 0 and loss is not None:
             print("update %d loss %.4f grad_norm %.3f replay %d" % (u, float(loss), float(g_norm), tr.replay.size()))
+        if u % 200 == 199:
+            check_sync()      # a persistent recurrence that gave up waiting for a sibling leaves garbage: stop, do not train on it
     torch.cuda.synchronize()
     dt = time.time() - t0
     tr.env.check_errors()
     tr.replay.check_errors()
+    check_sync()
     # Tachometer definitions (pyhanabi/utils.py:229-240)
     print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt,
                                                              (tr.actor.num_act - acts0) / dt, tr.replay.size()))

@@ -55,6 +55,9 @@ typedef struct hsad_env_config {
   int32_t track_deck_history; /* keep per-game dealt-card log for deck_history()                    */
   int32_t deal_mode;      /* 0 = exact integer fast path with fp64 fallback (default); 1 = always run the
                              literal libstdc++ discrete_distribution fp64 arithmetic (same results)   */
+  int32_t games_per_workgroup; /* kernel shape: 64 or 32 games per workgroup, 0 = chosen from num_games and the
+                             CU count (32 when 64-game workgroups would leave fewer than two per CU).  Scheduling
+                             only -- results are identical; both shapes are parity-tested                  */
   const float* eps_list;  /* HOST pointer, n_eps floats                                             */
 } hsad_env_config;
 
@@ -67,6 +70,8 @@ int hsad_env_num_action(const hsad_env* env);
 int hsad_env_hand_feature_size(const hsad_env* env);
 int hsad_env_num_games(const hsad_env* env);
 int hsad_env_num_players(const hsad_env* env);
+/* the kernel shape in use (32 or 64 games per workgroup; hsad_env_config.games_per_workgroup) */
+int hsad_env_games_per_workgroup(const hsad_env* env);
 /* bytes of internal device state held by the env (state planes + per-game mt19937) */
 int64_t hsad_env_state_bytes(const hsad_env* env);
 

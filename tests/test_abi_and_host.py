@@ -36,7 +36,7 @@ def test_create_rejects_bad_configs_without_touching_the_gpu(hsad_lib):
     h = C.c_void_p()
     bad = [
         dict(num_games=0), dict(players=1), dict(players=6), dict(hand_size=0), dict(hand_size=6),
-        dict(shuffle_obs=1), dict(n_eps=0), dict(knowledge_mode=2), dict(max_len=300),
+        dict(shuffle_obs=1), dict(n_eps=0), dict(knowledge_mode=2), dict(max_len=300), dict(games_per_workgroup=16),
     ]
     for override in bad:
         kw = dict(num_games=4, players=2, hand_size=5, bomb=0, seed0=1, max_len=80, sad=0, shuffle_obs=0,

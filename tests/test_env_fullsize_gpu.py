@@ -1,5 +1,9 @@
-"""BASELINE configs[1] at FULL size (65,536 concurrent 2-player games) through size-independent properties, plus the
-reference-bit-parity of a 1,024-game slice of the same run:
+"""BASELINE env configurations at FULL size through size-independent properties, plus the reference-bit-parity of a
+1,024-game slice of the same run:
+  configs[1]  65,536 concurrent 2-player games (no SAD, no colour shuffle),
+  the dev.sh / sad+op production shape: 65,536 2-player games with SAD and colour shuffle (64-game workgroups),
+  configs[4]  5 players, hand 4, colour shuffle, SAD, 16,384 games per GPU -- in BOTH kernel shapes (the automatic
+              32-game workgroups and the 64-game ones).
 
 * card conservation and token ranges in every game after every block of steps (deck + hands + discards + fireworks = the
   50-card deck; 0 <= info <= 8; 0 <= life <= 3; score = sum of fireworks),
@@ -15,14 +19,25 @@ import torch
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
 DEV = "cuda:0"
-G, ITERS, SEED, PSEED = 65536, 90, 2024, 77
+ITERS, SEED, PSEED = 90, 2024, 77
 EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
 FULL_DECK = np.array([3, 2, 2, 2, 1] * 5, dtype=np.int64)
 
+SHAPES = {
+    "configs1_2p_65536": dict(G=65536, players=2, hand_size=5, sad=False, shuffle_color=False, gpw=0, expect_gpw=64),
+    "2p_sad_op_65536": dict(G=65536, players=2, hand_size=5, sad=True, shuffle_color=True, gpw=0, expect_gpw=64),
+    "configs4_5p_16384_gpw32": dict(G=16384, players=5, hand_size=4, sad=True, shuffle_color=True, gpw=0, expect_gpw=32),
+    "configs4_5p_16384_gpw64": dict(G=16384, players=5, hand_size=4, sad=True, shuffle_color=True, gpw=64, expect_gpw=64),
+}
 
-def make(parts, lock, chunk=0):
+
+def make(shape, parts, lock, chunk=0):
     from hanabi_sad_amd import BatchedHanabiEnv
-    e = BatchedHanabiEnv(G, seed=SEED, eps_list=EPS, max_len=80, device=DEV, track_deck_history=False)
+    c = SHAPES[shape]
+    e = BatchedHanabiEnv(c["G"], players=c["players"], hand_size=c["hand_size"], sad=c["sad"], shuffle_color=c["shuffle_color"],
+                         seed=SEED, eps_list=EPS, max_len=80, device=DEV, track_deck_history=False,
+                         games_per_workgroup=c["gpw"])
+    assert e.games_per_workgroup == c["expect_gpw"]
     e.set_partitions(parts)
     e.set_rollout_stagger(lock)
     e.set_rollout_chunk(chunk)
@@ -56,8 +71,9 @@ def checksum(t):
     return int((x.flatten() * w).sum().item())
 
 
-def test_full_size_rollout_properties_and_partition_invariance():
-    a, b, pers = make(1, 0), make(3, 30), make(1, 5, 30)
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_full_size_rollout_properties_and_partition_invariance(shape):
+    a, b, pers = make(shape, 1, 0), make(shape, 3, 30), make(shape, 1, 5, 30)
     for blk in range(3):
         a.rollout_random(ITERS // 3, PSEED)
         b.rollout_random(ITERS // 3, PSEED)
@@ -81,17 +97,20 @@ def test_full_size_rollout_properties_and_partition_invariance():
         assert torch.equal(lm[:, :, -1] == 1, noop_only)
     assert len(b.last_rollout_ms()) == 3
     # determinism: a fresh env with the same seeds reproduces the state dump
-    c = make(2, 45)
+    c = make(shape, 2, 45)
     c.rollout_random(ITERS, PSEED)
     torch.cuda.synchronize()
     assert np.array_equal(c.export_state().cpu().numpy(), a.export_state().cpu().numpy())
 
 
-def test_first_1024_games_of_the_full_size_run_equal_the_oracle():
+@pytest.mark.parametrize("shape", list(SHAPES))
+def test_first_1024_games_of_the_full_size_run_equal_the_oracle(shape):
     from oracle.oracle import OracleVecEnv
     n = 1024
-    dev = make(1, 5, 45)      # persistent launches: what bench.py times
-    ref = OracleVecEnv(n, SEED, players=2, hand_size=5, eps_list=EPS, max_len=80)
+    c = SHAPES[shape]
+    dev = make(shape, 1, 5, 45)      # persistent launches: what bench.py times
+    ref = OracleVecEnv(n, SEED, players=c["players"], hand_size=c["hand_size"], eps_list=EPS, max_len=80, sad=c["sad"],
+                       shuffle_color=c["shuffle_color"])
     for blk in range(2):
         dev.rollout_random(45, PSEED)
         ref.rollout(45, PSEED)

@@ -40,15 +40,22 @@ def _cmp(name, dev, ref, it):
             name, it, len(bad), bad[0], dev[tuple(bad[0])], np.asarray(ref)[tuple(bad[0])]))
 
 
+# both kernel shapes (hsad_env_config.games_per_workgroup): the automatic choice picks 32-game workgroups for every G a CPU
+# oracle can follow, so the 64-game instantiations -- what production sizes (>= 32,768 games) run -- are forced explicitly
+GPW = [32, 64]
+
+
+@pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "p%dh%d_sad%d_sc%d_k%d_d%d" % (
     c["players"], c["hand_size"], c["sad"], c["shuffle_color"], c["knowledge_mode"], c.get("deal_mode", 0)))
-def test_env_bit_parity(cfg):
+def test_env_bit_parity(cfg, gpw):
     from hanabi_sad_amd import BatchedHanabiEnv
     cfg = dict(cfg)
     G, iters = cfg.pop("G"), cfg.pop("iters")
     deal_mode = cfg.pop("deal_mode", 0)
     seed, pseed = 9000, 77
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", deal_mode=deal_mode, **cfg)
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", deal_mode=deal_mode, games_per_workgroup=gpw, **cfg)
+    assert dev.games_per_workgroup == gpw
     refs = [OracleEnv(seed=seed + g, eps_list=EPS, **cfg) for g in range(G)]
     P, F, A, H = dev.P, dev.F, dev.A, dev.H
     assert (F, A) == (refs[0].F, refs[0].A)
@@ -131,13 +138,19 @@ def test_illegal_move_is_reported_not_applied():
     dict(players=4, hand_size=4, sad=False, shuffle_color=False, knowledge_mode=0, bomb=1, max_len=80),  # <4,4>
     dict(players=5, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80),    # generic <0,0>
     dict(players=2, hand_size=5, sad=False, shuffle_color=False, knowledge_mode=0, bomb=0, max_len=12),  # <2,5>, short games
-], ids=lambda c: "p%dh%d" % (c["players"], c["hand_size"]))
-def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg):
-    """the persistent rollout kernel (hsad_env_set_rollout_chunk) has its own (players, hand) instantiations"""
+    dict(players=2, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80),    # <2,5>, dev.sh shape
+    dict(players=2, hand_size=5, sad=True, shuffle_color=False, knowledge_mode=1, bomb=1, max_len=80),   # <2,5>, V0 + bomb
+], ids=lambda c: "p%dh%d_sad%d_sc%d_k%d_b%d" % (c["players"], c["hand_size"], c["sad"], c["shuffle_color"],
+                                                 c["knowledge_mode"], c["bomb"]))
+@pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
+def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg, gpw):
+    """the persistent rollout kernel (hsad_env_set_rollout_chunk) has its own (players, hand) instantiations, each in
+    the 32- and the 64-games-per-workgroup shape"""
     from hanabi_sad_amd import BatchedHanabiEnv
     from oracle.oracle import OracleVecEnv
     G, seed, pseed = 64 * 2 + 11, 777, 3
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", **cfg)
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", games_per_workgroup=gpw, **cfg)
+    assert dev.games_per_workgroup == gpw
     dev.set_rollout_chunk(13)
     ref = OracleVecEnv(G, seed, eps_list=EPS, **cfg)
     for blk in range(2):
@@ -159,14 +172,17 @@ def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg):
 
 @pytest.mark.parametrize("parts,lock_us,chunk_iters", [(1, 0, 0), (3, 0, 0), (3, 30, 0), (2, 45, 0), (8, 0, 0), (8, 5, 0),
                                                         (1, 0, 7), (1, 10, 20), (3, 5, 50), (1, 0, 1)])
-def test_rollout_random_matches_oracle(parts, lock_us, chunk_iters):
+@pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
+def test_rollout_random_matches_oracle(parts, lock_us, chunk_iters, gpw):
     """hsad_env_rollout_random (fused policy; optional multi-stream partitions with a phase lock between the partition
     chains; or PERSISTENT launches that run chunk_iters iterations of every game each, workgroups started staggered --
     scheduling only) == oracle thread-loop."""
     from hanabi_sad_amd import BatchedHanabiEnv
     from oracle.oracle import OracleVecEnv
     G, iters, seed, pseed = 64 * 9 + 5, 60, 4242, 11
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, sad=True, shuffle_color=True, device="cuda:0")
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, sad=True, shuffle_color=True, device="cuda:0",
+                           games_per_workgroup=gpw)
+    assert dev.games_per_workgroup == gpw
     dev.set_partitions(parts)
     dev.set_rollout_stagger(lock_us)
     dev.set_rollout_chunk(chunk_iters)
