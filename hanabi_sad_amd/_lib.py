@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip")]
 _lib = None
 
 
@@ -126,6 +126,12 @@ SIGNATURES = {
     "hsad_lstm_backward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,
+                                C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "hsad_lstm_cell_f32_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "hsad_lstm_cell_f32_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "hsad_heads_backward_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,
+                                          C.c_int, _P]),
     "hsad_td_loss": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P]),
 }
 

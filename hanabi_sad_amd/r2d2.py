@@ -222,10 +222,7 @@ class R2D2NetKernels:
         self.A = self.w["fc_a.weight"].shape[0]
         self.NP = self.w["pred.weight"].shape[0]
         self.L = 2
-        extra = [k for k in self.w if k.startswith("lstm.") and k[-1] not in "01"] + [k for k in self.w if k.startswith("net.") and not k.startswith("net.0.")]
-        if extra:
-            raise _lib.HsadError("R2D2NetKernels supports the reference default shape only (1 fc layer, 2 LSTM layers); "
-                                 "unexpected parameters: %s" % extra)
+        self._check_shape(self.w)
         self.Fp = _pad64(self.F)
         self.perm = gate_block_perm(self.H, self.device)
         self.perm32 = self.perm.to(torch.int32).contiguous()
@@ -251,6 +248,26 @@ class R2D2NetKernels:
             self.WhhT = [torch.empty(H, 4 * H, dtype=bf, device=d) for _ in range(self.L)]
             self.WheadsT = torch.zeros(H, self.NHp, dtype=bf, device=d)
         self.refresh()
+
+    precision = "bf16"
+
+    @staticmethod
+    def _check_shape(w):
+        extra = [k for k in w if k.startswith("lstm.") and k[-1] not in "01"] + [k for k in w if k.startswith("net.") and not k.startswith("net.0.")]
+        if extra:
+            raise _lib.HsadError("the R2D2 kernels support the reference default shape only (1 fc layer, 2 LSTM layers); "
+                                 "unexpected parameters: %s" % extra)
+
+    @staticmethod
+    def make(weights, device="cuda:0", precision="bf16", **kw):
+        """bf16 = the production kernels (bf16 MFMA operands, fp32 accumulate / state); fp32 = the exact mode
+        (r2d2_f32.R2D2NetF32: fp32 operands on v_mfma_f32_32x32x2_f32, the reference's arithmetic type)"""
+        if precision == "fp32":
+            from .r2d2_f32 import R2D2NetF32
+            return R2D2NetF32(weights, device, **kw)
+        if precision != "bf16":
+            raise _lib.HsadError("precision must be 'bf16' or 'fp32'")
+        return R2D2NetKernels(weights, device, **kw)
 
     def _prep(self, src, perm, dst, dstT):
         R, C = src.shape
@@ -444,8 +461,9 @@ class R2D2Learner:
     clip + Adam), sync_target_with_online().  IQL batches [T,B,*] and VDN batches [T,B,P,*] (Q summed over players)."""
 
     def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0,
-                 device="cuda:0"):
+                 device="cuda:0", precision="bf16"):
         self.device = torch.device(device)
+        self.precision = precision
         self.multi_step, self.gamma = int(multi_step), float(gamma)
         self.lr, self.eps, self.grad_clip = float(lr), float(eps), float(grad_clip)
         # flat fp32 master parameters with named views (same names / shapes as R2D2Net.state_dict())
@@ -462,7 +480,7 @@ class R2D2Learner:
             gviews[k] = self.gflat[off:off + n].view(shape)
             views[k].copy_(online_weights[k])
             off += n
-        self.online = R2D2NetKernels(views, device, with_transposes=True)
+        self.online = R2D2NetKernels.make(views, device, precision, with_transposes=True)
         self.online.w = views           # the kernels' fp32 master weights ARE the flat buffer
         self.online.refresh()
         self.grad = gviews
@@ -471,7 +489,7 @@ class R2D2Learner:
         NH, Hh = self.online.NH, self.online.H
         self.g_wheads = self.gflat[o0:o0 + NH * Hh].view(NH, Hh)
         self.g_bheads = self.gflat[o0 + NH * Hh:o0 + NH * Hh + NH]
-        self.target = R2D2NetKernels(target_weights, device)
+        self.target = R2D2NetKernels.make(target_weights, device, precision)
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
         self.wgrad_split = 8     # split-K factor of the weight-gradient GEMMs (contraction over T*B)
@@ -482,6 +500,8 @@ class R2D2Learner:
 
     def _refresh_transposes(self):
         n = self.online
+        if self.precision == "fp32":
+            return
         self.WhhT, self.WihT, self.WheadsT, self.NHp = n.WhhT, n.WihT, n.WheadsT, n.NHp   # filled by online.refresh()
 
     def _wgrad_ws(self, n_out):
@@ -505,6 +525,9 @@ class R2D2Learner:
     def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
         """batch: dict priv_s [T,B,F], legal_move [T,B,A], a [T,B] i64, reward/bootstrap [T,B], seq_len [B],
         own_hand [T,B,3*hand].  Returns per-sequence loss [B] and priority [T,B]; fills self.grad."""
+        if self.precision == "fp32":
+            from .r2d2_f32 import loss_f32
+            return loss_f32(self, batch, weight, pred_weight, compute_grad)
         lib = _lib.load_library()
         on, tg, d = self.online, self.target, self.device
         priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]

@@ -59,11 +59,11 @@ class Trainer:
         W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed)
         # only the learner rank holds optimizer state; actor ranks receive parameters by broadcast
         self.learner = R2D2Learner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
-                                   device=device) if rank == 0 else None
+                                   device=device, precision=args.precision) if rank == 0 else None
         # the actors run their own copies of the agent, refreshed every actor_sync_freq updates
         # (ActGroup.update_model / BatchRunner::updateModel, create.py:143-145)
-        self.act_online = R2D2NetKernels(W, device)
-        self.act_target = R2D2NetKernels(W, device)
+        self.act_online = R2D2NetKernels.make(W, device, args.precision)
+        self.act_target = R2D2NetKernels.make(W, device, args.precision)
         self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
         self.vdn = args.method == "vdn"
         fields = transition_fields(self.env, self.vdn)
@@ -149,6 +149,9 @@ def parse_args(argv=None):
     p.add_argument("--act_eps_alpha", type=float, default=7)
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"],
+                   help="bf16 = production kernels (bf16 MFMA operands, fp32 accumulate/state); fp32 = the exact mode (the "
+                        "reference's arithmetic type, for validation: ~20x slower)")
     p.add_argument("--dist_backend", type=str, default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (smoke runs "
                    "with several ranks sharing a GPU: tensors are staged through host memory)")
     return p.parse_args(argv)

@@ -410,6 +410,30 @@ int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const fl
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * fp32-EXACT mode of the R2D2 network (csrc/hsad_r2d2_f32.hip): the reference's arithmetic type throughout
+ * (pyhanabi/r2d2.py:42-57,99-131,383-499) on v_mfma_f32_32x32x2_f32 (bitwise a k-ordered fmaf chain) with libm-accurate
+ * activations -- the mode the golden vectors are matched in at fp32 round-off, and the yardstick the bf16 path's stated
+ * tolerances are measured against.  Correctness mode: one launch per time step, no reduced-precision storage.
+ * ------------------------------------------------------------------------------------------ */
+/* C[M,N] = A * B^T (+bias[N]) (ReLU) (zero where relu_mask <= 0) (accumulated into C); operand element (m,k) of A at
+ * A[m*sam + k*sak], (n,k) of B at B[n*sbn + k*sbk] -- any of NT / NN / TN / TT without materialised transposes;
+ * row_map (may be NULL): result row r lands in row row_map[r] of C. */
+int hsad_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, int M, int N, int K,
+                  const float* bias, float* C, int ldc, int relu, int accumulate, const float* relu_mask, int ldmask,
+                  const int32_t* row_map, void* stream);
+/* nn.LSTM cell (gate columns [i|f|g|o] x H, natural order): gates [Bn,4H] in = pre-activations, out = activated gates;
+ * c_prev (NULL = zeros) -> c_out, h_out [Bn,H]. */
+int hsad_lstm_cell_f32_forward(float* gates, const float* c_prev, float* c_out, float* h_out, int Bn, int H, void* stream);
+/* BPTT through one cell: dh = dO (may be NULL) + dh_rec (may be NULL); dc_io [Bn,H] carries dc (in: from step t+1, out:
+ * for step t-1); dG [Bn,4H] = gradient wrt the gate pre-activations. */
+int hsad_lstm_cell_f32_backward(const float* gates, const float* c, const float* c_prev, const float* dO, const float* dh_rec,
+                                float* dc_io, float* dG, int Bn, int H, void* stream);
+/* hsad_heads_backward with an fp32 output [M, ldo] */
+int hsad_heads_backward_f32(const float* dqa, const float* legal, const int64_t* action, const float* heads, int ldh,
+                            const float* own_hand, const float* weight, int M, int B, int A, int NP, float pred_scale,
+                            float* out32, int ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
