@@ -1,8 +1,9 @@
-"""GPU tests of the hand-written R2D2 network kernels.
+"""GPU tests of the hand-written R2D2 network kernels: structure.
 
-Two kinds of reference: (1) a torch computation that rounds operands to bf16 at exactly the points the kernels
-do (tight tolerance: checks MFMA fragment layouts, tiling, epilogues); (2) the fp32 restatement pinned by the
-reference's golden vectors (bf16 tolerance, stated per quantity)."""
+Reference here = a torch computation that rounds operands to bf16 at exactly the points the kernels do (tight tolerance:
+checks MFMA fragment layouts, tiling, epilogues), plus schedule-equivalence checks (persistent vs per-step, chunk-pipelined vs
+unchunked, exchange protocols).  The comparisons with the REFERENCE's golden vectors and with fp32 autograd at full size live
+in tests/test_r2d2_precision_gpu.py, in both precisions, with the bf16 tolerances at 2x the measured error."""
 import os
 
 import numpy as np
@@ -130,42 +131,6 @@ def test_lstm_layer_forward_matches_bf16_emulated_torch(T, Bn, H, persistent):
     assert torch.allclose(hT, hf, rtol=2e-3, atol=2e-3)
 
 
-def test_forward_td_loss_against_golden_weights():
-    """Whole forward + TD/Huber/priority with the reference's (small) golden weights and batch."""
-    from hanabi_sad_amd.r2d2 import R2D2NetKernels, td_loss
-    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
-    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
-    t = lambda k: torch.tensor(z[k]).to(DEV)
-    priv, legal, a = t("loss.priv_s"), t("loss.legal_move"), t("loss.a")
-    online, target = R2D2NetKernels(Won, DEV), R2D2NetKernels(Wtg, DEV)
-    qa, greedy, q, o = online.forward(priv, legal, a)
-    # fp32 reference of the same nets
-    Wd = {k: v.to(DEV) for k, v in Won.items()}
-    T, B = a.shape
-    h0 = torch.zeros(2, B, online.H, device=DEV)
-    rqa, rgreedy, rq, ro = ref.net_forward(Wd, priv, legal, a, h0, h0.clone())
-    assert torch.allclose(q, rq, atol=2e-2, rtol=2e-2), (q - rq).abs().max()
-    assert torch.allclose(qa, rqa, atol=2e-2, rtol=2e-2)
-    assert torch.allclose(o.float(), ro, atol=2e-2, rtol=2e-2)
-    # greedy actions may only differ where the top-2 legal q are within the bf16 tolerance
-    diff = greedy != rgreedy
-    if diff.any():
-        top2 = ((1 + rq - rq.min()) * legal).topk(2, dim=2).values
-        assert ((top2[..., 0] - top2[..., 1])[diff] < 5e-2).all()
-    tqa, _, _, _ = target.forward(priv, legal, rgreedy)
-    err, prio, loss, dqa = td_loss(qa, tqa, t("loss.reward"), t("loss.bootstrap"), t("loss.seq_len"), int(z["meta"][8]),
-                                   float(z["gamma"][0]), weight=t("loss.weight"), want_grad=True)
-    assert np.allclose(prio.cpu().numpy(), z["loss.rl.priority"], atol=4e-2, rtol=4e-2)
-    assert np.allclose(loss.cpu().numpy(), z["loss.rl.loss"], atol=6e-2, rtol=6e-2)
-    # the TD kernel itself is exact fp32 arithmetic: feed it the reference's q-values
-    Wt = {k: v.to(DEV) for k, v in Wtg.items()}
-    rtqa, _, _, _ = ref.net_forward(Wt, priv, legal, rgreedy, h0, h0.clone())
-    err2, prio2, loss2, _ = td_loss(rqa.contiguous(), rtqa.contiguous(), t("loss.reward"), t("loss.bootstrap"),
-                                    t("loss.seq_len"), int(z["meta"][8]), float(z["gamma"][0]))
-    assert np.allclose(prio2.cpu().numpy(), z["loss.rl.priority"], atol=2e-5, rtol=2e-5)
-    assert np.allclose(loss2.cpu().numpy(), z["loss.rl.loss"], atol=2e-5, rtol=2e-5)
-
-
 def test_forward_full_size_against_fp32_restatement():
     """BASELINE configs[2] shapes: F=838, H=512, A=21, T=80, B=128, random-init nets."""
     from hanabi_sad_amd.r2d2 import R2D2NetKernels
@@ -190,35 +155,12 @@ def test_forward_full_size_against_fp32_restatement():
     Wd = {k: v.to(DEV) for k, v in W.items()}
     h0 = torch.zeros(2, B, H, device=DEV)
     rqa, rgreedy, rq, ro = ref.net_forward(Wd, priv, legal, a, h0, h0.clone())
-    assert torch.allclose(q, rq, atol=3e-2, rtol=3e-2), (q - rq).abs().max()
-    assert (greedy == rgreedy).float().mean() > 0.97
+    assert float((q - rq).abs().max()) < 6e-3, (q - rq).abs().max()       # measured 2.6e-3 (bf16 operands, 80 steps)
+    assert (greedy == rgreedy).float().mean() > 0.99
 
 
 def relerr(a, b):
     return float((a - b).norm() / b.norm().clamp(min=1e-12))
-
-
-@pytest.mark.parametrize("tag,pw", [("rl", 0.0), ("aux", 0.25)])
-def test_learner_gradients_against_reference_golden(tag, pw):
-    """loss / priority / every parameter gradient of (loss*weight).mean() vs the reference's autograd
-    (tests/golden, small net).  bf16 GEMM operands => tolerances are relative Frobenius errors."""
-    from hanabi_sad_amd.r2d2 import R2D2Learner
-    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
-    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
-    lr = R2D2Learner(Won, Wtg, int(z["meta"][8]), float(z["gamma"][0]), device=DEV)
-    t = lambda k: torch.tensor(z[k]).to(DEV)
-    batch = {k: t("loss." + k) for k in ("priv_s", "legal_move", "a", "reward", "bootstrap", "seq_len", "own_hand")}
-    loss, prio = lr.loss(batch, t("loss.weight"), pw)
-    assert np.allclose(loss.cpu().numpy(), z["loss.%s.loss" % tag], atol=8e-2, rtol=8e-2)
-    assert np.allclose(prio.cpu().numpy(), z["loss.%s.priority" % tag], atol=4e-2, rtol=4e-2)
-    worst = {}
-    for k, g in lr.grad.items():
-        want = torch.tensor(z["loss.%s.grad.%s" % (tag, k)]).to(DEV)
-        if want.abs().max() == 0:
-            assert g.abs().max() < 1e-6, k
-            continue
-        worst[k] = (relerr(g, want), float((g * want).sum() / (g.norm() * want.norm())))
-    assert all(np.isfinite(e) and e < 0.08 and c > 0.995 for e, c in worst.values()), worst
 
 
 def test_adam_step_matches_torch():
@@ -302,9 +244,11 @@ def test_persistent_recurrences_match_per_step_kernels_and_fp32_autograd(H, T, B
     Wtd = {k: v.to(DEV) for k, v in Wt.items()}
     rloss, rprio = ref.loss(Wd, Wtd, batch, 3, 0.999, 0.25)
     (rloss * weight).mean().backward()
-    assert torch.allclose(res[True][0], rloss.detach(), rtol=8e-2, atol=8e-2)
-    bad = {k: relerr(res[True][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[True][2][k], Wd[k].grad) > 0.1}
-    assert not bad, bad
+    # per-sequence losses: a bf16 near-tie may flip one greedy action (one target Q, one sequence) -- 90th percentile
+    dl = (res[True][0] - rloss.detach()).abs()
+    assert float(dl.kthvalue(max(1, int(0.9 * dl.numel()))).values) < 5e-2, dl
+    bad = {k: relerr(res[True][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[True][2][k], Wd[k].grad) > 1e-2}
+    assert not bad, bad                                                     # measured <= 3.4e-3 at the BASELINE shape
 
 
 @pytest.mark.parametrize("H,T,B,chunks", [(512, 80, 128, 4), (256, 20, 64, 5), (512, 12, 48, 3)])
@@ -334,7 +278,7 @@ def test_layer_pipelined_chunks_equal_the_unchunked_recurrences(H, T, B, chunks)
     Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
     rloss, _ = ref.loss(Wd, {k: v.to(DEV) for k, v in Wt.items()}, batch, 3, 0.999, 0.25)
     (rloss * weight).mean().backward()
-    bad = {k: relerr(res[chunks][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[chunks][2][k], Wd[k].grad) > 0.1}
+    bad = {k: relerr(res[chunks][2][k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and relerr(res[chunks][2][k], Wd[k].grad) > 1e-2}
     assert not bad, bad
 
 
@@ -443,40 +387,3 @@ def test_fused_inference_cell_matches_the_two_kernel_path(N, H):
     assert torch.allclose(h1[0], torch.sigmoid(o) * torch.tanh(c), atol=2e-3, rtol=2e-3)
 
 
-def test_agent_act_and_compute_priority_against_reference_golden():
-    from hanabi_sad_amd.r2d2 import R2D2Agent, R2D2NetKernels
-    z = np.load(os.path.join(GOLD, "r2d2_iql_sad_small.npz"))
-    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
-    agent = R2D2Agent(R2D2NetKernels(Won, DEV), R2D2NetKernels(Wtg, DEV), int(z["meta"][8]), float(z["gamma"][0]))
-    flat = lambda k: torch.tensor(z[k]).flatten(0, 1).to(DEV)
-
-    def hid(hk, ck):
-        f = lambda h: torch.tensor(h).reshape(h.shape[0] * h.shape[1], 2, -1).transpose(0, 1).contiguous().to(DEV)
-        return {"h0": f(z[hk]), "c0": f(z[ck])}
-    obs = {"priv_s": flat("act.priv_s"), "legal_move": flat("act.legal_move"), "eps": torch.zeros(flat("act.priv_s").shape[0], device=DEV)}
-    reply, new_hid = agent.act(obs, hid("act.h0", "act.c0"))
-    want = torch.tensor(z["act.out_greedy_a"].reshape(-1)).to(DEV)
-    # with eps = 0 both outputs are the greedy action; bf16 may only flip near-ties
-    assert torch.equal(reply["a"], reply["greedy_a"])
-    assert (reply["greedy_a"] == want).float().mean() >= 0.9
-    G = want.shape[0]
-    assert np.allclose(new_hid["h0"].transpose(0, 1).cpu().numpy(), z["act.out_h0"].reshape(G, 2, -1), atol=2e-2)
-    assert np.allclose(new_hid["c0"].transpose(0, 1).cpu().numpy(), z["act.out_c0"].reshape(G, 2, -1), atol=3e-2)
-    nobs = {"priv_s": flat("prio.next_priv_s"), "legal_move": flat("prio.next_legal_move")}
-    p = agent.compute_priority(obs, flat("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
-                               flat("prio.reward"), flat("prio.bootstrap"))
-    assert np.allclose(p.cpu().numpy(), z["prio.out"].reshape(-1), atol=4e-2, rtol=4e-2)
-    # the actor loop hands over the greedy action of its own act() on (next_obs, next_hid) instead of a third pass
-    nobs["eps"] = torch.zeros_like(obs["eps"])
-    nreply, _ = agent.act(nobs, hid("prio.next_h0", "prio.next_c0"))
-    p2 = agent.compute_priority(obs, flat("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
-                                flat("prio.reward"), flat("prio.bootstrap"), next_greedy_a=nreply["greedy_a"])
-    assert torch.equal(p, p2)
-    # exploration: eps = 1 must pick uniformly among legal moves, deterministic in (seed, counter)
-    obs["eps"] = torch.ones_like(obs["eps"])
-    agent.counter = 5
-    r1, _ = agent.act(obs, hid("act.h0", "act.c0"))
-    agent.counter = 5
-    r2, _ = agent.act(obs, hid("act.h0", "act.c0"))
-    assert torch.equal(r1["a"], r2["a"])
-    assert (obs["legal_move"].gather(1, r1["a"].unsqueeze(1)) == 1).all()

@@ -1,8 +1,8 @@
 """VDN layouts ([.., P, ..] tensors, Q summed over the players of a game; pyhanabi/r2d2.py:254-258,316-345,386-412) on the
 HIP kernels: golden vectors from the reference agent (tests/golden/r2d2_vdn_small.npz), fp32 autograd at the BASELINE
 shape (pipelined persistent recurrences with B*P = 256 rows), and the actor pipeline end to end.
-Tolerances as for the IQL tests (bf16 MFMA operands): priorities / loss atol+rtol 5e-2, gradients relative Frobenius
-error with cosine > 0.99."""
+The golden-vector comparison lives in tests/test_r2d2_precision_gpu.py (fp32-exact and bf16 parametrisations); tolerances here
+are 2-3 x the measured bf16 errors."""
 import os
 
 import numpy as np
@@ -22,47 +22,6 @@ def relerr(a, b):
 
 def cosine(a, b):
     return float(torch.nn.functional.cosine_similarity(a.float().flatten(), b.float().flatten(), dim=0))
-
-
-def test_vdn_learner_and_priority_against_reference_golden():
-    from hanabi_sad_amd.r2d2 import R2D2Agent, R2D2Learner, R2D2NetKernels
-    z = np.load(os.path.join(GOLD, "r2d2_vdn_small.npz"))
-    assert int(z["meta"][0]) == 1
-    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
-    n, gamma = int(z["meta"][8]), float(z["gamma"][0])
-    lr = R2D2Learner(Won, Wtg, n, gamma, device=DEV)
-    batch = {k[5:]: torch.tensor(z[k]).to(DEV) for k in z.files if k.startswith("loss.") and k.count(".") == 1}
-    assert batch["priv_s"].dim() == 4
-    loss, prio = lr.loss(batch, batch["weight"], 0.0)
-    assert np.allclose(loss.cpu().numpy(), z["loss.rl.loss"], atol=5e-2, rtol=5e-2)
-    assert np.allclose(prio.cpu().numpy(), z["loss.rl.priority"], atol=5e-2, rtol=5e-2)
-    bad = {}
-    for k, g in lr.grad.items():
-        want = torch.tensor(z["loss.rl.grad." + k])
-        if float(want.norm()) < 1e-7:
-            assert float(g.norm()) < 1e-5, k       # pred.* receives no gradient without the aux task
-            continue
-        if relerr(g.cpu(), want) > 0.12 or cosine(g.cpu(), want) < 0.99:
-            bad[k] = (relerr(g.cpu(), want), cosine(g.cpu(), want))
-    assert not bad, bad
-    with pytest.raises(Exception):
-        lr.loss(batch, batch["weight"], 0.25)        # VDN + aux: broken in the reference, rejected here
-    # compute_priority: Q summed over the 2 players of a game
-    P = z["act.priv_s"].shape[2]
-    agent = R2D2Agent(R2D2NetKernels(Won, DEV), R2D2NetKernels(Wtg, DEV), n, gamma)
-    f2 = lambda k: torch.tensor(z[k]).flatten(0, 2).to(DEV)
-
-    def hid(hk, ck):
-        f = lambda h: torch.tensor(h).reshape(h.shape[0] * h.shape[1], 2, -1).transpose(0, 1).contiguous().to(DEV)
-        return {"h0": f(z[hk]), "c0": f(z[ck])}
-    obs = {"priv_s": f2("act.priv_s"), "legal_move": f2("act.legal_move")}
-    nobs = {"priv_s": f2("prio.next_priv_s"), "legal_move": f2("prio.next_legal_move")}
-    p = agent.compute_priority(obs, f2("prio.a"), nobs, hid("act.h0", "act.c0"), hid("prio.next_h0", "prio.next_c0"),
-                               torch.tensor(z["prio.reward"]).flatten().to(DEV),
-                               torch.tensor(z["prio.bootstrap"]).flatten().to(DEV), num_player=P)
-    assert np.allclose(p.cpu().numpy(), z["prio.out"].reshape(-1), atol=5e-2, rtol=5e-2)
-    reply, _ = agent.act({**obs, "eps": torch.zeros(obs["priv_s"].shape[0], device=DEV)}, hid("act.h0", "act.c0"))
-    assert (reply["greedy_a"].cpu() == torch.tensor(z["act.out_greedy_a"].reshape(-1))).float().mean() >= 0.9
 
 
 def test_vdn_pipelined_learner_matches_fp32_autograd_at_baseline_shape():
@@ -88,12 +47,13 @@ def test_vdn_pipelined_learner_matches_fp32_autograd_at_baseline_shape():
     Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
     rloss, rprio = ref.loss(Wd, {k: v.to(DEV) for k, v in Wt.items()}, batch, 3, 0.999, 0.0)
     (rloss * weight).mean().backward()
-    assert torch.allclose(loss, rloss.detach(), rtol=8e-2, atol=1.5e-1)
-    # a bf16 near-tie can flip a greedy action and with it one target Q: allow 2 % outliers
-    close = (prio - rprio.detach()).abs() <= 8e-2 + 8e-2 * rprio.detach().abs()
-    assert float(close.float().mean()) > 0.98
+    # a bf16 near-tie can flip a greedy action and with it one target Q (one sequence): percentiles instead of max
+    dl = (loss - rloss.detach()).abs()
+    assert float(dl.kthvalue(int(0.9 * dl.numel())).values) < 1e-1, dl
+    dp = (prio - rprio.detach()).abs().flatten()
+    assert float(dp.kthvalue(int(0.999 * dp.numel())).values) < 1.2e-2
     bad = {k: relerr(lr.grad[k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and float(Wd[k].grad.norm()) > 0
-           and relerr(lr.grad[k], Wd[k].grad) > 0.1}
+           and relerr(lr.grad[k], Wd[k].grad) > 1.5e-2}
     assert not bad, bad
 
 
