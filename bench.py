@@ -41,9 +41,9 @@ def measured_traffic_bytes(G, mode, chunk=0):
     iterations per launch) from the committed rocprofv3 PMC passes (profiles/, collected with separate --pmc WRITE_SIZE /
     FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py).  Only valid for the configuration
     it was measured at; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
     try:
-        for k, rec in json.load(open(path)).items():
+        for k, rec in json.load(open(path))["env"].items():
             if chunk > 0:
                 if k.startswith("env_rollout_kernel<2,5>"):
                     return rec["hbm_bytes_per_iteration"] * chunk if G == 65536 else None   # chunk = iterations per launch
@@ -55,10 +55,23 @@ def measured_traffic_bytes(G, mode, chunk=0):
     return None
 
 
-def learner_bench(dev, updates=20, warmup=3):
+def gemm_traffic_bytes():
+    """HBM bytes per launch of the learner's LSTM input-projection GEMM (10240x2048x512) from the committed PMC passes"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))["gemm"]
+        for k, v in rec.items():
+            if k.startswith("gemm_nt_bf16_kernel"):
+                return v["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
+def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     """Second half of BASELINE.json's metric: R2D2 learner samples/sec at configs[2] (2p SAD IQL, F=838, A=21,
     H=512, 2-layer LSTM, B=128, T=80, n=3): sample-shaped synthetic batch -> loss fwd (online+target) -> BPTT ->
     clip+Adam, all on the hand-written HIP kernels (bf16 MFMA operands, fp32 accumulate/state)."""
+    import hanabi_sad_amd.r2d2 as r2d2
     from hanabi_sad_amd.r2d2 import R2D2Learner, gemm_nt
     torch.manual_seed(0)
     F, H, A, T, B = 838, 512, 21, 80, 128
@@ -94,9 +107,21 @@ def learner_bench(dev, updates=20, warmup=3):
         upd()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / updates
+    r2d2.check_sync()
     flop = 380.3e9  # online fwd + target fwd + online bwd
-    # the time-batched LSTM input-projection GEMM (M=T*B, N=4H, K=H), timed live with events on the launch stream
     M, N, K = T * B, 4 * H, H
+    if not gemm_probe:
+        return {"value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3}
+    # the time-batched LSTM input-projection GEMM (M=T*B, N=4H, K=H) WHERE IT RUNS: HIP events around its launches inside
+    # five more updates (the layer-0 projections of the online and the target net), on the stream it is launched on
+    r2d2.GEMM_TIMING = []
+    for _ in range(5):
+        upd()
+    torch.cuda.synchronize()
+    in_upd = [e0.elapsed_time(e1) for (m_, n_, k_, e0, e1) in r2d2.GEMM_TIMING if (m_, n_, k_) == (M, N, K)]
+    r2d2.GEMM_TIMING = None
+    in_update_ms = sum(in_upd) / max(1, len(in_upd))
+    # ... and standalone, back to back (what rocprofv3's AverageNs of a GEMM-only run shows)
     A16 = torch.randn(M, K, device=dev).to(torch.bfloat16)
     B16 = torch.randn(N, K, device=dev).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev)
@@ -108,7 +133,8 @@ def learner_bench(dev, updates=20, warmup=3):
         gemm_nt(A16, B16, M, N, K, out32=C)
     e1.record()
     torch.cuda.synchronize()
-    gemm_ms = e0.elapsed_time(e1) / 20
+    standalone_ms = e0.elapsed_time(e1) / 20
+    gemm_ms = in_update_ms if in_upd else standalone_ms
     gemm_tf = 2.0 * M * N * K / (gemm_ms * 1e-3) / 1e12
     return {
         "value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3, "dtype": "bf16 MFMA operands, fp32 accumulate",
@@ -116,8 +142,10 @@ def learner_bench(dev, updates=20, warmup=3):
                                "synthetic batch, random-init nets, loss fwd + BPTT + clip + Adam"},
         "update_tflops": flop / dt / 1e12,
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d)" % (M, N, K),
-                     "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0, "traffic": None,
-                     "avg_launch_ms": gemm_ms},
+                     "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0,
+                     "traffic": gemm_traffic_bytes(), "avg_launch_ms": gemm_ms, "in_update_launches_timed": len(in_upd),
+                     "standalone_avg_launch_ms": standalone_ms, "algorithmic_flop_per_launch": 2.0 * M * N * K,
+                     "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * N * 4},
     }
 
 

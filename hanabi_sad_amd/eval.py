@@ -9,15 +9,20 @@ import numpy as np
 import torch
 
 from .env import BatchedHanabiEnv
-from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2NetKernels, zero_hidden_rows
+from .r2d2 import R2D2Agent, R2D2NetKernels
 
 
-def evaluate(weights, num_game, seed, bomb, sad, *, num_player=2, hand_size=5, device="cuda:0", max_steps=200):
-    """-> (mean score, fraction of perfect games, scores list, num perfect) like eval.evaluate"""
+def evaluate(weights, num_game, seed, bomb, sad, *, num_player=2, hand_size=5, device="cuda:0", max_steps=200, precision="bf16",
+             shuffle_color=False):
+    """-> (mean score, fraction of perfect games, scores list, num perfect) like eval.evaluate.  `weights`: a weight dict, or
+    an R2D2Agent / net already on the device (its online net acts for every player)"""
     env = BatchedHanabiEnv(num_game, players=num_player, hand_size=hand_size, seed=seed, bomb=bomb, eps_list=[0.0],
-                           max_len=-1, sad=bool(sad), device=device, track_deck_history=False)
-    net = R2D2NetKernels(weights, device)
-    agent = R2D2Agent(net, net, 1, 0.99)
+                           max_len=-1, sad=bool(sad), shuffle_color=bool(shuffle_color), device=device, track_deck_history=False)
+    if isinstance(weights, R2D2Agent):
+        agent = R2D2Agent(weights.online, weights.online, 1, 0.99)
+    else:
+        net = weights if hasattr(weights, "trunk") else R2D2NetKernels.make(weights, device, precision)
+        agent = R2D2Agent(net, net, 1, 0.99)
     N = num_game * num_player
     hid = agent.get_h0(N)
     env.reset()
@@ -54,14 +59,4 @@ def _drain_errors(env):
     return n.value, g.value, c.value
 
 
-def save_weights(weights, path):
-    """online_net.state_dict() in the reference's key names -> `.pthw`"""
-    torch.save({k: weights[k].detach().cpu().clone() for k in PARAM_ORDER}, path)
-
-
-def load_weights(path, device="cpu"):
-    sd = torch.load(path, map_location=device)
-    missing = [k for k in PARAM_ORDER if k not in sd]
-    if missing:
-        raise KeyError("checkpoint lacks %s (expected R2D2Net.state_dict() keys)" % missing)
-    return {k: sd[k].float() for k in PARAM_ORDER}
+from .checkpoint import load_weights, save_weights  # noqa: E402,F401  (kept importable from here)

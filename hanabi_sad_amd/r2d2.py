@@ -36,8 +36,23 @@ def gate16_perm(H, device):
     return (gate * H + ub * 16 + u).reshape(-1).to(device)
 
 
+GEMM_TIMING = None   # bench.py: a list here makes gemm_nt bracket every launch with HIP events on its stream -> (M, N, K, e0, e1)
+
+
 def gemm_nt(A16, B16, M, N, K, bias=None, out32=None, out16=None, relu=False, accumulate=False):
     lib = _lib.load_library()
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        GEMM_TIMING.append((M, N, K, e0, e1))
+        e0.record()
+        try:
+            return _gemm_nt(lib, A16, B16, M, N, K, bias, out32, out16, relu, accumulate)
+        finally:
+            e1.record()
+    return _gemm_nt(lib, A16, B16, M, N, K, bias, out32, out16, relu, accumulate)
+
+
+def _gemm_nt(lib, A16, B16, M, N, K, bias, out32, out16, relu, accumulate):
     _lib.check(lib.hsad_gemm_nt_bf16(
         A16.data_ptr(), A16.stride(0), B16.data_ptr(), B16.stride(0), M, N, K,
         None if bias is None else bias.data_ptr(),

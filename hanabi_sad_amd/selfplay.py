@@ -87,16 +87,25 @@ class Trainer:
         self.act_online.refresh()
         self.act_target.refresh()
 
-    def learner_update(self):
-        """one learner iteration; collective when world > 1 (every rank calls it in lock-step: actor ranks serve their
-        share of the batch, receive the new priorities of the rows they contributed and, every actor_sync_freq updates,
-        the parameters)"""
+    def learner_update(self, stopwatch=None):
+        """one learner iteration (selfplay.py:208-244); collective when world > 1 (every rank calls it in lock-step: actor ranks
+        serve their share of the batch, receive the new priorities of the rows they contributed and, every actor_sync_freq
+        updates, the parameters).  stopwatch: a common.Stopwatch that receives the reference's five sections, each closed by a
+        device synchronisation like there (selfplay.py:215-241) -- off by default: the fences cost throughput."""
         a = self.args
+
+        def mark(key, sync=True):
+            if stopwatch is not None:
+                if sync:
+                    torch.cuda.synchronize()
+                stopwatch.time(key)
         if self.learner is not None and self.num_update % a.num_update_between_sync == 0:
             self.learner.sync_target_with_online()
         if self.num_update % a.actor_sync_freq == 0:
             self.update_actor_model()
+        mark("sync and updating")
         res = self.sharded.sample(a.batchsize)
+        mark("sample data", sync=False)
         if self.learner is None:
             self.sharded.update_priority()
             self.num_update += 1
@@ -111,30 +120,46 @@ class Trainer:
                      "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)
+        mark("forward & backward")
         g_norm = self.learner.optimizer_step()
+        mark("update model")
         self.sharded.update_priority(prio)
+        mark("updating priority", sync=False)
         self.num_update += 1
         return (loss * weight).mean(), g_norm
 
 
 def parse_args(argv=None):
+    """flags of pyhanabi/selfplay.py:26-86 (same names; defaults of the formal run scripts tools/*.sh where the two differ),
+    plus the few this stack adds (--num_game, --act_steps_per_update, --num_update, --precision, --stopwatch, --dist_backend)"""
     p = argparse.ArgumentParser(description="R2D2 self-play on the device pipeline (flags as in pyhanabi/selfplay.py)")
+    p.add_argument("--save_dir", type=str, default="", help="checkpoints + train.log go here; empty = do not save / tee")
     p.add_argument("--method", type=str, default="iql", choices=["iql", "vdn"])
+    p.add_argument("--shuffle_obs", type=int, default=0)
+    p.add_argument("--shuffle_color", type=int, default=0)
+    p.add_argument("--pred_weight", type=float, default=0.0)
+    p.add_argument("--num_eps", type=int, default=80)
+    p.add_argument("--load_model", type=str, default="")
     p.add_argument("--seed", type=int, default=10001)
     p.add_argument("--gamma", type=float, default=0.999)
     p.add_argument("--eta", type=float, default=0.9)
     p.add_argument("--train_bomb", type=int, default=0)
+    p.add_argument("--eval_bomb", type=int, default=0)
     p.add_argument("--sad", type=int, default=1)
-    p.add_argument("--shuffle_color", type=int, default=0)
-    p.add_argument("--pred_weight", type=float, default=0.0)
     p.add_argument("--num_player", type=int, default=2)
     p.add_argument("--hand_size", type=int, default=5)
     p.add_argument("--lr", type=float, default=6.25e-5)
     p.add_argument("--eps", type=float, default=1.5e-5)
     p.add_argument("--grad_clip", type=float, default=5.0)
+    p.add_argument("--num_lstm_layer", type=int, default=2)
     p.add_argument("--rnn_hid_dim", type=int, default=512)
+    p.add_argument("--train_device", type=str, default="cuda:0", help="accepted for compatibility: rank r trains / acts on its own GPU")
+    p.add_argument("--act_device", type=str, default="", help="accepted for compatibility (see --train_device)")
     p.add_argument("--batchsize", type=int, default=128)
-    p.add_argument("--num_update", type=int, default=100)
+    p.add_argument("--num_epoch", type=int, default=0, help="epochs of --epoch_len updates, each followed by Tachometer / "
+                   "statistics / evaluation / top-k save; 0 = the plain --num_update loop")
+    p.add_argument("--epoch_len", type=int, default=1000)
+    p.add_argument("--num_update", type=int, default=100, help="updates of the plain loop (when --num_epoch 0)")
     p.add_argument("--num_update_between_sync", type=int, default=2500)
     p.add_argument("--multi_step", type=int, default=3)
     p.add_argument("--burn_in_frames", type=int, default=2000)
@@ -143,21 +168,88 @@ def parse_args(argv=None):
     p.add_argument("--priority_weight", type=float, default=0.6)
     p.add_argument("--max_len", type=int, default=80)
     p.add_argument("--prefetch", type=int, default=3)
+    p.add_argument("--num_thread", type=int, default=0, help="with --num_game_per_thread: concurrent games = their product")
+    p.add_argument("--num_game_per_thread", type=int, default=0)
     p.add_argument("--num_game", type=int, default=4096, help="concurrent games on this GPU (num_thread*num_game_per_thread)")
-    p.add_argument("--num_eps", type=int, default=80)
     p.add_argument("--act_base_eps", type=float, default=0.1)
     p.add_argument("--act_eps_alpha", type=float, default=7)
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
+    p.add_argument("--num_eval_game", type=int, default=1000)
+    p.add_argument("--stopwatch", type=int, default=0, help="1 = time the reference's five learner sections (adds device syncs)")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"],
                    help="bf16 = production kernels (bf16 MFMA operands, fp32 accumulate/state); fp32 = the exact mode (the "
                         "reference's arithmetic type, for validation: ~20x slower)")
     p.add_argument("--dist_backend", type=str, default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (smoke runs "
                    "with several ranks sharing a GPU: tensors are staged through host memory)")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if args.num_thread > 0 and args.num_game_per_thread > 0:
+        args.num_game = args.num_thread * args.num_game_per_thread
+    if args.shuffle_obs:
+        raise SystemExit("--shuffle_obs is not supported (selfplay.py:175 asserts it off)")
+    if args.num_lstm_layer != 2:
+        raise SystemExit("--num_lstm_layer: the kernels implement the reference default of 2 layers")
+    return args
+
+
+def run_epochs(tr, args, rank=0):
+    """the epoch loop of selfplay.py:201-281: Tachometer / Stopwatch / MultiCounter output per epoch, then evaluation of the
+    online net on fresh games (eval.py:19-66) and the top-k / every-50-epochs saves"""
+    from .common import MultiCounter, Stopwatch, Tachometer, TopkSaver
+    from .eval import evaluate
+    saver = TopkSaver(args.save_dir, 5) if (args.save_dir and rank == 0) else None
+    stat, tach, sw = MultiCounter(args.save_dir or None), Tachometer(), Stopwatch()
+    history = []
+    rows = torch.zeros(args.epoch_len, 2, dtype=torch.float32, device=tr.device)   # (loss, grad_norm) per update, read once per epoch
+    factor = args.num_player if args.method == "vdn" else 1
+
+    class _ActCount:       # Tachometer reads sum(actor.num_act()): DeviceActor counts P acts per game step (utils.py:345-352)
+        def num_act(self_inner):
+            return tr.actor.num_act // factor
+    for epoch in range(args.num_epoch):
+        if rank == 0:
+            print("beginning of epoch: ", epoch)
+        tach.start()
+        stat.reset()
+        sw.reset()
+        for b in range(args.epoch_len):
+            for _ in range(args.act_steps_per_update):
+                tr.actor.step()
+            loss, g_norm = tr.learner_update(sw if args.stopwatch else None)
+            if loss is not None:
+                rows[b, 0], rows[b, 1] = loss, g_norm
+        check_sync()
+        tr.env.check_errors()
+        tr.replay.check_errors()
+        if rank != 0:
+            continue
+        for l_, g_ in rows.cpu().tolist():
+            stat["loss"].feed(l_)
+            stat["grad_norm"].feed(g_)
+        print("EPOCH: %d" % epoch)
+        tach.lap([_ActCount()], tr.replay, args.epoch_len * args.batchsize, factor)
+        if args.stopwatch:
+            sw.summary()
+        stat.summary(epoch)
+        # context.pause() has no counterpart: actors and learner alternate on this GPU, nothing runs while we evaluate
+        eval_seed = (9917 + epoch * 999999) % 7777777
+        score, perfect, _, _ = evaluate(tr.learner.online, args.num_eval_game, eval_seed, args.eval_bomb, args.sad,
+                                        num_player=args.num_player, hand_size=args.hand_size, device=str(tr.device))
+        saved = False
+        if saver is not None:
+            force = "model_epoch%d" % epoch if (epoch > 0 and epoch % 50 == 0) else None
+            sd = {k: tr.learner.online.w[k].detach().cpu().clone() for k in PARAM_ORDER}
+            saved = saver.save(None, sd, score, force_save_name=force)
+        print("epoch %d, eval score: %.4f, perfect: %.2f, model saved: %s" % (epoch, score, perfect * 100, saved))
+        print("==========")
+        history.append((score, perfect, saved))
+    return history
 
 
 def main(argv=None):
+    import pprint
+    import sys
+    from .common import Logger, set_all_seeds
     from .dist import rank_world
     args = parse_args(argv)
     rank, world = rank_world()
@@ -168,18 +260,35 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.dist_backend)
     dev = "cuda:%d" % torch.cuda.current_device()
+    if args.save_dir and rank == 0:
+        import os
+        os.makedirs(args.save_dir, exist_ok=True)
+        sys.stdout = Logger(os.path.join(args.save_dir, "train.log"))
+    set_all_seeds(args.seed)
+    if rank == 0:
+        pprint.pprint(vars(args))       # first thing in train.log: doubles as the saved configuration (utils.py:87-116)
     if args.method == "vdn":
         # selfplay.py:103-106: a VDN transition holds every player's row, so batch / replay / burn-in count games
         args.batchsize = int(np.round(args.batchsize / args.num_player))
         args.replay_buffer_size //= args.num_player
         args.burn_in_frames //= args.num_player
     tr = Trainer(args, dev, rank, world)
+    if args.load_model and tr.learner is not None:
+        from .checkpoint import load_weight
+        print("*****loading pretrained model*****")
+        load_weight(tr.learner.online.w, args.load_model)        # online net only, like selfplay.py:143-146
+        tr.learner.online.refresh()
+        print("*****done*****")
     t0 = time.time()
     while tr.replay.size() < max(args.batchsize, args.burn_in_frames // world):   # per-shard share of the burn-in
         for _ in range(10):
             tr.actor.step()
     tr.env.check_errors()
     print("burn-in done: replay %d sequences after %d acts in %.1fs" % (tr.replay.size(), tr.actor.num_act, time.time() - t0))
+    if args.num_epoch > 0:
+        run_epochs(tr, args, rank)
+        torch.cuda.synchronize()
+        return
     t0, acts0 = time.time(), tr.actor.num_act
     for u in range(args.num_update):
         for _ in range(args.act_steps_per_update):

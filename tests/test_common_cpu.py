@@ -1,0 +1,119 @@
+"""CPU tests of the run-level utilities (hanabi_sad_amd/common.py, checkpoint.py): behaviour of the
+reference's TopkSaver / Stopwatch / MultiCounter / Tachometer / Logger and of its `.pthw` loaders, the latter against files
+written by the reference itself (tests/golden/ref_small*.pthw, tests/golden/make_pthw_fixture.py)."""
+import os
+import sys
+
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REF_FLAGS = ["save_dir", "method", "shuffle_obs", "shuffle_color", "pred_weight", "num_eps", "load_model", "seed", "gamma", "eta",
+             "train_bomb", "eval_bomb", "sad", "num_player", "hand_size", "lr", "eps", "grad_clip", "num_lstm_layer",
+             "rnn_hid_dim", "train_device", "batchsize", "num_epoch", "epoch_len", "num_update_between_sync", "multi_step",
+             "burn_in_frames", "replay_buffer_size", "priority_exponent", "priority_weight", "max_len", "prefetch", "num_thread",
+             "num_game_per_thread", "act_base_eps", "act_eps_alpha", "act_device", "actor_sync_freq"]   # selfplay.py:26-86
+
+
+def test_every_reference_flag_is_accepted():
+    from hanabi_sad_amd.selfplay import parse_args
+    a = parse_args([])
+    for f in REF_FLAGS:
+        assert hasattr(a, f), f
+    a = parse_args(["--num_thread", "80", "--num_game_per_thread", "80", "--method", "vdn", "--act_device", "cuda:1,cuda:2"])
+    assert a.num_game == 6400
+    with pytest.raises(SystemExit):
+        parse_args(["--shuffle_obs", "1"])
+
+
+def test_topk_saver_keeps_the_best_k(tmp_path):
+    from hanabi_sad_amd.common import TopkSaver
+    s = TopkSaver(str(tmp_path / "ck"), 3)
+    sd = lambda v: {"w": torch.tensor([float(v)])}
+    assert [s.save(None, sd(p), p) for p in (5.0, 1.0, 3.0)] == [True, True, True]
+    assert s.save(None, sd(0.5), 0.5) is False                     # worse than everything kept
+    assert s.save(None, sd(4.0), 4.0, force_save_name="model_epoch50") is True   # replaces the 1.0
+    kept = sorted(float(torch.load(str(tmp_path / "ck" / ("model%d.pthw" % i)))["w"]) for i in range(3))
+    assert kept == [3.0, 4.0, 5.0]
+    assert float(torch.load(str(tmp_path / "ck" / "model_epoch50.pthw"))["w"]) == 4.0
+    s.save(None, sd(0.1), 0.1, save_latest=True)
+    assert float(torch.load(str(tmp_path / "ck" / "latest.pthw"))["w"]) == pytest.approx(0.1)
+
+
+def test_stopwatch_multicounter_tachometer_output(capsys):
+    from hanabi_sad_amd.common import MultiCounter, Stopwatch, Tachometer, ValueStats, num2str, sec2str
+    sw = Stopwatch()
+    for _ in range(3):
+        sw.time("sample data")
+        sw.time("forward & backward")
+    sw.summary()
+    out = capsys.readouterr().out
+    assert "@@@Time" in out and "sample data" in out and "forward & backward" in out and "@@@total time per iter" in out
+    st = MultiCounter(None)
+    for v in (3.0, 1.0, 2.0):
+        st["loss"].feed(v)
+    st.inc("saved")
+    st.summary(7)
+    out = capsys.readouterr().out
+    assert "7:loss" in out and "avg:   2.0000" in out and "min:   1.0000[   1]" in out and "max:   3.0000[   0]" in out
+    assert "saved: 1/1" in out
+    v = ValueStats("x")
+    assert v.summary() == "x[0]"
+    assert sec2str(3725) == "1H 02M 05S" and num2str(999) == "999" and num2str(1500) == "1.500K" and num2str(2.5e6) == "2.500M"
+
+    class A:
+        n = 0
+
+        def num_act(self):
+            return self.n
+
+    class R:
+        def num_add(self):
+            return 40
+
+        def size(self):
+            return 30
+    a, t = A(), Tachometer()
+    t.start()
+    a.n = 1000
+    import time
+    time.sleep(0.05)
+    train, act, add = t.lap([a], R(), 128, 2)
+    out = capsys.readouterr().out
+    assert "Speed: train:" in out and "buffer_size: 30" in out and "Total Sample: train: 128, act: 1.000K" in out
+    assert act / train == pytest.approx(1000 / 128) and add / train == pytest.approx(40 / 128)
+
+
+def test_logger_tees_stdout(tmp_path, capsys):
+    from hanabi_sad_amd.common import Logger
+    path = str(tmp_path / "exp" / "train.log")
+    old = sys.stdout
+    try:
+        sys.stdout = Logger(path)
+        print("hello log")
+    finally:
+        sys.stdout = old
+    assert "hello log" in open(path).read()
+
+
+def test_load_weight_semantics_on_files_written_by_the_reference(capsys):
+    from hanabi_sad_amd.checkpoint import load_weight, load_weights, op_model_arch
+    from hanabi_sad_amd.selfplay import init_weights
+    ref = torch.load(os.path.join(GOLD, "ref_small.pthw"), map_location="cpu")
+    W = init_weights(838, 64, 21, 5, 3)
+    assert set(W) == set(ref)                                   # same key names as R2D2Net.state_dict()
+    loaded, kept, dropped = load_weight(W, os.path.join(GOLD, "ref_small.pthw"))
+    assert not kept and not dropped and all(torch.equal(W[k], ref[k]) for k in ref)
+    assert all(torch.equal(v, ref[k]) for k, v in load_weights(os.path.join(GOLD, "ref_small.pthw")).items())
+    # legacy file: no pred.* (keep the net's own), an unknown key (ignored)
+    W2 = init_weights(838, 64, 21, 5, 4)
+    own_pred = W2["pred.weight"].clone()
+    loaded, kept, dropped = load_weight(W2, os.path.join(GOLD, "ref_small_legacy.pthw"))
+    out = capsys.readouterr().out
+    assert sorted(kept) == ["pred.bias", "pred.weight"] and dropped == ["obsolete.weight"]
+    assert "warning: pred.weight not loaded" in out and "removing: obsolete.weight not used" in out
+    assert torch.equal(W2["pred.weight"], own_pred) and torch.equal(W2["fc_a.weight"], ref["fc_a.weight"])
+    with pytest.raises(ValueError):
+        load_weight(init_weights(838, 32, 21, 5, 0), os.path.join(GOLD, "ref_small.pthw"))
+    assert [op_model_arch(i) for i in (0, 2, 3, 5, 6, 8, 9, 11)] == [(1, False), (1, False), (1, True), (1, True), (2, False),
+                                                                     (2, False), (2, True), (2, True)]

@@ -1,16 +1,20 @@
-"""Summarise two rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE; each collected in its own run with --kernel-trace only,
-as MI355X_MICROARCH.md §HBM prescribes) of tools/pmc_probe.py into profiles/<round>_pmc_hbm_traffic.json.
+"""Summarise rocprofv3 PMC passes (WRITE_SIZE and FETCH_SIZE, each collected in its OWN run with --kernel-trace only, as
+MI355X_MICROARCH.md §HBM prescribes) of tools/pmc_probe.py legs into profiles/<round>_pmc_hbm_traffic.json.
 
-  python tools/pmc_summarize.py <write_counter_collection.csv> <fetch_counter_collection.csv> <out.json>
+  python tools/pmc_summarize.py <out.json> <leg>:<write_counter_collection.csv>:<fetch_counter_collection.csv> ...
 
-Corrections: WRITE_SIZE is reported in KiB and is calibrated against a streaming fill of known size in the same run;
-FETCH_SIZE counts wide coalesced 128-B requests as 64 B on gfx950 (x2), calibrated against a known copy."""
+Corrections (the guide: FETCH_SIZE reports 1/2 of a wide coalesced read on gfx950; WRITE_SIZE and other access widths are
+UNCALIBRATED -- calibrate on a known byte count in the same run): every leg ends with a streaming fill and a copy of exactly
+CAL_BYTES; write_factor = CAL_BYTES / WRITE_SIZE(fill), fetch_factor = CAL_BYTES / FETCH_SIZE(copy).  The factors must come
+out near 1 (WRITE_SIZE in KiB) and near 2: anything else means the calibration kernel was not found or the counter changed
+meaning, and this script FAILS instead of guessing."""
 import csv, json, re, sys
 from collections import defaultdict
 
+CAL_BYTES = 65536 * 2 * 783 * 4
 G, P, F, A, H = 65536, 2, 783, 21, 5
-ALGO = (P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 + 256) * G     # SURVEY.md §8(d) bytes per env-step x G
-FILL_BYTES = G * P * F * 4
+ALGO_ENV = (P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 + 256) * G     # SURVEY.md §8(d) bytes per env-step x G
+GEMM_ALGO = 10240 * 512 * 2 + 2048 * 512 * 2 + 10240 * 2048 * 4    # A + B read (bf16), C written (fp32)
 
 
 def per_kernel(path, counter):
@@ -22,55 +26,78 @@ def per_kernel(path, counter):
 
 
 def pick(acc, pattern):
+    out = []
     for k, v in acc.items():
         if re.search(pattern, k):
-            return v
-    return []
+            out += v
+    return out
+
+
+def calibration(w, f):
+    fill = [v for v in pick(w, r"FillFunctor<float>") if v > 0.5 * CAL_BYTES / 1024]      # only the CAL_BYTES fills
+    copy = [v for v in pick(f, r"direct_copy_kernel|copyBuffer") if v > 0.2 * CAL_BYTES / 1024]
+    if not fill or not copy:
+        raise SystemExit("calibration kernels not found (fill: %d, copy: %d dispatches of the right size)" % (len(fill), len(copy)))
+    wf = (CAL_BYTES / 1024.0) / (sum(fill) / len(fill))
+    ff = (CAL_BYTES / 1024.0) / (sum(copy) / len(copy))
+    if not (0.9 < wf < 1.1) or not (1.8 < ff < 2.2):
+        raise SystemExit("implausible calibration: write_factor %.3f (want ~1), fetch_factor %.3f (want ~2)" % (wf, ff))
+    return {"cal_bytes": CAL_BYTES, "fill_WRITE_SIZE_KiB": sum(fill) / len(fill), "write_factor": wf,
+            "copy_FETCH_SIZE_KiB": sum(copy) / len(copy), "fetch_factor": ff,
+            "note": "factors = known bytes / counter, measured in this run on a %d-byte streaming fill (WRITE_SIZE, KiB) and copy "
+                    "(FETCH_SIZE, KiB; wide coalesced reads count half on gfx950)" % CAL_BYTES}
 
 
 def mean(v):
     return sum(v) / len(v) if v else None
 
 
-w, f = per_kernel(sys.argv[1], "WRITE_SIZE"), per_kernel(sys.argv[2], "FETCH_SIZE")
-fill_w = max(pick(w, "fillBufferAligned|FillFunctor|fill") or [0])          # the calibration fill of FILL_BYTES
-copy_f = max(pick(f, "copyBuffer|copy") or [0])
-write_factor = (FILL_BYTES / 1024.0) / fill_w if fill_w else None
-fetch_factor = (FILL_BYTES / 1024.0) / copy_f if copy_f else None
-out = {
-    "command": "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python tools/pmc_probe.py ; "
-               "rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python tools/pmc_probe.py  (separate passes)",
-    "calibration": {"fill_bytes": FILL_BYTES, "fill_WRITE_SIZE_KiB": fill_w, "write_factor": write_factor,
-                    "copy_FETCH_SIZE_KiB": copy_f, "fetch_factor": fetch_factor,
-                    "note": "factors = known bytes / counter; MI355X_MICROARCH.md §HBM: WRITE_SIZE exact in KiB, "
-                            "FETCH_SIZE undercounts wide coalesced reads 2x on gfx950"},
+KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None, note)]
+    "env": [("env_rollout_kernel<2,5> persistent fused reset+policy+step+observe, G=65536, 50 iterations per launch",
+             r"env_rollout_kernel<2, 5>", ALGO_ENV * 50, "iterations_per_launch=50"),
+            ("env_kernel<3,2,5> fused reset+policy+step+observe (rollout), G=65536 in 3 partition launches", r"env_kernel<3, 2, 5>", ALGO_ENV / 3, ""),
+            ("env_kernel<1,2,5> step+observe, G=65536", r"env_kernel<1, 2, 5>", ALGO_ENV, ""),
+            ("env_kernel<0,2,5> reset-terminated, G=65536", r"env_kernel<0, 2, 5>", None, "")],
+    "gemm": [("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
+    "learner": [("learner update: gemm_nt_bf16_kernel<128,128> (all shapes of an update)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
+                ("learner update: gemm_nt_bf16_kernel<128,64>", r"gemm_nt_bf16_kernel<128, 64>", None, ""),
+                ("learner update: lstm_seq_fwd_kernel<16> (4 recurrences x 20 steps per launch)", r"lstm_seq_fwd_kernel<16>", None, ""),
+                ("learner update: lstm_seq_bwd_kernel<64> (2 recurrences x 20 steps per launch)", r"lstm_seq_bwd_kernel<64>", None, ""),
+                ("learner update: transpose_bf16_kernel", r"transpose_bf16_kernel", None, ""),
+                ("learner update: sum_slabs_kernel", r"sum_slabs_kernel", None, ""),
+                ("learner update: adam_kernel", r"adam_kernel", None, "")],
+    "actor": [("actor step: lstm_cell_gemm256_kernel (32,768 rows x 2048 x 1024)", r"lstm_cell_gemm256_kernel", None, ""),
+              ("actor step: gemm_nt_bf16_kernel<128,128> (input linear / heads)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
+              ("actor step: env_kernel<1,2,5> G=16384", r"env_kernel<1, 2, 5>", None, ""),
+              ("actor step: cast_pad_bf16_vec8_kernel", r"cast_pad_bf16_vec8_kernel", None, ""),
+              ("actor step: pack_rows_kernel", r"pack_rows_kernel", None, ""),
+              ("actor step: seq_flush_copy_kernel", r"seq_flush_copy_kernel", None, "")],
 }
-PARTS = 3    # the launch-per-iteration rollout runs as 3 stream partitions: one launch covers G/3 games
-CHUNK = 50   # the persistent rollout kernel: one launch = CHUNK iterations of all G games (tools/pmc_probe.py)
-wk, fk = mean(pick(w, r"env_rollout_kernel<2, 5>")), mean(pick(f, r"env_rollout_kernel<2, 5>"))
-if wk is not None:
-    wf = write_factor if write_factor and abs(write_factor - 1) < 0.05 else 1.0
-    ff = fetch_factor if fetch_factor and 1.5 < fetch_factor < 2.5 else 2.0
-    hbm = (wk * wf + (fk or 0.0) * ff) * 1024.0
-    out["env_rollout_kernel<2,5> persistent fused reset+policy+step+observe, G=65536, %d iterations per launch" % CHUNK] = {
-        "WRITE_SIZE_KiB": wk, "FETCH_SIZE_KiB_raw": fk, "dispatches": len(pick(w, r"env_rollout_kernel<2, 5>")),
-        "iterations_per_launch": CHUNK, "hbm_bytes_per_launch": hbm, "hbm_bytes_per_iteration": hbm / CHUNK,
-        "algorithmic_bytes_per_launch": ALGO * CHUNK, "traffic_over_algorithmic": hbm / (ALGO * CHUNK)}
-for mode, label in ((3, "env_kernel<3,2,5> fused reset+policy+step+observe (rollout), G=65536 in 3 partition launches"),
-                    (1, "env_kernel<1,2,5> step+observe, G=65536"),
-                    (0, "env_kernel<0,2,5> reset-terminated, G=65536")):
-    pat = r"env_kernel<%d, 2, 5>" % mode
-    wk, fk = mean(pick(w, pat)), mean(pick(f, pat))
-    if wk is None:
-        continue
-    wf = write_factor if write_factor and abs(write_factor - 1) < 0.05 else 1.0
-    ff = fetch_factor if fetch_factor and 1.5 < fetch_factor < 2.5 else 2.0
-    hbm = (wk * wf + (fk or 0.0) * ff) * 1024.0
-    rec = {"WRITE_SIZE_KiB": wk, "FETCH_SIZE_KiB_raw": fk, "dispatches": len(pick(w, pat)), "hbm_bytes_per_launch": hbm}
-    if mode in (1, 3):
-        algo = ALGO / PARTS if mode == 3 else ALGO
-        rec["algorithmic_bytes_per_launch"] = algo
-        rec["traffic_over_algorithmic"] = hbm / algo
-    out[label] = rec
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if k.startswith("env_")}, indent=1))
+
+out = {"command": "rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -- python tools/pmc_probe.py <leg> ; the same with "
+                  "--pmc FETCH_SIZE (separate passes; no other trace domains)"}
+for spec in sys.argv[2:]:
+    leg, wpath, fpath = spec.split(":")
+    w, f = per_kernel(wpath, "WRITE_SIZE"), per_kernel(fpath, "FETCH_SIZE")
+    cal = calibration(w, f)
+    rec = {"calibration": cal}
+    for label, pat, algo, note in KERNELS[leg]:
+        wv, fv = pick(w, pat), pick(f, pat)
+        if not wv:
+            continue
+        hbm = (mean(wv) * cal["write_factor"] + (mean(fv) or 0.0) * cal["fetch_factor"]) * 1024.0
+        r = {"dispatches": len(wv), "WRITE_SIZE_KiB": mean(wv), "FETCH_SIZE_KiB_raw": mean(fv), "hbm_bytes_per_launch": hbm,
+             "hbm_write_bytes_per_launch": mean(wv) * cal["write_factor"] * 1024.0,
+             "hbm_read_bytes_per_launch": (mean(fv) or 0.0) * cal["fetch_factor"] * 1024.0}
+        if algo:
+            r["algorithmic_bytes_per_launch"] = algo
+            r["traffic_over_algorithmic"] = hbm / algo
+        if note.startswith("iterations_per_launch="):
+            n = int(note.split("=")[1])
+            r["iterations_per_launch"] = n
+            r["hbm_bytes_per_iteration"] = hbm / n
+        rec[label] = r
+    out[leg] = rec
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(json.dumps({leg: {k: (v.get("traffic_over_algorithmic"), v["hbm_bytes_per_launch"]) for k, v in rec.items() if k != "calibration"}
+                  for leg, rec in out.items() if leg != "command"}, indent=1))
