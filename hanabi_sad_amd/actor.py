@@ -34,6 +34,9 @@ class DeviceActor:
         self.eta = float(eta)
         self.multi_step = int(multi_step)
         self.writer = SequenceWriter(self.E, multi_step, gamma, seq_len, transition_fields(env, self.vdn), env.device)
+        self.cached_q = getattr(agent, "cached_q", True)      # False: a contract model (rela.ContractAgent): reference flow
+        if hasattr(agent, "configure"):
+            agent.configure(self.P, self.vdn)
         self.hid = agent.get_h0(self.N)
         self.history_hid = deque()
         self.q_hist = deque()                 # (Q_online(s_t, a_t), online weight version) per step still in the n-step window
@@ -59,6 +62,8 @@ class DeviceActor:
         # pass on the live observation -- exactly the two numbers compute_priority needs from time t (as `obs` n steps from
         # now, as `next_obs` right now).  Two network passes per step instead of the reference's four, no observation ever
         # read back from the n-step ring.
+        if not self.cached_q:
+            return self._step_contract(obs)
         reply, self.hid = agent.act(obs, self.hid, with_q=True)
         self.q_hist.append((reply["q_online_a"], reply["versions"][0]))
         fields = dict(obs)
@@ -92,5 +97,27 @@ class DeviceActor:
             assert torch.equal(prio, full), "cached-Q priorities differ from compute_priority"
             self.n_checked += 1
             self.n_checked_stale += int(stale)
+        self.writer.push_sequence(prio)
+        self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)
+
+    def _step_contract(self, obs):
+        """the rest of step() for a model that only offers the reference's contract (act / compute_priority): the n-step
+        priority is ITS compute_priority on the popped transition with the hidden states of t-n and t (r2d2_actor.h:128-156)"""
+        env, agent, P = self.env, self.agent, self.P
+        reply, self.hid = agent.act(obs, self.hid)
+        fields = dict(obs)
+        fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
+        self.writer.push_obs_action(fields)
+        env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))
+        self.num_act += self.N
+        r = env.reward if self.vdn else env.reward.repeat_interleave(P)
+        t = env.terminal if self.vdn else env.terminal.repeat_interleave(P)
+        self.writer.push_reward_terminal(r, t)
+        zero_hidden_rows(self.hid, env.terminal, P)
+        if not self.writer.can_pop():
+            return
+        hid_s = self.history_hid.popleft()
+        cur, nxt, rew, term, boot = self.writer.pop_transition(want_fields=True, want_next=True)
+        prio = agent.compute_priority_dict(cur, nxt, hid_s, self.history_hid[-1], rew, term, boot)
         self.writer.push_sequence(prio)
         self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)

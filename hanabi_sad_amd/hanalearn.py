@@ -105,7 +105,7 @@ class HanabiVecEnv:
     def append(self, env):
         if self.impl is not None:
             raise RuntimeError("HanabiVecEnv.append after the device env was built")
-        env._vec = (self, len(self.envs))
+        env._vec = (self, len(self.envs))     # (a game absorbed into a merged batch is re-appended there: latest wins)
         self.envs.append(env)
 
     def size(self):
@@ -129,58 +129,141 @@ class HanabiThreadLoop:
     """hanalearn.HanabiThreadLoop(actor | [actor per player], vec_env, eval) (cpp/thread_loop.h:14-88).  There is no thread:
     `step()` is one iteration of the loop body for all games of the vector env, driven by rela.Context.  Training mode =
     actor.DeviceActor (IQL when given a list of per-player actors, VDN for a single actor with num_player = P); eval mode =
-    every player acts greedily until each game has finished once."""
+    every player acts greedily with ITS actor's model (cross-play: one runner per seat, eval.py:43-46) until each game has
+    finished once.
+
+    The reference creates one loop per thread (create.py:57-76) -- or, for evaluation, one per GAME (eval.py:40-47: 1,000 loops
+    of one game).  Loops are built lazily, and rela.Context merges compatible ones (same models, same configuration, consecutive
+    seeds) into ONE batched device loop before the first step (`absorb`), so a driver written for the reference still advances
+    all its games with one launch per kernel."""
 
     def __init__(self, actors, vec_env, eval_mode):
+        self.per_thread = [list(actors) if isinstance(actors, (list, tuple)) else [actors]]   # actor(s) of every merged thread
+        self.is_list = isinstance(actors, (list, tuple))
+        self.vec_envs = [vec_env]
+        self.eval_mode = bool(eval_mode)
+        self.master, self.impl, self.env, self.done = None, None, None, False
+        self._built = False
+        if not vec_env.envs:
+            raise RuntimeError("HanabiThreadLoop over an empty HanabiVecEnv")
+
+    # ---- merging (rela.Context) ----
+    def merge_key(self):
+        a0, c0 = self.per_thread[0], dict(self.vec_envs[0].envs[0].cfg)
+        c0.pop("seed")
+        cfg = tuple((a.multi_step, a.num_envs if self.eval_mode else None, a.gamma, a.eta, a.seq_len, a.num_player, id(a.replay))
+                    for a in a0)
+        return (self.eval_mode, self.is_list, tuple(id(a.runner) for a in a0), cfg, tuple(sorted(c0.items())),
+                self.vec_envs[0].envs[0].device)
+
+    def seed_range(self):
+        envs = [e for v in self.vec_envs for e in v.envs]
+        return envs[0].cfg["seed"], envs[-1].cfg["seed"]
+
+    def can_absorb(self, other):
+        return (not self._built and not other._built and other.master is None and self.merge_key() == other.merge_key()
+                and other.seed_range()[0] == self.seed_range()[1] + 1)
+
+    def absorb(self, other):
+        self.per_thread += other.per_thread
+        self.vec_envs += other.vec_envs
+        other.master = self
+
+    @property
+    def actors(self):
+        return [a for group in self.per_thread for a in group]
+
+    def _build(self):
         from .actor import DeviceActor, transition_fields
         from .r2d2 import R2D2Agent
-        self.actors = list(actors) if isinstance(actors, (list, tuple)) else [actors]
-        a0 = self.actors[0]
-        self.eval_mode = bool(eval_mode)
-        run = a0.runner
-        self.env = vec_env.batched(run.device)
-        self.vdn = not isinstance(actors, (list, tuple)) and a0.num_player > 1
+        self._built = True
+        if len(self.vec_envs) > 1:                 # merged: one vector env over all games, in seed order
+            merged = HanabiVecEnv()
+            for v in self.vec_envs:
+                for e in v.envs:
+                    merged.append(e)               # re-points every game at its row of the merged batch
+            self.vec_envs = [merged]
+        a0 = self.per_thread[0]
+        runs = [a.runner for a in a0]
+        self.env = self.vec_envs[0].batched(runs[0].device)
+        P = self.env.P
+        self.vdn = not self.is_list and a0[0].num_player > 1
         if self.eval_mode:
-            self.agent = R2D2Agent(run.online, run.online, 1, 0.99)
-            self.hid = self.agent.get_h0(self.env.G * self.env.P)
+            seats = runs if (self.is_list and len(runs) == P) else [runs[0]] * P
+            self.same_model = all(r is seats[0] for r in seats)
+            self.agents = []
+            for r in (seats[:1] if self.same_model else seats):
+                ag = r.make_agent(1, 0.99)
+                if hasattr(ag, "configure"):
+                    ag.configure(1, False)
+                elif ag.target is not ag.online:
+                    ag = R2D2Agent(ag.online, ag.online, 1, 0.99)       # evaluation only ever calls `act`
+                self.agents.append(ag)
+            rows = self.env.G * P if self.same_model else self.env.G
+            self.hids = [ag.get_h0(rows) for ag in self.agents]
             self.env.reset()
-            self.done = False
-            self.impl = None
         else:
-            self.agent = R2D2Agent(run.online, run.target, a0.multi_step, a0.gamma, seed=self.env.G)
+            run = runs[0]
+            self.agent = run.make_agent(a0[0].multi_step, a0[0].gamma, seed=self.env.G)
             fields = transition_fields(self.env, self.vdn)
-            replay = a0.replay.bind_schema(fields, a0.seq_len, run.device)
-            self.impl = DeviceActor(self.env, self.agent, replay, a0.multi_step, a0.gamma, a0.eta, a0.seq_len, vdn=self.vdn)
+            replay = a0[0].replay.bind_schema(fields, a0[0].seq_len, run.device)
+            self.impl = DeviceActor(self.env, self.agent, replay, a0[0].multi_step, a0[0].gamma, a0[0].eta, a0[0].seq_len,
+                                    vdn=self.vdn)
 
     def step(self):
+        if self.master is not None:
+            return                                  # advanced by the loop that absorbed this one
+        if not self._built:
+            self._build()
         if not self.eval_mode:
-            before = self.impl.num_act
             self.impl.step()
-            per_actor = (self.impl.num_act - before) // len(self.actors)   # R2D2Actor::numAct_ += num_envs per act()
-            for a in self.actors:
-                a._num_act += per_actor
+            for group, v in zip(self.per_thread, self._thread_sizes()):
+                for a in group:                     # R2D2Actor::numAct_ += num_envs per act() (r2d2_actor.h:98)
+                    a._num_act += v
             return
         if self.done:
             return
-        env, N = self.env, self.env.G * self.env.P
+        env, G, P = self.env, self.env.G, self.env.P
         done = env.query()[:, 0] == 1
         if bool(done.all()):
             self.done = True
             return
-        obs = {"priv_s": env.priv_s.view(N, env.F), "legal_move": env.legal_move.view(N, env.A),
-               "eps": torch.zeros(N, device=env.device)}
-        reply, self.hid = self.agent.act(obs, self.hid)
-        a = reply["greedy_a"].view(env.G, env.P)
+        if self.same_model:
+            N = G * P
+            obs = {"priv_s": env.priv_s.view(N, env.F), "legal_move": env.legal_move.view(N, env.A),
+                   "eps": torch.zeros(N, device=env.device)}
+            reply, self.hids[0] = self.agents[0].act(obs, self.hids[0])
+            a = reply["greedy_a"].view(G, P)
+        else:                                       # cross-play: seat p is played by its own model on its own rows
+            cols = []
+            for p, ag in enumerate(self.agents):
+                obs = {"priv_s": env.priv_s[:, p].contiguous(), "legal_move": env.legal_move[:, p].contiguous(),
+                       "eps": torch.zeros(G, device=env.device)}
+                reply, self.hids[p] = ag.act(obs, self.hids[p])
+                cols.append(reply["greedy_a"])
+            a = torch.stack(cols, 1)
         a = torch.where(done.unsqueeze(1), torch.full_like(a, env.A - 1), a).contiguous()   # finished games: ignored noop
         env.step(a, a)
+        for group, v in zip(self.per_thread, self._thread_sizes()):
+            for act in group:
+                act._num_act += v
         if bool(done.any()):
             import ctypes as C
             n, g, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
             env.lib.hsad_env_error_count(env.h, C.byref(n), C.byref(g), C.byref(c))   # drain the "finished game" notes
 
+    def _thread_sizes(self):
+        if not hasattr(self, "_sizes"):
+            G, n = self.env.G, len(self.per_thread)
+            self._sizes = [G // n] * n if G % n == 0 else [G] + [0] * (n - 1)
+        return self._sizes
+
     def finished(self):
+        if self.master is not None:
+            return self.master.finished()
         return self.eval_mode and self.done
 
     def scores(self):
         """lastScore() of every game (eval.py:57-66)"""
-        return self.env.query()[:, 5].cpu().tolist()
+        src = self.master or self
+        return src.env.query()[:, 5].cpu().tolist()

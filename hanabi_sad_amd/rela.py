@@ -73,14 +73,105 @@ def aggregate_priority(priority, seq_len, eta):
     return out if priority.device.type == "cuda" else out.cpu()
 
 
+class ContractAgent:
+    """The reference's MODEL CONTRACT honoured for an arbitrary model (rela/batch_runner.h:24,76,108; rela/r2d2_actor.h:61-172):
+    BatchRunner calls three methods of the agent it is given -- `act(dict) -> dict`, `compute_priority(dict) -> dict`,
+    `get_h0(batchsize) -> dict` (on `model._c` when the model is a TorchScript wrapper, else on the model itself) -- with
+    tensors shaped [slots, envs, (players), ...] and the hidden state batch-first [slots, envs * players', layers, hidden].
+    Any architecture that implements them (a second fc layer, skip connections, other recurrent cores, the OBL models of
+    pyhanabi/tools/obl_model.py) acts in the device rollout through this adapter: the observations never leave the GPU, all
+    games are ONE slot of `envs` rows, and the n-step priority is the model's own compute_priority on the transition read
+    back from the sequence writer, exactly the reference's call.  (The default R2D2Net shape takes the HIP kernels instead.)"""
+
+    cached_q = False          # DeviceActor: priorities come from compute_priority on the popped transition (reference flow)
+
+    def __init__(self, model, device, multi_step, gamma):
+        self.model, self.device = model, torch.device(device)
+        self.impl = getattr(model, "_c", model)
+        self.multi_step, self.gamma = multi_step, gamma
+        self.num_player, self.vdn = 1, False
+        self.online = self.target = self          # DeviceActor reads agent.online.version for its cached-Q bookkeeping only
+        self.version = 0
+
+    def configure(self, num_player, vdn):
+        self.num_player, self.vdn = int(num_player), bool(vdn)
+
+    def _lead(self, x, n_rows):
+        """[N, ...] rows -> the contract's [1, E, (P), ...]"""
+        x = x.to(self.device)
+        if self.vdn:
+            return x.reshape((1, n_rows // self.num_player, self.num_player) + tuple(x.shape[1:]))
+        return x.reshape((1, n_rows) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def _hid_in(h):      # [L, N, H] -> [1, N, L, H]
+        return h.transpose(0, 1).unsqueeze(0).contiguous()
+
+    def _hid_out(self, h, like):
+        return h.to(self.device).reshape(like.shape[1], like.shape[0], like.shape[2]).transpose(0, 1).contiguous()
+
+    def get_h0(self, n):
+        with torch.no_grad():
+            h = self.impl.get_h0(int(n))
+        out = {}
+        for k, v in h.items():
+            v = v.to(self.device).float()
+            if v.dim() == 3 and v.shape[1] != n and v.shape[0] == n:     # batch-first variant
+                v = v.transpose(0, 1)
+            out[k] = v.contiguous()
+        return out
+
+    def act(self, obs, hid, with_q=False):
+        n = obs["priv_s"].shape[0]
+        d = {k: self._lead(v, n) for k, v in obs.items() if k in ("priv_s", "legal_move", "eps", "own_hand")}
+        if "eps" not in d:
+            d["eps"] = self._lead(torch.zeros(n, device=self.device), n)
+        for k in ("h0", "c0"):
+            d[k] = self._hid_in(hid[k])
+        with torch.no_grad():
+            reply = self.impl.act(d)
+        new_hid = {k: self._hid_out(reply[k], hid[k]) for k in ("h0", "c0")}
+        out = {"a": reply["a"].to(self.device).reshape(-1).long().contiguous(),
+               "greedy_a": reply["greedy_a"].to(self.device).reshape(-1).long().contiguous()}
+        return out, new_hid
+
+    def compute_priority_dict(self, cur, nxt, hid, next_hid, reward, terminal, bootstrap):
+        """cur / nxt: the popped transition's fields as [E, w] rows (IQL) or [G, P*w] (VDN); -> priority [E]"""
+        P = self.num_player if self.vdn else 1
+        E = reward.shape[0]
+
+        def shape(name, x):
+            if name in ("a", "greedy_a", "eps"):
+                return x.reshape((1, E, P) if self.vdn else (1, E))
+            return x.reshape((1, E, P, -1) if self.vdn else (1, E, -1))
+        d = {}
+        for k, v in cur.items():
+            d[k] = shape(k, v)
+        for k, v in nxt.items():
+            if k not in ("a", "greedy_a"):
+                d["next_" + k] = shape(k, v)
+        d["reward"], d["bootstrap"] = reward.reshape(1, E), bootstrap.reshape(1, E)
+        d["terminal"] = terminal.reshape(1, E)
+        d["temperature"] = torch.ones_like(d["eps"])      # read (and ignored) by the reference's compute_priority (SURVEY F6a)
+        for k in ("h0", "c0"):
+            d[k] = self._hid_in(hid[k])
+            d["next_" + k] = self._hid_in(next_hid[k])
+        with torch.no_grad():
+            p = self.impl.compute_priority(d)["priority"]
+        return p.to(self.device).reshape(-1).float().contiguous()
+
+
 class BatchRunner:
     """rela.BatchRunner(py_model, device, max_batchsize, methods) (rela/batch_runner.h:17-130): holds the acting copy of the
-    agent.  `py_model` is anything with state_dict() carrying `online_net.*` / `target_net.*` (the reference R2D2Agent) or a
-    plain dict of such tensors.  There is nothing to batch across threads, so start()/stop() are no-ops."""
+    agent.  `py_model` with state_dict() carrying `online_net.*` / `target_net.*` of the default R2D2Net shape (the reference
+    R2D2Agent), or a plain dict of such tensors, runs on the HIP kernels; any other object that implements the model contract
+    (`act` / `compute_priority` / `get_h0`, see ContractAgent) is called as it is.  There is nothing to batch across threads,
+    so start()/stop() are no-ops."""
 
     def __init__(self, py_model, device, max_batchsize=100, methods=None):
         self.device = device
         self.online = self.target = None
+        self.model = None                     # set for contract models (no kernels)
         self.update_model(py_model)
 
     @staticmethod
@@ -92,11 +183,33 @@ class BatchRunner:
             raise KeyError("BatchRunner: state_dict has no online_net.* entries")
         return on, (tg or on)
 
+    @staticmethod
+    def _kernel_shape(on):
+        """the default R2D2Net (1 fc layer, 2 LSTM layers, dueling + aux heads: pyhanabi/r2d2.py:22-57) and nothing else"""
+        from .r2d2 import PARAM_ORDER
+        return set(on) == set(PARAM_ORDER)
+
     def update_model(self, py_model):
         """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
         from .r2d2 import R2D2NetKernels
-        on, tg = self._split(py_model)
         with _MODEL_LOCK:
+            contract = hasattr(getattr(py_model, "_c", py_model), "act") and not isinstance(py_model, dict)
+            try:
+                on, tg = self._split(py_model)
+                use_kernels = self._kernel_shape(on) and (not contract or not getattr(py_model, "force_contract", False))
+            except (KeyError, AttributeError):
+                if not contract:
+                    raise
+                use_kernels = False
+            if not use_kernels:
+                if not contract:
+                    raise KeyError("BatchRunner: the model is neither the default R2D2Net shape nor an object with act / "
+                                   "compute_priority / get_h0")
+                if self.model is None:
+                    self.model = py_model
+                elif self.model is not py_model:
+                    self.model.load_state_dict(py_model.state_dict())
+                return
             if self.online is None:
                 self.online, self.target = R2D2NetKernels(on, self.device), R2D2NetKernels(tg, self.device)
                 return
@@ -110,6 +223,13 @@ class BatchRunner:
 
     def stop(self):
         pass
+
+    def make_agent(self, multi_step, gamma, seed=0):
+        """the acting agent over this runner's model (R2D2Actor::act / postAct call `act` and `compute_priority` on it)"""
+        if self.model is not None:
+            return ContractAgent(self.model, self.device, multi_step, gamma)
+        from .r2d2 import R2D2Agent
+        return R2D2Agent(self.online, self.target, multi_step, gamma, seed=seed)
 
 
 class R2D2Actor:
@@ -173,14 +293,31 @@ class Context:
             e, self._error = self._error, None
             raise e
 
+    def _coalesce(self):
+        """merge compatible hanalearn.HanabiThreadLoops (same models and configuration, consecutive seeds) into one batched
+        device loop each: the reference pushes one loop per thread -- or per game, in eval.py -- and every one of them would
+        otherwise be its own set of kernel launches"""
+        last = {}
+        for lp in self.loops:
+            if not hasattr(lp, "can_absorb") or lp._built or lp.master is not None:
+                continue
+            key = lp.merge_key()
+            head = last.get(key)
+            if head is not None and head.can_absorb(lp):
+                head.absorb(lp)
+            else:
+                last[key] = lp
+
     def start(self):
         import threading
+        self._coalesce()
         if self._thread is None:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
 
     def step(self):
         """advance every attached loop by one lock-step iteration from the caller's thread (alternative to start())"""
+        self._coalesce()
         for lp in self.loops:
             if not (hasattr(lp, "finished") and lp.finished()):
                 with _MODEL_LOCK:

@@ -33,7 +33,9 @@ def create_envs(hanalearn, num_env, seed, num_player, hand_size, bomb, eps, max_
 
 @pytest.mark.parametrize("method", ["iql", "vdn"])
 def test_reference_shaped_training_driver(method):
-    from hanabi_sad_amd import hanalearn, rela
+    import hanalearn
+    import rela                     # the top-level module names the reference's drivers import (create.py:16-21)
+    assert rela.__file__.endswith(".so") and hanalearn.__file__.endswith(".so")
     from hanabi_sad_amd.r2d2 import R2D2Learner
     from hanabi_sad_amd.selfplay import generate_explore_eps
     num_thread, per_thread, P, hand, n, gamma, eta, T, B = 2, 96, 2, 5, 3, 0.999, 0.9, 80, 32
@@ -85,8 +87,11 @@ def test_reference_shaped_training_driver(method):
     assert n_act > 0 and replay.num_add() >= replay.size() > 0
     context.terminate()
     assert context.terminated()
-    for th in threads:
-        th.env.check_errors()
+    # the per-thread loops were merged into ONE batched device loop (consecutive seeds, same models): one launch per kernel
+    assert threads[1].master is threads[0] and threads[0].env.G == num_thread * per_thread
+    threads[0].env.check_errors()
+    per_actor = [a.num_act() for a in actors]
+    assert len(set(per_actor)) == 1 and per_actor[0] % per_thread == 0          # R2D2Actor::numAct_ += num_envs per act()
 
 
 def test_reference_shaped_eval_driver():
@@ -112,3 +117,43 @@ def test_reference_shaped_eval_driver():
     scores = [g.last_score() for g in games]
     assert len(scores) == num_game and all(0 <= s <= 25 for s in scores)
     assert all(g.terminated() for g in games)
+
+
+@pytest.mark.parametrize("cross_play", [False, True])
+def test_eval_driver_with_one_loop_per_game_like_eval_py(cross_play):
+    """pyhanabi/eval.py:25-66 verbatim in shape: ONE vector env + thread loop per game, one R2D2Actor per seat (its own runner:
+    cross-play when the runners differ), context.start(), poll terminated(), game.last_score().  The context merges the
+    per-game loops into one batched loop; self-play scores must equal hanabi_sad_amd.eval.evaluate on the same seeds."""
+    import hanalearn
+    import rela
+    from hanabi_sad_amd.eval import evaluate
+    num_game, P, seed = 48, 2, 2024
+    games = create_envs(hanalearn, num_game, seed, P, 5, 0, [0.0], -1, True)
+    agents = [TinyAgent(games[0].feature_size(), 64, games[0].num_action(), 5, 5 + (i if cross_play else 0)) for i in range(P)]
+    runners = [rela.BatchRunner(ag, DEV, 1000, ["act"]) for ag in agents]
+    context = rela.Context()
+    loops = []
+    for g in games:
+        env = hanalearn.HanabiVecEnv()
+        env.append(g)
+        loops.append(hanalearn.HanabiThreadLoop([rela.R2D2Actor(runners[i], 1) for i in range(P)], env, True))
+        context.push_env_thread(loops[-1])
+    for r in runners:
+        r.start()
+    context.start()
+    t0 = time.time()
+    while not context.terminated():
+        assert time.time() - t0 < 120
+        time.sleep(0.05)
+    context.terminate()
+    for r in runners:
+        r.stop()
+    assert all(lp.master is loops[0] for lp in loops[1:]) and loops[0].env.G == num_game
+    scores = [g.last_score() for g in games]
+    assert all(g.terminated() for g in games) and all(0 <= s <= 25 for s in scores)
+    if not cross_play:
+        W = {k[len("online_net."):]: v for k, v in agents[0].state_dict().items() if k.startswith("online_net.")}
+        _, _, want, _ = evaluate(W, num_game, seed, 0, True, device=DEV)
+        assert scores == want
+    else:
+        assert not loops[0].same_model and len(loops[0].agents) == P
