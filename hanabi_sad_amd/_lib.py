@@ -128,6 +128,7 @@ SIGNATURES = {
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,
                                 C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "hsad_eltwise_mul": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),
     "hsad_lstm_cell_f32_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "hsad_lstm_cell_f32_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "hsad_heads_backward_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,

@@ -170,9 +170,31 @@ __global__ void heads_bwd_f32_kernel(const float* __restrict__ dqa, const float*
   for (int j = col; j < ldo; ++j) o[j] = 0.f;
 }
 
+// out = a * b elementwise, bf16 (is_bf16) or fp32 operands: the private x public gating of the OBL nets (tools/obl_model.py:98)
+__global__ void eltwise_mul_kernel(const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out, long n, int is_bf16) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (is_bf16) {
+    const unsigned short x = reinterpret_cast<const unsigned short*>(a)[i], y = reinterpret_cast<const unsigned short*>(b)[i];
+    const float p = __uint_as_float((unsigned)x << 16) * __uint_as_float((unsigned)y << 16);
+    unsigned u = __float_as_uint(p);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    reinterpret_cast<unsigned short*>(out)[i] = (unsigned short)(u >> 16);
+  } else {
+    reinterpret_cast<float*>(out)[i] = reinterpret_cast<const float*>(a)[i] * reinterpret_cast<const float*>(b)[i];
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int hsad_eltwise_mul(const void* a, const void* b, void* out, int64_t n, int is_bf16, void* stream) {
+  if (!a || !b || !out || n < 1) return ffail(HSAD_ERR_INVALID, "eltwise_mul: bad arguments");
+  hipLaunchKernelGGL(eltwise_mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n, is_bf16);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
 
 int hsad_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk, int M, int N, int K,
                   const float* bias, float* C, int ldc, int relu, int accumulate, const float* relu_mask, int ldmask,

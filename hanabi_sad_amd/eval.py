@@ -20,6 +20,8 @@ def evaluate(weights, num_game, seed, bomb, sad, *, num_player=2, hand_size=5, d
                            max_len=-1, sad=bool(sad), shuffle_color=bool(shuffle_color), device=device, track_deck_history=False)
     if isinstance(weights, R2D2Agent):
         agent = R2D2Agent(weights.online, weights.online, 1, 0.99)
+    elif hasattr(weights, "act") and hasattr(weights, "get_h0"):
+        agent = weights                      # any acting agent (obl.OBLAgent, rela.ContractAgent): used as it is
     else:
         net = weights if hasattr(weights, "trunk") else R2D2NetKernels.make(weights, device, precision)
         agent = R2D2Agent(net, net, 1, 0.99)

@@ -196,6 +196,8 @@ class HanabiThreadLoop:
                 ag = r.make_agent(1, 0.99)
                 if hasattr(ag, "configure"):
                     ag.configure(1, False)
+                elif getattr(ag, "device_agent", False):
+                    pass
                 elif ag.target is not ag.online:
                     ag = R2D2Agent(ag.online, ag.online, 1, 0.99)       # evaluation only ever calls `act`
                 self.agents.append(ag)

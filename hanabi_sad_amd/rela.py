@@ -192,6 +192,9 @@ class BatchRunner:
     def update_model(self, py_model):
         """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
         from .r2d2 import R2D2NetKernels
+        if getattr(py_model, "device_agent", False):      # an acting agent of this package (e.g. obl.OBLAgent): used as it is
+            self.agent_obj = py_model
+            return
         with _MODEL_LOCK:
             contract = hasattr(getattr(py_model, "_c", py_model), "act") and not isinstance(py_model, dict)
             try:
@@ -226,6 +229,8 @@ class BatchRunner:
 
     def make_agent(self, multi_step, gamma, seed=0):
         """the acting agent over this runner's model (R2D2Actor::act / postAct call `act` and `compute_priority` on it)"""
+        if getattr(self, "agent_obj", None) is not None:
+            return self.agent_obj
         if self.model is not None:
             return ContractAgent(self.model, self.device, multi_step, gamma)
         from .r2d2 import R2D2Agent

@@ -429,6 +429,9 @@ int hsad_lstm_cell_f32_forward(float* gates, const float* c_prev, float* c_out, 
  * for step t-1); dG [Bn,4H] = gradient wrt the gate pre-activations. */
 int hsad_lstm_cell_f32_backward(const float* gates, const float* c, const float* c_prev, const float* dO, const float* dh_rec,
                                 float* dc_io, float* dG, int Bn, int H, void* stream);
+/* out[i] = a[i] * b[i], n elements, bf16 (is_bf16) or fp32: the private x public gating of the OBL model family
+ * (pyhanabi/tools/obl_model.py:96-99) */
+int hsad_eltwise_mul(const void* a, const void* b, void* out, int64_t n, int is_bf16, void* stream);
 /* hsad_heads_backward with an fp32 output [M, ldo] */
 int hsad_heads_backward_f32(const float* dqa, const float* legal, const int64_t* action, const float* heads, int ldh,
                             const float* own_hand, const float* weight, int M, int B, int A, int NP, float pred_scale,
