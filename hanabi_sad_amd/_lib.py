@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip", "hsad_agent.hip")]
 _lib = None
 
 
@@ -128,6 +128,29 @@ SIGNATURES = {
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,
                                 C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "hsad_r2d2_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "hsad_r2d2_net_destroy": (None, [_P]),
+    "hsad_r2d2_num_params": (C.c_int, []),
+    "hsad_r2d2_param_name": (C.c_char_p, [C.c_int]),
+    "hsad_r2d2_net_param_count": (C.c_int64, [_P]),
+    "hsad_r2d2_net_param_offset": (C.c_int64, [_P, C.c_int]),
+    "hsad_r2d2_net_param_size": (C.c_int64, [_P, C.c_int]),
+    "hsad_r2d2_net_params": (_P, [_P]),
+    "hsad_r2d2_net_refresh": (C.c_int, [_P, _P]),
+    "hsad_r2d2_net_version": (C.c_uint64, [_P]),
+    "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_r2d2_q_of": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_r2d2_compute_priority": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double,
+                                             _P, _P, _P]),
+    "hsad_r2d2_learner_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float, C.POINTER(_P)]),
+    "hsad_r2d2_learner_destroy": (None, [_P]),
+    "hsad_r2d2_learner_set_schedule": (C.c_int, [_P, C.c_int, C.c_int]),
+    "hsad_r2d2_learner_grad": (_P, [_P]),
+    "hsad_r2d2_learner_timed_out": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
+    "hsad_r2d2_loss_bwd": (C.c_int, [_P, _P]),
+    "hsad_r2d2_optimizer_step": (C.c_int, [_P, C.c_float, C.c_float, C.POINTER(_P), _P]),
+    "hsad_r2d2_sync_target_with_online": (C.c_int, [_P, _P]),
     "hsad_eltwise_mul": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),
     "hsad_lstm_cell_f32_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "hsad_lstm_cell_f32_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),

@@ -1,0 +1,242 @@
+"""Python face of the COMPOSITE C-ABI entry points (include/hsad.h `hsad_r2d2_*`, csrc/hsad_agent.hip): the agent and the learner as
+the reference's native side sees them -- `act`, `compute_priority` (rela/batch_runner.h:74-113, rela/r2d2_actor.h:61-172) and
+the learner step (pyhanabi/selfplay.py:208-244) -- each ONE library call.  The kernel schedule lives in the library; these
+classes only hand over pointers, so a C++ / pybind host replaces them with the stub in INTEGRATION.md.
+
+`CNet` owns nothing on the Python side: its weights are torch views over the library's flat fp32 parameter vector (named like
+R2D2Net.state_dict()).  `CompositeAgent` / `CompositeLearner` offer the same call surface as r2d2.R2D2Agent / r2d2.R2D2Learner
+(hanabi_sad_amd/r2d2.py keeps the same schedule in Python for the fp32-exact mode and for A/B tests)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _s(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class _DevArray:
+    """exposes a library-owned device allocation to torch (no copy) through __cuda_array_interface__"""
+
+    def __init__(self, ptr, n, owner):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        self.owner = owner
+
+
+def _view(ptr, n, device, owner):
+    return torch.as_tensor(_DevArray(ptr, n, owner), device=device)
+
+
+def param_names():
+    lib = _lib.load_library()
+    return [lib.hsad_r2d2_param_name(i).decode() for i in range(lib.hsad_r2d2_num_params())]
+
+
+class CNet:
+    """hsad_r2d2_net: R2D2Net(in_dim, hid_dim, out_dim, 2 LSTM layers, hand_size) living in the library"""
+
+    def __init__(self, weights, device="cuda:0", with_backward=False):
+        self.lib = _lib.load_library()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HsadError("CNet needs a ROCm device; there is no CPU path")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.H = weights["fc_v.weight"].shape[1]
+        self.F = weights["net.0.weight"].shape[1]
+        self.A = weights["fc_a.weight"].shape[0]
+        self.NP = weights["pred.weight"].shape[0]
+        self.L = 2
+        extra = [k for k in weights if k not in param_names()]
+        if extra:
+            raise _lib.HsadError("the R2D2 kernels support the reference default shape only; unexpected parameters: %s" % extra)
+        self.h = C.c_void_p()
+        _lib.check(self.lib.hsad_r2d2_net_create(self.F, self.H, self.A, self.NP // 3, int(with_backward), idx, C.byref(self.h)))
+        n = self.lib.hsad_r2d2_net_param_count(self.h)
+        self.flat = _view(self.lib.hsad_r2d2_net_params(self.h), n, self.device, self)
+        self.w = {}
+        for i, name in enumerate(param_names()):
+            o, sz = self.lib.hsad_r2d2_net_param_offset(self.h, i), self.lib.hsad_r2d2_net_param_size(self.h, i)
+            self.w[name] = self.flat[o:o + sz].view(weights[name].shape)
+            self.w[name].copy_(weights[name])
+        self.refresh()
+
+    def refresh(self):
+        _lib.check(self.lib.hsad_r2d2_net_refresh(self.h, _s(self.device)))
+
+    @property
+    def version(self):
+        return int(self.lib.hsad_r2d2_net_version(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsad_r2d2_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CompositeAgent:
+    """R2D2Agent.act / compute_priority (pyhanabi/r2d2.py:247-361) as single library calls (hsad_r2d2_act,
+    hsad_r2d2_compute_priority); same interface as r2d2.R2D2Agent, so actor.DeviceActor drives either"""
+
+    def __init__(self, online: CNet, target: CNet, multi_step, gamma, seed=0):
+        self.online, self.target = online, target
+        self.multi_step, self.gamma = int(multi_step), float(gamma)
+        self.seed, self.counter = int(seed), 0
+        self.device, self.lib = online.device, online.lib
+
+    def get_h0(self, n):
+        z = torch.zeros(self.online.L, n, self.online.H, dtype=torch.float32, device=self.device)
+        return {"h0": z, "c0": z.clone()}
+
+    def act(self, obs, hid, with_q=False):
+        n, on, d = obs["priv_s"].shape[0], self.online, self.device
+        a = torch.empty(n, dtype=torch.int64, device=d)
+        g = torch.empty(n, dtype=torch.int64, device=d)
+        h = torch.empty(on.L, n, on.H, dtype=torch.float32, device=d)
+        c = torch.empty(on.L, n, on.H, dtype=torch.float32, device=d)
+        fused = n >= 1024
+        h16_in = hid.get("h0_16") if fused else None
+        h16 = torch.empty(on.L, n, on.H, dtype=torch.bfloat16, device=d) if fused else None
+        qa = torch.empty(n, dtype=torch.float32, device=d) if with_q else None
+        tq = torch.empty(n, dtype=torch.float32, device=d) if with_q else None
+        eps = obs.get("eps")
+        p = lambda t: None if t is None else t.contiguous().data_ptr()
+        _lib.check(self.lib.hsad_r2d2_act(on.h, self.target.h if with_q else None, n, p(obs["priv_s"]), p(obs["legal_move"]), p(eps),
+                                          p(hid["h0"]), p(hid["c0"]), p(h16_in), self.seed, self.counter, a.data_ptr(), g.data_ptr(),
+                                          h.data_ptr(), c.data_ptr(), p(h16), p(qa), p(tq), _s(d)))
+        self.counter += 1
+        reply, new_hid = {"a": a, "greedy_a": g}, {"h0": h, "c0": c}
+        if fused:
+            new_hid["h0_16"] = h16
+        if with_q:
+            reply["q_online_a"], reply["q_target_greedy"] = qa, tq
+            reply["versions"] = (on.version, self.target.version)
+        return reply, new_hid
+
+    def q_of(self, net, obs, action, hid, pre=None):
+        """Q_net(s, action) [N] for one step from the carried hidden state (hsad_r2d2_q_of)"""
+        n = action.shape[0]
+        qa = torch.empty(n, dtype=torch.float32, device=self.device)
+        p = lambda t: t.contiguous().data_ptr()
+        _lib.check(self.lib.hsad_r2d2_q_of(net.h, n, p(obs["priv_s"]), p(obs["legal_move"]), p(action), p(hid["h0"]), p(hid["c0"]),
+                                           qa.data_ptr(), _s(self.device)))
+        return qa
+
+    def priority_from_q(self, qa, tqa, reward, bootstrap, num_player=1):
+        n = qa.shape[0]
+        if num_player > 1:
+            qa, tqa = qa.view(-1, num_player).sum(1), tqa.view(-1, num_player).sum(1)
+            n = n // num_player
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.hsad_nstep_priority(qa.contiguous().data_ptr(), tqa.contiguous().data_ptr(), reward.contiguous().data_ptr(),
+                                                bootstrap.contiguous().data_ptr(), self.multi_step, self.gamma, n, out.data_ptr(),
+                                                _s(self.device)))
+        return out
+
+    def compute_priority(self, obs, a, next_obs, hid, next_hid, reward, bootstrap, num_player=1, next_greedy_a=None):
+        n, d = a.shape[0], self.device
+        out = torch.empty(n // num_player, dtype=torch.float32, device=d)
+        p = lambda t: None if t is None else t.contiguous().data_ptr()
+        _lib.check(self.lib.hsad_r2d2_compute_priority(
+            self.online.h, self.target.h, n, int(num_player), p(obs["priv_s"]), p(obs["legal_move"]), p(a), p(next_obs["priv_s"]),
+            p(next_obs["legal_move"]), p(hid["h0"]), p(hid["c0"]), p(next_hid["h0"]), p(next_hid["c0"]), p(reward), p(bootstrap),
+            self.multi_step, self.gamma, p(next_greedy_a), out.data_ptr(), _s(d)))
+        return out
+
+
+class CompositeLearner:
+    """the learner step of selfplay.py:208-244 as library calls: loss() = hsad_r2d2_loss_fwd (+ hsad_r2d2_loss_bwd),
+    optimizer_step(), sync_target_with_online().  Same surface as r2d2.R2D2Learner (flat / gflat / grad / online.w)."""
+
+    precision = "bf16"
+
+    def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device="cuda:0",
+                 T=None, rows=None):
+        self.device = torch.device(device)
+        self.lib = _lib.load_library()
+        self.online = CNet(online_weights, device, with_backward=True)
+        self.target = CNet(target_weights, device)
+        self.cfg = (int(multi_step), float(gamma), float(lr), float(eps), float(grad_clip))
+        self.multi_step, self.gamma = int(multi_step), float(gamma)
+        self.h, self.shape = None, None
+        self.flat = self.online.flat
+        self.chunks, self.wgrad_split = 4, 8
+        self.grad = {}
+        if T is not None:
+            self._ensure(T, rows)
+
+    def _ensure(self, T, rows):
+        if self.shape == (T, rows):
+            return
+        if self.h is not None:
+            raise _lib.HsadError("CompositeLearner was created for batches of %s; got %s" % (self.shape, (T, rows)))
+        ms, gm, lr, eps, clip = self.cfg
+        self.h = C.c_void_p()
+        _lib.check(self.lib.hsad_r2d2_learner_create(self.online.h, self.target.h, int(T), int(rows), ms, gm, lr, eps, clip, C.byref(self.h)))
+        _lib.check(self.lib.hsad_r2d2_learner_set_schedule(self.h, int(self.chunks), int(self.wgrad_split)))
+        self.shape = (T, rows)
+        n = self.online.flat.numel()
+        self.gflat = _view(self.lib.hsad_r2d2_learner_grad(self.h), n, self.device, self)
+        for i, name in enumerate(param_names()):
+            o, sz = self.lib.hsad_r2d2_net_param_offset(self.online.h, i), self.lib.hsad_r2d2_net_param_size(self.online.h, i)
+            self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
+
+    def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
+        priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]
+        P = 1
+        if priv.dim() == 4:
+            P = priv.shape[2]
+            priv, legal, a = priv.flatten(1, 2), legal.flatten(1, 2), a.flatten(1, 2)
+        T, rows, _ = priv.shape
+        self._ensure(T, rows)
+        d, B = self.device, rows // P
+        loss = torch.empty(B, dtype=torch.float32, device=d)
+        prio = torch.empty(T, B, dtype=torch.float32, device=d)
+        own = batch.get("own_hand") if pred_weight > 0 else None
+        p = lambda t: None if t is None else t.contiguous().data_ptr()
+        keep = [priv.contiguous(), legal.contiguous(), a.contiguous(), None if own is None else own.contiguous(), weight.contiguous()]
+        self._alive = keep       # loss_bwd reads these
+        _lib.check(self.lib.hsad_r2d2_loss_fwd(self.h, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), p(batch["reward"]),
+                                               p(batch["bootstrap"]), p(batch["seq_len"]), None if own is None else keep[3].data_ptr(),
+                                               keep[4].data_ptr(), P, float(pred_weight), loss.data_ptr(), prio.data_ptr(),
+                                               int(compute_grad), _s(d)))
+        if compute_grad:
+            _lib.check(self.lib.hsad_r2d2_loss_bwd(self.h, _s(d)))
+        return loss, prio
+
+    def optimizer_step(self, beta1=0.9, beta2=0.999):
+        gp = C.c_void_p()
+        _lib.check(self.lib.hsad_r2d2_optimizer_step(self.h, beta1, beta2, C.byref(gp), _s(self.device)))
+        return torch.sqrt(_view(gp.value, 1, self.device, self)[0])
+
+    def sync_target_with_online(self):
+        if self.h is None:
+            for k, v in self.online.w.items():
+                self.target.w[k].copy_(v)
+            self.target.refresh()
+            return
+        _lib.check(self.lib.hsad_r2d2_sync_target_with_online(self.h, _s(self.device)))
+
+    def check_sync(self):
+        t = C.c_int32(0)
+        _lib.check(self.lib.hsad_r2d2_learner_timed_out(self.h, C.byref(t)))
+        if t.value:
+            raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hsad_r2d2_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

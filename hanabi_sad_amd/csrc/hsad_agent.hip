@@ -1,0 +1,913 @@
+// hsad_agent.hip — the COMPOSITE entry points of the drop-in boundary (include/hsad.h: hsad_r2d2_net_*, hsad_r2d2_act,
+// hsad_r2d2_compute_priority, hsad_r2d2_learner_*, hsad_r2d2_loss_fwd / _loss_bwd / _optimizer_step).
+//
+// What they replace: the methods the reference's native side calls on the agent -- `act` and `compute_priority` through
+// rela::BatchRunner (rela/batch_runner.h:74-113, rela/r2d2_actor.h:61-172 -> pyhanabi/r2d2.py:247-361) -- and the learner step
+// of pyhanabi/selfplay.py:208-244 (R2D2Agent.loss, r2d2.py:383-499; backward; clip; Adam).  A C++ / pybind host can run the
+// agent and the learner through these calls alone: the whole kernel schedule (operand casts, GEMMs, fused cells, persistent
+// recurrences pipelined over layers and time chunks, heads, TD loss, BPTT, weight gradients on a side stream, Adam, operand
+// refresh) lives here, behind plain pointers.  The library owns the weights (one flat fp32 vector per net, tensors in the
+// order of hsad_r2d2_param_name), every bf16 operand copy and all workspace; callers own inputs and outputs.
+//
+// The kernels themselves are the ones in hsad_r2d2.hip, reached through their C entry points.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hsad.h"
+
+extern "C" int hsad_internal_set_error(int code, const char* msg);
+
+namespace {
+
+int afail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return hsad_internal_set_error(code, buf);
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return afail(HSAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define CK(expr)            \
+  do {                      \
+    const int rc_ = (expr); \
+    if (rc_) return rc_;    \
+  } while (0)
+
+typedef unsigned short bf16_t;
+inline int pad64(int k) { return (k + 63) / 64 * 64; }
+
+const char* kParamNames[16] = {"net.0.weight",      "net.0.bias",        "lstm.weight_ih_l0", "lstm.weight_hh_l0",
+                               "lstm.bias_ih_l0",   "lstm.bias_hh_l0",   "lstm.weight_ih_l1", "lstm.weight_hh_l1",
+                               "lstm.bias_ih_l1",   "lstm.bias_hh_l1",   "fc_a.weight",       "fc_v.weight",
+                               "pred.weight",       "fc_a.bias",         "fc_v.bias",         "pred.bias"};
+enum { P_W1 = 0, P_B1, P_WIH0, P_WHH0, P_BIH0, P_BHH0, P_WIH1, P_WHH1, P_BIH1, P_BHH1, P_WA, P_WV, P_WP, P_BA, P_BV, P_BP };
+
+// grow-only device buffer
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int need(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    if (hipMalloc(&p, bytes) != hipSuccess) return afail(HSAD_ERR_NOMEM, "hipMalloc of %zu bytes failed", bytes);
+    cap = bytes;
+    return 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+  ~Buf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+// tiny elementwise helpers of the composite paths
+__global__ void sum_players_kernel(const float* __restrict__ x, int n_out, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out) return;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += x[(size_t)i * P + p];
+  out[i] = s;
+}
+__global__ void repeat_players_kernel(const float* __restrict__ x, int n_in, int P, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_in * P) out[i] = x[i / P];
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += a * x[i];
+}
+
+}  // namespace
+
+struct hsad_r2d2_net {
+  int F, Fp, H, A, NP, NH, NHp, device;
+  bool with_backward;
+  size_t n_param;
+  size_t off[17];
+  float* flat = nullptr;     // fp32 masters, all tensors back to back (order kParamNames)
+  bool owns_flat = true;
+  Buf flat_buf, ops, perms, scratch;
+  bf16_t *W1, *Wih[2], *Whh[2], *Wheads, *Wcat16[2], *WihT[2], *WhhT[2], *WheadsT;
+  float *bg[2], *bheads, *bias16[2];
+  int32_t *perm32, *perm16;
+  uint64_t version = 0;
+  // acting workspace (grows with the row count)
+  Buf ws;
+  float* w(int i) const { return flat + off[i]; }
+};
+
+namespace {
+
+size_t net_tensor_elems(const hsad_r2d2_net* n, int i) {
+  const size_t H = n->H, F = n->F, A = n->A, NP = n->NP;
+  switch (i) {
+    case P_W1: return H * F;
+    case P_B1: return H;
+    case P_WIH0: case P_WHH0: case P_WIH1: case P_WHH1: return 4 * H * H;
+    case P_BIH0: case P_BHH0: case P_BIH1: case P_BHH1: return 4 * H;
+    case P_WA: return A * H;
+    case P_WV: return H;
+    case P_WP: return NP * H;
+    case P_BA: return A;
+    case P_BV: return 1;
+    default: return NP;
+  }
+}
+
+int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
+  const int H = n->H;
+  void* st = (void*)s;
+  n->version++;
+  CK(hsad_prepare_weight(n->w(P_W1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0, st));
+  for (int l = 0; l < 2; ++l) {
+    const float* wih = n->w(l ? P_WIH1 : P_WIH0);
+    const float* whh = n->w(l ? P_WHH1 : P_WHH0);
+    const float* bih = n->w(l ? P_BIH1 : P_BIH0);
+    const float* bhh = n->w(l ? P_BHH1 : P_BHH0);
+    CK(hsad_prepare_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H, st));
+    CK(hsad_prepare_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H, st));
+    CK(hsad_bias_sum_perm(bih, bhh, n->perm32, n->bg[l], 4 * H, st));
+    if (n->Wcat16[l] && !n->with_backward) {
+      CK(hsad_prepare_weight(wih, 4 * H, H, H, n->perm16, n->Wcat16[l], 2 * H, nullptr, 0, st));
+      CK(hsad_prepare_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0, st));
+      CK(hsad_bias_sum_perm(bih, bhh, n->perm16, n->bias16[l], 4 * H, st));
+    }
+  }
+  const int wi[3] = {P_WA, P_WV, P_WP}, bi[3] = {P_BA, P_BV, P_BP}, rows[3] = {n->A, 1, n->NP};
+  int r0 = 0;
+  for (int k = 0; k < 3; ++k) {
+    CK(hsad_prepare_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
+                           n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp, st));
+    CK(hsad_bias_sum_perm(n->w(bi[k]), nullptr, nullptr, n->bheads + r0, rows[k], st));
+    r0 += rows[k];
+  }
+  return 0;
+}
+
+// fp32 [L*N, H] -> bf16 scratch, x-projection etc.: the single-step trunk (R2D2Net.act, r2d2.py:65-78) on N rows.
+// out: o16 = lstm output bf16 [N,H] (points into ws), optional new state.  h16_in: bf16(h0) [L,N,H] when the caller has it.
+struct StepOut {
+  bf16_t* o16;
+  bf16_t* h16_new;   // [L,N,H] (fused path only, else null)
+};
+
+int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const float* c0, const bf16_t* h16_in, float* h_out,
+             float* c_out, char* wsp, StepOut* out, hipStream_t s) {
+  const int H = n->H;
+  void* st = (void*)s;
+  const size_t NH_ = (size_t)N * H;
+  bf16_t* x = reinterpret_cast<bf16_t*>(wsp);
+  wsp += NH_ * 2;
+  CK(hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(P_B1), nullptr, 0, x, H, 1, 0, st));
+  const bool fused = n->Wcat16[0] && !n->with_backward && N >= 1024;
+  if (fused) {
+    bf16_t* h16 = reinterpret_cast<bf16_t*>(wsp);
+    wsp += 2 * NH_ * 2;
+    bf16_t* h16n = reinterpret_cast<bf16_t*>(wsp);
+    wsp += 2 * NH_ * 2;
+    if (!h16_in) {
+      CK(hsad_cast_pad_bf16(h0, 2 * N, H, H, h16, H, st));
+      h16_in = h16;
+    }
+    const bf16_t* xin = x;
+    for (int l = 0; l < 2; ++l) {
+      CK(hsad_lstm_cell_fused(N, H, H, xin, H, h16_in + (size_t)l * NH_, n->Wcat16[l], n->bias16[l], c0 + (size_t)l * NH_,
+                              c_out ? c_out + (size_t)l * NH_ : nullptr, h_out ? h_out + (size_t)l * NH_ : nullptr,
+                              h16n + (size_t)l * NH_, st));
+      xin = h16n + (size_t)l * NH_;
+    }
+    out->o16 = h16n + NH_;
+    out->h16_new = h16n;
+    return 0;
+  }
+  // small batches: projection GEMM + one recurrence step per layer
+  float* gates = reinterpret_cast<float*>(wsp);
+  wsp += (size_t)N * 4 * H * 4;
+  bf16_t* hseq = reinterpret_cast<bf16_t*>(wsp);
+  wsp += 2 * NH_ * 2;
+  bf16_t* sc16 = reinterpret_cast<bf16_t*>(wsp);
+  wsp += NH_ * 2;
+  float* cs = reinterpret_cast<float*>(wsp);
+  wsp += 2 * NH_ * 4;
+  float* ht = reinterpret_cast<float*>(wsp);
+  wsp += 2 * NH_ * 4;
+  const bf16_t* inp = x;
+  for (int l = 0; l < 2; ++l) {
+    CK(hsad_gemm_nt_bf16(inp, H, n->Wih[l], H, N, 4 * H, H, n->bg[l], gates, 4 * H, nullptr, 0, 0, 0, st));
+    CK(hsad_lstm_layer_forward(1, N, H, gates, n->Whh[l], h0 + (size_t)l * NH_, c0 + (size_t)l * NH_, hseq + (size_t)l * NH_,
+                               c_out ? c_out + (size_t)l * NH_ : cs + (size_t)l * NH_, sc16,
+                               h_out ? h_out + (size_t)l * NH_ : ht + (size_t)l * NH_, nullptr, 0, st));
+    inp = hseq + (size_t)l * NH_;
+  }
+  out->o16 = hseq + NH_;
+  out->h16_new = nullptr;
+  return 0;
+}
+
+size_t step_ws_bytes(const hsad_r2d2_net* n, int N) {
+  const size_t NH_ = (size_t)N * n->H;
+  return NH_ * 2 + std::max<size_t>(4 * NH_ * 2, (size_t)N * 4 * n->H * 4 + 3 * NH_ * 2 + 4 * NH_ * 4) + 256;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hsad_r2d2_num_params(void) { return 16; }
+const char* hsad_r2d2_param_name(int i) { return (i >= 0 && i < 16) ? kParamNames[i] : nullptr; }
+
+int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size, int with_backward, int device, hsad_r2d2_net** out) {
+  if (!out || in_dim < 1 || num_action < 1 || hand_size < 1) return afail(HSAD_ERR_INVALID, "r2d2_net_create: bad dimensions");
+  if (hid_dim < 64 || hid_dim % 64) return afail(HSAD_ERR_INVALID, "r2d2_net_create: hid_dim must be a multiple of 64");
+  HIP_TRY(hipSetDevice(device));
+  auto* n = new hsad_r2d2_net();
+  n->F = in_dim;
+  n->Fp = pad64(in_dim);
+  n->H = hid_dim;
+  n->A = num_action;
+  n->NP = 3 * hand_size;
+  n->NH = n->A + 1 + n->NP;
+  n->NHp = pad64(n->NH);
+  n->device = device;
+  n->with_backward = with_backward != 0;
+  size_t o = 0;
+  for (int i = 0; i < 16; ++i) {
+    n->off[i] = o;
+    o += net_tensor_elems(n, i);     // back to back: [fc_a | fc_v | pred] weights / biases form contiguous [NH, H] / [NH] blocks
+  }
+  n->off[16] = o;
+  n->n_param = o;
+  if (n->flat_buf.need(o * 4)) {
+    delete n;
+    return HSAD_ERR_NOMEM;
+  }
+  n->flat = n->flat_buf.as<float>();
+  (void)hipMemset(n->flat, 0, o * 4);
+  const size_t H = hid_dim, H4 = 4 * H;
+  // operand arena
+  size_t need = H * n->Fp * 2 + 2 * (H4 * H * 2) * 2 + 2 * H4 * 4 + (size_t)n->NH * H * 2 + n->NHp * 4 + 2 * (H4 * 2 * H * 2) + 2 * H4 * 4 +
+                (with_backward ? 2 * 2 * (H * H4 * 2) + H * n->NHp * 2 : 0) + 4096;
+  if (n->ops.need(need) || n->perms.need(2 * H4 * 4)) {
+    delete n;
+    return HSAD_ERR_NOMEM;
+  }
+  (void)hipMemset(n->ops.p, 0, need);
+  char* p = n->ops.as<char>();
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += (bytes + 255) & ~(size_t)255;
+    return r;
+  };
+  n->W1 = (bf16_t*)take(H * n->Fp * 2);
+  for (int l = 0; l < 2; ++l) {
+    n->Wih[l] = (bf16_t*)take(H4 * H * 2);
+    n->Whh[l] = (bf16_t*)take(H4 * H * 2);
+    n->bg[l] = (float*)take(H4 * 4);
+    n->Wcat16[l] = with_backward ? nullptr : (bf16_t*)take(H4 * 2 * H * 2);
+    n->bias16[l] = with_backward ? nullptr : (float*)take(H4 * 4);
+    n->WihT[l] = with_backward ? (bf16_t*)take(H * H4 * 2) : nullptr;
+    n->WhhT[l] = with_backward ? (bf16_t*)take(H * H4 * 2) : nullptr;
+  }
+  n->Wheads = (bf16_t*)take((size_t)n->NH * H * 2);
+  n->bheads = (float*)take(n->NHp * 4);
+  n->WheadsT = with_backward ? (bf16_t*)take(H * n->NHp * 2) : nullptr;
+  // row permutations of the LSTM weights: gate-blocked (32 units x [i f g o]) and gate16 (16 units x [i f g o])
+  std::vector<int32_t> pm(2 * H4);
+  for (int nb = 0; nb < (int)H / 32; ++nb)
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 32; ++u) pm[nb * 128 + g * 32 + u] = g * (int)H + nb * 32 + u;
+  for (int ub = 0; ub < (int)H / 16; ++ub)
+    for (int g = 0; g < 4; ++g)
+      for (int u = 0; u < 16; ++u) pm[H4 + ub * 64 + g * 16 + u] = g * (int)H + ub * 16 + u;
+  n->perm32 = n->perms.as<int32_t>();
+  n->perm16 = n->perm32 + H4;
+  if (hipMemcpy(n->perm32, pm.data(), pm.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    delete n;
+    return afail(HSAD_ERR_HIP, "r2d2_net_create: permutation upload failed");
+  }
+  *out = n;
+  return 0;
+}
+
+void hsad_r2d2_net_destroy(hsad_r2d2_net* n) { delete n; }
+int64_t hsad_r2d2_net_param_count(const hsad_r2d2_net* n) { return n ? (int64_t)n->n_param : 0; }
+float* hsad_r2d2_net_params(hsad_r2d2_net* n) { return n ? n->flat : nullptr; }
+int64_t hsad_r2d2_net_param_offset(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i <= 16) ? (int64_t)n->off[i] : -1; }
+int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i < 16) ? (int64_t)net_tensor_elems(n, i) : -1; }
+uint64_t hsad_r2d2_net_version(const hsad_r2d2_net* n) { return n ? n->version : 0; }
+
+int hsad_r2d2_net_refresh(hsad_r2d2_net* n, void* stream) {
+  if (!n) return afail(HSAD_ERR_INVALID, "null net");
+  return net_refresh(n, (hipStream_t)stream);
+}
+
+// R2D2Agent.act (pyhanabi/r2d2.py:247-303) for N rows (one row per (game, player)): eps-greedy action, greedy action, new
+// hidden state.  q_online_a / q_target_greedy (both or neither; `target` required with them): Q_online(s, a) of the pass just
+// run and Q_target(s, greedy_a) from one target-net pass -- what compute_priority needs from this time step.
+int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const float* legal_move,
+                  const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
+                  int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
+                  float* q_target_greedy, void* stream) {
+  if (!online || !priv_s || !legal_move || !h0 || !c0 || !a || !greedy_a || !h_out || !c_out || N < 1)
+    return afail(HSAD_ERR_INVALID, "r2d2_act: null argument");
+  if ((q_online_a != nullptr) != (q_target_greedy != nullptr) || (q_online_a && !target))
+    return afail(HSAD_ERR_INVALID, "r2d2_act: q_online_a and q_target_greedy come together and need the target net");
+  hsad_r2d2_net* n = online;
+  hipStream_t s = (hipStream_t)stream;
+  const int H = n->H, A = n->A, NH = n->NH;
+  const size_t a16_b = (size_t)N * n->Fp * 2, hd_b = (size_t)N * NH * 4, q_b = (size_t)N * A * 4, sc_b = (4 + (N + 255) / 256) * 4;
+  const size_t step_b = step_ws_bytes(n, N);
+  CK(n->ws.need(a16_b + 2 * step_b + 2 * hd_b + q_b + sc_b + 1024));
+  char* p = n->ws.as<char>();
+  bf16_t* a16 = (bf16_t*)p;
+  p += a16_b;
+  char* ws_on = p;
+  p += step_b;
+  char* ws_tg = p;
+  p += step_b;
+  float* hd = (float*)p;
+  p += hd_b;
+  float* hd_t = (float*)p;
+  p += hd_b;
+  float* q = (float*)p;
+  p += q_b;
+  float* scratch = (float*)p;
+  CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
+  StepOut so{};
+  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s));
+  if (h_out_bf16 && so.h16_new) HIP_TRY(hipMemcpyAsync(h_out_bf16, so.h16_new, (size_t)2 * N * H * 2, hipMemcpyDeviceToDevice, s));
+  CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
+  CK(hsad_act_select(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, scratch, stream));
+  if (q_online_a) {
+    CK(hsad_q_head(hd, NH, legal_move, a, N, A, q, q_online_a, nullptr, scratch, stream));
+    if (target->F != n->F || target->H != H || target->A != A) return afail(HSAD_ERR_INVALID, "r2d2_act: online / target shapes differ");
+    StepOut st{};
+    // the target pass shares the bf16 casts of the observation and (fused path) of the hidden state
+    const bf16_t* h16_shared = (const bf16_t*)h0_bf16;
+    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);   // the cast net_step made
+    CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s));
+    CK(hsad_gemm_nt_bf16(st.o16, H, target->Wheads, H, N, NH, H, target->bheads, hd_t, NH, nullptr, 0, 0, 0, stream));
+    CK(hsad_q_head(hd_t, NH, legal_move, greedy_a, N, A, q, q_target_greedy, nullptr, scratch, stream));
+  }
+  return 0;
+}
+
+// Q_net(s, action) [N] for one step from the carried hidden state
+static int net_q_of(hsad_r2d2_net* n, int N, const float* priv_s, const float* legal, const int64_t* action, const float* h0,
+                    const float* c0, float* qa, int64_t* greedy_out, hipStream_t s) {
+  void* stream = (void*)s;
+  const int H = n->H, A = n->A, NH = n->NH;
+  const size_t a16_b = (size_t)N * n->Fp * 2, hd_b = (size_t)N * NH * 4, q_b = (size_t)N * A * 4, sc_b = (4 + (N + 255) / 256) * 4;
+  const size_t step_b = step_ws_bytes(n, N);
+  CK(n->ws.need(a16_b + 2 * step_b + 2 * hd_b + q_b + sc_b + 1024 + (size_t)N * 8));
+  char* p = n->ws.as<char>();
+  bf16_t* a16 = (bf16_t*)p;
+  p += a16_b;
+  char* ws_on = p;
+  p += 2 * step_b;
+  float* hd = (float*)p;
+  p += 2 * hd_b;
+  float* q = (float*)p;
+  p += q_b;
+  float* scratch = (float*)p;
+  p += sc_b;
+  int64_t* junk = (int64_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
+  StepOut so{};
+  CK(net_step(n, N, a16, h0, c0, nullptr, nullptr, nullptr, ws_on, &so, s));
+  CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
+  if (greedy_out) CK(hsad_act_select(hd, NH, legal, nullptr, N, A, 0, 0, junk, greedy_out, scratch, stream));
+  if (qa) CK(hsad_q_head(hd, NH, legal, action, N, A, q, qa, nullptr, scratch, stream));
+  return 0;
+}
+
+// Q_net(s, action) [N] for one step from the carried hidden state (one network pass; the pieces compute_priority is made of)
+int hsad_r2d2_q_of(hsad_r2d2_net* net, int N, const float* priv_s, const float* legal_move, const int64_t* action, const float* h0,
+                   const float* c0, float* qa, void* stream) {
+  if (!net || !priv_s || !legal_move || !action || !h0 || !c0 || !qa || N < 1) return afail(HSAD_ERR_INVALID, "r2d2_q_of: null argument");
+  return net_q_of(net, N, priv_s, legal_move, action, h0, c0, qa, nullptr, (hipStream_t)stream);
+}
+
+// R2D2Agent.compute_priority (pyhanabi/r2d2.py:305-361): |r + bootstrap * gamma^n * Q_target(s', argmax_a' adv_online(s')) - Q_online(s, a)|
+// rows are (game, player) pairs; num_player > 1 = VDN: Q summed over the players of a game, reward / bootstrap / priority per game.
+// next_greedy_a (may be NULL): argmax_a' adv_online(s') when the caller already has it (the act() of the same iteration).
+int hsad_r2d2_compute_priority(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, int num_player, const float* priv_s,
+                               const float* legal_move, const int64_t* a, const float* next_priv_s, const float* next_legal_move,
+                               const float* h0, const float* c0, const float* next_h0, const float* next_c0, const float* reward,
+                               const float* bootstrap, int multi_step, double gamma, const int64_t* next_greedy_a, float* priority,
+                               void* stream) {
+  if (!online || !target || !priv_s || !legal_move || !a || !next_priv_s || !next_legal_move || !h0 || !c0 || !next_h0 || !next_c0 ||
+      !reward || !bootstrap || !priority || N < 1 || num_player < 1 || N % num_player)
+    return afail(HSAD_ERR_INVALID, "r2d2_compute_priority: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_game = N / num_player;
+  CK(online->scratch.need((size_t)N * (4 + 4 + 8) + (size_t)n_game * 8 + 64));
+  float* qa = online->scratch.as<float>();
+  float* tqa = qa + N;
+  int64_t* na = reinterpret_cast<int64_t*>(tqa + N);
+  float* sq = reinterpret_cast<float*>(na + N);
+  CK(net_q_of(online, N, priv_s, legal_move, a, h0, c0, qa, nullptr, s));
+  if (!next_greedy_a) {
+    CK(net_q_of(online, N, next_priv_s, next_legal_move, nullptr, next_h0, next_c0, nullptr, na, s));
+    next_greedy_a = na;
+  }
+  CK(net_q_of(target, N, next_priv_s, next_legal_move, next_greedy_a, next_h0, next_c0, tqa, nullptr, s));
+  int n_out = N;
+  if (num_player > 1) {
+    n_out = n_game;
+    hipLaunchKernelGGL(sum_players_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, qa, n_out, num_player, sq);
+    hipLaunchKernelGGL(sum_players_kernel, dim3((n_out + 255) / 256), dim3(256), 0, s, tqa, n_out, num_player, sq + n_out);
+    qa = sq;
+    tqa = sq + n_out;
+  }
+  return hsad_nstep_priority(qa, tqa, reward, bootstrap, multi_step, gamma, n_out, priority, stream);
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Learner: loss forward (online + target net), BPTT, clip + Adam  (pyhanabi/selfplay.py:208-244, r2d2.py:383-499)
+// =====================================================================================================================
+struct hsad_r2d2_learner {
+  hsad_r2d2_net *on, *tg;
+  int T, B, M, multi_step, n_cu, step_count = 0;
+  double gamma;
+  float lr, adam_eps, clip;
+  int wgrad_split = 8, chunks = 4;
+  Buf arena, opt, sync_buf;
+  float *gflat, *m, *v, *osc;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  // activations (q = 0 online, 1 target)
+  bf16_t *a16, *x1[2], *hseq[2][2], *xchg_f[2][2], *zero16, *sc16;
+  float *gates[2][2], *cseq[2][2], *hT[2][2], *czero;
+  float *heads, *heads_t, *q, *qa, *tqa, *qa_s, *tqa_s, *err, *dqa, *dqa_r, *w_r, *xs, *qscratch;
+  int64_t* greedy;
+  // backward
+  bf16_t *dheads, *dG[2], *dx1, *hsT[2], *hpT[2], *x1T, *a16T, *dGT, *dx1T, *dheadsT, *xchg_b[2];
+  int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
+  float *dO0, *dO1, *dc[2], *wgrad_ws;
+  // ping-pong counter blocks of the persistent launches: [kind fwd/bwd][nrec - 1][flip]
+  unsigned* sync[2][4][2];
+  int flip[2][4];
+  unsigned* sync1;        // unchunked single-recurrence launches (the kernels zero it themselves)
+  size_t sync_words[2][4];
+  // what loss_fwd saw (loss_bwd continues from it)
+  const float *b_legal = nullptr, *b_own = nullptr, *b_weight = nullptr;
+  const int64_t* b_a = nullptr;
+  float pred_weight = 0.f;
+  int num_player = 1, nch = 1;
+  bool have_fwd = false;
+};
+
+namespace {
+
+// persistent multi-recurrence launches + the shared delayed-copy operand of the weight gradients need H in {256, 512}, at most
+// 512 rows, rows a multiple of 8 and T * rows a multiple of the GEMM K tile; everything else takes the unchunked schedule
+bool can_pipeline(const hsad_r2d2_learner* L) {
+  const int H = L->on->H;
+  return (H == 256 || H == 512) && L->B <= 512 && L->B % 8 == 0 && L->M % 64 == 0;
+}
+int pick_chunks(const hsad_r2d2_learner* L) {
+  if (!can_pipeline(L)) return 1;
+  int c = L->chunks;
+  while (c > 1 && (L->T % c || ((L->T / c) * L->B) % 64)) --c;
+  return c;
+}
+inline int nrb_of(int B) { return (B + 31) / 32; }
+
+int transpose16(const bf16_t* src, int R, int C, int lds, bf16_t* dst, int ldd, float* csum, float* csum2, const int32_t* cmap, void* st) {
+  if (csum) return hsad_transpose_bf16_colsum(src, R, C, lds, dst, ldd, csum, csum2, cmap, st);
+  return hsad_transpose_bf16(src, R, C, lds, dst, ldd, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T, int rows_per_step, int multi_step, double gamma,
+                             float lr, float eps, float grad_clip, hsad_r2d2_learner** out) {
+  if (!online || !target || !out || T < 1 || rows_per_step < 1) return afail(HSAD_ERR_INVALID, "r2d2_learner_create: bad arguments");
+  if (!online->with_backward) return afail(HSAD_ERR_INVALID, "r2d2_learner_create: the online net must be created with_backward");
+  if (online->F != target->F || online->H != target->H || online->A != target->A || online->NP != target->NP)
+    return afail(HSAD_ERR_INVALID, "r2d2_learner_create: online / target shapes differ");
+  HIP_TRY(hipSetDevice(online->device));
+  auto* L = new hsad_r2d2_learner();
+  L->on = online;
+  L->tg = target;
+  L->T = T;
+  L->B = rows_per_step;
+  L->M = T * rows_per_step;
+  L->multi_step = multi_step;
+  L->gamma = gamma;
+  L->lr = lr;
+  L->adam_eps = eps;
+  L->clip = grad_clip;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&L->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) L->n_cu = 256;
+  const size_t M = L->M, B = L->B, H = online->H, H4 = 4 * H, Fp = online->Fp, NH = online->NH, NHp = online->NHp, A = online->A;
+  const int nch = pick_chunks(L);
+  const bool pipe0 = can_pipeline(L);
+  const size_t Mp = pad64((int)M);
+  L->Mp = (int)Mp;
+  const size_t Tc = T / nch, nrb = nrb_of((int)B), xf = Tc * nrb * 32 * H, xb = Tc * nrb * 32 * H4;
+  // ---- one arena for every activation of an update ----
+  std::vector<std::pair<void**, size_t>> plan;
+  auto want = [&](auto** pp, size_t bytes) { plan.push_back({reinterpret_cast<void**>(pp), (bytes + 255) & ~(size_t)255}); };
+  want(&L->a16, M * Fp * 2);
+  for (int q = 0; q < 2; ++q) {
+    want(&L->x1[q], M * H * 2);
+    for (int l = 0; l < 2; ++l) {
+      want(&L->gates[q][l], M * H4 * 4);
+      want(&L->hseq[q][l], M * H * 2);
+      want(&L->cseq[q][l], M * H * 4);
+      want(&L->hT[q][l], B * H * 4);
+      want(&L->xchg_f[q][l], xf * 2);
+    }
+  }
+  want(&L->zero16, B * H * 2);
+  want(&L->sc16, B * H * 2);
+  want(&L->czero, B * H * 4);
+  want(&L->heads, M * NH * 4);
+  want(&L->heads_t, M * NH * 4);
+  want(&L->q, M * A * 4);
+  want(&L->qa, M * 4);
+  want(&L->tqa, M * 4);
+  want(&L->qa_s, M * 4);
+  want(&L->tqa_s, M * 4);
+  want(&L->err, M * 4);
+  want(&L->dqa, M * 4);
+  want(&L->dqa_r, M * 4);
+  want(&L->w_r, B * 4);
+  want(&L->xs, B * 4);
+  want(&L->qscratch, (8 + (M + 255) / 256) * 4);
+  want(&L->greedy, M * 8);
+  want(&L->dheads, M * NHp * 2);
+  want(&L->dO0, M * H * 4);
+  want(&L->dO1, M * H * 4);
+  for (int l = 0; l < 2; ++l) {
+    want(&L->dG[l], (size_t)(T + 1) * B * H4 * 2);
+    want(&L->dc[l], B * H * 4);
+    want(&L->hsT[l], pipe0 ? H * (B + M) * 2 : H * Mp * 2);
+    want(&L->hpT[l], pipe0 ? 256 : H * Mp * 2);
+    want(&L->xchg_b[l], xb * 2);
+  }
+  want(&L->dx1, M * H * 2);
+  want(&L->x1T, H * Mp * 2);
+  want(&L->a16T, Fp * Mp * 2);
+  want(&L->dGT, H4 * Mp * 2);
+  want(&L->dx1T, H * Mp * 2);
+  want(&L->dheadsT, NHp * Mp * 2);
+  want(&L->wgrad_ws, (size_t)L->wgrad_split * H4 * std::max(H, (size_t)online->F) * 4);
+  size_t total = 0;
+  for (auto& e : plan) total += e.second;
+  if (L->arena.need(total + 256)) {
+    delete L;
+    return HSAD_ERR_NOMEM;
+  }
+  (void)hipMemset(L->arena.p, 0, total);
+  char* p = L->arena.as<char>();
+  for (auto& e : plan) {
+    *e.first = p;
+    p += e.second;
+  }
+  // optimizer state + gradient
+  const size_t np = online->n_param;
+  if (L->opt.need(np * 4 * 3 + 64)) {
+    delete L;
+    return HSAD_ERR_NOMEM;
+  }
+  (void)hipMemset(L->opt.p, 0, np * 4 * 3 + 64);
+  L->gflat = L->opt.as<float>();
+  L->m = L->gflat + np;
+  L->v = L->m + np;
+  L->osc = L->v + np;
+  // counter blocks (zero-initialised: a ping-pong launch clears its partner for the next one)
+  size_t sw = 0;
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 4; ++r) {
+      L->sync_words[k][r] = (size_t)(r + 1) * nrb * (Tc + 2) + 4;
+      sw += 2 * L->sync_words[k][r];
+    }
+  const size_t s1 = nrb * ((size_t)T + 2) + 4;
+  if (L->sync_buf.need((sw + s1) * 4)) {
+    delete L;
+    return HSAD_ERR_NOMEM;
+  }
+  (void)hipMemset(L->sync_buf.p, 0, (sw + s1) * 4);
+  unsigned* sp = L->sync_buf.as<unsigned>();
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 4; ++r) {
+      for (int f = 0; f < 2; ++f) {
+        L->sync[k][r][f] = sp;
+        sp += L->sync_words[k][r];
+      }
+      L->flip[k][r] = 0;
+    }
+  L->sync1 = sp;
+  if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess) {
+    delete L;
+    return afail(HSAD_ERR_HIP, "r2d2_learner_create: stream / event creation failed");
+  }
+  *out = L;
+  return 0;
+}
+
+void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
+  if (!L) return;
+  if (L->side) (void)hipStreamDestroy(L->side);
+  for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c})
+    if (e) (void)hipEventDestroy(e);
+  delete L;
+}
+float* hsad_r2d2_learner_grad(hsad_r2d2_learner* L) { return L ? L->gflat : nullptr; }
+int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_split) {
+  if (!L || chunks < 1 || wgrad_split < 1 || wgrad_split > 8) return afail(HSAD_ERR_INVALID, "learner_set_schedule: chunks >= 1, wgrad_split 1..8");
+  L->chunks = chunks;
+  L->wgrad_split = wgrad_split;
+  return 0;
+}
+/* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
+int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
+  if (!L || !timed_out) return afail(HSAD_ERR_INVALID, "null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  *timed_out = 0;
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 4; ++r)
+      for (int f = 0; f < 2; ++f) {
+        unsigned v = 0;
+        HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + L->sync_words[k][r] - 4, 4, hipMemcpyDeviceToHost));
+        *timed_out |= (int32_t)v;
+      }
+  return 0;
+}
+
+// loss forward: batch tensors [T, rows, ...] with rows = B (IQL) or B_games * num_player (VDN: Q summed over a game's players;
+// reward / bootstrap [T, games], seq_len / weight / loss [games], priority [T, games]).  own_hand may be NULL (pred_weight = 0).
+int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const float* legal_move, const int64_t* a, const float* reward,
+                       const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
+                       float pred_weight, float* loss, float* priority, int want_grad, void* stream) {
+  if (!L || !priv_s || !legal_move || !a || !reward || !bootstrap || !seq_len || !loss || !priority || num_player < 1 || L->B % num_player)
+    return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: bad arguments");
+  if (pred_weight > 0 && num_player > 1)
+    return afail(HSAD_ERR_INVALID, "VDN with the auxiliary task is broken in the reference (aux_task_vdn, SURVEY F6b) and has no defined behaviour");
+  if (pred_weight > 0 && !own_hand) return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: pred_weight > 0 needs own_hand");
+  if (want_grad && !weight) return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: the gradient needs the importance weights");
+  hsad_r2d2_net* nets[2] = {L->on, L->tg};
+  hipStream_t s = (hipStream_t)stream;
+  const int T = L->T, B = L->B, M = L->M, H = L->on->H, H4 = 4 * H, A = L->on->A, NH = L->on->NH, Fp = L->on->Fp;
+  const int nch = pick_chunks(L);
+  L->nch = nch;
+  CK(hsad_cast_pad_bf16(priv_s, M, L->on->F, L->on->F, L->a16, Fp, stream));
+  for (int q = 0; q < 2; ++q) {
+    CK(hsad_gemm_nt_bf16(L->a16, Fp, nets[q]->W1, Fp, M, H, Fp, nets[q]->w(P_B1), nullptr, 0, L->x1[q], H, 1, 0, stream));
+    CK(hsad_gemm_nt_bf16(L->x1[q], H, nets[q]->Wih[0], H, M, H4, H, nets[q]->bg[0], L->gates[q][0], H4, nullptr, 0, 0, 0, stream));
+  }
+  if (can_pipeline(L)) {
+    // layers software-pipelined over time chunks: stage st runs layer 0 on chunk st and layer 1 on chunk st - 1, for both nets, as
+    // ONE multi-recurrence persistent launch
+    const int Tc = T / nch, nrb = nrb_of(B);
+    const int per_launch = std::max(1, std::min(4, L->n_cu / ((H / 32) * nrb)));
+    for (int st = 0; st <= nch; ++st) {
+      hsad_lstm_fwd_rec recs[4];
+      int nr = 0;
+      for (int q = 0; q < 2; ++q) {
+        auto rec = [&](int l, int c) {
+          const size_t t0 = (size_t)c * Tc;
+          hsad_lstm_fwd_rec r;
+          r.gates = L->gates[q][l] + t0 * B * H4;
+          r.Whh_blocked = nets[q]->Whh[l];
+          r.h_prev16 = c == 0 ? L->zero16 : L->hseq[q][l] + (t0 - 1) * B * H;
+          r.c_prev = c == 0 ? nullptr : L->cseq[q][l] + (t0 - 1) * B * H;
+          r.hseq16 = L->hseq[q][l] + t0 * B * H;
+          r.cseq = L->cseq[q][l] + t0 * B * H;
+          r.hT = L->hT[q][l];
+          r.xchg = L->xchg_f[q][l];
+          return r;
+        };
+        if (st < nch) recs[nr++] = rec(0, st);
+        if (st >= 1) {
+          const size_t t0 = (size_t)(st - 1) * Tc;
+          CK(hsad_gemm_nt_bf16(L->hseq[q][0] + t0 * B * H, H, nets[q]->Wih[1], H, Tc * B, H4, H, nets[q]->bg[1],
+                               L->gates[q][1] + t0 * B * H4, H4, nullptr, 0, 0, 0, stream));
+          recs[nr++] = rec(1, st - 1);
+        }
+      }
+      for (int i = 0; i < nr; i += per_launch) {
+        const int n = std::min(per_launch, nr - i);
+        int& f = L->flip[0][n - 1];
+        CK(hsad_lstm_forward_chunk_multi(n, Tc, B, H, recs + i, L->sync[0][n - 1][f], L->sync[0][n - 1][f ^ 1], stream));
+        f ^= 1;
+      }
+    }
+  } else {
+    for (int q = 0; q < 2; ++q)
+      for (int l = 0; l < 2; ++l) {
+        if (l == 1)
+          CK(hsad_gemm_nt_bf16(L->hseq[q][0], H, nets[q]->Wih[1], H, M, H4, H, nets[q]->bg[1], L->gates[q][1], H4, nullptr, 0, 0, 0, stream));
+        CK(hsad_lstm_layer_forward(T, B, H, L->gates[q][l], nets[q]->Whh[l], nullptr, L->czero, L->hseq[q][l], L->cseq[q][l], L->sc16,
+                                   L->hT[q][l], L->sync1, 1, stream));
+      }
+  }
+  // heads, Q-values, double-DQN target
+  CK(hsad_gemm_nt_bf16(L->hseq[0][1], H, L->on->Wheads, H, M, NH, H, L->on->bheads, L->heads, NH, nullptr, 0, 0, 0, stream));
+  CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, L->greedy, L->qscratch, stream));
+  CK(hsad_gemm_nt_bf16(L->hseq[1][1], H, L->tg->Wheads, H, M, NH, H, L->tg->bheads, L->heads_t, NH, nullptr, 0, 0, 0, stream));
+  CK(hsad_q_head(L->heads_t, NH, legal_move, L->greedy, M, A, L->q, L->tqa, nullptr, L->qscratch, stream));
+  const float *qa = L->qa, *tqa = L->tqa;
+  const int Bg = B / num_player;
+  if (num_player > 1) {
+    const int n = T * Bg;
+    hipLaunchKernelGGL(sum_players_kernel, dim3((n + 255) / 256), dim3(256), 0, s, L->qa, n, num_player, L->qa_s);
+    hipLaunchKernelGGL(sum_players_kernel, dim3((n + 255) / 256), dim3(256), 0, s, L->tqa, n, num_player, L->tqa_s);
+    qa = L->qa_s;
+    tqa = L->tqa_s;
+  }
+  CK(hsad_td_loss(qa, tqa, reward, bootstrap, seq_len, T, Bg, L->multi_step, L->gamma, L->err, priority, loss, want_grad ? L->dqa : nullptr,
+                  weight, stream));
+  if (pred_weight > 0) {
+    CK(hsad_aux_xent(L->heads, NH, own_hand, T, B, A, L->on->NP, L->xs, stream));
+    hipLaunchKernelGGL(axpy_kernel, dim3((B + 255) / 256), dim3(256), 0, s, loss, L->xs, pred_weight, B);
+  }
+  HIP_TRY(hipGetLastError());
+  L->b_legal = legal_move;
+  L->b_a = a;
+  L->b_own = pred_weight > 0 ? own_hand : nullptr;
+  L->b_weight = weight;
+  L->pred_weight = pred_weight;
+  L->num_player = num_player;
+  L->have_fwd = want_grad != 0;
+  return 0;
+}
+
+// BPTT of the last loss_fwd(want_grad = 1) of mean_b(weight_b * loss_b) into the learner's flat gradient (order = the net's
+// parameter vector).  The batch tensors given to loss_fwd must still be alive.
+int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
+  if (!L || !L->have_fwd) return afail(HSAD_ERR_STATE, "r2d2_loss_bwd: call loss_fwd(want_grad = 1) first");
+  L->have_fwd = false;
+  hsad_r2d2_net* on = L->on;
+  hipStream_t s = (hipStream_t)stream;
+  const int T = L->T, B = L->B, M = L->M, H = on->H, H4 = 4 * H, A = on->A, NH = on->NH, NHp = on->NHp, Fp = on->Fp, F = on->F, NP = on->NP;
+  const int nch = L->nch, P = L->num_player, Bg = B / P;
+  const float *dqa = L->dqa, *weight = L->b_weight;
+  if (P > 1) {
+    hipLaunchKernelGGL(repeat_players_kernel, dim3((M + 255) / 256), dim3(256), 0, s, L->dqa, T * Bg, P, L->dqa_r);
+    hipLaunchKernelGGL(repeat_players_kernel, dim3((B + 255) / 256), dim3(256), 0, s, L->b_weight, Bg, P, L->w_r);
+    dqa = L->dqa_r;
+    weight = L->w_r;
+  }
+  CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
+                         L->dheads, NHp, stream));
+  CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO1, H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+  HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
+  float* g[16];
+  for (int i = 0; i < 16; ++i) g[i] = L->gflat + on->off[i];
+  const bool pipe = can_pipeline(L);
+  const int Mp = L->Mp;            // == M in the pipelined schedule
+  // weight-gradient work runs on the side stream in the pipelined schedule (it overlaps the recurrences), else in line
+  hipStream_t ws = pipe ? L->side : s;
+  void* wst = (void*)ws;
+  // transposed operands.  Pipelined: [H, B + M] with x^T in columns B.., so that [:, :M] is the one-step-delayed copy (h_{t-1},
+  // zeros for t = 0) and one transpose serves the input-weight and the recurrent-weight gradient.  Unchunked schedule (any T, B):
+  // x^T and the delayed copy are separate zero-padded [H, Mp] buffers.
+  const int ldh = pipe ? B + M : Mp;
+  const bf16_t* hs_x[2] = {pipe ? L->hsT[0] + B : L->hsT[0], pipe ? L->hsT[1] + B : L->hsT[1]};
+  const bf16_t* hs_d[2] = {pipe ? L->hsT[0] : L->hpT[0], pipe ? L->hsT[1] : L->hpT[1]};
+  auto wgrad = [&](const bf16_t* AT, const bf16_t* BT, int ldb, int Mo, int No, float* outp, int ldc, const int32_t* rmap) {
+    return hsad_gemm_nt_bf16_splitk(AT, Mp, BT, ldb, Mo, No, Mp, L->wgrad_split, L->wgrad_ws, outp, ldc, rmap, wst);
+  };
+  auto layer_wgrad = [&](int l, const bf16_t* inT, int ld_in) {
+    if (M % 4 == 0) {      // the transpose also accumulates both bias gradients (= the un-blocked column sums of dG)
+      CK(transpose16(L->dG[l], M, H4, H4, L->dGT, Mp, g[l ? P_BIH1 : P_BIH0], g[l ? P_BHH1 : P_BHH0], on->perm32, wst));
+    } else {
+      CK(transpose16(L->dG[l], M, H4, H4, L->dGT, Mp, nullptr, nullptr, nullptr, wst));
+      CK(hsad_colsum_acc(L->dG[l], 1, M, H4, H4, g[l ? P_BIH1 : P_BIH0], g[l ? P_BHH1 : P_BHH0], on->perm32, wst));
+    }
+    CK(wgrad(L->dGT, inT, ld_in, H4, H, g[l ? P_WIH1 : P_WIH0], H, on->perm32));
+    CK(wgrad(L->dGT, hs_d[l], ldh, H4, H, g[l ? P_WHH1 : P_WHH0], H, on->perm32));
+    return 0;
+  };
+  if (pipe) {
+    HIP_TRY(hipEventRecord(L->ev_a, s));
+    HIP_TRY(hipStreamWaitEvent(ws, L->ev_a, 0));
+  }
+  for (int l = 0; l < 2; ++l) {
+    if (pipe) {
+      HIP_TRY(hipMemset2DAsync(L->hsT[l], (size_t)(B + M) * 2, 0, (size_t)B * 2, H, ws));
+      CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l] + B, B + M, nullptr, nullptr, nullptr, wst));
+    } else {
+      CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l], Mp, nullptr, nullptr, nullptr, wst));
+      HIP_TRY(hipMemset2DAsync(L->hpT[l], (size_t)Mp * 2, 0, (size_t)B * 2, H, ws));
+      if (M > B) CK(transpose16(L->hseq[0][l], M - B, H, H, L->hpT[l] + B, Mp, nullptr, nullptr, nullptr, wst));
+    }
+  }
+  CK(transpose16(L->x1[0], M, H, H, L->x1T, Mp, nullptr, nullptr, nullptr, wst));
+  CK(transpose16(L->a16, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
+  CK(transpose16(L->dheads, M, NHp, NHp, L->dheadsT, Mp, nullptr, nullptr, nullptr, wst));
+  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[1], ldh, NH, H, Mp, nullptr, g[P_WA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
+  CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[P_BA], nullptr, nullptr, wst));
+  if (pipe) {
+    const int Tc = T / nch, nrb = nrb_of(B);
+    const size_t Mc = (size_t)Tc * B;
+    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)B * H * 4, s));
+    HIP_TRY(hipMemsetAsync(L->dc[1], 0, (size_t)B * H * 4, s));
+    const float* dOs[2] = {L->dO0, L->dO1};
+    const int per_launch = std::max(1, std::min(2, L->n_cu / ((H / 32) * nrb)));
+    for (int st = 0; st <= nch; ++st) {
+      hsad_lstm_bwd_rec recs[2];
+      int nr = 0;
+      auto brec = [&](int l, int c) {
+        const size_t t0 = (size_t)c * Tc;
+        hsad_lstm_bwd_rec r;
+        r.gates = L->gates[0][l] + t0 * B * H4;
+        r.cseq = L->cseq[0][l] + t0 * B * H;
+        r.c_before = c == 0 ? nullptr : L->cseq[0][l] + (t0 - 1) * B * H;
+        r.WhhT_blocked = on->WhhT[l];
+        r.dO = dOs[l] + t0 * B * H;
+        r.dG16 = L->dG[l] + t0 * B * H4;
+        r.dc_io = L->dc[l];
+        r.has_next = c != nch - 1;
+        r.xchg = L->xchg_b[l];
+        return r;
+      };
+      if (st < nch) recs[nr++] = brec(1, nch - 1 - st);
+      if (st >= 1) {
+        const int c0 = nch - st;
+        CK(hsad_gemm_nt_bf16_ex(L->dG[1] + (size_t)c0 * Mc * H4, H4, on->WihT[1], H4, (int)Mc, H, H4, nullptr, L->dO0 + (size_t)c0 * Mc * H, H,
+                                nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+        recs[nr++] = brec(0, c0);
+      }
+      for (int i = 0; i < nr; i += per_launch) {
+        const int n = std::min(per_launch, nr - i);
+        int& f = L->flip[1][n - 1];
+        CK(hsad_lstm_backward_chunk_multi(n, Tc, B, H, recs + i, L->sync[1][n - 1][f], L->sync[1][n - 1][f ^ 1], stream));
+        f ^= 1;
+      }
+      if (st == nch - 1) HIP_TRY(hipEventRecord(L->ev_b, s));      // layer 1 complete
+    }
+    HIP_TRY(hipStreamWaitEvent(ws, L->ev_b, 0));
+    CK(layer_wgrad(1, hs_x[0], ldh));
+    HIP_TRY(hipEventRecord(L->ev_c, s));                            // layer 0 complete
+    HIP_TRY(hipStreamWaitEvent(ws, L->ev_c, 0));
+    CK(layer_wgrad(0, L->x1T, Mp));
+  } else {
+    for (int l = 1; l >= 0; --l) {
+      CK(hsad_lstm_layer_backward(T, B, H, L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], l ? L->dO1 : L->dO0, L->dG[l], L->dc[l],
+                                  L->sync1, stream));
+      if (l == 1)
+        CK(hsad_gemm_nt_bf16_ex(L->dG[1], H4, on->WihT[1], H4, M, H, H4, nullptr, L->dO0, H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+      CK(layer_wgrad(l, l ? hs_x[0] : L->x1T, l ? ldh : Mp));
+    }
+  }
+  CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->x1[0], H, nullptr, stream));
+  if (M % 4 == 0 && H % 4 == 0) {
+    CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, g[P_B1], nullptr, nullptr, stream));
+  } else {
+    CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, nullptr, nullptr, nullptr, stream));
+    CK(hsad_colsum_acc(L->dx1, 1, M, H, H, g[P_B1], nullptr, nullptr, stream));
+  }
+  CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[P_W1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+  if (pipe) {
+    HIP_TRY(hipEventRecord(L->ev_a, ws));
+    HIP_TRY(hipStreamWaitEvent(s, L->ev_a, 0));
+  }
+  return 0;
+}
+
+// torch.nn.utils.clip_grad_norm_ + Adam.step (selfplay.py:231-235) on the online net + re-derivation of its kernel operands.
+// grad_norm_sq_dev (may be NULL): device float that receives the squared pre-clip global gradient norm.
+int hsad_r2d2_optimizer_step(hsad_r2d2_learner* L, float beta1, float beta2, float** grad_norm_sq_dev, void* stream) {
+  if (!L) return afail(HSAD_ERR_INVALID, "null learner");
+  L->step_count++;
+  CK(hsad_adam_step(L->on->flat, L->gflat, L->m, L->v, (int64_t)L->on->n_param, L->clip, L->lr, beta1, beta2, L->adam_eps, L->step_count, L->osc,
+                    stream));
+  if (grad_norm_sq_dev) *grad_norm_sq_dev = L->osc;
+  return net_refresh(L->on, (hipStream_t)stream);
+}
+
+int hsad_r2d2_sync_target_with_online(hsad_r2d2_learner* L, void* stream) {
+  if (!L) return afail(HSAD_ERR_INVALID, "null learner");
+  HIP_TRY(hipMemcpyAsync(L->tg->flat, L->on->flat, L->on->n_param * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return net_refresh(L->tg, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -22,8 +22,14 @@ def evaluate(weights, num_game, seed, bomb, sad, *, num_player=2, hand_size=5, d
         agent = R2D2Agent(weights.online, weights.online, 1, 0.99)
     elif hasattr(weights, "act") and hasattr(weights, "get_h0"):
         agent = weights                      # any acting agent (obl.OBLAgent, rela.ContractAgent): used as it is
+    elif hasattr(weights, "trunk"):
+        agent = R2D2Agent(weights, weights, 1, 0.99)
+    elif precision == "bf16":
+        from .composite import CNet, CompositeAgent
+        net = CNet(weights, device)
+        agent = CompositeAgent(net, net, 1, 0.99)
     else:
-        net = weights if hasattr(weights, "trunk") else R2D2NetKernels.make(weights, device, precision)
+        net = R2D2NetKernels.make(weights, device, precision)
         agent = R2D2Agent(net, net, 1, 0.99)
     N = num_game * num_player
     hid = agent.get_h0(N)

@@ -199,7 +199,7 @@ class HanabiThreadLoop:
                 elif getattr(ag, "device_agent", False):
                     pass
                 elif ag.target is not ag.online:
-                    ag = R2D2Agent(ag.online, ag.online, 1, 0.99)       # evaluation only ever calls `act`
+                    ag = type(ag)(ag.online, ag.online, 1, 0.99)        # evaluation only ever calls `act`
                 self.agents.append(ag)
             rows = self.env.G * P if self.same_model else self.env.G
             self.hids = [ag.get_h0(rows) for ag in self.agents]

@@ -214,7 +214,8 @@ class BatchRunner:
                     self.model.load_state_dict(py_model.state_dict())
                 return
             if self.online is None:
-                self.online, self.target = R2D2NetKernels(on, self.device), R2D2NetKernels(tg, self.device)
+                from .composite import CNet
+                self.online, self.target = CNet(on, self.device), CNet(tg, self.device)    # library-owned nets (composite ABI)
                 return
             for net, sd in ((self.online, on), (self.target, tg)):
                 for k, v in sd.items():
@@ -233,8 +234,8 @@ class BatchRunner:
             return self.agent_obj
         if self.model is not None:
             return ContractAgent(self.model, self.device, multi_step, gamma)
-        from .r2d2 import R2D2Agent
-        return R2D2Agent(self.online, self.target, multi_step, gamma, seed=seed)
+        from .composite import CompositeAgent
+        return CompositeAgent(self.online, self.target, multi_step, gamma, seed=seed)
 
 
 class R2D2Actor:

@@ -58,13 +58,23 @@ class Trainer:
                                     device=device, track_deck_history=False)
         W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed)
         # only the learner rank holds optimizer state; actor ranks receive parameters by broadcast
-        self.learner = R2D2Learner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
-                                   device=device, precision=args.precision) if rank == 0 else None
-        # the actors run their own copies of the agent, refreshed every actor_sync_freq updates
-        # (ActGroup.update_model / BatchRunner::updateModel, create.py:143-145)
-        self.act_online = R2D2NetKernels.make(W, device, args.precision)
-        self.act_target = R2D2NetKernels.make(W, device, args.precision)
-        self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
+        # bf16 (production): agent and learner are the library's composite entry points (include/hsad.h hsad_r2d2_*: the whole
+        # kernel schedule behind one C call each); fp32 (exact mode): the same schedule orchestrated from r2d2.py / r2d2_f32.py
+        composite = args.precision == "bf16" and not getattr(args, "python_schedule", 0)
+        if composite:
+            from .composite import CNet, CompositeAgent, CompositeLearner
+            self.learner = CompositeLearner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
+                                            device=device) if rank == 0 else None
+            self.act_online, self.act_target = CNet(W, device), CNet(W, device)
+            self.agent = CompositeAgent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
+        else:
+            self.learner = R2D2Learner(W, W, args.multi_step, args.gamma, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip,
+                                       device=device, precision=args.precision) if rank == 0 else None
+            # the actors run their own copies of the agent, refreshed every actor_sync_freq updates
+            # (ActGroup.update_model / BatchRunner::updateModel, create.py:143-145)
+            self.act_online = R2D2NetKernels.make(W, device, args.precision)
+            self.act_target = R2D2NetKernels.make(W, device, args.precision)
+            self.agent = R2D2Agent(self.act_online, self.act_target, args.multi_step, args.gamma, seed=args.seed + 17 * rank)
         self.vdn = args.method == "vdn"
         fields = transition_fields(self.env, self.vdn)
         # the reference's capacity is split evenly over the per-GPU shards
@@ -180,6 +190,8 @@ def parse_args(argv=None):
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"],
                    help="bf16 = production kernels (bf16 MFMA operands, fp32 accumulate/state); fp32 = the exact mode (the "
                         "reference's arithmetic type, for validation: ~20x slower)")
+    p.add_argument("--python_schedule", type=int, default=0, help="1 = drive the bf16 kernels from r2d2.py instead of the "
+                   "library's composite entry points (same kernels, same order; for A/B tests)")
     p.add_argument("--dist_backend", type=str, default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (smoke runs "
                    "with several ranks sharing a GPU: tensors are staged through host memory)")
     args = p.parse_args(argv)
@@ -219,6 +231,8 @@ def run_epochs(tr, args, rank=0):
             if loss is not None:
                 rows[b, 0], rows[b, 1] = loss, g_norm
         check_sync()
+        if tr.learner is not None and hasattr(tr.learner, "check_sync"):
+            tr.learner.check_sync()
         tr.env.check_errors()
         tr.replay.check_errors()
         if rank != 0:
@@ -233,7 +247,7 @@ def run_epochs(tr, args, rank=0):
         stat.summary(epoch)
         # context.pause() has no counterpart: actors and learner alternate on this GPU, nothing runs while we evaluate
         eval_seed = (9917 + epoch * 999999) % 7777777
-        score, perfect, _, _ = evaluate(tr.learner.online, args.num_eval_game, eval_seed, args.eval_bomb, args.sad,
+        score, perfect, _, _ = evaluate(tr.learner.online.w, args.num_eval_game, eval_seed, args.eval_bomb, args.sad,
                                         num_player=args.num_player, hand_size=args.hand_size, device=str(tr.device))
         saved = False
         if saver is not None:
@@ -303,6 +317,8 @@ def main(argv=None):
     tr.env.check_errors()
     tr.replay.check_errors()
     check_sync()
+    if tr.learner is not None and hasattr(tr.learner, "check_sync"):
+        tr.learner.check_sync()
     # Tachometer definitions (pyhanabi/utils.py:229-240)
     print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt,
                                                              (tr.actor.num_act - acts0) / dt, tr.replay.size()))

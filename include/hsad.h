@@ -411,6 +411,69 @@ int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const fl
                              void* sync_scratch, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * COMPOSITE entry points (csrc/hsad_agent.hip): the agent methods the reference's native side calls through
+ * rela::BatchRunner -- `act`, `compute_priority` (rela/batch_runner.h:74-113, rela/r2d2_actor.h:61-172 ->
+ * pyhanabi/r2d2.py:247-361) -- and the learner step of pyhanabi/selfplay.py:208-244 (R2D2Agent.loss r2d2.py:383-499, backward,
+ * clip_grad_norm_, Adam, sync_target_with_online), each as ONE call on plain pointers.  The library owns the weights (one flat
+ * fp32 vector per net: tensors back to back in the order of hsad_r2d2_param_name = the reference's state_dict names), their bf16
+ * kernel operands and all workspace; a C++ / pybind host needs nothing else to run the agent and the learner.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hsad_r2d2_net hsad_r2d2_net;
+typedef struct hsad_r2d2_learner hsad_r2d2_learner;
+/* R2D2Net(in_dim, hid_dim, out_dim = num_action, 2 LSTM layers, hand_size) (pyhanabi/r2d2.py:22-57).  with_backward = 1: the
+ * learner's online net (keeps transposed operands; never steps single rows), 0: acting / target nets. */
+int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size, int with_backward, int device, hsad_r2d2_net** out);
+void hsad_r2d2_net_destroy(hsad_r2d2_net* net);
+int hsad_r2d2_num_params(void);                 /* 16 tensors */
+const char* hsad_r2d2_param_name(int i);        /* "net.0.weight", ..., "pred.bias" */
+int64_t hsad_r2d2_net_param_count(const hsad_r2d2_net* net);          /* fp32 elements of the flat vector */
+int64_t hsad_r2d2_net_param_offset(const hsad_r2d2_net* net, int i);  /* element offset of tensor i (i = 16: the end) */
+int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* net, int i);
+float* hsad_r2d2_net_params(hsad_r2d2_net* net);                      /* device pointer: write weights here, then refresh */
+int hsad_r2d2_net_refresh(hsad_r2d2_net* net, void* stream);          /* re-derive the bf16 / permuted / transposed operands */
+uint64_t hsad_r2d2_net_version(const hsad_r2d2_net* net);             /* bumped by every refresh */
+/* R2D2Agent.act for N rows (one per (game, player)): priv_s fp32 [N,F], legal_move [N,A], eps [N] (NULL = greedy), hidden state
+ * h0 / c0 fp32 [L,N,H] in, h_out / c_out out (h0_bf16 / h_out_bf16, optional: the bf16 copy the fused cell kernels read / write
+ * anyway, carried by the caller to save a cast per step) -> a, greedy_a int64 [N].  q_online_a / q_target_greedy (both or
+ * neither): Q_online(s, a) of the pass that picked the action and Q_target(s, greedy_a) from one target-net pass, i.e. what
+ * compute_priority needs from this step.  Exploration: counter-based hash of (seed, row, counter). */
+int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const float* legal_move,
+                  const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
+                  int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
+                  float* q_target_greedy, void* stream);
+/* R2D2Agent.compute_priority (r2d2.py:305-361): |r + bootstrap gamma^n Q_target(s', argmax adv_online(s')) - Q_online(s, a)|.
+ * num_player > 1 = VDN: Q summed over the players of a game; reward / bootstrap / priority are then per game [N / num_player].
+ * next_greedy_a (may be NULL): the argmax when the caller already has it (the act() of the same iteration). */
+int hsad_r2d2_compute_priority(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, int num_player, const float* priv_s,
+                               const float* legal_move, const int64_t* a, const float* next_priv_s, const float* next_legal_move,
+                               const float* h0, const float* c0, const float* next_h0, const float* next_c0, const float* reward,
+                               const float* bootstrap, int multi_step, double gamma, const int64_t* next_greedy_a, float* priority,
+                               void* stream);
+/* Q_net(s, action) fp32 [N] for one step from the carried hidden state: the single pass compute_priority is built from (an actor
+ * redoes Q_online(s_{t-n}, a_{t-n}) with it when the weights were synced inside the n-step window) */
+int hsad_r2d2_q_of(hsad_r2d2_net* net, int N, const float* priv_s, const float* legal_move, const int64_t* action, const float* h0,
+                   const float* c0, float* qa, void* stream);
+/* learner over batches of T steps x rows_per_step rows (rows = batch size, x num_player for VDN); nets stay owned by the caller */
+int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T, int rows_per_step, int multi_step, double gamma,
+                             float lr, float eps, float grad_clip, hsad_r2d2_learner** out);
+void hsad_r2d2_learner_destroy(hsad_r2d2_learner* learner);
+int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int wgrad_split);
+float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
+int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
+/* R2D2Agent.loss forward: priv_s [T,rows,F], legal_move [T,rows,A], a int64 [T,rows], own_hand [T,rows,3*hand] (NULL without the
+ * aux task); reward / bootstrap [T,B], seq_len / weight [B] with B = rows / num_player games -> loss [B], priority [T,B].
+ * want_grad keeps what loss_bwd needs (weight required). */
+int hsad_r2d2_loss_fwd(hsad_r2d2_learner* learner, const float* priv_s, const float* legal_move, const int64_t* a, const float* reward,
+                       const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
+                       float pred_weight, float* loss, float* priority, int want_grad, void* stream);
+/* (loss * weight).mean().backward(): BPTT into hsad_r2d2_learner_grad; the batch given to loss_fwd must still be alive */
+int hsad_r2d2_loss_bwd(hsad_r2d2_learner* learner, void* stream);
+/* clip_grad_norm_ + Adam.step + operand refresh; grad_norm_sq_dev (may be NULL) receives a device pointer to the squared
+ * pre-clip gradient norm */
+int hsad_r2d2_optimizer_step(hsad_r2d2_learner* learner, float beta1, float beta2, float** grad_norm_sq_dev, void* stream);
+int hsad_r2d2_sync_target_with_online(hsad_r2d2_learner* learner, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp32-EXACT mode of the R2D2 network (csrc/hsad_r2d2_f32.hip): the reference's arithmetic type throughout
  * (pyhanabi/r2d2.py:42-57,99-131,383-499) on v_mfma_f32_32x32x2_f32 (bitwise a k-ordered fmaf chain) with libm-accurate
  * activations -- the mode the golden vectors are matched in at fp32 round-off, and the yardstick the bf16 path's stated

@@ -151,7 +151,7 @@ def test_device_actor_loop_equals_oracle_env_plus_reference_buffers(method, play
 def test_batched_eval_scores_equal_the_oracle_under_the_same_greedy_actions(players, hand, sad, bomb):
     """eval.evaluate (all games in lock-step, finished games parked) vs pyhanabi/eval.py semantics on oracle games"""
     import hanabi_sad_amd.eval as ev
-    from hanabi_sad_amd.r2d2 import R2D2Agent
+    from hanabi_sad_amd.composite import CompositeAgent as R2D2Agent      # the agent evaluate() builds (composite C ABI)
     from hanabi_sad_amd.selfplay import init_weights
     G, SEED = 64, 777
     probe = OracleEnv(players=players, hand_size=hand, seed=1, sad=sad, max_len=-1)
