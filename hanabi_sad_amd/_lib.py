@@ -85,6 +85,11 @@ SIGNATURES = {
     "hsad_replay_size": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hsad_replay_get": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P]),
     "hsad_replay_last_ids": (C.c_int, [_P, _P, C.c_int, _P]),
+    "hsad_replay_set_outstanding": (C.c_int, [_P, C.c_int]),
+    "hsad_replay_set_field_output": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "hsad_replay_row_bytes": (C.c_int, [_P]),
+    "hsad_replay_field_bytes": (C.c_int, [_P, C.c_int]),
+    "hsad_seqwriter_set_prepacked": (C.c_int, [_P, C.c_uint32]),
     "hsad_replay_error_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "hsad_seqwriter_create": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(Field), C.c_int,
                                         C.POINTER(_P)]),

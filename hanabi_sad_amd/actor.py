@@ -11,7 +11,7 @@ import torch
 
 from .env import BatchedHanabiEnv
 from .r2d2 import R2D2Agent, zero_hidden_rows
-from .replay import DeviceReplay, SequenceWriter
+from .replay import Bits, DeviceReplay, SequenceWriter
 
 
 def transition_fields(env, vdn=False):
@@ -19,8 +19,12 @@ def transition_fields(env, vdn=False):
     (cpp/hanabi_env.cc:197-204; pyhanabi/r2d2.py:296-303).  IQL: one transition per (game, player); VDN: one per
     game with the players' rows concatenated ([P, w] flattened)."""
     m = env.P if vdn else 1
-    return [("priv_s", m * env.F, torch.float32), ("legal_move", m * env.A, torch.float32), ("eps", m, torch.float32),
-            ("own_hand", m * 3 * env.H, torch.float32), ("a", m, torch.int64), ("greedy_a", m, torch.int64)]
+    # every plane of the observation, the legal-move mask and the own-hand target are 0/1: stored as bits (32x less HBM per
+    # stored step and per sampled batch).  The V0-belief encoding (knowledge_mode 1) holds count ratios and stays float32.
+    binary = Bits(m)
+    obs_dt = binary if getattr(env, "knowledge_mode", 0) == 0 else torch.float32
+    return [("priv_s", m * env.F, obs_dt), ("legal_move", m * env.A, binary), ("eps", m, torch.float32),
+            ("own_hand", m * 3 * env.H, binary), ("a", m, torch.int64), ("greedy_a", m, torch.int64)]
 
 
 class DeviceActor:

@@ -15,6 +15,7 @@
 // std::uniform_real_distribution<float> the reference uses.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -33,6 +34,7 @@ namespace {
 
 constexpr int kMaxFields = 16;
 constexpr int kMaxBatch = 1024;
+constexpr int kMaxOutstanding = 4;  // = the size of ReplayCtl::q_n
 
 int rfail(int code, const char* fmt, ...) {
   char buf[512];
@@ -53,23 +55,33 @@ int rfail(int code, const char* fmt, ...) {
 struct RowLayout {
   int n_fields;
   int width[kMaxFields];
-  int esize[kMaxFields];
+  int esize[kMaxFields];   // bytes per element; 0 for a bit field
+  int nseg[kMaxFields];    // bit field: equal segments (e.g. the players of a VDN row), each starting on a 64-bit word
+  int nbytes[kMaxFields];  // bytes the field takes in a stored row
   int offset[kMaxFields];  // byte offset inside the row (8-byte aligned)
   int row_bytes;           // multiple of 16
 };
 
+// A bit field (HSAD_BITS) holds values that are exactly 0.0f or 1.0f at the API -- every Hanabi observation plane is
+// (cpp/hanabi_env.cc:115-205 on the canonical encoder) -- as one bit each: 32x less HBM per stored step and per sampled
+// batch.  dtype = HSAD_BITS | (segments << 8).
 int make_layout(int n_fields, const hsad_field* f, RowLayout* L) {
   if (n_fields < 1 || n_fields > kMaxFields) return rfail(HSAD_ERR_INVALID, "n_fields must be 1..%d", kMaxFields);
   L->n_fields = n_fields;
   int off = 0;
   for (int k = 0; k < n_fields; ++k) {
     if (f[k].width < 1) return rfail(HSAD_ERR_INVALID, "field %d has width %d", k, f[k].width);
-    int es = f[k].dtype == HSAD_F32 ? 4 : (f[k].dtype == HSAD_I64 ? 8 : (f[k].dtype == HSAD_U8 ? 1 : 0));
-    if (!es) return rfail(HSAD_ERR_INVALID, "field %d has unknown dtype %d", k, f[k].dtype);
+    const int kind = f[k].dtype & 0xff, seg = (f[k].dtype >> 8) ? (f[k].dtype >> 8) : 1;
+    int es = kind == HSAD_F32 ? 4 : (kind == HSAD_I64 ? 8 : (kind == HSAD_U8 ? 1 : 0));
+    if (!es && kind != HSAD_BITS) return rfail(HSAD_ERR_INVALID, "field %d has unknown dtype %d", k, f[k].dtype);
+    if (kind != HSAD_BITS && (f[k].dtype >> 8)) return rfail(HSAD_ERR_INVALID, "field %d: segments only apply to bit fields", k);
+    if (f[k].width % seg) return rfail(HSAD_ERR_INVALID, "field %d: width %d is not a multiple of its %d segments", k, f[k].width, seg);
     L->width[k] = f[k].width;
     L->esize[k] = es;
+    L->nseg[k] = seg;
+    L->nbytes[k] = es ? f[k].width * es : seg * ((f[k].width / seg + 63) / 64) * 8;
     L->offset[k] = off;
-    off += (f[k].width * es + 7) & ~7;
+    off += (L->nbytes[k] + 7) & ~7;
   }
   L->row_bytes = (off + 15) & ~15;
   return HSAD_OK;
@@ -77,9 +89,6 @@ int make_layout(int n_fields, const hsad_field* f, RowLayout* L) {
 
 struct FieldPtrs {
   const void* p[kMaxFields];
-};
-struct FieldPtrsMut {
-  void* p[kMaxFields];
 };
 
 // One WAVEFRONT per row (4 rows per 256-thread block).  src element (i, t) of field k lives at ((i*src_T + t) * width_k);
@@ -109,11 +118,44 @@ __device__ __forceinline__ void copy_bytes_wave(unsigned char* d, const unsigned
   else copy_words_wave<unsigned char>(d, s, nbytes, lane, zero);
 }
 
+// float 0/1 values -> bits, one wavefront per row: 64 values per ballot.  A value that is neither is counted in *err.
+__device__ __forceinline__ void pack_bits_wave(unsigned char* d, const float* s, int w, int nseg, int lane, int* err) {
+  const int sw = w / nseg, words = (sw + 63) / 64;
+  unsigned long long* dw = reinterpret_cast<unsigned long long*>(d);
+  bool bad = false;
+  for (int g = 0; g < nseg; ++g)
+    for (int c = 0; c < words; ++c) {
+      const int j = c * 64 + lane;
+      const float v = j < sw ? s[g * sw + j] : 0.f;
+      bad |= (v != 0.f) & (v != 1.f);
+      const unsigned long long m = __ballot(v != 0.f);
+      if (lane == 0) dw[g * words + c] = m;
+    }
+  if (__ballot(bad) && lane == 0 && err) atomicAdd(err, 1);
+}
+
+// bits -> float32 [nseg][w/nseg] (ld = w/nseg) or bf16 [nseg][ld], ld >= w/nseg with the tail of each segment zero-filled
+template <typename OUT>
+__device__ __forceinline__ void unpack_bits_wave(OUT* d, const unsigned char* s, int w, int nseg, int ld, int lane, bool zero) {
+  const int sw = w / nseg, words = (sw + 63) / 64;
+  const unsigned long long* sw64 = reinterpret_cast<const unsigned long long*>(s);
+  for (int g = 0; g < nseg; ++g) {
+    for (int c = 0; c < words; ++c) {
+      const int j = c * 64 + lane;
+      if (j >= sw) break;
+      const unsigned long long m = zero ? 0ull : sw64[g * words + c];
+      d[(size_t)g * ld + j] = (OUT)(float)((m >> lane) & 1ull);
+    }
+    for (int j = sw + lane; j < ld; j += 64) d[(size_t)g * ld + j] = (OUT)0.f;
+  }
+}
+
 // fields [n][T][w]  ->  rows[(slot0 + i) % ring][t]     (replay add)
 // fields [E][w] (T=1) -> rows[base_row + e]             (history ring push)
+// prepacked: bit k set = field k's source already is in the stored format (bit words written by the env kernel)
 __global__ __launch_bounds__(256) void pack_rows_kernel(RowLayout L, FieldPtrs src, unsigned char* rows, int n, int T, int map,
                                                         int slot0, int ring, const int* __restrict__ n_dev,
-                                                        const int* __restrict__ slot0_dev) {
+                                                        const int* __restrict__ slot0_dev, unsigned prepacked, int* err) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= n * T) return;
   const int i = row / T, t = row - i * T;
@@ -122,14 +164,37 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(RowLayout L, FieldPtrs s
   const size_t dst_row = (map == MAP_RING) ? ((size_t)((s0 + i) % ring) * T + t) : ((size_t)s0 + row);
   unsigned char* dst = rows + dst_row * L.row_bytes;
   for (int k = 0; k < L.n_fields; ++k) {
-    const int nbytes = L.width[k] * L.esize[k];
+    if (L.esize[k] == 0 && !((prepacked >> k) & 1u)) {
+      pack_bits_wave(dst + L.offset[k], static_cast<const float*>(src.p[k]) + (size_t)row * L.width[k], L.width[k], L.nseg[k], lane,
+                     err);
+      continue;
+    }
+    const int nbytes = L.nbytes[k];
     copy_bytes_wave(dst + L.offset[k], static_cast<const unsigned char*>(src.p[k]) + (size_t)row * nbytes, nbytes, lane, false);
   }
 }
 
+// what the caller wants a bit field unpacked to (FieldOut::kind); other fields are always copied as stored
+enum BitsOut : int { BITS_F32 = 0, BITS_BF16 = 1, BITS_RAW = 2 };
+struct FieldOut {
+  void* p[kMaxFields];
+  int kind[kMaxFields];
+  int ld[kMaxFields];  // BITS_BF16: elements per output row (>= width, the rest is zero-filled)
+};
+
+inline FieldOut field_out(const RowLayout& L, void* const* ptrs, const int* kind = nullptr, const int* ld = nullptr) {
+  FieldOut fo;
+  for (int k = 0; k < kMaxFields; ++k) {
+    fo.p[k] = k < L.n_fields ? ptrs[k] : nullptr;
+    fo.kind[k] = (kind && k < L.n_fields) ? kind[k] : (int)BITS_F32;
+    fo.ld[k] = (ld && k < L.n_fields) ? ld[k] : 0;
+  }
+  return fo;
+}
+
 // rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
 // or, with ids == nullptr, row index base_row + b (T must be 1 then) .
-__global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldPtrsMut dst, int B, int T,
+__global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldOut dst, int B, int T,
                                                           const int* __restrict__ ids, int base_row,
                                                           const int* __restrict__ valid_rows = nullptr) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // = t*B + b
@@ -140,8 +205,16 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const uns
   const unsigned char* s = rows + src_row * L.row_bytes;
   for (int k = 0; k < L.n_fields; ++k) {
     if (!dst.p[k]) continue;
-    const int nbytes = L.width[k] * L.esize[k];
-    copy_bytes_wave(static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes, s + L.offset[k], nbytes, lane, pad);
+    if (L.esize[k] == 0 && dst.kind[k] == BITS_F32) {
+      unpack_bits_wave(static_cast<float*>(dst.p[k]) + (size_t)row * L.width[k], s + L.offset[k], L.width[k], L.nseg[k],
+                       L.width[k] / L.nseg[k], lane, pad);
+    } else if (L.esize[k] == 0 && dst.kind[k] == BITS_BF16) {
+      unpack_bits_wave(static_cast<__hip_bfloat16*>(dst.p[k]) + (size_t)row * L.nseg[k] * dst.ld[k], s + L.offset[k], L.width[k],
+                       L.nseg[k], dst.ld[k], lane, pad);
+    } else {
+      const int nbytes = L.nbytes[k];
+      copy_bytes_wave(static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes, s + L.offset[k], nbytes, lane, pad);
+    }
   }
 }
 
@@ -169,20 +242,30 @@ struct ReplayCtl {
   int n_sampled, err;
   int add_start, add_n;  // slot range of the add in flight (consumed by the payload copy kernels)
   int size_before_pop, pad;
+  // drawn batches whose priorities have not come back yet, oldest first (the reference's prefetch queue hands out up to
+  // `prefetch` batches drawn before the priorities of the batches in training are written back: prioritized_replay.h:232-262)
+  int q_head, q_count;
+  int q_n[4];
 };
 
 struct ReplayDev {
   ReplayCtl* ctl;
   float* weights;
   unsigned char* evicted;
-  int* sampled_ids;
+  int* sampled_ids;  // ids of the LATEST draw (gather kernels, hsad_replay_last_ids)
+  int* q_ids;        // [depth][kMaxBatch] ids of the outstanding draws
   float* sampled_w;
   int* valid_rows;   // [ring] steps of the slot's sequence that are stored; readers materialise the reference's padding
                      // (zeros, terminal = 1, bootstrap = 0) for the steps after them.  T for hsad_replay_add, the episode
                      // length for sequences flushed by the sequence writer (which therefore never writes padding)
   int ring, capacity;
+  int depth;  // outstanding draws kept (1 = the strict sample / update alternation)
   float alpha, beta;
 };
+
+// priority^alpha.  std::pow(x, 1.0f) returns x exactly on the host; the device powf is only accurate to an ulp, so alpha = 1
+// is taken literally (keeps dyadic test priorities and the running sum exact)
+__device__ __forceinline__ float prio_weight(float p, float alpha) { return alpha == 1.f ? p : powf(p, alpha); }
 
 // PrioritizedReplay::add bookkeeping (ConcurrentQueue::blockAppend): weights = priority^alpha stored at
 // tail.., sequential float block sum added to the running double, tail/size/num_add advanced.
@@ -223,7 +306,7 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
     const int m = min(4096, cnt - base);
     __syncthreads();
     for (int i = tid; i < m; i += 256) {
-      const float w = powf(priority[base + i], rd.alpha);
+      const float w = prio_weight(priority[base + i], rd.alpha);
       rd.weights[(c.tail + base + i) % rd.ring] = w;
       s_w[i] = w;
     }
@@ -289,6 +372,9 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   const int N = c.size, head = c.head, ring = rd.ring;
   const float sum = (float)c.sum;
   const float segment = sum / (B > 0 ? B : 1);
+  // queue slot of this draw; a draw into a full queue replaces the newest entry (depth 1: the draw before it)
+  const int q_full = c.q_count >= rd.depth;
+  const int q_slot = (c.q_head + (q_full ? c.q_count - 1 : c.q_count)) % rd.depth;
   if (tid < B) {
     if (targets) {
       s_rand[tid] = fminf(fmaxf(targets[tid], 0.f), sum * (1.f - 1e-6f));
@@ -345,6 +431,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     s_id[tid] = id;
     s_w[tid] = w;
     rd.sampled_ids[tid] = id;
+    rd.q_ids[q_slot * kMaxBatch + tid] = id;
     rd.sampled_w[tid] = w;
     rd.evicted[id] = 0;  // getElementAndMark
   }
@@ -380,6 +467,8 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     cc.head = (head + npop) % ring;
     cc.size = N - npop;
     cc.n_sampled = B;
+    cc.q_n[q_slot] = B;
+    if (!q_full) cc.q_count += 1;
     cc.size_before_pop = N;
     *rd.ctl = cc;
   }
@@ -399,20 +488,26 @@ __global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B
   __shared__ unsigned char s_live[kMaxBatch];
   const int tid = threadIdx.x;
   ReplayCtl c = *rd.ctl;
-  if (B == 0 || c.n_sampled != B) {
+  const int have = c.q_count > 0 ? c.q_n[c.q_head] : 0;   // the OLDEST outstanding draw is the one being answered
+  if (B == 0 || have != B) {
     if (tid == 0) {
-      if (B != 0) c.err += 1;
-      else c.n_sampled = 0;
+      if (have != B) c.err += 1;
+      else if (c.q_count > 0) {  // an empty draw (a shard without quota) is answered by an empty update
+        c.q_head = (c.q_head + 1) % rd.depth;
+        c.q_count -= 1;
+      }
+      if (c.q_count == 0) c.n_sampled = 0;
       *rd.ctl = c;
     }
     return;
   }
+  const int* q_ids = rd.q_ids + c.q_head * kMaxBatch;
   float old = 0.f;
   if (tid < B) {
-    const int id = rd.sampled_ids[tid];
+    const int id = q_ids[tid];
     s_id[tid] = id;
     s_live[tid] = !rd.evicted[id];
-    s_w[tid] = powf(priority[tid], rd.alpha);
+    s_w[tid] = prio_weight(priority[tid], rd.alpha);
     old = rd.weights[id];
   }
   __syncthreads();
@@ -438,7 +533,9 @@ __global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B
     for (int i = 0; i < B; ++i)
       if (s_live[i]) diff += s_diff[i];
     c.sum += diff;
-    c.n_sampled = 0;
+    c.q_head = (c.q_head + 1) % rd.depth;
+    c.q_count -= 1;
+    if (c.q_count == 0) c.n_sampled = 0;
     *rd.ctl = c;
   }
 }
@@ -639,8 +736,12 @@ __global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDe
   }
 }
 
-__global__ void seq_reset_finished_kernel(SeqDev sd, const ReplayCtl* ctl) {
+__global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0 && *w_err) {  // contract violations logged by the writer (push past seq_len, a non-binary value in a bit field)
+    atomicAdd(&ctl->err, *w_err);   // surface through the replay's error count, which the drivers poll
+    *w_err = 0;
+  }
   if (k >= sd.n_fin[0]) return;
   // sequences the replay refused (ring full) are dropped with an error already logged there
   const int e = sd.fin_env[k];
@@ -668,6 +769,8 @@ struct hsad_replay {
   hipEvent_t canon_ev[kCanonSlots] = {};
   int canon_next = 0;
   int* d_tmp_id;
+  int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
+  int out_ld[kMaxFields] = {};
   std::mt19937 rng;
   hipStream_t last_stream;
   int64_t bytes;
@@ -680,6 +783,7 @@ struct hsad_seqwriter {
   int head, count, rt_count;  // deque state of the n+1 history (host side: it advances deterministically)
   int pend_slot;              // history slot of the transition popped last (valid until the next push)
   bool pending;
+  unsigned prepacked = 0;     // bit fields whose push_obs_action source already is bit words (hsad_seqwriter_set_prepacked)
   int* d_err;
   int64_t bytes;
 };
@@ -719,6 +823,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
   rd.ring = (int)(1.25 * capacity);
   if (rd.ring < 1) rd.ring = 1;
   rd.capacity = capacity;
+  rd.depth = 1;
   rd.alpha = alpha;
   rd.beta = beta;
   const size_t ring = rd.ring, T = seq_len;
@@ -737,6 +842,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
       (he = alloc((void**)&rd.evicted, ring)) != hipSuccess ||
       (he = alloc((void**)&rd.ctl, sizeof(ReplayCtl))) != hipSuccess ||
       (he = alloc((void**)&rd.sampled_ids, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&rd.q_ids, kMaxOutstanding * kMaxBatch * 4)) != hipSuccess ||
       (he = alloc((void**)&rd.sampled_w, kMaxBatch * 4)) != hipSuccess ||
       (he = alloc((void**)&rd.valid_rows, ring * 4)) != hipSuccess ||
       (he = alloc((void**)&r->d_canon, kMaxBatch * 4)) != hipSuccess ||
@@ -766,7 +872,7 @@ void hsad_replay_destroy(hsad_replay* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   void* ptrs[] = {r->rows, r->reward, r->terminal, r->bootstrap, r->seq_len, r->rd.weights, r->rd.evicted, r->rd.ctl,
-                  r->rd.sampled_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id};
+                  r->rd.sampled_ids, r->rd.q_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : r->canon_ev)
@@ -802,7 +908,7 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
   // payload rows; add_n (<= n) from the control block bounds the copy
   hipLaunchKernelGGL(pack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, fp, r->rows, n, r->T, (int)MAP_RING, 0,
-                     r->rd.ring, &r->rd.ctl->add_n, &r->rd.ctl->add_start);
+                     r->rd.ring, &r->rd.ctl->add_n, &r->rd.ctl->add_start, 0u, &r->rd.ctl->err);
   hipLaunchKernelGGL(replay_add_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->rd, n, r->T, reward,
                      terminal, bootstrap, seq_len, r->reward, r->terminal, r->bootstrap, r->seq_len);
   HIP_TRY(hipGetLastError());
@@ -823,8 +929,7 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
   HIP_TRY(upload_canon(r, slot, batch, s));
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight);
-  FieldPtrsMut fp;
-  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+  const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
                      r->rd.sampled_ids, 0, r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((batch * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
@@ -866,8 +971,7 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   }
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon);
   if (n > 0) {
-    FieldPtrsMut fp;
-    for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+    const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,
                        r->rd.valid_rows);
     hipLaunchKernelGGL(gather_scalars_kernel, dim3((n * r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
@@ -884,6 +988,35 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
   r->last_stream = (hipStream_t)stream;
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_set_field_output(hsad_replay* r, int field, int kind, int ld) {
+  if (!r || field < 0 || field >= r->L.n_fields) return rfail(HSAD_ERR_INVALID, "bad field index");
+  if (kind != BITS_F32 && r->L.esize[field] != 0) return rfail(HSAD_ERR_INVALID, "field %d is not a bit field", field);
+  const int sw = r->L.width[field] / r->L.nseg[field];
+  if (kind == BITS_BF16 && ld < sw) return rfail(HSAD_ERR_INVALID, "bf16 row length %d is shorter than the field's %d values", ld, sw);
+  if (kind != BITS_F32 && kind != BITS_BF16 && kind != BITS_RAW) return rfail(HSAD_ERR_INVALID, "unknown output kind %d", kind);
+  r->out_kind[field] = kind;
+  r->out_ld[field] = kind == BITS_BF16 ? ld : 0;
+  return HSAD_OK;
+}
+
+int hsad_replay_row_bytes(const hsad_replay* r) { return r ? r->L.row_bytes : 0; }
+int hsad_replay_field_bytes(const hsad_replay* r, int field) {
+  return (r && field >= 0 && field < r->L.n_fields) ? r->L.nbytes[field] : 0;
+}
+
+int hsad_replay_set_outstanding(hsad_replay* r, int depth) {
+  if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
+  if (depth < 1 || depth > kMaxOutstanding) return rfail(HSAD_ERR_INVALID, "outstanding draws must be 1..%d", kMaxOutstanding);
+  HIP_TRY(hipDeviceSynchronize());
+  ReplayCtl c;
+  HIP_TRY(hipMemcpy(&c, r->rd.ctl, sizeof(c), hipMemcpyDeviceToHost));
+  if (c.q_count != 0) return rfail(HSAD_ERR_STATE, "%d drawn batches are waiting for their priorities", c.q_count);
+  c.q_head = 0;
+  HIP_TRY(hipMemcpy(r->rd.ctl, &c, sizeof(c), hipMemcpyHostToDevice));
+  r->rd.depth = depth;
   return HSAD_OK;
 }
 
@@ -911,8 +1044,7 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
   if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
-  FieldPtrsMut fp;
-  for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? out_fields[k] : nullptr;
+  const FieldOut fp = field_out(r->L, out_fields);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
                      r->rd.valid_rows);
   hipLaunchKernelGGL(gather_scalars_kernel, dim3((r->T + 255) / 256), dim3(256), 0, s, r->reward, r->terminal,
@@ -1004,9 +1136,18 @@ int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields,
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? fields[k] : nullptr;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((w->sd.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
-                     w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr);
+                     w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr, w->prepacked, w->d_err);
   HIP_TRY(hipGetLastError());
   w->count += 1;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_set_prepacked(hsad_seqwriter* w, uint32_t field_mask) {
+  if (!w) return rfail(HSAD_ERR_INVALID, "null argument");
+  for (int k = 0; k < 32; ++k)
+    if (((field_mask >> k) & 1u) && (k >= w->L.n_fields || w->L.esize[k] != 0))
+      return rfail(HSAD_ERR_INVALID, "field %d is not a bit field", k);
+  w->prepacked = field_mask;
   return HSAD_OK;
 }
 
@@ -1036,8 +1177,7 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
     void* const* of = pass == 0 ? out_fields : out_next_fields;
     if (!of) continue;
     const int slot = pass == 0 ? w->head : (w->head + sd.n) % sd.depth;
-    FieldPtrsMut fp;
-    for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? of[k] : nullptr;
+    const FieldOut fp = field_out(w->L, of);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((sd.E + 3) / 4), dim3(256), 0, s, w->L, sd.hist_rows, fp, sd.E, 1,
                        (const int*)nullptr, slot * sd.E);
   }
@@ -1073,7 +1213,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
   hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min((sd.E * sd.T + 3) / 4, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);
-  hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl);
+  hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl, w->d_err);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -29,6 +29,7 @@ class BatchedHanabiEnv:
         self.F = L.hsad_env_feature_size(self.h)
         self.A = L.hsad_env_num_action(self.h)
         self.sad = bool(sad)
+        self.knowledge_mode = int(knowledge_mode)
         self.games_per_workgroup = L.hsad_env_games_per_workgroup(self.h)   # kernel shape in use (32 | 64)
         d = self.device
         self.priv_s = torch.zeros(self.G, self.P, self.F, dtype=torch.float32, device=d)

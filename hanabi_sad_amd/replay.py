@@ -16,11 +16,26 @@ _DT = {torch.float32: 0, torch.int64: 1, torch.uint8: 2, torch.bool: 2}
 _TORCH_DT = {0: torch.float32, 1: torch.int64, 2: torch.uint8}
 
 
+class Bits:
+    """field dtype: float32 0.0 / 1.0 values at the API, ONE BIT each in the stored rows (include/hsad.h HSAD_BITS).
+    segments: equal parts of the field that each start on a 64-bit word (the players of a VDN row)"""
+
+    def __init__(self, segments=1):
+        self.segments = int(segments)
+
+    def __repr__(self):
+        return "Bits(%d)" % self.segments
+
+
+def _api_dtype(dt):
+    return torch.float32 if isinstance(dt, Bits) else (torch.uint8 if dt == torch.bool else dt)
+
+
 def _fields_struct(fields):
     arr = (_lib.Field * len(fields))()
     for i, (_, width, dtype) in enumerate(fields):
         arr[i].width = int(width)
-        arr[i].dtype = _DT[dtype]
+        arr[i].dtype = (3 | (dtype.segments << 8)) if isinstance(dtype, Bits) else _DT[dtype]
     return arr
 
 
@@ -57,6 +72,7 @@ class DeviceReplay:
             raise _lib.HsadError("DeviceReplay needs a ROCm device; there is no CPU path")
         self.fields = [(n, int(w), dt) for n, w, dt in fields]
         self.T = int(seq_len)
+        self._out = {}
         self.h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.hsad_replay_create(int(capacity), int(seed), float(alpha), float(beta), int(prefetch),
@@ -80,7 +96,7 @@ class DeviceReplay:
     def _check_field_tensors(self, tensors, lead):
         out = []
         for (name, w, dt), t in zip(self.fields, tensors):
-            want = torch.uint8 if dt == torch.bool else dt
+            want = _api_dtype(dt)
             t = t.to(want) if t.dtype != want else t
             assert t.is_contiguous() and t.device == self.device, name
             assert tuple(t.shape) in (tuple(lead) + (w,), tuple(lead)) or t.numel() == int(torch.tensor(lead).prod()) * w, \
@@ -99,11 +115,30 @@ class DeviceReplay:
                                             seq_len.contiguous().data_ptr(), priority.contiguous().data_ptr(),
                                             None if n_dev is None else n_dev.data_ptr(), _stream(self.device)))
 
+    def set_field_output(self, name, kind, ld=0):
+        """what sample() / sample_at() return for bit field `name`: "f32" [T,B,width] float32 (default) | "bf16" [T,B,segments,ld]
+        bfloat16, zero-padded to ld per segment (the learner's GEMM operand, no cast pass) | "raw" [T,B,bytes] uint8"""
+        k = [n for n, _, _ in self.fields].index(name)
+        code = {"f32": 0, "bf16": 1, "raw": 2}[kind]
+        _lib.check(self.lib.hsad_replay_set_field_output(self.h, k, code, int(ld)))
+        self._out[name] = (kind, int(ld))
+
+    def _alloc_outs(self, n):
+        d, T, outs = self.device, self.T, []
+        for k, (name, w, dt) in enumerate(self.fields):
+            kind, ld = self._out.get(name, ("f32", 0))
+            if kind == "bf16":
+                outs.append(torch.empty(T, n, dt.segments, ld, dtype=torch.bfloat16, device=d))
+            elif kind == "raw":
+                outs.append(torch.empty(T, n, self.lib.hsad_replay_field_bytes(self.h, k), dtype=torch.uint8, device=d))
+            else:
+                outs.append(torch.empty(T, n, w, dtype=_api_dtype(dt), device=d))
+        return outs
+
     def sample(self, batch):
         """-> (dict of fields [T,B,width], reward [T,B], terminal [T,B] bool, bootstrap [T,B], seq_len [B]), weight [B]"""
         d, T = self.device, self.T
-        outs = [torch.empty(T, batch, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d)
-                for _, w, dt in self.fields]
+        outs = self._alloc_outs(batch)
         reward = torch.empty(T, batch, dtype=torch.float32, device=d)
         terminal = torch.empty(T, batch, dtype=torch.uint8, device=d)
         bootstrap = torch.empty(T, batch, dtype=torch.float32, device=d)
@@ -135,7 +170,7 @@ class DeviceReplay:
         import numpy as np
         targets = np.ascontiguousarray(targets, dtype=np.float32)
         n, d, T = int(targets.shape[0]), self.device, self.T
-        outs = [torch.empty(T, n, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d) for _, w, dt in self.fields]
+        outs = self._alloc_outs(n)
         reward = torch.empty(T, n, dtype=torch.float32, device=d)
         terminal = torch.empty(T, n, dtype=torch.uint8, device=d)
         bootstrap = torch.empty(T, n, dtype=torch.float32, device=d)
@@ -165,7 +200,7 @@ class DeviceReplay:
 
     def get(self, idx):
         d, T = self.device, self.T
-        outs = [torch.empty(T, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d) for _, w, dt in self.fields]
+        outs = [torch.empty(T, w, dtype=(_api_dtype(dt)), device=d) for _, w, dt in self.fields]
         reward = torch.empty(T, dtype=torch.float32, device=d)
         terminal = torch.empty(T, dtype=torch.uint8, device=d)
         bootstrap = torch.empty(T, dtype=torch.float32, device=d)
@@ -173,6 +208,11 @@ class DeviceReplay:
         _lib.check(self.lib.hsad_replay_get(self.h, int(idx), _ptr_array(outs), reward.data_ptr(), terminal.data_ptr(),
                                             bootstrap.data_ptr(), seq_len.data_ptr(), _stream(d)))
         return {name: t for (name, _, _), t in zip(self.fields, outs)}, reward, terminal.bool(), bootstrap, seq_len
+
+    def set_outstanding(self, depth):
+        """drawn batches that may wait for their priorities at once (the reference's prefetch queue); update_priority answers
+        the oldest one"""
+        _lib.check(self.lib.hsad_replay_set_outstanding(self.h, int(depth)))
 
     def last_ids(self, batch):
         out = torch.empty(batch, dtype=torch.int32, device=self.device)
@@ -215,7 +255,7 @@ class SequenceWriter:
         ts = []
         for name, w, dt in self.fields:
             t = fields[name]
-            want = torch.uint8 if dt == torch.bool else dt
+            want = _api_dtype(dt)
             t = (t.to(want) if t.dtype != want else t).contiguous()
             assert t.device == self.device and t.numel() == self.E * w, (name, tuple(t.shape))
             ts.append(t)
@@ -234,7 +274,7 @@ class SequenceWriter:
         """-> (obs/action fields of step t, of step t+n, n-step reward, terminal, bootstrap); want_fields / want_next = False
         skip reading the respective rows back from the history ring (None)"""
         d, E = self.device, self.E
-        mk = lambda: [torch.empty(E, w, dtype=(torch.uint8 if dt == torch.bool else dt), device=d)
+        mk = lambda: [torch.empty(E, w, dtype=(_api_dtype(dt)), device=d)
                       for _, w, dt in self.fields]
         cur = mk() if want_fields else None
         nxt = mk() if (want_fields if want_next is None else want_next) else None

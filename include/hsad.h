@@ -170,7 +170,14 @@ int hsad_env_error_count(hsad_env* env, int32_t* count, int32_t* first_game, int
  * action TensorDicts, e.g. priv_s, legal_move, eps, own_hand, a, greedy_a); reward, terminal,
  * bootstrap and seq_len are implicit.  All tensor arguments are device pointers.
  * ------------------------------------------------------------------------------------------ */
-typedef enum { HSAD_F32 = 0, HSAD_I64 = 1, HSAD_U8 = 2 } hsad_dtype;
+/* HSAD_BITS: values that are exactly 0.0f / 1.0f at the API (float32 tensors), stored as ONE BIT each -- every plane of the
+ * Hanabi observation, the legal-move mask and the own-hand target are (cpp/hanabi_env.cc:115-205).  dtype = HSAD_BITS |
+ * (segments << 8): `segments` equal parts (the players of a VDN row), each starting on a 64-bit word.  Storing a value that
+ * is neither 0 nor 1 is counted by hsad_replay_error_count (the sequence writer's count joins it at the next flush). */
+typedef enum { HSAD_F32 = 0, HSAD_I64 = 1, HSAD_U8 = 2, HSAD_BITS = 3 } hsad_dtype;
+/* what hsad_replay_sample writes for a bit field: float32 [width] | bf16 [segments][ld] zero-padded (the learner's GEMM operand,
+ * no cast pass) | the stored 64-bit words */
+typedef enum { HSAD_BITS_AS_F32 = 0, HSAD_BITS_AS_BF16 = 1, HSAD_BITS_AS_RAW = 2 } hsad_bits_out;
 typedef struct hsad_field {
   int32_t width; /* elements per step (per env)          */
   int32_t dtype; /* hsad_dtype                            */
@@ -226,6 +233,16 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
                     float* bootstrap, float* seq_len, void* stream);
 /* physical ring slots of the last sample (device int32 [batch]); debugging / tests */
 int hsad_replay_last_ids(hsad_replay* r, int32_t* out, int batch, void* stream);
+/* Drawn batches that may wait for their priorities at once (1..4, default 1 = strict alternation).  The reference's
+ * prefetch queue (prioritized_replay.h:232-262, prefetch = 3 in selfplay.py) draws up to `prefetch` batches before the
+ * priorities of the batches in training are written back; with depth k, hsad_replay_update_priority answers the OLDEST
+ * outstanding draw, and elements evicted since their draw are skipped as in ConcurrentQueue::update.  A draw into a full
+ * queue replaces the newest entry.  HSAD_ERR_STATE while draws are outstanding. */
+int hsad_replay_set_outstanding(hsad_replay* r, int depth);
+/* Output format of bit field `field` in hsad_replay_sample / _sample_at (hsad_bits_out; ld = bf16 elements per segment row). */
+int hsad_replay_set_field_output(hsad_replay* r, int field, int kind, int ld);
+int hsad_replay_row_bytes(const hsad_replay* r);              /* bytes of one stored step                     */
+int hsad_replay_field_bytes(const hsad_replay* r, int field); /* bytes of field `field` inside a stored step  */
 int hsad_replay_error_count(hsad_replay* r, int32_t* count);
 
 typedef struct hsad_seqwriter hsad_seqwriter;
@@ -236,6 +253,9 @@ int hsad_seqwriter_create(int num_envs, int multi_step, float gamma, int seq_len
 void hsad_seqwriter_destroy(hsad_seqwriter* w);
 /* MultiStepBuffer::pushObsAndAction: fields[k] -> [E, width_k] of the current step */
 int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields, void* stream);
+/* Bit fields in `field_mask` arrive in hsad_seqwriter_push_obs_action already as bit words (the stored format: per segment
+ * ceil(width / segments / 64) uint64, LSB first) -- what hsad_env_bind_packed makes the env kernel write. */
+int hsad_seqwriter_set_prepacked(hsad_seqwriter* w, uint32_t field_mask);
 /* MultiStepBuffer::pushRewardAndTerminal: reward float32 [E], terminal uint8 [E] */
 int hsad_seqwriter_push_reward_terminal(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, void* stream);
 /* MultiStepBuffer::canPop (host-side count, no synchronisation) */

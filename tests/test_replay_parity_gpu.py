@@ -34,11 +34,13 @@ def test_aggregate_priority_matches_reference():
         assert np.allclose(got, R.aggregate_priority(p, sl, 0.9), rtol=RTOL, atol=0)
 
 
-def random_stream(rng, E, d, T, steps, p_term=0.12):
+def random_stream(rng, E, d, T, steps, p_term=0.12, binary=False):
     """obs/action/reward/terminal per step with random episode ends; episodes never exceed T steps."""
     age = np.zeros(E, np.int64)
     for _ in range(steps):
         obs = rng.standard_normal((E, d)).astype(np.float32)
+        if binary:
+            obs = (obs > 0.3).astype(np.float32)
         a = rng.integers(0, 21, E).astype(np.int64)
         r = rng.integers(0, 2, E).astype(np.float32) * rng.random(E).astype(np.float32)
         age += 1
@@ -50,7 +52,7 @@ def random_stream(rng, E, d, T, steps, p_term=0.12):
 FLOW_CASES = [(37, 11, 3, 20, 0.999), (5, 3, 1, 6, 0.9), (130, 40, 5, 80, 0.99)]
 
 
-def drive_actor_flow(E, d, n, T, gamma, with_device):
+def drive_actor_flow(E, d, n, T, gamma, with_device, bits=0):
     """The R2D2Actor::postAct data path (r2d2_actor.h:103-172) driven with identical random streams through the
     reference classes and (with_device) the HIP implementation.  The replay is sized so that the reference's
     blocking blockAppend can never trigger: cap >= 4*E and a sample/update pair follows any add that fills it."""
@@ -58,6 +60,9 @@ def drive_actor_flow(E, d, n, T, gamma, with_device):
     eta, alpha, beta, B = 0.9, 0.9, 0.6, 16
     cap = max(64, 4 * E + 8)
     fields = [("s", d, torch.float32), ("a", 1, torch.int64)]
+    if bits:   # the observation as a bit field of `bits` segments: same tensors at the API, 1 bit per value in HBM
+        from hanabi_sad_amd.replay import Bits
+        fields[0] = ("s", d, Bits(bits))
     msb = R.MultiStepBuffer(n, E, gamma, d)
     buf = R.R2D2Buffer(E, 1, n, T, d)
     ref = R.Replay(cap, 7, alpha, beta, T, d)
@@ -66,7 +71,7 @@ def drive_actor_flow(E, d, n, T, gamma, with_device):
         w = SequenceWriter(E, n, gamma, T, fields, DEV)
         rep = DeviceReplay(cap, 7, alpha, beta, 0, T, fields, DEV)
     n_flush = n_samples = step = 0
-    for obs, a, r, t in random_stream(rng, E, d, T, 400 if E < 100 else 260):
+    for obs, a, r, t in random_stream(rng, E, d, T, 400 if E < 100 else 260, binary=bool(bits)):
         step += 1
         msb.push_obs_action(obs, a)
         msb.push_reward_terminal(r, t)
@@ -129,6 +134,52 @@ def drive_actor_flow(E, d, n, T, gamma, with_device):
 @pytest.mark.parametrize("E,d,n,T,gamma", FLOW_CASES)
 def test_sequence_writer_and_replay_flow_matches_reference(E, d, n, T, gamma):
     drive_actor_flow(E, d, n, T, gamma, with_device=True)
+
+
+@pytest.mark.parametrize("E,d,n,T,gamma,seg", [(37, 11, 3, 20, 0.999, 1), (5, 130, 1, 6, 0.9, 2), (130, 838, 5, 80, 0.99, 1),
+                                               (33, 3 * 658, 3, 12, 0.99, 3)])
+def test_bit_packed_observation_rows_match_reference(E, d, n, T, gamma, seg):
+    """HSAD_BITS fields: the same flow with 0/1 observations stored one bit per value (widths that are not multiples of 64,
+    segmented rows as VDN uses them) -- every tensor that comes back out is still bit-equal to the reference's"""
+    drive_actor_flow(E, d, n, T, gamma, with_device=True, bits=seg)
+
+
+def test_bit_field_outputs_and_validation():
+    """sample() formats of a bit field (float32 / zero-padded bf16 per segment / stored words) agree with each other, and a
+    value that is neither 0 nor 1 is reported instead of being silently rounded"""
+    from hanabi_sad_amd import HsadError
+    from hanabi_sad_amd.replay import Bits, DeviceReplay
+    rng = np.random.default_rng(3)
+    T, P, F, n, B = 6, 2, 70, 40, 16
+    fields = [("s", P * F, Bits(P)), ("x", 5, torch.float32)]
+    reps = [DeviceReplay(64, 5, 0.9, 0.6, 0, T, fields, DEV) for _ in range(3)]
+    reps[1].set_field_output("s", "bf16", 96)
+    reps[2].set_field_output("s", "raw")
+    obs = (rng.random((n, T, P * F)) < 0.4).astype(np.float32)
+    x = rng.standard_normal((n, T, 5)).astype(np.float32)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    sl = rng.integers(1, T + 1, n).astype(np.float32)
+    for r in reps:
+        r.add({"s": dev(obs), "x": dev(x)}, z(n, T), z(n, T).to(torch.uint8), z(n, T), dev(sl), z(n) + 1)
+    outs = [r.sample(B)[0][0] for r in reps]
+    ids = reps[0].last_ids(B).cpu().numpy()
+    want = np.transpose(obs[ids], (1, 0, 2)).copy()
+    f32 = outs[0]["s"].cpu().numpy()
+    assert np.array_equal(f32, want)
+    b16 = outs[1]["s"].float().cpu().numpy()
+    assert b16.shape == (T, B, P, 96)
+    assert np.array_equal(b16[..., :F].reshape(T, B, P * F), want) and not b16[..., F:].any()
+    raw = outs[2]["s"].cpu().numpy()
+    assert raw.shape == (T, B, P * 16)                               # ceil(70 / 64) words per segment
+    bits = np.unpackbits(raw.reshape(T, B, P, 16), axis=-1, bitorder="little")[..., :F]
+    assert np.array_equal(bits.reshape(T, B, P * F).astype(np.float32), want)
+    for o in outs[1:]:
+        assert np.array_equal(o["x"].cpu().numpy(), outs[0]["x"].cpu().numpy())
+    reps[0].check_errors()
+    obs[3, 2, 17] = 0.5
+    reps[0].add({"s": dev(obs), "x": dev(x)}, z(n, T), z(n, T).to(torch.uint8), z(n, T), dev(sl), z(n) + 1)
+    with pytest.raises(HsadError):
+        reps[0].check_errors()
 
 
 def make_sequences(rng, n, T, d, first_id):
@@ -207,3 +258,71 @@ def test_full_ring_evicts_oldest_instead_of_blocking():
     add(100, 11)                                    # larger than the whole ring
     with pytest.raises(HsadError):
         rep.check_errors()
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_outstanding_draws_are_answered_oldest_first(depth):
+    """hsad_replay_set_outstanding(k): the reference's prefetch queue keeps up to `prefetch` drawn batches whose priorities
+    have not come back (prioritized_replay.h:232-262).  Host model of ConcurrentQueue (weights by ring slot, evicted flags,
+    running sum) driven by the ids the device reports for each draw; with dyadic priorities and alpha = 1 every sum is exact,
+    so the device's running sum must equal the model's after every call -- a priority written to the wrong draw's ids, or to
+    an element evicted since its draw, changes it."""
+    from hanabi_sad_amd import HsadError
+    from hanabi_sad_amd.replay import DeviceReplay
+    rng = np.random.default_rng(11 + depth)
+    T, d, cap, B = 4, 3, 96, 16
+    ring = int(1.25 * cap)
+    rep = DeviceReplay(cap, 7, 1.0, 0.5, 0, T, [("s", d, torch.float32)], DEV)
+    rep.set_outstanding(depth)
+    w = np.zeros(ring, np.float64)
+    evicted = np.zeros(ring, bool)
+    head = tail = size = 0
+    total = 0.0
+    queue = []
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    n_skipped = 0
+    for it in range(120):
+        n = int(rng.integers(4, 24))
+        prio = (rng.integers(1, 64, n) / 16.0).astype(np.float32)
+        rep.add({"s": z(n, T, d)}, z(n, T), z(n, T).to(torch.uint8), z(n, T), z(n) + T, dev(prio))
+        npop = max(0, size + n - ring)            # a full ring makes room first (see the test above)
+        for k in range(npop):
+            j = (head + k) % ring
+            total -= w[j]
+            evicted[j] = True
+        head, size = (head + npop) % ring, size - npop
+        for i in range(n):
+            w[(tail + i) % ring] = prio[i]
+        total += float(prio.astype(np.float64).sum())
+        tail, size = (tail + n) % ring, size + n
+        assert rep.priority_sum() == (total, size)
+        if size < B:
+            continue
+        while len(queue) < depth:                  # draw ahead until the queue is full
+            rep.sample(B)
+            ids = rep.last_ids(B).cpu().numpy()
+            evicted[ids] = False
+            npop = max(0, size - cap)
+            for k in range(npop):
+                j = (head + k) % ring
+                total -= w[j]
+                evicted[j] = True
+            head, size = (head + npop) % ring, size - npop
+            queue.append(ids)
+            assert rep.priority_sum() == (total, size)
+        ids = queue.pop(0)                          # the learner finishes the OLDEST batch
+        newp = (rng.integers(1, 64, B) / 16.0).astype(np.float32)
+        rep.update_priority(dev(newp))
+        for i in range(B):
+            if evicted[ids[i]]:
+                n_skipped += 1
+                continue
+            total += float(newp[i]) - w[ids[i]]
+            w[ids[i]] = newp[i]
+        assert rep.priority_sum() == (total, size), "iteration %d" % it
+    rep.check_errors()
+    assert depth == 1 or n_skipped > 0             # elements evicted between draw and update were exercised
+    with pytest.raises(HsadError):                 # draws are outstanding: the depth cannot change now
+        if not queue:
+            rep.sample(B)
+        rep.set_outstanding(1)
