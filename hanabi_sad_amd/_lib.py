@@ -56,6 +56,7 @@ SIGNATURES = {
     "hsad_env_games_per_workgroup": (C.c_int, [_P]),
     "hsad_env_state_bytes": (C.c_int64, [_P]),
     "hsad_env_bind_outputs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "hsad_env_bind_packed": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),
     "hsad_env_reset": (C.c_int, [_P, _P]),
     "hsad_env_step": (C.c_int, [_P, _P, _P, _P]),
     "hsad_env_policy_random": (C.c_int, [_P, C.c_uint64, _P, _P, _P]),
@@ -143,7 +144,8 @@ SIGNATURES = {
     "hsad_r2d2_net_params": (_P, [_P]),
     "hsad_r2d2_net_refresh": (C.c_int, [_P, _P]),
     "hsad_r2d2_net_version": (C.c_uint64, [_P]),
-    "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hsad_r2d2_net_in_dim_padded": (C.c_int, [_P]),
+    "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_q_of": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_compute_priority": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double,
                                              _P, _P, _P]),
@@ -152,7 +154,7 @@ SIGNATURES = {
     "hsad_r2d2_learner_set_schedule": (C.c_int, [_P, C.c_int, C.c_int]),
     "hsad_r2d2_learner_grad": (_P, [_P]),
     "hsad_r2d2_learner_timed_out": (C.c_int, [_P, C.POINTER(C.c_int32)]),
-    "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
+    "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
     "hsad_r2d2_loss_bwd": (C.c_int, [_P, _P]),
     "hsad_r2d2_optimizer_step": (C.c_int, [_P, C.c_float, C.c_float, C.POINTER(_P), _P]),
     "hsad_r2d2_sync_target_with_online": (C.c_int, [_P, _P]),

@@ -29,7 +29,7 @@ def transition_fields(env, vdn=False):
 
 class DeviceActor:
     def __init__(self, env: BatchedHanabiEnv, agent: R2D2Agent, replay: DeviceReplay, multi_step, gamma, eta, seq_len,
-                 vdn=False):
+                 vdn=False, packed_obs=None):
         self.env, self.agent, self.replay = env, agent, replay
         self.G, self.P = env.G, env.P
         self.N = self.G * self.P              # agent rows (hidden state [L, N, H]) in both layouts
@@ -39,6 +39,15 @@ class DeviceActor:
         self.multi_step = int(multi_step)
         self.writer = SequenceWriter(self.E, multi_step, gamma, seq_len, transition_fields(env, self.vdn), env.device)
         self.cached_q = getattr(agent, "cached_q", True)      # False: a contract model (rela.ContractAgent): reference flow
+        # packed observation path: the env kernel writes the observation as the replay's bit words and as the net's bf16 operand
+        # from its on-chip bit rows; the float32 observation (the reference's API-boundary format) is not written at all, and
+        # neither the bf16 cast nor the row-pack pass runs.  Needs an agent that takes bf16 input (composite.CompositeAgent).
+        if packed_obs is None:
+            packed_obs = bool(getattr(agent, "accepts_bf16_obs", False)) and self.cached_q and getattr(env, "knowledge_mode", 0) == 0
+        self.packed_obs = bool(packed_obs)
+        if self.packed_obs:
+            env.enable_packed(agent.online.Fp, keep_float32=False)
+            self.writer.set_prepacked(("priv_s", "legal_move", "own_hand"))
         if hasattr(agent, "configure"):
             agent.configure(self.P, self.vdn)
         self.hid = agent.get_h0(self.N)
@@ -51,6 +60,9 @@ class DeviceActor:
 
     def _rows(self):
         e, N = self.env, self.N
+        if self.packed_obs:
+            return {"priv_s_bf16": e.priv_s_bf16.view(N, -1), "legal_move": e.legal_move.view(N, e.A), "eps": e.eps.view(N),
+                    "own_hand": e.own_hand.view(N, 3 * e.H)}
         return {"priv_s": e.priv_s.view(N, e.F), "legal_move": e.legal_move.view(N, e.A), "eps": e.eps.view(N),
                 "own_hand": e.own_hand.view(N, 3 * e.H)}
 
@@ -70,7 +82,10 @@ class DeviceActor:
             return self._step_contract(obs)
         reply, self.hid = agent.act(obs, self.hid, with_q=True)
         self.q_hist.append((reply["q_online_a"], reply["versions"][0]))
-        fields = dict(obs)
+        if self.packed_obs:
+            fields = {"priv_s": env.priv_bits, "legal_move": env.legal_bits, "own_hand": env.own_bits, "eps": obs["eps"]}
+        else:
+            fields = dict(obs)
         fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
         self.writer.push_obs_action(fields)
         env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))

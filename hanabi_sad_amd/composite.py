@@ -60,6 +60,7 @@ class CNet:
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.h, i), self.lib.hsad_r2d2_net_param_size(self.h, i)
             self.w[name] = self.flat[o:o + sz].view(weights[name].shape)
             self.w[name].copy_(weights[name])
+        self.Fp = self.lib.hsad_r2d2_net_in_dim_padded(self.h)
         self.refresh()
 
     def refresh(self):
@@ -85,6 +86,8 @@ class CompositeAgent:
     """R2D2Agent.act / compute_priority (pyhanabi/r2d2.py:247-361) as single library calls (hsad_r2d2_act,
     hsad_r2d2_compute_priority); same interface as r2d2.R2D2Agent, so actor.DeviceActor drives either"""
 
+    accepts_bf16_obs = True     # act() takes obs["priv_s_bf16"]: actor.DeviceActor then runs the env's packed observation path
+
     def __init__(self, online: CNet, target: CNet, multi_step, gamma, seed=0):
         self.online, self.target = online, target
         self.multi_step, self.gamma = int(multi_step), float(gamma)
@@ -96,7 +99,8 @@ class CompositeAgent:
         return {"h0": z, "c0": z.clone()}
 
     def act(self, obs, hid, with_q=False):
-        n, on, d = obs["priv_s"].shape[0], self.online, self.device
+        """obs["priv_s"] float32 [N,F], or obs["priv_s_bf16"] [N, in_dim_padded] as the env's packed outputs provide it"""
+        n, on, d = obs["legal_move"].shape[0], self.online, self.device
         a = torch.empty(n, dtype=torch.int64, device=d)
         g = torch.empty(n, dtype=torch.int64, device=d)
         h = torch.empty(on.L, n, on.H, dtype=torch.float32, device=d)
@@ -108,7 +112,11 @@ class CompositeAgent:
         tq = torch.empty(n, dtype=torch.float32, device=d) if with_q else None
         eps = obs.get("eps")
         p = lambda t: None if t is None else t.contiguous().data_ptr()
-        _lib.check(self.lib.hsad_r2d2_act(on.h, self.target.h if with_q else None, n, p(obs["priv_s"]), p(obs["legal_move"]), p(eps),
+        p16 = obs.get("priv_s_bf16")
+        if p16 is not None and (p16.dtype != torch.bfloat16 or p16.shape[-1] != on.Fp or p16.numel() != n * on.Fp):
+            raise _lib.HsadError("priv_s_bf16 must be bf16 [%d, %d]; got %s %s" % (n, on.Fp, p16.dtype, tuple(p16.shape)))
+        _lib.check(self.lib.hsad_r2d2_act(on.h, self.target.h if with_q else None, n, None if p16 is not None else p(obs["priv_s"]),
+                                          p(p16), p(obs["legal_move"]), p(eps),
                                           p(hid["h0"]), p(hid["c0"]), p(h16_in), self.seed, self.counter, a.data_ptr(), g.data_ptr(),
                                           h.data_ptr(), c.data_ptr(), p(h16), p(qa), p(tq), _s(d)))
         self.counter += 1
@@ -189,12 +197,20 @@ class CompositeLearner:
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
 
     def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
-        priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]
+        """batch["priv_s"] float32 [T,B,(P,)F] -- or batch["priv_s_bf16"] [T,B,P,in_dim_padded] bf16, what DeviceReplay.sample
+        returns for the bit-packed observation with set_field_output("priv_s", "bf16", in_dim_padded) --, legal_move [T,B,(P,)A]"""
+        legal, a = batch["legal_move"], batch["a"]
+        p16 = batch.get("priv_s_bf16")
+        priv = p16 if p16 is not None else batch["priv_s"]
         P = 1
+        if legal.dim() == 4:
+            P = legal.shape[2]
+            legal, a = legal.flatten(1, 2), a.flatten(1, 2)
         if priv.dim() == 4:
-            P = priv.shape[2]
-            priv, legal, a = priv.flatten(1, 2), legal.flatten(1, 2), a.flatten(1, 2)
-        T, rows, _ = priv.shape
+            priv = priv.flatten(1, 2)
+        T, rows, _ = legal.shape
+        if p16 is not None and (priv.dtype != torch.bfloat16 or tuple(priv.shape) != (T, rows, self.online.Fp)):
+            raise _lib.HsadError("priv_s_bf16 must be bf16 [T, rows, %d]; got %s %s" % (self.online.Fp, priv.dtype, tuple(priv.shape)))
         self._ensure(T, rows)
         d, B = self.device, rows // P
         loss = torch.empty(B, dtype=torch.float32, device=d)
@@ -203,7 +219,8 @@ class CompositeLearner:
         p = lambda t: None if t is None else t.contiguous().data_ptr()
         keep = [priv.contiguous(), legal.contiguous(), a.contiguous(), None if own is None else own.contiguous(), weight.contiguous()]
         self._alive = keep       # loss_bwd reads these
-        _lib.check(self.lib.hsad_r2d2_loss_fwd(self.h, keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), p(batch["reward"]),
+        _lib.check(self.lib.hsad_r2d2_loss_fwd(self.h, None if p16 is not None else keep[0].data_ptr(),
+                                               keep[0].data_ptr() if p16 is not None else None, keep[1].data_ptr(), keep[2].data_ptr(), p(batch["reward"]),
                                                p(batch["bootstrap"]), p(batch["seq_len"]), None if own is None else keep[3].data_ptr(),
                                                keep[4].data_ptr(), P, float(pred_weight), loss.data_ptr(), prio.data_ptr(),
                                                int(compute_grad), _s(d)))

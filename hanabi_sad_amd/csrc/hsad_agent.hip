@@ -312,6 +312,7 @@ float* hsad_r2d2_net_params(hsad_r2d2_net* n) { return n ? n->flat : nullptr; }
 int64_t hsad_r2d2_net_param_offset(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i <= 16) ? (int64_t)n->off[i] : -1; }
 int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i < 16) ? (int64_t)net_tensor_elems(n, i) : -1; }
 uint64_t hsad_r2d2_net_version(const hsad_r2d2_net* n) { return n ? n->version : 0; }
+int hsad_r2d2_net_in_dim_padded(const hsad_r2d2_net* n) { return n ? n->Fp : 0; }
 
 int hsad_r2d2_net_refresh(hsad_r2d2_net* n, void* stream) {
   if (!n) return afail(HSAD_ERR_INVALID, "null net");
@@ -321,11 +322,11 @@ int hsad_r2d2_net_refresh(hsad_r2d2_net* n, void* stream) {
 // R2D2Agent.act (pyhanabi/r2d2.py:247-303) for N rows (one row per (game, player)): eps-greedy action, greedy action, new
 // hidden state.  q_online_a / q_target_greedy (both or neither; `target` required with them): Q_online(s, a) of the pass just
 // run and Q_target(s, greedy_a) from one target-net pass -- what compute_priority needs from this time step.
-int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const float* legal_move,
-                  const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
+int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16,
+                  const float* legal_move, const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
                   int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
                   float* q_target_greedy, void* stream) {
-  if (!online || !priv_s || !legal_move || !h0 || !c0 || !a || !greedy_a || !h_out || !c_out || N < 1)
+  if (!online || (!priv_s && !priv_s_bf16) || !legal_move || !h0 || !c0 || !a || !greedy_a || !h_out || !c_out || N < 1)
     return afail(HSAD_ERR_INVALID, "r2d2_act: null argument");
   if ((q_online_a != nullptr) != (q_target_greedy != nullptr) || (q_online_a && !target))
     return afail(HSAD_ERR_INVALID, "r2d2_act: q_online_a and q_target_greedy come together and need the target net");
@@ -349,7 +350,8 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   float* q = (float*)p;
   p += q_b;
   float* scratch = (float*)p;
-  CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
+  if (priv_s_bf16) a16 = (bf16_t*)priv_s_bf16;   // [N, Fp] as hsad_env_bind_packed writes it: no cast pass
+  else CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
   StepOut so{};
   CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s));
   if (h_out_bf16 && so.h16_new) HIP_TRY(hipMemcpyAsync(h_out_bf16, so.h16_new, (size_t)2 * N * H * 2, hipMemcpyDeviceToDevice, s));
@@ -457,6 +459,7 @@ struct hsad_r2d2_learner {
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
   // activations (q = 0 online, 1 target)
   bf16_t *a16, *x1[2], *hseq[2][2], *xchg_f[2][2], *zero16, *sc16;
+  const bf16_t* a16_in = nullptr;  // the input operand of the update in flight: a16 (cast here) or the caller's bf16 batch
   float *gates[2][2], *cseq[2][2], *hT[2][2], *czero;
   float *heads, *heads_t, *q, *qa, *tqa, *qa_s, *tqa_s, *err, *dqa, *dqa_r, *w_r, *xs, *qscratch;
   int64_t* greedy;
@@ -663,10 +666,11 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
 
 // loss forward: batch tensors [T, rows, ...] with rows = B (IQL) or B_games * num_player (VDN: Q summed over a game's players;
 // reward / bootstrap [T, games], seq_len / weight / loss [games], priority [T, games]).  own_hand may be NULL (pred_weight = 0).
-int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const float* legal_move, const int64_t* a, const float* reward,
+int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* priv_s_bf16, const float* legal_move, const int64_t* a, const float* reward,
                        const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
                        float pred_weight, float* loss, float* priority, int want_grad, void* stream) {
-  if (!L || !priv_s || !legal_move || !a || !reward || !bootstrap || !seq_len || !loss || !priority || num_player < 1 || L->B % num_player)
+  if (!L || (!priv_s && !priv_s_bf16) || !legal_move || !a || !reward || !bootstrap || !seq_len || !loss || !priority || num_player < 1 ||
+      L->B % num_player)
     return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: bad arguments");
   if (pred_weight > 0 && num_player > 1)
     return afail(HSAD_ERR_INVALID, "VDN with the auxiliary task is broken in the reference (aux_task_vdn, SURVEY F6b) and has no defined behaviour");
@@ -677,9 +681,15 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const float* l
   const int T = L->T, B = L->B, M = L->M, H = L->on->H, H4 = 4 * H, A = L->on->A, NH = L->on->NH, Fp = L->on->Fp;
   const int nch = pick_chunks(L);
   L->nch = nch;
-  CK(hsad_cast_pad_bf16(priv_s, M, L->on->F, L->on->F, L->a16, Fp, stream));
+  // priv_s_bf16: [M, Fp] zero-padded, e.g. straight out of hsad_replay_sample (HSAD_BITS_AS_BF16); it must stay valid until
+  // hsad_r2d2_loss_bwd has run (the input-layer weight gradient reads it again)
+  if (priv_s_bf16) L->a16_in = (const bf16_t*)priv_s_bf16;
+  else {
+    CK(hsad_cast_pad_bf16(priv_s, M, L->on->F, L->on->F, L->a16, Fp, stream));
+    L->a16_in = L->a16;
+  }
   for (int q = 0; q < 2; ++q) {
-    CK(hsad_gemm_nt_bf16(L->a16, Fp, nets[q]->W1, Fp, M, H, Fp, nets[q]->w(P_B1), nullptr, 0, L->x1[q], H, 1, 0, stream));
+    CK(hsad_gemm_nt_bf16(L->a16_in, Fp, nets[q]->W1, Fp, M, H, Fp, nets[q]->w(P_B1), nullptr, 0, L->x1[q], H, 1, 0, stream));
     CK(hsad_gemm_nt_bf16(L->x1[q], H, nets[q]->Wih[0], H, M, H4, H, nets[q]->bg[0], L->gates[q][0], H4, nullptr, 0, 0, 0, stream));
   }
   if (can_pipeline(L)) {
@@ -821,7 +831,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     }
   }
   CK(transpose16(L->x1[0], M, H, H, L->x1T, Mp, nullptr, nullptr, nullptr, wst));
-  CK(transpose16(L->a16, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
+  CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
   CK(transpose16(L->dheads, M, NHp, NHp, L->dheadsT, Mp, nullptr, nullptr, nullptr, wst));
   CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[1], ldh, NH, H, Mp, nullptr, g[P_WA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
   CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[P_BA], nullptr, nullptr, wst));

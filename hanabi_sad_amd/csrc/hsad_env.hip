@@ -85,6 +85,13 @@ struct EnvParams {
   float* legal;
   float* own;
   float* eps;
+  // device-consumer outputs (hsad_env_bind_packed): the observation rows in the replay's stored format (bit words) and as the
+  // net's bf16 GEMM operand, written from the same LDS bit rows; obs_f32 = 0 then skips the float32 observation stream
+  unsigned long long* priv_bits;   // [G*P][pw64]
+  unsigned long long* legal_out;   // [G*P]
+  unsigned long long* own_bits;    // [G*P]
+  unsigned short* priv16;          // [G*P][ld16] bf16, columns F..ld16-1 zero
+  int pw64, ld16, obs_f32;
   float* reward;
   uint8_t* terminal;
   unsigned long long* dbg;  // optional per-wave phase timestamps [grid][8] (hsad_env_debug_timing)
@@ -496,6 +503,57 @@ __device__ __forceinline__ float4 nib_to_f4(uint32_t nib) {
   return v;
 }
 
+// 64 bits from an arbitrary bit position of an LDS bit array (may read up to two words past the last one it needs: callers
+// mask, and the arrays are followed by other LDS data of the same workgroup)
+__device__ __forceinline__ uint64_t get64(const uint32_t* bits, uint32_t bp) {
+  const uint32_t w = bp >> 5, s = bp & 31;
+  uint64_t v = ((uint64_t)bits[w] | ((uint64_t)bits[w + 1] << 32)) >> s;
+  if (s) v |= (uint64_t)bits[w + 2] << (64u - s);
+  return v;
+}
+__device__ __forceinline__ uint32_t get8(const uint32_t* bits, uint32_t bp) {
+  const uint32_t w = bp >> 5, s = bp & 31;
+  const uint32_t lo = bits[w];
+  if (s <= 24) return (lo >> s) & 255u;
+  return ((lo >> s) | (bits[w + 1] << (32 - s))) & 255u;
+}
+
+// rows [row0, row0 + nrows) of the workgroup's LDS observation bit rows (row r = bits r*F .. r*F+F-1) as
+//   bit words   priv_bits[(grow0 + r) * pw64 + k]          (the replay's HSAD_BITS format: LSB first, tail bits zero)
+//   bf16 rows   priv16[(grow0 + r) * ld16 + j]             (1.0 = 0x3F80; columns >= F zero)
+__device__ __forceinline__ void stream_rows_packed(const EnvParams& ep, const uint32_t* s_obs, int row0, int nrows, size_t grow0,
+                                                   int tid, int nthreads) {
+  const uint32_t F = (uint32_t)ep.F;
+  if (ep.priv_bits) {
+    const int pw = ep.pw64;
+    for (int k = tid; k < nrows * pw; k += nthreads) {
+      const int r = k / pw, wd = k - r * pw;
+      const uint32_t left = F - (uint32_t)wd * 64u;
+      uint64_t v = get64(s_obs, (uint32_t)(row0 + r) * F + (uint32_t)wd * 64u);
+      if (left < 64u) v &= (1ull << left) - 1ull;
+      ep.priv_bits[(grow0 + r) * pw + wd] = v;
+    }
+  }
+  if (ep.priv16) {
+    const int cpr = ep.ld16 >> 3;  // 16-byte chunks (8 values) per row
+    for (int k = tid; k < nrows * cpr; k += nthreads) {
+      const int r = k / cpr, c = k - r * cpr;
+      const uint32_t j0 = (uint32_t)c * 8u;
+      uint32_t m = 0;
+      if (j0 < F) {
+        m = get8(s_obs, (uint32_t)(row0 + r) * F + j0);
+        if (F - j0 < 8u) m &= (1u << (F - j0)) - 1u;
+      }
+      uint4 o;
+      o.x = ((m & 1u) ? 0x3F80u : 0u) | ((m & 2u) ? 0x3F800000u : 0u);
+      o.y = ((m & 4u) ? 0x3F80u : 0u) | ((m & 8u) ? 0x3F800000u : 0u);
+      o.z = ((m & 16u) ? 0x3F80u : 0u) | ((m & 32u) ? 0x3F800000u : 0u);
+      o.w = ((m & 64u) ? 0x3F80u : 0u) | ((m & 128u) ? 0x3F800000u : 0u);
+      *reinterpret_cast<uint4*>(ep.priv16 + (grow0 + r) * (size_t)ep.ld16 + j0) = o;
+    }
+  }
+}
+
 // out[i] = bit(bit0 + i) ? 1.f : 0.f for i in [0, n): 16-byte stores wherever the address allows.
 __device__ __forceinline__ void stream_bits_f32(const uint32_t* bits, uint32_t bit0, float* out, uint32_t n, int lane) {
   const uintptr_t addr = (uintptr_t)out;
@@ -679,6 +737,7 @@ __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* 
     const uint64_t lm = legal_mask_of<TH>(P, H, ep.A, s_st, lane, p, pm);
     or_bits64(s_legal, (uint32_t)(lane * P + p) * (uint32_t)ep.A, lm);
     ep.legal_bits[(size_t)g * P + p] = lm;
+    if (ep.legal_out) ep.legal_out[(size_t)g * P + p] = lm;
 
     // own hand trinary [playable, discardable, other] (EncodeOwnHandTrinary)
     {
@@ -693,6 +752,7 @@ __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* 
         if (i < len) om |= 1u << (3 * i + (r == f ? 0 : (r < f ? 1 : 2)));
       }
       or_bits32(s_own, (uint32_t)(lane * P + p) * (uint32_t)(3 * H), om);
+      if (ep.own_bits) ep.own_bits[(size_t)g * P + p] = om;
     }
   }
 }
@@ -1165,11 +1225,14 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
   const size_t PF = (size_t)P * ep.F, PA = (size_t)P * ep.A, PO = (size_t)P * 3 * H;
   if (MODE >= 1) {
     // all ng games of the wave: one contiguous, 16-byte aligned range per output tensor
-    if (ep.nt_stores) {
+    if (!ep.obs_f32) {
+      // device consumers only: no float32 observation leaves the chip
+    } else if (ep.nt_stores) {
       stream_bits_f32_aligned<true>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
     } else {
       stream_bits_f32_aligned<false>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
     }
+    stream_rows_packed(ep, s_obs, 0, ng * P, (size_t)g0 * P, tid, kEnvThreads);
     stream_bits_f32_aligned<false>(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), tid, kEnvThreads);
     stream_bits_f32_aligned<false>(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), tid, kEnvThreads);
     if (valid && wave == 0) {
@@ -1188,7 +1251,8 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
     while (todo) {
       const int lg = __builtin_ctzll(todo);
       todo &= todo - 1;
-      stream_bits_f32(s_obs, (uint32_t)(lg * PF), ep.priv_s + (size_t)(g0 + lg) * PF, (uint32_t)PF, lane);
+      if (ep.obs_f32) stream_bits_f32(s_obs, (uint32_t)(lg * PF), ep.priv_s + (size_t)(g0 + lg) * PF, (uint32_t)PF, lane);
+      stream_rows_packed(ep, s_obs, lg * P, P, (size_t)(g0 + lg) * P, lane, kWave);
       stream_bits_f32(s_legal, (uint32_t)(lg * PA), ep.legal + (size_t)(g0 + lg) * PA, (uint32_t)PA, lane);
       stream_bits_f32(s_own, (uint32_t)(lg * PO), ep.own + (size_t)(g0 + lg) * PO, (uint32_t)PO, lane);
     }
@@ -1531,6 +1595,7 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
   if (!e) return set_error(HSAD_ERR_NOMEM, "host allocation failed");
   std::memset(&e->ep, 0, sizeof(e->ep));
   EnvParams& ep = e->ep;
+  ep.obs_f32 = 1;
   const int P = cfg->players, H = cfg->hand_size;
   ep.G = cfg->num_games;
   ep.Gpad = (ep.G + kWave - 1) / kWave * kWave;
@@ -1676,6 +1741,25 @@ int hsad_env_bind_outputs(hsad_env* e, float* priv_s, float* legal_move, float* 
   e->ep.reward = reward;
   e->ep.terminal = terminal;
   e->bound = true;
+  return HSAD_OK;
+}
+
+int hsad_env_bind_packed(hsad_env* e, uint64_t* priv_bits, uint64_t* legal_bits, uint64_t* own_bits, void* priv_s_bf16,
+                         int bf16_row_len, int keep_float32_obs) {
+  if (!e) return set_error(HSAD_ERR_INVALID, "null env");
+  if (e->ep.kmode != 0)
+    return set_error(HSAD_ERR_INVALID, "the V0-belief observation (knowledge_mode 1) holds count ratios, not bits: no packed outputs");
+  if (priv_s_bf16 && (bf16_row_len < e->ep.F || (bf16_row_len & 7) || ((uintptr_t)priv_s_bf16 & 15u)))
+    return set_error(HSAD_ERR_INVALID, "bf16 rows must be 16-byte aligned and a multiple of 8 values >= feature_size long");
+  if (!keep_float32_obs && !priv_bits && !priv_s_bf16)
+    return set_error(HSAD_ERR_INVALID, "dropping the float32 observation needs at least one packed observation output");
+  e->ep.priv_bits = reinterpret_cast<unsigned long long*>(priv_bits);
+  e->ep.legal_out = reinterpret_cast<unsigned long long*>(legal_bits);
+  e->ep.own_bits = reinterpret_cast<unsigned long long*>(own_bits);
+  e->ep.priv16 = static_cast<unsigned short*>(priv_s_bf16);
+  e->ep.pw64 = (e->ep.F + 63) / 64;
+  e->ep.ld16 = bf16_row_len;
+  e->ep.obs_f32 = keep_float32_obs ? 1 : 0;
   return HSAD_OK;
 }
 

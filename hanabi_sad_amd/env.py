@@ -44,6 +44,21 @@ class BatchedHanabiEnv:
                                            self.own_hand.data_ptr(), self.eps.data_ptr(), self.reward.data_ptr(),
                                            self.terminal.data_ptr()))
 
+    def enable_packed(self, bf16_row_len=0, keep_float32=True):
+        """outputs for device consumers (hsad_env_bind_packed): priv_bits int64 [G,P,ceil(F/64)], legal_bits / own_bits int64 [G,P]
+        (bit j = column j of the float32 tensor) and, with bf16_row_len, priv_s_bf16 [G,P,row_len] zero-padded.
+        keep_float32=False: the float32 priv_s tensor is no longer written (self.priv_s becomes None)"""
+        d, G, P = self.device, self.G, self.P
+        self.priv_bits = torch.zeros(G, P, (self.F + 63) // 64, dtype=torch.int64, device=d)
+        self.legal_bits = torch.zeros(G, P, dtype=torch.int64, device=d)
+        self.own_bits = torch.zeros(G, P, dtype=torch.int64, device=d)
+        self.priv_s_bf16 = torch.zeros(G, P, bf16_row_len, dtype=torch.bfloat16, device=d) if bf16_row_len else None
+        _lib.check(self.lib.hsad_env_bind_packed(self.h, self.priv_bits.data_ptr(), self.legal_bits.data_ptr(), self.own_bits.data_ptr(),
+                                                 self.priv_s_bf16.data_ptr() if bf16_row_len else None, int(bf16_row_len),
+                                                 int(bool(keep_float32))))
+        if not keep_float32:
+            self.priv_s = None
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.lib.hsad_env_destroy(self.h)
@@ -73,6 +88,9 @@ class BatchedHanabiEnv:
 
     def obs(self):
         """TensorDict view produced by VectorEnv::reset/step (rela/env.h:48-87)."""
+        if self.priv_s is None:   # enable_packed(keep_float32=False): the observation only exists as bit words / bf16 rows
+            return {"priv_s_bf16": self.priv_s_bf16, "priv_bits": self.priv_bits, "legal_move": self.legal_move, "eps": self.eps,
+                    "own_hand": self.own_hand}
         return {"priv_s": self.priv_s, "legal_move": self.legal_move, "eps": self.eps, "own_hand": self.own_hand}
 
     def reset(self):
@@ -80,7 +98,7 @@ class BatchedHanabiEnv:
         return self.obs()
 
     def step(self, a, greedy_a=None):
-        assert a.dtype == torch.int64 and a.is_contiguous() and a.device == self.priv_s.device
+        assert a.dtype == torch.int64 and a.is_contiguous() and a.device == self.legal_move.device
         g = greedy_a if greedy_a is not None else (a if self.sad else None)
         _lib.check(self.lib.hsad_env_step(self.h, a.data_ptr(), g.data_ptr() if g is not None else None,
                                           self._stream()))

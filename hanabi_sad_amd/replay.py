@@ -235,6 +235,7 @@ class SequenceWriter:
             raise _lib.HsadError("SequenceWriter needs a ROCm device; there is no CPU path")
         self.fields = [(n, int(w), dt) for n, w, dt in fields]
         self.E, self.T = int(num_envs), int(seq_len)
+        self._prepacked = set()
         self.h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.hsad_seqwriter_create(self.E, int(multi_step), float(gamma), self.T, len(self.fields),
@@ -251,10 +252,28 @@ class SequenceWriter:
         except Exception:
             pass
 
+    def set_prepacked(self, names):
+        """bit fields in `names` are handed to push_obs_action as their stored bit words (int64 tensors, e.g. the env's packed
+        outputs) instead of float32 0/1 values: a word copy instead of a pack pass"""
+        mask = 0
+        for k, (n, _, dt) in enumerate(self.fields):
+            if n in names:
+                if not isinstance(dt, Bits):
+                    raise _lib.HsadError("field %s is not a bit field" % n)
+                mask |= 1 << k
+        _lib.check(self.lib.hsad_seqwriter_set_prepacked(self.h, mask))
+        self._prepacked = set(names)
+
     def push_obs_action(self, fields):
         ts = []
         for name, w, dt in self.fields:
             t = fields[name]
+            if name in self._prepacked:
+                words = dt.segments * ((w // dt.segments + 63) // 64)
+                assert t.dtype == torch.int64 and t.is_contiguous() and t.device == self.device and t.numel() == self.E * words, \
+                    (name, t.dtype, tuple(t.shape))
+                ts.append(t)
+                continue
             want = _api_dtype(dt)
             t = (t.to(want) if t.dtype != want else t).contiguous()
             assert t.device == self.device and t.numel() == self.E * w, (name, tuple(t.shape))

@@ -85,6 +85,16 @@ int64_t hsad_env_state_bytes(const hsad_env* env);
 int hsad_env_bind_outputs(hsad_env* env, float* priv_s, float* legal_move, float* own_hand, float* eps,
                           float* reward, uint8_t* terminal);
 
+/* Outputs for DEVICE consumers, written by reset/step next to (or instead of) the float32 tensors from the same on-chip bit rows:
+ *   priv_bits  uint64 [G*P, ceil(F/64)]   the observation as bit words = the stored format of an HSAD_BITS field
+ *                                         (hsad_seqwriter_set_prepacked: no pack pass, 1/32 of the bytes)
+ *   legal_bits uint64 [G*P]               bit uid = legal_move[uid]          own_bits uint64 [G*P]   bit j = own_hand[j]
+ *   priv_s_bf16 bf16  [G*P, row_len]      the first GEMM's operand, columns F.. zero (hsad_r2d2_act priv_s_bf16: no cast pass)
+ * Any pointer may be NULL.  keep_float32_obs = 0 stops writing the float32 priv_s tensor (the reference's API-boundary format,
+ * 3.3 KB per row) -- legal_move / own_hand / eps / reward / terminal are always written.  Not available with knowledge_mode 1. */
+int hsad_env_bind_packed(hsad_env* env, uint64_t* priv_bits, uint64_t* legal_bits, uint64_t* own_bits, void* priv_s_bf16,
+                         int bf16_row_len, int keep_float32_obs);
+
 /* VectorEnv::reset (rela/env.h:48-60): (re)starts every game for which terminated() holds —
  * all of them on the first call — and rewrites only those games' observation rows
  * (HanabiEnv::reset, cpp/hanabi_env.cc:9-47). */
@@ -452,13 +462,15 @@ int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* net, int i);
 float* hsad_r2d2_net_params(hsad_r2d2_net* net);                      /* device pointer: write weights here, then refresh */
 int hsad_r2d2_net_refresh(hsad_r2d2_net* net, void* stream);          /* re-derive the bf16 / permuted / transposed operands */
 uint64_t hsad_r2d2_net_version(const hsad_r2d2_net* net);             /* bumped by every refresh */
-/* R2D2Agent.act for N rows (one per (game, player)): priv_s fp32 [N,F], legal_move [N,A], eps [N] (NULL = greedy), hidden state
+int hsad_r2d2_net_in_dim_padded(const hsad_r2d2_net* net);            /* row length of a bf16 observation operand (in_dim rounded up to 64) */
+/* R2D2Agent.act for N rows (one per (game, player)): priv_s fp32 [N,F] -- or priv_s_bf16 [N, in_dim_padded] zero-padded, as
+ * hsad_env_bind_packed writes it (then priv_s may be NULL and no cast pass runs) --, legal_move [N,A], eps [N] (NULL = greedy), hidden state
  * h0 / c0 fp32 [L,N,H] in, h_out / c_out out (h0_bf16 / h_out_bf16, optional: the bf16 copy the fused cell kernels read / write
  * anyway, carried by the caller to save a cast per step) -> a, greedy_a int64 [N].  q_online_a / q_target_greedy (both or
  * neither): Q_online(s, a) of the pass that picked the action and Q_target(s, greedy_a) from one target-net pass, i.e. what
  * compute_priority needs from this step.  Exploration: counter-based hash of (seed, row, counter). */
-int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const float* legal_move,
-                  const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
+int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16,
+                  const float* legal_move, const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
                   int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
                   float* q_target_greedy, void* stream);
 /* R2D2Agent.compute_priority (r2d2.py:305-361): |r + bootstrap gamma^n Q_target(s', argmax adv_online(s')) - Q_online(s, a)|.
@@ -482,8 +494,10 @@ float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gr
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
 /* R2D2Agent.loss forward: priv_s [T,rows,F], legal_move [T,rows,A], a int64 [T,rows], own_hand [T,rows,3*hand] (NULL without the
  * aux task); reward / bootstrap [T,B], seq_len / weight [B] with B = rows / num_player games -> loss [B], priority [T,B].
- * want_grad keeps what loss_bwd needs (weight required). */
-int hsad_r2d2_loss_fwd(hsad_r2d2_learner* learner, const float* priv_s, const float* legal_move, const int64_t* a, const float* reward,
+ * want_grad keeps what loss_bwd needs (weight required).  priv_s_bf16 (instead of priv_s): [T*rows, in_dim_padded] zero-padded bf16,
+ * e.g. what hsad_replay_sample writes for an HSAD_BITS field set to HSAD_BITS_AS_BF16; no cast pass, and it must stay valid until
+ * loss_bwd has been issued. */
+int hsad_r2d2_loss_fwd(hsad_r2d2_learner* learner, const float* priv_s, const void* priv_s_bf16, const float* legal_move, const int64_t* a, const float* reward,
                        const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
                        float pred_weight, float* loss, float* priority, int want_grad, void* stream);
 /* (loss * weight).mean().backward(): BPTT into hsad_r2d2_learner_grad; the batch given to loss_fwd must still be alive */

@@ -99,6 +99,8 @@ def test_actor_priorities_from_cached_q_equal_compute_priority_bit_for_bit(metho
     # the greedy action act() hands out is the argmax compute_priority would recompute on (next_obs, next_hid)
     agent = tr.actor.agent
     obs = tr.actor._rows()
+    assert tr.actor.packed_obs and "priv_s" not in obs       # the loop above ran on the env's packed observation outputs
+    obs["priv_s"] = obs["priv_s_bf16"][:, :tr.env.F].float().contiguous()
     hid = {k: v.clone() for k, v in tr.actor.hid.items()}
     reply, _ = agent.act(dict(obs, eps=torch.zeros_like(obs["eps"])), hid)
     z = torch.zeros(tr.actor.E, device="cuda:0")

@@ -40,6 +40,25 @@ def _cmp(name, dev, ref, it):
             name, it, len(bad), bad[0], dev[tuple(bad[0])], np.asarray(ref)[tuple(bad[0])]))
 
 
+def _bits(t, n):
+    raw = np.ascontiguousarray(t.cpu().numpy()).view(np.uint8).reshape(tuple(t.shape) + (8,))
+    b = np.unpackbits(raw, axis=-1, bitorder="little").reshape(tuple(t.shape[:-1]) + (-1,))
+    return b[..., :n], b[..., n:]
+
+
+def _cmp_packed(dev, r_priv, r_legal, r_own, it, tag):
+    """the device-consumer outputs (hsad_env_bind_packed) decode to exactly the oracle's float32 rows"""
+    F, A, O = r_priv.shape[-1], r_legal.shape[-1], r_own.shape[-1]
+    got, rest = _bits(dev.priv_bits, F)
+    assert np.array_equal(got, r_priv) and not rest.any(), "%s priv_bits differ at iteration %d" % (tag, it)
+    b16 = dev.priv_s_bf16.float().cpu().numpy()
+    assert np.array_equal(b16[..., :F], r_priv) and not b16[..., F:].any(), "%s priv_s_bf16 differs at iteration %d" % (tag, it)
+    got, rest = _bits(dev.legal_bits.unsqueeze(-1), A)
+    assert np.array_equal(got, r_legal) and not rest.any(), "%s legal_bits differ at iteration %d" % (tag, it)
+    got, rest = _bits(dev.own_bits.unsqueeze(-1), O)
+    assert np.array_equal(got, r_own) and not rest.any(), "%s own_bits differ at iteration %d" % (tag, it)
+
+
 # both kernel shapes (hsad_env_config.games_per_workgroup): the automatic choice picks 32-game workgroups for every G a CPU
 # oracle can follow, so the 64-game instantiations -- what production sizes (>= 32,768 games) run -- are forced explicitly
 GPW = [32, 64]
@@ -59,6 +78,9 @@ def test_env_bit_parity(cfg, gpw):
     refs = [OracleEnv(seed=seed + g, eps_list=EPS, **cfg) for g in range(G)]
     P, F, A, H = dev.P, dev.F, dev.A, dev.H
     assert (F, A) == (refs[0].F, refs[0].A)
+    packed = cfg["knowledge_mode"] == 0
+    if packed:   # bit words + bf16 rows next to the float32 tensors, all checked against the oracle
+        dev.enable_packed((F + 63) // 64 * 64, keep_float32=True)
     r_priv = np.zeros((G, P, F), np.float32)
     r_legal = np.zeros((G, P, A), np.float32)
     r_own = np.zeros((G, P, 3 * H), np.float32)
@@ -80,6 +102,8 @@ def test_env_bit_parity(cfg, gpw):
         _cmp("reset legal_move", dev.legal_move, r_legal, it)
         _cmp("reset own_hand", dev.own_hand, r_own, it)
         _cmp("reset eps", dev.eps, r_eps, it)
+        if packed:
+            _cmp_packed(dev, r_priv, r_legal, r_own, it, "reset")
         a, ga = dev.policy_random(pseed)
         for g, e in enumerate(refs):
             r_a[g], r_g[g] = policy_random(r_legal[g], pseed, g, int(counters[g]))
@@ -101,6 +125,8 @@ def test_env_bit_parity(cfg, gpw):
         _cmp("step eps", dev.eps, r_eps, it)
         _cmp("step reward", dev.reward, r_rew, it)
         _cmp("step terminal", dev.terminal, r_term, it)
+        if packed:
+            _cmp_packed(dev, r_priv, r_legal, r_own, it, "step")
         r_state = np.stack([e.export_state() for e in refs])
         _cmp("state dump", dev.export_state(), r_state, it)
         q = dev.query().cpu().numpy()
@@ -113,6 +139,46 @@ def test_env_bit_parity(cfg, gpw):
     for g, e in enumerate(refs):
         ref_dh = e.deck_history()
         assert cnt[g] == len(ref_dh) and list(dh[g, :cnt[g]]) == ref_dh
+
+
+@pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
+@pytest.mark.parametrize("cfg", [CONFIGS[1], CONFIGS[4]], ids=["p2h5", "p5h4"])
+def test_env_packed_outputs_without_the_float32_observation(cfg, gpw):
+    """keep_float32=False (what the actor loop runs): the observation only leaves the chip as bit words and bf16 rows, and they
+    still decode to the oracle's rows; V0-belief observations are refused"""
+    from hanabi_sad_amd import BatchedHanabiEnv, HsadError
+    cfg = dict(cfg)
+    G, iters = cfg.pop("G"), 50
+    cfg.pop("iters")
+    dev = BatchedHanabiEnv(G, seed=4242, eps_list=EPS, device="cuda:0", games_per_workgroup=gpw, **cfg)
+    dev.enable_packed((dev.F + 63) // 64 * 64 + 64, keep_float32=False)     # a longer row than needed: padding stays zero
+    assert dev.priv_s is None
+    refs = [OracleEnv(seed=4242 + g, eps_list=EPS, **cfg) for g in range(G)]
+    P, F, A, H = dev.P, dev.F, dev.A, dev.H
+    r_priv, r_legal, r_own = np.zeros((G, P, F), np.float32), np.zeros((G, P, A), np.float32), np.zeros((G, P, 3 * H), np.float32)
+    counters = np.zeros((G,), np.int64)
+    for it in range(iters):
+        dev.reset()
+        for g, e in enumerate(refs):
+            if e.terminated():
+                o = e.reset()
+                r_priv[g], r_legal[g], r_own[g] = o["priv_s"], o["legal_move"], o["own_hand"]
+        _cmp_packed(dev, r_priv, r_legal, r_own, it, "reset")
+        a, ga = dev.policy_random(5)
+        a_h, g_h = a.cpu().numpy(), ga.cpu().numpy()
+        dev.step(a, ga)
+        for g, e in enumerate(refs):
+            ra, rg = policy_random(r_legal[g], 5, g, int(counters[g]))
+            counters[g] += 1
+            assert np.array_equal(ra, a_h[g]) and np.array_equal(rg, g_h[g])
+            o, _, _ = e.step(ra, rg)
+            r_priv[g], r_legal[g], r_own[g] = o["priv_s"], o["legal_move"], o["own_hand"]
+            e.terminated()
+        dev.check_errors()
+        _cmp_packed(dev, r_priv, r_legal, r_own, it, "step")
+    v0 = BatchedHanabiEnv(4, seed=1, eps_list=EPS, device="cuda:0", knowledge_mode=1)
+    with pytest.raises(HsadError):
+        v0.enable_packed(896)
 
 
 def test_illegal_move_is_reported_not_applied():
