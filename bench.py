@@ -169,7 +169,24 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     dt = (time.perf_counter() - t0) / steps
     tr.env.check_errors()
     tr.replay.check_errors()
+    # one whole learner iteration on the sequences the rollout just produced (selfplay.py:208-244): prioritized sample out of the
+    # bit-packed replay (observation expanded straight to the bf16 GEMM operand) -> loss fwd + BPTT -> clip + Adam -> priorities
+    # aggregated and written back
+    it_ms = None
+    if tr.replay.size() >= args.batchsize:
+        for _ in range(3):
+            tr.learner_update()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            tr.learner_update()
+        torch.cuda.synchronize()
+        it_ms = (time.perf_counter() - t1) / 20 * 1e3
+        tr.learner.check_sync()
+        tr.replay.check_errors()
     out = {"value": games * 2 / dt, "unit": "acts/s", "ms_per_step": dt * 1e3, "game_steps_per_sec": games / dt,
+           "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
+           "observation_path": "packed (bit words + bf16 rows from the env kernel)" if tr.actor.packed_obs else "float32",
            "config": {"workload": "%d concurrent 2-player SAD games, IQL R2D2 agent (F=838 A=21 H=512 L=2) in the loop, n-step 3, "
                                   "max_len 80, priorities from online+target nets, finished sequences flushed into a "
                                   "65,536-sequence device replay" % games}}

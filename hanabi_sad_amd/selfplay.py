@@ -80,6 +80,11 @@ class Trainer:
         # the reference's capacity is split evenly over the per-GPU shards
         self.replay = DeviceReplay(max(args.batchsize, args.replay_buffer_size // world), args.seed + rank,
                                    args.priority_exponent, args.priority_weight, args.prefetch, args.max_len, fields, device)
+        # the learner's first GEMM reads the observation as zero-padded bf16 rows: have the sampler expand the stored bits into
+        # exactly that (no float32 batch, no cast pass)
+        self.bf16_batch = composite and self.env.knowledge_mode == 0
+        if self.bf16_batch:
+            self.replay.set_field_output("priv_s", "bf16", self.act_online.Fp)
         from .dist import ShardedReplay
         self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0)
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
@@ -121,12 +126,13 @@ class Trainer:
             self.num_update += 1
             return None, None
         (f, reward, terminal, bootstrap, seq_len), weight = res
+        pk = "priv_s_bf16" if self.bf16_batch else "priv_s"       # bf16: [T, B, P | 1, in_dim_padded] as sampled
         if self.vdn:    # [T, B, P*w] -> [T, B, P, w]
             P_, v4 = self.env.P, lambda t: t.view(t.shape[0], t.shape[1], self.env.P, -1)
-            batch = {"priv_s": v4(f["priv_s"]), "legal_move": v4(f["legal_move"]), "a": f["a"], "reward": reward,
+            batch = {pk: v4(f["priv_s"]), "legal_move": v4(f["legal_move"]), "a": f["a"], "reward": reward,
                      "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": v4(f["own_hand"])}
         else:
-            batch = {"priv_s": f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
+            batch = {pk: f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
                      "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)

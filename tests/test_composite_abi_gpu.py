@@ -189,3 +189,50 @@ def test_composite_learner_equals_python_orchestration_bit_for_bit_at_the_baseli
             pl.sync_target_with_online()
     check_sync()
     cl.check_sync()
+
+
+def test_bf16_observation_operands_give_the_same_bits_as_float32_inputs():
+    """priv_s_bf16 (what hsad_env_bind_packed / the bit-field sampler hand over): a 0/1 observation is exact in bf16, so act()
+    and the learner step must return the same bits as with the float32 tensor, minus the cast pass"""
+    from hanabi_sad_amd.composite import CNet, CompositeAgent, CompositeLearner
+    from hanabi_sad_amd.selfplay import init_weights
+    from tests.test_r2d2_kernels_gpu import _rand_batch
+    F, H, A, N = 838, 512, 21, 2048
+    W, Wt = init_weights(F, H, A, 5, 1), init_weights(F, H, A, 5, 2)
+    on, tg = CNet(W, DEV), CNet(Wt, DEV)
+    assert on.Fp == 896
+    g = torch.Generator(device="cpu").manual_seed(5)
+    priv = (torch.rand(N, F, generator=g) < 0.15).float().to(DEV)
+    p16 = torch.zeros(N, on.Fp, dtype=torch.bfloat16, device=DEV)
+    p16[:, :F] = priv
+    legal = (torch.rand(N, A, generator=g) < 0.5).float().to(DEV)
+    legal[:, 0] = 1
+    eps = torch.full((N,), 0.3, device=DEV)
+    hid = {"h0": (torch.randn(2, N, H, generator=g) * 0.3).to(DEV), "c0": (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)}
+    r32, h32 = CompositeAgent(on, tg, 3, 0.999, seed=1).act({"priv_s": priv, "legal_move": legal, "eps": eps}, hid, with_q=True)
+    r16, h16 = CompositeAgent(on, tg, 3, 0.999, seed=1).act({"priv_s_bf16": p16, "legal_move": legal, "eps": eps}, hid, with_q=True)
+    for k in ("a", "greedy_a", "q_online_a", "q_target_greedy"):
+        assert torch.equal(r32[k], r16[k]), k
+    assert torch.equal(h32["h0"], h16["h0"]) and torch.equal(h32["c0"], h16["c0"])
+    with pytest.raises(Exception):
+        CompositeAgent(on, tg, 3, 0.999).act({"priv_s_bf16": p16[:, :F].contiguous(), "legal_move": legal, "eps": eps}, hid)
+
+    T, B = 80, 128
+    batch, weight = _rand_batch(T, B, F, A)
+    batch["priv_s"] = (batch["priv_s"] > 0.8).float()
+    b16 = dict(batch)
+    del b16["priv_s"]
+    b16["priv_s_bf16"] = torch.zeros(T, B, 1, 896, dtype=torch.bfloat16, device=DEV)
+    b16["priv_s_bf16"][:, :, 0, :F] = batch["priv_s"]
+    la = CompositeLearner(W, Wt, 3, 0.999, lr=1e-3, device=DEV)
+    lb = CompositeLearner(W, Wt, 3, 0.999, lr=1e-3, device=DEV)
+    l1, p1 = la.loss(batch, weight, 0.25)
+    l2, p2 = lb.loss(b16, weight, 0.25)
+    assert torch.equal(l1, l2) and torch.equal(p1, p2)
+    for k in la.grad:
+        if k.startswith("lstm.weight"):
+            assert torch.equal(la.grad[k], lb.grad[k]), k
+        else:
+            assert relerr(la.grad[k], lb.grad[k]) < 1e-5, k
+    la.check_sync()
+    lb.check_sync()
