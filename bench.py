@@ -18,6 +18,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -195,6 +196,63 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     return out
 
 
+def exchange_bench(dev, rank, world, rounds=60, batch=128):
+    """--gpus N > 1: the learner <-> actor exchange of a multi-GPU self-play job (hanabi_sad_amd/dist.py ReplayLink) over RCCL, timed
+    per section with HIP events on the learner's exchange stream.  Rank 0 is the dedicated learner (empty shard), every other rank
+    an actor whose shard holds 2,048 synthetic 80-step sequences in the real transition layout (2p SAD: bit-packed 838-plane
+    observation); a parameter round ([online | target] = 2 x 4.9 M floats) every 10th round.  Collective: every rank calls it."""
+    from types import SimpleNamespace
+    from hanabi_sad_amd.actor import transition_fields
+    from hanabi_sad_amd.dist import ReplayLink
+    from hanabi_sad_amd.replay import DeviceReplay
+    T, n_seq, n_param = 80, 2048, 2 * 4_883_000
+    fields = transition_fields(SimpleNamespace(P=2, F=838, A=21, H=5, knowledge_mode=0), vdn=False)
+    shard = DeviceReplay(4096, 100 + rank, 0.9, 0.6, 0, T, fields, dev)
+    if rank != 0:
+        g = torch.Generator(device=dev).manual_seed(rank)
+        for lo in range(0, n_seq, 256):
+            n = 256
+            f = {"priv_s": (torch.rand(n, T, 838, device=dev, generator=g) < 0.15).float(),
+                 "legal_move": (torch.rand(n, T, 21, device=dev, generator=g) < 0.4).float(),
+                 "eps": torch.rand(n, T, 1, device=dev, generator=g), "own_hand": torch.zeros(n, T, 15, device=dev),
+                 "a": torch.zeros(n, T, 1, dtype=torch.int64, device=dev), "greedy_a": torch.zeros(n, T, 1, dtype=torch.int64, device=dev)}
+            z = torch.zeros(n, T, device=dev)
+            shard.add(f, z, z.to(torch.uint8), z + 1, torch.full((n,), float(T), device=dev), torch.rand(n, device=dev, generator=g) + 0.1)
+    shard.set_field_output("priv_s", "bf16", 896)
+    link = ReplayLink(shard, batch, 0.6, dev, learner_rank=0, depth=2, param_numel=n_param)
+    torch.cuda.synchronize()
+    out = None
+    if rank == 0:
+        prios = []
+        link.stage_params(torch.zeros(n_param, device=dev))
+        t0 = None
+        for r in range(rounds + 5):
+            if r == 5:                      # five warm-up rounds (communicator set-up, first-touch allocations)
+                torch.cuda.synchronize()
+                link.timer = type(link.timer)(dev)
+                t0 = time.perf_counter()
+            link.begin(prios.pop(0) if len(prios) >= 2 else None, params=(r % 10 == 5), stop=(r == rounds + 4))
+            (f, *_), w = link.finish()
+            prios.append(torch.rand(batch, device=dev) + 0.05)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / rounds * 1e3
+        out = {"world": world, "rounds": rounds, "batch": batch, "wire_bytes_per_sequence": shard.wire_bytes(),
+               "batch_bytes_per_rank_message": shard.wire_bytes() * batch, "param_bucket_bytes": n_param * 4,
+               "round_wall_ms": wall, "per_round_ms": link.timings(),
+               "note": "sections are HIP-event times on the learner's exchange stream, averaged over all rounds (param_bcast_ms: "
+                       "the parameter rounds' time spread over all rounds); actors serve a round between two polls of the store"}
+    else:
+        while True:
+            flags = link.poll()
+            if flags is None:
+                continue
+            if link.serve(flags):
+                break
+        torch.cuda.synchronize()
+    shard.check_errors()
+    return out
+
+
 def cpu_baseline(seconds=8.0):
     """The CPU oracle (port of the reference algorithm; the reference binary is unbuildable here: HLE
     submodule absent) in the reference's config-1 shape: 1 thread, 80 games, max_len 80, random policy."""
@@ -344,6 +402,13 @@ def main():
     achieved = bytes_per_step * G / (iter_ms * 1e-3) / 1e9        # all concurrent launches together = the chip's rate
     per_launch = bytes_per_step * (G / K) * iters_per_launch / (fused_ms * 1e-3) / 1e9
 
+    exchange = None
+    if world > 1 and not os.environ.get("HSAD_BENCH_NO_EXCHANGE"):
+        env_dims = (env.P, env.F, env.A, env.H)
+        del env
+        torch.cuda.empty_cache()
+        exchange = exchange_bench(dev, rank, world)
+        env = SimpleNamespace(P=env_dims[0], F=env_dims[1], A=env_dims[2], H=env_dims[3])
     if rank == 0:
         out = {
             "metric": "hanabi_env_steps_per_sec",
@@ -393,6 +458,8 @@ def main():
                 "event_pair_ms": step_raw_ms, "empty_event_pair_ms": pair_overhead_ms,
             },
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and not args.no_learner:
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:

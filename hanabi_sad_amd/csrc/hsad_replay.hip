@@ -192,17 +192,9 @@ inline FieldOut field_out(const RowLayout& L, void* const* ptrs, const int* kind
   return fo;
 }
 
-// rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
-// or, with ids == nullptr, row index base_row + b (T must be 1 then) .
-__global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldOut dst, int B, int T,
-                                                          const int* __restrict__ ids, int base_row,
-                                                          const int* __restrict__ valid_rows = nullptr) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // = t*B + b
-  if (row >= B * T) return;
-  const int t = row / B, b = row - t * B;
-  const size_t src_row = ids ? ((size_t)ids[b] * T + t) : ((size_t)base_row + b);
-  const bool pad = valid_rows && ids && t >= valid_rows[ids[b]];   // a step after the stored ones: all-zero fields
-  const unsigned char* s = rows + src_row * L.row_bytes;
+// one stored row -> the caller's field tensors at output row `row` (pad: a step after the stored ones, all-zero fields)
+__device__ __forceinline__ void unpack_one_row(const RowLayout& L, const unsigned char* s, const FieldOut& dst, int row, int lane,
+                                               bool pad) {
   for (int k = 0; k < L.n_fields; ++k) {
     if (!dst.p[k]) continue;
     if (L.esize[k] == 0 && dst.kind[k] == BITS_F32) {
@@ -214,6 +206,161 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const uns
     } else {
       const int nbytes = L.nbytes[k];
       copy_bytes_wave(static_cast<unsigned char*>(dst.p[k]) + (size_t)row * nbytes, s + L.offset[k], nbytes, lane, pad);
+    }
+  }
+}
+
+// rows -> fields.  Output element (t, b) (layout [T][B][w]) <- rows[slot(b)][t]; slot from ids[] (ring slots)
+// or, with ids == nullptr, row index base_row + b (T must be 1 then) .
+__global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const unsigned char* rows, FieldOut dst, int B, int T,
+                                                          const int* __restrict__ ids, int base_row,
+                                                          const int* __restrict__ valid_rows = nullptr) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // = t*B + b
+  if (row >= B * T) return;
+  const int t = row / B, b = row - t * B;
+  const size_t src_row = ids ? ((size_t)ids[b] * T + t) : ((size_t)base_row + b);
+  const bool pad = valid_rows && ids && t >= valid_rows[ids[b]];   // a step after the stored ones: all-zero fields
+  unpack_one_row(L, rows + src_row * L.row_bytes, dst, row, lane, pad);
+}
+
+// ---- sharded draw (one shard per GPU) entirely on the device: no host round trip between the gathered shard
+// statistics and the rows going out, so an actor rank can serve a learner's request between two of its own steps ----------------
+
+// The reference's stratified positions over the CONCATENATION of the shards (prioritized_replay.h:300-305 in float32, as
+// dist.stratified_positions) cut into per-shard targets (dist.split_positions): owner[i] = first shard whose inclusive weight
+// prefix reaches position i (never an empty shard), local target = position minus the weight of the shards before it.  The
+// positions this rank owns are compacted (they form one contiguous run, positions ascend) into local_mine[0 .. *n_mine).
+__global__ __launch_bounds__(1024) void shard_targets_kernel(const double* __restrict__ stats, int world, int rank,
+                                                             const float* __restrict__ canon, int B, int* __restrict__ owner,
+                                                             float* __restrict__ local_mine, int* __restrict__ n_mine) {
+  __shared__ double s_incl[64];
+  __shared__ int s_wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    double acc = 0.0;
+    for (int k = 0; k < world; ++k) {
+      acc += stats[2 * k];
+      s_incl[k] = acc;
+    }
+  }
+  __syncthreads();
+  const float total = (float)s_incl[world - 1];
+  const float seg = total / (float)B;
+  int own = -1;
+  float local = 0.f;
+  if (tid < B) {
+    const float r = canon[tid] * seg + (float)tid * seg;
+    const float pos = fminf(total - 0.1f, r);
+    int k = 0;
+    while (k < world - 1 && s_incl[k] < (double)pos) ++k;       // searchsorted(incl, pos, side="left"), clamped
+    auto sum_of = [&](int j) { return s_incl[j] - (j > 0 ? s_incl[j - 1] : 0.0); };
+    if (sum_of(k) <= 0.0) {                                      // never hand a position to an empty shard: the nearest non-empty one
+      int best = -1;
+      for (int j = 0; j < world; ++j)
+        if (sum_of(j) > 0.0 && (best < 0 || abs(j - k) < abs(best - k))) best = j;
+      k = best < 0 ? k : best;
+    }
+    own = k;
+    local = fmaxf((float)((double)pos - (k > 0 ? s_incl[k - 1] : 0.0)), 0.f);
+    owner[tid] = own;
+  }
+  const bool mine = own == rank;
+  const unsigned long long m = __ballot(mine);
+  if (lane == 0) s_wtot[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += s_wtot[w];
+  if (mine) local_mine[off + __popcll(m & ((1ull << lane) - 1ull))] = local;
+  if (tid == 0) {
+    int n = 0;
+    for (int w = 0; w < 16; ++w) n += s_wtot[w];
+    *n_mine = n;
+  }
+}
+
+// priorities of a whole batch -> the (contiguous) run of them that belongs to this rank's shard
+__global__ __launch_bounds__(1024) void compact_owned_kernel(const float* __restrict__ priority, const int* __restrict__ owner, int B,
+                                                             int rank, float* __restrict__ out, int* __restrict__ n_out) {
+  __shared__ int s_wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool mine = tid < B && owner[tid] == rank;
+  const unsigned long long m = __ballot(mine);
+  if (lane == 0) s_wtot[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += s_wtot[w];
+  if (mine) out[off + __popcll(m & ((1ull << lane) - 1ull))] = priority[tid];
+  if (tid == 0) {
+    int n = 0;
+    for (int w = 0; w < 16; ++w) n += s_wtot[w];
+    *n_out = n;
+  }
+}
+
+// wire format of one sampled sequence (what travels to the learner, hsad_replay_wire_bytes): T stored rows as they lie in the
+// ring (bit-packed observation included; steps after the episode zeroed) | reward f32 [T] | bootstrap f32 [T] | terminal u8 [T]
+// (padded to 4) | seq_len f32 | raw weight f32 -- rounded up to 16 bytes
+struct WireLayout {
+  int row_bytes, T, off_reward, off_bootstrap, off_terminal, off_tail, slot_bytes;
+};
+inline WireLayout wire_layout(const RowLayout& L, int T) {
+  WireLayout w;
+  w.row_bytes = L.row_bytes;
+  w.T = T;
+  w.off_reward = T * L.row_bytes;
+  w.off_bootstrap = w.off_reward + 4 * T;
+  w.off_terminal = w.off_bootstrap + 4 * T;
+  w.off_tail = w.off_terminal + ((T + 3) & ~3);
+  w.slot_bytes = (w.off_tail + 8 + 15) & ~15;
+  return w;
+}
+
+// slot j < *n_mine of this rank's wire buffer <- the j-th sequence of the draw just made (one wavefront per (j, t))
+__global__ __launch_bounds__(256) void wire_pack_kernel(WireLayout W, const unsigned char* __restrict__ rows, const int* __restrict__ ids,
+                                                        const int* __restrict__ n_dev, const int* __restrict__ valid_rows,
+                                                        const float* __restrict__ reward, const unsigned char* __restrict__ terminal,
+                                                        const float* __restrict__ bootstrap, const float* __restrict__ seq_len,
+                                                        const float* __restrict__ raw_w, unsigned char* __restrict__ wire, int B) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * W.T) return;
+  const int j = row / W.T, t = row - j * W.T;
+  if (j >= *n_dev) return;
+  const int id = ids[j];
+  const bool pad = t >= valid_rows[id];
+  unsigned char* slot = wire + (size_t)j * W.slot_bytes;
+  copy_bytes_wave(slot + (size_t)t * W.row_bytes, rows + ((size_t)id * W.T + t) * W.row_bytes, W.row_bytes, lane, pad);
+  if (lane == 0) {
+    const size_t s = (size_t)id * W.T + t;
+    reinterpret_cast<float*>(slot + W.off_reward)[t] = pad ? 0.f : reward[s];
+    reinterpret_cast<float*>(slot + W.off_bootstrap)[t] = pad ? 0.f : bootstrap[s];
+    slot[W.off_terminal + t] = pad ? (unsigned char)1 : terminal[s];
+    if (t == 0) {
+      reinterpret_cast<float*>(slot + W.off_tail)[0] = seq_len[id];
+      reinterpret_cast<float*>(slot + W.off_tail)[1] = raw_w[j];
+    }
+  }
+}
+
+// learner: batch position b came from rank owner[b], slot b - (number of positions owned by lower ranks)
+__global__ __launch_bounds__(256) void wire_unpack_kernel(RowLayout L, WireLayout W, const unsigned char* __restrict__ wire_all,
+                                                          const int* __restrict__ owner, int B, FieldOut dst, float* o_reward,
+                                                          unsigned char* o_terminal, float* o_bootstrap, float* o_seq_len,
+                                                          float* o_raw_w) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // = t*B + b
+  if (row >= B * W.T) return;
+  const int t = row / B, b = row - t * B;
+  const int k = owner[b];
+  int first = b;
+  while (first > 0 && owner[first - 1] == k) --first;          // runs are contiguous; B <= 1024
+  const unsigned char* slot = wire_all + ((size_t)k * B + (b - first)) * W.slot_bytes;
+  unpack_one_row(L, slot + (size_t)t * W.row_bytes, dst, row, lane, false);
+  if (lane == 0) {
+    if (o_reward) o_reward[row] = reinterpret_cast<const float*>(slot + W.off_reward)[t];
+    if (o_bootstrap) o_bootstrap[row] = reinterpret_cast<const float*>(slot + W.off_bootstrap)[t];
+    if (o_terminal) o_terminal[row] = slot[W.off_terminal + t];
+    if (t == 0) {
+      if (o_seq_len) o_seq_len[b] = reinterpret_cast<const float*>(slot + W.off_tail)[0];
+      if (o_raw_w) o_raw_w[b] = reinterpret_cast<const float*>(slot + W.off_tail)[1];
     }
   }
 }
@@ -262,6 +409,13 @@ struct ReplayDev {
   int depth;  // outstanding draws kept (1 = the strict sample / update alternation)
   float alpha, beta;
 };
+
+__global__ void replay_stats_kernel(ReplayDev rd, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = rd.ctl->sum;
+    out[1] = (double)rd.ctl->size;
+  }
+}
 
 // priority^alpha.  std::pow(x, 1.0f) returns x exactly on the host; the device powf is only accurate to an ulp, so alpha = 1
 // is taken literally (keeps dyadic test priorities and the running sum exact)
@@ -359,7 +513,9 @@ __global__ void replay_add_scalars_kernel(ReplayDev rd, int n, int T, const floa
 // shards before it); weight_out then receives the raw weights w_i and the caller forms the global IS weights.
 __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B, const float* __restrict__ canon,
                                                              float* __restrict__ weight_out,
-                                                             const float* __restrict__ targets = nullptr) {
+                                                             const float* __restrict__ targets = nullptr,
+                                                             const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) B = *n_dev;   // sharded draw: the number of positions that fell into this shard is only known on the device
   __shared__ double s_incl[1024];
   __shared__ double s_red[1024];
   __shared__ float s_rand[kMaxBatch];
@@ -481,7 +637,9 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
 // old weights and pow() are fetched / computed by B threads at once (the one-thread loop was 128 dependent global round
 // trips = 155 us); each element then finds the latest earlier occurrence of its id, which gives it the same "current
 // weight" the sequential loop would have read, so every float difference is the same, and thread 0 adds them in order.
-__global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B, const float* __restrict__ priority) {
+__global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B, const float* __restrict__ priority,
+                                                             const int* __restrict__ n_dev = nullptr) {
+  if (n_dev) B = *n_dev;
   __shared__ int s_id[kMaxBatch];
   __shared__ float s_w[kMaxBatch];
   __shared__ float s_diff[kMaxBatch];
@@ -769,6 +927,7 @@ struct hsad_replay {
   hipEvent_t canon_ev[kCanonSlots] = {};
   int canon_next = 0;
   int* d_tmp_id;
+  float* d_shard = nullptr;  // sharded draw scratch: compacted priorities [kMaxBatch] | raw weights [kMaxBatch] | counts (2 ints)
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
   int out_ld[kMaxFields] = {};
   std::mt19937 rng;
@@ -846,6 +1005,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
       (he = alloc((void**)&rd.sampled_w, kMaxBatch * 4)) != hipSuccess ||
       (he = alloc((void**)&rd.valid_rows, ring * 4)) != hipSuccess ||
       (he = alloc((void**)&r->d_canon, kMaxBatch * 4)) != hipSuccess ||
+      (he = alloc((void**)&r->d_shard, 2 * kMaxBatch * 4 + 16)) != hipSuccess ||
       (he = alloc((void**)&r->d_tmp_id, 16)) != hipSuccess) {
     rfail(HSAD_ERR_NOMEM, "hipMalloc failed for the replay (%zu B so far): %s", total, hipGetErrorString(he));
     hsad_replay_destroy(r);
@@ -872,7 +1032,7 @@ void hsad_replay_destroy(hsad_replay* r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
   void* ptrs[] = {r->rows, r->reward, r->terminal, r->bootstrap, r->seq_len, r->rd.weights, r->rd.evicted, r->rd.ctl,
-                  r->rd.sampled_ids, r->rd.q_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id};
+                  r->rd.sampled_ids, r->rd.q_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id, r->d_shard};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (hipEvent_t e : r->canon_ev)
@@ -987,6 +1147,57 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
   if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
   r->last_stream = (hipStream_t)stream;
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// ---- the sharded draw without host round trips (kernels above; choreography: hanabi_sad_amd/dist.py ReplayLink) ----
+int hsad_replay_stats(hsad_replay* r, double* out2, void* stream) {
+  if (!r || !out2) return rfail(HSAD_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(replay_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->rd, out2);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_wire_bytes(const hsad_replay* r) { return r ? wire_layout(r->L, r->T).slot_bytes : 0; }
+
+int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const double* all_stats, int world, int rank, int32_t* owner_out,
+                      uint8_t* wire_out, void* stream) {
+  if (!r || !canon || !all_stats || !owner_out || !wire_out) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > kMaxBatch || world < 1 || world > 64 || rank < 0 || rank >= world)
+    return rfail(HSAD_ERR_INVALID, "serve: batch 1..%d, world 1..64, rank inside it", kMaxBatch);
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  float* raw_w = r->d_shard + kMaxBatch;
+  int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch);
+  hipLaunchKernelGGL(shard_targets_kernel, dim3(1), dim3(1024), 0, s, all_stats, world, rank, canon, batch, owner_out, r->d_canon, n_mine);
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, raw_w, r->d_canon, n_mine);
+  const WireLayout W = wire_layout(r->L, r->T);
+  hipLaunchKernelGGL(wire_pack_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, W, r->rows, r->rd.sampled_ids, n_mine, r->rd.valid_rows,
+                     r->reward, r->terminal, r->bootstrap, r->seq_len, raw_w, wire_out, batch);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, const int32_t* owner, int rank, void* stream) {
+  if (!r || !priority || !owner) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad batch");
+  hipStream_t s = (hipStream_t)stream;
+  r->last_stream = s;
+  int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch) + 1;
+  hipLaunchKernelGGL(compact_owned_kernel, dim3(1), dim3(1024), 0, s, priority, owner, batch, rank, r->d_shard, n_mine);
+  hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_shard, n_mine);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_replay_assemble(hsad_replay* r, int batch, int world, const uint8_t* wire_all, const int32_t* owner, void* const* out_fields,
+                         float* reward, uint8_t* terminal, float* bootstrap, float* seq_len, float* raw_weight, void* stream) {
+  if (!r || !wire_all || !owner || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > kMaxBatch || world < 1) return rfail(HSAD_ERR_INVALID, "bad batch / world");
+  const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
+  hipLaunchKernelGGL(wire_unpack_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, (hipStream_t)stream, r->L, wire_layout(r->L, r->T),
+                     wire_all, owner, batch, fp, reward, terminal, bootstrap, seq_len, raw_weight);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -220,3 +220,239 @@ class ShardedReplay:
             if n_mine > 0:
                 dist.recv(part, src=self.learner)
             self.shard.update_priority(part.to(self.device))
+
+
+def _default_store():
+    """the rendezvous store of the default process group (a TCPStore under torchrun): the host-side signalling channel of ReplayLink"""
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+class _Timer:
+    """per-section time of the learner's side of a round: HIP events on the exchange stream (read one round late, so reading never
+    waits) or perf_counter on the host (gloo / CPU tests)"""
+
+    def __init__(self, device):
+        self.cuda = torch.device(device).type == "cuda"
+        self.ms, self.n, self.pending = {}, 0, None
+        self.marks = []
+
+    def start(self):
+        self._flush()
+        self.marks = []
+        self.mark(None)
+
+    def mark(self, name):
+        if self.cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+        else:
+            import time
+            self.marks.append((name, time.perf_counter()))
+
+    def stop(self):
+        self.pending, self.marks = self.marks, []
+
+    def _flush(self):
+        if not self.pending:
+            return
+        if self.cuda and not self.pending[-1][1].query():
+            return                       # still in flight: keep it for the next call
+        for (_, a), (name, b) in zip(self.pending[:-1], self.pending[1:]):
+            dt = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+            self.ms[name] = self.ms.get(name, 0.0) + dt
+        self.n += 1
+        self.pending = None
+
+    def summary(self):
+        self._flush()
+        return {k: v / max(self.n, 1) for k, v in self.ms.items()}
+
+
+class ReplayLink:
+    """The learner <-> actors exchange of a multi-GPU job, asynchronous and packed (the reference's
+    PrioritizedReplay::sample / updatePriority + BatchRunner::updateModel across processes: rela/prioritized_replay.h:208-257,
+    rela/batch_runner.h:74-77).  One prioritized-replay shard per rank behaves, for the learner, like ONE buffer over the
+    concatenation of the shards, but
+
+      * actors never wait for the learner's compute.  A round is opened by the learner BEFORE it issues the kernels of the update
+        in flight (`begin`), and runs on a side stream there; actor ranks notice it by polling a counter in the rendezvous store
+        between two of their own steps (`poll`) and serve it from their stream (`serve`) -- a header broadcast, a 16-byte-per-rank
+        all-gather, two small kernels and one send.
+      * the priorities of batch k travel in the header of a LATER round (k + 2 when rounds are pipelined like that), next to the
+        canonical uniforms of the new draw: no separate scatter, no message per shard.  Shards keep their drawn batches in a
+        queue and answer the oldest (hsad_replay_set_outstanding = the reference's prefetch depth: its prefetched batches are
+        drawn before the priorities of the batches in training are written back, too).
+      * nothing on an actor rank reads device memory from the host: shard statistics, stratification, ownership, the draw and the
+        packing of the rows are kernels (hsad_replay_stats / _serve / _update_owned); message sizes are fixed ([B] slots of
+        hsad_replay_wire_bytes: stored rows with the bit-packed observation, ~13 KB per sequence), so no size ever has to be known.
+      * every rank sends ONE buffer per round (gather to the learner = one grouped send / recv in RCCL); the learner unpacks all
+        of them with one kernel (hsad_replay_assemble) straight into the batch tensors (bf16 observation operand included).
+      * parameters go out as one persistent flat bucket [online | target], staged by the learner on its compute stream
+        (`stage_params`) and broadcast inside a round whose flags say so.
+
+    `shard`: hanabi_sad_amd.replay.DeviceReplay, or any stand-in with stats / wire_bytes / serve / answer / assemble /
+    draw_canonical / set_outstanding (the gloo CPU tests)."""
+
+    ROUND_KEY = "hsad/link/round"
+    PARAMS, STOP, HAS_PRIO = 1, 2, 4
+
+    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None):
+        import torch.distributed as dist
+        self.shard, self.B, self.beta = shard, int(batch), float(beta)
+        self.device = torch.device(device)
+        self.learner = int(learner_rank)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.is_learner = self.rank == self.learner
+        self.comm = comm_device_for(self.device)
+        self.staged = self.comm != self.device           # gloo with GPU shards (smoke runs): tensors travel through host memory
+        self.store = store if store is not None else _default_store()
+        shard.set_outstanding(depth)
+        B, wb, d = self.B, shard.wire_bytes(), self.device
+        self.hdr = torch.zeros(2 * B, dtype=torch.float32, device=d)             # canonical uniforms | priorities of an earlier batch
+        self.all_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d)
+        self.wire = torch.zeros(B, wb, dtype=torch.uint8, device=d)
+        self.wire_all = torch.zeros(self.world, B, wb, dtype=torch.uint8, device=d) if self.is_learner else None
+        self.bucket = torch.zeros(int(param_numel), dtype=torch.float32, device=d) if param_numel else None
+        self.opened = self.served = 0
+        cuda = d.type == "cuda"
+        self.xs = torch.cuda.Stream(d) if (cuda and self.is_learner) else None
+        self.hdr_host = [torch.zeros(B, dtype=torch.float32).pin_memory() if cuda else torch.zeros(B) for _ in range(4)]
+        self.hdr_ev = [None] * 4
+        self.timer = _Timer(d)
+        self._result = None
+
+    # -- transport (RCCL on the GPU; host staging only for gloo with GPU shards) --
+    def _bcast(self, t):
+        import torch.distributed as dist
+        if not self.staged:
+            dist.broadcast(t, src=self.learner)
+            return
+        h = t.cpu()
+        dist.broadcast(h, src=self.learner)
+        if not self.is_learner:
+            t.copy_(h)
+
+    def _all_gather_stats(self, mine):
+        import torch.distributed as dist
+        if not self.staged:
+            dist.all_gather_into_tensor(self.all_stats.view(-1), mine)
+            return
+        h = torch.zeros(self.world * 2, dtype=torch.float64)
+        dist.all_gather_into_tensor(h, mine.cpu())
+        self.all_stats.copy_(h.view(self.world, 2))
+
+    def _gather_wire(self):
+        import torch.distributed as dist
+        if not self.staged:
+            dist.gather(self.wire, list(self.wire_all.unbind(0)) if self.is_learner else None, dst=self.learner)
+            return
+        h = self.wire.cpu()
+        parts = [torch.empty_like(h) for _ in range(self.world)] if self.is_learner else None
+        dist.gather(h, parts, dst=self.learner)
+        if self.is_learner:
+            self.wire_all.copy_(torch.stack(parts))
+
+    # -- one round, every rank (stream-ordered on the caller's current stream) --
+    def _round(self, flags):
+        B, t = self.B, self.timer if self.is_learner else None
+        if t:
+            t.start()
+        self._bcast(self.hdr)
+        if t:
+            t.mark("header_bcast_ms")
+        if flags & self.HAS_PRIO:
+            self.shard.answer(self.hdr[B:], self.rank)
+        self._all_gather_stats(self.shard.stats())
+        if t:
+            t.mark("stats_allgather_ms")
+        owner = self.shard.serve(self.hdr[:B], self.all_stats, self.rank, self.wire)
+        if t:
+            t.mark("serve_ms")
+        self._gather_wire()
+        if t:
+            t.mark("batch_gather_ms")
+        if flags & self.PARAMS:
+            self._bcast(self.bucket)
+            if t:
+                t.mark("param_bcast_ms")
+        out = None
+        if self.is_learner:
+            batch, raw_w = self.shard.assemble(self.wire_all, owner)
+            # (N * w / sum)^-beta / max with N, sum over all shards (prioritized_replay.h:322-333), on the device
+            total = self.all_stats[:, 0].sum().to(torch.float32)
+            n_total = self.all_stats[:, 1].sum().to(torch.float32)
+            y = torch.pow(n_total * (raw_w / total), -self.beta)
+            out = (batch, y / y.max())
+            t.mark("assemble_ms")
+            t.stop()
+        self.served += 1
+        return out
+
+    # -- learner --
+    def stage_params(self, *flats):
+        """copy the parameter vectors (online, target) into the persistent bucket on the CURRENT stream; the next begin(params=True)
+        broadcasts that snapshot while later updates already change the live parameters"""
+        off = 0
+        for f in flats:
+            self.bucket[off:off + f.numel()].copy_(f.reshape(-1))
+            off += f.numel()
+
+    def begin(self, prio=None, params=False, stop=False):
+        """open a round: tell the actors (store), then run the learner's side on the exchange stream.  Call it BEFORE issuing the
+        kernels of the update that will run meanwhile; `prio` [B] = aggregated priorities of the OLDEST batch still unanswered."""
+        assert self.is_learner and self._result is None
+        flags = (self.PARAMS if params else 0) | (self.STOP if stop else 0) | (self.HAS_PRIO if prio is not None else 0)
+        r = self.opened
+        self.store.set("hsad/link/flags/%d" % r, str(flags))
+        self.store.add(self.ROUND_KEY, 1)
+        self.opened += 1
+        B, k = self.B, r % 4
+        canon = self.hdr_host[k]
+        if self.hdr_ev[k] is not None:
+            self.hdr_ev[k].synchronize()          # the copy that last read this pinned slot (four rounds ago)
+        canon.copy_(torch.from_numpy(self.shard.draw_canonical(B)))
+        if self.xs is not None:
+            self.xs.wait_stream(torch.cuda.current_stream(self.device))   # everything issued so far (the priorities, the staged bucket)
+            with torch.cuda.stream(self.xs):
+                self.hdr[:B].copy_(canon, non_blocking=True)
+                self.hdr_ev[k] = torch.cuda.Event()
+                self.hdr_ev[k].record()
+                if prio is not None:
+                    self.hdr[B:].copy_(prio)
+                self._result = self._round(flags)
+        else:
+            self.hdr[:B].copy_(canon)
+            if prio is not None:
+                self.hdr[B:].copy_(prio)
+            self._result = self._round(flags)
+
+    def finish(self):
+        """-> ((fields, reward, terminal, bootstrap, seq_len), weight) of the round opened by the last begin(); the current stream
+        waits for the exchange stream, the host does not"""
+        res, self._result = self._result, None
+        if self.xs is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_stream(self.xs)
+            (f, reward, terminal, bootstrap, seq_len), w = res
+            for x in list(f.values()) + [reward, terminal, bootstrap, seq_len, w]:
+                x.record_stream(cur)
+        return res
+
+    # -- actors --
+    def poll(self):
+        """has the learner opened a round this rank has not served yet?  -> its flags, or None.  Host-side only (one store query)"""
+        if int(self.store.add(self.ROUND_KEY, 0)) <= self.served:
+            return None
+        return int(self.store.get("hsad/link/flags/%d" % self.served))
+
+    def serve(self, flags):
+        """serve the round `poll` announced, on the current stream.  After a PARAMS round the new [online | target] parameters are in
+        self.bucket (stream-ordered)."""
+        assert not self.is_learner
+        self._round(flags)
+        return bool(flags & self.STOP)
+
+    def timings(self):
+        return self.timer.summary()

@@ -73,6 +73,7 @@ class DeviceReplay:
         self.fields = [(n, int(w), dt) for n, w, dt in fields]
         self.T = int(seq_len)
         self._out = {}
+        self._owners = []      # owner[] of the served draws that still wait for their priorities (oldest first)
         self.h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self.lib.hsad_replay_create(int(capacity), int(seed), float(alpha), float(beta), int(prefetch),
@@ -179,6 +180,52 @@ class DeviceReplay:
         _lib.check(self.lib.hsad_replay_sample_at(self.h, n, targets.ctypes.data_as(C.POINTER(C.c_float)), _ptr_array(outs),
                                                   reward.data_ptr(), terminal.data_ptr(), bootstrap.data_ptr(),
                                                   seq_len.data_ptr(), raw_w.data_ptr(), _stream(d)))
+        fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
+        return (fields, reward, terminal.bool(), bootstrap, seq_len), raw_w
+
+    # ---- the same draw without host round trips: shard interface of hanabi_sad_amd.dist.ReplayLink ----
+    def stats(self):
+        """(running weight sum, size) as a float64 [2] device tensor; stream-ordered, no synchronisation"""
+        out = torch.empty(2, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.hsad_replay_stats(self.h, out.data_ptr(), _stream(self.device)))
+        return out
+
+    def wire_bytes(self):
+        return int(self.lib.hsad_replay_wire_bytes(self.h))
+
+    def serve(self, canon, all_stats, rank, wire_out):
+        """one stratified draw over the concatenation of the shards described by all_stats [world, 2]: the positions that fall into
+        THIS shard are drawn and written, in batch order, into wire_out[0 ..] ([B, wire_bytes] uint8).  -> owner int32 [B]"""
+        B, world = int(canon.numel()), int(all_stats.shape[0])
+        assert canon.dtype == torch.float32 and all_stats.dtype == torch.float64 and canon.is_contiguous() and all_stats.is_contiguous()
+        assert wire_out.dtype == torch.uint8 and wire_out.is_contiguous() and wire_out.numel() >= B * self.wire_bytes()
+        owner = torch.empty(B, dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.hsad_replay_serve(self.h, B, canon.data_ptr(), all_stats.data_ptr(), world, int(rank), owner.data_ptr(),
+                                              wire_out.data_ptr(), _stream(self.device)))
+        self._owners.append(owner)
+        return owner
+
+    def answer(self, priority, rank):
+        """priorities [B] of the OLDEST outstanding served draw: the ones at positions this shard owned are written back"""
+        owner = self._owners.pop(0)
+        priority = priority.to(self.device, torch.float32).contiguous()
+        _lib.check(self.lib.hsad_replay_update_owned(self.h, int(priority.numel()), priority.data_ptr(), owner.data_ptr(), int(rank),
+                                                     _stream(self.device)))
+
+    def assemble(self, wire_all, owner):
+        """learner: every rank's wire buffer [world, B, wire_bytes] + the draw's owner[] -> the batch as sample() returns it, and the
+        raw weights [B] (the caller forms the importance weights over all shards)"""
+        world, B = int(wire_all.shape[0]), int(owner.numel())
+        d, T = self.device, self.T
+        outs = self._alloc_outs(B)
+        reward = torch.empty(T, B, dtype=torch.float32, device=d)
+        terminal = torch.empty(T, B, dtype=torch.uint8, device=d)
+        bootstrap = torch.empty(T, B, dtype=torch.float32, device=d)
+        seq_len = torch.empty(B, dtype=torch.float32, device=d)
+        raw_w = torch.empty(B, dtype=torch.float32, device=d)
+        _lib.check(self.lib.hsad_replay_assemble(self.h, B, world, wire_all.data_ptr(), owner.data_ptr(), _ptr_array(outs),
+                                                 reward.data_ptr(), terminal.data_ptr(), bootstrap.data_ptr(), seq_len.data_ptr(),
+                                                 raw_w.data_ptr(), _stream(d)))
         fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
         return (fields, reward, terminal.bool(), bootstrap, seq_len), raw_w
 

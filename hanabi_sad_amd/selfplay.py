@@ -52,7 +52,10 @@ class Trainer:
     def __init__(self, args, device="cuda:0", rank=0, world=1):
         self.args, self.device, self.rank, self.world = args, torch.device(device), rank, world
         eps = generate_explore_eps(args.act_base_eps, args.act_eps_alpha, args.num_eps)
-        self.env = BatchedHanabiEnv(args.num_game, players=args.num_player, hand_size=args.hand_size,
+        # several ranks: rank 0 is a dedicated learner (the reference's training thread owns its GPU, too); its env only provides the
+        # dimensions, and its replay shard stays empty
+        self.acting = world == 1 or rank != 0
+        self.env = BatchedHanabiEnv(args.num_game if self.acting else 1, players=args.num_player, hand_size=args.hand_size,
                                     seed=args.seed + rank * args.num_game, bomb=args.train_bomb, eps_list=eps,
                                     max_len=args.max_len, sad=bool(args.sad), shuffle_color=bool(args.shuffle_color),
                                     device=device, track_deck_history=False)
@@ -78,7 +81,8 @@ class Trainer:
         self.vdn = args.method == "vdn"
         fields = transition_fields(self.env, self.vdn)
         # the reference's capacity is split evenly over the per-GPU shards
-        self.replay = DeviceReplay(max(args.batchsize, args.replay_buffer_size // world), args.seed + rank,
+        n_shards = max(world - 1, 1)
+        self.replay = DeviceReplay(max(args.batchsize, args.replay_buffer_size // n_shards if self.acting else 0), args.seed + rank,
                                    args.priority_exponent, args.priority_weight, args.prefetch, args.max_len, fields, device)
         # the learner's first GEMM reads the observation as zero-padded bf16 rows: have the sampler expand the stored bits into
         # exactly that (no float32 batch, no cast pass)
@@ -86,9 +90,9 @@ class Trainer:
         if self.bf16_batch:
             self.replay.set_field_output("priv_s", "bf16", self.act_online.Fp)
         from .dist import ShardedReplay
-        self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0)
+        self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0) if world == 1 else None
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
-                                 vdn=self.vdn)
+                                 vdn=self.vdn) if self.acting else None
         self.num_update = 0
 
     def update_actor_model(self):
@@ -96,16 +100,12 @@ class Trainer:
             for k in PARAM_ORDER:
                 self.act_online.w[k].copy_(self.learner.online.w[k])
                 self.act_target.w[k].copy_(self.learner.target.w[k])
-        if self.world > 1:
-            from .dist import broadcast_params
-            broadcast_params([self.act_online.w[k] for k in PARAM_ORDER] + [self.act_target.w[k] for k in PARAM_ORDER], src=0)
         self.act_online.refresh()
         self.act_target.refresh()
 
     def learner_update(self, stopwatch=None):
-        """one learner iteration (selfplay.py:208-244); collective when world > 1 (every rank calls it in lock-step: actor ranks
-        serve their share of the batch, receive the new priorities of the rows they contributed and, every actor_sync_freq
-        updates, the parameters).  stopwatch: a common.Stopwatch that receives the reference's five sections, each closed by a
+        """one learner iteration (selfplay.py:208-244) of a single-GPU job (several GPUs: run_link_learner / run_link_actor below,
+        where the actor ranks never wait for this).  stopwatch: a common.Stopwatch that receives the reference's five sections, each closed by a
         device synchronisation like there (selfplay.py:215-241) -- off by default: the fences cost throughput."""
         a = self.args
 
@@ -121,19 +121,7 @@ class Trainer:
         mark("sync and updating")
         res = self.sharded.sample(a.batchsize)
         mark("sample data", sync=False)
-        if self.learner is None:
-            self.sharded.update_priority()
-            self.num_update += 1
-            return None, None
-        (f, reward, terminal, bootstrap, seq_len), weight = res
-        pk = "priv_s_bf16" if self.bf16_batch else "priv_s"       # bf16: [T, B, P | 1, in_dim_padded] as sampled
-        if self.vdn:    # [T, B, P*w] -> [T, B, P, w]
-            P_, v4 = self.env.P, lambda t: t.view(t.shape[0], t.shape[1], self.env.P, -1)
-            batch = {pk: v4(f["priv_s"]), "legal_move": v4(f["legal_move"]), "a": f["a"], "reward": reward,
-                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": v4(f["own_hand"])}
-        else:
-            batch = {pk: f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
-                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
+        batch, weight, seq_len = self.batch_of(res)
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)
         mark("forward & backward")
@@ -143,6 +131,19 @@ class Trainer:
         mark("updating priority", sync=False)
         self.num_update += 1
         return (loss * weight).mean(), g_norm
+
+    def batch_of(self, res):
+        """a sampled / assembled batch -> the learner's input dict (selfplay.py:222-224 + the VDN reshape), weight, seq_len"""
+        (f, reward, terminal, bootstrap, seq_len), weight = res
+        pk = "priv_s_bf16" if self.bf16_batch else "priv_s"       # bf16: [T, B, P | 1, in_dim_padded] as sampled
+        if self.vdn:    # [T, B, P*w] -> [T, B, P, w]
+            P_, v4 = self.env.P, lambda t: t.view(t.shape[0], t.shape[1], self.env.P, -1)
+            batch = {pk: v4(f["priv_s"]), "legal_move": v4(f["legal_move"]), "a": f["a"], "reward": reward,
+                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": v4(f["own_hand"])}
+        else:
+            batch = {pk: f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
+                     "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
+        return batch, weight, seq_len
 
 
 def parse_args(argv=None):
@@ -210,7 +211,117 @@ def parse_args(argv=None):
     return args
 
 
-def run_epochs(tr, args, rank=0):
+# ---- several GPUs: a dedicated learner rank and free-running actor ranks joined by dist.ReplayLink -------------------------------
+def make_link(tr, args):
+    from .dist import ReplayLink
+    n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else sum(tr.act_online.w[k].numel() for k in PARAM_ORDER)
+    return ReplayLink(tr.replay, args.batchsize, args.priority_weight, tr.device, learner_rank=0, depth=2, param_numel=2 * n)
+
+
+def _flat_of(net):
+    return net.flat if hasattr(net, "flat") else torch.cat([net.w[k].reshape(-1) for k in PARAM_ORDER])
+
+
+def _load_flat(net, flat):
+    if hasattr(net, "flat"):
+        net.flat.copy_(flat)
+    else:
+        off = 0
+        for k in PARAM_ORDER:
+            n = net.w[k].numel()
+            net.w[k].copy_(flat[off:off + n].view_as(net.w[k]))
+            off += n
+    net.refresh()
+
+
+def run_link_actor(tr, args, link):
+    """an actor rank: burn its shard in, then step its games for as long as the learner runs -- between two steps it asks the store
+    whether a round is open and serves it from its own stream (statistics, its share of the draw, late priorities, sometimes new
+    parameters).  It never waits for the learner's compute.  (The reference's actor threads free-run the same way while the
+    training thread trains: rela/context.h:43-50, selfplay.py:208-244.)"""
+    share = max(args.batchsize, args.burn_in_frames // max(link.world - 1, 1))
+    announced = False
+    n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else link.bucket.numel() // 2
+    while True:
+        tr.actor.step()
+        if not announced and tr.actor.num_act % (50 * tr.actor.N) == 0 and tr.replay.size() >= share:
+            link.store.set("hsad/link/acts/%d" % link.rank, "%d %d %d" % (tr.actor.num_act, tr.replay.num_add(), tr.replay.size()))
+            link.store.add("hsad/link/burned_in", 1)
+            announced = True
+        flags = link.poll()
+        if flags is None:
+            continue
+        stop = link.serve(flags)
+        if link.served % 64 == 0 or stop:     # Tachometer input for the learner (replay counters are read from the device: rarely)
+            link.store.set("hsad/link/acts/%d" % link.rank, "%d %d %d" % (tr.actor.num_act, tr.replay.num_add(), tr.replay.size()))
+        if flags & link.PARAMS:          # BatchRunner::updateModel: the learner's snapshot [online | target], stream-ordered
+            _load_flat(tr.act_online, link.bucket[:n])
+            _load_flat(tr.act_target, link.bucket[n:])
+        if stop:
+            break
+    torch.cuda.synchronize()
+    tr.env.check_errors()
+    tr.replay.check_errors()
+
+
+def run_link_learner(tr, args, link, num_update, on_update=None, stop=True):
+    """the learner rank: update u runs on the compute stream while round u+1 (the draw of batch u+1, the priorities of update u-1,
+    sometimes the parameters) runs on the exchange stream; neither side's host waits for the other's GPU"""
+    import time as _time
+    a, L = args, tr.learner
+    while int(link.store.add("hsad/link/burned_in", 0)) < link.world - 1:     # every actor shard holds its share of the burn-in
+        _time.sleep(0.05)
+    first = tr.num_update == 0
+    if first:
+        link.stage_params(_flat_of(L.online), _flat_of(L.target))
+        link.begin(None, params=True)
+        tr._cur, tr._prios = link.finish(), []
+    for u in range(num_update):
+        if tr.num_update % a.num_update_between_sync == 0:
+            L.sync_target_with_online()
+        params = tr.num_update % a.actor_sync_freq == 0 and tr.num_update > 0
+        if params:
+            link.stage_params(_flat_of(L.online), _flat_of(L.target))
+        link.begin(tr._prios.pop(0) if tr._prios else None, params=params)
+        batch, weight, seq_len = tr.batch_of(tr._cur)
+        loss, priority = L.loss(batch, weight, a.pred_weight)
+        tr._prios.append(aggregate_priority(priority, seq_len, a.eta))
+        g_norm = L.optimizer_step()
+        if on_update is not None:
+            on_update(u, (loss * weight).mean(), g_norm)
+        tr._cur = link.finish()
+        tr.num_update += 1
+    if stop:
+        link.begin(tr._prios.pop(0) if tr._prios else None, stop=True)
+        link.finish()
+    torch.cuda.synchronize()
+    if hasattr(L, "check_sync"):
+        L.check_sync()
+    check_sync()
+
+
+class LinkCounters:
+    """what the actor ranks last published (acts, replay adds, replay size), summed: the Tachometer's actors / replay_buffer on the
+    learner rank of a multi-GPU job"""
+
+    def __init__(self, link):
+        self.link = link
+
+    def _sum(self, col):
+        return sum(int(self.link.store.get("hsad/link/acts/%d" % r).decode().split()[col])
+                   for r in range(self.link.world) if r != self.link.learner)
+
+    def num_act(self):
+        return self._sum(0)
+
+    def num_add(self):
+        return self._sum(1)
+
+    def size(self):
+        return self._sum(2)
+
+
+def run_epochs(tr, args, rank=0, link=None):
     """the epoch loop of selfplay.py:201-281: Tachometer / Stopwatch / MultiCounter output per epoch, then evaluation of the
     online net on fresh games (eval.py:19-66) and the top-k / every-50-epochs saves"""
     from .common import MultiCounter, Stopwatch, Tachometer, TopkSaver
@@ -221,16 +332,22 @@ def run_epochs(tr, args, rank=0):
     rows = torch.zeros(args.epoch_len, 2, dtype=torch.float32, device=tr.device)   # (loss, grad_norm) per update, read once per epoch
     factor = args.num_player if args.method == "vdn" else 1
 
+    counters = LinkCounters(link) if link is not None else None
+
     class _ActCount:       # Tachometer reads sum(actor.num_act()): DeviceActor counts P acts per game step (utils.py:345-352)
         def num_act(self_inner):
-            return tr.actor.num_act // factor
+            return (counters.num_act() if counters else tr.actor.num_act) // factor
     for epoch in range(args.num_epoch):
         if rank == 0:
             print("beginning of epoch: ", epoch)
         tach.start()
         stat.reset()
         sw.reset()
-        for b in range(args.epoch_len):
+        if link is not None:     # several GPUs: the actor ranks free-run; this rank only trains (and evaluates below)
+            def record(b, loss, g_norm):
+                rows[b, 0], rows[b, 1] = loss, g_norm
+            run_link_learner(tr, args, link, args.epoch_len, on_update=record, stop=False)
+        for b in range(args.epoch_len if link is None else 0):
             for _ in range(args.act_steps_per_update):
                 tr.actor.step()
             loss, g_norm = tr.learner_update(sw if args.stopwatch else None)
@@ -241,13 +358,11 @@ def run_epochs(tr, args, rank=0):
             tr.learner.check_sync()
         tr.env.check_errors()
         tr.replay.check_errors()
-        if rank != 0:
-            continue
         for l_, g_ in rows.cpu().tolist():
             stat["loss"].feed(l_)
             stat["grad_norm"].feed(g_)
         print("EPOCH: %d" % epoch)
-        tach.lap([_ActCount()], tr.replay, args.epoch_len * args.batchsize, factor)
+        tach.lap([_ActCount()], counters if counters else tr.replay, args.epoch_len * args.batchsize, factor)
         if args.stopwatch:
             sw.summary()
         stat.summary(epoch)
@@ -299,6 +414,26 @@ def main(argv=None):
         load_weight(tr.learner.online.w, args.load_model)        # online net only, like selfplay.py:143-146
         tr.learner.online.refresh()
         print("*****done*****")
+    if world > 1:
+        link = make_link(tr, args)
+        if rank != 0:
+            run_link_actor(tr, args, link)
+        elif args.num_epoch > 0:
+            run_epochs(tr, args, rank, link)
+            run_link_learner(tr, args, link, 0, stop=True)
+        else:
+            t0 = time.time()
+
+            def show(u, loss, g_norm):
+                if u % 20 == 0:
+                    print("update %d loss %.4f grad_norm %.3f" % (u, float(loss), float(g_norm)))
+            run_link_learner(tr, args, link, args.num_update, on_update=show)
+            dt, c = time.time() - t0, LinkCounters(link)
+            print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt, c.num_act() / dt, c.size()))
+            print("exchange per round (ms): %s" % ", ".join("%s %.3f" % kv for kv in sorted(link.timings().items())))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     t0 = time.time()
     while tr.replay.size() < max(args.batchsize, args.burn_in_frames // world):   # per-shard share of the burn-in
         for _ in range(10):

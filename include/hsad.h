@@ -243,6 +243,27 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
                     float* bootstrap, float* seq_len, void* stream);
 /* physical ring slots of the last sample (device int32 [batch]); debugging / tests */
 int hsad_replay_last_ids(hsad_replay* r, int32_t* out, int batch, void* stream);
+
+/* The same sharded draw WITHOUT host round trips (every argument a device pointer; the exchange between the calls is the host's:
+ * RCCL through torch.distributed in hanabi_sad_amd/dist.py ReplayLink), so an actor rank serves a learner's request between two of
+ * its own steps and the learner never stalls the actors:
+ *   hsad_replay_stats         (sum, size) of this shard as two doubles -> all-gathered into all_stats [world][2]
+ *   hsad_replay_serve         canon [B] = the learner's canonical uniforms.  Computes the reference's stratified positions over the
+ *                             concatenation of the shards (prioritized_replay.h:300-305), owner_out[i] = shard of position i, draws
+ *                             the positions this shard owns and writes those sequences, in batch order, into slots 0.. of wire_out
+ *                             ([B][hsad_replay_wire_bytes]: stored rows incl. the bit-packed observation + reward / bootstrap /
+ *                             terminal / seq_len / raw weight).  The draw joins the outstanding queue (hsad_replay_set_outstanding).
+ *   hsad_replay_update_owned  priority [B] of a whole batch + that draw's owner[]: answers the OLDEST outstanding draw with the
+ *                             priorities of the positions this shard owned
+ *   hsad_replay_assemble      learner: wire_all [world][B][wire_bytes] (every rank's buffer) + owner[] -> the batch tensors exactly as
+ *                             hsad_replay_sample lays them out (bit fields per hsad_replay_set_field_output) + raw weights [B] */
+int hsad_replay_stats(hsad_replay* r, double* out2, void* stream);
+int hsad_replay_wire_bytes(const hsad_replay* r);
+int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const double* all_stats, int world, int rank, int32_t* owner_out,
+                      uint8_t* wire_out, void* stream);
+int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, const int32_t* owner, int rank, void* stream);
+int hsad_replay_assemble(hsad_replay* r, int batch, int world, const uint8_t* wire_all, const int32_t* owner, void* const* out_fields,
+                         float* reward, uint8_t* terminal, float* bootstrap, float* seq_len, float* raw_weight, void* stream);
 /* Drawn batches that may wait for their priorities at once (1..4, default 1 = strict alternation).  The reference's
  * prefetch queue (prioritized_replay.h:232-262, prefetch = 3 in selfplay.py) draws up to `prefetch` batches before the
  * priorities of the batches in training are written back; with depth k, hsad_replay_update_priority answers the OLDEST

@@ -1,0 +1,145 @@
+"""World-size-2/3 gloo tests of the asynchronous learner <-> actor exchange (hanabi_sad_amd/dist.py ReplayLink): rounds opened by the
+learner and noticed by polling actors, one packed buffer per rank, priorities piggybacked two rounds late and answered oldest-first,
+parameters as one flat bucket -- and the batches must still be what ONE PrioritizedReplay over the concatenated shards would draw
+from the same uniforms given the same (late) priority write-backs (rela/prioritized_replay.h:291-345).  The shard is a host stand-in
+with the DeviceReplay shard interface; the device kernels behind that interface are covered by tests/test_sharded_replay_gpu.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from hanabi_sad_amd.dist import ReplayLink, rank_world, split_positions, stratified_positions
+
+ALPHA, BETA, B, ROUNDS = 0.9, 0.6, 16, 7
+SIZES = %(sizes)r                     # elements per shard; the learner's (rank 0) may be empty: a dedicated learner
+
+def initial(k):
+    return (np.random.default_rng(100 + k).random(SIZES[k]).astype(np.float32) * 2 + 0.05) ** np.float32(ALPHA)
+
+class HostShard:
+    """the DeviceReplay shard interface on the host: element j of shard k carries the tag 1000 * k + j"""
+    def __init__(self, k):
+        self.k, self.w, self.rng = k, initial(k), np.random.default_rng(7)
+        self.queue, self.depth = [], 1
+    def set_outstanding(self, depth): self.depth = depth
+    def draw_canonical(self, n): return self.rng.random(n, dtype=np.float32)
+    def wire_bytes(self): return 16
+    def stats(self): return torch.tensor([float(np.sum(self.w.astype(np.float64))), float(len(self.w))], dtype=torch.float64)
+    def serve(self, canon, all_stats, rank, wire_out):
+        sums = all_stats[:, 0].numpy()
+        pos = stratified_positions(canon.numpy(), float(np.sum(sums)), len(canon))
+        owner, local = split_positions(pos, list(sums))
+        acc = np.cumsum(self.w.astype(np.float64))
+        ids = [int(min(np.searchsorted(acc, np.float64(t), side="left"), len(self.w) - 1)) for t in local[owner == rank]]
+        assert len(self.queue) < self.depth
+        self.queue.append((owner, ids))
+        slots = wire_out.view(torch.float32).view(-1, 4)
+        for j, i in enumerate(ids):
+            slots[j, 0], slots[j, 1] = 1000.0 * self.k + i, float(self.w[i])
+        return torch.from_numpy(owner.astype(np.int32))
+    def answer(self, prio, rank):
+        owner, ids = self.queue.pop(0)
+        for i, p in zip(ids, prio.numpy()[owner == rank]):
+            self.w[i] = np.float32(p) ** np.float32(ALPHA)
+    def assemble(self, wire_all, owner):
+        owner = owner.numpy()
+        slots = wire_all.view(torch.float32).view(wire_all.shape[0], -1, 4)
+        tags, raw = [], []
+        for b in range(len(owner)):
+            j = b - int(np.argmax(owner == owner[b]))
+            tags.append(float(slots[owner[b], j, 0])); raw.append(float(slots[owner[b], j, 1]))
+        tags = torch.tensor(tags)
+        return ({"tag": tags}, None, None, None, tags.clone()), torch.tensor(raw)
+
+rank, world = rank_world()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+NP = 1000
+link = ReplayLink(HostShard(rank), B, BETA, "cpu", learner_rank=0, depth=2, param_numel=NP)
+if rank == 0:
+    model = [initial(k) for k in range(world)]            # the single-buffer emulation: every shard's weights, updated when the priorities ARRIVE
+    rng = np.random.default_rng(7)
+    drawn, batches = [], []
+    for r in range(ROUNDS):
+        prio = None
+        if r >= 2:                                         # update r-2 is the newest finished one when round r is opened
+            prio = torch.tensor(drawn[r - 2][1])
+            for t, p in zip(drawn[r - 2][0], drawn[r - 2][1]):        # sequential: the last duplicate wins
+                model[int(t) // 1000][int(t) %% 1000] = np.float32(p) ** np.float32(ALPHA)
+        params = r == 3
+        if params:
+            link.stage_params(torch.arange(NP // 2, dtype=torch.float32), torch.arange(NP // 2, dtype=torch.float32) + 0.5)
+        link.begin(prio, params=params, stop=(r == ROUNDS - 1))
+        time.sleep(0.02)                                   # "update r-1 runs here"
+        (f, *_ , seq_len), weight = link.finish()
+        # what ONE buffer over the concatenation draws from the same uniforms
+        cat = np.concatenate(model)
+        tags = np.concatenate([1000 * k + np.arange(len(model[k])) for k in range(world)])
+        canon = rng.random(B, dtype=np.float32)
+        total = float(np.sum(np.concatenate([w.astype(np.float64) for w in model])))
+        pos = stratified_positions(canon, total, B)
+        acc = np.cumsum(cat.astype(np.float64))
+        want = np.minimum(np.searchsorted(acc, pos.astype(np.float64), side="left"), len(cat) - 1)
+        got = f["tag"].numpy()
+        gap = np.minimum(np.abs(acc[want] - pos), np.abs(pos - np.where(want > 0, acc[want - 1], 0)))
+        clear = gap > 1e-4 * max(total, 1.0)               # float32 rounding at an element boundary may pick the neighbour
+        assert clear.sum() >= B - 2 and np.array_equal(got[clear], tags[want][clear].astype(np.float32)), (r, got, tags[want])
+        raw = np.array([model[int(t) // 1000][int(t) %% 1000] for t in got], dtype=np.float32)
+        y = (np.float32(len(cat)) * (raw / np.float32(total))) ** np.float32(-BETA)
+        assert np.allclose(weight.numpy(), y / y.max(), rtol=1e-5), (r, weight, y / y.max())
+        drawn.append((got, (got %% 7 + 0.5 + r).astype(np.float32)))
+    t = link.timings()
+    assert set(t) >= {"header_bcast_ms", "stats_allgather_ms", "serve_ms", "batch_gather_ms", "param_bcast_ms", "assemble_ms"}, t
+    final = torch.from_numpy(np.concatenate(model))
+else:
+    n_poll = n_act = 0
+    got_params = False
+    while True:
+        flags = link.poll()
+        n_poll += 1
+        if flags is None:
+            n_act += 1                                      # an actor step would run here; it never blocks on the learner
+            time.sleep(0.001)
+            continue
+        stop = link.serve(flags)
+        if flags & ReplayLink.PARAMS:
+            assert torch.equal(link.bucket[:NP // 2], torch.arange(NP // 2, dtype=torch.float32))
+            assert torch.equal(link.bucket[NP // 2:], torch.arange(NP // 2, dtype=torch.float32) + 0.5)
+            got_params = True
+        if stop:
+            break
+    assert link.served == ROUNDS and got_params and n_act > ROUNDS   # it kept "acting" between the rounds
+    final = torch.empty(sum(SIZES), dtype=torch.float32)
+dist.broadcast(final, src=0)
+lo = sum(SIZES[:rank])
+# the late priorities reached exactly the owning elements of every shard (rounds 0 .. ROUNDS-3 were answered)
+assert np.array_equal(link.shard.w, final.numpy()[lo:lo + SIZES[rank]]), rank
+assert len(link.shard.queue) == 2                           # the last two draws are still waiting for theirs
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(%(out)r, "link%%d.ok" %% rank), "w").write("ok")
+'''
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("sizes", [[0, 40], [12, 0, 50], [0, 30, 25]])
+def test_replay_link_rounds_gloo(tmp_path, sizes):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT, "sizes": sizes, "out": str(tmp_path)})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % len(sizes), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert all((tmp_path / ("link%d.ok" % r)).exists() for r in range(len(sizes)))

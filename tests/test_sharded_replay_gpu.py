@@ -86,9 +86,10 @@ def test_two_shards_on_one_gpu_draw_the_same_elements_as_one_buffer():
     assert int((got != want).sum()) <= 1, (got, want)
 
 
-def test_two_rank_selfplay_assembles_batches_from_both_shards(tmp_path):
-    """End to end on this box's single GPU: two ranks (gloo transport, tensors staged through host memory) each roll
-    out their game shard into their own DeviceReplay shard; rank 0 learns from batches assembled from both."""
+def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path):
+    """End to end on this box's single GPU: three ranks (gloo transport, tensors staged through host memory) -- rank 0 only learns,
+    ranks 1 and 2 roll out their game shards into their own DeviceReplay shards and serve the learner's rounds between their steps
+    (dist.ReplayLink); the learner's batches are assembled from both shards, parameters flow back, everybody stops cleanly."""
     import os
     import socket
     import subprocess
@@ -97,9 +98,148 @@ def test_two_rank_selfplay_assembles_batches_from_both_shards(tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "-m", "hanabi_sad_amd.selfplay", "--num_game", "512", "--num_update", "12",
-           "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "hanabi_sad_amd.selfplay", "--num_game", "512", "--num_update", "45",
+           "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo", "--actor_sync_freq", "10"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert out.stdout.count("Speed: train:") == 2 and "update 0 loss" in out.stdout
+    assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and "batch_gather_ms" in out.stdout
+
+
+def test_device_side_sharded_draw_equals_the_host_choreography():
+    """hsad_replay_stats / _serve / _assemble / _update_owned (what dist.ReplayLink runs, no host round trip) against the host path
+    they replace (priority_sum -> stratified_positions / split_positions -> sample_at -> update_priority): same owners, same
+    elements, same rows, same weights, same shard state afterwards -- three shards (one empty), a bit-packed field unpacked to bf16"""
+    from hanabi_sad_amd.dist import split_positions, stratified_positions
+    from hanabi_sad_amd.replay import Bits, DeviceReplay
+    B, W = 32, 3
+    fields = [("s", D, torch.float32), ("a", 1, torch.int64), ("m", 70, Bits(1))]
+    rng = np.random.default_rng(4)
+
+    def rows(n, base):
+        f, *rest = make_rows(rng, n, base)
+        f["m"] = torch.tensor((rng.random((n, T, 70)) < 0.3).astype(np.float32), device=DEV)
+        return (f,) + tuple(rest)
+    dev_sh = [DeviceReplay(64, 5, 0.9, 0.6, 0, T, fields, DEV) for _ in range(W)]     # device-side path
+    host_sh = [DeviceReplay(64, 5, 0.9, 0.6, 0, T, fields, DEV) for _ in range(W)]    # host choreography
+    base = 0
+    for k, n in enumerate([25, 0, 35]):
+        if n:
+            r = rows(n, base)
+            dev_sh[k].add(*r)
+            host_sh[k].add(*r)
+            base += n
+    for s in dev_sh + host_sh:
+        s.set_field_output("m", "bf16", 128)
+    wb = dev_sh[0].wire_bytes()
+    cat = lambda parts, get, dim: torch.cat([get(p) for p in parts if get(p).shape[dim] > 0], dim)
+    for it in range(3):
+        canon = rng.random(B, dtype=np.float32)
+        sums = [s.priority_sum()[0] for s in host_sh]
+        pos = stratified_positions(canon, float(np.sum(np.asarray(sums, np.float64))), B)
+        owner_h, local = split_positions(pos, sums)
+        parts = [s.sample_at(local[owner_h == k]) for k, s in enumerate(host_sh)]
+        all_stats = torch.stack([s.stats() for s in dev_sh])
+        wire_all = torch.zeros(W, B, wb, dtype=torch.uint8, device=DEV)
+        owners = [s.serve(torch.tensor(canon, device=DEV), all_stats, k, wire_all[k]) for k, s in enumerate(dev_sh)]
+        assert all(torch.equal(o, owners[0]) for o in owners) and np.array_equal(owners[0].cpu().numpy(), owner_h)
+        assert 0 < int((owner_h == 0).sum()) < B and not (owner_h == 1).any()           # both non-empty shards serve, the empty one never
+        (f, reward, terminal, bootstrap, seq_len), raw_w = dev_sh[0].assemble(wire_all, owners[0])
+        assert torch.equal(f["a"], cat(parts, lambda p: p[0][0]["a"], 1)) and torch.equal(f["s"], cat(parts, lambda p: p[0][0]["s"], 1))
+        assert torch.equal(f["m"], cat(parts, lambda p: p[0][0]["m"], 1)) and f["m"].dtype == torch.bfloat16
+        assert torch.equal(reward, cat(parts, lambda p: p[0][1], 1)) and torch.equal(terminal, cat(parts, lambda p: p[0][2], 1))
+        assert torch.equal(bootstrap, cat(parts, lambda p: p[0][3], 1)) and torch.equal(seq_len, cat(parts, lambda p: p[0][4], 0))
+        assert torch.equal(raw_w, cat(parts, lambda p: p[1], 0))
+        newp = torch.tensor((rng.random(B) * 2 + 0.05).astype(np.float32), device=DEV)
+        for k in range(W):
+            host_sh[k].update_priority(newp[torch.tensor(owner_h == k, device=DEV)])
+            dev_sh[k].answer(newp, k)
+            assert host_sh[k].priority_sum() == dev_sh[k].priority_sum()
+    for s in dev_sh + host_sh:
+        s.check_errors()
+
+
+def test_late_priorities_reach_exactly_the_owned_elements():
+    """two shards, depth 2: serve A, serve B, answer A, answer B -- the running sums follow a host model of the weights"""
+    from hanabi_sad_amd.replay import DeviceReplay
+    B, W = 16, 2
+    rng = np.random.default_rng(9)
+    shards = [DeviceReplay(64, 5, 1.0, 0.6, 0, T, FIELDS, DEV) for _ in range(W)]
+    model = []
+    for k, s in enumerate(shards):
+        r = list(make_rows(rng, 30, 100 * k))
+        prio = (rng.integers(1, 64, 30) / 16.0).astype(np.float32)
+        r[5] = torch.tensor(prio, device=DEV)
+        s.add(*r)
+        s.set_outstanding(2)
+        model.append(prio.astype(np.float64).copy())
+    wb = shards[0].wire_bytes()
+    pending = []
+    for it in range(6):
+        if len(pending) == 2:
+            owner, ids, newp = pending.pop(0)
+            for k, s in enumerate(shards):
+                s.answer(torch.tensor(newp, device=DEV), k)
+                for i, p in zip(ids[k], newp[owner == k]):
+                    model[k][i] = p
+            for k, s in enumerate(shards):
+                assert s.priority_sum()[0] == float(model[k].sum()), (it, k)
+        canon = torch.tensor(rng.random(B, dtype=np.float32), device=DEV)
+        all_stats = torch.stack([s.stats() for s in shards])
+        wire_all = torch.zeros(W, B, wb, dtype=torch.uint8, device=DEV)
+        owner = [s.serve(canon, all_stats, k, wire_all[k]) for k, s in enumerate(shards)][0].cpu().numpy()
+        ids = [s.last_ids(B).cpu().numpy()[:int((owner == k).sum())] for k, s in enumerate(shards)]
+        (f, *_), raw_w = shards[0].assemble(wire_all, torch.tensor(owner, device=DEV, dtype=torch.int32))
+        tags = f["a"][0, :, 0].cpu().numpy()                          # element tag = 100 * shard + index at add time (= ring slot)
+        assert np.array_equal(tags, np.concatenate([100 * k + ids[k] for k in range(W)]))
+        assert np.array_equal(raw_w.cpu().numpy(), np.concatenate([model[k][ids[k]] for k in range(W)]).astype(np.float32))
+        pending.append((owner, ids, (rng.integers(1, 64, B) / 16.0).astype(np.float32)))
+    for s in shards:
+        s.check_errors()
+
+
+def test_replay_link_over_rccl_single_rank_equals_plain_sampling():
+    """dist.ReplayLink with the RCCL backend ("nccl") on this box's one GPU: the learner is the only rank and serves its own shard.
+    Every transport call of a round (broadcast, all_gather_into_tensor, gather, parameter bucket) goes through RCCL on the exchange
+    stream; the assembled batches must equal what hsad_replay_sample draws from an identical replay with the same uniforms, and
+    the late priorities must leave both replays in the same state."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from hanabi_sad_amd.dist import ReplayLink
+    from hanabi_sad_amd.replay import DeviceReplay
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B, cap = 16, 48
+        plain = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
+        shard = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
+        plain.set_outstanding(2)
+        rng = np.random.default_rng(0)
+        rows = make_rows(rng, 40, 0)
+        plain.add(*rows)
+        shard.add(*rows)
+        link = ReplayLink(shard, B, 0.6, DEV, learner_rank=0, depth=2, param_numel=64)
+        prios, got = [], []
+        for r in range(6):
+            prio = prios[r - 2] if r >= 2 else None
+            if r == 3:
+                link.stage_params(torch.arange(64, dtype=torch.float32, device=DEV))
+            link.begin(prio, params=(r == 3))
+            if prio is not None:
+                plain.update_priority(prio)                 # answers the oldest outstanding draw, like the shard does
+            x = plain.sample(B)
+            y = link.finish()
+            same_batch(x, y)
+            prios.append(torch.tensor((rng.random(B) * 2 + 0.05).astype(np.float32), device=DEV))
+        torch.cuda.synchronize()
+        assert plain.priority_sum() == shard.priority_sum()
+        assert torch.equal(link.bucket, torch.arange(64, dtype=torch.float32, device=DEV))
+        t = link.timings()
+        assert t["batch_gather_ms"] > 0 and t["header_bcast_ms"] > 0, t
+        plain.check_errors()
+        shard.check_errors()
+    finally:
+        dist.destroy_process_group()
