@@ -7,7 +7,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip", "hsad_agent.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip", "hsad_agent.hip", "hsad_comm.hip")]
 _lib = None
 
 
@@ -150,6 +150,15 @@ SIGNATURES = {
     "hsad_r2d2_net_refresh": (C.c_int, [_P, _P]),
     "hsad_r2d2_net_version": (C.c_uint64, [_P]),
     "hsad_r2d2_net_in_dim_padded": (C.c_int, [_P]),
+    "hsad_comm_unique_id": (C.c_int, [_P, C.c_int]),
+    "hsad_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "hsad_comm_destroy": (None, [_P]),
+    "hsad_comm_rank": (C.c_int, [_P]),
+    "hsad_comm_world": (C.c_int, [_P]),
+    "hsad_comm_bcast_params": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "hsad_comm_gather_batch": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
+    "hsad_comm_scatter_priority": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "hsad_comm_all_stats": (_P, [_P]),
     "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_q_of": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_compute_priority": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double,

@@ -1,0 +1,197 @@
+// hsad_comm_*: the multi-GPU exchange of a self-play job as C entry points (SURVEY.md section 8e / 8b last row) -- what
+// hanabi_sad_amd/dist.py ReplayLink does with torch.distributed, for a host that is not Python: one process per GPU, RCCL over xGMI.
+//
+//   reference                                                      here
+//   BatchRunner::updateModel across devices (batch_runner.h:74-77)  hsad_comm_bcast_params: ONE flat bucket, one ncclBroadcast
+//   PrioritizedReplay::sample over all actors' data (208-257)       hsad_comm_gather_batch: 16-byte all-gather of the shard statistics,
+//                                                                   device-side stratification + draw (hsad_replay_serve), ONE
+//                                                                   fixed-size message per rank in a grouped send / recv
+//   PrioritizedReplay::updatePriority                               hsad_comm_scatter_priority: the whole [B] vector is broadcast
+//                                                                   (512 B) and every shard keeps what it owns
+//
+// RCCL is bound at run time (dlopen): libhsad.so has no link-time dependency on it, and a process that already loaded a copy (PyTorch
+// ships one) keeps using that copy.  Every call is stream-ordered; nothing here synchronises the host.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <new>
+
+#include "hsad.h"
+
+extern "C" int hsad_internal_set_error(int code, const char* msg);
+
+namespace {
+
+int cfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  return hsad_internal_set_error(code, buf);
+}
+
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.lib ? &r : nullptr;
+  tried = true;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names)   // a copy that is already in the process first
+    if ((r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+  for (int i = 0; !r.lib && i < 3; ++i) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+  if (!r.lib) return nullptr;
+#define BIND(field, sym)                                                   \
+  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, sym));        \
+  if (!r.field) {                                                          \
+    r.lib = nullptr;                                                       \
+    return nullptr;                                                        \
+  }
+  BIND(GetUniqueId, "ncclGetUniqueId")
+  BIND(CommInitRank, "ncclCommInitRank")
+  BIND(CommDestroy, "ncclCommDestroy")
+  BIND(Broadcast, "ncclBroadcast")
+  BIND(AllGather, "ncclAllGather")
+  BIND(Send, "ncclSend")
+  BIND(Recv, "ncclRecv")
+  BIND(GroupStart, "ncclGroupStart")
+  BIND(GroupEnd, "ncclGroupEnd")
+  BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+  return &r;
+}
+
+#define NCCL_TRY(expr)                                                                                          \
+  do {                                                                                                          \
+    ncclResult_t r_ = (expr);                                                                                   \
+    if (r_ != ncclSuccess) return cfail(HSAD_ERR_HIP, "%s failed: %s", #expr, R->GetErrorString(r_));           \
+  } while (0)
+#define HIP_TRY(expr)                                                                                \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess) return cfail(HSAD_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+}  // namespace
+
+struct hsad_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  double* my_stats = nullptr;   // [2]
+  double* all_stats = nullptr;  // [world][2]
+  float* prio = nullptr;        // [1024] broadcast landing zone of scatter_priority
+};
+
+extern "C" {
+
+int hsad_comm_unique_id(void* out, int out_bytes) {
+  Rccl* R = rccl();
+  if (!R) return cfail(HSAD_ERR_STATE, "RCCL (librccl.so) could not be loaded: %s", dlerror());
+  if (!out || out_bytes < (int)sizeof(ncclUniqueId)) return cfail(HSAD_ERR_INVALID, "unique id needs %d bytes", (int)sizeof(ncclUniqueId));
+  NCCL_TRY(R->GetUniqueId(static_cast<ncclUniqueId*>(out)));
+  return HSAD_OK;
+}
+
+int hsad_comm_init(const void* unique_id, int rank, int world, int device, hsad_comm** out) {
+  Rccl* R = rccl();
+  if (!R) return cfail(HSAD_ERR_STATE, "RCCL (librccl.so) could not be loaded: %s", dlerror());
+  if (!unique_id || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return cfail(HSAD_ERR_INVALID, "comm_init: bad arguments");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  hsad_comm* c = new (std::nothrow) hsad_comm();
+  if (!c) return cfail(HSAD_ERR_NOMEM, "host allocation failed");
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  ncclUniqueId id = *static_cast<const ncclUniqueId*>(unique_id);
+  ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return cfail(HSAD_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString(r));
+  }
+  if (hipMalloc((void**)&c->my_stats, 16) != hipSuccess || hipMalloc((void**)&c->all_stats, 16 * (size_t)world) != hipSuccess ||
+      hipMalloc((void**)&c->prio, 4096) != hipSuccess) {
+    hsad_comm_destroy(c);
+    return cfail(HSAD_ERR_NOMEM, "hipMalloc failed for the communicator scratch");
+  }
+  *out = c;
+  return HSAD_OK;
+}
+
+void hsad_comm_destroy(hsad_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  Rccl* R = rccl();
+  if (R && c->comm) (void)R->CommDestroy(c->comm);
+  if (c->my_stats) (void)hipFree(c->my_stats);
+  if (c->all_stats) (void)hipFree(c->all_stats);
+  if (c->prio) (void)hipFree(c->prio);
+  delete c;
+}
+
+int hsad_comm_rank(const hsad_comm* c) { return c ? c->rank : -1; }
+int hsad_comm_world(const hsad_comm* c) { return c ? c->world : 0; }
+
+int hsad_comm_bcast_params(hsad_comm* c, float* params, int64_t count, int root, void* stream) {
+  Rccl* R = rccl();
+  if (!R || !c || !params || count < 1 || root < 0 || root >= c->world) return cfail(HSAD_ERR_INVALID, "comm_bcast_params: bad arguments");
+  NCCL_TRY(R->Broadcast(params, params, (size_t)count, ncclFloat32, root, c->comm, (hipStream_t)stream));
+  return HSAD_OK;
+}
+
+int hsad_comm_gather_batch(hsad_comm* c, hsad_replay* shard, int batch, const float* canon, int root, int32_t* owner_out,
+                           uint8_t* wire_mine, uint8_t* wire_all, void* stream) {
+  Rccl* R = rccl();
+  if (!R || !c || !shard || !canon || !owner_out || !wire_mine || root < 0 || root >= c->world || (c->rank == root && !wire_all))
+    return cfail(HSAD_ERR_INVALID, "comm_gather_batch: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = hsad_replay_stats(shard, c->my_stats, stream);
+  if (rc) return rc;
+  NCCL_TRY(R->AllGather(c->my_stats, c->all_stats, 2, ncclFloat64, c->comm, s));
+  rc = hsad_replay_serve(shard, batch, canon, c->all_stats, c->world, c->rank, owner_out, wire_mine, stream);
+  if (rc) return rc;
+  const size_t bytes = (size_t)batch * hsad_replay_wire_bytes(shard);
+  NCCL_TRY(R->GroupStart());
+  if (c->rank == root) {
+    for (int k = 0; k < c->world; ++k) {
+      if (k == root) continue;
+      NCCL_TRY(R->Recv(wire_all + (size_t)k * bytes, bytes, ncclUint8, k, c->comm, s));
+    }
+  } else {
+    NCCL_TRY(R->Send(wire_mine, bytes, ncclUint8, root, c->comm, s));
+  }
+  NCCL_TRY(R->GroupEnd());
+  if (c->rank == root) HIP_TRY(hipMemcpyAsync(wire_all + (size_t)root * bytes, wire_mine, bytes, hipMemcpyDeviceToDevice, s));
+  return HSAD_OK;
+}
+
+int hsad_comm_scatter_priority(hsad_comm* c, hsad_replay* shard, int batch, const float* priority, const int32_t* owner, int root,
+                               void* stream) {
+  Rccl* R = rccl();
+  if (!R || !c || !shard || !owner || batch < 1 || batch > 1024 || root < 0 || root >= c->world || (c->rank == root && !priority))
+    return cfail(HSAD_ERR_INVALID, "comm_scatter_priority: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  NCCL_TRY(R->Broadcast(c->rank == root ? priority : c->prio, c->prio, (size_t)batch, ncclFloat32, root, c->comm, s));
+  return hsad_replay_update_owned(shard, batch, c->prio, owner, c->rank, stream);
+}
+
+const double* hsad_comm_all_stats(const hsad_comm* c) { return c ? c->all_stats : nullptr; }
+
+}  // extern "C"

@@ -529,6 +529,33 @@ int hsad_r2d2_optimizer_step(hsad_r2d2_learner* learner, float beta1, float beta
 int hsad_r2d2_sync_target_with_online(hsad_r2d2_learner* learner, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multi-GPU exchange (csrc/hsad_comm.hip): one process per GPU, RCCL over xGMI, bound at run time (dlopen) -- what
+ * hanabi_sad_amd/dist.py ReplayLink does through torch.distributed, for a host that is not Python.  Stream-ordered, no host
+ * synchronisation.  The host distributes the unique id (its own rendezvous: a file, a socket, MPI ...).
+ *   reference: BatchRunner::updateModel across devices (rela/batch_runner.h:74-77), PrioritizedReplay::sample /
+ *   updatePriority over every actor's data (rela/prioritized_replay.h:208-257).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hsad_comm hsad_comm;
+int hsad_comm_unique_id(void* out, int out_bytes);           /* >= 128 bytes; rank 0 creates it, every rank passes the same bytes */
+int hsad_comm_init(const void* unique_id, int rank, int world, int device, hsad_comm** out);
+void hsad_comm_destroy(hsad_comm* comm);
+int hsad_comm_rank(const hsad_comm* comm);
+int hsad_comm_world(const hsad_comm* comm);
+/* parameters as ONE flat bucket (hsad_r2d2_net_params of the learner's net on root, of the acting nets elsewhere; refresh after) */
+int hsad_comm_bcast_params(hsad_comm* comm, float* params, int64_t count, int root, void* stream);
+/* one prioritized draw over the concatenation of all ranks' shards: statistics all-gather (16 bytes per rank), hsad_replay_serve
+ * on every shard, then every rank's wire buffer [batch][hsad_replay_wire_bytes] to root in one grouped send / recv.  canon [batch]:
+ * the same uniforms on every rank (root's, e.g. sent along by hsad_comm_bcast_params' sibling call or a header broadcast).
+ * root then calls hsad_replay_assemble(shard, batch, world, wire_all, owner_out, ...).  wire_all: root only, [world][batch][bytes]. */
+int hsad_comm_gather_batch(hsad_comm* comm, hsad_replay* shard, int batch, const float* canon, int root, int32_t* owner_out,
+                           uint8_t* wire_mine, uint8_t* wire_all, void* stream);
+/* new priorities [batch] of the oldest outstanding draw (root's pointer; NULL elsewhere) + that draw's owner[]: broadcast, and every
+ * shard writes back the positions it owned (hsad_replay_update_owned) */
+int hsad_comm_scatter_priority(hsad_comm* comm, hsad_replay* shard, int batch, const float* priority, const int32_t* owner, int root,
+                               void* stream);
+const double* hsad_comm_all_stats(const hsad_comm* comm);   /* device [world][2] (sum, size) of the last gather: the importance weights' N and sum */
+
+/* ------------------------------------------------------------------------------------------
  * fp32-EXACT mode of the R2D2 network (csrc/hsad_r2d2_f32.hip): the reference's arithmetic type throughout
  * (pyhanabi/r2d2.py:42-57,99-131,383-499) on v_mfma_f32_32x32x2_f32 (bitwise a k-ordered fmaf chain) with libm-accurate
  * activations -- the mode the golden vectors are matched in at fp32 round-off, and the yardstick the bf16 path's stated

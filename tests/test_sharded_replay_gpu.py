@@ -243,3 +243,49 @@ def test_replay_link_over_rccl_single_rank_equals_plain_sampling():
         shard.check_errors()
     finally:
         dist.destroy_process_group()
+
+
+def test_hsad_comm_c_entry_points_single_rank():
+    """hsad_comm_{unique_id, init, bcast_params, gather_batch, scatter_priority} (csrc/hsad_comm.hip: RCCL bound with dlopen, no
+    torch.distributed) on the one GPU of this box: a world of one rank, every call through the real RCCL communicator; the drawn
+    batch and the shard state afterwards equal the plain sampler's on an identical replay"""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.replay import DeviceReplay, _stream
+    lib = _lib.load_library()
+    uid = (C.c_char * 256)()
+    _lib.check(lib.hsad_comm_unique_id(uid, 256))
+    comm = C.c_void_p()
+    _lib.check(lib.hsad_comm_init(uid, 0, 1, torch.cuda.current_device(), C.byref(comm)))
+    try:
+        assert lib.hsad_comm_rank(comm) == 0 and lib.hsad_comm_world(comm) == 1
+        B, cap = 16, 48
+        plain = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
+        shard = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
+        rng = np.random.default_rng(0)
+        rows = make_rows(rng, 40, 0)
+        plain.add(*rows)
+        shard.add(*rows)
+        st = _stream(torch.device(DEV))
+        params = torch.arange(1000, dtype=torch.float32, device=DEV)
+        _lib.check(lib.hsad_comm_bcast_params(comm, params.data_ptr(), 1000, 0, st))
+        assert torch.equal(params, torch.arange(1000, dtype=torch.float32, device=DEV))
+        wb = shard.wire_bytes()
+        for it in range(3):
+            canon = torch.tensor(shard.draw_canonical(B), device=DEV)
+            owner = torch.empty(B, dtype=torch.int32, device=DEV)
+            wire, wire_all = torch.zeros(B, wb, dtype=torch.uint8, device=DEV), torch.zeros(1, B, wb, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.hsad_comm_gather_batch(comm, shard.h, B, canon.data_ptr(), 0, owner.data_ptr(), wire.data_ptr(),
+                                                  wire_all.data_ptr(), st))
+            batch, raw_w = shard.assemble(wire_all, owner)
+            x = plain.sample(B)
+            (fx, rx, tx, bx, lx), wx = x
+            assert torch.equal(batch[0]["a"], fx["a"]) and torch.equal(batch[0]["s"], fx["s"]) and torch.equal(batch[1], rx)
+            assert torch.equal(batch[4], lx) and (owner == 0).all()
+            newp = torch.tensor((rng.random(B) * 2 + 0.05).astype(np.float32), device=DEV)
+            _lib.check(lib.hsad_comm_scatter_priority(comm, shard.h, B, newp.data_ptr(), owner.data_ptr(), 0, st))
+            plain.update_priority(newp)
+            assert plain.priority_sum() == shard.priority_sum()
+        shard.check_errors()
+    finally:
+        lib.hsad_comm_destroy(comm)
