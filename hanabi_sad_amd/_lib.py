@@ -87,6 +87,7 @@ SIGNATURES = {
     "hsad_replay_get": (C.c_int, [_P, C.c_int, C.POINTER(_P), _P, _P, _P, _P, _P]),
     "hsad_replay_last_ids": (C.c_int, [_P, _P, C.c_int, _P]),
     "hsad_replay_set_outstanding": (C.c_int, [_P, C.c_int]),
+    "hsad_replay_error_kinds": (C.c_int, [_P]),
     "hsad_replay_stats": (C.c_int, [_P, _P, _P]),
     "hsad_replay_wire_bytes": (C.c_int, [_P]),
     "hsad_replay_serve": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P]),

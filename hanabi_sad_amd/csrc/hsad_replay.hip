@@ -174,6 +174,38 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(RowLayout L, FieldPtrs s
   }
 }
 
+// Small rows (<= 256 bytes: the bit-packed transition of the actor loop) whose fields all arrive in their stored format: one THREAD
+// per 4-byte word of the row instead of one wavefront walking six tiny fields one after the other.
+struct RowWordMap {
+  int n_dw;                       // row_bytes / 4 (0 = map not usable)
+  unsigned char fld[64];          // field of row word j (255 = padding)
+  unsigned char idx[64];          // word index inside that field
+  unsigned char fld_dw[kMaxFields];
+};
+inline RowWordMap make_word_map(const RowLayout& L, unsigned prepacked) {
+  RowWordMap m{};
+  if (L.row_bytes > 256) return m;
+  for (int j = 0; j < 64; ++j) m.fld[j] = 255;
+  for (int k = 0; k < L.n_fields; ++k) {
+    if ((L.esize[k] == 0 && !((prepacked >> k) & 1u)) || (L.nbytes[k] & 3)) return m;   // needs the packing path / odd size
+    m.fld_dw[k] = (unsigned char)(L.nbytes[k] / 4);
+    for (int j = 0; j < L.nbytes[k] / 4; ++j) {
+      m.fld[L.offset[k] / 4 + j] = (unsigned char)k;
+      m.idx[L.offset[k] / 4 + j] = (unsigned char)j;
+    }
+  }
+  m.n_dw = L.row_bytes / 4;
+  return m;
+}
+__global__ __launch_bounds__(256) void pack_rows_words_kernel(RowWordMap M, FieldPtrs src, unsigned char* rows, int n_rows, int row0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int row = i / M.n_dw, j = i - row * M.n_dw;
+  if (row >= n_rows) return;
+  const int k = M.fld[j];
+  const unsigned v = k == 255 ? 0u : static_cast<const unsigned*>(src.p[k])[(size_t)row * M.fld_dw[k] + M.idx[j]];
+  reinterpret_cast<unsigned*>(rows)[((size_t)row0 + row) * M.n_dw + j] = v;
+}
+
 // what the caller wants a bit field unpacked to (FieldOut::kind); other fields are always copied as stored
 enum BitsOut : int { BITS_F32 = 0, BITS_BF16 = 1, BITS_RAW = 2 };
 struct FieldOut {
@@ -393,6 +425,7 @@ struct ReplayCtl {
   // `prefetch` batches drawn before the priorities of the batches in training are written back: prioritized_replay.h:232-262)
   int q_head, q_count;
   int q_n[4];
+  int err_kind;   // OR of: 1 add larger than the ring, 2 draw beyond the weight sum, 4 update without a matching draw, 8 writer / packing
 };
 
 struct ReplayDev {
@@ -451,11 +484,17 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
     __syncthreads();
   }
   const double popped = s_red[0];
-  // weights = priority^alpha: computed and stored by all threads; the running sum is the reference's sequential float
-  // accumulation (prioritized_replay.h add -> blockAppend), so it is added up by ONE thread, in order, out of LDS
-  __shared__ float s_w[4096];
-  __shared__ float s_sum;
-  if (tid == 0) s_sum = 0.f;
+  // weights = priority^alpha: computed and stored by all threads
+  __shared__ __attribute__((aligned(16))) float s_w[4096];
+  __shared__ float s_chunk[64];
+  __shared__ double s_sum;
+  // The reference adds up a block's weights sequentially in FLOAT and adds that to the running double (blockAppend,
+  // prioritized_replay.h:59-74).  Its blocks are what ONE actor thread finishes at a time (<= a few dozen sequences); the lock-step
+  // pipeline appends thousands at once, and a float sum over thousands of weights is off by ~1e-2 -- after a few thousand adds the
+  // running sum has drifted past the 0.1 margin of the stratified draw ("draw beyond the weight sum", which the reference asserts
+  // on, too).  So the block is summed the way the reference would sum it had it arrived in blocks of 64: float, in order, inside a
+  // 64-chunk (one thread per chunk), the chunk sums added in order to a double.  Blocks of <= 64 are bit-identical to before.
+  if (tid == 0) s_sum = 0.0;
   for (int base = 0; base < cnt; base += 4096) {
     const int m = min(4096, cnt - base);
     __syncthreads();
@@ -465,19 +504,28 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
       s_w[i] = w;
     }
     __syncthreads();
+    const int nchunk = (m + 63) / 64;
+    if (tid < nchunk) {
+      float sum = 0.f;
+      const int i1 = min(tid * 64 + 64, m);
+      for (int i = tid * 64; i < i1; ++i) sum += s_w[i];
+      s_chunk[tid] = sum;
+    }
+    __syncthreads();
     if (tid == 0) {
-      float sum = s_sum;
-      for (int i = 0; i < m; ++i) sum += s_w[i];
-      s_sum = sum;
+      double acc = s_sum;
+      for (int k = 0; k < nchunk; ++k) acc += (double)s_chunk[k];
+      s_sum = acc;
     }
   }
   __syncthreads();
   if (tid != 0) return;
-  const float sum = s_sum;
+  const double sum = s_sum;
   c.sum -= popped;
   c.head = (c.head + npop) % rd.ring;
   c.size -= npop;
   c.err += err;
+  if (err) c.err_kind |= 1;
   c.add_start = c.tail;
   c.add_n = cnt;
   c.tail = (c.tail + cnt) % rd.ring;
@@ -580,6 +628,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     }
     if (found < 0) {  // the reference asserts here
       atomicAdd(&rd.ctl->err, 1);
+      atomicOr(&rd.ctl->err_kind, 2);
       found = N > 0 ? N - 1 : 0;
       w = N > 0 ? rd.weights[(head + found) % ring] : 0.f;
     }
@@ -649,7 +698,10 @@ __global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B
   const int have = c.q_count > 0 ? c.q_n[c.q_head] : 0;   // the OLDEST outstanding draw is the one being answered
   if (B == 0 || have != B) {
     if (tid == 0) {
-      if (have != B) c.err += 1;
+      if (have != B) {
+        c.err += 1;
+        c.err_kind |= 4;
+      }
       else if (c.q_count > 0) {  // an empty draw (a shard without quota) is answered by an empty update
         c.q_head = (c.q_head + 1) % rd.depth;
         c.q_count -= 1;
@@ -769,23 +821,26 @@ __global__ void seq_pop_kernel(SeqDev sd, int head, float* o_reward, unsigned ch
   if (o_bootstrap) o_bootstrap[e] = bootstrap;
 }
 
-// R2D2Buffer::push (rela/transition_buffer.h:134-176): one block per env
-__global__ void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const float* __restrict__ priority,
-                                int* __restrict__ err) {
-  const int e = blockIdx.x;
+// R2D2Buffer::push (rela/transition_buffer.h:134-176): LPE lanes per env (16 for the bit-packed rows of <= 256 bytes, a wavefront
+// for float32 observation rows), 256-thread blocks
+template <int LPE>
+__global__ __launch_bounds__(256) void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const float* __restrict__ priority,
+                                                       int* __restrict__ err) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) / LPE, lane = threadIdx.x % LPE;
+  if (e >= sd.E) return;
   const int idx = sd.next_idx[e];
   if (idx >= sd.T || idx < 0) {  // assert(nextIdx < seqLen) in the reference
-    if (threadIdx.x == 0) atomicAdd(err, 1);
+    if (lane == 0) atomicAdd(err, 1);
     return;
   }
   const uint4* src = reinterpret_cast<const uint4*>(sd.hist_rows + ((size_t)pend_slot * sd.E + e) * row_bytes);
   uint4* dst = reinterpret_cast<uint4*>(sd.st_rows + ((size_t)e * sd.T + idx) * row_bytes);
   const int nq = row_bytes / 16;
-  for (int j = threadIdx.x; j < nq; j += blockDim.x) dst[j] = src[j];
+  for (int j = lane; j < nq; j += LPE) dst[j] = src[j];
   const unsigned char term = sd.pend_terminal[e];
   // the padding of a finished sequence (zeros, terminal = 1, bootstrap = 0, priority 0: transition.cc:29-40) is not written
   // here or anywhere: the replay's readers produce it (valid_rows), and nothing else reads staging rows past len[e]
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     sd.st_reward[(size_t)e * sd.T + idx] = sd.pend_reward[e];
     sd.st_terminal[(size_t)e * sd.T + idx] = term;
     sd.st_bootstrap[(size_t)e * sd.T + idx] = sd.pend_bootstrap[e];
@@ -799,32 +854,32 @@ __global__ void seq_push_kernel(SeqDev sd, int row_bytes, int pend_slot, const f
   }
 }
 
-// R2D2Buffer::popTransition bookkeeping + aggregatePriority for finished envs, ascending env order.
+// R2D2Buffer::popTransition bookkeeping: the finished envs, in ascending env order (the order the reference appends them in).
+// 16 wavefronts, each owns a contiguous sixteenth of the envs and walks it 64 at a time with coalesced loads: a ballot gives the
+// finished ones of the 64, popcounts give their slots.
 __global__ __launch_bounds__(1024) void seq_collect_kernel(SeqDev sd, float eta, float c1m, int* n_out) {
-  __shared__ int s_cnt[1024];
-  const int tid = threadIdx.x;
-  const int per = (sd.E + 1023) / 1024;
-  const int e0 = tid * per, e1 = min(e0 + per, sd.E);
+  __shared__ int s_cnt[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = ((sd.E + 15) / 16 + 63) & ~63;          // envs per wavefront, a multiple of 64
+  const int e0 = wave * per, e1 = min(e0 + per, sd.E);
   int cnt = 0;
-  for (int e = e0; e < e1; ++e) cnt += sd.len[e] > 0;
-  s_cnt[tid] = cnt;
+  for (int e = e0 + lane; e - lane < e1; e += 64) cnt += __popcll(__ballot(e < e1 && sd.len[e] > 0));
+  if (lane == 0) s_cnt[wave] = cnt;
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int j = 0; j < 1024; ++j) {
-      const int v = s_cnt[j];
-      s_cnt[j] = acc;
-      acc += v;
-    }
-    sd.n_fin[0] = acc;
-    if (n_out) n_out[0] = acc;
+  int k = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) k += s_cnt[w];
+    total += s_cnt[w];
   }
-  __syncthreads();
-  int k = s_cnt[tid];
-  for (int e = e0; e < e1; ++e) {
-    if (sd.len[e] <= 0) continue;
-    sd.fin_env[k] = e;
-    ++k;
+  if (tid == 0) {
+    sd.n_fin[0] = total;
+    if (n_out) n_out[0] = total;
+  }
+  for (int e = e0 + lane; e - lane < e1; e += 64) {
+    const bool fin = e < e1 && sd.len[e] > 0;
+    const unsigned long long m = __ballot(fin);
+    if (fin) sd.fin_env[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    k += __popcll(m);
   }
 }
 
@@ -852,30 +907,27 @@ __global__ __launch_bounds__(256) void seq_aggregate_kernel(SeqDev sd, float eta
   }
 }
 
-// Finished staging sequences -> replay ring (rows + scalars).  One wavefront per (sequence, step) row, up to four 16-byte
-// chunks per lane in flight.  Only the len stored steps move: the reference's padding (R2D2Buffer::push -> padLike,
-// transition_buffer.h:150-166 / transition.cc:29-40: zeros, terminal = 1, bootstrap = 0) is never written -- valid_rows
-// [slot] = len tells the readers (sample / sample_at / get) to produce it.  With untrained agents episodes last ~10 of the
-// 80 steps, so this is 8x less replay traffic per finished episode.
+// Finished staging sequences -> replay ring (rows + scalars).  One wavefront per SEQUENCE: its len stored rows are contiguous in
+// staging and in the ring, so they move as one run of 16-byte chunks (a 10-step episode of bit-packed rows is 1.6 KB = two wave
+// loads).  Only the len stored steps move: the reference's padding (R2D2Buffer::push -> padLike, transition_buffer.h:150-166 /
+// transition.cc:29-40: zeros, terminal = 1, bootstrap = 0) is never written -- valid_rows[slot] = len tells the readers (sample /
+// sample_at / get) to produce it.
 __global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDev rd, int row_bytes, unsigned char* r_rows,
                                                              float* r_reward, unsigned char* r_terminal, float* r_bootstrap,
                                                              float* r_seq_len) {
   const int n_add = rd.ctl->add_n, start = rd.ctl->add_start;   // the count only exists on the device: grid-stride
-  const int total = n_add * sd.T;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int nq = row_bytes / 16;
-  for (int row = blockIdx.x * 4 + wave; row < total; row += gridDim.x * 4) {
-    const int k = row / sd.T, t = row - k * sd.T;
+  for (int k = blockIdx.x * 4 + wave; k < n_add; k += gridDim.x * 4) {
     const int e = sd.fin_env[k];
     const int L = sd.len[e];
     const int slot = (start + k) % rd.ring;
-    if (t == 0 && lane == 0) {
+    if (lane == 0) {
       r_seq_len[slot] = sd.fin_len[k];
       rd.valid_rows[slot] = L;
     }
-    if (t >= L) continue;
-    uint4* dst = reinterpret_cast<uint4*>(r_rows + ((size_t)slot * sd.T + t) * row_bytes);
-    const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + ((size_t)e * sd.T + t) * row_bytes);
+    const int nq = L * (row_bytes / 16);
+    uint4* dst = reinterpret_cast<uint4*>(r_rows + (size_t)slot * sd.T * row_bytes);
+    const uint4* src = reinterpret_cast<const uint4*>(sd.st_rows + (size_t)e * sd.T * row_bytes);
     for (int j0 = lane; j0 < nq; j0 += 256) {
       uint4 v[4];
 #pragma unroll
@@ -885,7 +937,7 @@ __global__ __launch_bounds__(256) void seq_flush_copy_kernel(SeqDev sd, ReplayDe
       for (int u = 0; u < 4; ++u)
         if (j0 + 64 * u < nq) dst[j0 + 64 * u] = v[u];
     }
-    if (lane == 0) {
+    for (int t = lane; t < L; t += 64) {
       const size_t o = (size_t)slot * sd.T + t, i = (size_t)e * sd.T + t;
       r_reward[o] = sd.st_reward[i];
       r_terminal[o] = sd.st_terminal[i];
@@ -898,6 +950,7 @@ __global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err)
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0 && *w_err) {  // contract violations logged by the writer (push past seq_len, a non-binary value in a bit field)
     atomicAdd(&ctl->err, *w_err);   // surface through the replay's error count, which the drivers poll
+    atomicOr(&ctl->err_kind, 8);
     *w_err = 0;
   }
   if (k >= sd.n_fin[0]) return;
@@ -927,6 +980,7 @@ struct hsad_replay {
   hipEvent_t canon_ev[kCanonSlots] = {};
   int canon_next = 0;
   int* d_tmp_id;
+  int last_err_kind = 0;
   float* d_shard = nullptr;  // sharded draw scratch: compacted priorities [kMaxBatch] | raw weights [kMaxBatch] | counts (2 ints)
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
   int out_ld[kMaxFields] = {};
@@ -943,6 +997,7 @@ struct hsad_seqwriter {
   int pend_slot;              // history slot of the transition popped last (valid until the next push)
   bool pending;
   unsigned prepacked = 0;     // bit fields whose push_obs_action source already is bit words (hsad_seqwriter_set_prepacked)
+  RowWordMap wmap{};          // word-per-thread copy map, usable when every field arrives in its stored format
   int* d_err;
   int64_t bytes;
 };
@@ -1231,6 +1286,8 @@ int hsad_replay_set_outstanding(hsad_replay* r, int depth) {
   return HSAD_OK;
 }
 
+int hsad_replay_error_kinds(const hsad_replay* r) { return r ? r->last_err_kind : 0; }
+
 int hsad_replay_size(hsad_replay* r, int32_t* size, int32_t* num_add) {
   if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
   ReplayCtl c;
@@ -1247,6 +1304,7 @@ int hsad_replay_error_count(hsad_replay* r, int32_t* count) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(&c, r->rd.ctl, sizeof(c), hipMemcpyDeviceToHost));
   *count = c.err;
+  r->last_err_kind = (c.err && !c.err_kind) ? 8 : c.err_kind;
   return HSAD_OK;
 }
 
@@ -1279,6 +1337,7 @@ int hsad_seqwriter_create(int num_envs, int multi_step, float gamma, int seq_len
   hsad_seqwriter* w = new (std::nothrow) hsad_seqwriter();
   if (!w) return rfail(HSAD_ERR_NOMEM, "host allocation failed");
   int rc = make_layout(n_fields, fields, &w->L);
+  if (rc == HSAD_OK) w->wmap = make_word_map(w->L, 0u);
   if (rc != HSAD_OK) {
     delete w;
     return rc;
@@ -1346,8 +1405,12 @@ int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields,
   const int slot = (w->head + w->count) % w->sd.depth;
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < w->L.n_fields ? fields[k] : nullptr;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((w->sd.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
-                     w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr, w->prepacked, w->d_err);
+  if (w->wmap.n_dw)
+    hipLaunchKernelGGL(pack_rows_words_kernel, dim3((w->sd.E * w->wmap.n_dw + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->wmap, fp,
+                       w->sd.hist_rows, w->sd.E, slot * w->sd.E);
+  else
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((w->sd.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, w->L, fp, w->sd.hist_rows,
+                       w->sd.E, 1, (int)MAP_LINEAR, slot * w->sd.E, 0, (const int*)nullptr, (const int*)nullptr, w->prepacked, w->d_err);
   HIP_TRY(hipGetLastError());
   w->count += 1;
   return HSAD_OK;
@@ -1359,6 +1422,7 @@ int hsad_seqwriter_set_prepacked(hsad_seqwriter* w, uint32_t field_mask) {
     if (((field_mask >> k) & 1u) && (k >= w->L.n_fields || w->L.esize[k] != 0))
       return rfail(HSAD_ERR_INVALID, "field %d is not a bit field", k);
   w->prepacked = field_mask;
+  w->wmap = make_word_map(w->L, field_mask);
   return HSAD_OK;
 }
 
@@ -1404,7 +1468,11 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
 int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream) {
   if (!w || !priority) return rfail(HSAD_ERR_INVALID, "null argument");
   if (!w->pending) return rfail(HSAD_ERR_STATE, "no popped transition to push");
-  hipLaunchKernelGGL(seq_push_kernel, dim3(w->sd.E), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
+  if (w->L.row_bytes <= 256)
+    hipLaunchKernelGGL(seq_push_kernel<16>, dim3((w->sd.E + 15) / 16), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
+                       w->pend_slot, priority, w->d_err);
+  else
+    hipLaunchKernelGGL(seq_push_kernel<64>, dim3((w->sd.E + 3) / 4), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
                      w->pend_slot, priority, w->d_err);
   HIP_TRY(hipGetLastError());
   w->pending = false;
@@ -1422,7 +1490,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
   hipLaunchKernelGGL(seq_aggregate_kernel, dim3((sd.E + 3) / 4), dim3(256), 0, s, sd, eta, c1m);
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, sd.E, sd.n_fin, sd.fin_prio);
-  hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min((sd.E * sd.T + 3) / 4, 8192)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
+  hipLaunchKernelGGL(seq_flush_copy_kernel, dim3(std::min((sd.E + 3) / 4, 2048)), dim3(256), 0, s, sd, r->rd, w->L.row_bytes, r->rows,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);
   hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl, w->d_err);
   HIP_TRY(hipGetLastError());

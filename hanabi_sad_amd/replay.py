@@ -270,8 +270,11 @@ class DeviceReplay:
         n = C.c_int32(0)
         _lib.check(self.lib.hsad_replay_error_count(self.h, C.byref(n)))
         if n.value:
-            raise _lib.HsadError("replay logged %d contract violation(s) (ring overflow on add, sample beyond the "
-                                 "weight sum, or update_priority without a matching sample)" % n.value)
+            kinds = self.lib.hsad_replay_error_kinds(self.h)
+            names = [t for b, t in ((1, "add larger than the ring"), (2, "draw beyond the weight sum"),
+                                    (4, "update_priority without a matching draw"),
+                                    (8, "sequence writer: push past seq_len or a non-binary value in a bit field")) if kinds & b]
+            raise _lib.HsadError("replay logged %d contract violation(s): %s" % (n.value, "; ".join(names) or "?"))
 
 
 class SequenceWriter:

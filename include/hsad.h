@@ -275,6 +275,9 @@ int hsad_replay_set_field_output(hsad_replay* r, int field, int kind, int ld);
 int hsad_replay_row_bytes(const hsad_replay* r);              /* bytes of one stored step                     */
 int hsad_replay_field_bytes(const hsad_replay* r, int field); /* bytes of field `field` inside a stored step  */
 int hsad_replay_error_count(hsad_replay* r, int32_t* count);
+/* which contracts the violations counted by the last hsad_replay_error_count call broke (OR of 1 = add larger than the ring,
+ * 2 = draw beyond the weight sum, 4 = update_priority without a matching draw, 8 = sequence writer / non-binary bit field) */
+int hsad_replay_error_kinds(const hsad_replay* r);
 
 typedef struct hsad_seqwriter hsad_seqwriter;
 

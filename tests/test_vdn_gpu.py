@@ -73,5 +73,7 @@ def test_vdn_selfplay_end_to_end():
     tr.replay.check_errors()
     # one transition per GAME: field widths carry the player dimension
     (f, reward, terminal, bootstrap, seq_len), w = tr.replay.sample(8)
-    assert f["priv_s"].shape == (80, 8, 2 * tr.env.F) and f["a"].shape == (80, 8, 2) and reward.shape == (80, 8)
+    # (the Trainer has the sampler expand the bit-packed observation straight into the learner's zero-padded bf16 operand)
+    assert f["priv_s"].shape == (80, 8, 2, 896) and f["priv_s"].dtype == torch.bfloat16 and not f["priv_s"][..., tr.env.F:].any()
+    assert f["legal_move"].shape == (80, 8, 2 * tr.env.A) and f["a"].shape == (80, 8, 2) and reward.shape == (80, 8)
     tr.replay.update_priority(torch.ones(8, device=DEV))
