@@ -103,6 +103,7 @@ SIGNATURES = {
     "hsad_seqwriter_destroy": (None, [_P]),
     "hsad_seqwriter_push_obs_action": (C.c_int, [_P, C.POINTER(_P), _P]),
     "hsad_seqwriter_push_reward_terminal": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_seqwriter_push_reward_terminal_rep": (C.c_int, [_P, _P, _P, C.c_int, _P]),
     "hsad_seqwriter_can_pop": (C.c_int, [_P]),
     "hsad_seqwriter_pop_transition": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P]),
     "hsad_seqwriter_push_sequence": (C.c_int, [_P, _P, _P]),
@@ -134,6 +135,9 @@ SIGNATURES = {
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "hsad_nstep_priority": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "hsad_zero_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "hsad_act_select_q": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+    "hsad_q_at": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
+    "hsad_zero_state_rows": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "hsad_lstm_forward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -91,9 +91,7 @@ class DeviceActor:
         env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))
         self.num_act += self.N               # Tachometer counts P acts per game step in both layouts (utils.py:229-236)
         # postAct: reward / terminal of the game go to each of its players' rows (IQL) or to the game's row (VDN)
-        r = env.reward if self.vdn else env.reward.repeat_interleave(P)
-        t = env.terminal if self.vdn else env.terminal.repeat_interleave(P)
-        self.writer.push_reward_terminal(r, t)
+        self.writer.push_reward_terminal(env.reward, env.terminal, repeat=1 if self.vdn else P)
         zero_hidden_rows(self.hid, env.terminal, P)                                    # r2d2_actor.h:109-126
         if not self.writer.can_pop():
             return

@@ -169,7 +169,7 @@ struct StepOut {
 };
 
 int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const float* c0, const bf16_t* h16_in, float* h_out,
-             float* c_out, char* wsp, StepOut* out, hipStream_t s) {
+             float* c_out, char* wsp, StepOut* out, hipStream_t s, bf16_t* h16_dst = nullptr) {
   const int H = n->H;
   void* st = (void*)s;
   const size_t NH_ = (size_t)N * H;
@@ -180,7 +180,7 @@ int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const 
   if (fused) {
     bf16_t* h16 = reinterpret_cast<bf16_t*>(wsp);
     wsp += 2 * NH_ * 2;
-    bf16_t* h16n = reinterpret_cast<bf16_t*>(wsp);
+    bf16_t* h16n = h16_dst ? h16_dst : reinterpret_cast<bf16_t*>(wsp);   // h16_dst: the caller's [L,N,H] buffer, written in place
     wsp += 2 * NH_ * 2;
     if (!h16_in) {
       CK(hsad_cast_pad_bf16(h0, 2 * N, H, H, h16, H, st));
@@ -353,12 +353,13 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   if (priv_s_bf16) a16 = (bf16_t*)priv_s_bf16;   // [N, Fp] as hsad_env_bind_packed writes it: no cast pass
   else CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
   StepOut so{};
-  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s));
-  if (h_out_bf16 && so.h16_new) HIP_TRY(hipMemcpyAsync(h_out_bf16, so.h16_new, (size_t)2 * N * H * 2, hipMemcpyDeviceToDevice, s));
+  // (the bf16 copy of the new state goes straight into the caller's buffer: it must not alias h0_bf16, which layer 1 still reads)
+  if (h_out_bf16 && h_out_bf16 == h0_bf16) return afail(HSAD_ERR_INVALID, "r2d2_act: h_out_bf16 must not alias h0_bf16");
+  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16));
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
-  CK(hsad_act_select(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, scratch, stream));
+  // action, greedy action and Q_online(s, a) from one pass over the heads (same arithmetic as hsad_act_select + hsad_q_head)
+  CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
   if (q_online_a) {
-    CK(hsad_q_head(hd, NH, legal_move, a, N, A, q, q_online_a, nullptr, scratch, stream));
     if (target->F != n->F || target->H != H || target->A != A) return afail(HSAD_ERR_INVALID, "r2d2_act: online / target shapes differ");
     StepOut st{};
     // the target pass shares the bf16 casts of the observation and (fused path) of the hidden state
@@ -366,7 +367,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);   // the cast net_step made
     CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s));
     CK(hsad_gemm_nt_bf16(st.o16, H, target->Wheads, H, N, NH, H, target->bheads, hd_t, NH, nullptr, 0, 0, 0, stream));
-    CK(hsad_q_head(hd_t, NH, legal_move, greedy_a, N, A, q, q_target_greedy, nullptr, scratch, stream));
+    CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
   }
   return 0;
 }

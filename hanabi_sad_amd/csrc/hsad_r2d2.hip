@@ -1904,6 +1904,107 @@ __global__ void act_select_kernel(const float* __restrict__ heads, int ldh, cons
   a_out[m] = act;
 }
 
+
+// ---- the acting tail with everything an actor step needs from the online heads in ONE kernel (after adv_min_kernel): eps-greedy
+// action, greedy action AND Q_online(s, a) of the chosen action -- the numbers act_select_kernel + q_head_kernel + min_reduce give,
+// in the same arithmetic, from one coalesced pass: a block stages its 256 rows of heads / legal through LDS (row strides 37 / 21
+// floats are odd: conflict-free), and reduces the per-block minima itself instead of waiting for a one-block reduction launch.
+__global__ __launch_bounds__(256) void act_select_q_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
+                                                           const float* __restrict__ eps, const float* __restrict__ block_min, int nb,
+                                                           int N, int A, unsigned long long seed, unsigned long long counter,
+                                                           int64_t* __restrict__ a_out, int64_t* __restrict__ greedy_out,
+                                                           float* __restrict__ qa_out, int R) {
+  extern __shared__ float s_act[];
+  float* s_h = s_act;                    // [R][ldh]   (R <= 256 rows per block: what fits 60 KB of LDS)
+  float* s_l = s_act + R * ldh;          // [R][A]
+  __shared__ float s_red[256];
+  const int tid = threadIdx.x, m0 = blockIdx.x * R, rows = min(R, N - m0);
+  for (int i = tid; i < rows * ldh; i += 256) s_h[i] = heads[(size_t)m0 * ldh + i];
+  for (int i = tid; i < rows * A; i += 256) s_l[i] = legal[(size_t)m0 * A + i];
+  float mn = 3.4e38f;
+  for (int i = tid; i < nb; i += 256) mn = fminf(mn, block_min[i]);
+  s_red[tid] = mn;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (tid < k) s_red[tid] = fminf(s_red[tid], s_red[tid + k]);
+    __syncthreads();
+  }
+  mn = s_red[0];
+  if (tid >= rows) return;
+  const int m = m0 + tid;
+  const float* h = s_h + tid * ldh;
+  const float* lg = s_l + tid * A;
+  float best = -3.4e38f, mean = 0.f;
+  int bi = 0, nlegal = 0;
+  for (int j = 0; j < A; ++j) {
+    const float l = lg[j];
+    const float sc = (1.f + h[j] - mn) * l;
+    if (sc > best) {
+      best = sc;
+      bi = j;
+    }
+    nlegal += l != 0.f;
+    mean += h[j] * l;
+  }
+  greedy_out[m] = bi;
+  int act = bi;
+  const float e = eps ? eps[m] : 0.f;
+  if (e > 0.f && nlegal > 0) {
+    const unsigned long long hh = act_mix64(act_mix64(seed ^ (0xD1342543DE82EF95ull * (unsigned long long)m)) + counter);
+    const float u = (float)((hh >> 40) & 0xFFFFFFull) * (1.f / 16777216.f);
+    if (u < e) {
+      int k = (int)(((hh & 0xFFFFFFFFull) * (unsigned long long)nlegal) >> 32);
+      for (int j = 0; j < A; ++j)
+        if (lg[j] != 0.f && k-- == 0) {
+          act = j;
+          break;
+        }
+    }
+  }
+  a_out[m] = act;
+  if (qa_out) {
+    mean /= (float)A;
+    qa_out[m] = h[A] + h[act] * lg[act] - mean;     // q_head_kernel's v + a*legal - mean_A(a*legal) at the chosen action
+  }
+}
+
+// Q(s, action) only (the target pass of an actor step: Q_target(s, greedy)): q_head_kernel's value at one action, no [M,A] matrix,
+// no minimum
+__global__ __launch_bounds__(256) void q_at_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
+                                                   const int64_t* __restrict__ action, int M, int A, float* __restrict__ qa, int R) {
+  extern __shared__ float s_act[];
+  float* s_h = s_act;
+  float* s_l = s_act + R * ldh;
+  const int tid = threadIdx.x, m0 = blockIdx.x * R, rows = min(R, M - m0);
+  for (int i = tid; i < rows * ldh; i += 256) s_h[i] = heads[(size_t)m0 * ldh + i];
+  for (int i = tid; i < rows * A; i += 256) s_l[i] = legal[(size_t)m0 * A + i];
+  __syncthreads();
+  if (tid >= rows) return;
+  const float* h = s_h + tid * ldh;
+  const float* lg = s_l + tid * A;
+  float mean = 0.f;
+  for (int j = 0; j < A; ++j) mean += h[j] * lg[j];
+  mean /= (float)A;
+  const int act = (int)action[m0 + tid];
+  qa[m0 + tid] = h[A] + h[act] * lg[act] - mean;
+}
+
+// fp32 h / c [L,N,H] and the bf16 copy of h an acting step carries, zeroed together for the rows whose env terminated
+__global__ __launch_bounds__(256) void zero_state_rows_kernel(float* __restrict__ h, float* __restrict__ c, unsigned* __restrict__ h16,
+                                                              const unsigned char* __restrict__ flag, int L, int N, int H,
+                                                              int rows_per_flag) {
+  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (layer, row) index
+  if (w >= (size_t)L * N) return;
+  const int row = (int)(w % N), lane = threadIdx.x & 63;
+  if (!flag[row / rows_per_flag]) return;
+  for (int i = lane; i < H; i += 64) {
+    h[w * H + i] = 0.f;
+    c[w * H + i] = 0.f;
+  }
+  if (h16)
+    for (int i = lane; i < H / 2; i += 64) h16[w * (H / 2) + i] = 0u;
+}
+
 // R2D2Agent.compute_priority tail (r2d2.py:355-360): |reward + bootstrap * gamma^n * target_qa - online_qa|
 __global__ void nstep_priority_kernel(const float* __restrict__ qa, const float* __restrict__ tqa, const float* __restrict__ reward,
                                       const float* __restrict__ bootstrap, float gamma_n, int N, float* __restrict__ out) {
@@ -2414,6 +2515,42 @@ int hsad_act_select(const float* heads, int ldh, const float* legal, const float
   hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
   hipLaunchKernelGGL(act_select_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, legal, eps, scratch, N, A,
                      (unsigned long long)seed, (unsigned long long)counter, a_out, greedy_out);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// rows of heads + legal a 256-thread block stages in <= 60 KB of LDS
+static int staged_rows(int ldh, int A) { return std::min(256, (60 * 1024) / ((ldh + A) * 4)); }
+
+int hsad_act_select_q(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
+                      uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* scratch, void* stream) {
+  if (!heads || !legal || !a_out || !greedy_out || !scratch) return nfail(HSAD_ERR_INVALID, "act_select_q: null");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (N + 255) / 256;
+  const int R = staged_rows(ldh, A);
+  if (R < 1) return nfail(HSAD_ERR_INVALID, "act_select_q: heads / legal rows too wide for the staged kernel");
+  hipLaunchKernelGGL(adv_min_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, N, A, scratch + 1);
+  hipLaunchKernelGGL(act_select_q_kernel, dim3((N + R - 1) / R), dim3(256), (size_t)R * (ldh + A) * 4, s, heads, ldh, legal, eps, scratch + 1,
+                     nb, N, A, (unsigned long long)seed, (unsigned long long)counter, a_out, greedy_out, qa_out, R);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_q_at(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* qa, void* stream) {
+  if (!heads || !legal || !action || !qa) return nfail(HSAD_ERR_INVALID, "q_at: null argument");
+  const int R = staged_rows(ldh, A);
+  if (R < 1) return nfail(HSAD_ERR_INVALID, "q_at: heads / legal rows too wide for the staged kernel");
+  hipLaunchKernelGGL(q_at_kernel, dim3((M + R - 1) / R), dim3(256), (size_t)R * (ldh + A) * 4, (hipStream_t)stream, heads, ldh, legal, action,
+                     M, A, qa, R);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_zero_state_rows(float* h, float* c, void* h_bf16, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream) {
+  if (!h || !c || !flag || rows_per_flag < 1 || (H & 1)) return nfail(HSAD_ERR_INVALID, "zero_state_rows: bad arguments");
+  const size_t waves = (size_t)L * N;
+  hipLaunchKernelGGL(zero_state_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, c,
+                     static_cast<unsigned*>(h_bf16), flag, L, N, H, rows_per_flag);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -486,15 +486,11 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
   const double popped = s_red[0];
   // weights = priority^alpha: computed and stored by all threads
   __shared__ __attribute__((aligned(16))) float s_w[4096];
-  __shared__ float s_chunk[64];
-  __shared__ double s_sum;
-  // The reference adds up a block's weights sequentially in FLOAT and adds that to the running double (blockAppend,
-  // prioritized_replay.h:59-74).  Its blocks are what ONE actor thread finishes at a time (<= a few dozen sequences); the lock-step
-  // pipeline appends thousands at once, and a float sum over thousands of weights is off by ~1e-2 -- after a few thousand adds the
-  // running sum has drifted past the 0.1 margin of the stratified draw ("draw beyond the weight sum", which the reference asserts
-  // on, too).  So the block is summed the way the reference would sum it had it arrived in blocks of 64: float, in order, inside a
-  // 64-chunk (one thread per chunk), the chunk sums added in order to a double.  Blocks of <= 64 are bit-identical to before.
-  if (tid == 0) s_sum = 0.0;
+  __shared__ float s_sum;
+  // the running sum grows by the block's weights added up sequentially in FLOAT (blockAppend, prioritized_replay.h:59-74): ONE
+  // thread, in order, out of LDS.  (The reference's blocks are one actor thread's handful; the thousands-at-once blocks of the
+  // lock-step pipeline make this sum lossy -- ~1e-2 per add -- which replay_sample_kernel repairs, see there.)
+  if (tid == 0) s_sum = 0.f;
   for (int base = 0; base < cnt; base += 4096) {
     const int m = min(4096, cnt - base);
     __syncthreads();
@@ -504,23 +500,24 @@ __global__ __launch_bounds__(256) void replay_add_ctl_kernel(ReplayDev rd, int n
       s_w[i] = w;
     }
     __syncthreads();
-    const int nchunk = (m + 63) / 64;
-    if (tid < nchunk) {
-      float sum = 0.f;
-      const int i1 = min(tid * 64 + 64, m);
-      for (int i = tid * 64; i < i1; ++i) sum += s_w[i];
-      s_chunk[tid] = sum;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      double acc = s_sum;
-      for (int k = 0; k < nchunk; ++k) acc += (double)s_chunk[k];
-      s_sum = acc;
+    if (tid == 0) {   // only the LDS reads are batched; the order of the additions is the reference's
+      float sum = s_sum;
+      int i = 0;
+      for (; i + 16 <= m; i += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(&s_w[i]), b = *reinterpret_cast<const float4*>(&s_w[i + 4]);
+        const float4 c4 = *reinterpret_cast<const float4*>(&s_w[i + 8]), d = *reinterpret_cast<const float4*>(&s_w[i + 12]);
+        sum += a.x; sum += a.y; sum += a.z; sum += a.w;
+        sum += b.x; sum += b.y; sum += b.z; sum += b.w;
+        sum += c4.x; sum += c4.y; sum += c4.z; sum += c4.w;
+        sum += d.x; sum += d.y; sum += d.z; sum += d.w;
+      }
+      for (; i < m; ++i) sum += s_w[i];
+      s_sum = sum;
     }
   }
   __syncthreads();
   if (tid != 0) return;
-  const double sum = s_sum;
+  const float sum = s_sum;
   c.sum -= popped;
   c.head = (c.head + npop) % rd.ring;
   c.size -= npop;
@@ -574,19 +571,9 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   const int tid = threadIdx.x;
   const ReplayCtl c = *rd.ctl;
   const int N = c.size, head = c.head, ring = rd.ring;
-  const float sum = (float)c.sum;
-  const float segment = sum / (B > 0 ? B : 1);
   // queue slot of this draw; a draw into a full queue replaces the newest entry (depth 1: the draw before it)
   const int q_full = c.q_count >= rd.depth;
   const int q_slot = (c.q_head + (q_full ? c.q_count - 1 : c.q_count)) % rd.depth;
-  if (tid < B) {
-    if (targets) {
-      s_rand[tid] = fminf(fmaxf(targets[tid], 0.f), sum * (1.f - 1e-6f));
-    } else {
-      float r = canon[tid] * segment + tid * segment;  // uniform_real_distribution(0, segment)(rng) + i * segment
-      s_rand[tid] = fminf(sum - 0.1f, r);
-    }
-  }
   // chunked prefix sums of the weights in ring order, accumulated in double like the reference's accSum
   const int C = (N + 1023) / 1024;
   {
@@ -604,6 +591,24 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     }
   }
   __syncthreads();
+  // The draw uses the RUNNING sum like the reference (sum_, maintained incrementally in blockAppend / blockPop / update).  That
+  // sum is lossy: every add contributes a float block sum, and the lock-step pipeline's blocks are thousands of sequences where
+  // the reference's are a handful, so it drifts by ~1e-2 per add -- after a few thousand adds a position lands beyond the real
+  // cumulative weight, which the reference answers with assert(false).  The exact total of the weights is on hand here (the last
+  // inclusive prefix), so a running sum that is off by more than half the draw's 0.1 safety margin is replaced by it.  Never
+  // happens at the reference's block sizes (parity tests: difference < 1e-3), keeps a long run alive.
+  const double exact = s_incl[1023];
+  const bool heal = fabs(c.sum - exact) > 0.05;
+  const float sum = (float)(heal ? exact : c.sum);
+  const float segment = sum / (B > 0 ? B : 1);
+  if (tid < B) {
+    if (targets) {
+      s_rand[tid] = fminf(fmaxf(targets[tid], 0.f), sum * (1.f - 1e-6f));
+    } else {
+      float r = canon[tid] * segment + tid * segment;  // uniform_real_distribution(0, segment)(rng) + i * segment
+      s_rand[tid] = fminf(sum - 0.1f, r);
+    }
+  }
   if (tid < B) {
     const float target = s_rand[tid];
     // first chunk whose inclusive prefix reaches the target (and is positive)
@@ -668,6 +673,7 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     for (int i = 1; i < B; ++i) m = fmaxf(m, s_y[i]);
     s_max = m;
     ReplayCtl cc = *rd.ctl;
+    if (heal) cc.sum = exact;
     cc.sum -= s_red[0];
     cc.head = (head + npop) % ring;
     cc.size = N - npop;
@@ -795,6 +801,16 @@ struct SeqDev {
   int* n_fin;       // [1]
 };
 
+// MultiStepBuffer::pushRewardAndTerminal for E = G * repeat rows from per-game values (IQL: every player of a game gets the game's
+// reward / terminal, create.py:115-131) in one launch instead of two repeat_interleave ops + two copies
+__global__ void seq_push_rt_kernel(float* __restrict__ hr, unsigned char* __restrict__ ht, const float* __restrict__ reward,
+                                   const unsigned char* __restrict__ terminal, int E, int repeat) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  hr[e] = reward[e / repeat];
+  ht[e] = terminal[e / repeat];
+}
+
 // MultiStepBuffer::popTransition (rela/transition_buffer.h:51-99)
 __global__ void seq_pop_kernel(SeqDev sd, int head, float* o_reward, unsigned char* o_terminal, float* o_bootstrap) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -855,31 +871,61 @@ __global__ __launch_bounds__(256) void seq_push_kernel(SeqDev sd, int row_bytes,
 }
 
 // R2D2Buffer::popTransition bookkeeping: the finished envs, in ascending env order (the order the reference appends them in).
-// 16 wavefronts, each owns a contiguous sixteenth of the envs and walks it 64 at a time with coalesced loads: a ballot gives the
-// finished ones of the 64, popcounts give their slots.
+// 16 wavefronts, each owns a contiguous sixteenth of the envs and reads it ONCE, 256 envs per step (one 16-byte load per lane,
+// all of a wavefront's loads issued before the first is used); a shuffle prefix sum over the lanes' counts gives the slots.
+constexpr int kCollectIters = 16;   // 16 wavefronts x 16 steps x 256 envs = 65,536 envs per pass over the registers
 __global__ __launch_bounds__(1024) void seq_collect_kernel(SeqDev sd, float eta, float c1m, int* n_out) {
   __shared__ int s_cnt[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = ((sd.E + 15) / 16 + 63) & ~63;          // envs per wavefront, a multiple of 64
-  const int e0 = wave * per, e1 = min(e0 + per, sd.E);
-  int cnt = 0;
-  for (int e = e0 + lane; e - lane < e1; e += 64) cnt += __popcll(__ballot(e < e1 && sd.len[e] > 0));
-  if (lane == 0) s_cnt[wave] = cnt;
-  __syncthreads();
-  int k = 0, total = 0;
-  for (int w = 0; w < 16; ++w) {
-    if (w < wave) k += s_cnt[w];
-    total += s_cnt[w];
+  // envs per wavefront and pass: a multiple of 256, at most kCollectIters * 256; pass p covers [p * 16 * span, (p + 1) * 16 * span)
+  const int span = min(kCollectIters * 256, ((sd.E + 15) / 16 + 255) & ~255);
+  int k_base = 0;                                           // finished envs before this pass (E > 65,536: several passes)
+  for (int p0 = 0; p0 < sd.E; p0 += 16 * span) {
+    const int e0 = p0 + wave * span, e1 = min(e0 + span, sd.E);
+    unsigned fin[kCollectIters];    // bit j = env (e0 + it * 256 + lane * 4 + j) finished
+    int cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kCollectIters; ++it) {
+      const int e = e0 + it * 256 + lane * 4;
+      unsigned f = 0;
+      if (e + 3 < e1) {
+        const int4 v = *reinterpret_cast<const int4*>(sd.len + e);
+        f = (v.x > 0 ? 1u : 0u) | (v.y > 0 ? 2u : 0u) | (v.z > 0 ? 4u : 0u) | (v.w > 0 ? 8u : 0u);
+      } else {
+        for (int j = 0; j < 4; ++j)
+          if (e + j < e1 && sd.len[e + j] > 0) f |= 1u << j;
+      }
+      fin[it] = f;
+      cnt += __popc(f);
+    }
+    int wsum = cnt;
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, 64);
+    __syncthreads();                 // (s_cnt of the previous pass has been consumed)
+    if (lane == 0) s_cnt[wave] = wsum;
+    __syncthreads();
+    int k = k_base, total = 0;
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) k += s_cnt[w];
+      total += s_cnt[w];
+    }
+    k_base += total;
+#pragma unroll
+    for (int it = 0; it < kCollectIters; ++it) {
+      const int c = __popc(fin[it]);
+      int incl = c;                  // inclusive prefix sum of the lanes' counts
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      int pos = k + incl - c;
+      for (int j = 0; j < 4; ++j)
+        if ((fin[it] >> j) & 1u) sd.fin_env[pos++] = e0 + it * 256 + lane * 4 + j;
+      k += __shfl(incl, 63, 64);
+    }
   }
   if (tid == 0) {
-    sd.n_fin[0] = total;
-    if (n_out) n_out[0] = total;
-  }
-  for (int e = e0 + lane; e - lane < e1; e += 64) {
-    const bool fin = e < e1 && sd.len[e] > 0;
-    const unsigned long long m = __ballot(fin);
-    if (fin) sd.fin_env[k + __popcll(m & ((1ull << lane) - 1ull))] = e;
-    k += __popcll(m);
+    sd.n_fin[0] = k_base;
+    if (n_out) n_out[0] = k_base;
   }
 }
 
@@ -1434,6 +1480,17 @@ int hsad_seqwriter_push_reward_terminal(hsad_seqwriter* w, const float* reward, 
                          hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(hipMemcpyAsync(w->sd.hist_t + (size_t)slot * w->sd.E, terminal, w->sd.E, hipMemcpyDeviceToDevice,
                          (hipStream_t)stream));
+  w->rt_count += 1;
+  return HSAD_OK;
+}
+
+int hsad_seqwriter_push_reward_terminal_rep(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, int repeat, void* stream) {
+  if (!w || !reward || !terminal || repeat < 1 || w->sd.E % repeat) return rfail(HSAD_ERR_INVALID, "bad argument");
+  if (w->rt_count != w->count - 1) return rfail(HSAD_ERR_STATE, "reward/terminal must follow each obs/action push");
+  const int slot = (w->head + w->rt_count) % w->sd.depth;
+  hipLaunchKernelGGL(seq_push_rt_kernel, dim3((w->sd.E + 255) / 256), dim3(256), 0, (hipStream_t)stream, w->sd.hist_r + (size_t)slot * w->sd.E,
+                     w->sd.hist_t + (size_t)slot * w->sd.E, reward, terminal, w->sd.E, repeat);
+  HIP_TRY(hipGetLastError());
   w->rt_count += 1;
   return HSAD_OK;
 }

@@ -908,6 +908,13 @@ class R2D2Agent:
 
 def zero_hidden_rows(hid, terminal_u8, rows_per_flag):
     lib = _lib.load_library()
+    h, c, h16 = hid["h0"], hid["c0"], hid.get("h0_16")
+    if h.dtype == torch.float32 and c.dtype == torch.float32 and h.shape[2] % 2 == 0:      # one launch for the whole carried state
+        L, N, H = h.shape
+        assert h.is_contiguous() and c.is_contiguous() and (h16 is None or h16.is_contiguous())
+        _lib.check(lib.hsad_zero_state_rows(h.data_ptr(), c.data_ptr(), None if h16 is None else h16.data_ptr(),
+                                            terminal_u8.data_ptr(), L, N, H, rows_per_flag, _s(h.device)))
+        return
     for k in ("h0", "c0"):
         x = hid[k]
         L, N, H = x.shape

@@ -330,9 +330,15 @@ class SequenceWriter:
             ts.append(t)
         _lib.check(self.lib.hsad_seqwriter_push_obs_action(self.h, _ptr_array(ts), _stream(self.device)))
 
-    def push_reward_terminal(self, reward, terminal):
+    def push_reward_terminal(self, reward, terminal, repeat=1):
+        """reward / terminal of this step: [E], or with repeat = k per-game values [E / k] that every k consecutive rows share"""
         reward = reward.to(torch.float32).contiguous()
         terminal = terminal.to(torch.uint8).contiguous()
+        if repeat > 1:
+            assert reward.numel() * repeat == self.E and terminal.numel() * repeat == self.E
+            _lib.check(self.lib.hsad_seqwriter_push_reward_terminal_rep(self.h, reward.data_ptr(), terminal.data_ptr(), int(repeat),
+                                                                        _stream(self.device)))
+            return
         _lib.check(self.lib.hsad_seqwriter_push_reward_terminal(self.h, reward.data_ptr(), terminal.data_ptr(),
                                                                 _stream(self.device)))
 

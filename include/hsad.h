@@ -292,6 +292,8 @@ int hsad_seqwriter_push_obs_action(hsad_seqwriter* w, const void* const* fields,
 int hsad_seqwriter_set_prepacked(hsad_seqwriter* w, uint32_t field_mask);
 /* MultiStepBuffer::pushRewardAndTerminal: reward float32 [E], terminal uint8 [E] */
 int hsad_seqwriter_push_reward_terminal(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, void* stream);
+/* the same from per-GAME values: row e gets reward[e / repeat], terminal[e / repeat] (IQL: repeat = players) */
+int hsad_seqwriter_push_reward_terminal_rep(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, int repeat, void* stream);
 /* MultiStepBuffer::canPop (host-side count, no synchronisation) */
 int hsad_seqwriter_can_pop(const hsad_seqwriter* w);
 /* MultiStepBuffer::popTransition: n-step return / bootstrap / terminal of the oldest step -> float32/uint8 [E];
@@ -417,6 +419,13 @@ int hsad_nstep_priority(const float* qa, const float* target_qa, const float* re
                         int multi_step, double gamma, int N, float* out, void* stream);
 /* zero rows r of fp32 x[L,N,H] where flag[r / rows_per_flag] != 0 (hidden-state reset on terminal, r2d2_actor.h:109-126) */
 int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);
+/* the same three results an acting step needs from the online heads in one pass: hsad_act_select + Q(s, a) of the chosen action
+ * (hsad_q_head's value at a_out; qa_out may be NULL), and Q(s, action) alone for the target pass */
+int hsad_act_select_q(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
+                      uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* scratch, void* stream);
+int hsad_q_at(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* qa, void* stream);
+/* hsad_zero_rows for the whole carried state at once: fp32 h / c [L,N,H] and (optional) the bf16 copy of h */
+int hsad_zero_state_rows(float* h, float* c, void* h_bf16, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);
 /* One recurrence of a multi-recurrence chunk launch (see hsad_lstm_forward_chunk for the field meanings) */
 typedef struct hsad_lstm_fwd_rec {
   float* gates;
