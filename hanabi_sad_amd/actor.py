@@ -57,6 +57,8 @@ class DeviceActor:
         self.n_checked = self.n_checked_stale = 0
         self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
         self.n_finished = torch.zeros(1, dtype=torch.int32, device=env.device)
+        self._side = torch.cuda.Stream(env.device) if self.cached_q else None      # reset of ended games, see _reset_terminated
+        self._reset_pending = False
 
     def _rows(self):
         e, N = self.env, self.N
@@ -66,10 +68,34 @@ class DeviceActor:
         return {"priv_s": e.priv_s.view(N, e.F), "legal_move": e.legal_move.view(N, e.A), "eps": e.eps.view(N),
                 "own_hand": e.own_hand.view(N, 3 * e.H)}
 
+    def _reset_terminated(self):
+        """`if (terminated) reset` at the top of the thread-loop body (cpp/thread_loop.h:46-52).  The reset kernel is latency-bound --
+        a handful of lanes each shuffle a deck with mt19937 while the rest of the chip idles (~35 us) -- and nothing between one
+        env.step and the next act() touches the env, so the reset of the games that just ended is issued on a side stream right
+        after env.step (_prefetch_reset) and overlaps the n-step / sequence / replay bookkeeping of the same iteration; the end of
+        step() joins it, so nothing outside step() ever runs next to it."""
+        if self._reset_pending:
+            self._reset_pending = False       # already issued behind the previous env.step and joined at the end of that step()
+        else:
+            self.env.reset()
+
+    def _prefetch_reset(self):
+        if self._side is None:
+            return
+        main = torch.cuda.current_stream(self.env.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self.env.reset()
+        self._reset_pending = True
+
+    def _join_reset(self):
+        if self._reset_pending:
+            torch.cuda.current_stream(self.env.device).wait_stream(self._side)
+
     def step(self):
         """one iteration of the thread-loop body: reset-terminated -> act -> step -> postAct"""
         env, agent, P = self.env, self.agent, self.P
-        env.reset()
+        self._reset_terminated()
         obs = self._rows()
         # historyHidden_.push_back(hidden_): by reference -- R2D2Agent.act returns fresh state tensors and never writes the
         # ones it is given, and zero_hidden_rows below only touches the new ones, which enter the history next step
@@ -89,11 +115,13 @@ class DeviceActor:
         fields["a"], fields["greedy_a"] = reply["a"], reply["greedy_a"]
         self.writer.push_obs_action(fields)
         env.step(reply["a"].view(self.G, P), reply["greedy_a"].view(self.G, P))
+        self._prefetch_reset()
         self.num_act += self.N               # Tachometer counts P acts per game step in both layouts (utils.py:229-236)
         # postAct: reward / terminal of the game go to each of its players' rows (IQL) or to the game's row (VDN)
         self.writer.push_reward_terminal(env.reward, env.terminal, repeat=1 if self.vdn else P)
         zero_hidden_rows(self.hid, env.terminal, P)                                    # r2d2_actor.h:109-126
         if not self.writer.can_pop():
+            self._join_reset()
             return
         hid_s = self.history_hid.popleft()
         qa_s, version_s = self.q_hist.popleft()
@@ -115,7 +143,8 @@ class DeviceActor:
             self.n_checked += 1
             self.n_checked_stale += int(stale)
         self.writer.push_sequence(prio)
-        self.n_finished = self.writer.flush_to_replay(self.replay, self.eta)
+        self.n_finished = self.writer.flush_to_replay(self.replay, self.eta, out=self.n_finished)
+        self._join_reset()
 
     def _step_contract(self, obs):
         """the rest of step() for a model that only offers the reference's contract (act / compute_priority): the n-step

@@ -361,14 +361,15 @@ class SequenceWriter:
             terminal.data_ptr(), bootstrap.data_ptr(), _stream(d)))
         names = [n for n, _, _ in self.fields]
         return (dict(zip(names, cur)) if cur else None, dict(zip(names, nxt)) if nxt else None, reward,
-                terminal.bool(), bootstrap)
+                terminal.view(torch.bool), bootstrap)          # (0 / 1 bytes: reinterpreted, not converted)
 
     def push_sequence(self, priority):
         priority = priority.to(torch.float32).contiguous()
         _lib.check(self.lib.hsad_seqwriter_push_sequence(self.h, priority.data_ptr(), _stream(self.device)))
 
-    def flush_to_replay(self, replay, eta):
-        n = torch.zeros(1, dtype=torch.int32, device=self.device)
+    def flush_to_replay(self, replay, eta, out=None):
+        """finished sequences -> replay; returns the device counter of how many (written by the kernel; `out` reuses a tensor)"""
+        n = out if out is not None else torch.empty(1, dtype=torch.int32, device=self.device)
         _lib.check(self.lib.hsad_seqwriter_flush_to_replay(self.h, replay.h, float(eta), n.data_ptr(),
                                                            _stream(self.device)))
         return n
