@@ -532,7 +532,10 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   const bool pipe0 = can_pipeline(L);
   const size_t Mp = pad64((int)M);
   L->Mp = (int)Mp;
-  const size_t Tc = T / nch, nrb = nrb_of((int)B), xf = Tc * nrb * 32 * H, xb = Tc * nrb * 32 * H4;
+  // hand-off buffers and counter blocks are sized for the longest chunk any schedule can ask for (chunks = 1: Tc = T), so that
+  // hsad_r2d2_learner_set_schedule may change the chunk count of an existing learner
+  (void)nch;
+  const size_t Tc = T, nrb = nrb_of((int)B), xf = Tc * nrb * 32 * H, xb = Tc * nrb * 32 * H4;
   // ---- one arena for every activation of an update ----
   std::vector<std::pair<void**, size_t>> plan;
   auto want = [&](auto** pp, size_t bytes) { plan.push_back({reinterpret_cast<void**>(pp), (bytes + 255) & ~(size_t)255}); };
@@ -646,6 +649,13 @@ void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* L) { return L ? L->gflat : nullptr; }
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_split) {
   if (!L || chunks < 1 || wgrad_split < 1 || wgrad_split > 8) return afail(HSAD_ERR_INVALID, "learner_set_schedule: chunks >= 1, wgrad_split 1..8");
+  if (chunks != L->chunks) {
+    // the counter blocks of the ping-pong launches are laid out per chunk length: start the new schedule from clean ones
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
+    for (int k = 0; k < 2; ++k)
+      for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
+  }
   L->chunks = chunks;
   L->wgrad_split = wgrad_split;
   return 0;
@@ -655,11 +665,13 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
   if (!L || !timed_out) return afail(HSAD_ERR_INVALID, "null argument");
   HIP_TRY(hipDeviceSynchronize());
   *timed_out = 0;
+  // the sticky word sits behind the counters of a launch: (recurrences) x (row blocks) x (chunk length + 2) words in
+  const size_t Tc = (size_t)L->T / pick_chunks(L), nrb = nrb_of(L->B);
   for (int k = 0; k < 2; ++k)
     for (int r = 0; r < 4; ++r)
       for (int f = 0; f < 2; ++f) {
         unsigned v = 0;
-        HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + L->sync_words[k][r] - 4, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + (size_t)(r + 1) * nrb * (Tc + 2), 4, hipMemcpyDeviceToHost));
         *timed_out |= (int32_t)v;
       }
   return 0;

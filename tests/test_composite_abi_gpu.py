@@ -238,3 +238,27 @@ def test_bf16_observation_operands_give_the_same_bits_as_float32_inputs():
             assert relerr(la.grad[k], lb.grad[k]) < 1e-5, k
     la.check_sync()
     lb.check_sync()
+
+
+def test_schedule_of_an_existing_learner_can_be_changed():
+    """hsad_r2d2_learner_set_schedule after creation: hand-off buffers and counter blocks are sized for any chunk count (a learner
+    created with 4 chunks and switched to 2 used to overrun its counter blocks: 884 ms updates that ended in the sticky time-out);
+    the schedule only changes WHEN things run -- loss and priorities are bit-identical, no time-out"""
+    from hanabi_sad_amd.composite import CompositeLearner
+    from hanabi_sad_amd.selfplay import init_weights
+    from tests.test_r2d2_kernels_gpu import _rand_batch
+    F, H, A, T, B = 838, 512, 21, 80, 128
+    W, Wt = init_weights(F, H, A, 5, 1), init_weights(F, H, A, 5, 2)
+    batch, weight = _rand_batch(T, B, F, A)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    ref_loss, ref_prio = L.loss(batch, weight, 0.0)
+    ref_g = {k: v.clone() for k, v in L.grad.items() if k.startswith("lstm.weight")}
+    for chunks in (2, 8, 1, 5, 4):
+        import ctypes as C
+        from hanabi_sad_amd import _lib
+        _lib.check(L.lib.hsad_r2d2_learner_set_schedule(L.h, chunks, 8))
+        loss, prio = L.loss(batch, weight, 0.0)
+        assert torch.equal(loss, ref_loss) and torch.equal(prio, ref_prio), chunks
+        for k, v in ref_g.items():
+            assert relerr(L.grad[k], v) < 1e-5, (chunks, k)
+        L.check_sync()
