@@ -135,6 +135,10 @@ SIGNATURES = {
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "hsad_nstep_priority": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "hsad_zero_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "hsad_refresh_begin": (C.c_int, []),
+    "hsad_refresh_add_weight": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int]),
+    "hsad_refresh_add_bias": (C.c_int, [_P, _P, _P, _P, C.c_int]),
+    "hsad_refresh_launch": (C.c_int, [_P]),
     "hsad_act_select_q": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
     "hsad_q_at": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "hsad_zero_state_rows": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -133,31 +133,39 @@ size_t net_tensor_elems(const hsad_r2d2_net* n, int i) {
 
 int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
   const int H = n->H;
-  void* st = (void*)s;
   n->version++;
-  CK(hsad_prepare_weight(n->w(P_W1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0, st));
+  // every derived operand in one launch: weight jobs first, then the biases
+  CK(hsad_refresh_begin());
+  CK(hsad_refresh_add_weight(n->w(P_W1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0));
   for (int l = 0; l < 2; ++l) {
     const float* wih = n->w(l ? P_WIH1 : P_WIH0);
     const float* whh = n->w(l ? P_WHH1 : P_WHH0);
-    const float* bih = n->w(l ? P_BIH1 : P_BIH0);
-    const float* bhh = n->w(l ? P_BHH1 : P_BHH0);
-    CK(hsad_prepare_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H, st));
-    CK(hsad_prepare_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H, st));
-    CK(hsad_bias_sum_perm(bih, bhh, n->perm32, n->bg[l], 4 * H, st));
+    CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H));
+    CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H));
     if (n->Wcat16[l] && !n->with_backward) {
-      CK(hsad_prepare_weight(wih, 4 * H, H, H, n->perm16, n->Wcat16[l], 2 * H, nullptr, 0, st));
-      CK(hsad_prepare_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0, st));
-      CK(hsad_bias_sum_perm(bih, bhh, n->perm16, n->bias16[l], 4 * H, st));
+      CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm16, n->Wcat16[l], 2 * H, nullptr, 0));
+      CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0));
     }
   }
   const int wi[3] = {P_WA, P_WV, P_WP}, bi[3] = {P_BA, P_BV, P_BP}, rows[3] = {n->A, 1, n->NP};
   int r0 = 0;
   for (int k = 0; k < 3; ++k) {
-    CK(hsad_prepare_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
-                           n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp, st));
-    CK(hsad_bias_sum_perm(n->w(bi[k]), nullptr, nullptr, n->bheads + r0, rows[k], st));
+    CK(hsad_refresh_add_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
+                               n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp));
     r0 += rows[k];
   }
+  for (int l = 0; l < 2; ++l) {
+    const float* bih = n->w(l ? P_BIH1 : P_BIH0);
+    const float* bhh = n->w(l ? P_BHH1 : P_BHH0);
+    CK(hsad_refresh_add_bias(bih, bhh, n->perm32, n->bg[l], 4 * H));
+    if (n->Wcat16[l] && !n->with_backward) CK(hsad_refresh_add_bias(bih, bhh, n->perm16, n->bias16[l], 4 * H));
+  }
+  r0 = 0;
+  for (int k = 0; k < 3; ++k) {
+    CK(hsad_refresh_add_bias(n->w(bi[k]), nullptr, nullptr, n->bheads + r0, rows[k]));
+    r0 += rows[k];
+  }
+  CK(hsad_refresh_launch((void*)s));
   return 0;
 }
 

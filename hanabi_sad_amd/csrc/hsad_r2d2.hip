@@ -446,6 +446,66 @@ __global__ void prepare_weight_kernel(const float* __restrict__ src, int R, int 
   }
 }
 
+
+// Every operand of a net re-derived from its fp32 master weights in ONE launch (net_refresh: 8 weight matrices + 5 biases used to be 13
+// launches of ~5 us each at the end of every learner update).  Weight job = prepare_weight_kernel's work for one matrix; bias job =
+// bias_sum_perm_kernel's.  blockIdx.x walks the 32x32 tiles of all weight jobs, then 256-element blocks of the bias jobs.
+struct RefreshWeightJob {
+  const float* src;
+  const int32_t* perm;
+  bf16_t* dst;
+  bf16_t* dstT;
+  int R, C, lds, ldd, ldt, tiles_c, tile0;
+};
+struct RefreshBiasJob {
+  const float* a;
+  const float* b;
+  const int32_t* perm;
+  float* out;
+  int n, block0;
+};
+struct RefreshJobs {
+  RefreshWeightJob w[12];
+  RefreshBiasJob b[8];
+  int nw, nb, weight_tiles, total_blocks;
+};
+__global__ __launch_bounds__(256) void refresh_jobs_kernel(RefreshJobs J) {
+  __shared__ bf16_t tile[32][33];
+  const int blk = blockIdx.x, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (blk < J.weight_tiles) {
+    int k = 0;
+    while (k + 1 < J.nw && blk >= J.w[k + 1].tile0) ++k;
+    const RefreshWeightJob& q = J.w[k];
+    const int t = blk - q.tile0;
+    const int c0 = (t % q.tiles_c) * 32, r0 = (t / q.tiles_c) * 32;
+    for (int i = ty; i < 32; i += 8) {
+      const int r = r0 + i, c = c0 + tx;
+      bf16_t v = (bf16_t)0;
+      if (r < q.R && c < q.C) {
+        v = f2bf(q.src[(size_t)(q.perm ? q.perm[r] : r) * q.lds + c]);
+        if (q.dst) q.dst[(size_t)r * q.ldd + c] = v;
+      }
+      tile[i][tx] = v;
+    }
+    if (!q.dstT) return;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < q.C && r < q.R) q.dstT[(size_t)c * q.ldt + r] = tile[tx][i];
+    }
+    return;
+  }
+  const int bb = blk - J.weight_tiles;
+  int k = 0;
+  while (k + 1 < J.nb && bb >= J.b[k + 1].block0) ++k;
+  const RefreshBiasJob& q = J.b[k];
+  const int i = (bb - q.block0) * 256 + threadIdx.x;
+  if (i < q.n) {
+    const int j = q.perm ? q.perm[i] : i;
+    q.out[i] = q.a[j] + (q.b ? q.b[j] : 0.f);
+  }
+}
+
 // out[i] = a[perm[i]] + b[perm[i]]  (gate bias b_ih + b_hh in the gate-blocked order)
 __global__ void bias_sum_perm_kernel(const float* a, const float* b, const int32_t* perm, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1509,34 +1569,50 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgsN m) {
 // heads fp32 [M, ldh]: columns [0, A) = advantage, column A = value.  legal fp32 [M, A].
 // pass 1: q = v + a*legal - mean_A(a*legal), qa = q[action], per-block min(q);  pass 2: greedy with the GLOBAL min.
 // ---------------------------------------------------------------------------------------------------
-__global__ void q_head_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
-                              const int64_t* __restrict__ action, int M, int A, float* __restrict__ q,
-                              float* __restrict__ qa, float* __restrict__ block_min) {
+__global__ __launch_bounds__(256) void q_head_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ legal,
+                                                     const int64_t* __restrict__ action, int M, int A, float* __restrict__ q,
+                                                     float* __restrict__ qa, float* __restrict__ block_min, int R) {
+  // a block stages its R <= 256 rows of heads / legal through LDS with coalesced loads (row strides of 37 / 21 floats made the
+  // thread-per-row version touch 64 cache lines per load instruction) and writes its q rows back the same way
+  extern __shared__ float s_qh[];
+  float* s_h = s_qh;                 // [R][ldh]
+  float* s_l = s_qh + R * ldh;       // [R][A]  legal, then q
   __shared__ float smin[256];
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  const int tid = threadIdx.x;
   float mn = 3.4e38f;
-  if (m < M) {
-    const float* h = heads + (size_t)m * ldh;
-    const float* lg = legal + (size_t)m * A;
-    const float v = h[A];
-    float mean = 0.f;
-    for (int j = 0; j < A; ++j) mean += h[j] * lg[j];
-    mean /= (float)A;
-    const int act = action ? (int)action[m] : 0;
-    for (int j = 0; j < A; ++j) {
-      const float qq = v + h[j] * lg[j] - mean;
-      q[(size_t)m * A + j] = qq;
-      mn = fminf(mn, qq);
-      if (action && j == act) qa[m] = qq;
+  // a block owns 256 rows (one minimum per 256 rows: the scratch contract of hsad_q_head) and walks them R at a time
+  for (int sub = 0; sub < 256; sub += R) {
+    const int m0 = blockIdx.x * 256 + sub, rows = min(min(R, 256 - sub), M - m0);
+    if (rows <= 0) break;
+    __syncthreads();
+    for (int i = tid; i < rows * ldh; i += 256) s_h[i] = heads[(size_t)m0 * ldh + i];
+    for (int i = tid; i < rows * A; i += 256) s_l[i] = legal[(size_t)m0 * A + i];
+    __syncthreads();
+    if (tid < rows) {
+      const float* h = s_h + tid * ldh;
+      float* lg = s_l + tid * A;
+      const float v = h[A];
+      float mean = 0.f;
+      for (int j = 0; j < A; ++j) mean += h[j] * lg[j];
+      mean /= (float)A;
+      const int act = action ? (int)action[m0 + tid] : 0;
+      for (int j = 0; j < A; ++j) {
+        const float qq = v + h[j] * lg[j] - mean;
+        lg[j] = qq;
+        mn = fminf(mn, qq);
+        if (action && j == act) qa[m0 + tid] = qq;
+      }
     }
+    __syncthreads();
+    for (int i = tid; i < rows * A; i += 256) q[(size_t)m0 * A + i] = s_l[i];
   }
-  smin[threadIdx.x] = mn;
+  smin[tid] = mn;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if (threadIdx.x < s) smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+    if (tid < s) smin[tid] = fminf(smin[tid], smin[tid + s]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) block_min[blockIdx.x] = smin[0];
+  if (tid == 0) block_min[blockIdx.x] = smin[0];
 }
 
 __global__ void min_reduce_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
@@ -1786,19 +1862,31 @@ __global__ void sum_slabs_kernel(const float* __restrict__ ws, int n, int M, int
 
 // column sums of a bf16 or fp32 [M, ld] matrix -> fp32 [N]   (bias gradients).  Grid = (N/64, row chunks of 512);
 // block 64x4: coalesced 64-column row segments, LDS reduce, one atomicAdd per column per block (out pre-zeroed).
+constexpr int kColsumRows = 128;   // rows per block: a [10240, 512] matrix is 8 x 80 blocks (was 8 x 20: a quarter of the CUs, 55 us)
 template <typename TIn>
 __global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld, float* __restrict__ out,
                               float* __restrict__ out2 = nullptr, const int32_t* __restrict__ col_map = nullptr) {
   __shared__ float s[4][65];
   const int col = blockIdx.x * 64 + threadIdx.x;
-  const int r0 = blockIdx.y * 512, r1 = min(M, r0 + 512);
+  const int r0 = blockIdx.y * kColsumRows, r1 = min(M, r0 + kColsumRows);
   float acc = 0.f;
   if (col < N)
-    for (int r = r0 + threadIdx.y; r < r1; r += 4) {
-      if constexpr (sizeof(TIn) == 2)
-        acc += bf2f(src[(size_t)r * ld + col]);
-      else
-        acc += src[(size_t)r * ld + col];
+    for (int rb = r0 + threadIdx.y; rb < r1; rb += 32) {     // eight independent loads per round
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 4 * u;
+        if (r < r1) {
+          if constexpr (sizeof(TIn) == 2)
+            v[u] = bf2f(src[(size_t)r * ld + col]);
+          else
+            v[u] = src[(size_t)r * ld + col];
+        } else {
+          v[u] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
     }
   s[threadIdx.y][threadIdx.x] = acc;
   __syncthreads();
@@ -1814,7 +1902,19 @@ __global__ void colsum_kernel(const TIn* __restrict__ src, int M, int N, int ld,
 __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* __restrict__ out) {
   __shared__ float s[256];
   float acc = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += g[i] * g[i];
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nth = (size_t)gridDim.x * 256;
+  if ((((uintptr_t)g) & 15) == 0) {            // 16-byte loads, two in flight per thread
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const size_t n4 = n >> 2;
+    for (size_t i = tid; i < n4; i += 2 * nth) {
+      const float4 a = g4[i];
+      const float4 b = i + nth < n4 ? g4[i + nth] : make_float4(0.f, 0.f, 0.f, 0.f);
+      acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    }
+    for (size_t i = (n4 << 2) + tid; i < n; i += nth) acc += g[i] * g[i];
+  } else {
+    for (size_t i = tid; i < n; i += nth) acc += g[i] * g[i];
+  }
   s[threadIdx.x] = acc;
   __syncthreads();
   for (int k = 128; k > 0; k >>= 1) {
@@ -2206,6 +2306,43 @@ int hsad_prepare_weight(const float* src, int R, int C, int ld_src, const int32_
   return HSAD_OK;
 }
 
+// ---- batched refresh: hsad_refresh_begin / _add_weight / _add_bias / _launch (one kernel for every operand of a net) ----
+struct hsad_refresh_batch {
+  RefreshJobs J;
+};
+static thread_local hsad_refresh_batch g_refresh;
+
+int hsad_refresh_begin() {
+  g_refresh.J.nw = g_refresh.J.nb = g_refresh.J.weight_tiles = g_refresh.J.total_blocks = 0;
+  return HSAD_OK;
+}
+int hsad_refresh_add_weight(const float* src, int R, int C, int ld_src, const int32_t* perm, void* dst16, int ld_dst, void* dstT16,
+                            int ld_dstT) {
+  RefreshJobs& J = g_refresh.J;
+  if (!src || (!dst16 && !dstT16) || R <= 0 || C <= 0 || J.nw >= 12 || J.nb != 0)
+    return nfail(HSAD_ERR_INVALID, "refresh_add_weight: bad arguments, more than 12 matrices, or a weight after a bias");
+  RefreshWeightJob& q = J.w[J.nw++];
+  q = RefreshWeightJob{src, perm, (bf16_t*)dst16, (bf16_t*)dstT16, R, C, ld_src, ld_dst, ld_dstT, (C + 31) / 32, J.weight_tiles};
+  J.weight_tiles += q.tiles_c * ((R + 31) / 32);
+  J.total_blocks = J.weight_tiles;
+  return HSAD_OK;
+}
+int hsad_refresh_add_bias(const float* a, const float* b, const int32_t* perm, float* out, int n) {
+  RefreshJobs& J = g_refresh.J;
+  if (!a || !out || n <= 0 || J.nb >= 8) return nfail(HSAD_ERR_INVALID, "refresh_add_bias: bad arguments or more than 8 biases");
+  RefreshBiasJob& q = J.b[J.nb++];
+  q = RefreshBiasJob{a, b, perm, out, n, J.total_blocks - J.weight_tiles};
+  J.total_blocks += (n + 255) / 256;
+  return HSAD_OK;
+}
+int hsad_refresh_launch(void* stream) {
+  RefreshJobs& J = g_refresh.J;
+  if (J.total_blocks < 1) return HSAD_OK;
+  hipLaunchKernelGGL(refresh_jobs_kernel, dim3(J.total_blocks), dim3(256), 0, (hipStream_t)stream, J);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
 int hsad_bias_sum_perm(const float* a, const float* b, const int32_t* perm, float* out, int n, void* stream) {
   if (!a || !out || n <= 0) return nfail(HSAD_ERR_INVALID, "bias_sum_perm: bad arguments");
   hipLaunchKernelGGL(bias_sum_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, b, perm, out, n);
@@ -2367,13 +2504,19 @@ int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* t
   return HSAD_OK;
 }
 
+// rows of heads + legal a 256-thread block stages in <= 60 KB of LDS
+static int staged_rows(int ldh, int A) { return std::min(256, (60 * 1024) / ((ldh + A) * 4)); }
+
 int hsad_q_head(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* q,
                 float* qa, int64_t* greedy, float* scratch, void* stream) {
   if (!heads || !legal || !q || !scratch) return nfail(HSAD_ERR_INVALID, "q_head: null argument");
   if (action && !qa) return nfail(HSAD_ERR_INVALID, "q_head: qa output required with actions");
   hipStream_t s = (hipStream_t)stream;
+  const int R = staged_rows(ldh, A);
+  if (R < 1) return nfail(HSAD_ERR_INVALID, "q_head: heads / legal rows too wide for the staged kernel");
   const int nb = (M + 255) / 256;
-  hipLaunchKernelGGL(q_head_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, legal, action, M, A, q, qa, scratch + 1);
+  hipLaunchKernelGGL(q_head_kernel, dim3(nb), dim3(256), (size_t)R * (ldh + A) * 4, s, heads, ldh, legal, action, M, A, q, qa,
+                     scratch + 1, R);
   hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
   if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3(nb), dim3(256), 0, s, q, legal, scratch, M, A, greedy);
   HIP_TRY(hipGetLastError());
@@ -2469,7 +2612,7 @@ int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, 
   if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum: null");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(out, 0, sizeof(float) * N, s));
-  const dim3 grid((N + 63) / 64, (M + 511) / 512), block(64, 4);
+  const dim3 grid((N + 63) / 64, (M + kColsumRows - 1) / kColsumRows), block(64, 4);
   if (is_bf16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, out);
   else
@@ -2482,7 +2625,7 @@ int hsad_colsum_acc(const void* src, int is_bf16, int M, int N, int ld, float* o
                     void* stream) {
   if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum_acc: null");
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((N + 63) / 64, (M + 511) / 512), block(64, 4);
+  const dim3 grid((N + 63) / 64, (M + kColsumRows - 1) / kColsumRows), block(64, 4);
   if (is_bf16)
     hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, out, out2, col_map);
   else
@@ -2497,7 +2640,7 @@ int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
     return nfail(HSAD_ERR_INVALID, "adam_step: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(scratch, 0, 4, s));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad, (size_t)n, scratch);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, grad, (size_t)n, scratch);
   const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);  // torch: beta ** step
   const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
@@ -2518,9 +2661,6 @@ int hsad_act_select(const float* heads, int ldh, const float* legal, const float
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
-
-// rows of heads + legal a 256-thread block stages in <= 60 KB of LDS
-static int staged_rows(int ldh, int A) { return std::min(256, (60 * 1024) / ((ldh + A) * 4)); }
 
 int hsad_act_select_q(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
                       uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* scratch, void* stream) {

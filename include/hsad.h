@@ -384,6 +384,13 @@ int hsad_prepare_weight(const float* src, int R, int C, int ld_src, const int32_
                         void* dstT16, int ld_dstT, void* stream);
 /* out[i] = a[perm[i]] + b[perm[i]] (b / perm may be NULL): the gate bias b_ih + b_hh in gate-blocked order */
 int hsad_bias_sum_perm(const float* a, const float* b, const int32_t* perm, float* out, int n, void* stream);
+/* the same, batched: every operand of a net re-derived in ONE launch (hsad_r2d2_net_refresh uses it).  begin, then up to 12
+ * hsad_prepare_weight jobs, then up to 8 hsad_bias_sum_perm jobs, then launch.  The job list is thread-local host state. */
+int hsad_refresh_begin(void);
+int hsad_refresh_add_weight(const float* src, int R, int C, int ld_src, const int32_t* perm, void* dst16, int ld_dst, void* dstT16,
+                            int ld_dstT);
+int hsad_refresh_add_bias(const float* a, const float* b, const int32_t* perm, float* out, int n);
+int hsad_refresh_launch(void* stream);
 /* BPTT through one LSTM layer (learner batches).  gates/cseq: saved by hsad_lstm_layer_forward; c0 (may be NULL =
  * zeros); WhhT_blocked bf16 [H,4H] = transpose of the gate-blocked W_hh; dO fp32 [T,Bn,H] (may be NULL).
  * Output dG16 bf16 [T+1,Bn,4H] (slot T is scratch): gradient wrt the gate pre-activations, gate-blocked.
