@@ -539,6 +539,24 @@ struct LstmStepArgs {
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x)); }
 
+// The whole cell update with TWO reciprocals instead of five (the fused actor kernels' epilogue is bound by the quarter-rate
+// transcendental unit: 5 v_exp + 5 v_rcp per unit).  With ei = e^-i, ef = e^-f, eg = e^2g, eo = e^-o:
+//   c = c_prev / (1 + ef) + (eg - 1) / ((1 + ei)(1 + eg)) = [c_prev (1 + ei)(1 + eg) + (eg - 1)(1 + ef)] / [(1 + ef)(1 + ei)(1 + eg)]
+//   h = (ec - 1) / ((1 + eo)(ec + 1)),  ec = e^2c
+// Pre-activations are clamped to +-25 (2x: +-12.5 for the tanh arguments) so that the product of three (1 + e) terms stays below
+// 3.7e32; sigmoid(-25) = 1.4e-11 and 1 - tanh(12.5) = 2.8e-11 are below fp32 resolution of the results.
+__device__ __forceinline__ void lstm_cell_shared_rcp(float pi, float pf, float pg, float po, float c_prev, float& c, float& h) {
+  // (v_med3_f32: one instruction per clamp)
+  const float ei = __expf(-__builtin_amdgcn_fmed3f(pi, -25.f, 25.f));
+  const float ef = __expf(-__builtin_amdgcn_fmed3f(pf, -25.f, 25.f));
+  const float eg = __expf(2.f * __builtin_amdgcn_fmed3f(pg, -12.5f, 12.5f));
+  const float eo = __expf(-__builtin_amdgcn_fmed3f(po, -25.f, 25.f));
+  const float dig = (1.f + ei) * (1.f + eg), df = 1.f + ef;
+  c = (c_prev * dig + (eg - 1.f) * df) * __builtin_amdgcn_rcpf(df * dig);
+  const float ec = __expf(2.f * __builtin_amdgcn_fmed3f(c, -12.5f, 12.5f));
+  h = (ec - 1.f) * __builtin_amdgcn_rcpf((1.f + eo) * (ec + 1.f));
+}
+
 template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
   // big batches (actors): wave w owns rows [32w, 32w+32) of the block, full K; small batches use lstm_step_small_kernel
@@ -786,9 +804,8 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
         const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
         const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
         const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
-        const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
-        const float c = gf * cp[i][k] + gi * gg;
-        const float h = go * tanhf_(c);
+        float c, h;
+        lstm_cell_shared_rcp(pi + bi, pf + bf_, pg + bg, po + bo, cp[i][k], c, h);
         if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
         if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
         if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
@@ -917,9 +934,8 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
         const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
         const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
         const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
-        const float gi = sigmoidf_(pi + bi), gf = sigmoidf_(pf + bf_), gg = tanhf_(pg + bg), go = sigmoidf_(po + bo);
-        const float c = gf * cp[k] + gi * gg;
-        const float h = go * tanhf_(c);
+        float c, h;
+        lstm_cell_shared_rcp(pi + bi, pf + bf_, pg + bg, po + bo, cp[k], c, h);
         if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
         if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
         if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
