@@ -270,6 +270,35 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128):
     return out
 
 
+def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50):
+    """BASELINE configs[4] at its per-GPU size (131,072 games over 8 GPUs = 16,384 per GPU): 5 players, hand 4, SAD, colour shuffle
+    (F = 1439, A = 49) through the same persistent rollout kernel, timed with events like the headline run"""
+    from hanabi_sad_amd import BatchedHanabiEnv
+    env = BatchedHanabiEnv(games, players=5, hand_size=4, seed=7, eps_list=EPS, max_len=80, sad=True, shuffle_color=True, device=dev,
+                           track_deck_history=False)
+    env.set_rollout_chunk(chunk)
+    env.rollout_random(warmup, 99)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    env.rollout_random(steps, 99)
+    e1.record()
+    torch.cuda.synchronize()
+    env.check_errors()
+    it_ms = e0.elapsed_time(e1) / steps
+    bps = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, True)
+    gbs = bps * games / (it_ms * 1e-3) / 1e9
+    out = {"value": games / (it_ms * 1e-3), "unit": "env-steps/s", "iteration_ms": it_ms, "games": games,
+           "config": {"workload": "BASELINE configs[4] per GPU: %d concurrent 5-player games (hand 4, SAD, colour shuffle; F=%d A=%d), "
+                                  "random-legal policy, persistent fused kernel, %d iterations per launch" % (games, env.F, env.A, chunk),
+                      "games_per_workgroup": env.games_per_workgroup},
+           "roofline": {"bound": "hbm", "kernel": "env_rollout_kernel<5,4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_env_step": bps}}
+    del env
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(seconds=8.0):
     """The CPU oracle (port of the reference algorithm; the reference binary is unbuildable here: HLE
     submodule absent) in the reference's config-1 shape: 1 thread, 80 games, max_len 80, random policy."""
@@ -477,6 +506,8 @@ def main():
         }
         if exchange is not None:
             out["exchange"] = exchange
+        if world == 1 and not args.no_actor:
+            out["env_configs4"] = env_config4_bench(dev)
         if world == 1 and not args.no_learner:
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:

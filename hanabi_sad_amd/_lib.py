@@ -54,6 +54,8 @@ SIGNATURES = {
     "hsad_env_num_games": (C.c_int, [_P]),
     "hsad_env_num_players": (C.c_int, [_P]),
     "hsad_env_games_per_workgroup": (C.c_int, [_P]),
+    "hsad_env_threads_per_workgroup": (C.c_int, [_P]),
+    "hsad_env_set_threads_per_workgroup": (C.c_int, [_P, C.c_int]),
     "hsad_env_state_bytes": (C.c_int64, [_P]),
     "hsad_env_bind_outputs": (C.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "hsad_env_bind_packed": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int]),

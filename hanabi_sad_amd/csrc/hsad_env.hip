@@ -62,6 +62,8 @@ enum : int {
 struct EnvParams {
   int G, Gpad, P, H, A, F, F0, LAL, OB, OD, OL, OK, DECKW;
   int max_len, sad, shuffle_color, bomb, kmode, n_eps, track_dh, npl;
+  int nthreads;    // workgroup size: 128 (wave 0 logic, wave 1 LDS clearing, both build + stream) or 256 (two more waves for clearing,
+                   // row building and streaming: when the launch has so few workgroups that a CU would hold only four waves)
   int gpw;         // games per workgroup: 64 (one per lane of the logic wave) or 32 (lanes 32-63 idle in the logic phase, half
                    // the LDS bit rows): twice the workgroups when 64-game ones would leave most CUs with a single one
   int obs_words, legal_words, own_words, win_w;
@@ -850,7 +852,8 @@ __device__ __forceinline__ int policy_pick(uint64_t seed, uint64_t game, uint64_
 //         (nothing consumes it in the random-policy rollout).
 // TP/TH: compile-time players / hand size (0 = run-time values from EnvParams).
 // =================================================================================================
-constexpr int kEnvThreads = 2 * kWave;  // wave 0: game logic; wave 1: LDS zeroing; both: row building + streaming
+constexpr int kEnvThreads = 4 * kWave;  // at most; EnvParams::nthreads (128 | 256) is what a launch uses.  wave 0: game logic; the
+                                      // other waves: LDS zeroing; all: row building + streaming
 
 template <int MODE, int TP, int TH>
 __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __restrict__ a_in, const int64_t* __restrict__ g_in,
@@ -867,6 +870,7 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = tid >> 6;
+  const int nthreads = ep.nthreads, nwaves = nthreads >> 6;
   const int g0 = ep.g_begin + blockIdx.x * ep.gpw + g_bias;   // g_bias: always 0 (see env_rollout_kernel)
   const int g = g0 + lane;
   const bool valid = lane < ep.gpw && g < ep.G;
@@ -923,11 +927,12 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
     }
   } else {
     const int nz = ep.obs_words + ep.legal_words + ep.own_words;
+    const int zt = tid - kWave, zn = nthreads - kWave;            // the clearing waves' thread index / count
     uint4* z4 = reinterpret_cast<uint4*>(s_obs);
-    for (int k = lane; k < (nz >> 2); k += kWave) z4[k] = make_uint4(0u, 0u, 0u, 0u);
-    for (int k = (nz & ~3) + lane; k < nz; k += kWave) s_obs[k] = 0u;
+    for (int k = zt; k < (nz >> 2); k += zn) z4[k] = make_uint4(0u, 0u, 0u, 0u);
+    for (int k = (nz & ~3) + zt; k < nz; k += zn) s_obs[k] = 0u;
     if (MODE == 0 || MODE == 3)
-      for (int k = lane; k < min(ep.n_eps, 128); k += kWave) s_eps[k] = ep.eps_list[k];
+      for (int k = zt; k < min(ep.n_eps, 128); k += zn) s_eps[k] = ep.eps_list[k];
   }
   __syncthreads();
   STAMP(1);
@@ -1208,7 +1213,7 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
   Refill rf;
   refill_issue(rf, rng, active && wave == 0);
   // both waves build rows: wave w takes observers w, w+2, ...
-  if (active) build_rows<TP, TH>(ep, s_st, lane, g, s_obs, s_legal, s_own, s_grec[lane], wave, 2);
+  if (active) build_rows<TP, TH>(ep, s_st, lane, g, s_obs, s_legal, s_own, s_grec[lane], wave, nwaves);
   STAMP(3);
   if (active && wave == 0) {
     refill_finish(rf, rng);
@@ -1228,13 +1233,13 @@ __device__ __forceinline__ void env_body(const EnvParams& ep, const int64_t* __r
     if (!ep.obs_f32) {
       // device consumers only: no float32 observation leaves the chip
     } else if (ep.nt_stores) {
-      stream_bits_f32_aligned<true>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
+      stream_bits_f32_aligned<true>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, nthreads);
     } else {
-      stream_bits_f32_aligned<false>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, kEnvThreads);
+      stream_bits_f32_aligned<false>(s_obs, ep.priv_s + (size_t)g0 * PF, (uint32_t)(ng * PF), tid, nthreads);
     }
-    stream_rows_packed(ep, s_obs, 0, ng * P, (size_t)g0 * P, tid, kEnvThreads);
-    stream_bits_f32_aligned<false>(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), tid, kEnvThreads);
-    stream_bits_f32_aligned<false>(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), tid, kEnvThreads);
+    stream_rows_packed(ep, s_obs, 0, ng * P, (size_t)g0 * P, tid, nthreads);
+    stream_bits_f32_aligned<false>(s_legal, ep.legal + (size_t)g0 * PA, (uint32_t)(ng * PA), tid, nthreads);
+    stream_bits_f32_aligned<false>(s_own, ep.own + (size_t)g0 * PO, (uint32_t)(ng * PO), tid, nthreads);
     if (valid && wave == 0) {
       for (int p = 0; p < P; ++p) ep.eps[(size_t)g * P + p] = __uint_as_float(ST(PLEPS(p)));
       ep.reward[g] = reward;
@@ -1559,9 +1564,9 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
   ep.a_out = a_out;
   ep.g_out = g_out;
   if (mode == 3 && n_iter > 1)
-    hipLaunchKernelGGL(pick_rollout_kernel(ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(kEnvThreads), lds, stream, ep);
+    hipLaunchKernelGGL(pick_rollout_kernel(ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(ep.nthreads), lds, stream, ep);
   else
-    hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(kEnvThreads), lds,
+    hipLaunchKernelGGL(pick_env_kernel(mode, ep.P, ep.H), dim3((g_count + ep.gpw - 1) / ep.gpw), dim3(ep.nthreads), lds,
                        stream, ep, a, g);
 }
 
@@ -1635,6 +1640,11 @@ int hsad_env_create(const hsad_env_config* cfg, hsad_env** out) {
     (void)hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
     const int forced = getenv("HSAD_ENV_GPW") ? atoi(getenv("HSAD_ENV_GPW")) : cfg->games_per_workgroup;
     ep.gpw = (forced == 32 || forced == 64) ? forced : ((ep.G + kWave - 1) / kWave < 2 * dev_cus ? 32 : 64);
+    // workgroup size: with two workgroups per CU or fewer, 128-thread workgroups leave a CU with four waves to clear, build and
+    // stream its rows (5-player configs at 16,384 games: 52 % of the HBM roofline) -- give those launches four waves each
+    const int forced_t = getenv("HSAD_ENV_THREADS") ? atoi(getenv("HSAD_ENV_THREADS")) : 0;
+    const int n_wg = (ep.G + ep.gpw - 1) / ep.gpw;
+    ep.nthreads = (forced_t == 128 || forced_t == 256) ? forced_t : (n_wg <= 2 * dev_cus ? 256 : 128);
   }
   ep.obs_words = (ep.gpw * P * ep.F + 31) / 32 + 3;
   ep.legal_words = (ep.gpw * P * ep.A + 31) / 32 + 3;
@@ -1724,6 +1734,12 @@ int hsad_env_hand_feature_size(const hsad_env* e) { return e ? e->ep.H * 25 : 0;
 int hsad_env_num_games(const hsad_env* e) { return e ? e->ep.G : 0; }
 int hsad_env_num_players(const hsad_env* e) { return e ? e->ep.P : 0; }
 int hsad_env_games_per_workgroup(const hsad_env* e) { return e ? e->ep.gpw : 0; }
+int hsad_env_threads_per_workgroup(const hsad_env* e) { return e ? e->ep.nthreads : 0; }
+int hsad_env_set_threads_per_workgroup(hsad_env* e, int threads) {
+  if (!e || (threads != 128 && threads != 256)) return set_error(HSAD_ERR_INVALID, "threads per workgroup must be 128 or 256");
+  e->ep.nthreads = threads;
+  return HSAD_OK;
+}
 int64_t hsad_env_state_bytes(const hsad_env* e) { return e ? (int64_t)e->state_bytes : 0; }
 int hsad_env_state_words(const hsad_env* e) { return e ? 80 + e->ep.P * e->ep.H * 6 + e->ep.P * 10 : 0; }
 

@@ -12,7 +12,7 @@ from . import _lib
 class BatchedHanabiEnv:
     def __init__(self, num_games, players=2, hand_size=5, seed=1, bomb=0, eps_list=(0.0,), max_len=80, sad=False,
                  shuffle_obs=False, shuffle_color=False, knowledge_mode=0, device="cuda:0", track_deck_history=True,
-                 deal_mode=0, games_per_workgroup=0):
+                 deal_mode=0, games_per_workgroup=0, threads_per_workgroup=0):
         self.lib = _lib.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -31,6 +31,9 @@ class BatchedHanabiEnv:
         self.sad = bool(sad)
         self.knowledge_mode = int(knowledge_mode)
         self.games_per_workgroup = L.hsad_env_games_per_workgroup(self.h)   # kernel shape in use (32 | 64)
+        if threads_per_workgroup:
+            _lib.check(L.hsad_env_set_threads_per_workgroup(self.h, int(threads_per_workgroup)))
+        self.threads_per_workgroup = L.hsad_env_threads_per_workgroup(self.h)   # 128 | 256
         d = self.device
         self.priv_s = torch.zeros(self.G, self.P, self.F, dtype=torch.float32, device=d)
         self.legal_move = torch.zeros(self.G, self.P, self.A, dtype=torch.float32, device=d)

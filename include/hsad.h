@@ -72,6 +72,10 @@ int hsad_env_num_games(const hsad_env* env);
 int hsad_env_num_players(const hsad_env* env);
 /* the kernel shape in use (32 or 64 games per workgroup; hsad_env_config.games_per_workgroup) */
 int hsad_env_games_per_workgroup(const hsad_env* env);
+/* workgroup size of the env kernels: 128 (one logic wave + one helper) or 256 (three helpers for clearing, building and streaming
+ * the rows; chosen when the launch has at most two workgroups per CU).  Results never depend on it; the setter is for tests. */
+int hsad_env_threads_per_workgroup(const hsad_env* env);
+int hsad_env_set_threads_per_workgroup(hsad_env* env, int threads);
 /* bytes of internal device state held by the env (state planes + per-game mt19937) */
 int64_t hsad_env_state_bytes(const hsad_env* env);
 

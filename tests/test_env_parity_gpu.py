@@ -62,19 +62,24 @@ def _cmp_packed(dev, r_priv, r_legal, r_own, it, tag):
 # both kernel shapes (hsad_env_config.games_per_workgroup): the automatic choice picks 32-game workgroups for every G a CPU
 # oracle can follow, so the 64-game instantiations -- what production sizes (>= 32,768 games) run -- are forced explicitly
 GPW = [32, 64]
+# ... and both workgroup sizes (hsad_env_set_threads_per_workgroup): 256-thread workgroups are what launches with at most two
+# workgroups per CU use (every G of these tests), 128-thread ones what the 65,536-game production shapes use
+THREADS = [128, 256]
 
 
+@pytest.mark.parametrize("threads", THREADS, ids=lambda t: "t%d" % t)
 @pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
 @pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: "p%dh%d_sad%d_sc%d_k%d_d%d" % (
     c["players"], c["hand_size"], c["sad"], c["shuffle_color"], c["knowledge_mode"], c.get("deal_mode", 0)))
-def test_env_bit_parity(cfg, gpw):
+def test_env_bit_parity(cfg, gpw, threads):
     from hanabi_sad_amd import BatchedHanabiEnv
     cfg = dict(cfg)
     G, iters = cfg.pop("G"), cfg.pop("iters")
     deal_mode = cfg.pop("deal_mode", 0)
     seed, pseed = 9000, 77
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", deal_mode=deal_mode, games_per_workgroup=gpw, **cfg)
-    assert dev.games_per_workgroup == gpw
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", deal_mode=deal_mode, games_per_workgroup=gpw,
+                           threads_per_workgroup=threads, **cfg)
+    assert dev.games_per_workgroup == gpw and dev.threads_per_workgroup == threads
     refs = [OracleEnv(seed=seed + g, eps_list=EPS, **cfg) for g in range(G)]
     P, F, A, H = dev.P, dev.F, dev.A, dev.H
     assert (F, A) == (refs[0].F, refs[0].A)
@@ -208,15 +213,16 @@ def test_illegal_move_is_reported_not_applied():
     dict(players=2, hand_size=5, sad=True, shuffle_color=False, knowledge_mode=1, bomb=1, max_len=80),   # <2,5>, V0 + bomb
 ], ids=lambda c: "p%dh%d_sad%d_sc%d_k%d_b%d" % (c["players"], c["hand_size"], c["sad"], c["shuffle_color"],
                                                  c["knowledge_mode"], c["bomb"]))
+@pytest.mark.parametrize("threads", THREADS, ids=lambda t: "t%d" % t)
 @pytest.mark.parametrize("gpw", GPW, ids=lambda g: "gpw%d" % g)
-def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg, gpw):
+def test_persistent_rollout_matches_oracle_for_every_kernel_specialisation(cfg, gpw, threads):
     """the persistent rollout kernel (hsad_env_set_rollout_chunk) has its own (players, hand) instantiations, each in
     the 32- and the 64-games-per-workgroup shape"""
     from hanabi_sad_amd import BatchedHanabiEnv
     from oracle.oracle import OracleVecEnv
     G, seed, pseed = 64 * 2 + 11, 777, 3
-    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", games_per_workgroup=gpw, **cfg)
-    assert dev.games_per_workgroup == gpw
+    dev = BatchedHanabiEnv(G, seed=seed, eps_list=EPS, device="cuda:0", games_per_workgroup=gpw, threads_per_workgroup=threads, **cfg)
+    assert dev.games_per_workgroup == gpw and dev.threads_per_workgroup == threads
     dev.set_rollout_chunk(13)
     ref = OracleVecEnv(G, seed, eps_list=EPS, **cfg)
     for blk in range(2):
