@@ -86,7 +86,8 @@ def test_two_shards_on_one_gpu_draw_the_same_elements_as_one_buffer():
     assert int((got != want).sum()) <= 1, (got, want)
 
 
-def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path):
+@pytest.mark.parametrize("extra", [[], ["--method", "vdn"], ["--pred_weight", "0.25"]], ids=["iql", "vdn", "aux"])
+def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path, extra):
     """End to end on this box's single GPU: three ranks (gloo transport, tensors staged through host memory) -- rank 0 only learns,
     ranks 1 and 2 roll out their game shards into their own DeviceReplay shards and serve the learner's rounds between their steps
     (dist.ReplayLink); the learner's batches are assembled from both shards, parameters flow back, everybody stops cleanly."""
@@ -100,7 +101,7 @@ def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path):
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "hanabi_sad_amd.selfplay", "--num_game", "512", "--num_update", "45",
-           "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo", "--actor_sync_freq", "10"]
+           "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo", "--actor_sync_freq", "10"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and "batch_gather_ms" in out.stdout
