@@ -557,6 +557,34 @@ __device__ __forceinline__ void lstm_cell_shared_rcp(float pi, float pf, float p
   h = (ec - 1.f) * __builtin_amdgcn_rcpf((1.f + eo) * (ec + 1.f));
 }
 
+// the same for two units at once: the additions / multiplications on <2 x float> become v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// (one issue slot for two lanes' worth of work); clamps, exponentials and reciprocals stay per element
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t exp2_clamped2(f32x2_t x, float lim, float scale) {
+  f32x2_t m = {__builtin_amdgcn_fmed3f(x.x, -lim, lim), __builtin_amdgcn_fmed3f(x.y, -lim, lim)};
+  const f32x2_t sc = {scale, scale};
+  m = m * sc;
+  f32x2_t r = {__builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y)};
+  return r;
+}
+__device__ __forceinline__ f32x2_t rcp2(f32x2_t x) {
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(x.x);
+  r.y = __builtin_amdgcn_rcpf(x.y);
+  return r;
+}
+__device__ __forceinline__ void lstm_cell_shared_rcp_x2(f32x2_t pi, f32x2_t pf, f32x2_t pg, f32x2_t po, f32x2_t c_prev, f32x2_t& c,
+                                                        f32x2_t& h) {
+  constexpr float kL = 1.4426950408889634f;   // log2(e): e^x = 2^(x log2 e)
+  const f32x2_t ei = exp2_clamped2(pi, 25.f, -kL), ef = exp2_clamped2(pf, 25.f, -kL);
+  const f32x2_t eg = exp2_clamped2(pg, 12.5f, 2.f * kL), eo = exp2_clamped2(po, 25.f, -kL);
+  const f32x2_t one = {1.f, 1.f};
+  const f32x2_t dig = (one + ei) * (one + eg), df = one + ef;
+  c = (c_prev * dig + (eg - one) * df) * rcp2(df * dig);
+  const f32x2_t ec = exp2_clamped2(c, 12.5f, 2.f * kL);
+  h = (ec - one) * rcp2((one + eo) * (ec + one));
+}
+
 template <int BM, int KIT>
 __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStepArgs a) {
   // big batches (actors): wave w owns rows [32w, 32w+32) of the block, full K; small batches use lstm_step_small_kernel
@@ -794,21 +822,32 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
     for (int i = 0; i < 2; ++i) {
       // lo lanes finish accumulator rows k < 8 and receive {f, o} for them, hi lanes rows 8 + k and receive {i, g}
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float l0 = acc[i][0][k], h0 = acc[i][0][8 + k], l1 = acc[i][1][k], h1 = acc[i][1][8 + k];
-        asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));   // keeps "hi ? x[k] : x[8 + k]" a select of two registers
-        const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);           // (as a select of the INDEX it becomes a 16-way chain)
-        const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
-        const int row = rowof[i][k];
-        if (row >= a.Bn) continue;
-        const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
-        const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
-        const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
-        float c, h;
-        lstm_cell_shared_rcp(pi + bi, pf + bf_, pg + bg, po + bo, cp[i][k], c, h);
-        if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
-        if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
-        if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
+      for (int k = 0; k < 8; k += 2) {      // two units per round: packed fp32 arithmetic in the cell update
+        f32x2_t vpi, vpf, vpg, vpo, vcp, c2, h2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kk = k + u;
+          float l0 = acc[i][0][kk], h0 = acc[i][0][8 + kk], l1 = acc[i][1][kk], h1 = acc[i][1][8 + kk];
+          asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));   // keeps "hi ? x[k] : x[8 + k]" a select of two registers
+          const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);           // (as a select of the INDEX it becomes a 16-way chain)
+          const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
+          const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
+          vpi[u] = hi ? g0 : m0v;
+          vpg[u] = hi ? g1 : m1v;
+          vpf[u] = hi ? m0v : g0;
+          vpo[u] = hi ? m1v : g1;
+          vcp[u] = cp[i][kk];
+        }
+        const f32x2_t vbi = {bi, bi}, vbf = {bf_, bf_}, vbg = {bg, bg}, vbo = {bo, bo};
+        lstm_cell_shared_rcp_x2(vpi + vbi, vpf + vbf, vpg + vbg, vpo + vbo, vcp, c2, h2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = rowof[i][k + u];
+          if (row >= a.Bn) continue;
+          if (a.c_out) a.c_out[(size_t)row * H + unit] = c2[u];
+          if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h2[u];
+          if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h2[u]);
+        }
       }
     }
     if (!more) break;
@@ -924,21 +963,34 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
         cp[k] = row < a.Bn ? a.c_prev[(size_t)row * H + unit] : 0.f;
       }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float l0 = acc[i][0][k], h0 = acc[i][0][8 + k], l1 = acc[i][1][k], h1 = acc[i][1][8 + k];
-        asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
-        const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);
-        const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
-        const int row = cm0 + wm * 128 + i * 32 + (k & 3) + 8 * (k >> 2) + rsub;
-        if (row >= a.Bn) continue;
-        const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
-        const float pi = hi ? g0 : m0v, pg = hi ? g1 : m1v;
-        const float pf = hi ? m0v : g0, po = hi ? m1v : g1;
-        float c, h;
-        lstm_cell_shared_rcp(pi + bi, pf + bf_, pg + bg, po + bo, cp[k], c, h);
-        if (a.c_out) a.c_out[(size_t)row * H + unit] = c;
-        if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h;
-        if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h);
+      for (int k = 0; k < 8; k += 2) {      // two units per round: packed fp32 arithmetic in the cell update
+        f32x2_t vpi, vpf, vpg, vpo, vcp, c2, h2;
+        int rows[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int kk = k + u;
+          float l0 = acc[i][0][kk], h0 = acc[i][0][8 + kk], l1 = acc[i][1][kk], h1 = acc[i][1][8 + kk];
+          asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
+          const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);
+          const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
+          rows[u] = cm0 + wm * 128 + i * 32 + (kk & 3) + 8 * (kk >> 2) + rsub;
+          const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
+          vpi[u] = hi ? g0 : m0v;
+          vpg[u] = hi ? g1 : m1v;
+          vpf[u] = hi ? m0v : g0;
+          vpo[u] = hi ? m1v : g1;
+          vcp[u] = cp[kk];
+        }
+        const f32x2_t vbi = {bi, bi}, vbf = {bf_, bf_}, vbg = {bg, bg}, vbo = {bo, bo};
+        lstm_cell_shared_rcp_x2(vpi + vbi, vpf + vbf, vpg + vbg, vpo + vbo, vcp, c2, h2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = rows[u];
+          if (row >= a.Bn) continue;
+          if (a.c_out) a.c_out[(size_t)row * H + unit] = c2[u];
+          if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h2[u];
+          if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h2[u]);
+        }
       }
     }
     if (!more) break;
