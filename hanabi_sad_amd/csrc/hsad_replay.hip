@@ -559,7 +559,8 @@ __global__ void replay_add_scalars_kernel(ReplayDev rd, int n, int T, const floa
 __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B, const float* __restrict__ canon,
                                                              float* __restrict__ weight_out,
                                                              const float* __restrict__ targets = nullptr,
-                                                             const int* __restrict__ n_dev = nullptr) {
+                                                             const int* __restrict__ n_dev = nullptr,
+                                                             unsigned long long* done = nullptr, unsigned long long seq = 0) {
   if (n_dev) B = *n_dev;   // sharded draw: the number of positions that fell into this shard is only known on the device
   __shared__ double s_incl[1024];
   __shared__ double s_red[1024];
@@ -685,6 +686,8 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   }
   __syncthreads();
   if (tid < B) weight_out[tid] = targets ? s_w[tid] : s_y[tid] / s_max;
+  // the uniforms of this draw have been consumed: their pinned staging slot may be refilled (canon_slot)
+  if (done && tid == 0) __hip_atomic_store(done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // PrioritizedReplay::updatePriority -> ConcurrentQueue::update (prioritized_replay.h:110-131): for i = 0..B-1 in order,
@@ -1023,7 +1026,13 @@ struct hsad_replay {
   // the stream before it (a whole actor step in the self-play loop); slot k is reused once the copy recorded in ev[k] is done
   static constexpr int kCanonSlots = 8;
   float* h_canon_ring = nullptr;   // [kCanonSlots][kMaxBatch], hipHostMalloc
-  hipEvent_t canon_ev[kCanonSlots] = {};
+  // a slot is free again once the draw that consumed its uniforms has run: the sampling kernel publishes the sequence number of
+  // its draw into host-visible (fine-grained) memory, which the host reads without any HIP call.  (An event per slot made the host
+  // wait: hipEventSynchronize on an old, long-complete marker returned only when the most recent work of the stream had finished.)
+  unsigned long long slot_seq[kCanonSlots] = {};
+  unsigned long long draw_seq = 0;
+  volatile unsigned long long* h_done = nullptr;   // hipHostMalloc (coherent), written by replay_sample_kernel
+  unsigned long long* d_done = nullptr;            // device view of h_done
   int canon_next = 0;
   int* d_tmp_id;
   int last_err_kind = 0;
@@ -1113,8 +1122,11 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
     return HSAD_ERR_NOMEM;
   }
   he = hipHostMalloc((void**)&r->h_canon_ring, sizeof(float) * hsad_replay::kCanonSlots * kMaxBatch, hipHostMallocDefault);
-  for (int k = 0; k < hsad_replay::kCanonSlots && he == hipSuccess; ++k)
-    he = hipEventCreateWithFlags(&r->canon_ev[k], hipEventDisableTiming);
+  if (he == hipSuccess) he = hipHostMalloc((void**)&r->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (he == hipSuccess) {
+    *r->h_done = 0ull;
+    he = hipHostGetDevicePointer((void**)&r->d_done, (void*)r->h_done, 0);
+  }
   if (he != hipSuccess) {
     rfail(HSAD_ERR_HIP, "pinned staging for the replay sampler: %s", hipGetErrorString(he));
     hsad_replay_destroy(r);
@@ -1136,8 +1148,7 @@ void hsad_replay_destroy(hsad_replay* r) {
                   r->rd.sampled_ids, r->rd.q_ids, r->rd.sampled_w, r->rd.valid_rows, r->d_canon, r->d_tmp_id, r->d_shard};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (hipEvent_t e : r->canon_ev)
-    if (e) (void)hipEventDestroy(e);
+  if (r->h_done) (void)hipHostFree((void*)r->h_done);
   if (r->h_canon_ring) (void)hipHostFree(r->h_canon_ring);
   delete r;
 }
@@ -1146,12 +1157,13 @@ void hsad_replay_destroy(hsad_replay* r) {
 static float* canon_slot(hsad_replay* r, int* slot) {
   *slot = r->canon_next;
   r->canon_next = (r->canon_next + 1) % hsad_replay::kCanonSlots;
-  (void)hipEventSynchronize(r->canon_ev[*slot]);   // returns at once for an event never recorded / long finished
+  // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call
+  if (*r->h_done < r->slot_seq[*slot]) (void)hipStreamSynchronize(r->last_stream);
+  r->slot_seq[*slot] = ++r->draw_seq;     // the draw about to be issued
   return r->h_canon_ring + (size_t)*slot * kMaxBatch;
 }
 static hipError_t upload_canon(hsad_replay* r, int slot, int n, hipStream_t s) {
-  hipError_t e = hipMemcpyAsync(r->d_canon, r->h_canon_ring + (size_t)slot * kMaxBatch, sizeof(float) * n, hipMemcpyHostToDevice, s);
-  return e != hipSuccess ? e : hipEventRecord(r->canon_ev[slot], s);
+  return hipMemcpyAsync(r->d_canon, r->h_canon_ring + (size_t)slot * kMaxBatch, sizeof(float) * n, hipMemcpyHostToDevice, s);
 }
 
 int64_t hsad_replay_bytes(const hsad_replay* r) { return r ? r->bytes : 0; }
@@ -1189,7 +1201,8 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   float* hc = canon_slot(r, &slot);
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
   HIP_TRY(upload_canon(r, slot, batch, s));
-  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight);
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight, (const float*)nullptr,
+                     (const int*)nullptr, r->d_done, r->slot_seq[slot]);
   const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
                      r->rd.sampled_ids, 0, r->rd.valid_rows);
@@ -1230,7 +1243,8 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
     for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
     HIP_TRY(upload_canon(r, slot, n, s));
   }
-  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon);
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon, (const int*)nullptr,
+                     r->d_done, r->draw_seq);
   if (n > 0) {
     const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,
