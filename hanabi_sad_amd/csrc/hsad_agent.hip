@@ -341,9 +341,9 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   hsad_r2d2_net* n = online;
   hipStream_t s = (hipStream_t)stream;
   const int H = n->H, A = n->A, NH = n->NH;
-  const size_t a16_b = (size_t)N * n->Fp * 2, hd_b = (size_t)N * NH * 4, q_b = (size_t)N * A * 4, sc_b = (4 + (N + 255) / 256) * 4;
+  const size_t a16_b = (size_t)N * n->Fp * 2, hd_b = (size_t)N * NH * 4, sc_b = (4 + (N + 255) / 256) * 4;
   const size_t step_b = step_ws_bytes(n, N);
-  CK(n->ws.need(a16_b + 2 * step_b + 2 * hd_b + q_b + sc_b + 1024));
+  CK(n->ws.need(a16_b + 2 * step_b + 2 * hd_b + sc_b + 1024));
   char* p = n->ws.as<char>();
   bf16_t* a16 = (bf16_t*)p;
   p += a16_b;
@@ -355,8 +355,6 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   p += hd_b;
   float* hd_t = (float*)p;
   p += hd_b;
-  float* q = (float*)p;
-  p += q_b;
   float* scratch = (float*)p;
   if (priv_s_bf16) a16 = (bf16_t*)priv_s_bf16;   // [N, Fp] as hsad_env_bind_packed writes it: no cast pass
   else CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));

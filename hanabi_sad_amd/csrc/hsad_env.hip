@@ -672,7 +672,6 @@ __device__ __forceinline__ void build_rows(const EnvParams& ep, const uint32_t* 
   const int deck_size = (misc >> 8) & 63;
   const uint64_t disc = (uint64_t)ST(PL_DISC_LO) | ((uint64_t)ST(PL_DISC_HI) << 32);
   const uint32_t lastmv = ST(PL_LASTMV);
-  const int cur = board_cur(board);
   const int info = board_info(board), life = board_life(board);
   const uint32_t F = (uint32_t)ep.F;
 
@@ -1354,7 +1353,6 @@ __global__ void query_kernel(EnvParams ep, int32_t* __restrict__ out) {
 
 __global__ void legal_query_kernel(EnvParams ep, const int32_t* __restrict__ uid, uint8_t* __restrict__ out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  const int P = ep.P;
   if (g >= ep.G) return;
   const uint32_t board = GP(PL_BOARD);
   const int cur = board_cur(board);

@@ -545,19 +545,7 @@ __device__ __forceinline__ float tanhf_(float x) { return 1.f - 2.f * __builtin_
 //   h = (ec - 1) / ((1 + eo)(ec + 1)),  ec = e^2c
 // Pre-activations are clamped to +-25 (2x: +-12.5 for the tanh arguments) so that the product of three (1 + e) terms stays below
 // 3.7e32; sigmoid(-25) = 1.4e-11 and 1 - tanh(12.5) = 2.8e-11 are below fp32 resolution of the results.
-__device__ __forceinline__ void lstm_cell_shared_rcp(float pi, float pf, float pg, float po, float c_prev, float& c, float& h) {
-  // (v_med3_f32: one instruction per clamp)
-  const float ei = __expf(-__builtin_amdgcn_fmed3f(pi, -25.f, 25.f));
-  const float ef = __expf(-__builtin_amdgcn_fmed3f(pf, -25.f, 25.f));
-  const float eg = __expf(2.f * __builtin_amdgcn_fmed3f(pg, -12.5f, 12.5f));
-  const float eo = __expf(-__builtin_amdgcn_fmed3f(po, -25.f, 25.f));
-  const float dig = (1.f + ei) * (1.f + eg), df = 1.f + ef;
-  c = (c_prev * dig + (eg - 1.f) * df) * __builtin_amdgcn_rcpf(df * dig);
-  const float ec = __expf(2.f * __builtin_amdgcn_fmed3f(c, -12.5f, 12.5f));
-  h = (ec - 1.f) * __builtin_amdgcn_rcpf((1.f + eo) * (ec + 1.f));
-}
-
-// the same for two units at once: the additions / multiplications on <2 x float> become v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
+// Two units at once: the additions / multiplications on <2 x float> become v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32
 // (one issue slot for two lanes' worth of work); clamps, exponentials and reciprocals stay per element
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2_t exp2_clamped2(f32x2_t x, float lim, float scale) {
@@ -1424,7 +1412,6 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
   const int u = nb * 32 + wu * 16 + (lane & 15);
   const int ucol = nb * 128 + wu * 16 + (lane & 15);
   const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
-  const int row_l = rb * 32 + wr * 16 + (lane & 15);
   float dcs[4] = {0.f, 0.f, 0.f, 0.f};
   if (a.dc_io) {
 #pragma unroll
