@@ -410,8 +410,8 @@ class ReplayLink:
         self.opened += 1
         B, k = self.B, r % 4
         canon = self.hdr_host[k]
-        if self.hdr_ev[k] is not None:
-            self.hdr_ev[k].synchronize()          # the copy that last read this pinned slot (four rounds ago)
+        if self.hdr_ev[k] is not None and not self.hdr_ev[k].query():
+            self.hdr_ev[k].synchronize()          # the copy that last read this pinned slot (four rounds ago) -- normally long done
         canon.copy_(torch.from_numpy(self.shard.draw_canonical(B)))
         if self.xs is not None:
             self.xs.wait_stream(torch.cuda.current_stream(self.device))   # everything issued so far (the priorities, the staged bucket)
