@@ -985,154 +985,6 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
   }
 }
 
-// 256 x 128 tiles, four waves (2 x 2 of 128 x 64: the same per-wave sub-tile and cell update as above), ONE 48 KB operand buffer
-// and therefore TWO workgroups per CU: instead of double buffering inside a workgroup, the other workgroup's MFMAs run while this
-// one waits for its operand tile, and -- the point -- one's VALU-bound cell update overlaps the other's k loop.
-__global__ __launch_bounds__(256, 2) void lstm_cell_gemm_2wg_kernel(LstmCellArgs a) {
-  constexpr int BM = 256, BN = 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
-  bf16_t* sA = reinterpret_cast<bf16_t*>(smem_cell);   // [BM][64] swizzled (ONE buffer: the other workgroup of the CU is the overlap)
-  bf16_t* sB = sA + BM * kBK;                           // [BN][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int H = a.H, K = a.Kx + H, N4 = 4 * H;
-  const int tiles_n = N4 / BN, tiles_m = (a.Bn + BM - 1) / BM;
-  const bool xcd_order = (gridDim.x % 8) == 0;           // see lstm_cell_gemm_kernel
-  const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
-  const int per_xcd = gridDim.x / n_xcd;
-  int seq = blockIdx.x / n_xcd;
-  int m0 = 0, n0 = 0;
-  auto set_tile = [&](int sq) -> bool {
-    const int mt = (sq / tiles_n) * n_xcd + xcd;
-    n0 = (sq % tiles_n) * BN;
-    m0 = mt * BM;
-    return mt < tiles_m;
-  };
-  // wave w moves the 8-row pieces w, w + 4, ... of each operand (32 pieces of A, 16 of B)
-  const int prow = lane >> 3;
-  uint32_t boff[4], aoff_x[8], aoff_h[8];
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rl = (it * 4 + wave) * 8 + prow;
-    boff[it] = (uint32_t)(rl * K + swz_chunk(rl, lane & 7) * 8) * 2u;
-  }
-  auto set_rows = [&]() {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int rl = (it * 4 + wave) * 8 + prow;
-      const int gr = min(m0 + rl, a.Bn - 1);
-      const int ch = swz_chunk(rl, lane & 7) * 8;
-      aoff_x[it] = (uint32_t)(gr * a.ldx + ch) * 2u;
-      aoff_h[it] = (uint32_t)(gr * H + ch) * 2u;
-    }
-  };
-  auto issue_tile = [&](int k0, int buf) {
-    const bool part2 = k0 >= a.Kx;
-    const char* abase = reinterpret_cast<const char*>(part2 ? a.h_prev16 + (k0 - a.Kx) : a.x + k0);
-    const char* bbase = reinterpret_cast<const char*>(a.Wcat + (size_t)n0 * K + k0);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int piece = it * 4 + wave;
-      glds16(reinterpret_cast<const bf16_t*>(abase + (part2 ? aoff_h[it] : aoff_x[it])), sA + piece * 8 * kBK);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int piece = it * 4 + wave;
-      glds16(reinterpret_cast<const bf16_t*>(bbase + boff[it]), sB + piece * 8 * kBK);
-    }
-  };
-
-  if (!set_tile(seq)) return;
-  set_rows();
-  issue_tile(0, 0);
-  const int nk = K / kBK;
-  for (;;) {
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int kt = 0; kt < nk; ++kt) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of k tile kt have landed ...
-      __syncthreads();                                   // ... everyone's have
-      const bf16_t* pa = sA;
-      const bf16_t* pb = sB;
-#pragma unroll
-      for (int kk = 0; kk < kBK / 16; ++kk) {
-        bf16x8 fa[4], fb[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = lds_frag_swz(pb, wn * 64 + j * 32, kk, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = lds_frag_swz(pa, wm * 128 + i * 32, kk, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-      }
-      if (kt + 1 < nk) {
-        __syncthreads();                                 // everybody has read the buffer: refill it (the other workgroup of this
-        issue_tile((kt + 1) * kBK, 0);                   // CU computes meanwhile)
-      }
-    }
-    // ---- epilogue (as lstm_cell_gemm_kernel: lo lanes hold {i, g}, hi lanes {f, o} of unit (lane & 15)) ----
-    const int cm0 = m0, cn0 = n0;
-    const bool hi = (lane & 16) != 0;
-    const int unit = (cn0 + wn * 64) / 4 + (lane & 15);
-    const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
-    const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
-    const int rsub = 4 * (lane >> 5) + (hi ? 16 : 0);
-    seq += per_xcd;
-    const bool more = set_tile(seq);
-    if (more) {                                // the single buffer was last read in step nk - 1: behind a barrier it may be refilled
-      __syncthreads();
-      set_rows();
-      issue_tile(0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float cp[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int row = cm0 + wm * 128 + i * 32 + (k & 3) + 8 * (k >> 2) + rsub;
-        cp[k] = row < a.Bn ? a.c_prev[(size_t)row * H + unit] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k += 2) {      // two units per round: packed fp32 arithmetic in the cell update
-        f32x2_t vpi, vpf, vpg, vpo, vcp, c2, h2;
-        int rows[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kk = k + u;
-          float l0 = acc[i][0][kk], h0 = acc[i][0][8 + kk], l1 = acc[i][1][kk], h1 = acc[i][1][8 + kk];
-          asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
-          const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);
-          const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
-          rows[u] = cm0 + wm * 128 + i * 32 + (kk & 3) + 8 * (kk >> 2) + rsub;
-          const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
-          vpi[u] = hi ? g0 : m0v;
-          vpg[u] = hi ? g1 : m1v;
-          vpf[u] = hi ? m0v : g0;
-          vpo[u] = hi ? m1v : g1;
-          vcp[u] = cp[kk];
-        }
-        const f32x2_t vbi = {bi, bi}, vbf = {bf_, bf_}, vbg = {bg, bg}, vbo = {bo, bo};
-        lstm_cell_shared_rcp_x2(vpi + vbi, vpf + vbf, vpg + vbg, vpo + vbo, vcp, c2, h2);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int row = rows[u];
-          if (row >= a.Bn) continue;
-          if (a.c_out) a.c_out[(size_t)row * H + unit] = c2[u];
-          if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h2[u];
-          if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h2[u]);
-        }
-      }
-    }
-    if (!more) break;
-  }
-}
-
 // Small-batch variant (learner: Bn = 128): block = 32 rows x 32 hidden units, 4 waves in a 2x2 grid, each wave
 // owning 16 rows x 16 units with FOUR 16x16 accumulators (i,f,g,o) over the full K — no cross-wave reduction and
 // the transcendental-heavy cell update is spread over all four waves.  v_mfma_f32_16x16x32_bf16: lane l holds
@@ -2665,14 +2517,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands of 4 GB and more are not supported (32-bit offsets)");
   static const int force_tile = getenv("HSAD_CELL_TILE") ? atoi(getenv("HSAD_CELL_TILE")) : 0;   // developer switch: 128 | 256
   const bool big = force_tile ? force_tile == 256 : (Bn >= 4096 && (4 * H) % 256 == 0);
-  if (force_tile == 2) {   // 256 x 128 tiles, one 48 KB operand buffer, two workgroups per CU
-    const size_t lds = (size_t)(256 + 128) * kBK * sizeof(bf16_t);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_2wg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long tiles = (long)(4 * H / 128) * ((Bn + 255) / 256);
-    long grid = std::min<long>(tiles, 2L * n_cu);
-    if (grid >= 64) grid &= ~7L;
-    hipLaunchKernelGGL(lstm_cell_gemm_2wg_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
-  } else if (big && (4 * H) % 256 == 0) {
+  if (big && (4 * H) % 256 == 0) {
     const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)(4 * H / 256) * ((Bn + 255) / 256);
