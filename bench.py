@@ -187,6 +187,18 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     dt = (time.perf_counter() - t0) / steps
     tr.env.check_errors()
     tr.replay.check_errors()
+    # the dominant kernel of a step (four launches: two LSTM layers x online / target net) where it runs: HIP events around every
+    # launch of the fused GEMM + cell kernel during 40 more steps, on the stream it is launched on
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    lib = _lib.load_library()
+    _lib.check(lib.hsad_lstm_cell_timing(1))
+    for _ in range(40):
+        tr.actor.step()
+    ms, fl, nl = C.c_double(0), C.c_double(0), C.c_int32(0)
+    _lib.check(lib.hsad_lstm_cell_timing_read(C.byref(ms), C.byref(fl), C.byref(nl)))
+    _lib.check(lib.hsad_lstm_cell_timing(0))
+    cell_tf = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     # one whole learner iteration on the sequences the rollout just produced (selfplay.py:208-244): prioritized sample out of the
     # bit-packed replay (observation expanded straight to the bf16 GEMM operand) -> loss fwd + BPTT -> clip + Adam -> priorities
     # aggregated and written back
@@ -204,6 +216,11 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
         tr.replay.check_errors()
     out = {"value": games * 2 / dt, "unit": "acts/s", "ms_per_step": dt * 1e3, "game_steps_per_sec": games / dt,
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
+           "roofline": {"bound": "mfma", "kernel": "lstm_cell_gemm256_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d; "
+                                                   "4 launches per step)" % (games * 2, 2048, 1024),
+                        "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": None,
+                        "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
+                        "share_of_step": 4 * ms.value / (dt * 1e3)},
            "observation_path": "packed (bit words + bf16 rows from the env kernel)" if tr.actor.packed_obs else "float32",
            "config": {"workload": "%d concurrent 2-player SAD games, IQL R2D2 agent (F=838 A=21 H=512 L=2) in the loop, n-step 3, "
                                   "max_len 80, priorities from online+target nets, finished sequences flushed into a "

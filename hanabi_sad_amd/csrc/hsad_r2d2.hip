@@ -2496,6 +2496,42 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
   return HSAD_OK;
 }
 
+// ---- measurement hook: HIP events around every fused-cell launch, on the stream it is launched on (bench.py's actor roofline) ----
+namespace {
+struct CellTiming {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<double> flop;
+} g_cell_timing;
+}  // namespace
+
+int hsad_lstm_cell_timing(int enable) {
+  g_cell_timing.on = enable != 0;
+  return HSAD_OK;
+}
+
+// average duration (ms) and FLOP of the launches recorded since the last read; synchronises the device and clears the record
+int hsad_lstm_cell_timing_read(double* avg_ms, double* avg_flop, int32_t* launches) {
+  if (!avg_ms || !launches) return nfail(HSAD_ERR_INVALID, "cell_timing_read: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < g_cell_timing.ev.size(); ++i) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, g_cell_timing.ev[i].first, g_cell_timing.ev[i].second));
+    ms += t;
+    fl += g_cell_timing.flop[i];
+    (void)hipEventDestroy(g_cell_timing.ev[i].first);
+    (void)hipEventDestroy(g_cell_timing.ev[i].second);
+  }
+  const size_t n = g_cell_timing.ev.size();
+  *launches = (int32_t)n;
+  *avg_ms = n ? ms / n : 0.0;
+  if (avg_flop) *avg_flop = n ? fl / n : 0.0;
+  g_cell_timing.ev.clear();
+  g_cell_timing.flop.clear();
+  return HSAD_OK;
+}
+
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream) {
@@ -2515,6 +2551,12 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
                  Bn, H, Kx, ldx};
   if ((size_t)Bn * (size_t)std::max(ldx, H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands of 4 GB and more are not supported (32-bit offsets)");
+  hipEvent_t t_e0 = nullptr, t_e1 = nullptr;
+  if (g_cell_timing.on) {
+    HIP_TRY(hipEventCreate(&t_e0));
+    HIP_TRY(hipEventCreate(&t_e1));
+    HIP_TRY(hipEventRecord(t_e0, (hipStream_t)stream));
+  }
   static const int force_tile = getenv("HSAD_CELL_TILE") ? atoi(getenv("HSAD_CELL_TILE")) : 0;   // developer switch: 128 | 256
   const bool big = force_tile ? force_tile == 256 : (Bn >= 4096 && (4 * H) % 256 == 0);
   if (big && (4 * H) % 256 == 0) {
@@ -2533,6 +2575,11 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     hipLaunchKernelGGL(lstm_cell_gemm_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, a);
   }
   HIP_TRY(hipGetLastError());
+  if (t_e0) {
+    HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
+    g_cell_timing.ev.push_back({t_e0, t_e1});
+    g_cell_timing.flop.push_back(2.0 * Bn * 4.0 * H * (Kx + H));
+  }
   return HSAD_OK;
 }
 

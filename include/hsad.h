@@ -353,6 +353,11 @@ int hsad_lstm_set_exchange_mode(int force_cross_xcd);
  * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
  * publish); out16 may be NULL; reset != 0 clears them */
 int hsad_lstm_debug_timing(uint64_t* out16, int reset);
+/* measurement hook for the fused cell kernel (hsad_lstm_cell_fused, i.e. every LSTM layer of an acting step): while enabled, each
+ * launch is bracketed by HIP events on its own stream; _read returns the average duration and FLOP of the launches recorded since
+ * the last read (synchronises) and clears the record.  bench.py's actor roofline. */
+int hsad_lstm_cell_timing(int enable);
+int hsad_lstm_cell_timing_read(double* avg_ms, double* avg_flop, int32_t* launches);
 /* reads the timeout word of a sync_scratch buffer used with T steps / Bn rows (synchronises the device) */
 int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* timed_out);
 /* Dueling head + masked argmax (r2d2.py:106-131): heads fp32 [M,ldh] = [advantage(A) | value(1) | ...],
