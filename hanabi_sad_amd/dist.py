@@ -420,6 +420,7 @@ class ReplayLink:
                 self.hdr_ev[k] = torch.cuda.Event()
                 self.hdr_ev[k].record()
                 if prio is not None:
+                    prio.record_stream(self.xs)           # allocated on the compute stream, read here
                     self.hdr[B:].copy_(prio)
                 self._result = self._round(flags)
         else:
