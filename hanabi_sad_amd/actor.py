@@ -58,6 +58,7 @@ class DeviceActor:
         self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
         self.n_finished = torch.zeros(1, dtype=torch.int32, device=env.device)
         self._side = torch.cuda.Stream(env.device) if self.cached_q else None      # reset of ended games, see _reset_terminated
+        self._side_flush = torch.cuda.Stream(env.device) if self.cached_q else None   # flush of finished sequences, see _flush
         self._reset_pending = False
 
     def _rows(self):
@@ -143,8 +144,20 @@ class DeviceActor:
             self.n_checked += 1
             self.n_checked_stale += int(stale)
         self.writer.push_sequence(prio)
-        self.n_finished = self.writer.flush_to_replay(self.replay, self.eta, out=self.n_finished)
+        self._flush()
         self._join_reset()
+
+    def _flush(self):
+        """finished sequences -> replay.  The chain is five small launches, three of them single-workgroup scans (~80 us with the
+        chip idle around them); issued on a side stream it overlaps the next step's network passes.  No join here: the library
+        orders whoever touches the writer's cursors or the replay next -- on any stream -- behind it (StreamFence in
+        csrc/hsad_replay.hip)."""
+        if self._side_flush is None:
+            self.n_finished = self.writer.flush_to_replay(self.replay, self.eta, out=self.n_finished)
+            return
+        self._side_flush.wait_stream(torch.cuda.current_stream(self.env.device))
+        with torch.cuda.stream(self._side_flush):
+            self.n_finished = self.writer.flush_to_replay(self.replay, self.eta, out=self.n_finished)
 
     def _step_contract(self, obs):
         """the rest of step() for a model that only offers the reference's contract (act / compute_priority): the n-step

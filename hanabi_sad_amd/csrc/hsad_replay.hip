@@ -1032,6 +1032,34 @@ __global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err)
 
 }  // namespace
 
+// Ordering across two streams without the caller's help: the flush of finished sequences may be issued on a side stream (the actor
+// loop overlaps its single-workgroup scans with the next step's network passes); it arms this fence, and the next operation on the
+// same object that arrives on ANOTHER stream first makes its stream wait for the flush.  One event record per flush, one wait per
+// consumer stream -- not a marker per call.
+struct StreamFence {
+  hipEvent_t ev = nullptr;
+  hipStream_t stream = nullptr;
+  bool armed = false;
+  hipError_t arm(hipStream_t s) {
+    if (!ev) {
+      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    stream = s;
+    armed = true;
+    return hipEventRecord(ev, s);
+  }
+  hipError_t pass(hipStream_t s) {        // call at the top of every operation that touches what the flush touches
+    if (!armed || s == stream) return hipSuccess;
+    armed = false;                        // later work on `s` is ordered behind this wait
+    return hipStreamWaitEvent(s, ev, 0);
+  }
+  void destroy() {
+    if (ev) (void)hipEventDestroy(ev);
+    ev = nullptr;
+  }
+};
+
 // ===================================================================================================
 struct hsad_replay {
   RowLayout L;
@@ -1056,6 +1084,7 @@ struct hsad_replay {
   unsigned long long* d_done = nullptr;            // device view of h_done
   int canon_next = 0;
   int* d_tmp_id;
+  StreamFence fence;
   int last_err_kind = 0;
   float* d_shard = nullptr;  // sharded draw scratch: compacted priorities [kMaxBatch] | raw weights [kMaxBatch] | counts (2 ints)
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
@@ -1072,6 +1101,7 @@ struct hsad_seqwriter {
   int head, count, rt_count;  // deque state of the n+1 history (host side: it advances deterministically)
   int pend_slot;              // history slot of the transition popped last (valid until the next push)
   bool pending;
+  StreamFence fence;
   unsigned prepacked = 0;     // bit fields whose push_obs_action source already is bit words (hsad_seqwriter_set_prepacked)
   RowWordMap wmap{};          // word-per-thread copy map, usable when every field arrives in its stored format
   int* d_err;
@@ -1170,6 +1200,7 @@ void hsad_replay_destroy(hsad_replay* r) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (r->h_done) (void)hipHostFree((void*)r->h_done);
+  r->fence.destroy();
   if (r->h_canon_ring) (void)hipHostFree(r->h_canon_ring);
   delete r;
 }
@@ -1197,6 +1228,7 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
   if (n < 1) return HSAD_OK;
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(r->fence.pass(s));
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, n, n_dev, priority);
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
@@ -1215,6 +1247,7 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "batch must be 1..%d", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(r->fence.pass(s));
   // canonical uniforms exactly as std::uniform_real_distribution<float> would draw them (libstdc++:
   // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
   // the segment depends on the device-side running sum)
@@ -1258,6 +1291,7 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (n < 0 || n > kMaxBatch || (n > 0 && (!targets_host || !raw_weight))) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(r->fence.pass(s));
   if (n > 0) {
     int slot;
     float* hc = canon_slot(r, &slot);
@@ -1282,6 +1316,7 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
   if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
   if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
   r->last_stream = (hipStream_t)stream;
+  HIP_TRY(r->fence.pass((hipStream_t)stream));
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -1290,6 +1325,7 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
 // ---- the sharded draw without host round trips (kernels above; choreography: hanabi_sad_amd/dist.py ReplayLink) ----
 int hsad_replay_stats(hsad_replay* r, double* out2, void* stream) {
   if (!r || !out2) return rfail(HSAD_ERR_INVALID, "null argument");
+  HIP_TRY(r->fence.pass((hipStream_t)stream));
   hipLaunchKernelGGL(replay_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->rd, out2);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -1304,6 +1340,7 @@ int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const doubl
     return rfail(HSAD_ERR_INVALID, "serve: batch 1..%d, world 1..64, rank inside it", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(r->fence.pass(s));
   float* raw_w = r->d_shard + kMaxBatch;
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch);
   hipLaunchKernelGGL(shard_targets_kernel, dim3(1), dim3(1024), 0, s, all_stats, world, rank, canon, batch, owner_out, r->d_canon, n_mine);
@@ -1320,6 +1357,7 @@ int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, c
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(r->fence.pass(s));
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch) + 1;
   hipLaunchKernelGGL(compact_owned_kernel, dim3(1), dim3(1024), 0, s, priority, owner, batch, rank, r->d_shard, n_mine);
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_shard, n_mine);
@@ -1393,6 +1431,7 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
                     float* bootstrap, float* seq_len, void* stream) {
   if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
   hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(r->fence.pass(s));
   hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
   const FieldOut fp = field_out(r->L, out_fields);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
@@ -1476,6 +1515,7 @@ void hsad_seqwriter_destroy(hsad_seqwriter* w) {
                   sd.fin_prio, sd.fin_len, sd.n_fin, w->d_err};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  w->fence.destroy();
   delete w;
 }
 
@@ -1560,6 +1600,7 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
 int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream) {
   if (!w || !priority) return rfail(HSAD_ERR_INVALID, "null argument");
   if (!w->pending) return rfail(HSAD_ERR_STATE, "no popped transition to push");
+  HIP_TRY(w->fence.pass((hipStream_t)stream));   // the previous flush (possibly on another stream) resets the cursors this reads
   if (w->L.row_bytes <= 256)
     hipLaunchKernelGGL(seq_push_kernel<16>, dim3((w->sd.E + 15) / 16), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
                        w->pend_slot, priority, w->d_err);
@@ -1577,6 +1618,8 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
     return rfail(HSAD_ERR_INVALID, "sequence writer and replay were created with different layouts");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
+  HIP_TRY(w->fence.pass(s));
+  HIP_TRY(r->fence.pass(s));
   const SeqDev& sd = w->sd;
   const float c1m = (float)(1.0 - (double)eta);
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
@@ -1586,6 +1629,9 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
                      r->reward, r->terminal, r->bootstrap, r->seq_len);
   hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl, w->d_err);
   HIP_TRY(hipGetLastError());
+  // whoever touches the writer's cursors or the replay next, on whatever stream, is ordered behind this flush
+  HIP_TRY(w->fence.arm(s));
+  HIP_TRY(r->fence.arm(s));
   return HSAD_OK;
 }
 
