@@ -163,6 +163,7 @@ SIGNATURES = {
     "hsad_r2d2_net_refresh": (C.c_int, [_P, _P]),
     "hsad_r2d2_net_version": (C.c_uint64, [_P]),
     "hsad_r2d2_net_in_dim_padded": (C.c_int, [_P]),
+    "hsad_r2d2_target_q": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_comm_unique_id": (C.c_int, [_P, C.c_int]),
     "hsad_comm_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "hsad_comm_destroy": (None, [_P]),

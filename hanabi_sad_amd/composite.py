@@ -98,8 +98,10 @@ class CompositeAgent:
         z = torch.zeros(self.online.L, n, self.online.H, dtype=torch.float32, device=self.device)
         return {"h0": z, "c0": z.clone()}
 
-    def act(self, obs, hid, with_q=False):
-        """obs["priv_s"] float32 [N,F], or obs["priv_s_bf16"] [N, in_dim_padded] as the env's packed outputs provide it"""
+    def act(self, obs, hid, with_q=False, defer_target=False):
+        """obs["priv_s"] float32 [N,F], or obs["priv_s_bf16"] [N, in_dim_padded] as the env's packed outputs provide it.
+        with_q: also Q_online(s, a) and Q_target(s, greedy_a); defer_target: leave the target half to target_q() -- the caller
+        issues the env step (which only needs the actions) first and runs the two side by side"""
         n, on, d = obs["legal_move"].shape[0], self.online, self.device
         a = torch.empty(n, dtype=torch.int64, device=d)
         g = torch.empty(n, dtype=torch.int64, device=d)
@@ -109,13 +111,13 @@ class CompositeAgent:
         h16_in = hid.get("h0_16") if fused else None
         h16 = torch.empty(on.L, n, on.H, dtype=torch.bfloat16, device=d) if fused else None
         qa = torch.empty(n, dtype=torch.float32, device=d) if with_q else None
-        tq = torch.empty(n, dtype=torch.float32, device=d) if with_q else None
+        tq = torch.empty(n, dtype=torch.float32, device=d) if (with_q and not defer_target) else None
         eps = obs.get("eps")
         p = lambda t: None if t is None else t.contiguous().data_ptr()
         p16 = obs.get("priv_s_bf16")
         if p16 is not None and (p16.dtype != torch.bfloat16 or p16.shape[-1] != on.Fp or p16.numel() != n * on.Fp):
             raise _lib.HsadError("priv_s_bf16 must be bf16 [%d, %d]; got %s %s" % (n, on.Fp, p16.dtype, tuple(p16.shape)))
-        _lib.check(self.lib.hsad_r2d2_act(on.h, self.target.h if with_q else None, n, None if p16 is not None else p(obs["priv_s"]),
+        _lib.check(self.lib.hsad_r2d2_act(on.h, self.target.h if tq is not None else None, n, None if p16 is not None else p(obs["priv_s"]),
                                           p(p16), p(obs["legal_move"]), p(eps),
                                           p(hid["h0"]), p(hid["c0"]), p(h16_in), self.seed, self.counter, a.data_ptr(), g.data_ptr(),
                                           h.data_ptr(), c.data_ptr(), p(h16), p(qa), p(tq), _s(d)))
@@ -127,6 +129,17 @@ class CompositeAgent:
             reply["q_online_a"], reply["q_target_greedy"] = qa, tq
             reply["versions"] = (on.version, self.target.version)
         return reply, new_hid
+
+    def target_q(self, obs, hid, greedy_a):
+        """Q_target(s, greedy_a) [N] from the state that ENTERED act(): the half act(defer_target=True) left out (hsad_r2d2_target_q)"""
+        n, d = greedy_a.shape[0], self.device
+        tq = torch.empty(n, dtype=torch.float32, device=d)
+        p = lambda t: None if t is None else t.contiguous().data_ptr()
+        p16 = obs.get("priv_s_bf16")
+        h16 = hid.get("h0_16") if n >= 1024 else None
+        _lib.check(self.lib.hsad_r2d2_target_q(self.target.h, n, None if p16 is not None else p(obs["priv_s"]), p(p16), p(obs["legal_move"]),
+                                               p(hid["h0"]), p(hid["c0"]), p(h16), p(greedy_a), tq.data_ptr(), _s(d)))
+        return tq
 
     def q_of(self, net, obs, action, hid, pre=None):
         """Q_net(s, action) [N] for one step from the carried hidden state (hsad_r2d2_q_of)"""

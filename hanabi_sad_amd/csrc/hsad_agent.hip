@@ -336,8 +336,8 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
                   float* q_target_greedy, void* stream) {
   if (!online || (!priv_s && !priv_s_bf16) || !legal_move || !h0 || !c0 || !a || !greedy_a || !h_out || !c_out || N < 1)
     return afail(HSAD_ERR_INVALID, "r2d2_act: null argument");
-  if ((q_online_a != nullptr) != (q_target_greedy != nullptr) || (q_online_a && !target))
-    return afail(HSAD_ERR_INVALID, "r2d2_act: q_online_a and q_target_greedy come together and need the target net");
+  if (q_target_greedy && (!q_online_a || !target))
+    return afail(HSAD_ERR_INVALID, "r2d2_act: q_target_greedy needs q_online_a and the target net");
   hsad_r2d2_net* n = online;
   hipStream_t s = (hipStream_t)stream;
   const int H = n->H, A = n->A, NH = n->NH;
@@ -365,7 +365,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
   // action, greedy action and Q_online(s, a) from one pass over the heads (same arithmetic as hsad_act_select + hsad_q_head)
   CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
-  if (q_online_a) {
+  if (q_target_greedy) {
     if (target->F != n->F || target->H != H || target->A != A) return afail(HSAD_ERR_INVALID, "r2d2_act: online / target shapes differ");
     StepOut st{};
     // the target pass shares the bf16 casts of the observation and (fused path) of the hidden state
@@ -375,6 +375,32 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     CK(hsad_gemm_nt_bf16(st.o16, H, target->Wheads, H, N, NH, H, target->bheads, hd_t, NH, nullptr, 0, 0, 0, stream));
     CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
   }
+  return 0;
+}
+
+// Q_target(s, greedy_a) alone: the target-net half of an acting step as its own call, so that a caller can issue the env step
+// (which only needs the online half's actions) before it and run the two side by side (actor.DeviceActor does)
+int hsad_r2d2_target_q(hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16, const float* legal_move,
+                       const float* h0, const float* c0, const void* h0_bf16, const int64_t* greedy_a, float* q_target_greedy, void* stream) {
+  if (!target || (!priv_s && !priv_s_bf16) || !legal_move || !h0 || !c0 || !greedy_a || !q_target_greedy || N < 1)
+    return afail(HSAD_ERR_INVALID, "r2d2_target_q: null argument");
+  hsad_r2d2_net* n = target;
+  hipStream_t s = (hipStream_t)stream;
+  const int H = n->H, A = n->A, NH = n->NH;
+  const size_t a16_b = (size_t)N * n->Fp * 2, hd_b = (size_t)N * NH * 4, step_b = step_ws_bytes(n, N);
+  CK(n->ws.need(a16_b + step_b + hd_b + 1024));
+  char* p = n->ws.as<char>();
+  bf16_t* a16 = (bf16_t*)p;
+  p += a16_b;
+  char* ws = p;
+  p += step_b;
+  float* hd = (float*)p;
+  if (priv_s_bf16) a16 = (bf16_t*)priv_s_bf16;
+  else CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
+  StepOut st{};
+  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, nullptr, nullptr, ws, &st, s));
+  CK(hsad_gemm_nt_bf16(st.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
+  CK(hsad_q_at(hd, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
   return 0;
 }
 

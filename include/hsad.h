@@ -515,13 +515,18 @@ int hsad_r2d2_net_in_dim_padded(const hsad_r2d2_net* net);            /* row len
 /* R2D2Agent.act for N rows (one per (game, player)): priv_s fp32 [N,F] -- or priv_s_bf16 [N, in_dim_padded] zero-padded, as
  * hsad_env_bind_packed writes it (then priv_s may be NULL and no cast pass runs) --, legal_move [N,A], eps [N] (NULL = greedy), hidden state
  * h0 / c0 fp32 [L,N,H] in, h_out / c_out out (h0_bf16 / h_out_bf16, optional: the bf16 copy the fused cell kernels read / write
- * anyway, carried by the caller to save a cast per step) -> a, greedy_a int64 [N].  q_online_a / q_target_greedy (both or
- * neither): Q_online(s, a) of the pass that picked the action and Q_target(s, greedy_a) from one target-net pass, i.e. what
+ * anyway, carried by the caller to save a cast per step) -> a, greedy_a int64 [N].  q_online_a / q_target_greedy (optional; the
+ * latter needs the former and `target`): Q_online(s, a) of the pass that picked the action and Q_target(s, greedy_a) from one target-net pass, i.e. what
  * compute_priority needs from this step.  Exploration: counter-based hash of (seed, row, counter). */
 int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16,
                   const float* legal_move, const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
                   int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
                   float* q_target_greedy, void* stream);
+/* the two halves of that call separately: hsad_r2d2_act with target = NULL, q_target_greedy = NULL and q_online_a set gives the action,
+ * the greedy action, the new state and Q_online(s, a); hsad_r2d2_target_q gives Q_target(s, greedy_a) from the same inputs.  A caller
+ * that issues the env step between them (it only needs the actions) can run it next to the target pass. */
+int hsad_r2d2_target_q(hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16, const float* legal_move,
+                       const float* h0, const float* c0, const void* h0_bf16, const int64_t* greedy_a, float* q_target_greedy, void* stream);
 /* R2D2Agent.compute_priority (r2d2.py:305-361): |r + bootstrap gamma^n Q_target(s', argmax adv_online(s')) - Q_online(s, a)|.
  * num_player > 1 = VDN: Q summed over the players of a game; reward / bootstrap / priority are then per game [N / num_player].
  * next_greedy_a (may be NULL): the argmax when the caller already has it (the act() of the same iteration). */

@@ -58,8 +58,8 @@ def test_device_actor_loop_equals_oracle_env_plus_reference_buffers(method, play
     rec_a, rec_g, rec_p = [], [], []
     orig_act, orig_push = actor.agent.act, actor.writer.push_sequence
 
-    def act(obs, hid, with_q=False):
-        reply, nh = orig_act(obs, hid, with_q=with_q)
+    def act(obs, hid, with_q=False, **kw):
+        reply, nh = orig_act(obs, hid, with_q=with_q, **kw)
         rec_a.append(reply["a"].view(G, P).cpu().numpy().copy())
         rec_g.append(reply["greedy_a"].view(G, P).cpu().numpy().copy())
         return reply, nh

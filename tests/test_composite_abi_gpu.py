@@ -262,3 +262,31 @@ def test_schedule_of_an_existing_learner_can_be_changed():
         for k, v in ref_g.items():
             assert relerr(L.grad[k], v) < 1e-5, (chunks, k)
         L.check_sync()
+
+
+def test_act_in_two_halves_equals_the_single_call():
+    """hsad_r2d2_act(target = NULL, q_online_a) + hsad_r2d2_target_q == hsad_r2d2_act with both Q outputs, to the bit (fused-cell path
+    with the carried bf16 state, and the small-batch path)"""
+    from hanabi_sad_amd.composite import CNet, CompositeAgent
+    from hanabi_sad_amd.selfplay import init_weights
+    F, H, A = 838, 512, 21
+    W, Wt = init_weights(F, H, A, 5, 1), init_weights(F, H, A, 5, 2)
+    on, tg = CNet(W, DEV), CNet(Wt, DEV)
+    for N in (2048, 96):
+        g = torch.Generator(device="cpu").manual_seed(N)
+        priv = (torch.rand(N, F, generator=g) < 0.15).float().to(DEV)
+        legal = (torch.rand(N, A, generator=g) < 0.5).float().to(DEV)
+        legal[:, 0] = 1
+        obs = {"priv_s": priv, "legal_move": legal, "eps": torch.full((N,), 0.3, device=DEV)}
+        hid = {"h0": (torch.randn(2, N, H, generator=g) * 0.3).to(DEV), "c0": (torch.randn(2, N, H, generator=g) * 0.3).to(DEV)}
+        one, two = CompositeAgent(on, tg, 3, 0.999, seed=1), CompositeAgent(on, tg, 3, 0.999, seed=1)
+        for step in range(2):                      # second step: the state carries its bf16 copy
+            r1, h1 = one.act(obs, hid if step == 0 else h1, with_q=True)
+            hin = hid if step == 0 else h2
+            r2, h2 = two.act(obs, hin, with_q=True, defer_target=True)
+            assert r2["q_target_greedy"] is None
+            tq = two.target_q(obs, hin, r2["greedy_a"])
+            for k in ("a", "greedy_a", "q_online_a"):
+                assert torch.equal(r1[k], r2[k]), (N, step, k)
+            assert torch.equal(r1["q_target_greedy"], tq), (N, step)
+            assert torch.equal(h1["h0"], h2["h0"]) and torch.equal(h1["c0"], h2["c0"])
