@@ -110,7 +110,7 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     dt_py = (time.perf_counter() - t0) / updates
     r2d2.check_sync()
     # the product path: the same kernel schedule behind the library's composite entry points (hsad_r2d2_loss_fwd / _loss_bwd /
-    # _optimizer_step: one C call each); the Python-orchestrated learner above only serves the in-update GEMM event timing below
+    # _optimizer_step: one C call each); the Python-orchestrated learner above is the A/B reference (python_schedule_ms_per_update)
     from hanabi_sad_amd.composite import CompositeLearner
     cl = CompositeLearner(W, W, 3, 0.999, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device=dev)
     for _ in range(warmup):
@@ -129,15 +129,27 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     M, N, K = T * B, 4 * H, H
     if not gemm_probe:
         return {"value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3}
-    # the time-batched LSTM input-projection GEMM (M=T*B, N=4H, K=H) WHERE IT RUNS: HIP events around its launches inside
-    # five more updates (the layer-0 projections of the online and the target net), on the stream it is launched on
-    r2d2.GEMM_TIMING = []
+    # the time-batched LSTM input-projection GEMM (M=T*B, N=4H, K=H) WHERE IT RUNS: HIP events around its launches inside five more
+    # updates of the product (composite) learner, on the stream it is launched on.  There the online and the target net's projection
+    # are ONE launch of two problems (hsad_gemm_nt_bf16_pair): per-problem time = launch time / 2.
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    lib = _lib.load_library()
+    cl2 = CompositeLearner(W, W, 3, 0.999, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device=dev)
+    for _ in range(2):
+        cl2.loss(batch, weight, 0.0)
+        cl2.optimizer_step()
+    _lib.check(lib.hsad_gemm_timing(1))
     for _ in range(5):
-        upd()
-    torch.cuda.synchronize()
-    in_upd = [e0.elapsed_time(e1) for (m_, n_, k_, e0, e1) in r2d2.GEMM_TIMING if (m_, n_, k_) == (M, N, K)]
-    r2d2.GEMM_TIMING = None
-    in_update_ms = sum(in_upd) / max(1, len(in_upd))
+        cl2.loss(batch, weight, 0.0)
+        cl2.optimizer_step()
+    g_ms, g_n, g_np = C.c_double(0), C.c_int32(0), C.c_int32(1)
+    _lib.check(lib.hsad_gemm_timing_read(M, N, K, C.byref(g_ms), C.byref(g_n), C.byref(g_np)))
+    _lib.check(lib.hsad_gemm_timing(0))
+    cl2.check_sync()
+    cl2.close()
+    in_upd = [g_ms.value / max(g_np.value, 1)] * g_n.value
+    in_update_ms = g_ms.value / max(g_np.value, 1)
     # ... and standalone, back to back (what rocprofv3's AverageNs of a GEMM-only run shows)
     A16 = torch.randn(M, K, device=dev).to(torch.bfloat16)
     B16 = torch.randn(N, K, device=dev).to(torch.bfloat16)
@@ -159,9 +171,10 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
         "config": {"workload": "BASELINE configs[2]: 2p SAD IQL learner update, F=838 A=21 H=512 L=2 B=128 T=80 n=3, "
                                "synthetic batch, random-init nets, loss fwd + BPTT + clip + Adam"},
         "update_tflops": flop / dt / 1e12,
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d)" % (M, N, K),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d; online + target net = one launch of two "
+                               "problems, avg_launch_ms is per problem)" % (M, N, K),
                      "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0,
-                     "traffic": gemm_traffic_bytes(), "avg_launch_ms": gemm_ms, "in_update_launches_timed": len(in_upd),
+                     "traffic": gemm_traffic_bytes(), "avg_launch_ms": gemm_ms, "in_update_launches_timed": len(in_upd), "problems_per_launch": g_np.value,
                      "standalone_avg_launch_ms": standalone_ms, "algorithmic_flop_per_launch": 2.0 * M * N * K,
                      "algorithmic_bytes_per_launch": M * K * 2 + N * K * 2 + M * N * 4},
     }

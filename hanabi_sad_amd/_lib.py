@@ -137,6 +137,10 @@ SIGNATURES = {
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "hsad_nstep_priority": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "hsad_zero_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "hsad_gemm_nt_bf16_pair": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, C.c_int,
+                                         C.c_int, _P]),
+    "hsad_gemm_timing": (C.c_int, [C.c_int]),
+    "hsad_gemm_timing_read": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "hsad_lstm_cell_timing": (C.c_int, [C.c_int]),
     "hsad_lstm_cell_timing_read": (C.c_int, [_P, _P, _P]),
     "hsad_refresh_begin": (C.c_int, []),

@@ -733,10 +733,11 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
     CK(hsad_cast_pad_bf16(priv_s, M, L->on->F, L->on->F, L->a16, Fp, stream));
     L->a16_in = L->a16;
   }
-  for (int q = 0; q < 2; ++q) {
-    CK(hsad_gemm_nt_bf16(L->a16_in, Fp, nets[q]->W1, Fp, M, H, Fp, nets[q]->w(P_B1), nullptr, 0, L->x1[q], H, 1, 0, stream));
-    CK(hsad_gemm_nt_bf16(L->x1[q], H, nets[q]->Wih[0], H, M, H4, H, nets[q]->bg[0], L->gates[q][0], H4, nullptr, 0, 0, 0, stream));
-  }
+  // the online / target pair of each forward GEMM is ONE launch (hsad_gemm_nt_bf16_pair): input layer, then layer-0 projection
+  CK(hsad_gemm_nt_bf16_pair(L->a16_in, L->a16_in, Fp, nets[0]->W1, nets[1]->W1, Fp, M, H, Fp, nets[0]->w(P_B1), nets[1]->w(P_B1), nullptr,
+                            nullptr, 0, L->x1[0], L->x1[1], H, 1, stream));
+  CK(hsad_gemm_nt_bf16_pair(L->x1[0], L->x1[1], H, nets[0]->Wih[0], nets[1]->Wih[0], H, M, H4, H, nets[0]->bg[0], nets[1]->bg[0],
+                            L->gates[0][0], L->gates[1][0], H4, nullptr, nullptr, 0, 0, stream));
   if (can_pipeline(L)) {
     // layers software-pipelined over time chunks: stage st runs layer 0 on chunk st and layer 1 on chunk st - 1, for both nets, as
     // ONE multi-recurrence persistent launch
@@ -760,12 +761,13 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
           return r;
         };
         if (st < nch) recs[nr++] = rec(0, st);
-        if (st >= 1) {
-          const size_t t0 = (size_t)(st - 1) * Tc;
-          CK(hsad_gemm_nt_bf16(L->hseq[q][0] + t0 * B * H, H, nets[q]->Wih[1], H, Tc * B, H4, H, nets[q]->bg[1],
-                               L->gates[q][1] + t0 * B * H4, H4, nullptr, 0, 0, 0, stream));
-          recs[nr++] = rec(1, st - 1);
-        }
+        if (st >= 1) recs[nr++] = rec(1, st - 1);
+      }
+      if (st >= 1) {      // layer-1 projection of chunk st - 1, both nets in one launch
+        const size_t t0 = (size_t)(st - 1) * Tc;
+        CK(hsad_gemm_nt_bf16_pair(L->hseq[0][0] + t0 * B * H, L->hseq[1][0] + t0 * B * H, H, nets[0]->Wih[1], nets[1]->Wih[1], H, Tc * B, H4,
+                                  H, nets[0]->bg[1], nets[1]->bg[1], L->gates[0][1] + t0 * B * H4, L->gates[1][1] + t0 * B * H4, H4, nullptr,
+                                  nullptr, 0, 0, stream));
       }
       for (int i = 0; i < nr; i += per_launch) {
         const int n = std::min(per_launch, nr - i);

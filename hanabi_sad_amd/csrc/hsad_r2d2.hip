@@ -106,6 +106,11 @@ struct GemmArgs {
   const int32_t* row_map;  // optional [M]: result row r is written to row row_map[r] of C32 / C16
   int gz;                  // number of K splits (1 = none)
   size_t slab_stride;      // split-K without atomics: split z writes its partial result to C32 + z * slab_stride
+  // two problems of the same shape in one launch (hsad_gemm_nt_bf16_pair: the online / target pair of every forward GEMM of the
+  // learner): byte distances from the first problem's pointers to the second's.  1280 tiles per problem are 2.5 per resident
+  // workgroup -- three rounds of which the last is half empty; 2560 are five full rounds.
+  int npair;
+  long long dA, dB, dbias, dC32, dC16;
 };
 
 // LDS bytes of gemm_nt_bf16_kernel<BM,BN>: operand buffer 0 | operand buffer 1, the latter shared with the epilogue's output
@@ -132,15 +137,16 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   // so that workgroups running together share the A panel in L2, and the first operand tile of the next output tile is
   // requested before the epilogue of the current one
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
-  const int n_tiles = tiles_n * tiles_m * g.gz;
-  int m0 = 0, n0 = 0, bz = 0;
+  const int n_tiles = tiles_n * tiles_m * g.gz * g.npair;
+  int m0 = 0, n0 = 0, bz = 0, pp = 0;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;        // 8-row pieces per wave and operand
   uint32_t aoff[A_IT], boff[B_IT];                      // byte offsets of this lane's 16-byte chunk in each piece
   const int prow = lane >> 3;
   auto set_tile = [&](int t) {
     n0 = (t % tiles_n) * BN;
     m0 = ((t / tiles_n) % tiles_m) * BM;
-    bz = t / (tiles_n * tiles_m);
+    bz = (t / (tiles_n * tiles_m)) % g.gz;
+    pp = t / (tiles_n * tiles_m * g.gz);
     // rows past the end of A / B repeat the last row: what they produce is never stored
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -154,8 +160,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
     }
   };
   auto issue_tile = [&](int k0, int buf) {
-    const char* abase = reinterpret_cast<const char*>(g.A + k0);
-    const char* bbase = reinterpret_cast<const char*>(g.B + k0);
+    const char* abase = reinterpret_cast<const char*>(g.A + k0) + pp * g.dA;
+    const char* bbase = reinterpret_cast<const char*>(g.B + k0) + pp * g.dB;
     bf16_t* da = sOp + buf * BUF;
     bf16_t* db = da + BM * kBK;
 #pragma unroll
@@ -210,6 +216,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
   }
 
   const int cm0 = m0, cn0 = n0, cbz = bz;                   // this tile's coordinates for the epilogue
+  const float* const e_bias = g.bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(g.bias) + pp * g.dbias) : nullptr;
+  float* const e_C32 = g.C32 ? reinterpret_cast<float*>(reinterpret_cast<char*>(g.C32) + pp * g.dC32) : nullptr;
+  bf16_t* const e_C16 = g.C16 ? reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(g.C16) + pp * g.dC16) : nullptr;
   __syncthreads();                                          // both operand buffers are dead: 0 may be refilled, 1 staged into
   if (q + qstep < tpx && tbase + q + qstep < n_tiles) {     // next tile's first operand tile flies during the epilogue
     set_tile(tbase + q + qstep);
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = cn0 + wn * WN + j * 32 + (lane & 31);
-      bias[j] = (g.bias && col < g.N && !cbz) ? g.bias[col] : 0.f;
+      bias[j] = (e_bias && col < g.N && !cbz) ? e_bias[col] : 0.f;
     }
     typedef float nt_f4 __attribute__((ext_vector_type(4)));
     constexpr int LPR = WN / 4;          // lanes per output row
@@ -265,19 +274,19 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
             uint2 o;
             o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
             o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-            *reinterpret_cast<uint2*>(g.C16 + (size_t)row * g.ldc16 + col) = o;
+            *reinterpret_cast<uint2*>(e_C16 + (size_t)row * g.ldc16 + col) = o;
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (col + e < g.N) {
                 float x = v[e];
                 if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col + e]) > 0.f)) x = 0.f;
-                g.C16[(size_t)row * g.ldc16 + col + e] = f2bf(x);
+                e_C16[(size_t)row * g.ldc16 + col + e] = f2bf(x);
               }
           }
         } else if (row < g.M) {
           const nt_f4 v = *reinterpret_cast<const nt_f4*>(sC + rl * CS + cw);
-          float* p = g.C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
+          float* p = e_C32 + (size_t)cbz * g.slab_stride + (size_t)row * g.ldc + col;
           if (col + 3 < g.N) {
             __builtin_nontemporal_store(v, reinterpret_cast<nt_f4*>(p));
           } else {
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = cn0 + wn * WN + j * 32 + (lane & 31);
-      const float b = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+      const float b = (e_bias && col < g.N) ? e_bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = cm0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -304,13 +313,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(GemmArgs g) {
           if (g.mask16 && !(bf2f(g.mask16[(size_t)row * g.ldmask + col]) > 0.f)) v = 0.f;
           const int orow = g.row_map ? g.row_map[row] : row;
           if (g.C32) {
-            float* p = g.C32 + (size_t)orow * g.ldc + col;
+            float* p = e_C32 + (size_t)orow * g.ldc + col;
             if (g.k_chunk)
               atomicAdd(p, v);
             else
               *p = g.accumulate ? (*p + v) : v;
           }
-          if (g.C16) g.C16[(size_t)orow * g.ldc16 + col] = f2bf(v);
+          if (g.C16) e_C16[(size_t)orow * g.ldc16 + col] = f2bf(v);
         }
       }
     }
@@ -2261,9 +2270,26 @@ static long gemm_grid(long tiles, int n_cu) {
   return want & ~7L;
 }
 
+struct GemmPair {
+  long long dA, dB, dbias, dC32, dC16;
+};
+
+// ---- measurement hook: HIP events around every GEMM launch, on the stream it is launched on (bench.py: the projection GEMM where it
+// runs inside the learner update) ----
+namespace {
+struct GemmTimingRec {
+  hipEvent_t e0, e1;
+  int M, N, K, np;
+};
+struct GemmTiming {
+  bool on = false;
+  std::vector<GemmTimingRec> recs;
+} g_gemm_timing;
+}  // namespace
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* C32,
                        int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k, const void* relu_mask16,
-                       int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream) {
+                       int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream,
+                       const GemmPair* pair = nullptr) {
   if (!A || !B || (!C32 && !C16)) return nfail(HSAD_ERR_INVALID, "gemm: null operand");
   if (K % kBK || (lda % 8) || (ldb % 8)) return nfail(HSAD_ERR_INVALID, "gemm: K must be a multiple of 64 and lda/ldb of 8");
   if (((uintptr_t)A | (uintptr_t)B) & 15) return nfail(HSAD_ERR_INVALID, "gemm: operands must be 16-byte aligned");
@@ -2272,7 +2298,16 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
   if (split_k > 1 && (!C32 || C16 || relu || relu_mask16))
     return nfail(HSAD_ERR_INVALID, "gemm: split-K only supports a plain fp32 output (pre-zeroed or accumulated into)");
   GemmArgs g{(const bf16_t*)A, (const bf16_t*)B, bias, C32, (bf16_t*)C16, M, N, K, lda, ldb, ldc, ldc16, relu, accumulate,
-             0, (const bf16_t*)relu_mask16, ldmask, row_map, 1, 0};
+             0, (const bf16_t*)relu_mask16, ldmask, row_map, 1, 0, 1, 0, 0, 0, 0, 0};
+  if (pair) {
+    g.npair = 2;
+    g.dA = pair->dA;
+    g.dB = pair->dB;
+    g.dbias = pair->dbias;
+    g.dC32 = pair->dC32;
+    g.dC16 = pair->dC16;
+  }
+  const int np = g.npair;
   int gz = 1;
   if (split_k > 1) {
     int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
@@ -2289,20 +2324,60 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
+  GemmTimingRec trec{nullptr, nullptr, M, N, K, np};
+  if (g_gemm_timing.on) {
+    HIP_TRY(hipEventCreate(&trec.e0));
+    HIP_TRY(hipEventCreate(&trec.e1));
+    HIP_TRY(hipEventRecord(trec.e0, s));
+  }
   // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
-  const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
+  const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz * np;
   if (N <= 64 || tiles128 < n_cu) {
     const size_t lds = gemm_lds_bytes(128, 64);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz;
+    const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz * np;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 64>), dim3((unsigned)gemm_grid(tiles, n_cu)), dim3(256), lds, s, g);
   } else {
     const size_t lds = gemm_lds_bytes(128, 128);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128) * gz;
+    const long tiles = (long)((N + 127) / 128) * ((M + 127) / 128) * gz * np;
     hipLaunchKernelGGL((gemm_nt_bf16_kernel<128, 128>), dim3((unsigned)gemm_grid(tiles, n_cu)), dim3(256), lds, s, g);
   }
   HIP_TRY(hipGetLastError());
+  if (trec.e0) {
+    HIP_TRY(hipEventRecord(trec.e1, s));
+    g_gemm_timing.recs.push_back(trec);
+  }
+  return HSAD_OK;
+}
+
+int hsad_gemm_timing(int enable) {
+  g_gemm_timing.on = enable != 0;
+  return HSAD_OK;
+}
+
+// average duration (ms) of the recorded launches of shape M x N x K and how many problems each launch held (1, or 2 for
+// hsad_gemm_nt_bf16_pair); synchronises the device and clears the whole record
+int hsad_gemm_timing_read(int M, int N, int K, double* avg_ms, int32_t* launches, int32_t* problems_per_launch) {
+  if (!avg_ms || !launches) return nfail(HSAD_ERR_INVALID, "gemm_timing_read: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  double ms = 0.0;
+  int n = 0, np = 1;
+  for (auto& r : g_gemm_timing.recs) {
+    if (r.M == M && r.N == N && r.K == K) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+      ms += t;
+      np = r.np;
+      ++n;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_gemm_timing.recs.clear();
+  *avg_ms = n ? ms / n : 0.0;
+  *launches = n;
+  if (problems_per_launch) *problems_per_launch = np;
   return HSAD_OK;
 }
 
@@ -2326,6 +2401,21 @@ int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int
                      N, C32, ldc, row_map);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
+}
+
+int hsad_gemm_nt_bf16_pair(const void* A0, const void* A1, int lda, const void* B0, const void* B1, int ldb, int M, int N, int K,
+                           const float* bias0, const float* bias1, float* C32_0, float* C32_1, int ldc, void* C16_0, void* C16_1,
+                           int ldc16, int relu, void* stream) {
+  if (!A1 || !B1 || (bias0 != nullptr) != (bias1 != nullptr) || (C32_0 != nullptr) != (C32_1 != nullptr) ||
+      (C16_0 != nullptr) != (C16_1 != nullptr))
+    return nfail(HSAD_ERR_INVALID, "gemm_pair: the two problems must use the same set of operands");
+  if ((((uintptr_t)A1 | (uintptr_t)B1) & 15) || ((uintptr_t)C32_1 & 15) != ((uintptr_t)C32_0 & 15) ||
+      ((uintptr_t)C16_1 & 7) != ((uintptr_t)C16_0 & 7))
+    return nfail(HSAD_ERR_INVALID, "gemm_pair: operands of the second problem must be aligned like the first's");
+  const GemmPair pr{(long long)((const char*)A1 - (const char*)A0), (long long)((const char*)B1 - (const char*)B0),
+                    (long long)((const char*)bias1 - (const char*)bias0), (long long)((char*)C32_1 - (char*)C32_0),
+                    (long long)((char*)C16_1 - (char*)C16_0)};
+  return gemm_launch(A0, lda, B0, ldb, M, N, K, bias0, C32_0, ldc, C16_0, ldc16, relu, 0, 1, nullptr, 0, nullptr, 0, nullptr, stream, &pr);
 }
 
 int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,

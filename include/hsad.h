@@ -319,6 +319,11 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
  * zero padded), outputs fp32 C32 (optionally accumulated into) and/or bf16 C16.  nn.Linear forward. */
 int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias,
                       float* C32, int ldc, void* C16, int ldc16, int relu, int accumulate, void* stream);
+/* two problems of the same shape (A0 B0^T, A1 B1^T; both with bias / fp32 output / bf16 output or both without) as ONE launch: the
+ * online / target pair of every forward GEMM of the learner.  Tile rounds: 2 x 2.5 -> 5. */
+int hsad_gemm_nt_bf16_pair(const void* A0, const void* A1, int lda, const void* B0, const void* B1, int ldb, int M, int N, int K,
+                           const float* bias0, const float* bias1, float* C32_0, float* C32_1, int ldc, void* C16_0, void* C16_1,
+                           int ldc16, int relu, void* stream);
 /* fp32 [M,K] (row stride ld_src) -> bf16 [M,Kp] zero padded */
 int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream);
 /* bf16 [R,C] -> [C,R] */
@@ -358,6 +363,9 @@ int hsad_lstm_debug_timing(uint64_t* out16, int reset);
  * the last read (synchronises) and clears the record.  bench.py's actor roofline. */
 int hsad_lstm_cell_timing(int enable);
 int hsad_lstm_cell_timing_read(double* avg_ms, double* avg_flop, int32_t* launches);
+/* the same for the bf16 GEMM: events around every launch while enabled; _read averages the launches of one shape */
+int hsad_gemm_timing(int enable);
+int hsad_gemm_timing_read(int M, int N, int K, double* avg_ms, int32_t* launches, int32_t* problems_per_launch);
 /* reads the timeout word of a sync_scratch buffer used with T steps / Bn rows (synchronises the device) */
 int hsad_lstm_sync_timed_out(const void* sync_scratch, int T, int Bn, int32_t* timed_out);
 /* Dueling head + masked argmax (r2d2.py:106-131): heads fp32 [M,ldh] = [advantage(A) | value(1) | ...],
