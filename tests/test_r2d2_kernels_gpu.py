@@ -387,3 +387,38 @@ def test_fused_inference_cell_matches_the_two_kernel_path(N, H):
     assert torch.allclose(h1[0], torch.sigmoid(o) * torch.tanh(c), atol=2e-3, rtol=2e-3)
 
 
+
+
+@pytest.mark.parametrize("M,N,K,out", [(10240, 2048, 512, "f32"), (10240, 512, 896, "bf16relu"), (2560, 2048, 512, "f32"),
+                                      (300, 37, 128, "f32"), (1000, 200, 64, "bf16relu")])
+def test_gemm_pair_launch_equals_two_launches(M, N, K, out):
+    """hsad_gemm_nt_bf16_pair (two problems of one shape in one launch: the learner's online / target forward GEMMs) is bit-identical
+    to two single launches -- separately allocated operands, shapes with row / column tails, both tile sizes, both output kinds"""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s, gemm_nt
+    lib = _lib.load_library()
+    g = torch.Generator(device="cpu").manual_seed(M + N)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    A = [mk(M, K).to(torch.bfloat16) for _ in range(2)]
+    pad = torch.empty(12345, device=DEV)                      # keeps the allocations apart: the deltas are arbitrary
+    Bm = [mk(N, K).to(torch.bfloat16) for _ in range(2)]
+    bias = [mk(N) for _ in range(2)]
+    relu = out == "bf16relu"
+    dt = torch.bfloat16 if relu else torch.float32
+    want = [torch.empty(M, N, dtype=dt, device=DEV) for _ in range(2)]
+    got = [torch.full((M, N), 7.0, dtype=dt, device=DEV) for _ in range(2)]
+    for q in range(2):
+        gemm_nt(A[q], Bm[q], M, N, K, bias=bias[q], **({"out16": want[q], "relu": True} if relu else {"out32": want[q]}))
+    p = lambda t: t.data_ptr()
+    _lib.check(lib.hsad_gemm_nt_bf16_pair(p(A[0]), p(A[1]), K, p(Bm[0]), p(Bm[1]), K, M, N, K, p(bias[0]), p(bias[1]),
+                                          None if relu else p(got[0]), None if relu else p(got[1]), 0 if relu else N,
+                                          p(got[0]) if relu else None, p(got[1]) if relu else None, N if relu else 0, int(relu), _s(torch.device(DEV))))
+    for q in range(2):
+        assert torch.equal(got[q], want[q]), (q, M, N, K)
+    # the same A for both problems (the input layer: one observation, two nets)
+    _lib.check(lib.hsad_gemm_nt_bf16_pair(p(A[0]), p(A[0]), K, p(Bm[0]), p(Bm[1]), K, M, N, K, p(bias[0]), p(bias[1]),
+                                          None if relu else p(got[0]), None if relu else p(got[1]), 0 if relu else N,
+                                          p(got[0]) if relu else None, p(got[1]) if relu else None, N if relu else 0, int(relu), _s(torch.device(DEV))))
+    ref = torch.empty(M, N, dtype=dt, device=DEV)
+    gemm_nt(A[0], Bm[1], M, N, K, bias=bias[1], **({"out16": ref, "relu": True} if relu else {"out32": ref}))
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], ref)
