@@ -243,6 +243,9 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     return out
 
 
+EXCHANGE_TIMEOUT_S = 180
+
+
 def exchange_bench(dev, rank, world, rounds=60, batch=128):
     """--gpus N > 1: the learner <-> actor exchange of a multi-GPU self-play job (hanabi_sad_amd/dist.py ReplayLink) over RCCL, timed
     per section with HIP events on the learner's exchange stream.  Rank 0 is the dedicated learner (empty shard), every other rank
@@ -479,13 +482,7 @@ def main():
     achieved = bytes_per_step * G / (iter_ms * 1e-3) / 1e9        # all concurrent launches together = the chip's rate
     per_launch = bytes_per_step * (G / K) * iters_per_launch / (fused_ms * 1e-3) / 1e9
 
-    exchange = None
-    if world > 1 and not os.environ.get("HSAD_BENCH_NO_EXCHANGE"):
-        env_dims = (env.P, env.F, env.A, env.H)
-        del env
-        torch.cuda.empty_cache()
-        exchange = exchange_bench(dev, rank, world)
-        env = SimpleNamespace(P=env_dims[0], F=env_dims[1], A=env_dims[2], H=env_dims[3])
+    out = None
     if rank == 0:
         out = {
             "metric": "hanabi_env_steps_per_sec",
@@ -535,8 +532,29 @@ def main():
                 "event_pair_ms": step_raw_ms, "empty_event_pair_ms": pair_overhead_ms,
             },
         }
-        if exchange is not None:
+    if world > 1 and not os.environ.get("HSAD_BENCH_NO_EXCHANGE"):
+        # the exchange leg is collective: a rank that never arrives would leave the others inside a collective for good and the
+        # headline number, already measured, unprinted.  A watchdog prints the line without the leg and ends the process instead.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["exchange"] = {"error": "the exchange leg did not finish within %d s" % EXCHANGE_TIMEOUT_S}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        del env
+        torch.cuda.empty_cache()
+        try:
+            exchange = exchange_bench(dev, rank, world)
+        except Exception as e:               # (a failure on ONE rank: the others meet the watchdog)
+            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+        if rank == 0:
             out["exchange"] = exchange
+    if rank == 0:
         if world == 1 and not args.no_actor:
             out["env_configs4"] = env_config4_bench(dev)
         if world == 1 and not args.no_learner:
