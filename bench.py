@@ -243,7 +243,7 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     return out
 
 
-EXCHANGE_TIMEOUT_S = 180
+EXCHANGE_TIMEOUT_S = int(os.environ.get("HSAD_BENCH_EXCHANGE_TIMEOUT", "180"))
 
 
 def exchange_bench(dev, rank, world, rounds=60, batch=128):
