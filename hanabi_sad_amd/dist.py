@@ -296,7 +296,8 @@ class ReplayLink:
     draw_canonical / set_outstanding (the gloo CPU tests)."""
 
     ROUND_KEY = "hsad/link/round"
-    PARAMS, STOP, HAS_PRIO = 1, 2, 4
+    FLAG_SLOTS = 64        # flags of round r live in key r % 64: the learner's host is never more than four rounds ahead of its own
+    PARAMS, STOP, HAS_PRIO = 1, 2, 4   # exchange stream (hdr_ev below) and that stream cannot pass a round an actor has not served
 
     def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None):
         import torch.distributed as dist
@@ -405,7 +406,7 @@ class ReplayLink:
         assert self.is_learner and self._result is None
         flags = (self.PARAMS if params else 0) | (self.STOP if stop else 0) | (self.HAS_PRIO if prio is not None else 0)
         r = self.opened
-        self.store.set("hsad/link/flags/%d" % r, str(flags))
+        self.store.set("hsad/link/flags/%d" % (r % self.FLAG_SLOTS), str(flags))
         self.store.add(self.ROUND_KEY, 1)
         self.opened += 1
         B, k = self.B, r % 4
@@ -446,7 +447,7 @@ class ReplayLink:
         """has the learner opened a round this rank has not served yet?  -> its flags, or None.  Host-side only (one store query)"""
         if int(self.store.add(self.ROUND_KEY, 0)) <= self.served:
             return None
-        return int(self.store.get("hsad/link/flags/%d" % self.served))
+        return int(self.store.get("hsad/link/flags/%d" % (self.served % self.FLAG_SLOTS)))
 
     def serve(self, flags):
         """serve the round `poll` announced, on the current stream.  After a PARAMS round the new [online | target] parameters are in
