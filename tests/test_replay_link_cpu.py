@@ -62,6 +62,7 @@ rank, world = rank_world()
 dist.init_process_group("gloo", rank=rank, world_size=world)
 NP = 1000
 link = ReplayLink(HostShard(rank), B, BETA, "cpu", learner_rank=0, depth=2, param_numel=NP)
+link.FLAG_SLOTS = 4                                        # fewer flag keys than rounds: the ring of store keys wraps in this test
 if rank == 0:
     model = [initial(k) for k in range(world)]            # the single-buffer emulation: every shard's weights, updated when the priorities ARRIVE
     rng = np.random.default_rng(7)
