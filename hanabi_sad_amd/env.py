@@ -3,7 +3,6 @@ write.  One object = G games = what the reference builds as G `hanalearn.HanabiE
 `HanabiVecEnv`s (pyhanabi/create.py:24-54; rela/env.h:29-108)."""
 import ctypes as C
 
-import numpy as np
 import torch
 
 from . import _lib

@@ -175,7 +175,6 @@ class HanabiThreadLoop:
 
     def _build(self):
         from .actor import DeviceActor, transition_fields
-        from .r2d2 import R2D2Agent
         self._built = True
         if len(self.vec_envs) > 1:                 # merged: one vector env over all games, in seed order
             merged = HanabiVecEnv()

@@ -10,8 +10,6 @@ elementwise kernel.  State-dict keys are the reference's: priv_net.{0,2,4}.*, pu
 `act` follows obl_model.py:247-300: the input is the SAD observation (838 features; the trailing greedy-action section and the
 own-hand block are cut away), eps-greedy unless `greedy`, and BOTH reply fields carry the chosen action (the reference sets
 reply["greedy_a"] = action)."""
-import ctypes as C
-
 import torch
 
 from . import _lib

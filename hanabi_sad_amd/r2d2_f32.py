@@ -10,7 +10,7 @@ selfplay's --precision flag.  There is still no CPU or torch fallback: every con
 import torch
 
 from . import _lib
-from .r2d2 import PARAM_ORDER, _s
+from .r2d2 import _s
 
 
 def gemm_f32(A, B, M, N, K, out, a_strides=None, b_strides=None, bias=None, relu=False, accumulate=False, relu_mask=None,

@@ -191,7 +191,6 @@ class BatchRunner:
 
     def update_model(self, py_model):
         """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
-        from .r2d2 import R2D2NetKernels
         if getattr(py_model, "device_agent", False):      # an acting agent of this package (e.g. obl.OBLAgent): used as it is
             self.agent_obj = py_model
             return
