@@ -177,13 +177,13 @@ struct StepOut {
 };
 
 int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const float* c0, const bf16_t* h16_in, float* h_out,
-             float* c_out, char* wsp, StepOut* out, hipStream_t s, bf16_t* h16_dst = nullptr) {
+             float* c_out, char* wsp, StepOut* out, hipStream_t s, bf16_t* h16_dst = nullptr, bool x_ready = false) {
   const int H = n->H;
   void* st = (void*)s;
   const size_t NH_ = (size_t)N * H;
-  bf16_t* x = reinterpret_cast<bf16_t*>(wsp);
+  bf16_t* x = reinterpret_cast<bf16_t*>(wsp);   // x_ready: the caller already ran the input layer into the head of wsp
   wsp += NH_ * 2;
-  CK(hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(P_B1), nullptr, 0, x, H, 1, 0, st));
+  if (!x_ready) CK(hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(P_B1), nullptr, 0, x, H, 1, 0, st));
   const bool fused = n->Wcat16[0] && !n->with_backward && N >= 1024;
   if (fused) {
     bf16_t* h16 = reinterpret_cast<bf16_t*>(wsp);
@@ -361,7 +361,12 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   StepOut so{};
   // (the bf16 copy of the new state goes straight into the caller's buffer: it must not alias h0_bf16, which layer 1 still reads)
   if (h_out_bf16 && h_out_bf16 == h0_bf16) return afail(HSAD_ERR_INVALID, "r2d2_act: h_out_bf16 must not alias h0_bf16");
-  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16));
+  // both nets read the same observation: their input layers are ONE launch of two problems over a shared A operand
+  const bool pair_in = q_target_greedy && target->F == n->F && target->H == H && target->A == A;
+  if (pair_in)
+    CK(hsad_gemm_nt_bf16_pair(a16, a16, n->Fp, n->W1, target->W1, n->Fp, N, H, n->Fp, n->w(P_B1), target->w(P_B1), nullptr, nullptr, 0,
+                              ws_on, ws_tg, H, 1, stream));
+  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in));
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
   // action, greedy action and Q_online(s, a) from one pass over the heads (same arithmetic as hsad_act_select + hsad_q_head)
   CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
@@ -371,7 +376,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     // the target pass shares the bf16 casts of the observation and (fused path) of the hidden state
     const bf16_t* h16_shared = (const bf16_t*)h0_bf16;
     if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);   // the cast net_step made
-    CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s));
+    CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s, nullptr, pair_in));
     CK(hsad_gemm_nt_bf16(st.o16, H, target->Wheads, H, N, NH, H, target->bheads, hd_t, NH, nullptr, 0, 0, 0, stream));
     CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
   }
