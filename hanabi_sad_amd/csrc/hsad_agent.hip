@@ -367,6 +367,19 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     CK(hsad_gemm_nt_bf16_pair(a16, a16, n->Fp, n->W1, target->W1, n->Fp, N, H, n->Fp, n->w(P_B1), target->w(P_B1), nullptr, nullptr, 0,
                               ws_on, ws_tg, H, 1, stream));
   CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in));
+  if (pair_in && hd_b % 16 == 0) {
+    // ... and so are their head layers (N = A + 1 + 3 hand: one problem alone leaves half of the chip without a tile); the target's
+    // trunk therefore runs before the online heads.  Same kernels on the same operands as the sequence below: identical bits.
+    StepOut st{};
+    const bf16_t* h16_shared = (const bf16_t*)h0_bf16;
+    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);
+    CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s, nullptr, true));
+    CK(hsad_gemm_nt_bf16_pair(so.o16, st.o16, H, n->Wheads, target->Wheads, H, N, NH, H, n->bheads, target->bheads, hd, hd_t, NH, nullptr,
+                              nullptr, 0, 0, stream));
+    CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
+    CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
+    return 0;
+  }
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
   // action, greedy action and Q_online(s, a) from one pass over the heads (same arithmetic as hsad_act_select + hsad_q_head)
   CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
