@@ -2153,20 +2153,43 @@ __global__ __launch_bounds__(256) void q_at_kernel(const float* __restrict__ hea
   qa[m0 + tid] = h[A] + h[act] * lg[act] - mean;
 }
 
-// fp32 h / c [L,N,H] and the bf16 copy of h an acting step carries, zeroed together for the rows whose env terminated
+// fp32 h / c [L,N,H] and the bf16 copy of h an acting step carries, zeroed together for the rows whose env terminated.  A wave looks at
+// 64 (layer, row) pairs at once (one flag byte per lane, one ballot) and zeroes the few that are set with all its lanes: a step ends
+// ~1.5 % of its games, so most waves read 64 bytes and leave.
 __global__ __launch_bounds__(256) void zero_state_rows_kernel(float* __restrict__ h, float* __restrict__ c, unsigned* __restrict__ h16,
                                                               const unsigned char* __restrict__ flag, int L, int N, int H,
-                                                              int rows_per_flag) {
-  const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // (layer, row) index
-  if (w >= (size_t)L * N) return;
-  const int row = (int)(w % N), lane = threadIdx.x & 63;
-  if (!flag[row / rows_per_flag]) return;
-  for (int i = lane; i < H; i += 64) {
-    h[w * H + i] = 0.f;
-    c[w * H + i] = 0.f;
+                                                              int rows_per_flag, int vec) {
+  const int lane = threadIdx.x & 63;
+  const size_t total = (size_t)L * N;
+  const size_t w0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  if (w0 >= total) return;
+  const size_t wl = w0 + lane;
+  const bool set = wl < total && flag[(int)(wl % N) / rows_per_flag] != 0;
+  unsigned long long m = __ballot(set);
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const size_t w = w0 + b;
+    if (vec) {   // H % 8 == 0 and 16-byte aligned bases
+      float4* ph = reinterpret_cast<float4*>(h + w * H);
+      float4* pc = reinterpret_cast<float4*>(c + w * H);
+      for (int i = lane; i < H / 4; i += 64) {
+        ph[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (h16) {
+        uint4* p16 = reinterpret_cast<uint4*>(h16 + w * (H / 2));
+        for (int i = lane; i < H / 8; i += 64) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    } else {
+      for (int i = lane; i < H; i += 64) {
+        h[w * H + i] = 0.f;
+        c[w * H + i] = 0.f;
+      }
+      if (h16)
+        for (int i = lane; i < H / 2; i += 64) h16[w * (H / 2) + i] = 0u;
+    }
   }
-  if (h16)
-    for (int i = lane; i < H / 2; i += 64) h16[w * (H / 2) + i] = 0u;
 }
 
 // R2D2Agent.compute_priority tail (r2d2.py:355-360): |reward + bootstrap * gamma^n * target_qa - online_qa|
@@ -2880,9 +2903,10 @@ int hsad_q_at(const float* heads, int ldh, const float* legal, const int64_t* ac
 
 int hsad_zero_state_rows(float* h, float* c, void* h_bf16, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream) {
   if (!h || !c || !flag || rows_per_flag < 1 || (H & 1)) return nfail(HSAD_ERR_INVALID, "zero_state_rows: bad arguments");
-  const size_t waves = (size_t)L * N;
+  const size_t waves = ((size_t)L * N + 63) / 64;
+  const int vec = (H % 8 == 0) && ((((uintptr_t)h | (uintptr_t)c | (uintptr_t)h_bf16) & 15) == 0);
   hipLaunchKernelGGL(zero_state_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, c,
-                     static_cast<unsigned*>(h_bf16), flag, L, N, H, rows_per_flag);
+                     static_cast<unsigned*>(h_bf16), flag, L, N, H, rows_per_flag, vec);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

@@ -329,6 +329,8 @@ def test_zero_hidden_rows(L, N, H, rpf):
     from hanabi_sad_amd.r2d2 import zero_hidden_rows
     g = torch.Generator(device="cpu").manual_seed(N)
     hid = {"h0": torch.randn(L, N, H, generator=g).to(DEV), "c0": torch.randn(L, N, H, generator=g).to(DEV)}
+    if H % 2 == 0:                       # the bf16 copy of h an acting step carries is zeroed by the same launch
+        hid["h0_16"] = hid["h0"].to(torch.bfloat16)
     want = {k: v.clone() for k, v in hid.items()}
     flags = (torch.rand((N + rpf - 1) // rpf, generator=g) < 0.3).to(torch.uint8).to(DEV)
     zero_hidden_rows(hid, flags, rpf)
