@@ -804,9 +804,10 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
       }
   }
   // heads, Q-values, double-DQN target
-  CK(hsad_gemm_nt_bf16(L->hseq[0][1], H, L->on->Wheads, H, M, NH, H, L->on->bheads, L->heads, NH, nullptr, 0, 0, 0, stream));
+  // (the two head layers are one pair launch: N = A + 1 + 3 hand columns, one problem alone is 80 workgroups)
+  CK(hsad_gemm_nt_bf16_pair(L->hseq[0][1], L->hseq[1][1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
+                            L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
   CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, L->greedy, L->qscratch, stream));
-  CK(hsad_gemm_nt_bf16(L->hseq[1][1], H, L->tg->Wheads, H, M, NH, H, L->tg->bheads, L->heads_t, NH, nullptr, 0, 0, 0, stream));
   CK(hsad_q_head(L->heads_t, NH, legal_move, L->greedy, M, A, L->q, L->tqa, nullptr, L->qscratch, stream));
   const float *qa = L->qa, *tqa = L->tqa;
   const int Bg = B / num_player;
