@@ -620,9 +620,9 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->dheads, M * NHp * 2);
   want(&L->dO0, M * H * 4);
   want(&L->dO1, M * H * 4);
+  want(&L->dc[0], 2 * B * H * 4);      // dc[1] follows dc[0]: one memset clears both
   for (int l = 0; l < 2; ++l) {
     want(&L->dG[l], (size_t)(T + 1) * B * H4 * 2);
-    want(&L->dc[l], B * H * 4);
     want(&L->hsT[l], pipe0 ? H * (B + M) * 2 : H * Mp * 2);
     want(&L->hpT[l], pipe0 ? 256 : H * Mp * 2);
     want(&L->xchg_b[l], xb * 2);
@@ -646,6 +646,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     *e.first = p;
     p += e.second;
   }
+  L->dc[1] = L->dc[0] + B * H;
   // optimizer state + gradient
   const size_t np = online->n_param;
   if (L->opt.need(np * 4 * 3 + 64)) {
@@ -904,8 +905,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   if (pipe) {
     const int Tc = T / nch, nrb = nrb_of(B);
     const size_t Mc = (size_t)Tc * B;
-    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)B * H * 4, s));
-    HIP_TRY(hipMemsetAsync(L->dc[1], 0, (size_t)B * H * 4, s));
+    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
     const float* dOs[2] = {L->dO0, L->dO1};
     const int per_launch = std::max(1, std::min(2, L->n_cu / ((H / 32) * nrb)));
     for (int st = 0; st <= nch; ++st) {
