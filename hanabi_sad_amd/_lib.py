@@ -43,6 +43,12 @@ class LstmBwdRec(C.Structure):
                 ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p)]
 
 
+class LstmFusedRec(C.Structure):
+    """hsad_lstm_fused_rec (include/hsad.h)"""
+    _fields_ = [("Wih_blocked", C.c_void_p), ("Whh_blocked", C.c_void_p), ("bias_blocked", C.c_void_p), ("x16", C.c_void_p),
+                ("gates", C.c_void_p), ("cseq", C.c_void_p), ("hseq16", C.c_void_p), ("hT", C.c_void_p), ("xchg", C.c_void_p)]
+
+
 SIGNATURES = {
     "hsad_last_error": (C.c_char_p, []),
     "hsad_version": (C.c_char_p, []),
@@ -152,6 +158,7 @@ SIGNATURES = {
     "hsad_zero_state_rows": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "hsad_lstm_forward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "hsad_lstm_forward_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,

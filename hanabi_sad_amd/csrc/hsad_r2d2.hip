@@ -1379,6 +1379,327 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgsN m) {
   lstm_seq_fwd_body<KB>(m.r[rec_], rb_, nb_, m.nrb, m.nunit, m.group_words + G_, m.force_cross_xcd);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused persistent recurrence (round 3): the input projection runs INSIDE the recurrence and stacked layers run one step
+// apart in ONE launch -- no stand-alone x W_ih^T GEMM, no fp32 pre-activation round trip through HBM, no time chunks.
+//
+//   gates_t = [x_t | h_{t-1}] [W_ih | W_hh]^T + b           (x_t = the layer's input: a row-major sequence, or h_t of the layer below)
+//
+// Workgroup (rb, nb) of a recurrence owns 32 rows x 32 units exactly like lstm_seq_fwd_kernel, but BOTH of its weight slices are
+// stationary: the 128 x H slice of W_ih in LDS (133 KB), the 128 x H slice of W_hh as MFMA B fragments in REGISTERS (64 fragments
+// = 256 registers per lane at H = 512: one wave per SIMD owns the SIMD's whole 512-entry file, the compiler places them in
+// AGPRs and feeds v_mfma's B operand from there).  Per step a wave therefore issues 2 x 4 x KB MFMAs on two A tiles:
+//   * X tile (32 rows x H of the input): known early.  Layer 0 prefetches it with plain loads at the end of the previous step;
+//     a stacked layer reads the hand-off tiles the layer below published (same XCD, same L2) -- early (prefetched) when that
+//     layer is ahead, late (after its own H part) when it is the one being waited for.  Either way these MFMAs fill what used
+//     to be the exchange wait.
+//   * H tile (h_{t-1} of its own 16 unit-block workgroups): the critical path, unchanged protocol (counter per (step, row
+//     block), L2-local plain stores + sc1 loads for co-located groups, write-through + agent-scope atomics otherwise).
+// The two partial sums live in separate accumulators and are added once, so the result does not depend on which tile arrived
+// first.  The "super group" = the nl x (H/32) workgroups of all fused layers of one (net, row block) shares an XCD (verified by
+// the start-up handshake): layer l+1 consumes layer l's tiles through that L2 one step behind it.
+// ---------------------------------------------------------------------------------------------------
+struct LstmFusedArgs {
+  const bf16_t* Wih;        // [4H,H] gate-blocked; LDS-resident slice
+  const bf16_t* Whh;        // [4H,H] gate-blocked; register-resident slice
+  const float* bias;        // [4H] gate-blocked b_ih + b_hh
+  const bf16_t* x;          // [T,Bn,H] row-major input, or NULL: the input is `xin`
+  const bf16_t* xin;        // hand-off tiles of the producing recurrence of this launch [T][nrb][KB][32][32]
+  unsigned* xin_counters;   // its step counters [T][nrb]
+  float* gates;             // [T,Bn,4H] activated gates, or NULL (not kept)
+  float* cseq;              // [T,Bn,H], or NULL
+  bf16_t* hseq16;           // [T,Bn,H] row-major copy, or NULL
+  float* hT;                // optional [Bn,H]
+  bf16_t* xchg;             // [T][nrb][KB][32][32] (required)
+  unsigned* counters;       // [T][nrb], zeroed before launch
+  unsigned* timeout;
+  int T, Bn;
+};
+
+template <int KB>  // KB = H / 32
+__device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, const int rb, const int nb, const int nrb, const int nunit,
+                                                    u64_t* group_word, const int nmember, const int force_cross_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int H = KB * 32;
+  constexpr int WS = H + 8;
+  constexpr int QK = KB / 4;
+  constexpr int NKL = KB >= 16 ? 2 : 0;        // trailing k blocks of the W_hh slice kept in LDS instead of registers (register budget)
+  constexpr int KR = KB - NKL;                 // k blocks of W_hh in registers
+  constexpr int WS2 = NKL * 32 + 8;
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                 // [128][WS]  W_ih slice
+  bf16_t* sW2 = sW + 128 * WS;                                       // [128][WS2] last NKL k blocks of the W_hh slice
+  bf16_t* sH = sW2 + (NKL ? 128 * WS2 : 0);                          // [32][40]   h tile staging
+  int* s_okp = reinterpret_cast<int*>(sH + 32 * 40);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int kofs = (lane >> 4) * 8;
+  for (int c = tid; c < 128 * (H / 8); c += 256) {
+    const int r = c / (H / 8), q = c - r * (H / 8);
+    *reinterpret_cast<uint4*>(sW + r * WS + q * 8) = *reinterpret_cast<const uint4*>(a.Wih + (size_t)(nb * 128 + r) * H + q * 8);
+  }
+  if (NKL)
+    for (int c = tid; c < 128 * NKL * 4; c += 256) {
+      const int r = c / (NKL * 4), q = c - r * (NKL * 4);
+      *reinterpret_cast<uint4*>(sW2 + r * WS2 + q * 8) = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + KR * 32 + q * 8);
+    }
+  union Frag {
+    u64_t q[2];
+    u32x4 w;
+    bf16x8 v;
+  };
+  // W_hh slice as B fragments: gate j, k block kb -> row nb*128 + j*32 + wu*16 + (lane & 15), k = kb*32 + kofs .. +7
+  Frag wreg[4][KR];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int kb = 0; kb < KR; ++kb)
+      wreg[j][kb].w = *reinterpret_cast<const u32x4*>(a.Whh + (size_t)(nb * 128 + j * 32 + wu * 16 + (lane & 15)) * H + kb * 32 + kofs);
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
+  const int row_l = min(rb * 32 + wr * 16 + (lane & 15), a.Bn - 1);
+  float b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = a.bias[ucol + j * 32];
+  float cst[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nmember, a.timeout);
+  __syncthreads();
+  if (s_okp[1] < 0) return;
+  const int fast = force_cross_xcd ? 0 : s_okp[1];
+  const bool has_xc = a.x == nullptr;
+  const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
+  const int dbg_base = has_xc ? 8 : 0;     // phase timers: slots 0-6 first layer, 8-14 stacked layer (summed over nets)
+  u64_t stamp_ = dbg_on ? wall_clock64() : 0;
+
+  // bounded spin of thread 0 on a step counter, verdict broadcast through LDS slot `slot`
+  auto wait_ctr = [&](unsigned* ctr, int slot) -> bool {
+    if (tid == 0) {
+      unsigned spins = 0;
+      int ok = 1;
+      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nunit) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > 4000000u) {
+          __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+      s_okp[slot] = ok;
+    }
+    __syncthreads();
+    return s_okp[slot] != 0;
+  };
+  // this lane's fragment base inside the hand-off tiles of (step, row block): element (row wr*16 + (lane&15), k = kofs) of k block 0
+  auto tile_ptr = [&](const bf16_t* base, int step) {
+    return base + ((size_t)step * nrb + rb) * (size_t)KB * 1024 + (wr * 16 + (lane & 15)) * 32 + kofs;
+  };
+  Frag fx[KB];
+  bool x_pref = false;
+  if (!has_xc) {   // layer input from a row-major sequence: plain (compiler-tracked) loads, a step ahead
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) fx[kb].w = *reinterpret_cast<const u32x4*>(a.x + (size_t)row_l * H + kb * 32 + kofs);
+    x_pref = true;
+  }
+
+  for (int t = 0; t < a.T; ++t) {
+    f32x4 accx[4], acch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      accx[j] = f32x4{b4[j], b4[j], b4[j], b4[j]};
+      acch[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto mfma_x = [&](int k0, int k1) {      // B from the LDS-resident W_ih slice
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb < k0 || kb >= k1) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (j * 32 + wu * 16 + (lane & 15)) * WS + kb * 32 + kofs);
+          accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb].v, fb, accx[j], 0, 0, 0);
+        }
+      }
+    };
+    if (x_pref) mfma_x(0, KB);
+    LSTM_STAMP(dbg_base + 0)   // prefetched X tile x W_ih
+    if (t > 0) {
+      if (!wait_ctr(a.counters + (size_t)(t - 1) * nrb + rb, 0)) return;
+      LSTM_STAMP(dbg_base + 1)   // wait for h_{t-1}
+      Frag fh[KB];
+      const bf16_t* hp = tile_ptr(a.xchg, t - 1);
+      auto mfma_h = [&](int k0, int k1) {    // B from the register-resident W_hh slice
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          if (kb < k0 || kb >= k1) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (kb < KR) {
+              acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, wreg[j][kb < KR ? kb : 0].v, acch[j], 0, 0, 0);
+            } else {
+              const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW2 + (j * 32 + wu * 16 + (lane & 15)) * WS2 + (kb - KR) * 32 + kofs);
+              acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, fb, acch[j], 0, 0, 0);
+            }
+          }
+        }
+      };
+      if (fast) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fh[kb].w) : "v"(hp + (size_t)kb * 1024));
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QK) : "memory");
+          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QK) : "memory");
+          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QK) : "memory");
+          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+            if (kb >= qd * QK && kb < (qd + 1) * QK) asm volatile("" : "+v"(fh[kb].w));
+          mfma_h(qd * QK, (qd + 1) * QK);
+        }
+      } else {
+        const u64_t* hq = reinterpret_cast<const u64_t*>(hp);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          fh[kb].q[0] = __hip_atomic_load(hq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fh[kb].q[1] = __hip_atomic_load(hq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        mfma_h(0, KB);
+      }
+      LSTM_STAMP(dbg_base + 2)   // h tile loads + MFMAs
+    }
+    if (!x_pref) {   // stacked layer whose input tile was not there yet at the end of the previous step
+      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 3)) return;
+      const bf16_t* xp = tile_ptr(a.xin, t);
+      if (fast) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fx[kb].w) : "v"(xp + (size_t)kb * 1024));
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QK) : "memory");
+          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QK) : "memory");
+          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QK) : "memory");
+          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb)
+            if (kb >= qd * QK && kb < (qd + 1) * QK) asm volatile("" : "+v"(fx[kb].w));
+          mfma_x(qd * QK, (qd + 1) * QK);
+        }
+      } else {
+        const u64_t* xq = reinterpret_cast<const u64_t*>(xp);
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          fx[kb].q[0] = __hip_atomic_load(xq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fx[kb].q[1] = __hip_atomic_load(xq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        mfma_x(0, KB);
+      }
+      LSTM_STAMP(dbg_base + 3)   // late X tile: wait + loads + MFMAs
+    }
+    float keep_g[4][4], keep_h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = sigmoidf_(accx[0][r] + acch[0][r]);
+      const float gf = sigmoidf_(accx[1][r] + acch[1][r]);
+      const float gg = tanhf_(accx[2][r] + acch[2][r]);
+      const float go = sigmoidf_(accx[3][r] + acch[3][r]);
+      const float c = gf * cst[r] + gi * gg;
+      const float h = go * tanhf_(c);
+      cst[r] = c;
+      keep_g[r][0] = gi;
+      keep_g[r][1] = gf;
+      keep_g[r][2] = gg;
+      keep_g[r][3] = go;
+      keep_h[r] = h;
+      sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
+    }
+    __syncthreads();
+    LSTM_STAMP(dbg_base + 4)   // cell update + h tile to LDS
+    {  // publish: linear 2 KB block, thread tid -> bytes [8 tid, 8 tid + 8)
+      const int r = tid >> 3, q = tid & 7;
+      const u64_t v = *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
+      xchg_store8(reinterpret_cast<u64_t*>(a.xchg + (((size_t)t * nrb + rb) * KB + nb) * 1024 + r * 32 + q * 4), v, fast);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {   // is the NEXT input tile of a stacked layer already published?  (decides early / late X for step t + 1)
+      int early = 0;
+      if (has_xc && t + 1 < a.T)
+        early = __hip_atomic_load(a.xin_counters + (size_t)(t + 1) * nrb + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nunit;
+      s_okp[2] = early;
+    }
+    __syncthreads();
+    if (tid == 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    LSTM_STAMP(dbg_base + 5)   // publish: store, drain, signal
+    {
+      const int r = tid >> 3, q = tid & 7;
+      const int row = rb * 32 + r;
+      if (a.hseq16 && row < a.Bn)
+        *reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4) =
+            *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + r;
+      if (row < a.Bn) {
+        if (a.gates) {
+          float* gp = a.gates + ((size_t)t * a.Bn + row) * 4 * H + ucol;
+          gp[0] = keep_g[r][0];
+          gp[32] = keep_g[r][1];
+          gp[64] = keep_g[r][2];
+          gp[96] = keep_g[r][3];
+        }
+        if (a.cseq) a.cseq[((size_t)t * a.Bn + row) * H + u] = cst[r];
+        if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = keep_h[r];
+      }
+    }
+    // next step's X tile, issued now so that its MFMAs run inside the exchange wait (compiler-tracked loads only: they live
+    // across the loop edge)
+    x_pref = false;
+    if (t + 1 < a.T) {
+      if (!has_xc) {
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+          fx[kb].w = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(t + 1) * a.Bn + row_l) * H + kb * 32 + kofs);
+        x_pref = true;
+      } else if (s_okp[2]) {
+        const u64_t* xq = reinterpret_cast<const u64_t*>(tile_ptr(a.xin, t + 1));
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          fx[kb].q[0] = __hip_atomic_load(xq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fx[kb].q[1] = __hip_atomic_load(xq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        x_pref = true;
+      }
+    }
+    LSTM_STAMP(dbg_base + 6)   // state stores + next X tile issued
+  }
+}
+
+// records are ordered [net][layer]; layer l > 0 of a net takes its input from record - 1 when its x is NULL
+struct LstmFusedArgsN {
+  LstmFusedArgs r[6];
+  int nnet, nl, nrb, nunit;
+  u64_t* group_words;   // [nnet * nrb] (one per super group), zeroed before launch
+  int force_cross_xcd;
+  unsigned* zero_ptr;   // optional: the NEXT launch's sync scratch, zeroed by this launch
+  int zero_words;
+};
+
+template <int KB>
+__global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(LstmFusedArgsN m) {
+  if (blockIdx.x == 0 && m.zero_ptr)
+    for (int i = threadIdx.x; i < m.zero_words; i += 256) m.zero_ptr[i] = 0u;
+  // linear block id L -> XCD L % 8, slot L / 8; super group SG = x + 8 * (slot / (nl * nunit)) = (net, row block); inside it
+  // layer-major: all unit blocks of layer 0, then layer 1, ...
+  const int L = blockIdx.x, s = L >> 3;
+  const int per = m.nl * m.nunit;
+  const int p = s / per, within = s - p * per;
+  const int SG = (L & 7) + 8 * p;
+  if (SG >= m.nnet * m.nrb) return;
+  const int layer = within / m.nunit, nb = within - layer * m.nunit;
+  const int net = SG / m.nrb, rb = SG - net * m.nrb;
+  lstm_fused_fwd_body<KB>(m.r[net * m.nl + layer], rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+}
+
+
 
 
 // ---------------------------------------------------------------------------------------------------
@@ -2996,6 +3317,69 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
                             counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg};
   }
   return launch_seq_bwd(m, nrec, H, nrb, sync, s, (unsigned*)next_sync_scratch, (int)seq_sync_words(nrec, Tc, nrb));
+}
+
+// Fused persistent forward (lstm_fused_fwd_kernel): nnet independent nets x nlayer stacked layers over the WHOLE sequence in one
+// launch, the input projections computed inside the recurrences.  recs[net * nlayer + layer]; a record whose x16 is NULL takes its
+// input from the record before it (the layer below).  Needs nnet * ceil(Bn/32) * nlayer * (H/32) co-resident workgroups.
+// sync_scratch: uint32 [nnet*nlayer*(T+2)*ceil(Bn/32) + 4], same ping-pong convention as hsad_lstm_forward_chunk_multi.
+int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hsad_lstm_fused_rec* recs, void* sync_scratch,
+                            void* next_sync_scratch, void* stream) {
+  const int nrec = nnet * nlayer;
+  if (nnet < 1 || nlayer < 1 || nrec > 6 || !recs || !sync_scratch || T < 1) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: bad arguments");
+  if (!((H == 256 || H == 512) && Bn >= 1)) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: needs H in {256,512}");
+  hipStream_t s = (hipStream_t)stream;
+  const int nrb = (Bn + 31) / 32, nunit = H / 32, nsg = nnet * nrb;
+  // a super group (all fused layers of one (net, row block)) lives on ONE XCD, one workgroup per CU
+  const int grid = 8 * nlayer * nunit * ((nsg + 7) / 8);
+  if (grid > device_cus())
+    return nfail(HSAD_ERR_INVALID, "fused persistent LSTM launch needs %d co-resident workgroups per XCD, the device has %d (fuse fewer layers or nets per launch)",
+                 grid / 8, device_cus() / 8);
+  unsigned* sync = (unsigned*)sync_scratch;
+  unsigned* counters = sync + 2 * nrec * nrb;
+  const size_t words = seq_sync_words(nrec, T, nrb);
+  if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
+  LstmFusedArgsN m{};
+  for (int i = 0; i < nrec; ++i) {
+    const hsad_lstm_fused_rec& r = recs[i];
+    const int layer = i % nlayer;
+    if (!r.Wih_blocked || !r.Whh_blocked || !r.bias_blocked || !r.xchg || (!r.x16 && layer == 0))
+      return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: null pointer in record %d", i);
+    LstmFusedArgs& q = m.r[i];
+    q.Wih = (const bf16_t*)r.Wih_blocked;
+    q.Whh = (const bf16_t*)r.Whh_blocked;
+    q.bias = r.bias_blocked;
+    q.x = (const bf16_t*)r.x16;
+    q.xin = r.x16 ? nullptr : (const bf16_t*)recs[i - 1].xchg;
+    q.xin_counters = r.x16 ? nullptr : counters + (size_t)(i - 1) * T * nrb;
+    q.gates = r.gates;
+    q.cseq = r.cseq;
+    q.hseq16 = (bf16_t*)r.hseq16;
+    q.hT = r.hT;
+    q.xchg = (bf16_t*)r.xchg;
+    q.counters = counters + (size_t)i * T * nrb;
+    q.timeout = counters + (size_t)nrec * T * nrb;
+    q.T = T;
+    q.Bn = Bn;
+  }
+  m.nnet = nnet;
+  m.nl = nlayer;
+  m.nrb = nrb;
+  m.nunit = nunit;
+  m.group_words = reinterpret_cast<u64_t*>(sync);
+  m.force_cross_xcd = g_force_cross_xcd;
+  m.zero_ptr = (unsigned*)next_sync_scratch;
+  m.zero_words = next_sync_scratch ? (int)words : 0;
+  const size_t lds = (size_t)(128 * (H + 8) + (H >= 512 ? 128 * (2 * 32 + 8) : 0) + 32 * 40) * sizeof(bf16_t) + 16;
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_fused_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, m);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_fused_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, m);
+  }
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
 }
 
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,

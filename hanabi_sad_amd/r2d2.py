@@ -138,6 +138,37 @@ def check_sync():
         raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup: %s" % (bad,))
 
 
+def lstm_forward_fused(x16, nets, keep=True):
+    """hsad_lstm_forward_fused: x16 = one bf16 [T,Bn,H] input sequence per net; nets = per net a list (one entry per stacked
+    layer) of (Wih_blocked bf16 [4H,H], Whh_blocked bf16 [4H,H], bias_blocked fp32 [4H]).  All nets / layers in ONE persistent
+    launch.  -> per net, per layer: dict(gates, cseq, hseq, hT) (gates / cseq None when keep is False)"""
+    lib = _lib.load_library()
+    T, Bn, H = x16[0].shape
+    d = x16[0].device
+    nnet, nl = len(nets), len(nets[0])
+    nrb = (Bn + 31) // 32
+    recs = (_lib.LstmFusedRec * (nnet * nl))()
+    out, hold = [], []
+    for q in range(nnet):
+        out.append([])
+        for l in range(nl):
+            wih, whh, b = nets[q][l]
+            o = dict(gates=torch.empty(T, Bn, 4 * H, device=d) if keep else None, cseq=torch.empty(T, Bn, H, device=d) if keep else None,
+                     hseq=torch.empty(T, Bn, H, dtype=torch.bfloat16, device=d), hT=torch.empty(Bn, H, device=d))
+            xchg = torch.zeros(T * nrb * 32 * H, dtype=torch.bfloat16, device=d)
+            hold.append(xchg)
+            r = recs[q * nl + l]
+            r.Wih_blocked, r.Whh_blocked, r.bias_blocked = wih.data_ptr(), whh.data_ptr(), b.data_ptr()
+            r.x16 = x16[q].data_ptr() if l == 0 else None
+            r.gates = o["gates"].data_ptr() if keep else None
+            r.cseq = o["cseq"].data_ptr() if keep else None
+            r.hseq16, r.hT, r.xchg = o["hseq"].data_ptr(), o["hT"].data_ptr(), xchg.data_ptr()
+            out[q].append(o)
+    sync = sync_scratch(d, T, Bn, "fused", nnet * nl)
+    _lib.check(lib.hsad_lstm_forward_fused(nnet, nl, T, Bn, H, recs, sync.data_ptr(), None, _s(d)))
+    return out
+
+
 def lstm_layer_forward(gates, Whh_blocked16, h0, c0, persistent=True, hT_out=None, cseq_out=None, keep_gates=True):
     """gates fp32 [T,Bn,4H] (x-projection + biases, gate-blocked; overwritten with the activated gates).
     -> hseq bf16 [T,Bn,H], cseq fp32 [T,Bn,H], hT fp32 [Bn,H]  (hT_out / cseq_out: caller-provided destinations)"""

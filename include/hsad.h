@@ -486,6 +486,28 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
                                   void* next_sync_scratch, void* stream);
 int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
                                    void* next_sync_scratch, void* stream);
+/* FUSED persistent forward (round 3): nnet independent nets x nlayer stacked LSTM layers over the whole sequence in ONE launch.
+ * The input projection x_t W_ih^T is computed inside the recurrence (W_ih slice stationary in LDS, W_hh slice stationary in
+ * registers), stacked layers run one step apart and hand h_t tiles to each other through the L2 of their shared XCD: replaces
+ * the stand-alone projection GEMM + hsad_lstm_forward_chunk_multi stages of one nn.LSTM forward (pyhanabi/r2d2.py:99-105).
+ * recs[net * nlayer + layer]; x16 == NULL (layer > 0 only): the input is the record before it.  Weights gate-blocked
+ * (hsad_prepare_weight with the 32-unit permutation), bias = b_ih + b_hh in the same order; initial state zero.  Outputs per
+ * record: activated gates fp32 [T,Bn,4H] / cseq fp32 [T,Bn,H] (what BPTT reads; NULL = not kept), hseq16 bf16 [T,Bn,H], hT.
+ * xchg: bf16 scratch [T * 32*ceil(Bn/32) * H].  Needs nnet * ceil(Bn/32) * nlayer * (H/32) co-resident workgroups, H in {256, 512}.
+ * sync_scratch: uint32 [nnet*nlayer*(T+2)*ceil(Bn/32) + 4], ping-pong convention of hsad_lstm_forward_chunk_multi. */
+typedef struct hsad_lstm_fused_rec {
+  const void* Wih_blocked;
+  const void* Whh_blocked;
+  const float* bias_blocked;
+  const void* x16;
+  float* gates;
+  float* cseq;
+  void* hseq16;
+  float* hT;
+  void* xchg;
+} hsad_lstm_fused_rec;
+int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hsad_lstm_fused_rec* recs, void* sync_scratch,
+                            void* next_sync_scratch, void* stream);
 /* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
  * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
