@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <type_traits>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -50,6 +51,7 @@ typedef unsigned short bf16_t;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
 __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
   uint32_t u = __float_as_uint(f);
@@ -1406,28 +1408,38 @@ struct LstmFusedArgs {
   const bf16_t* x;          // [T,Bn,H] row-major input, or NULL: the input is `xin`
   const bf16_t* xin;        // hand-off tiles of the producing recurrence of this launch [T][nrb][KB][32][32]
   unsigned* xin_counters;   // its step counters [T][nrb]
-  float* gates;             // [T,Bn,4H] activated gates, or NULL (not kept)
-  float* cseq;              // [T,Bn,H], or NULL
-  bf16_t* hseq16;           // [T,Bn,H] row-major copy, or NULL
+  float* gates;             // [T,Bn,4H] activated gates, or NULL (then cseq is not kept either: a net without BPTT)
+  float* cseq;              // [T,Bn,H]
+  bf16_t* hseq16;           // [T,Bn,H] row-major copy (required)
   float* hT;                // optional [Bn,H]
   bf16_t* xchg;             // [T][nrb][KB][32][32] (required)
   unsigned* counters;       // [T][nrb], zeroed before launch
   unsigned* timeout;
-  int T, Bn;
+  int T, Bn;                // Bn: a multiple of 32 (the caller pads)
+  unsigned xchg_bytes;      // size of xchg / xin (buffer-resource bound)
+  int dbg;                  // phase timers on (hsad_lstm_debug_enable)
 };
 
-template <int KB>  // KB = H / 32
+// 16-byte L1-bypassing load of a hand-off tile fragment.  sc1 = the agent-scope load of the gfx942/gfx950 memory model (what
+// __hip_atomic_load(agent) emits for 8 bytes), as a raw buffer load so that the compiler tracks it (exact vmcnt waits,
+// fragments may live across the loop edge) -- the inline-asm loads of lstm_seq_fwd_kernel are invisible to it.
+__device__ __forceinline__ u32x4 tile_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */);
+}
+
+template <int KB, bool STACKED, bool KEEP>  // KB = H / 32; STACKED: input = tiles of the layer below; KEEP: gates / cseq are stored
 __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, const int rb, const int nb, const int nrb, const int nunit,
                                                     u64_t* group_word, const int nmember, const int force_cross_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int H = KB * 32;
-  constexpr int WS = H + 8;
-  constexpr int QK = KB / 4;
-  constexpr int NKL = KB >= 16 ? 2 : 0;        // trailing k blocks of the W_hh slice kept in LDS instead of registers (register budget)
+  constexpr int NKL = KB >= 16 ? 3 : 0;        // trailing k blocks of the W_hh slice kept in LDS instead of registers (register budget)
   constexpr int KR = KB - NKL;                 // k blocks of W_hh in registers
-  constexpr int WS2 = NKL * 32 + 8;
-  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);                 // [128][WS]  W_ih slice
-  bf16_t* sW2 = sW + 128 * WS;                                       // [128][WS2] last NKL k blocks of the W_hh slice
+  constexpr int WS2 = NKL * 32 + 16;           // 32-byte row pad: conflict-free for ds_read_b128's lane groups
+  // W_ih slice [128][H], rows UNPADDED, 16-byte chunk c of row r stored at chunk c ^ (r & 15) of its 256-byte window: the 16 lanes
+  // ds_read_b128 serves per LDS cycle ({0-3,12-15,20-27}, ... = rows x k-quarter pairs of a fragment read) then hit 16 distinct
+  // bank quads (the H + 8 padding of lstm_seq_fwd_kernel is 2-way conflicted for those groups: 8 instead of 4 cycles per read)
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* sW2 = sW + 128 * H;                                        // [128][WS2] last NKL k blocks of the W_hh slice
   bf16_t* sH = sW2 + (NKL ? 128 * WS2 : 0);                          // [32][40]   h tile staging
   int* s_okp = reinterpret_cast<int*>(sH + 32 * 40);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1435,7 +1447,7 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
   const int kofs = (lane >> 4) * 8;
   for (int c = tid; c < 128 * (H / 8); c += 256) {
     const int r = c / (H / 8), q = c - r * (H / 8);
-    *reinterpret_cast<uint4*>(sW + r * WS + q * 8) = *reinterpret_cast<const uint4*>(a.Wih + (size_t)(nb * 128 + r) * H + q * 8);
+    *reinterpret_cast<uint4*>(sW + r * H + (q ^ (r & 15)) * 8) = *reinterpret_cast<const uint4*>(a.Wih + (size_t)(nb * 128 + r) * H + q * 8);
   }
   if (NKL)
     for (int c = tid; c < 128 * NKL * 4; c += 256) {
@@ -1443,7 +1455,6 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
       *reinterpret_cast<uint4*>(sW2 + r * WS2 + q * 8) = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + KR * 32 + q * 8);
     }
   union Frag {
-    u64_t q[2];
     u32x4 w;
     bf16x8 v;
   };
@@ -1457,7 +1468,7 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
   const int u = nb * 32 + wu * 16 + (lane & 15);
   const int ucol = nb * 128 + wu * 16 + (lane & 15);
   const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
-  const int row_l = min(rb * 32 + wr * 16 + (lane & 15), a.Bn - 1);
+  const int row_l = rb * 32 + wr * 16 + (lane & 15);
   float b4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) b4[j] = a.bias[ucol + j * 32];
@@ -1466,141 +1477,208 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
   __syncthreads();
   if (s_okp[1] < 0) return;
   const int fast = force_cross_xcd ? 0 : s_okp[1];
-  const bool has_xc = a.x == nullptr;
-  const bool dbg_on = (rb == 0 && nb == 0 && tid == 0);
-  const int dbg_base = has_xc ? 8 : 0;     // phase timers: slots 0-6 first layer, 8-14 stacked layer (summed over nets)
+  const bool dbg_on = (a.dbg && rb == 0 && nb == 0 && tid == 0);
+  const int dbg_base = STACKED ? 8 : 0;     // phase timers: slots 0-6 first layer, 8-14 stacked layer (summed over nets)
   u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
-  // bounded spin of thread 0 on a step counter, verdict broadcast through LDS slot `slot`
-  auto wait_ctr = [&](unsigned* ctr, int slot) -> bool {
+  // bounded spin of thread 0 on a step counter, verdict broadcast through LDS slot `slot`.  Co-located groups poll with a SCALAR
+  // load (glc: misses the scalar cache, served by the XCD's L2 where the signal's atomic executes): a vector load would return
+  // in order behind the wave's outstanding tile loads.  probe (optional): a second counter that is only LOOKED at once the
+  // first is satisfied -- "has the layer below already published the step after next?" -> s_okp[2].
+  auto ctr_load = [&](unsigned* ctr) -> unsigned {
+    unsigned v;
+    if (fast) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+    else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  auto wait_ctr = [&](unsigned* ctr, int slot, unsigned* probe) -> bool {
     if (tid == 0) {
       unsigned spins = 0;
       int ok = 1;
-      while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nunit) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > 4000000u) {
+      while (ctr_load(ctr) < (unsigned)nunit) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 8000000u) {
           __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ok = 0;
           break;
         }
       }
       s_okp[slot] = ok;
+      s_okp[2] = probe ? (ctr_load(probe) >= (unsigned)nunit) : 0;
     }
     __syncthreads();
     return s_okp[slot] != 0;
   };
-  // this lane's fragment base inside the hand-off tiles of (step, row block): element (row wr*16 + (lane&15), k = kofs) of k block 0
-  auto tile_ptr = [&](const bf16_t* base, int step) {
-    return base + ((size_t)step * nrb + rb) * (size_t)KB * 1024 + (wr * 16 + (lane & 15)) * 32 + kofs;
-  };
-  Frag fx[KB];
-  bool x_pref = false;
-  if (!has_xc) {   // layer input from a row-major sequence: plain (compiler-tracked) loads, a step ahead
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) fx[kb].w = *reinterpret_cast<const u32x4*>(a.x + (size_t)row_l * H + kb * 32 + kofs);
-    x_pref = true;
-  }
+  // all sequence traffic goes through buffer resources: per-lane offsets are computed ONCE, the step enters as a scalar offset
+  // (no 64-bit address arithmetic per access), and the compiler tracks every load (exact vmcnt, fragments live across the loop edge)
+  const unsigned seq_bytes = (unsigned)((size_t)a.T * a.Bn * H * 2);
+  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (int)a.xchg_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(STACKED ? a.xin : a.x), 0, (int)(STACKED ? a.xchg_bytes : seq_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq16, 0, (int)seq_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(KEEP ? a.gates : a.hT), 0, KEEP ? (int)(seq_bytes * 8u) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(KEEP ? a.cseq : a.hT), 0, KEEP ? (int)(seq_bytes * 2u) : 0, 0x00020000);
+  // hand-off tiles: byte offset of this lane's fragment of k block 0 inside the tile of row block rb (k block kb: + kb * 2048);
+  // one step = nrb * KB * 2048 bytes
+  const unsigned tile_lane = (unsigned)((rb * KB * 1024 + (wr * 16 + (lane & 15)) * 32 + kofs) * 2);
+  const unsigned tile_step = (unsigned)(nrb * KB * 2048);
+  const unsigned xrow_lane = (unsigned)((row_l * H + kofs) * 2);                       // row-major input: fragment of k block 0
+  const unsigned seq_step = (unsigned)(a.Bn * H * 2);                                  // one step of a [T,Bn,H] bf16 sequence
+  const unsigned hs_lane = (unsigned)(((rb * 32 + (tid >> 3)) * H + nb * 32 + (tid & 7) * 4) * 2);
+  // fragment-major saved activations: block (rb, nb) of a step = 4096 floats of gates / 1024 floats of c
+  const unsigned g_lane = (unsigned)((((rb * KB + nb) * 4 + wave) * 4 * 64 + lane) * 16);
+  const unsigned c_lane = (unsigned)((((rb * KB + nb) * 4 + wave) * 64 + lane) * 16);
 
-  for (int t = 0; t < a.T; ++t) {
-    f32x4 accx[4], acch[4];
+  Frag fx[KB];                 // X tile of the NEXT step to run, (re)loaded fragment by fragment as the current one is consumed
+  float keep_g[4][4];          // activated gates / h row of the step just finished: stored inside the NEXT step's tile-load latency
+  u64_t keep_hrow = 0;
+  bool x_early = !STACKED;     // fx holds (or will hold) the tile of the step about to run
+  auto issue_x = [&](const int tn, const int k0, const int k1) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb < k0 || kb >= k1) continue;
+      if (STACKED) fx[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tile_lane + kb * 2048, (unsigned)tn * tile_step, 16 /* sc1 */);
+      else fx[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xrow_lane + kb * 64, (unsigned)tn * seq_step, 0);
+    }
+  };
+  if (!STACKED) issue_x(0, 0, KB);
+  // LDS fragment addresses of the swizzled W_ih slice: k block kb = 4 * (kb >> 2) + q lies at lane-dependent chunk
+  // ((4 q + g) ^ (r & 15)) of window kb >> 2
+  const bf16_t* wl[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wl[q] = sW + (wu * 16 + (lane & 15)) * H + (((q * 4 + (lane >> 4)) ^ (lane & 15)) * 8);
+
+  auto mfma_x = [&](f32x4 (&accx)[4], const int k0, const int k1) {   // k blocks [k0, k1): B from the LDS-resident W_ih slice,
+    bf16x8 fb[4], fn[4];                                                // fragments of k block kb + 1 in flight during kb's MFMAs
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fn[j] = *reinterpret_cast<const bf16x8*>(wl[k0 & 3] + j * 32 * H + (k0 >> 2) * 128);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      if (kb < k0 || kb >= k1) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = fn[j];
+      if (kb + 1 < k1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fn[j] = *reinterpret_cast<const bf16x8*>(wl[(kb + 1) & 3] + j * 32 * H + ((kb + 1) >> 2) * 128);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb].v, fb[j], accx[j], 0, 0, 0);
+    }
+  };
+  // pin the software pipeline of an mfma_x half: 4 LDS reads ahead, then one MFMA per LDS read (left alone the scheduler
+  // serialises read -> wait -> MFMA to save the four fragment registers, and every MFMA pays the LDS latency); `vmem` memory
+  // instructions issued in the same region are spread over the MFMAs
+  auto pin_x = [&](const int vmem) {
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int i = 0; i < 4 * (KB / 2) - 4; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (vmem && (i & 3) == 3 && i / 4 < vmem) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  };
+  auto flush_state = [&](const int tp) {      // stores of step tp: row-major h, and (KEEP) FRAGMENT-MAJOR gates / c:
+    union {                                   // gates [T][nrb][H/32][wave][r][lane][i f g o], c [T][nrb][H/32][wave][lane][r] -- read back
+      u64_t q;                                // only by the BPTT recurrence, which uses the same lane mapping; every store is a
+      u32x2 w;                                // contiguous 1 KB per wave
+    } hv;
+    hv.q = keep_hrow;
+    __builtin_amdgcn_raw_buffer_store_b64(hv.w, rs_hs, hs_lane, (unsigned)tp * seq_step, 0);
+    if (KEEP) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const u32x4 gv = {__float_as_uint(keep_g[r][0]), __float_as_uint(keep_g[r][1]), __float_as_uint(keep_g[r][2]), __float_as_uint(keep_g[r][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(gv, rs_g, g_lane + (unsigned)(r * 1024), (unsigned)tp * seq_step * 8u, 0);
+      }
+      const u32x4 cv = {__float_as_uint(cst[0]), __float_as_uint(cst[1]), __float_as_uint(cst[2]), __float_as_uint(cst[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(cv, rs_c, c_lane, (unsigned)tp * seq_step * 2u, 0);
+    }
+  };
+
+  auto step = [&](auto first_tag, const int t) -> bool {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    // a stacked layer adds its two partial sums at the end (the order in which its tiles arrive varies); a first layer always
+    // runs X then H and keeps ONE accumulator set
+    f32x4 accx[4], acch_[STACKED ? 4 : 1];
+    f32x4 (&acch)[4] = *reinterpret_cast<f32x4 (*)[4]>(STACKED ? acch_ : accx);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       accx[j] = f32x4{b4[j], b4[j], b4[j], b4[j]};
-      acch[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (STACKED) acch[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    auto mfma_x = [&](int k0, int k1) {      // B from the LDS-resident W_ih slice
+    Frag fh[KB];
+    const unsigned hso = (unsigned)(t - 1) * tile_step;
+    const bool more = t + 1 < a.T;
+    bool x_next = !STACKED && more;     // may the tile of step t + 1 be fetched during this step?
+    if (!FIRST) {
+      if (!wait_ctr(a.counters + (size_t)(t - 1) * nrb + rb, 0, (STACKED && more) ? a.xin_counters + (size_t)(t + 1) * nrb + rb : nullptr))
+        return false;
+      if (STACKED) x_next = s_okp[2] != 0;
+      LSTM_STAMP(dbg_base + 0)   // wait for h_{t-1}
+      // the h tile leaves in two halves: the second reuses registers that the first half of the X MFMAs frees (its data is not
+      // needed before the first half has been multiplied, and the tile takes ~0.4 us to stream in anyway)
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        if (kb < k0 || kb >= k1) continue;
+      for (int kb = 0; kb < KB / 2; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16 /* sc1 */);
+      __builtin_amdgcn_sched_barrier(0);   // the loads leave NOW; the scheduler would spread them over the X MFMAs to save registers
+    }
+    // Inside the latency of the h tile loads: the X half of this step, and -- memory instructions ride along with the MFMAs --
+    // the X tile of the NEXT step into the fragments just consumed, and the state of the PREVIOUS step.
+    if (x_early) {
+      mfma_x(accx, 0, KB / 2);
+      pin_x(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!FIRST) {
+#pragma unroll
+        for (int kb = KB / 2; kb < KB; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      mfma_x(accx, KB / 2, KB);
+      if (x_next) issue_x(t + 1, 0, KB / 2);
+      pin_x(KB / 2);
+      __builtin_amdgcn_sched_barrier(0);
+      if (x_next) issue_x(t + 1, KB / 2, KB);
+    } else if (!FIRST) {
+#pragma unroll
+      for (int kb = KB / 2; kb < KB; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16);
+    }
+    if (!FIRST) flush_state(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    LSTM_STAMP(dbg_base + 1)     // X tile x W_ih + next X tile / previous state issued
+    if (!FIRST) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW + (j * 32 + wu * 16 + (lane & 15)) * WS + kb * 32 + kofs);
-          accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb].v, fb, accx[j], 0, 0, 0);
-        }
-      }
-    };
-    if (x_pref) mfma_x(0, KB);
-    LSTM_STAMP(dbg_base + 0)   // prefetched X tile x W_ih
-    if (t > 0) {
-      if (!wait_ctr(a.counters + (size_t)(t - 1) * nrb + rb, 0)) return;
-      LSTM_STAMP(dbg_base + 1)   // wait for h_{t-1}
-      Frag fh[KB];
-      const bf16_t* hp = tile_ptr(a.xchg, t - 1);
-      auto mfma_h = [&](int k0, int k1) {    // B from the register-resident W_hh slice
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          if (kb < k0 || kb >= k1) continue;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (kb < KR) {
-              acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, wreg[j][kb < KR ? kb : 0].v, acch[j], 0, 0, 0);
-            } else {
-              const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW2 + (j * 32 + wu * 16 + (lane & 15)) * WS2 + (kb - KR) * 32 + kofs);
-              acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, fb, acch[j], 0, 0, 0);
-            }
+          if (kb < KR) {
+            acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, wreg[j][kb < KR ? kb : 0].v, acch[j], 0, 0, 0);
+          } else {
+            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW2 + (j * 32 + wu * 16 + (lane & 15)) * WS2 + (kb - KR) * 32 + kofs);
+            acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, fb, acch[j], 0, 0, 0);
           }
         }
-      };
-      if (fast) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fh[kb].w) : "v"(hp + (size_t)kb * 1024));
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QK) : "memory");
-          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QK) : "memory");
-          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QK) : "memory");
-          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb)
-            if (kb >= qd * QK && kb < (qd + 1) * QK) asm volatile("" : "+v"(fh[kb].w));
-          mfma_h(qd * QK, (qd + 1) * QK);
-        }
-      } else {
-        const u64_t* hq = reinterpret_cast<const u64_t*>(hp);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          fh[kb].q[0] = __hip_atomic_load(hq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          fh[kb].q[1] = __hip_atomic_load(hq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        mfma_h(0, KB);
-      }
-      LSTM_STAMP(dbg_base + 2)   // h tile loads + MFMAs
+      LSTM_STAMP(dbg_base + 3)   // h tile x W_hh (progressive: the compiler waits per fragment)
     }
-    if (!x_pref) {   // stacked layer whose input tile was not there yet at the end of the previous step
-      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 3)) return;
-      const bf16_t* xp = tile_ptr(a.xin, t);
-      if (fast) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fx[kb].w) : "v"(xp + (size_t)kb * 1024));
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * QK) : "memory");
-          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QK) : "memory");
-          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(QK) : "memory");
-          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb)
-            if (kb >= qd * QK && kb < (qd + 1) * QK) asm volatile("" : "+v"(fx[kb].w));
-          mfma_x(qd * QK, (qd + 1) * QK);
-        }
-      } else {
-        const u64_t* xq = reinterpret_cast<const u64_t*>(xp);
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          fx[kb].q[0] = __hip_atomic_load(xq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          fx[kb].q[1] = __hip_atomic_load(xq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        mfma_x(0, KB);
-      }
-      LSTM_STAMP(dbg_base + 3)   // late X tile: wait + loads + MFMAs
+    if (STACKED && !x_early) {   // the layer below had not published x_t when the previous step looked
+      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 3, more ? a.xin_counters + (size_t)(t + 1) * nrb + rb : nullptr)) return false;
+      x_next = s_okp[2] != 0;
+      issue_x(t, 0, KB);
+      mfma_x(accx, 0, KB / 2);
+      pin_x(0);
+      mfma_x(accx, KB / 2, KB);
+      pin_x(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (x_next) issue_x(t + 1, 0, KB);
+      LSTM_STAMP(dbg_base + 4)   // late X tile: wait + loads + MFMAs
     }
-    float keep_g[4][4], keep_h[4];
+    x_early = x_next;
+    float hlast[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float gi = sigmoidf_(accx[0][r] + acch[0][r]);
-      const float gf = sigmoidf_(accx[1][r] + acch[1][r]);
-      const float gg = tanhf_(accx[2][r] + acch[2][r]);
-      const float go = sigmoidf_(accx[3][r] + acch[3][r]);
+      const float gi = sigmoidf_(STACKED ? accx[0][r] + acch[0][r] : accx[0][r]);
+      const float gf = sigmoidf_(STACKED ? accx[1][r] + acch[1][r] : accx[1][r]);
+      const float gg = tanhf_(STACKED ? accx[2][r] + acch[2][r] : accx[2][r]);
+      const float go = sigmoidf_(STACKED ? accx[3][r] + acch[3][r] : accx[3][r]);
       const float c = gf * cst[r] + gi * gg;
       const float h = go * tanhf_(c);
       cst[r] = c;
@@ -1608,69 +1686,28 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
       keep_g[r][1] = gf;
       keep_g[r][2] = gg;
       keep_g[r][3] = go;
-      keep_h[r] = h;
+      hlast[r] = h;
       sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
     }
     __syncthreads();
-    LSTM_STAMP(dbg_base + 4)   // cell update + h tile to LDS
-    {  // publish: linear 2 KB block, thread tid -> bytes [8 tid, 8 tid + 8)
-      const int r = tid >> 3, q = tid & 7;
-      const u64_t v = *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
-      xchg_store8(reinterpret_cast<u64_t*>(a.xchg + (((size_t)t * nrb + rb) * KB + nb) * 1024 + r * 32 + q * 4), v, fast);
-    }
+    LSTM_STAMP(dbg_base + 5)     // cell update + h tile to LDS
+    keep_hrow = *reinterpret_cast<const u64_t*>(sH + (tid >> 3) * 40 + (tid & 7) * 4);
+    // publish: linear 2 KB block, thread tid -> bytes [8 tid, 8 tid + 8)
+    xchg_store8(reinterpret_cast<u64_t*>(a.xchg + (((size_t)t * nrb + rb) * KB + nb) * 1024) + tid, keep_hrow, fast);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {   // is the NEXT input tile of a stacked layer already published?  (decides early / late X for step t + 1)
-      int early = 0;
-      if (has_xc && t + 1 < a.T)
-        early = __hip_atomic_load(a.xin_counters + (size_t)(t + 1) * nrb + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nunit;
-      s_okp[2] = early;
-    }
     __syncthreads();
     if (tid == 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
-    LSTM_STAMP(dbg_base + 5)   // publish: store, drain, signal
-    {
-      const int r = tid >> 3, q = tid & 7;
-      const int row = rb * 32 + r;
-      if (a.hseq16 && row < a.Bn)
-        *reinterpret_cast<u64_t*>(a.hseq16 + (size_t)t * a.Bn * H + (size_t)row * H + nb * 32 + q * 4) =
-            *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4);
-    }
+    LSTM_STAMP(dbg_base + 6)     // publish: store, drain, signal
+    if (a.hT && !more) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + r;
-      if (row < a.Bn) {
-        if (a.gates) {
-          float* gp = a.gates + ((size_t)t * a.Bn + row) * 4 * H + ucol;
-          gp[0] = keep_g[r][0];
-          gp[32] = keep_g[r][1];
-          gp[64] = keep_g[r][2];
-          gp[96] = keep_g[r][3];
-        }
-        if (a.cseq) a.cseq[((size_t)t * a.Bn + row) * H + u] = cst[r];
-        if (a.hT && t == a.T - 1) a.hT[(size_t)row * H + u] = keep_h[r];
-      }
+      for (int r = 0; r < 4; ++r) a.hT[(size_t)(rbase + r) * H + u] = hlast[r];
     }
-    // next step's X tile, issued now so that its MFMAs run inside the exchange wait (compiler-tracked loads only: they live
-    // across the loop edge)
-    x_pref = false;
-    if (t + 1 < a.T) {
-      if (!has_xc) {
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
-          fx[kb].w = *reinterpret_cast<const u32x4*>(a.x + ((size_t)(t + 1) * a.Bn + row_l) * H + kb * 32 + kofs);
-        x_pref = true;
-      } else if (s_okp[2]) {
-        const u64_t* xq = reinterpret_cast<const u64_t*>(tile_ptr(a.xin, t + 1));
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          fx[kb].q[0] = __hip_atomic_load(xq + (size_t)kb * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          fx[kb].q[1] = __hip_atomic_load(xq + (size_t)kb * 256 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        x_pref = true;
-      }
-    }
-    LSTM_STAMP(dbg_base + 6)   // state stores + next X tile issued
-  }
+    return true;
+  };
+  if (!step(std::true_type{}, 0)) return;
+  for (int t = 1; t < a.T; ++t)
+    if (!step(std::false_type{}, t)) return;
+  flush_state(a.T - 1);
 }
 
 // records are ordered [net][layer]; layer l > 0 of a net takes its input from record - 1 when its x is NULL
@@ -1696,7 +1733,14 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(LstmFusedArgsN m) {
   if (SG >= m.nnet * m.nrb) return;
   const int layer = within / m.nunit, nb = within - layer * m.nunit;
   const int net = SG / m.nrb, rb = SG - net * m.nrb;
-  lstm_fused_fwd_body<KB>(m.r[net * m.nl + layer], rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+  const LstmFusedArgs& a = m.r[net * m.nl + layer];
+  if (a.x) {
+    if (a.gates) lstm_fused_fwd_body<KB, false, true>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+    else lstm_fused_fwd_body<KB, false, false>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+  } else {
+    if (a.gates) lstm_fused_fwd_body<KB, true, true>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+    else lstm_fused_fwd_body<KB, true, false>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+  }
 }
 
 
@@ -2543,6 +2587,7 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ x, c
 // [nrec * T * nrb step counters] [sticky timeout word] -- everything before the timeout word is zeroed per launch
 static inline size_t seq_sync_words(int nrec, int T, int nrb) { return (size_t)nrec * nrb * (T + 2); }
 static int g_force_cross_xcd = 0;   // hsad_lstm_set_exchange_mode
+static int g_lstm_dbg_enable = 0;   // hsad_lstm_debug_enable (fused kernels: the phase stamps cost ~0.1 us each)
 
 // CUs of the current device: the persistent recurrences spin on sibling workgroups, so a launch must fit the chip with one
 // workgroup per CU (their LDS footprint allows no second one)
@@ -3022,6 +3067,11 @@ int hsad_lstm_set_exchange_mode(int force_cross_xcd) {
   return HSAD_OK;
 }
 
+int hsad_lstm_debug_enable(int enable) {
+  g_lstm_dbg_enable = enable != 0;
+  return HSAD_OK;
+}
+
 int hsad_lstm_debug_timing(uint64_t* out16, int reset) {
   if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lstm_dbg), sizeof(uint64_t) * 16));
   if (reset) {
@@ -3327,7 +3377,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
                             void* next_sync_scratch, void* stream) {
   const int nrec = nnet * nlayer;
   if (nnet < 1 || nlayer < 1 || nrec > 6 || !recs || !sync_scratch || T < 1) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: bad arguments");
-  if (!((H == 256 || H == 512) && Bn >= 1)) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: needs H in {256,512}");
+  if (!((H == 256 || H == 512) && Bn >= 32 && Bn % 32 == 0 && (size_t)T * Bn * H * 16 < (1ull << 32)))
+    return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: needs H in {256,512} and a row count that is a multiple of 32 (pad the batch)");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = (Bn + 31) / 32, nunit = H / 32, nsg = nnet * nrb;
   // a super group (all fused layers of one (net, row block)) lives on ONE XCD, one workgroup per CU
@@ -3343,8 +3394,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fused_rec& r = recs[i];
     const int layer = i % nlayer;
-    if (!r.Wih_blocked || !r.Whh_blocked || !r.bias_blocked || !r.xchg || (!r.x16 && layer == 0))
-      return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: null pointer in record %d", i);
+    if (!r.Wih_blocked || !r.Whh_blocked || !r.bias_blocked || !r.xchg || !r.hseq16 || (!r.x16 && layer == 0) || (!r.gates != !r.cseq))
+      return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: null pointer in record %d (gates and cseq go together)", i);
     LstmFusedArgs& q = m.r[i];
     q.Wih = (const bf16_t*)r.Wih_blocked;
     q.Whh = (const bf16_t*)r.Whh_blocked;
@@ -3361,6 +3412,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     q.timeout = counters + (size_t)nrec * T * nrb;
     q.T = T;
     q.Bn = Bn;
+    q.xchg_bytes = (unsigned)((size_t)T * nrb * 32 * H * 2);
+    q.dbg = g_lstm_dbg_enable;
   }
   m.nnet = nnet;
   m.nl = nlayer;
@@ -3370,7 +3423,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
-  const size_t lds = (size_t)(128 * (H + 8) + (H >= 512 ? 128 * (2 * 32 + 8) : 0) + 32 * 40) * sizeof(bf16_t) + 16;
+  const size_t lds = (size_t)(128 * H + (H >= 512 ? 128 * (3 * 32 + 16) : 0) + 32 * 40) * sizeof(bf16_t) + 16;
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_fused_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, m);

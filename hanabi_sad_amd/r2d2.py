@@ -138,34 +138,58 @@ def check_sync():
         raise _lib.HsadError("persistent LSTM kernel timed out waiting for a sibling workgroup: %s" % (bad,))
 
 
-def lstm_forward_fused(x16, nets, keep=True):
-    """hsad_lstm_forward_fused: x16 = one bf16 [T,Bn,H] input sequence per net; nets = per net a list (one entry per stacked
-    layer) of (Wih_blocked bf16 [4H,H], Whh_blocked bf16 [4H,H], bias_blocked fp32 [4H]).  All nets / layers in ONE persistent
-    launch.  -> per net, per layer: dict(gates, cseq, hseq, hT) (gates / cseq None when keep is False)"""
+def unpack_saved_gates(gf, T, Bn, H):
+    """fragment-major activated gates of the fused recurrences (include/hsad.h, hsad_lstm_forward_fused) -> [T, Bn, 4H] gate-blocked"""
+    v = gf.view(T, Bn // 32, H // 32, 2, 2, 4, 4, 16, 4)          # t rb nb wr wu r lq ll j
+    return v.permute(0, 1, 3, 6, 5, 2, 8, 4, 7).reshape(T, Bn, 4 * H)   # t | rb wr lq r | nb j wu ll
+
+
+def unpack_saved_c(cf, T, Bn, H):
+    """fragment-major cell states -> [T, Bn, H]"""
+    v = cf.view(T, Bn // 32, H // 32, 2, 2, 4, 16, 4)             # t rb nb wr wu lq ll r
+    return v.permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(T, Bn, H)          # t | rb wr lq r | nb wu ll
+
+
+def lstm_forward_fused(x16, nets, keep=True, plan=None, unpack=True):
+    """hsad_lstm_forward_fused: x16 = one bf16 [T,Bn,H] input sequence per net (Bn a multiple of 32); nets = per net a list (one
+    entry per stacked layer) of (Wih_blocked bf16 [4H,H], Whh_blocked bf16 [4H,H], bias_blocked fp32 [4H]).  All nets / layers in
+    ONE persistent launch.  -> per net, per layer: dict(gates, cseq, hseq, hT) (gates / cseq None when keep is False).
+    plan: a dict that caches the output buffers and the record array between calls of the same shape.  unpack: return gates / cseq
+    row-major (the kernels store them fragment-major)."""
     lib = _lib.load_library()
     T, Bn, H = x16[0].shape
     d = x16[0].device
     nnet, nl = len(nets), len(nets[0])
     nrb = (Bn + 31) // 32
-    recs = (_lib.LstmFusedRec * (nnet * nl))()
-    out, hold = [], []
+    if plan is None or "recs" not in plan:
+        recs = (_lib.LstmFusedRec * (nnet * nl))()
+        out, hold = [], []
+        for q in range(nnet):
+            out.append([])
+            for l in range(nl):
+                o = dict(gates=torch.empty(T, Bn, 4 * H, device=d) if keep else None, cseq=torch.empty(T, Bn, H, device=d) if keep else None,
+                         hseq=torch.empty(T, Bn, H, dtype=torch.bfloat16, device=d), hT=torch.empty(Bn, H, device=d))
+                xchg = torch.zeros(T * nrb * 32 * H, dtype=torch.bfloat16, device=d)
+                hold.append(xchg)
+                r = recs[q * nl + l]
+                r.gates = o["gates"].data_ptr() if keep else None
+                r.cseq = o["cseq"].data_ptr() if keep else None
+                r.hseq16, r.hT, r.xchg = o["hseq"].data_ptr(), o["hT"].data_ptr(), xchg.data_ptr()
+                out[q].append(o)
+        if plan is not None:
+            plan.update(recs=recs, out=out, hold=hold)
+    else:
+        recs, out = plan["recs"], plan["out"]
     for q in range(nnet):
-        out.append([])
         for l in range(nl):
             wih, whh, b = nets[q][l]
-            o = dict(gates=torch.empty(T, Bn, 4 * H, device=d) if keep else None, cseq=torch.empty(T, Bn, H, device=d) if keep else None,
-                     hseq=torch.empty(T, Bn, H, dtype=torch.bfloat16, device=d), hT=torch.empty(Bn, H, device=d))
-            xchg = torch.zeros(T * nrb * 32 * H, dtype=torch.bfloat16, device=d)
-            hold.append(xchg)
             r = recs[q * nl + l]
             r.Wih_blocked, r.Whh_blocked, r.bias_blocked = wih.data_ptr(), whh.data_ptr(), b.data_ptr()
             r.x16 = x16[q].data_ptr() if l == 0 else None
-            r.gates = o["gates"].data_ptr() if keep else None
-            r.cseq = o["cseq"].data_ptr() if keep else None
-            r.hseq16, r.hT, r.xchg = o["hseq"].data_ptr(), o["hT"].data_ptr(), xchg.data_ptr()
-            out[q].append(o)
     sync = sync_scratch(d, T, Bn, "fused", nnet * nl)
     _lib.check(lib.hsad_lstm_forward_fused(nnet, nl, T, Bn, H, recs, sync.data_ptr(), None, _s(d)))
+    if keep and unpack:
+        return [[dict(o, gates=unpack_saved_gates(o["gates"], T, Bn, H), cseq=unpack_saved_c(o["cseq"], T, Bn, H)) for o in net] for net in out]
     return out
 
 

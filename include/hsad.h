@@ -358,6 +358,8 @@ int hsad_lstm_set_exchange_mode(int force_cross_xcd);
  * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
  * publish); out16 may be NULL; reset != 0 clears them */
 int hsad_lstm_debug_timing(uint64_t* out16, int reset);
+/* phase timers of the FUSED persistent kernels (off by default: a stamp costs ~0.1 us of the ~5 us step it measures) */
+int hsad_lstm_debug_enable(int enable);
 /* measurement hook for the fused cell kernel (hsad_lstm_cell_fused, i.e. every LSTM layer of an acting step): while enabled, each
  * launch is bracketed by HIP events on its own stream; _read returns the average duration and FLOP of the launches recorded since
  * the last read (synchronises) and clears the record.  bench.py's actor roofline. */
@@ -492,7 +494,10 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
  * the stand-alone projection GEMM + hsad_lstm_forward_chunk_multi stages of one nn.LSTM forward (pyhanabi/r2d2.py:99-105).
  * recs[net * nlayer + layer]; x16 == NULL (layer > 0 only): the input is the record before it.  Weights gate-blocked
  * (hsad_prepare_weight with the 32-unit permutation), bias = b_ih + b_hh in the same order; initial state zero.  Outputs per
- * record: activated gates fp32 [T,Bn,4H] / cseq fp32 [T,Bn,H] (what BPTT reads; NULL = not kept), hseq16 bf16 [T,Bn,H], hT.
+ * record: activated gates (T*Bn*4H floats) / cseq (T*Bn*H floats) in FRAGMENT-MAJOR order -- gates [T][Bn/32][H/32][wave 4][r 4][lane 64][i f g o],
+ * c [T][Bn/32][H/32][wave 4][lane 64][r 4], where (wave, lane, r) <-> row 32*rb + 16*(wave>>1) + 4*(lane>>4) + r, unit 32*nb + 16*(wave&1) + (lane&15):
+ * the per-lane order of the recurrence kernels, so every store (and every load of the BPTT recurrence) is a contiguous 1 KB per wave;
+ * (hanabi_sad_amd/r2d2.py unpack_saved_gates / unpack_saved_c restate the mapping for inspection).  NULL = not kept (a net without BPTT).  hseq16 bf16 [T,Bn,H] row-major, hT.
  * xchg: bf16 scratch [T * 32*ceil(Bn/32) * H].  Needs nnet * ceil(Bn/32) * nlayer * (H/32) co-resident workgroups, H in {256, 512}.
  * sync_scratch: uint32 [nnet*nlayer*(T+2)*ceil(Bn/32) + 4], ping-pong convention of hsad_lstm_forward_chunk_multi. */
 typedef struct hsad_lstm_fused_rec {

@@ -16,9 +16,11 @@ xs = [torch.randn(T, Bn, H, generator=g).to(DEV).to(torch.bfloat16) for _ in ran
 nets = [[((torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV)[perm].to(torch.bfloat16).contiguous(),
           (torch.randn(4 * H, H, generator=g) / H ** 0.5).to(DEV)[perm].to(torch.bfloat16).contiguous(),
           torch.zeros(4 * H, device=DEV)) for _ in range(nl)] for _ in range(nnet)]
-for keep in (True, False):
+for keep, dbg in ((True, 0), (True, 0), (True, 1), (False, 0)):
+    _lib.check(lib.hsad_lstm_debug_enable(dbg))
+    plan = {}
     for _ in range(3):
-        lstm_forward_fused(xs, nets, keep=keep)
+        lstm_forward_fused(xs, nets, keep=keep, plan=plan, unpack=False)
     torch.cuda.synchronize()
     buf = (C.c_uint64 * 16)()
     _lib.check(lib.hsad_lstm_debug_timing(buf, 1))
@@ -26,14 +28,16 @@ for keep in (True, False):
     n = 20
     e0.record()
     for _ in range(n):
-        lstm_forward_fused(xs, nets, keep=keep)
+        lstm_forward_fused(xs, nets, keep=keep, plan=plan, unpack=False)
     e1.record()
     torch.cuda.synchronize()
     check_sync()
     _lib.check(lib.hsad_lstm_debug_timing(buf, 1))
     ms = e0.elapsed_time(e1) / n
-    print("keep=%d nnet=%d nl=%d T=%d: %.1f us per launch (incl. allocation/memset), %.2f us per step" % (keep, nnet, nl, T, ms * 1e3, ms * 1e3 / (T + nl - 1)))
-    names = ["x-mfma", "wait h", "h load+mfma", "late x", "cell", "publish", "stores+x issue"]
+    print("dbg=%d " % dbg + "keep=%d nnet=%d nl=%d T=%d: %.1f us per launch (incl. allocation/memset), %.2f us per step" % (keep, nnet, nl, T, ms * 1e3, ms * 1e3 / (T + nl - 1)))
+    if not dbg:
+        continue
+    names = ["wait h", "x-mfma", "stores", "h-mfma", "late x", "cell", "publish"]
     for base, tag in ((0, "layer 0"), (8, "stacked")):
         v = [buf[base + i] / 100.0 / (n * nnet * T) for i in range(7)]
         print("  %s us/step: " % tag + "  ".join("%s %.2f" % (nm, x) for nm, x in zip(names, v)) + "  | sum %.2f" % sum(v))
