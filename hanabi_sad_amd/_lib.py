@@ -40,13 +40,14 @@ class LstmFwdRec(C.Structure):
 class LstmBwdRec(C.Structure):
     """hsad_lstm_bwd_rec (include/hsad.h)"""
     _fields_ = [("gates", C.c_void_p), ("cseq", C.c_void_p), ("c_before", C.c_void_p), ("WhhT_blocked", C.c_void_p),
-                ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p)]
+                ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p),
+                ("saved_frag_major", C.c_int)]
 
 
 class LstmFusedRec(C.Structure):
     """hsad_lstm_fused_rec (include/hsad.h)"""
     _fields_ = [("Wih_blocked", C.c_void_p), ("Whh_blocked", C.c_void_p), ("bias_blocked", C.c_void_p), ("x16", C.c_void_p),
-                ("gates", C.c_void_p), ("cseq", C.c_void_p), ("hseq16", C.c_void_p), ("hT", C.c_void_p), ("xchg", C.c_void_p)]
+                ("gates", C.c_void_p), ("cseq", C.c_void_p), ("hseq16", C.c_void_p), ("hT", C.c_void_p)]
 
 
 SIGNATURES = {
@@ -192,6 +193,7 @@ SIGNATURES = {
     "hsad_r2d2_learner_create": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.c_float, C.c_float, C.c_float, C.POINTER(_P)]),
     "hsad_r2d2_learner_destroy": (None, [_P]),
     "hsad_r2d2_learner_set_schedule": (C.c_int, [_P, C.c_int, C.c_int]),
+    "hsad_r2d2_learner_set_fused": (C.c_int, [_P, C.c_int]),
     "hsad_r2d2_learner_grad": (_P, [_P]),
     "hsad_r2d2_learner_timed_out": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),

@@ -189,6 +189,7 @@ class CompositeLearner:
         self.h, self.shape = None, None
         self.flat = self.online.flat
         self.chunks, self.wgrad_split = 4, 8
+        self.fused = True          # whole-sequence fused forward recurrences when the shape allows (hsad_r2d2_learner_set_fused)
         self.grad = {}
         if T is not None:
             self._ensure(T, rows)
@@ -202,12 +203,19 @@ class CompositeLearner:
         self.h = C.c_void_p()
         _lib.check(self.lib.hsad_r2d2_learner_create(self.online.h, self.target.h, int(T), int(rows), ms, gm, lr, eps, clip, C.byref(self.h)))
         _lib.check(self.lib.hsad_r2d2_learner_set_schedule(self.h, int(self.chunks), int(self.wgrad_split)))
+        _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
         self.shape = (T, rows)
         n = self.online.flat.numel()
         self.gflat = _view(self.lib.hsad_r2d2_learner_grad(self.h), n, self.device, self)
         for i, name in enumerate(param_names()):
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.online.h, i), self.lib.hsad_r2d2_net_param_size(self.online.h, i)
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
+
+    def set_fused(self, on):
+        """fused forward recurrences on / off (off = the chunk-pipelined schedule, the A/B reference of the fused kernels)"""
+        self.fused = bool(on)
+        if self.h is not None:
+            _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
 
     def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
         """batch["priv_s"] float32 [T,B,(P,)F] -- or batch["priv_s_bf16"] [T,B,P,in_dim_padded] bf16, what DeviceReplay.sample

@@ -504,6 +504,11 @@ struct hsad_r2d2_learner {
   double gamma;
   float lr, adam_eps, clip;
   int wgrad_split = 8, chunks = 4;
+  int fused_fwd = 1;          // whole-sequence fused forward recurrences (hsad_lstm_forward_fused) when the shape allows
+  bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
+  unsigned* fsync[2][2];      // ping-pong counter blocks of the fused launches: [nets per launch - 1][flip]
+  int fflip[2] = {0, 0};
+  size_t fsync_words[2];
   Buf arena, opt, sync_buf;
   float *gflat, *m, *v, *osc;
   hipStream_t side = nullptr;
@@ -538,6 +543,16 @@ namespace {
 bool can_pipeline(const hsad_r2d2_learner* L) {
   const int H = L->on->H;
   return (H == 256 || H == 512) && L->B <= 512 && L->B % 8 == 0 && L->M % 64 == 0;
+}
+// fused forward (one persistent launch over the whole sequence, both layers): nets per launch, 0 = not possible.  A (net, row
+// block)'s 2 x H/32 workgroups must share an XCD (one workgroup per CU)
+int fuse_nets(const hsad_r2d2_learner* L) {
+  const int H = L->on->H, nrb = (L->B + 31) / 32;
+  if (!L->fused_fwd || !can_pipeline(L) || L->B % 32 || (size_t)L->T * L->B * H * 16 >= (1ull << 32)) return 0;
+  const int per_xcd = L->n_cu / 8, per = 2 * (H / 32);
+  if (per * ((2 * nrb + 7) / 8) <= per_xcd) return 2;
+  if (per * ((nrb + 7) / 8) <= per_xcd) return 1;
+  return 0;
 }
 int pick_chunks(const hsad_r2d2_learner* L) {
   if (!can_pipeline(L)) return 1;
@@ -666,11 +681,16 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
       sw += 2 * L->sync_words[k][r];
     }
   const size_t s1 = nrb * ((size_t)T + 2) + 4;
-  if (L->sync_buf.need((sw + s1) * 4)) {
+  size_t fw = 0;
+  for (int k = 0; k < 2; ++k) {
+    L->fsync_words[k] = (size_t)(k + 1) * 2 * nrb * ((size_t)T + 2) + 4;
+    fw += 2 * L->fsync_words[k];
+  }
+  if (L->sync_buf.need((sw + s1 + fw) * 4)) {
     delete L;
     return HSAD_ERR_NOMEM;
   }
-  (void)hipMemset(L->sync_buf.p, 0, (sw + s1) * 4);
+  (void)hipMemset(L->sync_buf.p, 0, (sw + s1 + fw) * 4);
   unsigned* sp = L->sync_buf.as<unsigned>();
   for (int k = 0; k < 2; ++k)
     for (int r = 0; r < 4; ++r) {
@@ -681,6 +701,12 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
       L->flip[k][r] = 0;
     }
   L->sync1 = sp;
+  sp += s1;
+  for (int k = 0; k < 2; ++k)
+    for (int f = 0; f < 2; ++f) {
+      L->fsync[k][f] = sp;
+      sp += L->fsync_words[k];
+    }
   if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess) {
     delete L;
@@ -706,9 +732,22 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_s
     HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
     for (int k = 0; k < 2; ++k)
       for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
+    L->fflip[0] = L->fflip[1] = 0;
   }
   L->chunks = chunks;
   L->wgrad_split = wgrad_split;
+  return 0;
+}
+/* fused_fwd != 0 (default): the forward recurrences of a loss_fwd run as whole-sequence fused launches (projection inside the
+ * recurrence, layers one step apart) when the shape allows; 0: the chunk-pipelined schedule of hsad_r2d2_learner_set_schedule */
+int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
+  if (!L) return afail(HSAD_ERR_INVALID, "null learner");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
+  L->fflip[0] = L->fflip[1] = 0;
+  L->fused_fwd = fused_fwd != 0;
   return 0;
 }
 /* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
@@ -725,6 +764,12 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
         HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + (size_t)(r + 1) * nrb * (Tc + 2), 4, hipMemcpyDeviceToHost));
         *timed_out |= (int32_t)v;
       }
+  for (int k = 0; k < 2; ++k)
+    for (int f = 0; f < 2; ++f) {
+      unsigned v = 0;
+      HIP_TRY(hipMemcpy(&v, L->fsync[k][f] + L->fsync_words[k] - 4, 4, hipMemcpyDeviceToHost));
+      *timed_out |= (int32_t)v;
+    }
   return 0;
 }
 
@@ -755,9 +800,35 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   // the online / target pair of each forward GEMM is ONE launch (hsad_gemm_nt_bf16_pair): input layer, then layer-0 projection
   CK(hsad_gemm_nt_bf16_pair(L->a16_in, L->a16_in, Fp, nets[0]->W1, nets[1]->W1, Fp, M, H, Fp, nets[0]->w(P_B1), nets[1]->w(P_B1), nullptr,
                             nullptr, 0, L->x1[0], L->x1[1], H, 1, stream));
+  const int fnets = fuse_nets(L);
+  L->fwd_frag = fnets > 0;
+  if (fnets) {
+    // both LSTM layers of a net over the whole sequence as ONE persistent launch, the projections computed inside the
+    // recurrences (hsad_lstm_forward_fused); the target net keeps neither gates nor c (no BPTT through it)
+    hsad_lstm_fused_rec recs[4];
+    for (int q = 0; q < 2; ++q)
+      for (int l = 0; l < 2; ++l) {
+        hsad_lstm_fused_rec& r = recs[q * 2 + l];
+        r.Wih_blocked = nets[q]->Wih[l];
+        r.Whh_blocked = nets[q]->Whh[l];
+        r.bias_blocked = nets[q]->bg[l];
+        r.x16 = l == 0 ? L->x1[q] : nullptr;
+        r.gates = (q == 0 && want_grad) ? L->gates[q][l] : nullptr;
+        r.cseq = (q == 0 && want_grad) ? L->cseq[q][l] : nullptr;
+        r.hseq16 = L->hseq[q][l];
+        r.hT = L->hT[q][l];
+      }
+    for (int q0 = 0; q0 < 2; q0 += fnets) {
+      int& f = L->fflip[fnets - 1];
+      CK(hsad_lstm_forward_fused(fnets, 2, T, B, H, recs + q0 * 2, L->fsync[fnets - 1][f], L->fsync[fnets - 1][f ^ 1], stream));
+      f ^= 1;
+    }
+  } else {
   CK(hsad_gemm_nt_bf16_pair(L->x1[0], L->x1[1], H, nets[0]->Wih[0], nets[1]->Wih[0], H, M, H4, H, nets[0]->bg[0], nets[1]->bg[0],
                             L->gates[0][0], L->gates[1][0], H4, nullptr, nullptr, 0, 0, stream));
-  if (can_pipeline(L)) {
+  }
+  if (fnets) {
+  } else if (can_pipeline(L)) {
     // layers software-pipelined over time chunks: stage st runs layer 0 on chunk st and layer 1 on chunk st - 1, for both nets, as
     // ONE multi-recurrence persistent launch
     const int Tc = T / nch, nrb = nrb_of(B);
@@ -923,6 +994,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.dc_io = L->dc[l];
         r.has_next = c != nch - 1;
         r.xchg = L->xchg_b[l];
+        r.saved_frag_major = L->fwd_frag ? 1 : 0;
         return r;
       };
       if (st < nch) recs[nr++] = brec(1, nch - 1 - st);

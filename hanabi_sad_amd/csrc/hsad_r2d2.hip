@@ -1387,91 +1387,76 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgsN m) {
 //
 //   gates_t = [x_t | h_{t-1}] [W_ih | W_hh]^T + b           (x_t = the layer's input: a row-major sequence, or h_t of the layer below)
 //
-// Workgroup (rb, nb) of a recurrence owns 32 rows x 32 units exactly like lstm_seq_fwd_kernel, but BOTH of its weight slices are
-// stationary: the 128 x H slice of W_ih in LDS (133 KB), the 128 x H slice of W_hh as MFMA B fragments in REGISTERS (64 fragments
-// = 256 registers per lane at H = 512: one wave per SIMD owns the SIMD's whole 512-entry file, the compiler places them in
-// AGPRs and feeds v_mfma's B operand from there).  Per step a wave therefore issues 2 x 4 x KB MFMAs on two A tiles:
-//   * X tile (32 rows x H of the input): known early.  Layer 0 prefetches it with plain loads at the end of the previous step;
-//     a stacked layer reads the hand-off tiles the layer below published (same XCD, same L2) -- early (prefetched) when that
-//     layer is ahead, late (after its own H part) when it is the one being waited for.  Either way these MFMAs fill what used
-//     to be the exchange wait.
-//   * H tile (h_{t-1} of its own 16 unit-block workgroups): the critical path, unchanged protocol (counter per (step, row
-//     block), L2-local plain stores + sc1 loads for co-located groups, write-through + agent-scope atomics otherwise).
-// The two partial sums live in separate accumulators and are added once, so the result does not depend on which tile arrived
-// first.  The "super group" = the nl x (H/32) workgroups of all fused layers of one (net, row block) shares an XCD (verified by
-// the start-up handshake): layer l+1 consumes layer l's tiles through that L2 one step behind it.
+// Workgroup (rb, nb) of a recurrence owns 32 rows x 32 units like lstm_seq_fwd_kernel, but the work is split over its four
+// waves by UNITS: wave w owns units 8w..8w+7 (all four gates, all 32 rows).  Its slices of W_ih AND W_hh -- 32 gate rows x H
+// each -- are MFMA B fragments held in REGISTERS for the whole sequence (2 x 128 registers per lane at H = 512; one wave per
+// SIMD owns the SIMD's 512-entry file, the compiler places them in AGPRs and feeds v_mfma's B operand from there).  No weight
+// lives in LDS, so LDS is free for the ACTIVATION tiles: the 32 x H tile of h_{t-1} and a ring of three X tiles arrive by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, each tile fetched ONCE per CU instead of once per wave pair, 32 wave
+// instructions instead of 64), all waves read their A fragments from there (ds_read_b128, chunk-swizzled: conflict-free).
+// Per step:   poll h_{t-1} (scalar load)  ->  DMA h tile; DMA X tile t+2; store the state of step t-1  ->  X tile x W_ih (inside the
+// DMA latency)  ->  h tile landed, barrier  ->  h tile x W_hh  ->  cell update  ->  publish 64-byte row pieces of h_t  ->  signal.
+// A lane's accumulators hold two gates of a unit for two row halves; lanes n and n + 8 swap halves (DPP row_ror:8) so that each
+// finishes i, f, g, o of one (unit, row half).
+// The hand-off buffer IS the row-major bf16 h sequence [T, Bn, H] (a row block's 32 rows are one contiguous 32 x H tile): a
+// stacked layer reads the tiles the layer below published -- same XCD, same L2 -- two steps ahead when that layer leads, on
+// demand when it is the one being waited for.  The "super group" = the nl x (H/32) workgroups of all fused layers of one
+// (net, row block) shares an XCD (verified by the start-up handshake; otherwise the cross-XCD protocol: write-through stores,
+// device-scope atomics).
 // ---------------------------------------------------------------------------------------------------
 struct LstmFusedArgs {
-  const bf16_t* Wih;        // [4H,H] gate-blocked; LDS-resident slice
-  const bf16_t* Whh;        // [4H,H] gate-blocked; register-resident slice
+  const bf16_t* Wih;        // [4H,H] gate-blocked (row nb*128 + gate*32 + u)
+  const bf16_t* Whh;        // [4H,H] gate-blocked
   const float* bias;        // [4H] gate-blocked b_ih + b_hh
-  const bf16_t* x;          // [T,Bn,H] row-major input, or NULL: the input is `xin`
-  const bf16_t* xin;        // hand-off tiles of the producing recurrence of this launch [T][nrb][KB][32][32]
-  unsigned* xin_counters;   // its step counters [T][nrb]
-  float* gates;             // [T,Bn,4H] activated gates, or NULL (then cseq is not kept either: a net without BPTT)
-  float* cseq;              // [T,Bn,H]
-  bf16_t* hseq16;           // [T,Bn,H] row-major copy (required)
+  const bf16_t* x;          // [T,Bn,H] row-major input sequence (layer 0: any buffer; stacked: hseq16 of the layer below)
+  unsigned* xin_counters;   // stacked layer: step counters [T][nrb] of the layer below (NULL: x is complete before the launch)
+  float* gates;             // T*Bn*4H floats, fragment-major activated gates, or NULL (then cseq is not kept either: a net without BPTT)
+  float* cseq;              // T*Bn*H floats, fragment-major
+  bf16_t* hseq16;           // [T,Bn,H] row-major: output AND hand-off buffer (required)
   float* hT;                // optional [Bn,H]
-  bf16_t* xchg;             // [T][nrb][KB][32][32] (required)
   unsigned* counters;       // [T][nrb], zeroed before launch
   unsigned* timeout;
   int T, Bn;                // Bn: a multiple of 32 (the caller pads)
-  unsigned xchg_bytes;      // size of xchg / xin (buffer-resource bound)
   int dbg;                  // phase timers on (hsad_lstm_debug_enable)
 };
 
-// 16-byte L1-bypassing load of a hand-off tile fragment.  sc1 = the agent-scope load of the gfx942/gfx950 memory model (what
-// __hip_atomic_load(agent) emits for 8 bytes), as a raw buffer load so that the compiler tracks it (exact vmcnt waits,
-// fragments may live across the loop edge) -- the inline-asm loads of lstm_seq_fwd_kernel are invisible to it.
-__device__ __forceinline__ u32x4 tile_load16(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-  return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */);
-}
-
-template <int KB, bool STACKED, bool KEEP>  // KB = H / 32; STACKED: input = tiles of the layer below; KEEP: gates / cseq are stored
+template <int KB, bool STACKED, bool KEEP>  // KB = H / 32; STACKED: input published by the layer below during this launch; KEEP: gates / cseq stored
 __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, const int rb, const int nb, const int nrb, const int nunit,
                                                     u64_t* group_word, const int nmember, const int force_cross_xcd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int H = KB * 32;
-  constexpr int NKL = KB >= 16 ? 3 : 0;        // trailing k blocks of the W_hh slice kept in LDS instead of registers (register budget)
-  constexpr int KR = KB - NKL;                 // k blocks of W_hh in registers
-  constexpr int WS2 = NKL * 32 + 16;           // 32-byte row pad: conflict-free for ds_read_b128's lane groups
-  // W_ih slice [128][H], rows UNPADDED, 16-byte chunk c of row r stored at chunk c ^ (r & 15) of its 256-byte window: the 16 lanes
-  // ds_read_b128 serves per LDS cycle ({0-3,12-15,20-27}, ... = rows x k-quarter pairs of a fragment read) then hit 16 distinct
-  // bank quads (the H + 8 padding of lstm_seq_fwd_kernel is 2-way conflicted for those groups: 8 instead of 4 cycles per read)
-  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* sW2 = sW + 128 * H;                                        // [128][WS2] last NKL k blocks of the W_hh slice
-  bf16_t* sH = sW2 + (NKL ? 128 * WS2 : 0);                          // [32][40]   h tile staging
+  constexpr int TILE = 32 * H;                 // elements of one activation tile (32 rows x H)
+  constexpr int NX = 3;                        // X tile ring: tiles t, t+1, t+2
+  constexpr int ND = KB / 2;                   // LDS-DMA instructions per wave per tile (each moves 64 x 16 B)
+  // tiles: rows UNPADDED, 16-byte chunk c of row r at chunk position c ^ (r & 15) of its 256-byte window: the 16 lanes ds_read_b128
+  // serves per LDS cycle ({0-3,12-15,20-27}, ... = rows x k-quarter pairs of a fragment read) hit 16 distinct bank quads
+  bf16_t* sHt = reinterpret_cast<bf16_t*>(smem_raw);                 // h_{t-1} tile
+  bf16_t* sX = sHt + TILE;                                            // [NX] X tiles
+  bf16_t* sH = sX + NX * TILE;                                        // [32][40] staging of the h_t block this workgroup publishes
   int* s_okp = reinterpret_cast<int*>(sH + 32 * 40);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wu = wave & 1;
-  const int kofs = (lane >> 4) * 8;
-  for (int c = tid; c < 128 * (H / 8); c += 256) {
-    const int r = c / (H / 8), q = c - r * (H / 8);
-    *reinterpret_cast<uint4*>(sW + r * H + (q ^ (r & 15)) * 8) = *reinterpret_cast<const uint4*>(a.Wih + (size_t)(nb * 128 + r) * H + q * 8);
-  }
-  if (NKL)
-    for (int c = tid; c < 128 * NKL * 4; c += 256) {
-      const int r = c / (NKL * 4), q = c - r * (NKL * 4);
-      *reinterpret_cast<uint4*>(sW2 + r * WS2 + q * 8) = *reinterpret_cast<const uint4*>(a.Whh + (size_t)(nb * 128 + r) * H + KR * 32 + q * 8);
-    }
+  const int n = lane & 15, lq = lane >> 4;
   union Frag {
     u32x4 w;
     bf16x8 v;
   };
-  // W_hh slice as B fragments: gate j, k block kb -> row nb*128 + j*32 + wu*16 + (lane & 15), k = kb*32 + kofs .. +7
-  Frag wreg[4][KR];
+  // weight slices as B fragments: column group cg (0: gates i|f, 1: g|o), lane column n -> gate 2 cg + (n >> 3), unit 8 wave + (n & 7)
+  Frag wih[2][KB], whh[2][KB];
+  float b2[2];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int cg = 0; cg < 2; ++cg) {
+    const int wrow = nb * 128 + (cg * 2 + (n >> 3)) * 32 + wave * 8 + (n & 7);
+    b2[cg] = a.bias[wrow];
 #pragma unroll
-    for (int kb = 0; kb < KR; ++kb)
-      wreg[j][kb].w = *reinterpret_cast<const u32x4*>(a.Whh + (size_t)(nb * 128 + j * 32 + wu * 16 + (lane & 15)) * H + kb * 32 + kofs);
-  const int u = nb * 32 + wu * 16 + (lane & 15);
-  const int ucol = nb * 128 + wu * 16 + (lane & 15);
-  const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
-  const int row_l = rb * 32 + wr * 16 + (lane & 15);
-  float b4[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) b4[j] = a.bias[ucol + j * 32];
+    for (int kb = 0; kb < KB; ++kb) {
+      wih[cg][kb].w = *reinterpret_cast<const u32x4*>(a.Wih + (size_t)wrow * H + kb * 32 + lq * 8);
+      whh[cg][kb].w = *reinterpret_cast<const u32x4*>(a.Whh + (size_t)wrow * H + kb * 32 + lq * 8);
+    }
+  }
+  // the (row half, unit) this lane finishes: rows 16 (n >> 3) + 4 lq + r, unit 8 wave + (n & 7) of the block
+  const int half = n >> 3;
+  const int urow = half * 16 + lq * 4;                  // first of its 4 rows inside the 32-row block
+  const int ucl = wave * 8 + (n & 7);                   // unit inside the 32-unit block
   float cst[4] = {0.f, 0.f, 0.f, 0.f};
   if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nmember, a.timeout);
   __syncthreads();
@@ -1481,16 +1466,16 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
   const int dbg_base = STACKED ? 8 : 0;     // phase timers: slots 0-6 first layer, 8-14 stacked layer (summed over nets)
   u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
-  // bounded spin of thread 0 on a step counter, verdict broadcast through LDS slot `slot`.  Co-located groups poll with a SCALAR
-  // load (glc: misses the scalar cache, served by the XCD's L2 where the signal's atomic executes): a vector load would return
-  // in order behind the wave's outstanding tile loads.  probe (optional): a second counter that is only LOOKED at once the
-  // first is satisfied -- "has the layer below already published the step after next?" -> s_okp[2].
+  // Counter polls are SCALAR loads in co-located groups (glc: misses the scalar cache, served by the XCD's L2 where the
+  // signal's atomic executes): a vector load would return in order behind the wave's outstanding tile traffic.
   auto ctr_load = [&](unsigned* ctr) -> unsigned {
     unsigned v;
     if (fast) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
     else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
   };
+  // bounded spin of thread 0, verdict broadcast through LDS slot `slot`; probe (optional): a second counter that is only LOOKED
+  // at once the first is satisfied -> s_okp[2]
   auto wait_ctr = [&](unsigned* ctr, int slot, unsigned* probe) -> bool {
     if (tid == 0) {
       unsigned spins = 0;
@@ -1509,176 +1494,204 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
     __syncthreads();
     return s_okp[slot] != 0;
   };
-  // all sequence traffic goes through buffer resources: per-lane offsets are computed ONCE, the step enters as a scalar offset
-  // (no 64-bit address arithmetic per access), and the compiler tracks every load (exact vmcnt, fragments live across the loop edge)
+  // LDS-DMA of the 32 x H tile of rows [32 rb, 32 rb + 32) of step `step` of a row-major [T,Bn,H] sequence: wave instruction i
+  // fills LDS bytes [(wave ND + i) 1024, + 1024); LDS chunk position P holds the row's chunk (P mod 4KB) ^ (row & 15)
+  int dsrc[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int P = (wave * ND + i) * 64 + lane, row = P / (KB * 4), cpos = P - row * (KB * 4);
+    dsrc[i] = (row * H + ((cpos ^ (row & 15)) * 8)) * 2;      // byte offset inside the tile's global image
+  }
+  auto dma_piece = [&](const bf16_t* seq, const int step, bf16_t* dst, const int i) {
+    const char* g = reinterpret_cast<const char*>(seq + ((size_t)step * a.Bn + rb * 32) * H);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + dsrc[i]),
+                                     (__attribute__((address_space(3))) void*)(dst + (wave * ND + i) * 512), 16, 0, 16 /* sc1 */);
+  };
+  auto dma_tile = [&](const bf16_t* seq, const int step, bf16_t* dst) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dma_piece(seq, step, dst, i);
+  };
+  // A fragments of k block kb of row half rt of a tile: row 16 rt + n, chunk (4 kb + lq) ^ n
+  int aoff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) aoff[q] = n * H + (((q * 4 + lq) ^ n) * 8);
+  auto afrag = [&](const bf16_t* tile, const int rt, const int kb) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(tile + rt * 16 * H + aoff[kb & 3] + (kb >> 2) * 128);
+  };
   const unsigned seq_bytes = (unsigned)((size_t)a.T * a.Bn * H * 2);
-  const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)a.xchg, 0, (int)a.xchg_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_x =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(STACKED ? a.xin : a.x), 0, (int)(STACKED ? a.xchg_bytes : seq_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc((void*)a.hseq16, 0, (int)seq_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(KEEP ? a.gates : a.hT), 0, KEEP ? (int)(seq_bytes * 8u) : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)(KEEP ? a.cseq : a.hT), 0, KEEP ? (int)(seq_bytes * 2u) : 0, 0x00020000);
-  // hand-off tiles: byte offset of this lane's fragment of k block 0 inside the tile of row block rb (k block kb: + kb * 2048);
-  // one step = nrb * KB * 2048 bytes
-  const unsigned tile_lane = (unsigned)((rb * KB * 1024 + (wr * 16 + (lane & 15)) * 32 + kofs) * 2);
-  const unsigned tile_step = (unsigned)(nrb * KB * 2048);
-  const unsigned xrow_lane = (unsigned)((row_l * H + kofs) * 2);                       // row-major input: fragment of k block 0
-  const unsigned seq_step = (unsigned)(a.Bn * H * 2);                                  // one step of a [T,Bn,H] bf16 sequence
-  const unsigned hs_lane = (unsigned)(((rb * 32 + (tid >> 3)) * H + nb * 32 + (tid & 7) * 4) * 2);
+  const unsigned seq_step = (unsigned)(a.Bn * H * 2);                                  // bytes of one step of a [T,Bn,H] bf16 sequence
   // fragment-major saved activations: block (rb, nb) of a step = 4096 floats of gates / 1024 floats of c
   const unsigned g_lane = (unsigned)((((rb * KB + nb) * 4 + wave) * 4 * 64 + lane) * 16);
   const unsigned c_lane = (unsigned)((((rb * KB + nb) * 4 + wave) * 64 + lane) * 16);
-
-  Frag fx[KB];                 // X tile of the NEXT step to run, (re)loaded fragment by fragment as the current one is consumed
-  float keep_g[4][4];          // activated gates / h row of the step just finished: stored inside the NEXT step's tile-load latency
-  u64_t keep_hrow = 0;
-  bool x_early = !STACKED;     // fx holds (or will hold) the tile of the step about to run
-  auto issue_x = [&](const int tn, const int k0, const int k1) {
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < k0 || kb >= k1) continue;
-      if (STACKED) fx[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tile_lane + kb * 2048, (unsigned)tn * tile_step, 16 /* sc1 */);
-      else fx[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xrow_lane + kb * 64, (unsigned)tn * seq_step, 0);
-    }
-  };
-  if (!STACKED) issue_x(0, 0, KB);
-  // LDS fragment addresses of the swizzled W_ih slice: k block kb = 4 * (kb >> 2) + q lies at lane-dependent chunk
-  // ((4 q + g) ^ (r & 15)) of window kb >> 2
-  const bf16_t* wl[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) wl[q] = sW + (wu * 16 + (lane & 15)) * H + (((q * 4 + (lane >> 4)) ^ (lane & 15)) * 8);
-
-  auto mfma_x = [&](f32x4 (&accx)[4], const int k0, const int k1) {   // k blocks [k0, k1): B from the LDS-resident W_ih slice,
-    bf16x8 fb[4], fn[4];                                                // fragments of k block kb + 1 in flight during kb's MFMAs
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fn[j] = *reinterpret_cast<const bf16x8*>(wl[k0 & 3] + j * 32 * H + (k0 >> 2) * 128);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      if (kb < k0 || kb >= k1) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = fn[j];
-      if (kb + 1 < k1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fn[j] = *reinterpret_cast<const bf16x8*>(wl[(kb + 1) & 3] + j * 32 * H + ((kb + 1) >> 2) * 128);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[kb].v, fb[j], accx[j], 0, 0, 0);
-    }
-  };
-  // pin the software pipeline of an mfma_x half: 4 LDS reads ahead, then one MFMA per LDS read (left alone the scheduler
-  // serialises read -> wait -> MFMA to save the four fragment registers, and every MFMA pays the LDS latency); `vmem` memory
-  // instructions issued in the same region are spread over the MFMAs
-  auto pin_x = [&](const int vmem) {
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int i = 0; i < 4 * (KB / 2) - 4; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      if (vmem && (i & 3) == 3 && i / 4 < vmem) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-  };
-  auto flush_state = [&](const int tp) {      // stores of step tp: row-major h, and (KEEP) FRAGMENT-MAJOR gates / c:
-    union {                                   // gates [T][nrb][H/32][wave][r][lane][i f g o], c [T][nrb][H/32][wave][lane][r] -- read back
-      u64_t q;                                // only by the BPTT recurrence, which uses the same lane mapping; every store is a
-      u32x2 w;                                // contiguous 1 KB per wave
-    } hv;
-    hv.q = keep_hrow;
-    __builtin_amdgcn_raw_buffer_store_b64(hv.w, rs_hs, hs_lane, (unsigned)tp * seq_step, 0);
-    if (KEEP) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const u32x4 gv = {__float_as_uint(keep_g[r][0]), __float_as_uint(keep_g[r][1]), __float_as_uint(keep_g[r][2]), __float_as_uint(keep_g[r][3])};
-        __builtin_amdgcn_raw_buffer_store_b128(gv, rs_g, g_lane + (unsigned)(r * 1024), (unsigned)tp * seq_step * 8u, 0);
-      }
+  float keep_g[4][4];          // activated gates of the step just finished: stored during the NEXT step's MFMAs
+  // (KEEP) FRAGMENT-MAJOR gates [T][nrb][H/32][wave][r][lane][i f g o], c [T][nrb][H/32][wave][lane][r]: read back only by the BPTT
+  // recurrence (same lane mapping); every store is 1 KB contiguous per wave.  Piece j of step tp: 0-3 gates of row r = j, 4 = c.
+  auto flush_piece = [&](const int tp, const int j) {
+    if (j < 4) {
+      const u32x4 gv = {__float_as_uint(keep_g[j][0]), __float_as_uint(keep_g[j][1]), __float_as_uint(keep_g[j][2]), __float_as_uint(keep_g[j][3])};
+      __builtin_amdgcn_raw_buffer_store_b128(gv, rs_g, g_lane + (unsigned)(j * 1024), (unsigned)tp * seq_step * 8u, 0);
+    } else {
       const u32x4 cv = {__float_as_uint(cst[0]), __float_as_uint(cst[1]), __float_as_uint(cst[2]), __float_as_uint(cst[3])};
       __builtin_amdgcn_raw_buffer_store_b128(cv, rs_c, c_lane, (unsigned)tp * seq_step * 2u, 0);
     }
   };
 
+  // k blocks [K0, K1) of one tile x one weight slice: 4 MFMAs per k block; the A fragments of k blocks kb + 1 and kb + 2 are in
+  // flight during kb's MFMAs.  BACKGROUND memory instructions ride along, spread over the k blocks -- the vector-memory path
+  // moves 64 B/clk/CU and a wave that issues its ~1 KB instructions back to back stalls (and its MFMAs with it) until the path
+  // drains.  BG bit 0: the LDS-DMA of X tile `xp` (ND pieces), bit 1: the state of step `tp` (5 stores).
+  // The order is pinned (sched_group_barrier): left alone the scheduler serialises read -> wait -> MFMA and every k block pays
+  // the LDS latency.
+  auto mfma_tile = [&](f32x4 (&acc)[2][2], const bf16_t* tile, const Frag (&w)[2][KB], auto k0_tag, auto k1_tag, auto bg_tag, const int xp,
+                       const int tp) {
+    constexpr int K0 = decltype(k0_tag)::value, K1 = decltype(k1_tag)::value, NK = K1 - K0;
+    constexpr int BG = decltype(bg_tag)::value;
+    constexpr int NPF = (BG & 1) ? ND : 0, NST = ((BG & 2) && KEEP) ? 5 : 0, NOPS = NPF + NST;
+    constexpr int OPK = (NOPS + NK - 1) / NK;      // background instructions per k block
+    bf16x8 f0[2], f1[2], f2[2];
+    f1[0] = afrag(tile, 0, K0);
+    f1[1] = afrag(tile, 1, K0);
+    f2[0] = afrag(tile, 0, K0 + 1);
+    f2[1] = afrag(tile, 1, K0 + 1);
+#pragma unroll
+    for (int kb = K0; kb < K1; ++kb) {
+      f0[0] = f1[0];
+      f0[1] = f1[1];
+      f1[0] = f2[0];
+      f1[1] = f2[1];
+      if (kb + 2 < K1) {
+        f2[0] = afrag(tile, 0, kb + 2);
+        f2[1] = afrag(tile, 1, kb + 2);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) acc[rt][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[rt], w[cg][kb].v, acc[rt][cg], 0, 0, 0);
+#pragma unroll
+      for (int o = 0; o < OPK; ++o) {
+        const int j = (kb - K0) * OPK + o;
+        if (j < NPF) dma_piece(a.x, xp, sX + (xp % NX) * TILE, j);
+        else if (j < NOPS) flush_piece(tp, j - NPF);
+      }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int kb = K0; kb < K1; ++kb) {
+      if (kb + 2 < K1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+      for (int o = 0; o < OPK; ++o)
+        if ((kb - K0) * OPK + o < NOPS) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+    }
+  };
+  using BG0 = std::integral_constant<int, 0>;
+  using BG1 = std::integral_constant<int, 1>;
+  using BG2 = std::integral_constant<int, 2>;
+  using BG3 = std::integral_constant<int, 3>;
+  using KA = std::integral_constant<int, 0>;
+  using KM = std::integral_constant<int, KB / 2>;
+  using KE = std::integral_constant<int, KB>;
+
+  // X tile bookkeeping (wave-uniform): x_have = tiles whose DMA has been issued; x_safe = tiles that have passed a "landed"
+  // barrier (vmcnt(0) + __syncthreads) after their DMA was issued and may be read
+  int x_have = 0, x_safe = 0;
+  if (!STACKED) {          // the whole input exists before the launch: tiles 0 and 1 now
+    dma_tile(a.x, 0, sX);
+    if (a.T > 1) dma_tile(a.x, 1, sX + TILE);
+    x_have = a.T > 1 ? 2 : 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    x_safe = x_have;
+  }
+  // The X half of a step is split around the step boundary: k blocks [0, KB/2) of tile t + 1 run right AFTER step t has been
+  // published (the time the other workgroups need to publish theirs), with the background traffic; k blocks [KB/2, KB) run
+  // inside the DMA latency of the h tile.  accx carries the partial sum across the loop edge.
+  f32x4 accx[2][2];
+  bool x_half = false;           // accx already holds bias + the first half of this step's X product
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) accx[rt][cg] = f32x4{b2[cg], b2[cg], b2[cg], b2[cg]};
+
   auto step = [&](auto first_tag, const int t) -> bool {
     constexpr bool FIRST = decltype(first_tag)::value;
     // a stacked layer adds its two partial sums at the end (the order in which its tiles arrive varies); a first layer always
     // runs X then H and keeps ONE accumulator set
-    f32x4 accx[4], acch_[STACKED ? 4 : 1];
-    f32x4 (&acch)[4] = *reinterpret_cast<f32x4 (*)[4]>(STACKED ? acch_ : accx);
+    f32x4 acch_[STACKED ? 2 : 1][2];
+    f32x4 (&acch)[2][2] = *reinterpret_cast<f32x4 (*)[2][2]>(STACKED ? acch_ : accx);
+    if (STACKED) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      accx[j] = f32x4{b4[j], b4[j], b4[j], b4[j]};
-      if (STACKED) acch[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) acch[rt][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    Frag fh[KB];
-    const unsigned hso = (unsigned)(t - 1) * tile_step;
-    const bool more = t + 1 < a.T;
-    bool x_next = !STACKED && more;     // may the tile of step t + 1 be fetched during this step?
+    // tile to fetch in this step's background window: the next one not yet fetched, at most two steps ahead
+    const int xp = x_have;
+    bool pf = xp < a.T && xp <= t + 2 && xp > t;
     if (!FIRST) {
-      if (!wait_ctr(a.counters + (size_t)(t - 1) * nrb + rb, 0, (STACKED && more) ? a.xin_counters + (size_t)(t + 1) * nrb + rb : nullptr))
-        return false;
-      if (STACKED) x_next = s_okp[2] != 0;
+      if (!wait_ctr(a.counters + (size_t)(t - 1) * nrb + rb, 0, (STACKED && pf) ? a.xin_counters + (size_t)xp * nrb + rb : nullptr)) return false;
+      if (STACKED) pf = pf && s_okp[2] != 0;
       LSTM_STAMP(dbg_base + 0)   // wait for h_{t-1}
-      // the h tile leaves in two halves: the second reuses registers that the first half of the X MFMAs frees (its data is not
-      // needed before the first half has been multiplied, and the tile takes ~0.4 us to stream in anyway)
-#pragma unroll
-      for (int kb = 0; kb < KB / 2; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16 /* sc1 */);
-      __builtin_amdgcn_sched_barrier(0);   // the loads leave NOW; the scheduler would spread them over the X MFMAs to save registers
-    }
-    // Inside the latency of the h tile loads: the X half of this step, and -- memory instructions ride along with the MFMAs --
-    // the X tile of the NEXT step into the fragments just consumed, and the state of the PREVIOUS step.
-    if (x_early) {
-      mfma_x(accx, 0, KB / 2);
-      pin_x(0);
+      dma_tile(a.hseq16, t - 1, sHt);
       __builtin_amdgcn_sched_barrier(0);
-      if (!FIRST) {
-#pragma unroll
-        for (int kb = KB / 2; kb < KB; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      mfma_x(accx, KB / 2, KB);
-      if (x_next) issue_x(t + 1, 0, KB / 2);
-      pin_x(KB / 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (x_next) issue_x(t + 1, KB / 2, KB);
-    } else if (!FIRST) {
-#pragma unroll
-      for (int kb = KB / 2; kb < KB; ++kb) fh[kb].w = __builtin_amdgcn_raw_buffer_load_b128(rs_h, tile_lane + kb * 2048, hso, 16);
+    } else if (STACKED) {
+      pf = false;
     }
-    if (!FIRST) flush_state(t - 1);
+    const bf16_t* xt = sX + (t % NX) * TILE;
+    if (x_half) mfma_tile(accx, xt, wih, KM{}, KE{}, BG0{}, 0, 0);      // inside the latency of the h tile
     __builtin_amdgcn_sched_barrier(0);
-    LSTM_STAMP(dbg_base + 1)     // X tile x W_ih + next X tile / previous state issued
+    LSTM_STAMP(dbg_base + 1)     // h DMA issued, second half of X tile x W_ih
     if (!FIRST) {
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (kb < KR) {
-            acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, wreg[j][kb < KR ? kb : 0].v, acch[j], 0, 0, 0);
-          } else {
-            const bf16x8 fb = *reinterpret_cast<const bf16x8*>(sW2 + (j * 32 + wu * 16 + (lane & 15)) * WS2 + (kb - KR) * 32 + kofs);
-            acch[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[kb].v, fb, acch[j], 0, 0, 0);
-          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      x_safe = x_have;           // every DMA issued so far has landed for every wave
+      LSTM_STAMP(dbg_base + 2)   // h tile landed (all waves)
+      mfma_tile(acch, sHt, whh, KA{}, KE{}, BG0{}, 0, 0);
+      LSTM_STAMP(dbg_base + 3)   // h tile x W_hh
+    }
+    if (!x_half) {               // first step, or a stacked layer running right behind the layer below: the whole X product here
+      if (STACKED && x_safe <= t) {
+        const int far = min(t + 2, a.T - 1);
+        if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 3, far > t ? a.xin_counters + (size_t)far * nrb + rb : nullptr)) return false;
+        if (x_have <= t) {
+          dma_tile(a.x, t, sX + (t % NX) * TILE);
+          x_have = t + 1;
         }
-      LSTM_STAMP(dbg_base + 3)   // h tile x W_hh (progressive: the compiler waits per fragment)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        x_safe = x_have;
+        if (s_okp[2] && x_have <= far) {   // the layer below is two steps ahead by now: fetch up to tile t + 2, the following steps overlap again
+          for (int k = x_have; k <= far; ++k) dma_tile(a.x, k, sX + (k % NX) * TILE);
+          x_have = far + 1;
+          pf = false;
+        }
+      }
+      mfma_tile(accx, xt, wih, KA{}, KM{}, BG0{}, 0, 0);
+      mfma_tile(accx, xt, wih, KM{}, KE{}, BG0{}, 0, 0);
+      LSTM_STAMP(dbg_base + 4)   // whole X tile (late): wait + DMA + MFMAs
     }
-    if (STACKED && !x_early) {   // the layer below had not published x_t when the previous step looked
-      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 3, more ? a.xin_counters + (size_t)(t + 1) * nrb + rb : nullptr)) return false;
-      x_next = s_okp[2] != 0;
-      issue_x(t, 0, KB);
-      mfma_x(accx, 0, KB / 2);
-      pin_x(0);
-      mfma_x(accx, KB / 2, KB);
-      pin_x(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (x_next) issue_x(t + 1, 0, KB);
-      LSTM_STAMP(dbg_base + 4)   // late X tile: wait + loads + MFMAs
-    }
-    x_early = x_next;
+    if (pf && x_have != xp) pf = false;
+    // lanes n and n + 8 hold {i|f, g|o} of one unit for both row halves: swap so that lane n < 8 finishes row half 0 and lane
+    // n >= 8 row half 1 (i, f, g, o of ONE (unit, row half) each)
     float hlast[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float gi = sigmoidf_(STACKED ? accx[0][r] + acch[0][r] : accx[0][r]);
-      const float gf = sigmoidf_(STACKED ? accx[1][r] + acch[1][r] : accx[1][r]);
-      const float gg = tanhf_(STACKED ? accx[2][r] + acch[2][r] : accx[2][r]);
-      const float go = sigmoidf_(STACKED ? accx[3][r] + acch[3][r] : accx[3][r]);
+      float v[2][2], got[2];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) v[rt][cg] = STACKED ? accx[rt][cg][r] + acch[rt][cg][r] : accx[rt][cg][r];
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) {
+        const float send = half ? v[0][cg] : v[1][cg];
+        got[cg] = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(send), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+      }
+      const float gi = sigmoidf_(half ? got[0] : v[0][0]);
+      const float gf = sigmoidf_(half ? v[1][0] : got[0]);
+      const float gg = tanhf_(half ? got[1] : v[0][1]);
+      const float go = sigmoidf_(half ? v[1][1] : got[1]);
       const float c = gf * cst[r] + gi * gg;
       const float h = go * tanhf_(c);
       cst[r] = c;
@@ -1687,27 +1700,47 @@ __device__ __forceinline__ void lstm_fused_fwd_body(const LstmFusedArgs& a, cons
       keep_g[r][2] = gg;
       keep_g[r][3] = go;
       hlast[r] = h;
-      sH[(wr * 16 + 4 * (lane >> 4) + r) * 40 + wu * 16 + (lane & 15)] = f2bf(h);
+      sH[(urow + r) * 40 + ucl] = f2bf(h);
     }
     __syncthreads();
-    LSTM_STAMP(dbg_base + 5)     // cell update + h tile to LDS
-    keep_hrow = *reinterpret_cast<const u64_t*>(sH + (tid >> 3) * 40 + (tid & 7) * 4);
-    // publish: linear 2 KB block, thread tid -> bytes [8 tid, 8 tid + 8)
-    xchg_store8(reinterpret_cast<u64_t*>(a.xchg + (((size_t)t * nrb + rb) * KB + nb) * 1024) + tid, keep_hrow, fast);
+    LSTM_STAMP(dbg_base + 5)     // cell update + h block to LDS
+    {  // publish: 32 rows x 64 bytes of the row-major sequence; thread -> row tid >> 3, bytes [8 (tid & 7), + 8)
+      const int r = tid >> 3, q = tid & 7;
+      xchg_store8(reinterpret_cast<u64_t*>(a.hseq16 + ((size_t)t * a.Bn + rb * 32 + r) * H + nb * 32 + q * 4),
+                  *reinterpret_cast<const u64_t*>(sH + r * 40 + q * 4), fast);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
     LSTM_STAMP(dbg_base + 6)     // publish: store, drain, signal
-    if (a.hT && !more) {
+    if (a.hT && t + 1 == a.T) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a.hT[(size_t)(rbase + r) * H + u] = hlast[r];
+      for (int r = 0; r < 4; ++r) a.hT[(size_t)(rb * 32 + urow + r) * H + nb * 32 + ucl] = hlast[r];
+    }
+    // ---- background window: the other workgroups are still publishing ----
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int cg = 0; cg < 2; ++cg) accx[rt][cg] = f32x4{b2[cg], b2[cg], b2[cg], b2[cg]};
+    x_half = false;
+    if (pf) x_have = xp + 1;
+    if (t + 1 < a.T && x_safe > t + 1) {     // first half of the next step's X product, the traffic rides along
+      const bf16_t* xn = sX + ((t + 1) % NX) * TILE;
+      if (pf) mfma_tile(accx, xn, wih, KA{}, KM{}, BG3{}, xp, t);
+      else mfma_tile(accx, xn, wih, KA{}, KM{}, BG2{}, xp, t);
+      x_half = true;
+    } else {
+      if (pf) dma_tile(a.x, xp, sX + (xp % NX) * TILE);
+      if (KEEP) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) flush_piece(t, j);
+      }
     }
     return true;
   };
   if (!step(std::true_type{}, 0)) return;
   for (int t = 1; t < a.T; ++t)
     if (!step(std::false_type{}, t)) return;
-  flush_state(a.T - 1);
 }
 
 // records are ordered [net][layer]; layer l > 0 of a net takes its input from record - 1 when its x is NULL
@@ -1734,7 +1767,7 @@ __global__ __launch_bounds__(256) void lstm_fused_fwd_kernel(LstmFusedArgsN m) {
   const int layer = within / m.nunit, nb = within - layer * m.nunit;
   const int net = SG / m.nrb, rb = SG - net * m.nrb;
   const LstmFusedArgs& a = m.r[net * m.nl + layer];
-  if (a.x) {
+  if (!a.xin_counters) {
     if (a.gates) lstm_fused_fwd_body<KB, false, true>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
     else lstm_fused_fwd_body<KB, false, false>(a, rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
   } else {
@@ -1765,6 +1798,7 @@ struct LstmSeqBwdArgs {
   float* dc_io;        // optional [Bn,H]: running dc entering the last step of this chunk (in) / leaving its first (out)
   int has_next;        // dG slot T holds a real gradient (produced by an earlier launch for the following chunk)
   bf16_t* xchg;        // optional [T][ceil(Bn/32)][4H/32][32 rows][32 cols]: dG tiles in hand-off order
+  int frag;            // gates / cseq / c0 are in the FRAGMENT-MAJOR order of the fused forward (hsad_lstm_forward_fused; Bn % 32 == 0)
 };
 
 template <int KB>  // KB = 4H / 32
@@ -1801,17 +1835,43 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
   for (int t = a.T - 1; t >= 0; --t) {
     // everything the cell backward needs from this block's own saved activations (overlaps the wait)
     float g4[4][4], cc[4], cpv[4], dov[4];
+    if (a.frag) {
+      // fragment-major saved activations (include/hsad.h, hsad_lstm_forward_fused): this lane's (rows rbase..+3, unit u) sits at
+      // fused wave 2 wu + ((lane & 15) >> 3), fused lane 16 (lane >> 4) + 8 wr + (lane & 7): one 16-byte load per row / per c
+      const int fw = wu * 2 + ((lane & 15) >> 3), fl = (lane >> 4) * 16 + wr * 8 + (lane & 7);
+      const size_t blk = (size_t)rb * nunit_blocks + nb, nblk = (size_t)nrb * nunit_blocks;
+      const f32x4* gb = reinterpret_cast<const f32x4*>(a.gates) + ((size_t)t * nblk + blk) * 1024 + (size_t)fw * 256 + fl;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = min(rbase + r, a.Bn - 1);
-      const float* gp = a.gates + ((size_t)t * a.Bn + row) * K + ucol;
-      g4[r][0] = gp[0];
-      g4[r][1] = gp[32];
-      g4[r][2] = gp[64];
-      g4[r][3] = gp[96];
-      cc[r] = a.cseq[((size_t)t * a.Bn + row) * H + u];
-      cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
-      dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = gb[r * 64];
+        g4[r][0] = v[0];
+        g4[r][1] = v[1];
+        g4[r][2] = v[2];
+        g4[r][3] = v[3];
+      }
+      const f32x4 cv = reinterpret_cast<const f32x4*>(a.cseq)[((size_t)t * nblk + blk) * 256 + fw * 64 + fl];
+      f32x4 pv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > 0) pv = reinterpret_cast<const f32x4*>(a.cseq)[((size_t)(t - 1) * nblk + blk) * 256 + fw * 64 + fl];
+      else if (a.c0) pv = reinterpret_cast<const f32x4*>(a.c0)[blk * 256 + fw * 64 + fl];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cc[r] = cv[r];
+        cpv[r] = pv[r];
+        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + rbase + r) * H + u] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = min(rbase + r, a.Bn - 1);
+        const float* gp = a.gates + ((size_t)t * a.Bn + row) * K + ucol;
+        g4[r][0] = gp[0];
+        g4[r][1] = gp[32];
+        g4[r][2] = gp[64];
+        g4[r][3] = gp[96];
+        cc[r] = a.cseq[((size_t)t * a.Bn + row) * H + u];
+        cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
+        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
+      }
     }
     f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < a.T - 1 || a.has_next) {
@@ -3364,7 +3424,8 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
     bf16_t* dG = (bf16_t*)r.dG16;
     if (!r.has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
     m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
-                            counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg};
+                            counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg, r.saved_frag_major};
+    if (r.saved_frag_major && Bn % 32) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: fragment-major activations need Bn %% 32 == 0");
   }
   return launch_seq_bwd(m, nrec, H, nrb, sync, s, (unsigned*)next_sync_scratch, (int)seq_sync_words(nrec, Tc, nrb));
 }
@@ -3394,25 +3455,22 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fused_rec& r = recs[i];
     const int layer = i % nlayer;
-    if (!r.Wih_blocked || !r.Whh_blocked || !r.bias_blocked || !r.xchg || !r.hseq16 || (!r.x16 && layer == 0) || (!r.gates != !r.cseq))
+    if (!r.Wih_blocked || !r.Whh_blocked || !r.bias_blocked || !r.hseq16 || (!r.x16 && layer == 0) || (!r.gates != !r.cseq))
       return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: null pointer in record %d (gates and cseq go together)", i);
     LstmFusedArgs& q = m.r[i];
     q.Wih = (const bf16_t*)r.Wih_blocked;
     q.Whh = (const bf16_t*)r.Whh_blocked;
     q.bias = r.bias_blocked;
-    q.x = (const bf16_t*)r.x16;
-    q.xin = r.x16 ? nullptr : (const bf16_t*)recs[i - 1].xchg;
+    q.x = r.x16 ? (const bf16_t*)r.x16 : (const bf16_t*)recs[i - 1].hseq16;
     q.xin_counters = r.x16 ? nullptr : counters + (size_t)(i - 1) * T * nrb;
     q.gates = r.gates;
     q.cseq = r.cseq;
     q.hseq16 = (bf16_t*)r.hseq16;
     q.hT = r.hT;
-    q.xchg = (bf16_t*)r.xchg;
     q.counters = counters + (size_t)i * T * nrb;
     q.timeout = counters + (size_t)nrec * T * nrb;
     q.T = T;
     q.Bn = Bn;
-    q.xchg_bytes = (unsigned)((size_t)T * nrb * 32 * H * 2);
     q.dbg = g_lstm_dbg_enable;
   }
   m.nnet = nnet;
@@ -3423,7 +3481,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
-  const size_t lds = (size_t)(128 * H + (H >= 512 ? 128 * (3 * 32 + 16) : 0) + 32 * 40) * sizeof(bf16_t) + 16;
+  const size_t lds = (size_t)(4 * 32 * H + 32 * 40) * sizeof(bf16_t) + 16;   // h tile + ring of three X tiles + publish staging
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_fused_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, m);
@@ -3438,7 +3496,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream) {
-  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr};
+  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr, 0};
   return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, nullptr, stream);
 }
 

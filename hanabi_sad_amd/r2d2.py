@@ -140,14 +140,14 @@ def check_sync():
 
 def unpack_saved_gates(gf, T, Bn, H):
     """fragment-major activated gates of the fused recurrences (include/hsad.h, hsad_lstm_forward_fused) -> [T, Bn, 4H] gate-blocked"""
-    v = gf.view(T, Bn // 32, H // 32, 2, 2, 4, 4, 16, 4)          # t rb nb wr wu r lq ll j
-    return v.permute(0, 1, 3, 6, 5, 2, 8, 4, 7).reshape(T, Bn, 4 * H)   # t | rb wr lq r | nb j wu ll
+    v = gf.view(T, Bn // 32, H // 32, 4, 4, 4, 2, 8, 4)           # t rb nb wave r lq half u8 j
+    return v.permute(0, 1, 6, 5, 4, 2, 8, 3, 7).reshape(T, Bn, 4 * H)   # t | rb half lq r | nb j wave u8
 
 
 def unpack_saved_c(cf, T, Bn, H):
     """fragment-major cell states -> [T, Bn, H]"""
-    v = cf.view(T, Bn // 32, H // 32, 2, 2, 4, 16, 4)             # t rb nb wr wu lq ll r
-    return v.permute(0, 1, 3, 5, 7, 2, 4, 6).reshape(T, Bn, H)          # t | rb wr lq r | nb wu ll
+    v = cf.view(T, Bn // 32, H // 32, 4, 4, 2, 8, 4)              # t rb nb wave lq half u8 r
+    return v.permute(0, 1, 5, 4, 7, 2, 3, 6).reshape(T, Bn, H)          # t | rb half lq r | nb wave u8
 
 
 def lstm_forward_fused(x16, nets, keep=True, plan=None, unpack=True):
@@ -169,12 +169,10 @@ def lstm_forward_fused(x16, nets, keep=True, plan=None, unpack=True):
             for l in range(nl):
                 o = dict(gates=torch.empty(T, Bn, 4 * H, device=d) if keep else None, cseq=torch.empty(T, Bn, H, device=d) if keep else None,
                          hseq=torch.empty(T, Bn, H, dtype=torch.bfloat16, device=d), hT=torch.empty(Bn, H, device=d))
-                xchg = torch.zeros(T * nrb * 32 * H, dtype=torch.bfloat16, device=d)
-                hold.append(xchg)
                 r = recs[q * nl + l]
                 r.gates = o["gates"].data_ptr() if keep else None
                 r.cseq = o["cseq"].data_ptr() if keep else None
-                r.hseq16, r.hT, r.xchg = o["hseq"].data_ptr(), o["hT"].data_ptr(), xchg.data_ptr()
+                r.hseq16, r.hT = o["hseq"].data_ptr(), o["hT"].data_ptr()
                 out[q].append(o)
         if plan is not None:
             plan.update(recs=recs, out=out, hold=hold)

@@ -473,6 +473,7 @@ typedef struct hsad_lstm_bwd_rec {
   float* dc_io;
   int has_next;
   void* xchg; /* optional bf16 scratch [Tc * 32*ceil(Bn/32) * 4H]: dG tiles in hand-off order */
+  int saved_frag_major; /* gates / cseq / c_before are in the fragment-major order hsad_lstm_forward_fused stores (Bn % 32 == 0) */
 } hsad_lstm_bwd_rec;
 /* nrec (<= 4 forward, <= 2 backward) independent recurrences of identical shape in ONE persistent launch, e.g. layer 0
  * on chunk c+1 next to layer 1 on chunk c, for the online and the target net at once.  The overlap is inside the launch,
@@ -489,17 +490,20 @@ int hsad_lstm_forward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_ls
 int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_lstm_bwd_rec* recs, void* sync_scratch,
                                    void* next_sync_scratch, void* stream);
 /* FUSED persistent forward (round 3): nnet independent nets x nlayer stacked LSTM layers over the whole sequence in ONE launch.
- * The input projection x_t W_ih^T is computed inside the recurrence (W_ih slice stationary in LDS, W_hh slice stationary in
- * registers), stacked layers run one step apart and hand h_t tiles to each other through the L2 of their shared XCD: replaces
+ * The input projection x_t W_ih^T is computed inside the recurrence: a workgroup's four waves split its 32 units, each keeps its
+ * W_ih and W_hh slices as MFMA B fragments in registers for the whole sequence, the activation tiles arrive in LDS by LDS-DMA;
+ * stacked layers run a step apart and read the bf16 h sequence of the layer below through the L2 of their shared XCD.  Replaces
  * the stand-alone projection GEMM + hsad_lstm_forward_chunk_multi stages of one nn.LSTM forward (pyhanabi/r2d2.py:99-105).
- * recs[net * nlayer + layer]; x16 == NULL (layer > 0 only): the input is the record before it.  Weights gate-blocked
- * (hsad_prepare_weight with the 32-unit permutation), bias = b_ih + b_hh in the same order; initial state zero.  Outputs per
- * record: activated gates (T*Bn*4H floats) / cseq (T*Bn*H floats) in FRAGMENT-MAJOR order -- gates [T][Bn/32][H/32][wave 4][r 4][lane 64][i f g o],
- * c [T][Bn/32][H/32][wave 4][lane 64][r 4], where (wave, lane, r) <-> row 32*rb + 16*(wave>>1) + 4*(lane>>4) + r, unit 32*nb + 16*(wave&1) + (lane&15):
- * the per-lane order of the recurrence kernels, so every store (and every load of the BPTT recurrence) is a contiguous 1 KB per wave;
- * (hanabi_sad_amd/r2d2.py unpack_saved_gates / unpack_saved_c restate the mapping for inspection).  NULL = not kept (a net without BPTT).  hseq16 bf16 [T,Bn,H] row-major, hT.
- * xchg: bf16 scratch [T * 32*ceil(Bn/32) * H].  Needs nnet * ceil(Bn/32) * nlayer * (H/32) co-resident workgroups, H in {256, 512}.
- * sync_scratch: uint32 [nnet*nlayer*(T+2)*ceil(Bn/32) + 4], ping-pong convention of hsad_lstm_forward_chunk_multi. */
+ * recs[net * nlayer + layer]; x16 == NULL (layer > 0 only): the input is hseq16 of the record before it.  Weights gate-blocked
+ * (hsad_prepare_weight with the 32-unit permutation), bias = b_ih + b_hh in the same order; initial state zero; Bn a multiple of 32.
+ * Outputs per record: hseq16 bf16 [T,Bn,H] row-major (also the hand-off buffer between workgroups), hT, and -- what BPTT reads,
+ * NULL = not kept -- activated gates (T*Bn*4H floats) / cseq (T*Bn*H floats) in FRAGMENT-MAJOR order: gates
+ * [T][Bn/32][H/32][wave 4][r 4][lane 64][i f g o], c [T][Bn/32][H/32][wave 4][lane 64][r 4], where (wave, lane, r) <-> row
+ * 32 rb + 16 ((lane >> 3) & 1) + 4 (lane >> 4) + r, unit 32 nb + 8 wave + (lane & 7): the per-lane order of the fused recurrence
+ * kernels, so every store (and every load of the BPTT recurrence) is a contiguous 1 KB per wave (hanabi_sad_amd/r2d2.py
+ * unpack_saved_gates / unpack_saved_c restate the mapping for inspection).
+ * Needs nlayer * (H/32) * ceil(nnet * Bn/32 / 8) <= CUs / 8 (a (net, row block)'s workgroups share an XCD), H in {256, 512}.
+ * sync_scratch: uint32 [nnet*nlayer*(T+2)*Bn/32 + 4], ping-pong convention of hsad_lstm_forward_chunk_multi. */
 typedef struct hsad_lstm_fused_rec {
   const void* Wih_blocked;
   const void* Whh_blocked;
@@ -509,7 +513,6 @@ typedef struct hsad_lstm_fused_rec {
   float* cseq;
   void* hseq16;
   float* hT;
-  void* xchg;
 } hsad_lstm_fused_rec;
 int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hsad_lstm_fused_rec* recs, void* sync_scratch,
                             void* next_sync_scratch, void* stream);
@@ -579,6 +582,10 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
                              float lr, float eps, float grad_clip, hsad_r2d2_learner** out);
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* learner);
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int wgrad_split);
+/* fused_fwd != 0 (the default): the forward recurrences of hsad_r2d2_loss_fwd run as whole-sequence fused launches
+ * (hsad_lstm_forward_fused: projection inside the recurrence, layers one step apart, online + target net together) when the shape
+ * allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s workgroups fit an XCD); 0: the chunk-pipelined schedule.  Synchronises. */
+int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
 /* R2D2Agent.loss forward: priv_s [T,rows,F], legal_move [T,rows,A], a int64 [T,rows], own_hand [T,rows,3*hand] (NULL without the

@@ -37,7 +37,7 @@ for keep, dbg in ((True, 0), (True, 0), (True, 1), (False, 0)):
     print("dbg=%d " % dbg + "keep=%d nnet=%d nl=%d T=%d: %.1f us per launch (incl. allocation/memset), %.2f us per step" % (keep, nnet, nl, T, ms * 1e3, ms * 1e3 / (T + nl - 1)))
     if not dbg:
         continue
-    names = ["wait h", "x-mfma", "stores", "h-mfma", "late x", "cell", "publish"]
+    names = ["wait h", "issue+x-mfma", "h landed", "h-mfma", "late x", "cell", "publish"]
     for base, tag in ((0, "layer 0"), (8, "stacked")):
         v = [buf[base + i] / 100.0 / (n * nnet * T) for i in range(7)]
         print("  %s us/step: " % tag + "  ".join("%s %.2f" % (nm, x) for nm, x in zip(names, v)) + "  | sum %.2f" % sum(v))
