@@ -166,6 +166,10 @@ SIGNATURES = {
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,
                                 C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "hsad_r2d2_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "hsad_r2d2_net_create_ex": (C.c_int, [C.c_int] * 9 + [C.POINTER(_P)]),
+    "hsad_r2d2_net_num_params": (C.c_int, [_P]),
+    "hsad_r2d2_net_param_name": (C.c_char_p, [_P, C.c_int]),
+    "hsad_r2d2_net_arch": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "hsad_r2d2_net_destroy": (None, [_P]),
     "hsad_r2d2_num_params": (C.c_int, []),
     "hsad_r2d2_param_name": (C.c_char_p, [C.c_int]),

@@ -9,26 +9,27 @@ weights under exactly those names, so published weights map 1:1.
                                    warning) for keys the file lacks and dropping keys the net does not have (legacy files)
   load_sad_model(files, device)    utils.load_sad_model: one acting agent per file, dimensions read off the tensors
   load_op_model(method, i, j, ..)  utils.load_op_model: the Other-Play zoo models/op/<method>/M{idx}.pthw; idx selects the
-                                   architecture (1-2 fc layers, skip connection), of which the kernels run the default one"""
+                                   architecture (1-2 fc layers, skip connection); all twelve run on the kernels"""
 import os
 
 import torch
 
 from . import _lib
-from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2NetKernels
+from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2NetKernels, arch_of, param_order
 
 
 def save_weights(weights, path):
     """online_net.state_dict() in the reference's key names -> `.pthw`"""
-    torch.save({k: weights[k].detach().cpu().clone() for k in PARAM_ORDER}, path)
+    torch.save({k: weights[k].detach().cpu().clone() for k in param_order(*arch_of(weights))}, path)
 
 
 def load_weights(path, device="cpu"):
     sd = torch.load(path, map_location=device)
-    missing = [k for k in PARAM_ORDER if k not in sd]
+    names = param_order(*arch_of(sd))
+    missing = [k for k in names if k not in sd]
     if missing:
         raise KeyError("checkpoint lacks %s (expected R2D2Net.state_dict() keys)" % missing)
-    return {k: sd[k].float() for k in PARAM_ORDER}
+    return {k: sd[k].float() for k in names}
 
 
 def load_weight(target, weight_file, device="cpu", verbose=True):
@@ -61,25 +62,36 @@ def _dims(sd):
     return sd["net.0.weight"].shape[1], H, sd["fc_a.weight"].shape[0]
 
 
-def _blank(in_dim, hid_dim, out_dim, hand_size=5):
+def _blank(in_dim, hid_dim, out_dim, hand_size=5, num_fc_layer=1, num_lstm_layer=2):
     from .selfplay import init_weights
-    return init_weights(in_dim, hid_dim, out_dim, hand_size, 0)
+    return init_weights(in_dim, hid_dim, out_dim, hand_size, 0, num_lstm_layer=num_lstm_layer, num_fc_layer=num_fc_layer)
 
 
-def agent_from_file(weight_file, device="cuda:0", multi_step=3, gamma=0.999, precision="bf16"):
-    """an acting agent (online = target = the file's weights) on the HIP kernels"""
+def agent_from_file(weight_file, device="cuda:0", multi_step=3, gamma=0.999, precision="bf16", skip_connect=False):
+    """an acting agent (online = target = the file's weights) on the HIP kernels.  The architecture (1-2 fc layers, 1-3 LSTM layers)
+    is read off the file's keys; skip_connect is a constructor flag in the reference and therefore here.  The reference default in
+    bf16 runs the Python-orchestrated kernels or the composite entry points alike; every other architecture runs through the
+    library's composite entry points (bf16) or the fp32 exact mode."""
+    from .composite import CNet, CompositeAgent
+    from .r2d2 import arch_of
     sd = torch.load(weight_file, map_location="cpu")
-    extra = [k for k in sd if k.startswith("net.") and not k.startswith("net.0.")]
-    if extra:
-        raise _lib.HsadError("%s holds a %d-layer input MLP (%s); the kernels run the reference default (one fc layer, no skip "
-                             "connection) -- wrap such a model in rela.BatchRunner as a torch module instead"
-                             % (weight_file, 1 + len(extra) // 2, extra))
+    nfc, nl = arch_of(sd)
+    if not 1 <= nl <= 3 or any(k.startswith("net.") and k.split(".")[1] not in ("0", "2") for k in sd):
+        raise _lib.HsadError("%s: R2D2Net with %d LSTM layers / input MLP keys %s is outside what the reference's loaders construct"
+                             % (weight_file, nl, [k for k in sd if k.startswith("net.")]))
     in_dim, hid, out_dim = _dims(sd)
     hand = sd["pred.weight"].shape[0] // 3 if "pred.weight" in sd else 5
-    W = _blank(in_dim, hid, out_dim, hand)
+    W = _blank(in_dim, hid, out_dim, hand, nfc, nl)
     load_weight(W, weight_file, verbose=False)
-    net = R2D2NetKernels.make(W, device, precision)
-    return R2D2Agent(net, net, multi_step, gamma)
+    if precision == "fp32":
+        from .r2d2_f32 import R2D2NetF32
+        net = R2D2NetF32(W, device, skip_connect=skip_connect)
+        return R2D2Agent(net, net, multi_step, gamma)
+    if (nfc, nl) == (1, 2) and not skip_connect:
+        net = R2D2NetKernels.make(W, device, precision)
+        return R2D2Agent(net, net, multi_step, gamma)
+    net = CNet(W, device, skip_connect=skip_connect)
+    return CompositeAgent(net, net, multi_step, gamma)
 
 
 def load_sad_model(weight_files, device="cuda:0"):
@@ -93,9 +105,9 @@ def op_model_arch(idx):
     return (1 if idx < 6 else 2), (3 <= idx < 6 or idx >= 9)
 
 
-def load_op_model(method, idx1, idx2, device="cuda:0", root=None):
-    """utils.load_op_model (pyhanabi/utils.py:36-84): the two-player Other-Play zoo.  Models 0-2 have the default architecture
-    and run on the kernels; 3-11 (skip connection and / or two fc layers) are rejected with the reason."""
+def load_op_model(method, idx1, idx2, device="cuda:0", root=None, precision="bf16"):
+    """utils.load_op_model (pyhanabi/utils.py:36-84): the two-player Other-Play zoo, all twelve architectures -- M0-2 default,
+    M3-5 skip connection, M6-8 two fc layers, M9-11 both -- on the kernels."""
     root = root or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     folder = os.path.join(root, "models", "op", method)
     agents = []
@@ -106,8 +118,8 @@ def load_op_model(method, idx1, idx2, device="cuda:0", root=None):
         if not os.path.exists(path):
             raise FileNotFoundError("Cannot find weight at: %s" % path)
         num_fc, skip = op_model_arch(idx)
-        if num_fc != 1 or skip:
-            raise _lib.HsadError("M%d uses num_fc_layer=%d, skip_connect=%s; the kernels run the default architecture only"
-                                 % (idx, num_fc, skip))
-        agents.append(agent_from_file(path, device, 3, 0.999))
+        sd = torch.load(path, map_location="cpu")
+        if (2 if "net.2.weight" in sd else 1) != num_fc:
+            raise _lib.HsadError("M%d should have %d fc layer(s) (utils.py:46-57); the file has keys %s" % (idx, num_fc, [k for k in sd if k.startswith("net.")]))
+        agents.append(agent_from_file(path, device, 3, 0.999, precision, skip_connect=skip))
     return agents

@@ -29,15 +29,26 @@ def _view(ptr, n, device, owner):
     return torch.as_tensor(_DevArray(ptr, n, owner), device=device)
 
 
-def param_names():
+def param_names(net=None):
+    """state_dict names of the parameter tensors, in the order of the flat vector: the default architecture's 16, or a net's own"""
     lib = _lib.load_library()
-    return [lib.hsad_r2d2_param_name(i).decode() for i in range(lib.hsad_r2d2_num_params())]
+    if net is None:
+        return [lib.hsad_r2d2_param_name(i).decode() for i in range(lib.hsad_r2d2_num_params())]
+    return [lib.hsad_r2d2_net_param_name(net, i).decode() for i in range(lib.hsad_r2d2_net_num_params(net))]
+
+
+def arch_of(weights):
+    """(num_fc_layer, num_lstm_layer) read off the state_dict keys (net.2.* = a second fc layer; lstm.*_l{k})"""
+    nfc = 2 if "net.2.weight" in weights else 1
+    L = len([k for k in weights if k.startswith("lstm.weight_ih_l")])
+    return nfc, L
 
 
 class CNet:
-    """hsad_r2d2_net: R2D2Net(in_dim, hid_dim, out_dim, 2 LSTM layers, hand_size) living in the library"""
+    """hsad_r2d2_net: R2D2Net(in_dim, hid_dim, out_dim, num_lstm_layer, hand_size, num_fc_layer, skip_connect) living in the
+    library (pyhanabi/r2d2.py:22-57); the layer counts are read off the weight names, skip_connect is a flag like in the reference"""
 
-    def __init__(self, weights, device="cuda:0", with_backward=False):
+    def __init__(self, weights, device="cuda:0", with_backward=False, skip_connect=False):
         self.lib = _lib.load_library()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -47,16 +58,20 @@ class CNet:
         self.F = weights["net.0.weight"].shape[1]
         self.A = weights["fc_a.weight"].shape[0]
         self.NP = weights["pred.weight"].shape[0]
-        self.L = 2
-        extra = [k for k in weights if k not in param_names()]
-        if extra:
-            raise _lib.HsadError("the R2D2 kernels support the reference default shape only; unexpected parameters: %s" % extra)
+        self.nfc, self.L = arch_of(weights)
+        self.skip = bool(skip_connect)
         self.h = C.c_void_p()
-        _lib.check(self.lib.hsad_r2d2_net_create(self.F, self.H, self.A, self.NP // 3, int(with_backward), idx, C.byref(self.h)))
+        _lib.check(self.lib.hsad_r2d2_net_create_ex(self.F, self.H, self.A, self.NP // 3, self.nfc, self.L, int(self.skip), int(with_backward),
+                                                    idx, C.byref(self.h)))
+        self.names = param_names(self.h)
+        extra = [k for k in weights if k not in self.names]
+        if extra:
+            self.close()
+            raise _lib.HsadError("unexpected parameters for R2D2Net(num_fc_layer=%d, num_lstm_layer=%d): %s" % (self.nfc, self.L, extra))
         n = self.lib.hsad_r2d2_net_param_count(self.h)
         self.flat = _view(self.lib.hsad_r2d2_net_params(self.h), n, self.device, self)
         self.w = {}
-        for i, name in enumerate(param_names()):
+        for i, name in enumerate(self.names):
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.h, i), self.lib.hsad_r2d2_net_param_size(self.h, i)
             self.w[name] = self.flat[o:o + sz].view(weights[name].shape)
             self.w[name].copy_(weights[name])
@@ -207,7 +222,7 @@ class CompositeLearner:
         self.shape = (T, rows)
         n = self.online.flat.numel()
         self.gflat = _view(self.lib.hsad_r2d2_learner_grad(self.h), n, self.device, self)
-        for i, name in enumerate(param_names()):
+        for i, name in enumerate(self.online.names):
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.online.h, i), self.lib.hsad_r2d2_net_param_size(self.online.h, i)
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
 

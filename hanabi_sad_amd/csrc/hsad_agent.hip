@@ -49,11 +49,8 @@ int afail(int code, const char* fmt, ...) {
 typedef unsigned short bf16_t;
 inline int pad64(int k) { return (k + 63) / 64 * 64; }
 
-const char* kParamNames[16] = {"net.0.weight",      "net.0.bias",        "lstm.weight_ih_l0", "lstm.weight_hh_l0",
-                               "lstm.bias_ih_l0",   "lstm.bias_hh_l0",   "lstm.weight_ih_l1", "lstm.weight_hh_l1",
-                               "lstm.bias_ih_l1",   "lstm.bias_hh_l1",   "fc_a.weight",       "fc_v.weight",
-                               "pred.weight",       "fc_a.bias",         "fc_v.bias",         "pred.bias"};
-enum { P_W1 = 0, P_B1, P_WIH0, P_WHH0, P_BIH0, P_BHH0, P_WIH1, P_WHH1, P_BIH1, P_BHH1, P_WA, P_WV, P_WP, P_BA, P_BV, P_BP };
+constexpr int kMaxL = 3;     // nn.LSTM(num_layers): the reference's --num_lstm_layer (pyhanabi/selfplay.py:50), 1..3 here
+constexpr int kMaxP = 4 + 4 * kMaxL + 6;
 
 // grow-only device buffer
 struct Buf {
@@ -96,16 +93,24 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 
 }  // namespace
 
+// R2D2Net(in_dim, hid_dim, out_dim, num_lstm_layer, hand_size, num_fc_layer, skip_connect) (pyhanabi/r2d2.py:22-57).  Parameter
+// tensors in state_dict order of the module tree: net.0.*, [net.2.*], lstm.{weight_ih,weight_hh,bias_ih,bias_hh}_l{k}, then the heads
+// as [fc_a | fc_v | pred] weights and [fc_a | fc_v | pred] biases (contiguous [NH, H] / [NH] blocks).
 struct hsad_r2d2_net {
   int F, Fp, H, A, NP, NH, NHp, device;
+  int nfc = 1, L = 2;
+  bool skip = false;
   bool with_backward;
   size_t n_param;
-  size_t off[17];
-  float* flat = nullptr;     // fp32 masters, all tensors back to back (order kParamNames)
+  int np = 0;                          // parameter tensors
+  size_t off[kMaxP + 1];
+  std::string names[kMaxP];
+  int iW1, iB1, iW2 = -1, iB2 = -1, iWih[kMaxL], iWhh[kMaxL], iBih[kMaxL], iBhh[kMaxL], iWA, iWV, iWP, iBA, iBV, iBP;
+  float* flat = nullptr;     // fp32 masters, all tensors back to back
   bool owns_flat = true;
   Buf flat_buf, ops, perms, scratch;
-  bf16_t *W1, *Wih[2], *Whh[2], *Wheads, *Wcat16[2], *WihT[2], *WhhT[2], *WheadsT;
-  float *bg[2], *bheads, *bias16[2];
+  bf16_t *W1, *W2 = nullptr, *W2T = nullptr, *Wih[kMaxL], *Whh[kMaxL], *Wheads, *Wcat16[kMaxL], *WihT[kMaxL], *WhhT[kMaxL], *WheadsT;
+  float *bg[kMaxL], *bheads, *bias16[kMaxL];
   int32_t *perm32, *perm16;
   uint64_t version = 0;
   // acting workspace (grows with the row count)
@@ -117,18 +122,46 @@ namespace {
 
 size_t net_tensor_elems(const hsad_r2d2_net* n, int i) {
   const size_t H = n->H, F = n->F, A = n->A, NP = n->NP;
-  switch (i) {
-    case P_W1: return H * F;
-    case P_B1: return H;
-    case P_WIH0: case P_WHH0: case P_WIH1: case P_WHH1: return 4 * H * H;
-    case P_BIH0: case P_BHH0: case P_BIH1: case P_BHH1: return 4 * H;
-    case P_WA: return A * H;
-    case P_WV: return H;
-    case P_WP: return NP * H;
-    case P_BA: return A;
-    case P_BV: return 1;
-    default: return NP;
+  if (i == n->iW1) return H * F;
+  if (i == n->iB1 || i == n->iB2 || i == n->iWV) return H;
+  if (i == n->iW2) return H * H;
+  for (int l = 0; l < n->L; ++l) {
+    if (i == n->iWih[l] || i == n->iWhh[l]) return 4 * H * H;
+    if (i == n->iBih[l] || i == n->iBhh[l]) return 4 * H;
   }
+  if (i == n->iWA) return A * H;
+  if (i == n->iWP) return NP * H;
+  if (i == n->iBA) return A;
+  if (i == n->iBV) return 1;
+  return NP;
+}
+
+void net_build_table(hsad_r2d2_net* n) {
+  int k = 0;
+  auto add = [&](const std::string& nm) {
+    n->names[k] = nm;
+    return k++;
+  };
+  n->iW1 = add("net.0.weight");
+  n->iB1 = add("net.0.bias");
+  if (n->nfc == 2) {
+    n->iW2 = add("net.2.weight");
+    n->iB2 = add("net.2.bias");
+  }
+  for (int l = 0; l < n->L; ++l) {
+    const std::string sfx = "_l" + std::to_string(l);
+    n->iWih[l] = add("lstm.weight_ih" + sfx);
+    n->iWhh[l] = add("lstm.weight_hh" + sfx);
+    n->iBih[l] = add("lstm.bias_ih" + sfx);
+    n->iBhh[l] = add("lstm.bias_hh" + sfx);
+  }
+  n->iWA = add("fc_a.weight");
+  n->iWV = add("fc_v.weight");
+  n->iWP = add("pred.weight");
+  n->iBA = add("fc_a.bias");
+  n->iBV = add("fc_v.bias");
+  n->iBP = add("pred.bias");
+  n->np = k;
 }
 
 int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
@@ -136,10 +169,11 @@ int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
   n->version++;
   // every derived operand in one launch: weight jobs first, then the biases
   CK(hsad_refresh_begin());
-  CK(hsad_refresh_add_weight(n->w(P_W1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0));
-  for (int l = 0; l < 2; ++l) {
-    const float* wih = n->w(l ? P_WIH1 : P_WIH0);
-    const float* whh = n->w(l ? P_WHH1 : P_WHH0);
+  CK(hsad_refresh_add_weight(n->w(n->iW1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0));
+  if (n->nfc == 2) CK(hsad_refresh_add_weight(n->w(n->iW2), H, H, H, nullptr, n->W2, H, n->with_backward ? n->W2T : nullptr, H));
+  for (int l = 0; l < n->L; ++l) {
+    const float* wih = n->w(n->iWih[l]);
+    const float* whh = n->w(n->iWhh[l]);
     CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H));
     CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H));
     if (n->Wcat16[l] && !n->with_backward) {
@@ -147,16 +181,16 @@ int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
       CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0));
     }
   }
-  const int wi[3] = {P_WA, P_WV, P_WP}, bi[3] = {P_BA, P_BV, P_BP}, rows[3] = {n->A, 1, n->NP};
+  const int wi[3] = {n->iWA, n->iWV, n->iWP}, bi[3] = {n->iBA, n->iBV, n->iBP}, rows[3] = {n->A, 1, n->NP};
   int r0 = 0;
   for (int k = 0; k < 3; ++k) {
     CK(hsad_refresh_add_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
                                n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp));
     r0 += rows[k];
   }
-  for (int l = 0; l < 2; ++l) {
-    const float* bih = n->w(l ? P_BIH1 : P_BIH0);
-    const float* bhh = n->w(l ? P_BHH1 : P_BHH0);
+  for (int l = 0; l < n->L; ++l) {
+    const float* bih = n->w(n->iBih[l]);
+    const float* bhh = n->w(n->iBhh[l]);
     CK(hsad_refresh_add_bias(bih, bhh, n->perm32, n->bg[l], 4 * H));
     if (n->Wcat16[l] && !n->with_backward) CK(hsad_refresh_add_bias(bih, bhh, n->perm16, n->bias16[l], 4 * H));
   }
@@ -169,81 +203,127 @@ int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
   return 0;
 }
 
+__global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float s = __uint_as_float((uint32_t)a[i] << 16) + __uint_as_float((uint32_t)b[i] << 16);
+  uint32_t u = __float_as_uint(s);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  out[i] = (bf16_t)(u >> 16);
+}
+
+// the input MLP (R2D2Net.net: Linear + ReLU, x num_fc_layer) on N rows: a16 [N, Fp] -> x [N, H] bf16.  tmp: [N, H] bf16 scratch (2 layers)
+int net_input_mlp(hsad_r2d2_net* n, int N, const bf16_t* a16, bf16_t* x, bf16_t* tmp, void* st) {
+  const int H = n->H;
+  if (n->nfc == 1) return hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(n->iB1), nullptr, 0, x, H, 1, 0, st);
+  CK(hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(n->iB1), nullptr, 0, tmp, H, 1, 0, st));
+  return hsad_gemm_nt_bf16(tmp, H, n->W2, H, N, H, H, n->w(n->iB2), nullptr, 0, x, H, 1, 0, st);
+}
+
 // fp32 [L*N, H] -> bf16 scratch, x-projection etc.: the single-step trunk (R2D2Net.act, r2d2.py:65-78) on N rows.
 // out: o16 = lstm output bf16 [N,H] (points into ws), optional new state.  h16_in: bf16(h0) [L,N,H] when the caller has it.
+// with_skip: o16 = lstm output + x (skip_connect applies in R2D2Net.act only, r2d2.py:74-75; forward() ignores it)
 struct StepOut {
   bf16_t* o16;
   bf16_t* h16_new;   // [L,N,H] (fused path only, else null)
 };
 
 int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const float* c0, const bf16_t* h16_in, float* h_out,
-             float* c_out, char* wsp, StepOut* out, hipStream_t s, bf16_t* h16_dst = nullptr, bool x_ready = false) {
-  const int H = n->H;
+             float* c_out, char* wsp, StepOut* out, hipStream_t s, bf16_t* h16_dst = nullptr, bool x_ready = false, bool with_skip = false) {
+  const int H = n->H, L = n->L;
   void* st = (void*)s;
   const size_t NH_ = (size_t)N * H;
   bf16_t* x = reinterpret_cast<bf16_t*>(wsp);   // x_ready: the caller already ran the input layer into the head of wsp
   wsp += NH_ * 2;
-  if (!x_ready) CK(hsad_gemm_nt_bf16(a16, n->Fp, n->W1, n->Fp, N, H, n->Fp, n->w(P_B1), nullptr, 0, x, H, 1, 0, st));
+  bf16_t* xtmp = reinterpret_cast<bf16_t*>(wsp);  // second fc layer / skip sum
+  wsp += NH_ * 2;
+  if (!x_ready) CK(net_input_mlp(n, N, a16, x, xtmp, st));
   const bool fused = n->Wcat16[0] && !n->with_backward && N >= 1024;
+  bf16_t* o16 = nullptr;
   if (fused) {
     bf16_t* h16 = reinterpret_cast<bf16_t*>(wsp);
-    wsp += 2 * NH_ * 2;
+    wsp += L * NH_ * 2;
     bf16_t* h16n = h16_dst ? h16_dst : reinterpret_cast<bf16_t*>(wsp);   // h16_dst: the caller's [L,N,H] buffer, written in place
-    wsp += 2 * NH_ * 2;
+    wsp += L * NH_ * 2;
     if (!h16_in) {
-      CK(hsad_cast_pad_bf16(h0, 2 * N, H, H, h16, H, st));
+      CK(hsad_cast_pad_bf16(h0, L * N, H, H, h16, H, st));
       h16_in = h16;
     }
     const bf16_t* xin = x;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < L; ++l) {
       CK(hsad_lstm_cell_fused(N, H, H, xin, H, h16_in + (size_t)l * NH_, n->Wcat16[l], n->bias16[l], c0 + (size_t)l * NH_,
                               c_out ? c_out + (size_t)l * NH_ : nullptr, h_out ? h_out + (size_t)l * NH_ : nullptr,
                               h16n + (size_t)l * NH_, st));
       xin = h16n + (size_t)l * NH_;
     }
-    out->o16 = h16n + NH_;
+    o16 = h16n + (size_t)(L - 1) * NH_;
     out->h16_new = h16n;
-    return 0;
+  } else {
+    // small batches: projection GEMM + one recurrence step per layer
+    float* gates = reinterpret_cast<float*>(wsp);
+    wsp += (size_t)N * 4 * H * 4;
+    bf16_t* hseq = reinterpret_cast<bf16_t*>(wsp);
+    wsp += L * NH_ * 2;
+    bf16_t* sc16 = reinterpret_cast<bf16_t*>(wsp);
+    wsp += NH_ * 2;
+    float* cs = reinterpret_cast<float*>(wsp);
+    wsp += L * NH_ * 4;
+    float* ht = reinterpret_cast<float*>(wsp);
+    wsp += L * NH_ * 4;
+    const bf16_t* inp = x;
+    for (int l = 0; l < L; ++l) {
+      CK(hsad_gemm_nt_bf16(inp, H, n->Wih[l], H, N, 4 * H, H, n->bg[l], gates, 4 * H, nullptr, 0, 0, 0, st));
+      CK(hsad_lstm_layer_forward(1, N, H, gates, n->Whh[l], h0 + (size_t)l * NH_, c0 + (size_t)l * NH_, hseq + (size_t)l * NH_,
+                                 c_out ? c_out + (size_t)l * NH_ : cs + (size_t)l * NH_, sc16,
+                                 h_out ? h_out + (size_t)l * NH_ : ht + (size_t)l * NH_, nullptr, 0, st));
+      inp = hseq + (size_t)l * NH_;
+    }
+    o16 = hseq + (size_t)(L - 1) * NH_;
+    out->h16_new = nullptr;
   }
-  // small batches: projection GEMM + one recurrence step per layer
-  float* gates = reinterpret_cast<float*>(wsp);
-  wsp += (size_t)N * 4 * H * 4;
-  bf16_t* hseq = reinterpret_cast<bf16_t*>(wsp);
-  wsp += 2 * NH_ * 2;
-  bf16_t* sc16 = reinterpret_cast<bf16_t*>(wsp);
-  wsp += NH_ * 2;
-  float* cs = reinterpret_cast<float*>(wsp);
-  wsp += 2 * NH_ * 4;
-  float* ht = reinterpret_cast<float*>(wsp);
-  wsp += 2 * NH_ * 4;
-  const bf16_t* inp = x;
-  for (int l = 0; l < 2; ++l) {
-    CK(hsad_gemm_nt_bf16(inp, H, n->Wih[l], H, N, 4 * H, H, n->bg[l], gates, 4 * H, nullptr, 0, 0, 0, st));
-    CK(hsad_lstm_layer_forward(1, N, H, gates, n->Whh[l], h0 + (size_t)l * NH_, c0 + (size_t)l * NH_, hseq + (size_t)l * NH_,
-                               c_out ? c_out + (size_t)l * NH_ : cs + (size_t)l * NH_, sc16,
-                               h_out ? h_out + (size_t)l * NH_ : ht + (size_t)l * NH_, nullptr, 0, st));
-    inp = hseq + (size_t)l * NH_;
+  if (with_skip && n->skip) {
+    hipLaunchKernelGGL(add_bf16_kernel, dim3((unsigned)((NH_ + 255) / 256)), dim3(256), 0, s, o16, x, xtmp, NH_);
+    HIP_TRY(hipGetLastError());
+    o16 = xtmp;
   }
-  out->o16 = hseq + NH_;
-  out->h16_new = nullptr;
+  out->o16 = o16;
   return 0;
 }
 
 size_t step_ws_bytes(const hsad_r2d2_net* n, int N) {
-  const size_t NH_ = (size_t)N * n->H;
-  return NH_ * 2 + std::max<size_t>(4 * NH_ * 2, (size_t)N * 4 * n->H * 4 + 3 * NH_ * 2 + 4 * NH_ * 4) + 256;
+  const size_t NH_ = (size_t)N * n->H, L = n->L;
+  return 2 * NH_ * 2 + std::max<size_t>(2 * L * NH_ * 2, (size_t)N * 4 * n->H * 4 + (L + 1) * NH_ * 2 + 2 * L * NH_ * 4) + 256;
 }
 
 }  // namespace
 
 extern "C" {
 
+/* the default architecture's table (16 tensors); nets created with hsad_r2d2_net_create_ex report theirs through the _net_ variants */
 int hsad_r2d2_num_params(void) { return 16; }
-const char* hsad_r2d2_param_name(int i) { return (i >= 0 && i < 16) ? kParamNames[i] : nullptr; }
+const char* hsad_r2d2_param_name(int i) {
+  static const char* kDefault[16] = {"net.0.weight",      "net.0.bias",        "lstm.weight_ih_l0", "lstm.weight_hh_l0",
+                                     "lstm.bias_ih_l0",   "lstm.bias_hh_l0",   "lstm.weight_ih_l1", "lstm.weight_hh_l1",
+                                     "lstm.bias_ih_l1",   "lstm.bias_hh_l1",   "fc_a.weight",       "fc_v.weight",
+                                     "pred.weight",       "fc_a.bias",         "fc_v.bias",         "pred.bias"};
+  return (i >= 0 && i < 16) ? kDefault[i] : nullptr;
+}
+int hsad_r2d2_net_num_params(const hsad_r2d2_net* n) { return n ? n->np : 0; }
+const char* hsad_r2d2_net_param_name(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i < n->np) ? n->names[i].c_str() : nullptr; }
+int hsad_r2d2_net_arch(const hsad_r2d2_net* n, int32_t* num_fc_layer, int32_t* num_lstm_layer, int32_t* skip_connect) {
+  if (!n) return afail(HSAD_ERR_INVALID, "null net");
+  if (num_fc_layer) *num_fc_layer = n->nfc;
+  if (num_lstm_layer) *num_lstm_layer = n->L;
+  if (skip_connect) *skip_connect = n->skip ? 1 : 0;
+  return 0;
+}
 
-int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size, int with_backward, int device, hsad_r2d2_net** out) {
+int hsad_r2d2_net_create_ex(int in_dim, int hid_dim, int num_action, int hand_size, int num_fc_layer, int num_lstm_layer, int skip_connect,
+                            int with_backward, int device, hsad_r2d2_net** out) {
   if (!out || in_dim < 1 || num_action < 1 || hand_size < 1) return afail(HSAD_ERR_INVALID, "r2d2_net_create: bad dimensions");
   if (hid_dim < 64 || hid_dim % 64) return afail(HSAD_ERR_INVALID, "r2d2_net_create: hid_dim must be a multiple of 64");
+  if (num_fc_layer < 1 || num_fc_layer > 2) return afail(HSAD_ERR_INVALID, "r2d2_net_create: num_fc_layer must be 1 or 2");
+  if (num_lstm_layer < 1 || num_lstm_layer > kMaxL) return afail(HSAD_ERR_INVALID, "r2d2_net_create: num_lstm_layer must be 1..%d", kMaxL);
   HIP_TRY(hipSetDevice(device));
   auto* n = new hsad_r2d2_net();
   n->F = in_dim;
@@ -254,13 +334,17 @@ int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size,
   n->NH = n->A + 1 + n->NP;
   n->NHp = pad64(n->NH);
   n->device = device;
+  n->nfc = num_fc_layer;
+  n->L = num_lstm_layer;
+  n->skip = skip_connect != 0;
   n->with_backward = with_backward != 0;
+  net_build_table(n);
   size_t o = 0;
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < n->np; ++i) {
     n->off[i] = o;
     o += net_tensor_elems(n, i);     // back to back: [fc_a | fc_v | pred] weights / biases form contiguous [NH, H] / [NH] blocks
   }
-  n->off[16] = o;
+  n->off[n->np] = o;
   n->n_param = o;
   if (n->flat_buf.need(o * 4)) {
     delete n;
@@ -268,10 +352,10 @@ int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size,
   }
   n->flat = n->flat_buf.as<float>();
   (void)hipMemset(n->flat, 0, o * 4);
-  const size_t H = hid_dim, H4 = 4 * H;
+  const size_t H = hid_dim, H4 = 4 * H, L = n->L;
   // operand arena
-  size_t need = H * n->Fp * 2 + 2 * (H4 * H * 2) * 2 + 2 * H4 * 4 + (size_t)n->NH * H * 2 + n->NHp * 4 + 2 * (H4 * 2 * H * 2) + 2 * H4 * 4 +
-                (with_backward ? 2 * 2 * (H * H4 * 2) + H * n->NHp * 2 : 0) + 4096;
+  size_t need = H * n->Fp * 2 + 2 * H * H * 2 + L * (H4 * H * 2) * 2 + L * H4 * 4 + (size_t)n->NH * H * 2 + n->NHp * 4 + L * (H4 * 2 * H * 2) + L * H4 * 4 +
+                (with_backward ? L * 2 * (H * H4 * 2) + H * n->NHp * 2 : 0) + 8192;
   if (n->ops.need(need) || n->perms.need(2 * H4 * 4)) {
     delete n;
     return HSAD_ERR_NOMEM;
@@ -284,7 +368,15 @@ int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size,
     return r;
   };
   n->W1 = (bf16_t*)take(H * n->Fp * 2);
-  for (int l = 0; l < 2; ++l) {
+  if (n->nfc == 2) {
+    n->W2 = (bf16_t*)take(H * H * 2);
+    n->W2T = with_backward ? (bf16_t*)take(H * H * 2) : nullptr;
+  }
+  for (int l = 0; l < kMaxL; ++l) {
+    n->Wih[l] = n->Whh[l] = n->Wcat16[l] = n->WihT[l] = n->WhhT[l] = nullptr;
+    n->bg[l] = n->bias16[l] = nullptr;
+  }
+  for (int l = 0; l < n->L; ++l) {
     n->Wih[l] = (bf16_t*)take(H4 * H * 2);
     n->Whh[l] = (bf16_t*)take(H4 * H * 2);
     n->bg[l] = (float*)take(H4 * 4);
@@ -314,11 +406,15 @@ int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size,
   return 0;
 }
 
+int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size, int with_backward, int device, hsad_r2d2_net** out) {
+  return hsad_r2d2_net_create_ex(in_dim, hid_dim, num_action, hand_size, 1, 2, 0, with_backward, device, out);
+}
+
 void hsad_r2d2_net_destroy(hsad_r2d2_net* n) { delete n; }
 int64_t hsad_r2d2_net_param_count(const hsad_r2d2_net* n) { return n ? (int64_t)n->n_param : 0; }
 float* hsad_r2d2_net_params(hsad_r2d2_net* n) { return n ? n->flat : nullptr; }
-int64_t hsad_r2d2_net_param_offset(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i <= 16) ? (int64_t)n->off[i] : -1; }
-int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i < 16) ? (int64_t)net_tensor_elems(n, i) : -1; }
+int64_t hsad_r2d2_net_param_offset(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i <= n->np) ? (int64_t)n->off[i] : -1; }
+int64_t hsad_r2d2_net_param_size(const hsad_r2d2_net* n, int i) { return (n && i >= 0 && i < n->np) ? (int64_t)net_tensor_elems(n, i) : -1; }
 uint64_t hsad_r2d2_net_version(const hsad_r2d2_net* n) { return n ? n->version : 0; }
 int hsad_r2d2_net_in_dim_padded(const hsad_r2d2_net* n) { return n ? n->Fp : 0; }
 
@@ -338,6 +434,10 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     return afail(HSAD_ERR_INVALID, "r2d2_act: null argument");
   if (q_target_greedy && (!q_online_a || !target))
     return afail(HSAD_ERR_INVALID, "r2d2_act: q_target_greedy needs q_online_a and the target net");
+  if (q_online_a && online->skip)
+    return afail(HSAD_ERR_INVALID, "r2d2_act: cached Q-values are undefined for a skip_connect net -- R2D2Net.act adds the skip connection, "
+                 "R2D2Net.forward (what compute_priority evaluates) ignores it (pyhanabi/r2d2.py:74-75 vs 99-105); use hsad_r2d2_compute_priority");
+  if (target && (target->L != online->L || target->H != online->H)) return afail(HSAD_ERR_INVALID, "r2d2_act: online / target shapes differ");
   hsad_r2d2_net* n = online;
   hipStream_t s = (hipStream_t)stream;
   const int H = n->H, A = n->A, NH = n->NH;
@@ -362,17 +462,17 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   // (the bf16 copy of the new state goes straight into the caller's buffer: it must not alias h0_bf16, which layer 1 still reads)
   if (h_out_bf16 && h_out_bf16 == h0_bf16) return afail(HSAD_ERR_INVALID, "r2d2_act: h_out_bf16 must not alias h0_bf16");
   // both nets read the same observation: their input layers are ONE launch of two problems over a shared A operand
-  const bool pair_in = q_target_greedy && target->F == n->F && target->H == H && target->A == A;
+  const bool pair_in = q_target_greedy && target->F == n->F && target->H == H && target->A == A && n->nfc == 1 && target->nfc == 1;
   if (pair_in)
-    CK(hsad_gemm_nt_bf16_pair(a16, a16, n->Fp, n->W1, target->W1, n->Fp, N, H, n->Fp, n->w(P_B1), target->w(P_B1), nullptr, nullptr, 0,
+    CK(hsad_gemm_nt_bf16_pair(a16, a16, n->Fp, n->W1, target->W1, n->Fp, N, H, n->Fp, n->w(n->iB1), target->w(target->iB1), nullptr, nullptr, 0,
                               ws_on, ws_tg, H, 1, stream));
-  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in));
+  CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in, true));
   if (pair_in && hd_b % 16 == 0) {
     // ... and so are their head layers (N = A + 1 + 3 hand: one problem alone leaves half of the chip without a tile); the target's
     // trunk therefore runs before the online heads.  Same kernels on the same operands as the sequence below: identical bits.
     StepOut st{};
     const bf16_t* h16_shared = (const bf16_t*)h0_bf16;
-    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);
+    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)2 * N * H * 2);
     CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s, nullptr, true));
     CK(hsad_gemm_nt_bf16_pair(so.o16, st.o16, H, n->Wheads, target->Wheads, H, N, NH, H, n->bheads, target->bheads, hd, hd_t, NH, nullptr,
                               nullptr, 0, 0, stream));
@@ -388,7 +488,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     StepOut st{};
     // the target pass shares the bf16 casts of the observation and (fused path) of the hidden state
     const bf16_t* h16_shared = (const bf16_t*)h0_bf16;
-    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)N * H * 2);   // the cast net_step made
+    if (!h16_shared && so.h16_new) h16_shared = reinterpret_cast<const bf16_t*>(ws_on + (size_t)2 * N * H * 2);   // the cast net_step made
     CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s, nullptr, pair_in));
     CK(hsad_gemm_nt_bf16(st.o16, H, target->Wheads, H, N, NH, H, target->bheads, hd_t, NH, nullptr, 0, 0, 0, stream));
     CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
@@ -444,7 +544,9 @@ static int net_q_of(hsad_r2d2_net* n, int N, const float* priv_s, const float* l
   int64_t* junk = (int64_t*)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   CK(hsad_cast_pad_bf16(priv_s, N, n->F, n->F, a16, n->Fp, stream));
   StepOut so{};
-  CK(net_step(n, N, a16, h0, c0, nullptr, nullptr, nullptr, ws_on, &so, s));
+  // the greedy action of compute_priority comes from R2D2Agent.greedy_act = R2D2Net.act (skip connection applies), Q(s, a) from
+  // R2D2Net.forward (it does not): pyhanabi/r2d2.py:234-244, 340-345
+  CK(net_step(n, N, a16, h0, c0, nullptr, nullptr, nullptr, ws_on, &so, s, nullptr, false, greedy_out != nullptr));
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));
   if (greedy_out) CK(hsad_act_select(hd, NH, legal, nullptr, N, A, 0, 0, junk, greedy_out, scratch, stream));
   if (qa) CK(hsad_q_head(hd, NH, legal, action, N, A, q, qa, nullptr, scratch, stream));
@@ -506,23 +608,23 @@ struct hsad_r2d2_learner {
   int wgrad_split = 8, chunks = 4;
   int fused_fwd = 1;          // whole-sequence fused forward recurrences (hsad_lstm_forward_fused) when the shape allows
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
-  unsigned* fsync[2][2];      // ping-pong counter blocks of the fused launches: [nets per launch - 1][flip]
-  int fflip[2] = {0, 0};
-  size_t fsync_words[2];
+  unsigned* fsync[3][2];      // ping-pong counter blocks of the fused launches: [log2(recurrences per launch)][flip]
+  int fflip[3] = {0, 0, 0};
+  size_t fsync_words[3];
   Buf arena, opt, sync_buf;
   float *gflat, *m, *v, *osc;
   hipStream_t side = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
-  // activations (q = 0 online, 1 target)
-  bf16_t *a16, *x1[2], *hseq[2][2], *xchg_f[2][2], *zero16, *sc16;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  // activations (q = 0 online, 1 target).  xin = the LSTM's input = the last layer of the input MLP (x1, or x2 with two fc layers)
+  bf16_t *a16, *x1[2], *x2[2], *xin[2], *hseq[2][kMaxL], *xchg_f[2][kMaxL], *zero16, *sc16;
   const bf16_t* a16_in = nullptr;  // the input operand of the update in flight: a16 (cast here) or the caller's bf16 batch
-  float *gates[2][2], *cseq[2][2], *hT[2][2], *czero;
+  float *gates[2][kMaxL], *cseq[2][kMaxL], *hT[2][kMaxL], *czero;
   float *heads, *heads_t, *q, *qa, *tqa, *qa_s, *tqa_s, *err, *dqa, *dqa_r, *w_r, *xs, *qscratch;
   int64_t* greedy;
   // backward
-  bf16_t *dheads, *dG[2], *dx1, *hsT[2], *hpT[2], *x1T, *a16T, *dGT, *dx1T, *dheadsT, *xchg_b[2];
+  bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL];
   int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
-  float *dO0, *dO1, *dc[2], *wgrad_ws;
+  float *dO[kMaxL], *dc[kMaxL], *wgrad_ws;
   // ping-pong counter blocks of the persistent launches: [kind fwd/bwd][nrec - 1][flip]
   unsigned* sync[2][4][2];
   int flip[2][4];
@@ -539,20 +641,25 @@ struct hsad_r2d2_learner {
 namespace {
 
 // persistent multi-recurrence launches + the shared delayed-copy operand of the weight gradients need H in {256, 512}, at most
-// 512 rows, rows a multiple of 8 and T * rows a multiple of the GEMM K tile; everything else takes the unchunked schedule
+// 512 rows, rows a multiple of 8 and T * rows a multiple of the GEMM K tile; the layer pipeline is written for two LSTM layers;
+// everything else takes the unchunked schedule
 bool can_pipeline(const hsad_r2d2_learner* L) {
   const int H = L->on->H;
-  return (H == 256 || H == 512) && L->B <= 512 && L->B % 8 == 0 && L->M % 64 == 0;
+  return L->on->L == 2 && (H == 256 || H == 512) && L->B <= 512 && L->B % 8 == 0 && L->M % 64 == 0;
 }
-// fused forward (one persistent launch over the whole sequence, both layers): nets per launch, 0 = not possible.  A (net, row
-// block)'s 2 x H/32 workgroups must share an XCD (one workgroup per CU)
-int fuse_nets(const hsad_r2d2_learner* L) {
-  const int H = L->on->H, nrb = (L->B + 31) / 32;
-  if (!L->fused_fwd || !can_pipeline(L) || L->B % 32 || (size_t)L->T * L->B * H * 16 >= (1ull << 32)) return 0;
-  const int per_xcd = L->n_cu / 8, per = 2 * (H / 32);
-  if (per * ((2 * nrb + 7) / 8) <= per_xcd) return 2;
-  if (per * ((nrb + 7) / 8) <= per_xcd) return 1;
-  return 0;
+// fused forward (persistent launches over the whole sequence): nets per launch and stacked layers per launch; nets == 0 = not
+// possible.  A (net, row block)'s layers x H/32 workgroups must share an XCD (one workgroup per CU)
+struct FusePlan {
+  int nets, layers;
+};
+FusePlan fuse_plan(const hsad_r2d2_learner* L) {
+  const int H = L->on->H, nrb = (L->B + 31) / 32, NL = L->on->L;
+  if (!L->fused_fwd || !(H == 256 || H == 512) || L->B % 32 || (size_t)L->T * L->B * H * 16 >= (1ull << 32)) return {0, 0};
+  const int per_xcd = L->n_cu / 8;
+  for (int g = std::min(NL, 2); g >= 1; --g)
+    for (int nn = 2; nn >= 1; --nn)
+      if (g * (H / 32) * ((nn * nrb + 7) / 8) <= per_xcd) return {nn, g};
+  return {0, 0};
 }
 int pick_chunks(const hsad_r2d2_learner* L) {
   if (!can_pipeline(L)) return 1;
@@ -575,7 +682,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
                              float lr, float eps, float grad_clip, hsad_r2d2_learner** out) {
   if (!online || !target || !out || T < 1 || rows_per_step < 1) return afail(HSAD_ERR_INVALID, "r2d2_learner_create: bad arguments");
   if (!online->with_backward) return afail(HSAD_ERR_INVALID, "r2d2_learner_create: the online net must be created with_backward");
-  if (online->F != target->F || online->H != target->H || online->A != target->A || online->NP != target->NP)
+  if (online->F != target->F || online->H != target->H || online->A != target->A || online->NP != target->NP || online->L != target->L ||
+      online->nfc != target->nfc)
     return afail(HSAD_ERR_INVALID, "r2d2_learner_create: online / target shapes differ");
   HIP_TRY(hipSetDevice(online->device));
   auto* L = new hsad_r2d2_learner();
@@ -593,13 +701,12 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   (void)hipGetDevice(&dev);
   if (hipDeviceGetAttribute(&L->n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) L->n_cu = 256;
   const size_t M = L->M, B = L->B, H = online->H, H4 = 4 * H, Fp = online->Fp, NH = online->NH, NHp = online->NHp, A = online->A;
-  const int nch = pick_chunks(L);
+  const int NL = online->L, nfc = online->nfc;
   const bool pipe0 = can_pipeline(L);
   const size_t Mp = pad64((int)M);
   L->Mp = (int)Mp;
   // hand-off buffers and counter blocks are sized for the longest chunk any schedule can ask for (chunks = 1: Tc = T), so that
   // hsad_r2d2_learner_set_schedule may change the chunk count of an existing learner
-  (void)nch;
   const size_t Tc = T, nrb = nrb_of((int)B), xf = Tc * nrb * 32 * H, xb = Tc * nrb * 32 * H4;
   // ---- one arena for every activation of an update ----
   std::vector<std::pair<void**, size_t>> plan;
@@ -607,12 +714,13 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->a16, M * Fp * 2);
   for (int q = 0; q < 2; ++q) {
     want(&L->x1[q], M * H * 2);
-    for (int l = 0; l < 2; ++l) {
+    if (nfc == 2) want(&L->x2[q], M * H * 2);
+    for (int l = 0; l < NL; ++l) {
       want(&L->gates[q][l], M * H4 * 4);
       want(&L->hseq[q][l], M * H * 2);
       want(&L->cseq[q][l], M * H * 4);
       want(&L->hT[q][l], B * H * 4);
-      want(&L->xchg_f[q][l], xf * 2);
+      want(&L->xchg_f[q][l], pipe0 ? xf * 2 : 256);
     }
   }
   want(&L->zero16, B * H * 2);
@@ -633,17 +741,21 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->qscratch, (8 + (M + 255) / 256) * 4);
   want(&L->greedy, M * 8);
   want(&L->dheads, M * NHp * 2);
-  want(&L->dO0, M * H * 4);
-  want(&L->dO1, M * H * 4);
-  want(&L->dc[0], 2 * B * H * 4);      // dc[1] follows dc[0]: one memset clears both
-  for (int l = 0; l < 2; ++l) {
+  for (int l = 0; l < NL; ++l) want(&L->dO[l], M * H * 4);
+  want(&L->dc[0], (size_t)NL * B * H * 4);      // dc[l] follow dc[0]: one memset clears all
+  for (int l = 0; l < NL; ++l) {
     want(&L->dG[l], (size_t)(T + 1) * B * H4 * 2);
     want(&L->hsT[l], pipe0 ? H * (B + M) * 2 : H * Mp * 2);
     want(&L->hpT[l], pipe0 ? 256 : H * Mp * 2);
-    want(&L->xchg_b[l], xb * 2);
+    want(&L->xchg_b[l], pipe0 ? xb * 2 : 256);
   }
   want(&L->dx1, M * H * 2);
   want(&L->x1T, H * Mp * 2);
+  if (nfc == 2) {
+    want(&L->dx2, M * H * 2);
+    want(&L->x2T, H * Mp * 2);
+    want(&L->dx2T, H * Mp * 2);
+  }
   want(&L->a16T, Fp * Mp * 2);
   want(&L->dGT, H4 * Mp * 2);
   want(&L->dx1T, H * Mp * 2);
@@ -661,7 +773,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     *e.first = p;
     p += e.second;
   }
-  L->dc[1] = L->dc[0] + B * H;
+  for (int l = 1; l < NL; ++l) L->dc[l] = L->dc[0] + (size_t)l * B * H;
+  for (int q = 0; q < 2; ++q) L->xin[q] = nfc == 2 ? L->x2[q] : L->x1[q];
   // optimizer state + gradient
   const size_t np = online->n_param;
   if (L->opt.need(np * 4 * 3 + 64)) {
@@ -682,8 +795,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     }
   const size_t s1 = nrb * ((size_t)T + 2) + 4;
   size_t fw = 0;
-  for (int k = 0; k < 2; ++k) {
-    L->fsync_words[k] = (size_t)(k + 1) * 2 * nrb * ((size_t)T + 2) + 4;
+  for (int k = 0; k < 3; ++k) {
+    L->fsync_words[k] = ((size_t)1 << k) * nrb * ((size_t)T + 2) + 4;
     fw += 2 * L->fsync_words[k];
   }
   if (L->sync_buf.need((sw + s1 + fw) * 4)) {
@@ -702,13 +815,14 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     }
   L->sync1 = sp;
   sp += s1;
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
     for (int f = 0; f < 2; ++f) {
       L->fsync[k][f] = sp;
       sp += L->fsync_words[k];
     }
   if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&L->ev_d, hipEventDisableTiming) != hipSuccess) {
     delete L;
     return afail(HSAD_ERR_HIP, "r2d2_learner_create: stream / event creation failed");
   }
@@ -719,21 +833,23 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
   if (!L) return;
   if (L->side) (void)hipStreamDestroy(L->side);
-  for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c})
+  for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c, L->ev_d})
     if (e) (void)hipEventDestroy(e);
   delete L;
 }
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* L) { return L ? L->gflat : nullptr; }
+static int learner_reset_sync(hsad_r2d2_learner* L) {
+  // the counter blocks of the ping-pong launches are laid out per launch shape: start a new schedule from clean ones
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
+  for (int k = 0; k < 2; ++k)
+    for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
+  L->fflip[0] = L->fflip[1] = L->fflip[2] = 0;
+  return 0;
+}
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_split) {
   if (!L || chunks < 1 || wgrad_split < 1 || wgrad_split > 8) return afail(HSAD_ERR_INVALID, "learner_set_schedule: chunks >= 1, wgrad_split 1..8");
-  if (chunks != L->chunks) {
-    // the counter blocks of the ping-pong launches are laid out per chunk length: start the new schedule from clean ones
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
-    for (int k = 0; k < 2; ++k)
-      for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
-    L->fflip[0] = L->fflip[1] = 0;
-  }
+  if (chunks != L->chunks) CK(learner_reset_sync(L));
   L->chunks = chunks;
   L->wgrad_split = wgrad_split;
   return 0;
@@ -742,11 +858,7 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_s
  * recurrence, layers one step apart) when the shape allows; 0: the chunk-pipelined schedule of hsad_r2d2_learner_set_schedule */
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemset(L->sync_buf.p, 0, L->sync_buf.cap));
-  for (int k = 0; k < 2; ++k)
-    for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
-  L->fflip[0] = L->fflip[1] = 0;
+  CK(learner_reset_sync(L));
   L->fused_fwd = fused_fwd != 0;
   return 0;
 }
@@ -764,12 +876,17 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
         HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + (size_t)(r + 1) * nrb * (Tc + 2), 4, hipMemcpyDeviceToHost));
         *timed_out |= (int32_t)v;
       }
-  for (int k = 0; k < 2; ++k)
+  for (int k = 0; k < 3; ++k)
     for (int f = 0; f < 2; ++f) {
       unsigned v = 0;
       HIP_TRY(hipMemcpy(&v, L->fsync[k][f] + L->fsync_words[k] - 4, 4, hipMemcpyDeviceToHost));
       *timed_out |= (int32_t)v;
     }
+  {
+    unsigned v = 0;      // unchunked single-recurrence launches
+    HIP_TRY(hipMemcpy(&v, L->sync1 + nrb * ((size_t)L->T + 2), 4, hipMemcpyDeviceToHost));
+    *timed_out |= (int32_t)v;
+  }
   return 0;
 }
 
@@ -787,7 +904,7 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   if (want_grad && !weight) return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: the gradient needs the importance weights");
   hsad_r2d2_net* nets[2] = {L->on, L->tg};
   hipStream_t s = (hipStream_t)stream;
-  const int T = L->T, B = L->B, M = L->M, H = L->on->H, H4 = 4 * H, A = L->on->A, NH = L->on->NH, Fp = L->on->Fp;
+  const int T = L->T, B = L->B, M = L->M, H = L->on->H, H4 = 4 * H, A = L->on->A, NH = L->on->NH, Fp = L->on->Fp, NL = L->on->L, nfc = L->on->nfc;
   const int nch = pick_chunks(L);
   L->nch = nch;
   // priv_s_bf16: [M, Fp] zero-padded, e.g. straight out of hsad_replay_sample (HSAD_BITS_AS_BF16); it must stay valid until
@@ -797,40 +914,45 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
     CK(hsad_cast_pad_bf16(priv_s, M, L->on->F, L->on->F, L->a16, Fp, stream));
     L->a16_in = L->a16;
   }
-  // the online / target pair of each forward GEMM is ONE launch (hsad_gemm_nt_bf16_pair): input layer, then layer-0 projection
-  CK(hsad_gemm_nt_bf16_pair(L->a16_in, L->a16_in, Fp, nets[0]->W1, nets[1]->W1, Fp, M, H, Fp, nets[0]->w(P_B1), nets[1]->w(P_B1), nullptr,
-                            nullptr, 0, L->x1[0], L->x1[1], H, 1, stream));
-  const int fnets = fuse_nets(L);
-  L->fwd_frag = fnets > 0;
-  if (fnets) {
-    // both LSTM layers of a net over the whole sequence as ONE persistent launch, the projections computed inside the
-    // recurrences (hsad_lstm_forward_fused); the target net keeps neither gates nor c (no BPTT through it)
-    hsad_lstm_fused_rec recs[4];
-    for (int q = 0; q < 2; ++q)
-      for (int l = 0; l < 2; ++l) {
-        hsad_lstm_fused_rec& r = recs[q * 2 + l];
-        r.Wih_blocked = nets[q]->Wih[l];
-        r.Whh_blocked = nets[q]->Whh[l];
-        r.bias_blocked = nets[q]->bg[l];
-        r.x16 = l == 0 ? L->x1[q] : nullptr;
-        r.gates = (q == 0 && want_grad) ? L->gates[q][l] : nullptr;
-        r.cseq = (q == 0 && want_grad) ? L->cseq[q][l] : nullptr;
-        r.hseq16 = L->hseq[q][l];
-        r.hT = L->hT[q][l];
+  // the online / target pair of each forward GEMM is ONE launch (hsad_gemm_nt_bf16_pair): the input MLP (R2D2Net.net) ...
+  CK(hsad_gemm_nt_bf16_pair(L->a16_in, L->a16_in, Fp, nets[0]->W1, nets[1]->W1, Fp, M, H, Fp, nets[0]->w(nets[0]->iB1), nets[1]->w(nets[1]->iB1),
+                            nullptr, nullptr, 0, L->x1[0], L->x1[1], H, 1, stream));
+  if (nfc == 2)
+    CK(hsad_gemm_nt_bf16_pair(L->x1[0], L->x1[1], H, nets[0]->W2, nets[1]->W2, H, M, H, H, nets[0]->w(nets[0]->iB2), nets[1]->w(nets[1]->iB2),
+                              nullptr, nullptr, 0, L->x2[0], L->x2[1], H, 1, stream));
+  const FusePlan fp = fuse_plan(L);
+  L->fwd_frag = fp.nets > 0;
+  if (fp.nets) {
+    // the LSTM over the whole sequence as persistent launches with the projections computed inside the recurrences
+    // (hsad_lstm_forward_fused): up to two stacked layers and both nets per launch; the target net keeps neither gates nor c
+    for (int l0 = 0; l0 < NL; l0 += fp.layers) {
+      const int g = std::min(fp.layers, NL - l0);
+      for (int q0 = 0; q0 < 2; q0 += fp.nets) {
+        hsad_lstm_fused_rec recs[4];
+        for (int qi = 0; qi < fp.nets; ++qi)
+          for (int li = 0; li < g; ++li) {
+            const int q = q0 + qi, l = l0 + li;
+            hsad_lstm_fused_rec& r = recs[qi * g + li];
+            r.Wih_blocked = nets[q]->Wih[l];
+            r.Whh_blocked = nets[q]->Whh[l];
+            r.bias_blocked = nets[q]->bg[l];
+            r.x16 = li == 0 ? (l == 0 ? L->xin[q] : L->hseq[q][l - 1]) : nullptr;
+            r.gates = (q == 0 && want_grad) ? L->gates[q][l] : nullptr;
+            r.cseq = (q == 0 && want_grad) ? L->cseq[q][l] : nullptr;
+            r.hseq16 = L->hseq[q][l];
+            r.hT = L->hT[q][l];
+          }
+        const int nrec = fp.nets * g, k = nrec == 4 ? 2 : nrec - 1;
+        int& f = L->fflip[k];
+        CK(hsad_lstm_forward_fused(fp.nets, g, T, B, H, recs, L->fsync[k][f], L->fsync[k][f ^ 1], stream));
+        f ^= 1;
       }
-    for (int q0 = 0; q0 < 2; q0 += fnets) {
-      int& f = L->fflip[fnets - 1];
-      CK(hsad_lstm_forward_fused(fnets, 2, T, B, H, recs + q0 * 2, L->fsync[fnets - 1][f], L->fsync[fnets - 1][f ^ 1], stream));
-      f ^= 1;
     }
-  } else {
-  CK(hsad_gemm_nt_bf16_pair(L->x1[0], L->x1[1], H, nets[0]->Wih[0], nets[1]->Wih[0], H, M, H4, H, nets[0]->bg[0], nets[1]->bg[0],
-                            L->gates[0][0], L->gates[1][0], H4, nullptr, nullptr, 0, 0, stream));
-  }
-  if (fnets) {
   } else if (can_pipeline(L)) {
-    // layers software-pipelined over time chunks: stage st runs layer 0 on chunk st and layer 1 on chunk st - 1, for both nets, as
-    // ONE multi-recurrence persistent launch
+    // ... then the layer-0 projection; layers software-pipelined over time chunks: stage st runs layer 0 on chunk st and layer 1
+    // on chunk st - 1, for both nets, as ONE multi-recurrence persistent launch
+    CK(hsad_gemm_nt_bf16_pair(L->xin[0], L->xin[1], H, nets[0]->Wih[0], nets[1]->Wih[0], H, M, H4, H, nets[0]->bg[0], nets[1]->bg[0],
+                              L->gates[0][0], L->gates[1][0], H4, nullptr, nullptr, 0, 0, stream));
     const int Tc = T / nch, nrb = nrb_of(B);
     const int per_launch = std::max(1, std::min(4, L->n_cu / ((H / 32) * nrb)));
     for (int st = 0; st <= nch; ++st) {
@@ -868,16 +990,16 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
     }
   } else {
     for (int q = 0; q < 2; ++q)
-      for (int l = 0; l < 2; ++l) {
-        if (l == 1)
-          CK(hsad_gemm_nt_bf16(L->hseq[q][0], H, nets[q]->Wih[1], H, M, H4, H, nets[q]->bg[1], L->gates[q][1], H4, nullptr, 0, 0, 0, stream));
+      for (int l = 0; l < NL; ++l) {
+        CK(hsad_gemm_nt_bf16(l == 0 ? L->xin[q] : L->hseq[q][l - 1], H, nets[q]->Wih[l], H, M, H4, H, nets[q]->bg[l], L->gates[q][l], H4, nullptr, 0,
+                             0, 0, stream));
         CK(hsad_lstm_layer_forward(T, B, H, L->gates[q][l], nets[q]->Whh[l], nullptr, L->czero, L->hseq[q][l], L->cseq[q][l], L->sc16,
                                    L->hT[q][l], L->sync1, 1, stream));
       }
   }
   // heads, Q-values, double-DQN target
   // (the two head layers are one pair launch: N = A + 1 + 3 hand columns, one problem alone is 80 workgroups)
-  CK(hsad_gemm_nt_bf16_pair(L->hseq[0][1], L->hseq[1][1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
+  CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
                             L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
   CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, L->greedy, L->qscratch, stream));
   CK(hsad_q_head(L->heads_t, NH, legal_move, L->greedy, M, A, L->q, L->tqa, nullptr, L->qscratch, stream));
@@ -915,6 +1037,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   hsad_r2d2_net* on = L->on;
   hipStream_t s = (hipStream_t)stream;
   const int T = L->T, B = L->B, M = L->M, H = on->H, H4 = 4 * H, A = on->A, NH = on->NH, NHp = on->NHp, Fp = on->Fp, F = on->F, NP = on->NP;
+  const int NL = on->L, nfc = on->nfc, top = NL - 1;
   const int nch = L->nch, P = L->num_player, Bg = B / P;
   const float *dqa = L->dqa, *weight = L->b_weight;
   if (P > 1) {
@@ -925,10 +1048,10 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   }
   CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
                          L->dheads, NHp, stream));
-  CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO1, H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+  CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO[top], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
   HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
-  float* g[16];
-  for (int i = 0; i < 16; ++i) g[i] = L->gflat + on->off[i];
+  float* g[kMaxP];
+  for (int i = 0; i < on->np; ++i) g[i] = L->gflat + on->off[i];
   const bool pipe = can_pipeline(L);
   const int Mp = L->Mp;            // == M in the pipelined schedule
   // weight-gradient work runs on the side stream in the pipelined schedule (it overlaps the recurrences), else in line
@@ -938,27 +1061,30 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   // zeros for t = 0) and one transpose serves the input-weight and the recurrent-weight gradient.  Unchunked schedule (any T, B):
   // x^T and the delayed copy are separate zero-padded [H, Mp] buffers.
   const int ldh = pipe ? B + M : Mp;
-  const bf16_t* hs_x[2] = {pipe ? L->hsT[0] + B : L->hsT[0], pipe ? L->hsT[1] + B : L->hsT[1]};
-  const bf16_t* hs_d[2] = {pipe ? L->hsT[0] : L->hpT[0], pipe ? L->hsT[1] : L->hpT[1]};
+  const bf16_t *hs_x[kMaxL], *hs_d[kMaxL];
+  for (int l = 0; l < NL; ++l) {
+    hs_x[l] = pipe ? L->hsT[l] + B : L->hsT[l];
+    hs_d[l] = pipe ? L->hsT[l] : L->hpT[l];
+  }
   auto wgrad = [&](const bf16_t* AT, const bf16_t* BT, int ldb, int Mo, int No, float* outp, int ldc, const int32_t* rmap) {
     return hsad_gemm_nt_bf16_splitk(AT, Mp, BT, ldb, Mo, No, Mp, L->wgrad_split, L->wgrad_ws, outp, ldc, rmap, wst);
   };
   auto layer_wgrad = [&](int l, const bf16_t* inT, int ld_in) {
     if (M % 4 == 0) {      // the transpose also accumulates both bias gradients (= the un-blocked column sums of dG)
-      CK(transpose16(L->dG[l], M, H4, H4, L->dGT, Mp, g[l ? P_BIH1 : P_BIH0], g[l ? P_BHH1 : P_BHH0], on->perm32, wst));
+      CK(transpose16(L->dG[l], M, H4, H4, L->dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, wst));
     } else {
       CK(transpose16(L->dG[l], M, H4, H4, L->dGT, Mp, nullptr, nullptr, nullptr, wst));
-      CK(hsad_colsum_acc(L->dG[l], 1, M, H4, H4, g[l ? P_BIH1 : P_BIH0], g[l ? P_BHH1 : P_BHH0], on->perm32, wst));
+      CK(hsad_colsum_acc(L->dG[l], 1, M, H4, H4, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, wst));
     }
-    CK(wgrad(L->dGT, inT, ld_in, H4, H, g[l ? P_WIH1 : P_WIH0], H, on->perm32));
-    CK(wgrad(L->dGT, hs_d[l], ldh, H4, H, g[l ? P_WHH1 : P_WHH0], H, on->perm32));
+    CK(wgrad(L->dGT, inT, ld_in, H4, H, g[on->iWih[l]], H, on->perm32));
+    CK(wgrad(L->dGT, hs_d[l], ldh, H4, H, g[on->iWhh[l]], H, on->perm32));
     return 0;
   };
   if (pipe) {
     HIP_TRY(hipEventRecord(L->ev_a, s));
     HIP_TRY(hipStreamWaitEvent(ws, L->ev_a, 0));
   }
-  for (int l = 0; l < 2; ++l) {
+  for (int l = 0; l < NL; ++l) {
     if (pipe) {
       HIP_TRY(hipMemset2DAsync(L->hsT[l], (size_t)(B + M) * 2, 0, (size_t)B * 2, H, ws));
       CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l] + B, B + M, nullptr, nullptr, nullptr, wst));
@@ -969,15 +1095,17 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     }
   }
   CK(transpose16(L->x1[0], M, H, H, L->x1T, Mp, nullptr, nullptr, nullptr, wst));
+  if (nfc == 2) CK(transpose16(L->x2[0], M, H, H, L->x2T, Mp, nullptr, nullptr, nullptr, wst));
+  const bf16_t* xinT = nfc == 2 ? L->x2T : L->x1T;
   CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
   CK(transpose16(L->dheads, M, NHp, NHp, L->dheadsT, Mp, nullptr, nullptr, nullptr, wst));
-  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[1], ldh, NH, H, Mp, nullptr, g[P_WA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
-  CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[P_BA], nullptr, nullptr, wst));
+  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
+  CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
+  if (pipe) HIP_TRY(hipEventRecord(L->ev_d, ws));      // the transposed operands of the input MLP (x^T, a16^T) exist
   if (pipe) {
     const int Tc = T / nch, nrb = nrb_of(B);
     const size_t Mc = (size_t)Tc * B;
     HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
-    const float* dOs[2] = {L->dO0, L->dO1};
     const int per_launch = std::max(1, std::min(2, L->n_cu / ((H / 32) * nrb)));
     for (int st = 0; st <= nch; ++st) {
       hsad_lstm_bwd_rec recs[2];
@@ -989,7 +1117,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.cseq = L->cseq[0][l] + t0 * B * H;
         r.c_before = c == 0 ? nullptr : L->cseq[0][l] + (t0 - 1) * B * H;
         r.WhhT_blocked = on->WhhT[l];
-        r.dO = dOs[l] + t0 * B * H;
+        r.dO = L->dO[l] + t0 * B * H;
         r.dG16 = L->dG[l] + t0 * B * H4;
         r.dc_io = L->dc[l];
         r.has_next = c != nch - 1;
@@ -1000,7 +1128,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
       if (st < nch) recs[nr++] = brec(1, nch - 1 - st);
       if (st >= 1) {
         const int c0 = nch - st;
-        CK(hsad_gemm_nt_bf16_ex(L->dG[1] + (size_t)c0 * Mc * H4, H4, on->WihT[1], H4, (int)Mc, H, H4, nullptr, L->dO0 + (size_t)c0 * Mc * H, H,
+        CK(hsad_gemm_nt_bf16_ex(L->dG[1] + (size_t)c0 * Mc * H4, H4, on->WihT[1], H4, (int)Mc, H, H4, nullptr, L->dO[0] + (size_t)c0 * Mc * H, H,
                                 nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
         recs[nr++] = brec(0, c0);
       }
@@ -1016,24 +1144,44 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     CK(layer_wgrad(1, hs_x[0], ldh));
     HIP_TRY(hipEventRecord(L->ev_c, s));                            // layer 0 complete
     HIP_TRY(hipStreamWaitEvent(ws, L->ev_c, 0));
-    CK(layer_wgrad(0, L->x1T, Mp));
+    CK(layer_wgrad(0, xinT, Mp));
   } else {
-    for (int l = 1; l >= 0; --l) {
-      CK(hsad_lstm_layer_backward(T, B, H, L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], l ? L->dO1 : L->dO0, L->dG[l], L->dc[l],
-                                  L->sync1, stream));
-      if (l == 1)
-        CK(hsad_gemm_nt_bf16_ex(L->dG[1], H4, on->WihT[1], H4, M, H, H4, nullptr, L->dO0, H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
-      CK(layer_wgrad(l, l ? hs_x[0] : L->x1T, l ? ldh : Mp));
+    for (int l = top; l >= 0; --l) {
+      if (L->fwd_frag) {      // fragment-major saved activations: one persistent launch over the whole sequence
+        hsad_lstm_bwd_rec r{L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], L->dO[l], L->dG[l], L->dc[l], 0, nullptr, 1};
+        HIP_TRY(hipMemsetAsync(L->dc[l], 0, (size_t)B * H * 4, s));
+        CK(hsad_lstm_backward_chunk_multi(1, T, B, H, &r, L->sync1, nullptr, stream));
+      } else {
+        CK(hsad_lstm_layer_backward(T, B, H, L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], L->dO[l], L->dG[l], L->dc[l], L->sync1, stream));
+      }
+      if (l > 0)
+        CK(hsad_gemm_nt_bf16_ex(L->dG[l], H4, on->WihT[l], H4, M, H, H4, nullptr, L->dO[l - 1], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+      CK(layer_wgrad(l, l ? hs_x[l - 1] : xinT, l ? ldh : Mp));
     }
   }
-  CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->x1[0], H, nullptr, stream));
-  if (M % 4 == 0 && H % 4 == 0) {
-    CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, g[P_B1], nullptr, nullptr, stream));
+  // the input MLP: d(last fc output) = dG_0 W_ih0 masked by its ReLU, then one (bias column sum, weight gradient) per fc layer
+  if (pipe) HIP_TRY(hipStreamWaitEvent(s, L->ev_d, 0));
+  bf16_t* dxl = nfc == 2 ? L->dx2 : L->dx1;
+  bf16_t* dxlT = nfc == 2 ? L->dx2T : L->dx1T;
+  CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, dxl, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
+  const bool fast_cs = M % 4 == 0 && H % 4 == 0;
+  if (nfc == 2) {
+    if (fast_cs) {
+      CK(transpose16(dxl, M, H, H, dxlT, Mp, g[on->iB2], nullptr, nullptr, stream));
+    } else {
+      CK(transpose16(dxl, M, H, H, dxlT, Mp, nullptr, nullptr, nullptr, stream));
+      CK(hsad_colsum_acc(dxl, 1, M, H, H, g[on->iB2], nullptr, nullptr, stream));
+    }
+    CK(hsad_gemm_nt_bf16_ex(dxlT, Mp, L->x1T, Mp, H, H, Mp, nullptr, g[on->iW2], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+    CK(hsad_gemm_nt_bf16_ex(dxl, H, on->W2T, H, M, H, H, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->x1[0], H, nullptr, stream));
+  }
+  if (fast_cs) {
+    CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, g[on->iB1], nullptr, nullptr, stream));
   } else {
     CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, nullptr, nullptr, nullptr, stream));
-    CK(hsad_colsum_acc(L->dx1, 1, M, H, H, g[P_B1], nullptr, nullptr, stream));
+    CK(hsad_colsum_acc(L->dx1, 1, M, H, H, g[on->iB1], nullptr, nullptr, stream));
   }
-  CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[P_W1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+  CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
   if (pipe) {
     HIP_TRY(hipEventRecord(L->ev_a, ws));
     HIP_TRY(hipStreamWaitEvent(s, L->ev_a, 0));

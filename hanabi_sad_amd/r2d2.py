@@ -323,8 +323,9 @@ class R2D2NetKernels:
     def _check_shape(w):
         extra = [k for k in w if k.startswith("lstm.") and k[-1] not in "01"] + [k for k in w if k.startswith("net.") and not k.startswith("net.0.")]
         if extra:
-            raise _lib.HsadError("the R2D2 kernels support the reference default shape only (1 fc layer, 2 LSTM layers); "
-                                 "unexpected parameters: %s" % extra)
+            raise _lib.HsadError("the Python-orchestrated bf16 schedule (R2D2NetKernels / R2D2Learner, the A/B twin of the library's composite "
+                                 "entry points) is written for the reference default shape (1 fc layer, 2 LSTM layers); other architectures "
+                                 "run through composite.CNet / CompositeAgent / CompositeLearner or precision='fp32'.  Unexpected: %s" % extra)
 
     @staticmethod
     def make(weights, device="cuda:0", precision="bf16", **kw):
@@ -487,7 +488,22 @@ def td_loss(online_qa, target_qa, reward, bootstrap, seq_len, multi_step, gamma,
 PARAM_ORDER = ["net.0.weight", "net.0.bias",
                "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
                "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "lstm.bias_hh_l1",
-               "fc_a.weight", "fc_v.weight", "pred.weight", "fc_a.bias", "fc_v.bias", "pred.bias"]   # heads contiguous
+               "fc_a.weight", "fc_v.weight", "pred.weight", "fc_a.bias", "fc_v.bias", "pred.bias"]
+
+
+def arch_of(weights):
+    """(num_fc_layer, num_lstm_layer) read off R2D2Net state_dict keys (net.2.* = a second fc layer; lstm.*_l{k})"""
+    return (2 if "net.2.weight" in weights else 1), len([k for k in weights if k.startswith("lstm.weight_ih_l")])
+
+
+def param_order(num_fc_layer=1, num_lstm_layer=2):
+    """state_dict names of R2D2Net(num_lstm_layer, num_fc_layer) in the order of the library's flat parameter vector
+    (PARAM_ORDER = param_order(1, 2))"""
+    names = ["net.0.weight", "net.0.bias"] + (["net.2.weight", "net.2.bias"] if num_fc_layer == 2 else [])
+    for l in range(num_lstm_layer):
+        names += ["lstm.%s_l%d" % (k, l) for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    return names + ["fc_a.weight", "fc_v.weight", "pred.weight", "fc_a.bias", "fc_v.bias", "pred.bias"]
+   # heads contiguous
 
 
 def gemm_nt_ex(A16, B16, M, N, K, out32=None, out16=None, split_k=1, relu_mask=None, accumulate=False, row_map=None):
@@ -529,12 +545,15 @@ class R2D2Learner:
     clip + Adam), sync_target_with_online().  IQL batches [T,B,*] and VDN batches [T,B,P,*] (Q summed over players)."""
 
     def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0,
-                 device="cuda:0", precision="bf16"):
+                 device="cuda:0", precision="bf16", skip_connect=False):
         self.device = torch.device(device)
         self.precision = precision
         self.multi_step, self.gamma = int(multi_step), float(gamma)
         self.lr, self.eps, self.grad_clip = float(lr), float(eps), float(grad_clip)
-        # flat fp32 master parameters with named views (same names / shapes as R2D2Net.state_dict())
+        # flat fp32 master parameters with named views (same names / shapes as R2D2Net.state_dict()); the architecture (1-2 fc layers,
+        # 1-3 LSTM layers) is read off the weight names -- fp32 mode runs any of them, the bf16 Python schedule the default one
+        PARAM_ORDER = param_order(*arch_of(online_weights))
+        kw = {"skip_connect": skip_connect} if precision == "fp32" else {}
         sizes = [online_weights[k].numel() for k in PARAM_ORDER]
         self.flat = torch.empty(sum(sizes), dtype=torch.float32, device=self.device)
         self.gflat = torch.zeros_like(self.flat)
@@ -548,7 +567,8 @@ class R2D2Learner:
             gviews[k] = self.gflat[off:off + n].view(shape)
             views[k].copy_(online_weights[k])
             off += n
-        self.online = R2D2NetKernels.make(views, device, precision, with_transposes=True)
+        self.online = R2D2NetKernels.make(views, device, precision, with_transposes=True, **kw)
+        self.param_names = PARAM_ORDER
         self.online.w = views           # the kernels' fp32 master weights ARE the flat buffer
         self.online.refresh()
         self.grad = gviews
@@ -557,7 +577,7 @@ class R2D2Learner:
         NH, Hh = self.online.NH, self.online.H
         self.g_wheads = self.gflat[o0:o0 + NH * Hh].view(NH, Hh)
         self.g_bheads = self.gflat[o0 + NH * Hh:o0 + NH * Hh + NH]
-        self.target = R2D2NetKernels.make(target_weights, device, precision)
+        self.target = R2D2NetKernels.make(target_weights, device, precision, **kw)
         self.step_count = 0
         self.persistent = True   # one-launch weight-stationary recurrences (False = one launch per step)
         self.wgrad_split = 8     # split-K factor of the weight-gradient GEMMs (contraction over T*B)
@@ -586,7 +606,7 @@ class R2D2Learner:
         return c
 
     def sync_target_with_online(self):
-        for k in PARAM_ORDER:
+        for k in self.param_names:
             self.target.w[k].copy_(self.online.w[k])
         self.target.refresh()
 
@@ -875,12 +895,16 @@ class R2D2Agent:
         return (net.Wcat16 is not None and net.WihT is None and priv_s.shape[0] >= 1024 and h0.is_contiguous()
                 and c0.is_contiguous())
 
-    def _adv(self, net, priv_s, h0, c0, pre=None, want_state=True):
+    def _adv(self, net, priv_s, h0, c0, pre=None, want_state=True, skip=False):
+        """skip: this is R2D2Net.act (r2d2.py:65-78), which adds the skip connection o + x of a skip_connect net; forward() --
+        q_of / compute_priority -- does not"""
         self._h16 = None
         if self._fused(net, priv_s, h0, c0):
             o, h, c, self._h16 = net.step(priv_s, h0, c0, pre, want_state)   # big batches: fused GEMM + cell kernel per layer
             return net.heads(o), h, c
         o, h, c = net.trunk(priv_s.unsqueeze(0), h0, c0)
+        if skip and getattr(net, "skip", False):
+            o = o + net.last_x
         return net.heads(o.reshape(priv_s.shape[0], net.H)), h, c
 
     def act(self, obs, hid, with_q=False):
@@ -896,7 +920,10 @@ class R2D2Agent:
         pre = None
         if with_q and self._fused(on, obs["priv_s"], hid["h0"], hid["c0"]) and (on.Fp, on.H, on.L) == (tg.Fp, tg.H, tg.L):
             pre = on.precast(obs["priv_s"], hid["h0"], hid.get("h0_16"))   # both nets read the same bf16 operands
-        hd, h, c = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"], pre)
+        if with_q and getattr(on, "skip", False):
+            raise _lib.HsadError("cached Q-values are undefined for a skip_connect net (R2D2Net.act adds the skip connection, forward "
+                                 "ignores it); use compute_priority")
+        hd, h, c = self._adv(on, obs["priv_s"], hid["h0"], hid["c0"], pre, skip=True)
         new_hid = {"h0": h, "c0": c}
         if self._h16 is not None:
             new_hid["h0_16"] = self._h16     # bf16(h0), written by the cell kernels anyway; zero_hidden_rows keeps it in step
@@ -949,7 +976,7 @@ class R2D2Agent:
             na = next_greedy_a.contiguous().view(-1)
             assert na.dtype == torch.int64 and na.shape[0] == n
         else:
-            nhd, _, _ = self._adv(on, next_obs["priv_s"], next_hid["h0"], next_hid["c0"])
+            nhd, _, _ = self._adv(on, next_obs["priv_s"], next_hid["h0"], next_hid["c0"], skip=True)     # greedy_act = R2D2Net.act
             na = torch.empty(n, dtype=torch.int64, device=d)
             junk = torch.empty(n, dtype=torch.int64, device=d)
             scratch = torch.empty(2 + (n + 255) // 256, dtype=torch.float32, device=d)

@@ -34,19 +34,21 @@ class R2D2NetF32:
 
     precision = "fp32"
 
-    def __init__(self, weights, device="cuda:0", with_transposes=False):
-        from .r2d2 import R2D2NetKernels
+    def __init__(self, weights, device="cuda:0", with_transposes=False, skip_connect=False):
+        """any R2D2Net(num_lstm_layer, num_fc_layer, skip_connect) (pyhanabi/r2d2.py:22-57): the layer counts are read off the weight
+        names; skip_connect applies in act only, like in the reference (r2d2.py:74-75; forward ignores it)"""
+        from .r2d2 import arch_of
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.HsadError("R2D2NetF32 needs a ROCm device; there is no CPU path")
         self.lib = _lib.load_library()
         self.w = {k: v.detach().to(self.device, torch.float32).clone().contiguous() for k, v in weights.items()}
-        R2D2NetKernels._check_shape(self.w)
         self.H = self.w["fc_v.weight"].shape[1]
         self.F = self.w["net.0.weight"].shape[1]
         self.A = self.w["fc_a.weight"].shape[0]
         self.NP = self.w["pred.weight"].shape[0]
-        self.L = 2
+        self.nfc, self.L = arch_of(self.w)
+        self.skip = bool(skip_connect)
         self.NH = self.A + 1 + self.NP
         self.Fp = self.F
         self.Wcat16 = self.WihT = None        # R2D2Agent: no fused bf16 cell path here
@@ -72,6 +74,11 @@ class R2D2NetF32:
         gemm_f32(priv, w["net.0.weight"], M, H, F, x1, bias=w["net.0.bias"], relu=True)
         inp = x1
         saved = {"priv": priv, "x1": x1, "gates": [], "hseq": [], "cseq": []}
+        if self.nfc == 2:
+            x2 = torch.empty(M, H, dtype=torch.float32, device=d)
+            gemm_f32(x1, w["net.2.weight"], M, H, H, x2, bias=w["net.2.bias"], relu=True)
+            inp = saved["x2"] = x2
+        self.last_x = inp.view(T, N, H)      # R2D2Net.act's skip connection adds it to the LSTM output
         h_new = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
         c_new = torch.empty(self.L, N, H, dtype=torch.float32, device=d)
         for l in range(self.L):
@@ -167,11 +174,13 @@ def loss_f32(lr, batch, weight, pred_weight=0.0, compute_grad=True):
     # heads: dO1 = dheads Wheads; dWheads = dheads^T o1; db = column sums
     dO = torch.empty(M, H, dtype=torch.float32, device=d)
     gemm_f32(dheads, on.Wheads, M, H, NH, dO, b_strides=(1, H))
-    gemm_f32(dheads, hseq[1], NH, H, M, lr.g_wheads, a_strides=(1, NH), b_strides=(1, H))
+    NL = on.L
+    gemm_f32(dheads, hseq[NL - 1], NH, H, M, lr.g_wheads, a_strides=(1, NH), b_strides=(1, H))
     colsum(dheads, out=lr.g_bheads)
-    layer_in = [keep["x1"], hseq[0]]
+    xin = keep["x2"] if on.nfc == 2 else keep["x1"]
+    layer_in = [xin] + hseq[:NL - 1]
     dx1 = None
-    for l in (1, 0):
+    for l in range(NL - 1, -1, -1):
         Wih, Whh = w["lstm.weight_ih_l%d" % l], w["lstm.weight_hh_l%d" % l]
         gates, cseq = keep["gates"][l], keep["cseq"][l]
         dG = torch.empty(T, B, 4 * H, dtype=torch.float32, device=d)
@@ -192,12 +201,18 @@ def loss_f32(lr, batch, weight, pred_weight=0.0, compute_grad=True):
         db = colsum(dG2)
         g["lstm.bias_ih_l%d" % l].copy_(db)
         g["lstm.bias_hh_l%d" % l].copy_(db)
-        if l == 1:
+        if l > 0:
             dO = torch.empty(M, H, dtype=torch.float32, device=d)
             gemm_f32(dG2, Wih, M, H, 4 * H, dO, b_strides=(1, H))
         else:
             dx1 = torch.empty(M, H, dtype=torch.float32, device=d)
-            gemm_f32(dG2, Wih, M, H, 4 * H, dx1, b_strides=(1, H), relu_mask=keep["x1"])
+            gemm_f32(dG2, Wih, M, H, 4 * H, dx1, b_strides=(1, H), relu_mask=xin)
+    if on.nfc == 2:      # second fc layer: dW2 = dx2^T x1, db2, dx1 = (dx2 W2) masked by x1's ReLU
+        dx2 = dx1
+        gemm_f32(dx2, keep["x1"], H, H, M, g["net.2.weight"], a_strides=(1, H), b_strides=(1, H))
+        colsum(dx2, out=g["net.2.bias"])
+        dx1 = torch.empty(M, H, dtype=torch.float32, device=d)
+        gemm_f32(dx2, w["net.2.weight"], M, H, H, dx1, b_strides=(1, H), relu_mask=keep["x1"])
     gemm_f32(dx1, keep["priv"], H, on.F, M, g["net.0.weight"], a_strides=(1, H), b_strides=(1, on.F))
     colsum(dx1, out=g["net.0.bias"])
     return loss, prio

@@ -185,9 +185,10 @@ class BatchRunner:
 
     @staticmethod
     def _kernel_shape(on):
-        """the default R2D2Net (1 fc layer, 2 LSTM layers, dueling + aux heads: pyhanabi/r2d2.py:22-57) and nothing else"""
-        from .r2d2 import PARAM_ORDER
-        return set(on) == set(PARAM_ORDER)
+        """an R2D2Net state_dict (1-2 fc layers, 1-3 LSTM layers, dueling + aux heads: pyhanabi/r2d2.py:22-57) and nothing else"""
+        from .r2d2 import arch_of, param_order
+        nfc, nl = arch_of(on)
+        return 1 <= nl <= 3 and set(on) == set(param_order(nfc, nl))
 
     def update_model(self, py_model):
         """BatchRunner::updateModel (rela/batch_runner.h:74-77)"""
@@ -214,7 +215,8 @@ class BatchRunner:
                 return
             if self.online is None:
                 from .composite import CNet
-                self.online, self.target = CNet(on, self.device), CNet(tg, self.device)    # library-owned nets (composite ABI)
+                skip = bool(getattr(getattr(py_model, "online_net", None), "skip_connect", False))
+                self.online, self.target = CNet(on, self.device, skip_connect=skip), CNet(tg, self.device, skip_connect=skip)    # library-owned nets
                 return
             for net, sd in ((self.online, on), (self.target, tg)):
                 for k, v in sd.items():

@@ -16,7 +16,7 @@ import torch
 
 from .actor import DeviceActor, transition_fields
 from .env import BatchedHanabiEnv
-from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2Learner, R2D2NetKernels, check_sync
+from .r2d2 import PARAM_ORDER, R2D2Agent, R2D2Learner, R2D2NetKernels, arch_of, check_sync, param_order
 from .replay import DeviceReplay, aggregate_priority
 
 
@@ -31,7 +31,7 @@ def generate_explore_eps(base_eps, alpha, num_env):
     return out
 
 
-def init_weights(in_dim, hid_dim, out_dim, hand_size, seed):
+def init_weights(in_dim, hid_dim, out_dim, hand_size, seed, num_lstm_layer=2, num_fc_layer=1):
     """random-init R2D2Net parameters with nn.Linear / nn.LSTM's default U(-1/sqrt(fan), 1/sqrt(fan)) init,
     keyed like the reference state_dict (so `.pthw` checkpoints are interchangeable)"""
     g = torch.Generator(device="cpu").manual_seed(seed)
@@ -40,7 +40,9 @@ def init_weights(in_dim, hid_dim, out_dim, hand_size, seed):
     W = {"net.0.weight": u((H, in_dim), in_dim), "net.0.bias": u((H,), in_dim),
          "fc_v.weight": u((1, H), H), "fc_v.bias": u((1,), H), "fc_a.weight": u((out_dim, H), H),
          "fc_a.bias": u((out_dim,), H), "pred.weight": u((hand_size * 3, H), H), "pred.bias": u((hand_size * 3,), H)}
-    for l in range(2):
+    if num_fc_layer == 2:
+        W["net.2.weight"], W["net.2.bias"] = u((H, H), H), u((H,), H)
+    for l in range(num_lstm_layer):
         for k in ("weight_ih", "weight_hh"):
             W["lstm.%s_l%d" % (k, l)] = u((4 * H, H), H)
         for k in ("bias_ih", "bias_hh"):
@@ -59,7 +61,8 @@ class Trainer:
                                     seed=args.seed + rank * args.num_game, bomb=args.train_bomb, eps_list=eps,
                                     max_len=args.max_len, sad=bool(args.sad), shuffle_color=bool(args.shuffle_color),
                                     device=device, track_deck_history=False)
-        W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed)
+        W = init_weights(self.env.F, args.rnn_hid_dim, self.env.A, args.hand_size, args.seed, num_lstm_layer=args.num_lstm_layer)
+        self.param_names = list(param_order(1, args.num_lstm_layer))
         # only the learner rank holds optimizer state; actor ranks receive parameters by broadcast
         # bf16 (production): agent and learner are the library's composite entry points (include/hsad.h hsad_r2d2_*: the whole
         # kernel schedule behind one C call each); fp32 (exact mode): the same schedule orchestrated from r2d2.py / r2d2_f32.py
@@ -97,7 +100,7 @@ class Trainer:
 
     def update_actor_model(self):
         if self.learner is not None:
-            for k in PARAM_ORDER:
+            for k in self.param_names:
                 self.act_online.w[k].copy_(self.learner.online.w[k])
                 self.act_target.w[k].copy_(self.learner.target.w[k])
         self.act_online.refresh()
@@ -206,20 +209,22 @@ def parse_args(argv=None):
         args.num_game = args.num_thread * args.num_game_per_thread
     if args.shuffle_obs:
         raise SystemExit("--shuffle_obs is not supported (selfplay.py:175 asserts it off)")
-    if args.num_lstm_layer != 2:
-        raise SystemExit("--num_lstm_layer: the kernels implement the reference default of 2 layers")
+    if not 1 <= args.num_lstm_layer <= 3:
+        raise SystemExit("--num_lstm_layer: 1, 2 or 3 (nn.LSTM(num_layers), pyhanabi/selfplay.py:50)")
+    if args.num_lstm_layer != 2 and getattr(args, "python_schedule", 0):
+        raise SystemExit("--python_schedule 1 (the A/B twin of the composite entry points) is written for 2 LSTM layers")
     return args
 
 
 # ---- several GPUs: a dedicated learner rank and free-running actor ranks joined by dist.ReplayLink -------------------------------
 def make_link(tr, args):
     from .dist import ReplayLink
-    n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else sum(tr.act_online.w[k].numel() for k in PARAM_ORDER)
+    n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else sum(v.numel() for v in tr.act_online.w.values())
     return ReplayLink(tr.replay, args.batchsize, args.priority_weight, tr.device, learner_rank=0, depth=2, param_numel=2 * n)
 
 
 def _flat_of(net):
-    return net.flat if hasattr(net, "flat") else torch.cat([net.w[k].reshape(-1) for k in PARAM_ORDER])
+    return net.flat if hasattr(net, "flat") else torch.cat([net.w[k].reshape(-1) for k in param_order(*arch_of(net.w))])
 
 
 def _load_flat(net, flat):
@@ -227,7 +232,7 @@ def _load_flat(net, flat):
         net.flat.copy_(flat)
     else:
         off = 0
-        for k in PARAM_ORDER:
+        for k in param_order(*arch_of(net.w)):
             n = net.w[k].numel()
             net.w[k].copy_(flat[off:off + n].view_as(net.w[k]))
             off += n
@@ -373,7 +378,7 @@ def run_epochs(tr, args, rank=0, link=None):
         saved = False
         if saver is not None:
             force = "model_epoch%d" % epoch if (epoch > 0 and epoch % 50 == 0) else None
-            sd = {k: tr.learner.online.w[k].detach().cpu().clone() for k in PARAM_ORDER}
+            sd = {k: tr.learner.online.w[k].detach().cpu().clone() for k in tr.param_names}
             saved = saver.save(None, sd, score, force_save_name=force)
         print("epoch %d, eval score: %.4f, perfect: %.2f, model saved: %s" % (epoch, score, perfect * 100, saved))
         print("==========")

@@ -540,6 +540,16 @@ typedef struct hsad_r2d2_learner hsad_r2d2_learner;
 /* R2D2Net(in_dim, hid_dim, out_dim = num_action, 2 LSTM layers, hand_size) (pyhanabi/r2d2.py:22-57).  with_backward = 1: the
  * learner's online net (keeps transposed operands; never steps single rows), 0: acting / target nets. */
 int hsad_r2d2_net_create(int in_dim, int hid_dim, int num_action, int hand_size, int with_backward, int device, hsad_r2d2_net** out);
+/* The general R2D2Net(…, num_lstm_layer, hand_size, num_fc_layer, skip_connect) (pyhanabi/r2d2.py:22-57): num_fc_layer 1..2 (net.0 /
+ * net.2), num_lstm_layer 1..3 (--num_lstm_layer, selfplay.py:50), skip_connect = `o + x` in R2D2Net.act ONLY (r2d2.py:74-75;
+ * R2D2Net.forward -- compute_priority, td_error, the learner -- ignores it in the reference, and so does this library).  The
+ * Other-Play zoo models M3..M11 (pyhanabi/utils.py:46-57) are (1 fc, skip), (2 fc), (2 fc, skip).  hsad_r2d2_net_create = (1, 2, 0).
+ * Parameter tensors: hsad_r2d2_net_num_params / _param_name (state_dict names; the flat vector holds them in that order). */
+int hsad_r2d2_net_create_ex(int in_dim, int hid_dim, int num_action, int hand_size, int num_fc_layer, int num_lstm_layer, int skip_connect,
+                            int with_backward, int device, hsad_r2d2_net** out);
+int hsad_r2d2_net_num_params(const hsad_r2d2_net* net);
+const char* hsad_r2d2_net_param_name(const hsad_r2d2_net* net, int i);
+int hsad_r2d2_net_arch(const hsad_r2d2_net* net, int32_t* num_fc_layer, int32_t* num_lstm_layer, int32_t* skip_connect);
 void hsad_r2d2_net_destroy(hsad_r2d2_net* net);
 int hsad_r2d2_num_params(void);                 /* 16 tensors */
 const char* hsad_r2d2_param_name(int i);        /* "net.0.weight", ..., "pred.bias" */

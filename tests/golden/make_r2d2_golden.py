@@ -65,10 +65,13 @@ def state_arrays(agent):
     return {"w." + k: v.detach().cpu().numpy() for k, v in agent.state_dict().items()}
 
 
-def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, pred_weight=0.25, seed=0):
+def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, pred_weight=0.25, seed=0, num_lstm_layer=2, num_fc_layer=1,
+             skip_connect=False):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
-    agent = r2d2.R2D2Agent(vdn, multi_step, gamma, 0.9, "cpu", F, HID, A, 2, hand, False)
+    NLL = num_lstm_layer
+    agent = r2d2.R2D2Agent(vdn, multi_step, gamma, 0.9, "cpu", F, HID, A, NLL, hand, False, num_fc_layer=num_fc_layer,
+                           skip_connect=skip_connect)
     # decorrelate target from online so the double-DQN path is exercised
     with torch.no_grad():
         for p in agent.target_net.parameters():
@@ -76,6 +79,7 @@ def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, p
     out = dict(state_arrays(agent))
     out["meta"] = np.array([int(vdn), F, A, HID, T, B, G, hand, multi_step], np.int64)
     out["gamma"] = np.array([gamma], np.float64)
+    out["arch"] = np.array([num_lstm_layer, num_fc_layer, int(skip_connect)], np.int64)
     P = 2
 
     # ---- act (eps = 0 -> deterministic greedy branch; r2d2.py:247-303) ----
@@ -91,8 +95,8 @@ def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, p
         legal[..., 0] = 1
         eps = np.zeros((G, 1), np.float32)
         nh = G
-    h0 = (rng.standard_normal((G, nh // G, 2, HID)) * 0.3).astype(np.float32)
-    c0 = (rng.standard_normal((G, nh // G, 2, HID)) * 0.3).astype(np.float32)
+    h0 = (rng.standard_normal((G, nh // G, NLL, HID)) * 0.3).astype(np.float32)
+    c0 = (rng.standard_normal((G, nh // G, NLL, HID)) * 0.3).astype(np.float32)
     obs = {"priv_s": torch.tensor(priv), "legal_move": torch.tensor(legal), "eps": torch.tensor(eps),
            "h0": torch.tensor(h0), "c0": torch.tensor(c0)}
     with torch.no_grad():
@@ -166,5 +170,16 @@ def run_case(name, vdn, F, A, HID, T, B, G, hand=5, multi_step=3, gamma=0.999, p
 
 
 if __name__ == "__main__":
-    run_case("r2d2_iql_sad_small", False, 838, 21, 64, 12, 6, 10, seed=1)
-    run_case("r2d2_vdn_small", True, 783, 21, 64, 9, 4, 5, seed=2)
+    only = sys.argv[1:]
+    cases = {
+        "r2d2_iql_sad_small": lambda n: run_case(n, False, 838, 21, 64, 12, 6, 10, seed=1),
+        "r2d2_vdn_small": lambda n: run_case(n, True, 783, 21, 64, 9, 4, 5, seed=2),
+        # round 3: the architectures utils.load_op_model / --num_lstm_layer construct (r2d2.py:22-57, utils.py:46-57, selfplay.py:50)
+        "r2d2_fc2_skip_small": lambda n: run_case(n, False, 783, 21, 64, 10, 6, 8, seed=3, num_fc_layer=2, skip_connect=True),
+        "r2d2_skip_small": lambda n: run_case(n, False, 783, 21, 64, 8, 4, 8, seed=4, skip_connect=True),
+        "r2d2_lstm1_small": lambda n: run_case(n, False, 838, 21, 64, 10, 6, 8, seed=5, num_lstm_layer=1),
+        "r2d2_lstm3_fc2_small": lambda n: run_case(n, False, 838, 21, 64, 8, 4, 6, seed=6, num_lstm_layer=3, num_fc_layer=2),
+    }
+    for name, fn in cases.items():
+        if not only or name in only:
+            fn(name)

@@ -16,11 +16,15 @@ def weights_from_npz(z, prefix):
     return out
 
 
-def lstm(W, x, h0, c0, num_layer=2):
+def num_layers(W):
+    return len([k for k in W if k.startswith("lstm.weight_ih_l")])
+
+
+def lstm(W, x, h0, c0):
     """x [T,N,H]; h0/c0 [L,N,H] -> o [T,N,H], h [L,N,H], c [L,N,H]; gate order i,f,g,o like torch.nn.LSTM."""
     hs, cs = [], []
     inp = x
-    for l in range(num_layer):
+    for l in range(num_layers(W)):
         wih, whh = W["lstm.weight_ih_l%d" % l], W["lstm.weight_hh_l%d" % l]
         b = W["lstm.bias_ih_l%d" % l] + W["lstm.bias_hh_l%d" % l]
         h, c = h0[l], c0[l]
@@ -37,14 +41,23 @@ def lstm(W, x, h0, c0, num_layer=2):
     return inp, torch.stack(hs, 0), torch.stack(cs, 0)
 
 
+def mlp(W, priv_s):
+    x = F.relu(priv_s @ W["net.0.weight"].t() + W["net.0.bias"])          # r2d2.py:42-46
+    if "net.2.weight" in W:                                               # num_fc_layer = 2
+        x = F.relu(x @ W["net.2.weight"].t() + W["net.2.bias"])
+    return x
+
+
 def trunk(W, priv_s, h0, c0):
-    x = F.relu(priv_s @ W["net.0.weight"].t() + W["net.0.bias"])          # r2d2.py:42-46 (num_fc_layer = 1)
-    return lstm(W, x, h0, c0)
+    return lstm(W, mlp(W, priv_s), h0, c0)
 
 
-def net_act(W, priv_s, h0, c0):
-    """R2D2Net.act (r2d2.py:65-78): priv_s [N,F] -> advantage [N,A], new hidden."""
-    o, h, c = trunk(W, priv_s.unsqueeze(0), h0, c0)
+def net_act(W, priv_s, h0, c0, skip_connect=False):
+    """R2D2Net.act (r2d2.py:65-78): priv_s [N,F] -> advantage [N,A], new hidden.  skip_connect applies HERE only (forward ignores it)."""
+    x = mlp(W, priv_s.unsqueeze(0))
+    o, h, c = lstm(W, x, h0, c0)
+    if skip_connect:
+        o = o + x
     return (o @ W["fc_a.weight"].t() + W["fc_a.bias"]).squeeze(0), h, c
 
 
@@ -60,15 +73,15 @@ def net_forward(W, priv_s, legal_move, action, h0, c0):
     return qa, legal_q.argmax(2), q, o
 
 
-def greedy_act(W, priv_s, legal_move, h0, c0):
-    adv, h, c = net_act(W, priv_s, h0, c0)
+def greedy_act(W, priv_s, legal_move, h0, c0, skip_connect=False):
+    adv, h, c = net_act(W, priv_s, h0, c0, skip_connect)
     legal_adv = (1 + adv - adv.min()) * legal_move                            # r2d2.py:242
     return legal_adv.argmax(1), h, c
 
 
 def zeros_hid(W, n, like):
     H = W["fc_v.weight"].shape[1]
-    z = torch.zeros(2, n, H, dtype=like.dtype, device=like.device)
+    z = torch.zeros(num_layers(W), n, H, dtype=like.dtype, device=like.device)
     return z, z.clone()
 
 
@@ -118,10 +131,10 @@ def loss(Won, Wtg, batch, multi_step, gamma, pred_weight):
 
 
 def compute_priority(Won, Wtg, priv_s, legal_move, a, next_priv_s, next_legal_move, h0, c0, next_h0, next_c0, reward,
-                     bootstrap, multi_step, gamma, num_player=1):
+                     bootstrap, multi_step, gamma, num_player=1, skip_connect=False):
     """R2D2Agent.compute_priority, IQL, flat [N,*] inputs with hidden [L,N,H] (r2d2.py:305-361)."""
     qa, _, _, _ = net_forward(Won, priv_s.unsqueeze(0), legal_move.unsqueeze(0), a.unsqueeze(0), h0, c0)
-    next_a, _, _ = greedy_act(Won, next_priv_s, next_legal_move, next_h0, next_c0)
+    next_a, _, _ = greedy_act(Won, next_priv_s, next_legal_move, next_h0, next_c0, skip_connect)
     tqa, _, _, _ = net_forward(Wtg, next_priv_s.unsqueeze(0), next_legal_move.unsqueeze(0), next_a.unsqueeze(0), next_h0,
                                next_c0)
     qa, tqa = qa.squeeze(0), tqa.squeeze(0)

@@ -93,3 +93,37 @@ def test_vdn_act_priority_loss_and_gradients_match_reference():
     for k, v in Won.items():
         g_ = v.grad if v.grad is not None else torch.zeros_like(v)
         assert np.allclose(g_.numpy(), z["loss.rl.grad.%s" % k], rtol=1e-4, atol=1e-6), k
+
+
+ARCH_CASES = ["r2d2_fc2_skip_small", "r2d2_skip_small", "r2d2_lstm1_small", "r2d2_lstm3_fc2_small"]
+
+
+@pytest.mark.parametrize("name", ARCH_CASES)
+def test_other_architectures_match_reference(name):
+    """R2D2Net(num_lstm_layer 1-3, num_fc_layer 1-2, skip_connect) as utils.load_op_model / --num_lstm_layer construct them
+    (r2d2.py:22-57, utils.py:46-57, selfplay.py:50): act applies the skip connection, forward does not"""
+    z = load(name)
+    nl, nfc, skip = (int(v) for v in z["arch"])
+    Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
+    assert ref.num_layers(Won) == nl and ("net.2.weight" in Won) == (nfc == 2)
+    meta = z["meta"]
+    f = lambda k: torch.tensor(z[k]).flatten(0, 1)
+    g, h, c = ref.greedy_act(Won, f("act.priv_s"), f("act.legal_move"), hid_to_LNH(z["act.h0"]), hid_to_LNH(z["act.c0"]), bool(skip))
+    assert np.array_equal(g.numpy(), z["act.out_greedy_a"].reshape(-1))
+    G = g.shape[0]
+    assert np.allclose(h.transpose(0, 1).numpy(), z["act.out_h0"].reshape(G, nl, -1), **TOL)
+    p = ref.compute_priority(Won, Wtg, f("act.priv_s"), f("act.legal_move"), f("prio.a"), f("prio.next_priv_s"),
+                             f("prio.next_legal_move"), hid_to_LNH(z["act.h0"]), hid_to_LNH(z["act.c0"]),
+                             hid_to_LNH(z["prio.next_h0"]), hid_to_LNH(z["prio.next_c0"]), f("prio.reward"),
+                             f("prio.bootstrap"), int(meta[8]), float(z["gamma"][0]), skip_connect=bool(skip))
+    assert np.allclose(p.numpy(), z["prio.out"].reshape(-1), **TOL)
+    for v in Won.values():
+        v.requires_grad_(True)
+    batch = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("loss.") and k.count(".") == 1}
+    loss, prio = ref.loss(Won, Wtg, batch, int(meta[8]), float(z["gamma"][0]), 0.25)
+    assert np.allclose(loss.detach().numpy(), z["loss.aux.loss"], **TOL)
+    assert np.allclose(prio.detach().numpy(), z["loss.aux.priority"], **TOL)
+    (loss * batch["weight"]).mean().backward()
+    for k, v in Won.items():
+        g_ = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert np.allclose(g_.numpy(), z["loss.aux.grad.%s" % k], rtol=1e-4, atol=1e-6), k
