@@ -476,8 +476,8 @@ struct RefreshBiasJob {
   int n, block0;
 };
 struct RefreshJobs {
-  RefreshWeightJob w[12];
-  RefreshBiasJob b[8];
+  RefreshWeightJob w[20];
+  RefreshBiasJob b[12];
   int nw, nb, weight_tiles, total_blocks;
 };
 __global__ __launch_bounds__(256) void refresh_jobs_kernel(RefreshJobs J) {
@@ -2762,6 +2762,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     int chunk = ((K / kBK + split_k - 1) / split_k) * kBK;
     g.k_chunk = chunk;
     gz = (K + chunk - 1) / chunk;
+    if (gz == 1) g.k_chunk = 0;      // one k range after all (K <= 64 x split): a plain GEMM, not a one-slab atomic accumulation
   }
   g.gz = gz;
   g.slab_stride = gz > 1 ? slab_stride : 0;
@@ -2913,8 +2914,8 @@ int hsad_refresh_begin() {
 int hsad_refresh_add_weight(const float* src, int R, int C, int ld_src, const int32_t* perm, void* dst16, int ld_dst, void* dstT16,
                             int ld_dstT) {
   RefreshJobs& J = g_refresh.J;
-  if (!src || (!dst16 && !dstT16) || R <= 0 || C <= 0 || J.nw >= 12 || J.nb != 0)
-    return nfail(HSAD_ERR_INVALID, "refresh_add_weight: bad arguments, more than 12 matrices, or a weight after a bias");
+  if (!src || (!dst16 && !dstT16) || R <= 0 || C <= 0 || J.nw >= 20 || J.nb != 0)
+    return nfail(HSAD_ERR_INVALID, "refresh_add_weight: bad arguments, more than 20 matrices, or a weight after a bias");
   RefreshWeightJob& q = J.w[J.nw++];
   q = RefreshWeightJob{src, perm, (bf16_t*)dst16, (bf16_t*)dstT16, R, C, ld_src, ld_dst, ld_dstT, (C + 31) / 32, J.weight_tiles};
   J.weight_tiles += q.tiles_c * ((R + 31) / 32);
@@ -2923,7 +2924,7 @@ int hsad_refresh_add_weight(const float* src, int R, int C, int ld_src, const in
 }
 int hsad_refresh_add_bias(const float* a, const float* b, const int32_t* perm, float* out, int n) {
   RefreshJobs& J = g_refresh.J;
-  if (!a || !out || n <= 0 || J.nb >= 8) return nfail(HSAD_ERR_INVALID, "refresh_add_bias: bad arguments or more than 8 biases");
+  if (!a || !out || n <= 0 || J.nb >= 12) return nfail(HSAD_ERR_INVALID, "refresh_add_bias: bad arguments or more than 12 biases");
   RefreshBiasJob& q = J.b[J.nb++];
   q = RefreshBiasJob{a, b, perm, out, n, J.total_blocks - J.weight_tiles};
   J.total_blocks += (n + 255) / 256;

@@ -29,6 +29,35 @@ def test_agent_loaded_from_a_reference_checkpoint_acts_like_the_reference(precis
     assert len(load_sad_model([os.path.join(GOLD, "ref_small.pthw")] * 2, DEV)) == 2
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_load_op_model_runs_every_architecture_class_of_the_zoo(precision):
+    """utils.load_op_model (pyhanabi/utils.py:36-84): M0-2 default, M3-5 skip connection, M6-8 two fc layers, M9-11 both.  The files under
+    tests/golden/op_zoo were written by the reference (make_op_zoo_fixture.py), one per class; the loaded agents must answer like the
+    reference's agents: same greedy actions, same new hidden state"""
+    from hanabi_sad_amd.checkpoint import load_op_model
+    z = np.load(os.path.join(GOLD, "op_zoo_expected.npz"))
+    root = os.path.join(GOLD, "op_zoo")
+    t = lambda k: torch.tensor(z[k]).to(DEV)
+    for i, j in ((0, 3), (6, 9)):
+        agents = load_op_model("sad", i, j, DEV, root=root, precision=precision)
+        assert len(agents) == 2
+        for idx, agent in zip((i, j), agents):
+            obs = {"priv_s": t("priv_s"), "legal_move": t("legal_move"), "eps": torch.zeros(z["priv_s"].shape[0], device=DEV)}
+            reply, hid = agent.act(obs, {"h0": t("h0"), "c0": t("c0")})
+            tol = 1e-5 if precision == "fp32" else 2e-3
+            assert float((hid["h0"].cpu() - torch.tensor(z["M%d.out_h0" % idx])).abs().max()) < tol, idx
+            want = torch.tensor(z["M%d.greedy_a" % idx])
+            got = reply["greedy_a"].cpu()
+            if precision == "fp32":
+                assert torch.equal(got, want), idx
+            else:       # a bf16 flip is only acceptable between advantages the reference itself has within 5e-3 of each other
+                adv = torch.tensor(z["M%d.adv" % idx])
+                for r in torch.nonzero(got != want).flatten().tolist():
+                    assert abs(float(adv[r, got[r]] - adv[r, want[r]])) < 5e-3, (idx, r)
+    with pytest.raises(FileNotFoundError):
+        load_op_model("sad", 1, None, DEV, root=root)
+
+
 def test_epoch_loop_logs_evaluates_and_saves(tmp_path):
     from hanabi_sad_amd import selfplay
     from hanabi_sad_amd.checkpoint import load_weights
@@ -50,3 +79,26 @@ def test_epoch_loop_logs_evaluates_and_saves(tmp_path):
     w = load_weights(os.path.join(save_dir, "model0.pthw"))       # reference key names, loadable back
     ref = torch.load(os.path.join(GOLD, "ref_small.pthw"))
     assert set(w) == set(ref) and not torch.equal(w["fc_a.weight"], ref["fc_a.weight"])   # trained away from the loaded weights
+
+
+@pytest.mark.parametrize("nl", [1, 3])
+def test_num_lstm_layer_flag_trains_and_saves_that_architecture(tmp_path, nl):
+    """--num_lstm_layer (pyhanabi/selfplay.py:50): the epoch loop with a 1- / 3-layer LSTM end to end -- acting, replay, learner, evaluation,
+    checkpoint with the reference's key names for that depth, loadable back as an agent"""
+    from hanabi_sad_amd import selfplay
+    from hanabi_sad_amd.checkpoint import agent_from_file, load_weights
+    save_dir = str(tmp_path / ("exp_l%d" % nl))
+    argv = ["--save_dir", save_dir, "--num_game", "64", "--rnn_hid_dim", "64", "--batchsize", "16", "--replay_buffer_size", "2048",
+            "--burn_in_frames", "64", "--max_len", "40", "--num_epoch", "1", "--epoch_len", "5", "--num_eval_game", "32", "--seed", "3",
+            "--num_lstm_layer", str(nl)]
+    old = sys.stdout
+    try:
+        selfplay.main(argv)
+    finally:
+        sys.stdout = old
+    log = open(os.path.join(save_dir, "train.log")).read()
+    assert "epoch 0, eval score:" in log and "model saved: True" in log
+    w = load_weights(os.path.join(save_dir, "model0.pthw"))
+    assert sorted(k for k in w if k.startswith("lstm.weight_ih")) == ["lstm.weight_ih_l%d" % l for l in range(nl)]
+    agent = agent_from_file(os.path.join(save_dir, "model0.pthw"), DEV)
+    assert agent.get_h0(4)["h0"].shape[0] == nl
