@@ -1815,7 +1815,9 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
   const int kofs = (lane >> 4) * 8;
   for (int c = tid; c < 32 * (K / 8); c += 256) {
     const int r = c / (K / 8), q = c - r * (K / 8);
-    *reinterpret_cast<uint4*>(sW + r * WS + q * 8) = *reinterpret_cast<const uint4*>(a.WhhT + (size_t)(nb * 32 + r) * K + q * 8);
+    // rows unpadded, 16-byte chunk q at position q ^ (r & 15) of its 256-byte window: conflict-free for ds_read_b128's lane groups
+    // (the K + 8 padding was 2-way conflicted: 8 instead of 4 LDS cycles per fragment read)
+    *reinterpret_cast<uint4*>(sW + r * K + ((q ^ (r & 15)) * 8)) = *reinterpret_cast<const uint4*>(a.WhhT + (size_t)(nb * 32 + r) * K + q * 8);
   }
   const int u = nb * 32 + wu * 16 + (lane & 15);
   const int ucol = nb * 128 + wu * 16 + (lane & 15);
@@ -1879,8 +1881,14 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
         unsigned* ctr = a.counters + (size_t)(t + 1) * nrb + rb;
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nunit_blocks) {
-          __builtin_amdgcn_s_sleep(2);
+        // co-located groups poll with a SCALAR load (glc: served by the XCD's L2, where the signal's atomic executes): a vector load
+        // would return in order behind the own-activation loads issued above
+        for (;;) {
+          unsigned v;
+          if (fast) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+          else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v >= (unsigned)nunit_blocks) break;
+          __builtin_amdgcn_s_sleep(1);
           if (++spins > 4000000u) {
             __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = 0;
@@ -1908,8 +1916,12 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
       const bf16x8* g1 = use_x ? reinterpret_cast<const bf16x8*>(xb + (16 + (lane & 15)) * 32)
                                : reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row1) * K + kofs);
       const int kstep = use_x ? 128 : 4;     // bf16x8 units between consecutive k blocks of this lane's fragment
-      const bf16_t* w0 = sW + (lane & 15) * WS + kofs;
-      const bf16_t* w1 = sW + (16 + (lane & 15)) * WS + kofs;
+      // swizzled fragment addresses: k block kbi = 4 * (kbi >> 2) + q lies at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
+      int swz[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) swz[q] = ((q * 4 + (lane >> 4)) ^ (lane & 15)) * 8;
+      const bf16_t* w0 = sW + (lane & 15) * K;
+      const bf16_t* w1 = sW + (16 + (lane & 15)) * K;
       f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
       union Frag {
         u32x4 w;
@@ -1935,8 +1947,9 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const LstmSeqBwdArgs& a, const
 #pragma unroll
         for (int it = 0; it < KQ; ++it) {
           if (it < i0 || it >= i1) continue;
-          const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (wave * KQ + it) * 32);
-          const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (wave * KQ + it) * 32);
+          const int kbi = wave * KQ + it;
+          const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (kbi >> 2) * 128 + swz[it & 3]);
+          const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (kbi >> 2) * 128 + swz[it & 3]);
           p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb0, p00, 0, 0, 0);
           p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb1, p01, 0, 0, 0);
           p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb0, p10, 0, 0, 0);
@@ -3431,6 +3444,41 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
   return launch_seq_bwd(m, nrec, H, nrb, sync, s, (unsigned*)next_sync_scratch, (int)seq_sync_words(nrec, Tc, nrb));
 }
 
+namespace {
+struct FusedTiming {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<double> flop;
+} g_fused_timing;
+}  // namespace
+
+// HIP events around every hsad_lstm_forward_fused launch (on the stream it is launched on) while enabled: how bench.py times the
+// kernel that owns the learner's forward LSTM GEMM FLOPs INSIDE an update
+int hsad_lstm_fused_timing(int enable) {
+  g_fused_timing.on = enable != 0;
+  return HSAD_OK;
+}
+int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches) {
+  if (!avg_ms || !launches) return nfail(HSAD_ERR_INVALID, "fused_timing_read: null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < g_fused_timing.ev.size(); ++i) {
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, g_fused_timing.ev[i].first, g_fused_timing.ev[i].second));
+    ms += t;
+    fl += g_fused_timing.flop[i];
+    (void)hipEventDestroy(g_fused_timing.ev[i].first);
+    (void)hipEventDestroy(g_fused_timing.ev[i].second);
+  }
+  const size_t n = g_fused_timing.ev.size();
+  *launches = (int32_t)n;
+  *avg_ms = n ? ms / n : 0.0;
+  if (avg_flop) *avg_flop = n ? fl / n : 0.0;
+  g_fused_timing.ev.clear();
+  g_fused_timing.flop.clear();
+  return HSAD_OK;
+}
+
 // Fused persistent forward (lstm_fused_fwd_kernel): nnet independent nets x nlayer stacked layers over the WHOLE sequence in one
 // launch, the input projections computed inside the recurrences.  recs[net * nlayer + layer]; a record whose x16 is NULL takes its
 // input from the record before it (the layer below).  Needs nnet * ceil(Bn/32) * nlayer * (H/32) co-resident workgroups.
@@ -3483,6 +3531,12 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
   const size_t lds = (size_t)(4 * 32 * H + 32 * 40) * sizeof(bf16_t) + 16;   // h tile + ring of three X tiles + publish staging
+  hipEvent_t te0 = nullptr, te1 = nullptr;
+  if (g_fused_timing.on) {
+    HIP_TRY(hipEventCreate(&te0));
+    HIP_TRY(hipEventCreate(&te1));
+    HIP_TRY(hipEventRecord(te0, s));
+  }
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_fwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_fused_fwd_kernel<16>, dim3(grid), dim3(256), lds, s, m);
@@ -3491,6 +3545,11 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     hipLaunchKernelGGL(lstm_fused_fwd_kernel<8>, dim3(grid), dim3(256), lds, s, m);
   }
   HIP_TRY(hipGetLastError());
+  if (te0) {
+    HIP_TRY(hipEventRecord(te1, s));
+    g_fused_timing.ev.push_back({te0, te1});
+    g_fused_timing.flop.push_back((double)nrec * 2.0 * T * Bn * 4.0 * H * 2.0 * H);      // [x | h] [W_ih | W_hh]^T per recurrence
+  }
   return HSAD_OK;
 }
 

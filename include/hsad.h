@@ -516,6 +516,10 @@ typedef struct hsad_lstm_fused_rec {
 } hsad_lstm_fused_rec;
 int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hsad_lstm_fused_rec* recs, void* sync_scratch,
                             void* next_sync_scratch, void* stream);
+/* measurement hook (bench.py): HIP events around every hsad_lstm_forward_fused launch while enabled; _read returns the average
+ * launch duration, the algorithmic FLOP per launch (2 T Bn 4H 2H per recurrence) and the launch count, synchronises, clears */
+int hsad_lstm_fused_timing(int enable);
+int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches);
 /* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
  * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,
