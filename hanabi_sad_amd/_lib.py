@@ -41,7 +41,7 @@ class LstmBwdRec(C.Structure):
     """hsad_lstm_bwd_rec (include/hsad.h)"""
     _fields_ = [("gates", C.c_void_p), ("cseq", C.c_void_p), ("c_before", C.c_void_p), ("WhhT_blocked", C.c_void_p),
                 ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p),
-                ("saved_frag_major", C.c_int)]
+                ("saved_frag_major", C.c_int), ("tail_is_zero", C.c_int)]
 
 
 class LstmFusedRec(C.Structure):
@@ -138,6 +138,8 @@ SIGNATURES = {
     "hsad_heads_backward": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P,
                                       C.c_int, _P]),
     "hsad_aux_xent": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "hsad_loss_tail": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                 C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "hsad_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "hsad_colsum_acc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

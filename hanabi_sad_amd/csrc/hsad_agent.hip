@@ -608,6 +608,7 @@ struct hsad_r2d2_learner {
   int wgrad_split = 8, chunks = 4;
   int fused_fwd = 1;          // whole-sequence fused forward recurrences (hsad_lstm_forward_fused) when the shape allows
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
+  bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   unsigned* fsync[3][2];      // ping-pong counter blocks of the fused launches: [log2(recurrences per launch)][flip]
   int fflip[3] = {0, 0, 0};
   size_t fsync_words[3];
@@ -1001,6 +1002,23 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   // (the two head layers are one pair launch: N = A + 1 + 3 hand columns, one problem alone is 80 workgroups)
   CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
                             L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
+  L->dheads_ready = false;
+  if (num_player == 1) {
+    // IQL: the online Q-head, then everything up to d loss / d heads in ONE launch (hsad_loss_tail)
+    CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, nullptr, L->qscratch, stream));
+    CK(hsad_loss_tail(L->heads, L->heads_t, NH, legal_move, L->q, L->qa, L->qscratch + 1, (M + 255) / 256, reward, bootstrap, seq_len, weight,
+                      pred_weight > 0 ? own_hand : nullptr, a, T, B, A, L->on->NP, L->multi_step, L->gamma, pred_weight, L->greedy, L->tqa, L->err,
+                      priority, loss, L->xs, want_grad ? L->dqa : nullptr, want_grad ? L->dheads : nullptr, L->on->NHp, stream));
+    L->dheads_ready = want_grad != 0;
+    L->b_legal = legal_move;
+    L->b_a = a;
+    L->b_own = pred_weight > 0 ? own_hand : nullptr;
+    L->b_weight = weight;
+    L->pred_weight = pred_weight;
+    L->num_player = num_player;
+    L->have_fwd = want_grad != 0;
+    return 0;
+  }
   CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, L->greedy, L->qscratch, stream));
   CK(hsad_q_head(L->heads_t, NH, legal_move, L->greedy, M, A, L->q, L->tqa, nullptr, L->qscratch, stream));
   const float *qa = L->qa, *tqa = L->tqa;
@@ -1046,8 +1064,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     dqa = L->dqa_r;
     weight = L->w_r;
   }
-  CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
-                         L->dheads, NHp, stream));
+  if (!L->dheads_ready)
+    CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
+                           L->dheads, NHp, stream));
   CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO[top], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
   HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
   float* g[kMaxP];
@@ -1085,12 +1104,11 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     HIP_TRY(hipStreamWaitEvent(ws, L->ev_a, 0));
   }
   for (int l = 0; l < NL; ++l) {
+    // (the first B columns of the delayed copy -- h_{-1} = 0 -- are zero since the arena was created and nothing writes them)
     if (pipe) {
-      HIP_TRY(hipMemset2DAsync(L->hsT[l], (size_t)(B + M) * 2, 0, (size_t)B * 2, H, ws));
       CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l] + B, B + M, nullptr, nullptr, nullptr, wst));
     } else {
       CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l], Mp, nullptr, nullptr, nullptr, wst));
-      HIP_TRY(hipMemset2DAsync(L->hpT[l], (size_t)Mp * 2, 0, (size_t)B * 2, H, ws));
       if (M > B) CK(transpose16(L->hseq[0][l], M - B, H, H, L->hpT[l] + B, Mp, nullptr, nullptr, nullptr, wst));
     }
   }
@@ -1123,6 +1141,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.has_next = c != nch - 1;
         r.xchg = L->xchg_b[l];
         r.saved_frag_major = L->fwd_frag ? 1 : 0;
+        r.tail_is_zero = 1;      // dG slot T: zero since the arena was created, no kernel writes it
         return r;
       };
       if (st < nch) recs[nr++] = brec(1, nch - 1 - st);
@@ -1148,7 +1167,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   } else {
     for (int l = top; l >= 0; --l) {
       if (L->fwd_frag) {      // fragment-major saved activations: one persistent launch over the whole sequence
-        hsad_lstm_bwd_rec r{L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], L->dO[l], L->dG[l], L->dc[l], 0, nullptr, 1};
+        hsad_lstm_bwd_rec r{L->gates[0][l], L->cseq[0][l], nullptr, on->WhhT[l], L->dO[l], L->dG[l], L->dc[l], 0, nullptr, 1, 1};
         HIP_TRY(hipMemsetAsync(L->dc[l], 0, (size_t)B * H * 4, s));
         CK(hsad_lstm_backward_chunk_multi(1, T, B, H, &r, L->sync1, nullptr, stream));
       } else {

@@ -2314,6 +2314,136 @@ __global__ void heads_bwd_kernel(const float* __restrict__ dqa, const float* __r
   for (int j = col; j < ldo; ++j) o[j] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Everything between the online Q-head and the BPTT in ONE launch (IQL layout; replaces min_reduce + greedy + the target net's
+// q_head + td_loss + aux_xent + axpy + heads_bwd = seven ~6 us launches of an update).  One block per sequence b, one thread per
+// step t: global min(q) from the q-head's block minima -> greedy action (double DQN) -> Q_target(s, greedy) from the target
+// heads -> n-step target / TD error / Huber loss / priority / d loss / d qa -> (aux) cross-entropy of the own-hand prediction ->
+// (gradient) d loss / d heads row.  Every value is computed with the arithmetic and the summation order of the kernels it
+// replaces (bit-identical results).
+// ---------------------------------------------------------------------------------------------------
+struct LossTailArgs {
+  const float *heads, *heads_t, *legal, *q_online, *online_qa, *block_min, *reward, *bootstrap, *seq_len, *weight, *own_hand;
+  const int64_t* action;
+  int ldh, n_block_min, T, B, A, NP, n;
+  float gamma_n, pred_weight;
+  int64_t* greedy;
+  float *target_qa, *err, *priority, *loss, *xent_sum, *dqa;
+  bf16_t* dheads;
+  int ldo;
+};
+__global__ void loss_tail_kernel(LossTailArgs p) {
+  extern __shared__ float s_lt[];
+  float* s_tq = s_lt;                 // [T] Q_target(s_t, greedy_t)
+  float* s_x = s_lt + p.T;            // [T] aux cross-entropy of step t
+  float* s_sum = s_x + p.T;           // [blockDim] Huber terms
+  const int b = blockIdx.x, tid = threadIdx.x, T = p.T, B = p.B, A = p.A;
+  float mn = 3.4e38f;
+  for (int i = 0; i < p.n_block_min; ++i) mn = fminf(mn, p.block_min[i]);
+  for (int t = tid; t < T; t += blockDim.x) {
+    const size_t m = (size_t)t * B + b;
+    const float* lg = p.legal + m * A;
+    float best = -3.4e38f;
+    int bi = 0;
+    for (int j = 0; j < A; ++j) {
+      const float sc = (1.f + p.q_online[m * A + j] - mn) * lg[j];
+      if (sc > best) {
+        best = sc;
+        bi = j;
+      }
+    }
+    p.greedy[m] = bi;
+    const float* ht = p.heads_t + m * p.ldh;
+    float mean = 0.f;
+    for (int j = 0; j < A; ++j) mean += ht[j] * lg[j];
+    mean /= (float)A;
+    const float tq = ht[A] + ht[bi] * lg[bi] - mean;
+    p.target_qa[m] = tq;
+    s_tq[t] = tq;
+    if (p.own_hand && p.pred_weight > 0.f) {
+      const int slots = p.NP / 3;
+      const float* tg = p.own_hand + m * p.NP;
+      const float* lgt = p.heads + m * p.ldh + A + 1;
+      float nmask = 0.f, acc = 0.f;
+      for (int sidx = 0; sidx < slots; ++sidx) {
+        const float sm = tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+        const float l0 = lgt[3 * sidx], l1 = lgt[3 * sidx + 1], l2 = lgt[3 * sidx + 2];
+        const float mx = fmaxf(l0, fmaxf(l1, l2));
+        const float lse = mx + __logf(__expf(l0 - mx) + __expf(l1 - mx) + __expf(l2 - mx));
+        const float plogq = tg[3 * sidx] * (l0 - lse) + tg[3 * sidx + 1] * (l1 - lse) + tg[3 * sidx + 2] * (l2 - lse);
+        acc += plogq * sm;
+        nmask += sm;
+      }
+      s_x[t] = -acc / fmaxf(nmask, 1e-6f);
+    }
+  }
+  __syncthreads();
+  const float len = p.seq_len[b];
+  float sum = 0.f;
+  for (int t = tid; t < T; t += blockDim.x) {
+    const size_t m = (size_t)t * B + b;
+    const float tq = (t + p.n < T) ? s_tq[t + p.n] : 0.f;
+    const float target = p.reward[m] + p.bootstrap[m] * p.gamma_n * tq;
+    const float mask = (float)t < len ? 1.f : 0.f;
+    const float e = (target - p.online_qa[m]) * mask;
+    const float ae = fabsf(e);
+    p.err[m] = e;
+    p.priority[m] = ae;
+    sum += ae < 1.f ? 0.5f * e * e : ae - 0.5f;
+    if (p.dqa) {
+      const float g = fminf(fmaxf(e, -1.f), 1.f);
+      const float d = -g * mask * (p.weight ? p.weight[b] : 1.f) / (float)B;
+      p.dqa[m] = d;
+      if (p.dheads) {     // heads_bwd_kernel's row
+        bf16_t* o = p.dheads + m * p.ldo;
+        const float* lg = p.legal + m * A;
+        const int act = (int)p.action[m];
+        const float invA = 1.f / (float)A;
+        for (int j = 0; j < A; ++j) o[j] = f2bf(d * lg[j] * ((j == act ? 1.f : 0.f) - invA));
+        o[A] = f2bf(d);
+        int col = A + 1;
+        if (p.own_hand && p.pred_weight > 0.f) {
+          const float pred_scale = p.pred_weight / (float)B;
+          const float* tg = p.own_hand + m * p.NP;
+          const float* lgt = p.heads + m * p.ldh + A + 1;
+          const int slots = p.NP / 3;
+          float nmask = 0.f;
+          for (int sidx = 0; sidx < slots; ++sidx) nmask += tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+          const float scale = pred_scale * p.weight[b] / fmaxf(nmask, 1e-6f);
+          for (int sidx = 0; sidx < slots; ++sidx) {
+            const float l0 = lgt[3 * sidx], l1 = lgt[3 * sidx + 1], l2 = lgt[3 * sidx + 2];
+            const float mx = fmaxf(l0, fmaxf(l1, l2));
+            const float e0 = __expf(l0 - mx), e1 = __expf(l1 - mx), e2 = __expf(l2 - mx);
+            const float inv = 1.f / (e0 + e1 + e2);
+            const float sm = tg[3 * sidx] + tg[3 * sidx + 1] + tg[3 * sidx + 2];
+            o[col + 3 * sidx + 0] = f2bf((e0 * inv * sm - tg[3 * sidx + 0]) * sm * scale);
+            o[col + 3 * sidx + 1] = f2bf((e1 * inv * sm - tg[3 * sidx + 1]) * sm * scale);
+            o[col + 3 * sidx + 2] = f2bf((e2 * inv * sm - tg[3 * sidx + 2]) * sm * scale);
+          }
+          col += p.NP;
+        }
+        for (int j = col; j < p.ldo; ++j) o[j] = 0;
+      }
+    }
+  }
+  s_sum[tid] = sum;
+  __syncthreads();
+  for (int k = blockDim.x / 2; k > 0; k >>= 1) {   // fixed-order tree: deterministic (td_loss_kernel's)
+    if (tid < k) s_sum[tid] += s_sum[tid + k];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    float l = s_sum[0];
+    if (p.own_hand && p.pred_weight > 0.f) {
+      float total = 0.f;
+      for (int t = 0; t < T; ++t) total += s_x[t];   // aux_xent_kernel's order
+      p.xent_sum[b] = total;
+      l += p.pred_weight * total;
+    }
+    p.loss[b] = l;
+  }
+}
+
 // aux cross-entropy forward (cross_entropy, r2d2.py:133-153): per (t,b) xent summed over t into loss_aux[b]
 __global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const float* __restrict__ own_hand, int T, int Bsz,
                                 int A, int NP, float* __restrict__ xent_sum) {
@@ -3177,8 +3307,10 @@ int hsad_q_head(const float* heads, int ldh, const float* legal, const int64_t* 
   const int nb = (M + 255) / 256;
   hipLaunchKernelGGL(q_head_kernel, dim3(nb), dim3(256), (size_t)R * (ldh + A) * 4, s, heads, ldh, legal, action, M, A, q, qa,
                      scratch + 1, R);
-  hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
-  if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3(nb), dim3(256), 0, s, q, legal, scratch, M, A, greedy);
+  if (greedy) {      // (without a greedy output nobody reads the global minimum: scratch[1..] keeps the block minima)
+    hipLaunchKernelGGL(min_reduce_kernel, dim3(1), dim3(256), 0, s, scratch + 1, nb, scratch);
+    hipLaunchKernelGGL(greedy_kernel, dim3(nb), dim3(256), 0, s, q, legal, scratch, M, A, greedy);
+  }
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -3264,6 +3396,30 @@ int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int
   if (!heads || !own_hand || !xent_sum) return nfail(HSAD_ERR_INVALID, "aux_xent: null");
   hipLaunchKernelGGL(aux_xent_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, heads, ldh, own_hand, T, B,
                      A, NP, xent_sum);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
+                   const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
+                   const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step, double gamma,
+                   float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss, float* xent_sum, float* dqa,
+                   void* dheads16, int ldo, void* stream) {
+  if (!heads || !heads_t || !legal || !q_online || !online_qa || !block_min || !reward || !bootstrap || !seq_len || !greedy || !target_qa || !err ||
+      !priority || !loss || n_block_min < 1 || T < 1 || B < 1)
+    return nfail(HSAD_ERR_INVALID, "loss_tail: null argument");
+  if (pred_weight > 0 && own_hand && !xent_sum) return nfail(HSAD_ERR_INVALID, "loss_tail: the auxiliary task needs xent_sum");
+  if (dheads16 && (!dqa || !action || !weight || ldo < A + 1 + ((own_hand && pred_weight > 0) ? NP : 0)))
+    return nfail(HSAD_ERR_INVALID, "loss_tail: the head gradient needs dqa, the actions, the weights and ldo >= its columns");
+  float gamma_n = 1.f;
+  {
+    double g = 1.0;  // python: gamma ** multi_step in double, then a float32 tensor multiply
+    for (int i = 0; i < multi_step; ++i) g *= gamma;
+    gamma_n = (float)g;
+  }
+  LossTailArgs p{heads, heads_t, legal, q_online, online_qa, block_min, reward, bootstrap, seq_len, weight, own_hand, action, ldh, n_block_min, T, B, A, NP,
+                 multi_step, gamma_n, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, (bf16_t*)dheads16, ldo};
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(B), dim3(128), (size_t)(2 * T + 128) * 4, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -3436,7 +3592,7 @@ int hsad_lstm_backward_chunk_multi(int nrec, int Tc, int Bn, int H, const hsad_l
     const hsad_lstm_bwd_rec& r = recs[i];
     if (!r.gates || !r.cseq || !r.WhhT_blocked || !r.dG16 || !r.dc_io) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: null pointer in record");
     bf16_t* dG = (bf16_t*)r.dG16;
-    if (!r.has_next) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
+    if (!r.has_next && !r.tail_is_zero) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
     m.r[i] = LstmSeqBwdArgs{(const bf16_t*)r.WhhT_blocked, r.gates, r.cseq, r.c_before, r.dO, dG, counters + (size_t)i * Tc * nrb,
                             counters + (size_t)nrec * Tc * nrb, Tc, Bn, H, r.dc_io, r.has_next, (bf16_t*)r.xchg, r.saved_frag_major};
     if (r.saved_frag_major && Bn % 32) return nfail(HSAD_ERR_INVALID, "lstm_backward_chunk_multi: fragment-major activations need Bn %% 32 == 0");
@@ -3556,7 +3712,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
 int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const float* cseq, const float* c_before,
                              const void* WhhT_blocked, const float* dO, void* dG16, float* dc_io, int has_next,
                              void* sync_scratch, void* stream) {
-  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr, 0};
+  hsad_lstm_bwd_rec r{gates, cseq, c_before, WhhT_blocked, dO, dG16, dc_io, has_next, nullptr, 0, 0};
   return hsad_lstm_backward_chunk_multi(1, Tc, Bn, H, &r, sync_scratch, nullptr, stream);
 }
 

@@ -425,6 +425,16 @@ int hsad_heads_backward(const float* dqa, const float* legal, const int64_t* act
 /* aux own-hand cross-entropy summed over time (cross_entropy, r2d2.py:133-153): xent_sum fp32 [B] */
 int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int B, int A, int NP, float* xent_sum,
                   void* stream);
+/* Everything between the online Q-head and BPTT of an IQL learner update in ONE launch (one block per sequence): global min(q) from the
+ * block minima hsad_q_head left in its scratch (scratch + 1, (M + 255) / 256 of them) -> greedy action (r2d2.py:113-115) -> Q_target(s, greedy)
+ * from the target net's heads -> n-step TD error, Huber loss, priority, d loss / d qa (hsad_td_loss) -> auxiliary cross-entropy
+ * (hsad_aux_xent; loss += pred_weight * xent) -> d loss / d heads rows bf16 [M, ldo] (hsad_heads_backward; dheads16 NULL = no gradient).
+ * Same arithmetic and summation order as those entry points: bit-identical results, six launches fewer per update. */
+int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
+                   const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
+                   const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step, double gamma,
+                   float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss, float* xent_sum, float* dqa,
+                   void* dheads16, int ldo, void* stream);
 /* column sums (bias gradients) of a bf16 / fp32 [M, ld] matrix -> fp32 [N] */
 int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream);
 /* accumulating variant (no zeroing): out[col_map ? col_map[c] : c] += column sum c, and the same into out2 when given
@@ -474,6 +484,7 @@ typedef struct hsad_lstm_bwd_rec {
   int has_next;
   void* xchg; /* optional bf16 scratch [Tc * 32*ceil(Bn/32) * 4H]: dG tiles in hand-off order */
   int saved_frag_major; /* gates / cseq / c_before are in the fragment-major order hsad_lstm_forward_fused stores (Bn % 32 == 0) */
+  int tail_is_zero;     /* has_next == 0 only: dG16 slot Tc is known to hold zeros already (nothing ever writes it): skip its memset */
 } hsad_lstm_bwd_rec;
 /* nrec (<= 4 forward, <= 2 backward) independent recurrences of identical shape in ONE persistent launch, e.g. layer 0
  * on chunk c+1 next to layer 1 on chunk c, for the online and the target net at once.  The overlap is inside the launch,
