@@ -227,8 +227,9 @@ class CompositeLearner:
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
 
     def set_fused(self, on):
-        """fused forward recurrences on / off (off = the chunk-pipelined schedule, the A/B reference of the fused kernels)"""
-        self.fused = bool(on)
+        """fused forward recurrences on / off (off = the chunk-pipelined schedule, the A/B reference of the fused kernels); 3 = fused
+        forward with the joint two-recurrence BPTT launches instead of the two stream chains (A/B of the backward schedule)"""
+        self.fused = int(on)
         if self.h is not None:
             _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
 

@@ -860,7 +860,7 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_s
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");
   CK(learner_reset_sync(L));
-  L->fused_fwd = fused_fwd != 0;
+  L->fused_fwd = (fused_fwd & 1) != 0;
   return 0;
 }
 /* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
@@ -1125,10 +1125,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     const size_t Mc = (size_t)Tc * B;
     HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
     const int per_launch = std::max(1, std::min(2, L->n_cu / ((H / 32) * nrb)));
-    for (int st = 0; st <= nch; ++st) {
-      hsad_lstm_bwd_rec recs[2];
-      int nr = 0;
-      auto brec = [&](int l, int c) {
+    auto brec = [&](int l, int c) {
         const size_t t0 = (size_t)c * Tc;
         hsad_lstm_bwd_rec r;
         r.gates = L->gates[0][l] + t0 * B * H4;
@@ -1144,6 +1141,10 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.tail_is_zero = 1;      // dG slot T: zero since the arena was created, no kernel writes it
         return r;
       };
+    {
+    for (int st = 0; st <= nch; ++st) {
+      hsad_lstm_bwd_rec recs[2];
+      int nr = 0;
       if (st < nch) recs[nr++] = brec(1, nch - 1 - st);
       if (st >= 1) {
         const int c0 = nch - st;
@@ -1164,6 +1165,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     HIP_TRY(hipEventRecord(L->ev_c, s));                            // layer 0 complete
     HIP_TRY(hipStreamWaitEvent(ws, L->ev_c, 0));
     CK(layer_wgrad(0, xinT, Mp));
+    }
   } else {
     for (int l = top; l >= 0; --l) {
       if (L->fwd_frag) {      // fragment-major saved activations: one persistent launch over the whole sequence
