@@ -44,6 +44,13 @@ class LstmBwdRec(C.Structure):
                 ("saved_frag_major", C.c_int), ("tail_is_zero", C.c_int)]
 
 
+class LstmFusedBwdRec(C.Structure):
+    """hsad_lstm_fused_bwd_rec (include/hsad.h)"""
+    _fields_ = [("WhhT_blocked", C.c_void_p), ("WihT_above_blocked", C.c_void_p), ("gates", C.c_void_p), ("cseq", C.c_void_p),
+                ("c_before", C.c_void_p), ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int),
+                ("xchg", C.c_void_p), ("saved_frag_major", C.c_int), ("tail_is_zero", C.c_int)]
+
+
 class LstmFusedRec(C.Structure):
     """hsad_lstm_fused_rec (include/hsad.h)"""
     _fields_ = [("Wih_blocked", C.c_void_p), ("Whh_blocked", C.c_void_p), ("bias_blocked", C.c_void_p), ("x16", C.c_void_p),
@@ -121,6 +128,7 @@ SIGNATURES = {
                                     C.c_int, C.c_int, _P]),
     "hsad_cast_pad_bf16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "hsad_gemm_nt_bf16_splitk": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "hsad_gemm_nt_bf16_splitk_acc": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "hsad_transpose_bf16_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "hsad_prepare_weight": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int, _P]),
     "hsad_bias_sum_perm": (C.c_int, [_P, _P, _P, _P, C.c_int, _P]),
@@ -163,6 +171,7 @@ SIGNATURES = {
     "hsad_lstm_forward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_forward_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "hsad_lstm_backward_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_fused_timing": (C.c_int, [C.c_int]),
     "hsad_lstm_fused_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

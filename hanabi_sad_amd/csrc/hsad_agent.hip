@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -607,6 +608,12 @@ struct hsad_r2d2_learner {
   float lr, adam_eps, clip;
   int wgrad_split = 8, chunks = 4;
   int fused_fwd = 1;          // whole-sequence fused forward recurrences (hsad_lstm_forward_fused) when the shape allows
+  int fused_bwd = 1;          // BPTT: both layers in one launch per time chunk, dO of the lower layer inside its recurrence (hsad_lstm_backward_fused)
+  int bchunks = 1;            // time chunks of the fused BPTT (measured: 1 chunk 1.57 ms, 2 chunks 1.61, 4 chunks 1.78 per update)
+  hipEvent_t ev_ck[8];
+  unsigned* fbsync[2];        // ping-pong counter blocks of the fused BPTT launches (2 recurrences x up to T steps)
+  int fbflip = 0, fb_tc = 0;
+  size_t fbsync_words;
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   unsigned* fsync[3][2];      // ping-pong counter blocks of the fused launches: [log2(recurrences per launch)][flip]
@@ -625,7 +632,8 @@ struct hsad_r2d2_learner {
   // backward
   bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL];
   int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
-  float *dO[kMaxL], *dc[kMaxL], *wgrad_ws;
+  float *dO[kMaxL], *dc[kMaxL], *wgrad_ws, *wgrad_ws2;
+  bf16_t* dGT2;           // second transposed-gradient operand: layer 0's weight gradients on the main stream next to layer 1's on the side stream
   // ping-pong counter blocks of the persistent launches: [kind fwd/bwd][nrec - 1][flip]
   unsigned* sync[2][4][2];
   int flip[2][4];
@@ -762,6 +770,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->dx1T, H * Mp * 2);
   want(&L->dheadsT, NHp * Mp * 2);
   want(&L->wgrad_ws, (size_t)L->wgrad_split * H4 * std::max(H, (size_t)online->F) * 4);
+  want(&L->wgrad_ws2, pipe0 ? (size_t)L->wgrad_split * H4 * H * 4 : 256);
+  want(&L->dGT2, pipe0 ? H4 * Mp * 2 : 256);
   size_t total = 0;
   for (auto& e : plan) total += e.second;
   if (L->arena.need(total + 256)) {
@@ -800,6 +810,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     L->fsync_words[k] = ((size_t)1 << k) * nrb * ((size_t)T + 2) + 4;
     fw += 2 * L->fsync_words[k];
   }
+  L->fbsync_words = (size_t)2 * nrb * ((size_t)T + 2) + 4;
+  fw += 2 * L->fbsync_words;
   if (L->sync_buf.need((sw + s1 + fw) * 4)) {
     delete L;
     return HSAD_ERR_NOMEM;
@@ -821,6 +833,17 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
       L->fsync[k][f] = sp;
       sp += L->fsync_words[k];
     }
+  for (int f = 0; f < 2; ++f) {
+    L->fbsync[f] = sp;
+    sp += L->fbsync_words;
+  }
+  for (int i = 0; i < 8; ++i) {
+    L->ev_ck[i] = nullptr;
+    if (hipEventCreateWithFlags(&L->ev_ck[i], hipEventDisableTiming) != hipSuccess) {
+      delete L;
+      return afail(HSAD_ERR_HIP, "r2d2_learner_create: event creation failed");
+    }
+  }
   if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&L->ev_d, hipEventDisableTiming) != hipSuccess) {
@@ -834,6 +857,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
   if (!L) return;
   if (L->side) (void)hipStreamDestroy(L->side);
+  for (int i = 0; i < 8; ++i)
+    if (L->ev_ck[i]) (void)hipEventDestroy(L->ev_ck[i]);
   for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c, L->ev_d})
     if (e) (void)hipEventDestroy(e);
   delete L;
@@ -846,6 +871,8 @@ static int learner_reset_sync(hsad_r2d2_learner* L) {
   for (int k = 0; k < 2; ++k)
     for (int r = 0; r < 4; ++r) L->flip[k][r] = 0;
   L->fflip[0] = L->fflip[1] = L->fflip[2] = 0;
+  L->fbflip = 0;
+  L->fb_tc = 0;
   return 0;
 }
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* L, int chunks, int wgrad_split) {
@@ -861,6 +888,9 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");
   CK(learner_reset_sync(L));
   L->fused_fwd = (fused_fwd & 1) != 0;
+  L->fused_bwd = (fused_fwd & 1) != 0 && !(fused_fwd & 2);      // bit 1: keep the chunk-pipelined BPTT with its dO GEMMs (A/B)
+  const int bc = (fused_fwd >> 8) & 0xff;                       // bits 8-15: time chunks of the fused BPTT (0 = keep)
+  if (bc >= 1 && bc <= 8) L->bchunks = bc;
   return 0;
 }
 /* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
@@ -881,6 +911,12 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
     for (int f = 0; f < 2; ++f) {
       unsigned v = 0;
       HIP_TRY(hipMemcpy(&v, L->fsync[k][f] + L->fsync_words[k] - 4, 4, hipMemcpyDeviceToHost));
+      *timed_out |= (int32_t)v;
+    }
+  if (L->fb_tc)
+    for (int f = 0; f < 2; ++f) {
+      unsigned v = 0;
+      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)2 * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
       *timed_out |= (int32_t)v;
     }
   {
@@ -1120,7 +1156,61 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
   CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
   if (pipe) HIP_TRY(hipEventRecord(L->ev_d, ws));      // the transposed operands of the input MLP (x^T, a16^T) exist
-  if (pipe) {
+  int nbc = L->bchunks;
+  while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
+  std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;
+  bool defer_l0 = false;
+  const bool fbwd = pipe && L->fused_bwd && L->fwd_frag && B % 32 == 0 && 2 * (H / 32) * ((nrb_of(B) + 7) / 8) <= L->n_cu / 8 && nbc <= 8;
+  if (fbwd) {
+    // Both layers of a time chunk in ONE persistent launch (hsad_lstm_backward_fused): layer 0 runs a step behind layer 1 and computes
+    // its dO = dG1 W_ih1 inside the recurrence.  The chunk's weight gradients (contraction over its T/nbc * B rows, added up over the
+    // chunks) run on the side stream next to the following chunk's launch -- the launch occupies 4 of the 8 XCDs.
+    const int Tc = T / nbc;
+    const size_t Mc = (size_t)Tc * B;
+    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
+    chunk_wgrad = [=](int l, int c, void* st, bf16_t* dGT, float* wsp) -> int {
+      const size_t m0 = (size_t)c * Mc;
+      CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
+      const bf16_t* inT = l ? hs_x[l - 1] + m0 : xinT + m0;
+      CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, inT, l ? ldh : Mp, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWih[l]], H, on->perm32, st));
+      CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, hs_d[l] + m0, ldh, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWhh[l]], H, on->perm32, st));
+      return 0;
+    };
+    for (int c = nbc - 1; c >= 0; --c) {
+      const size_t t0 = (size_t)c * Tc;
+      hsad_lstm_fused_bwd_rec recs[2];
+      for (int k = 0; k < 2; ++k) {
+        const int l = 1 - k;
+        hsad_lstm_fused_bwd_rec& r = recs[k];
+        r.WhhT_blocked = on->WhhT[l];
+        r.WihT_above_blocked = k ? on->WihT[1] : nullptr;
+        r.gates = L->gates[0][l] + t0 * B * H4;
+        r.cseq = L->cseq[0][l] + t0 * B * H;
+        r.c_before = c == 0 ? nullptr : L->cseq[0][l] + (t0 - 1) * B * H;
+        r.dO = k ? nullptr : L->dO[1] + t0 * B * H;
+        r.dG16 = L->dG[l] + t0 * B * H4;
+        r.dc_io = L->dc[l];
+        r.has_next = c != nbc - 1;
+        r.xchg = L->xchg_b[l];
+        r.saved_frag_major = 1;
+        r.tail_is_zero = 1;
+      }
+      if (L->fb_tc != Tc) {      // another chunk length: the blocks' layout changes, start from clean ones
+        HIP_TRY(hipMemsetAsync(L->fbsync[0], 0, 2 * L->fbsync_words * 4, s));
+        L->fbflip = 0;
+        L->fb_tc = Tc;
+      }
+      int& f = L->fbflip;
+      CK(hsad_lstm_backward_fused(1, 2, Tc, B, H, recs, L->fbsync[f], L->fbsync[f ^ 1], stream));
+      f ^= 1;
+      HIP_TRY(hipEventRecord(L->ev_ck[c], s));
+      HIP_TRY(hipStreamWaitEvent(ws, L->ev_ck[c], 0));
+      CK(chunk_wgrad(1, c, wst, L->dGT, L->wgrad_ws));
+      // the last chunk's layer-0 gradients run on the caller's stream behind the input-MLP chain: two streams share the tail
+      if (c > 0) CK(chunk_wgrad(0, c, wst, L->dGT, L->wgrad_ws));
+      else defer_l0 = true;
+    }
+  } else if (pipe) {
     const int Tc = T / nch, nrb = nrb_of(B);
     const size_t Mc = (size_t)Tc * B;
     HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
@@ -1203,6 +1293,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     CK(hsad_colsum_acc(L->dx1, 1, M, H, H, g[on->iB1], nullptr, nullptr, stream));
   }
   CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+  if (defer_l0) CK(chunk_wgrad(0, 0, stream, L->dGT2, L->wgrad_ws2));
   if (pipe) {
     HIP_TRY(hipEventRecord(L->ev_a, ws));
     HIP_TRY(hipStreamWaitEvent(s, L->ev_a, 0));

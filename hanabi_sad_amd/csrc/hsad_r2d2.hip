@@ -2067,6 +2067,320 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqBwdArgsN m) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// Fused persistent BPTT (round 3): the stacked layers of a net run one step apart in ONE launch, and the gradient that reaches a
+// lower layer from the layer above -- dO^{l}_t = dG^{l+1}_t W_ih^{l+1}, a stand-alone GEMM per time chunk between recurrence
+// launches in rounds 1-2 -- is computed INSIDE the lower layer's recurrence:
+//
+//   dh^{l}_t = dO_t (top layer: from the heads)  +  dG^{l+1}_t W_ih^{l+1} (lower layers: the "X stream")  +  dG^{l}_{t+1} W_hh^{l}
+//
+// Same workgroup grid, K split over the four waves and exchange protocol as lstm_seq_bwd_kernel; the W_hh^T slice stays in LDS, the
+// X stream's W_ih^{l+1 T} slice (32 units x 4H) lives in REGISTERS (this wave's K quarter: 128 registers per lane at H = 512).
+// The X tile is the hand-off tile the layer above published for ITS exchange -- read through the L2 of the XCD both layers'
+// workgroups of a (net, row block) share ("super group", as in lstm_fused_fwd_kernel) -- and is multiplied first, inside the time the
+// own group needs to publish dG_{t+1}.
+// ---------------------------------------------------------------------------------------------------
+struct LstmFusedBwdArgs {
+  const bf16_t* WhhT;       // [H,4H] (gate-blocked columns): LDS-resident slice
+  const bf16_t* xW;         // [H,4H] W_ih^{l+1 T} of the layer above, or NULL (top layer): register-resident slice
+  const bf16_t* xin;        // hand-off tiles of the layer above [T][nrb][4H/32][32][32]
+  unsigned* xin_counters;   // its step counters [T][nrb]
+  const float* gates;       // saved activations of this layer
+  const float* cseq;
+  const float* c0;          // c of the step before the chunk (NULL = zeros)
+  const float* dO;          // [T,Bn,H] fp32 or NULL
+  bf16_t* dG;               // [T+1,Bn,4H] row-major (weight-gradient GEMMs; slot T = the following chunk's first step when has_next)
+  bf16_t* xchg;             // hand-off tiles [T][nrb][4H/32][32][32] (required)
+  unsigned* counters;       // [T][nrb], zeroed before launch
+  unsigned* timeout;
+  float* dc_io;
+  int dbg;
+  int T, Bn, has_next, frag, feeds;   // feeds: a layer below consumes this layer's tiles (publish + signal step 0, too)
+};
+
+template <int KB>  // KB = 4H / 32
+__device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, const int rb, const int nb, const int nrb, const int nunit_blocks,
+                                                    u64_t* group_word, const int nmember, const int force_cross_xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int K = KB * 32, H = K / 4, KQ = KB / 4;
+  constexpr int WS = K + 8;
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem_raw);  // [32][K] swizzled (allocation keeps the old padded size)
+  bf16_t* sG = sW + 32 * WS;                          // [32][136] dG tile staging
+  int* s_okp = reinterpret_cast<int*>(sG + 32 * 136);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wu = wave & 1;
+  const int kofs = (lane >> 4) * 8;
+  for (int c = tid; c < 32 * (K / 8); c += 256) {
+    const int r = c / (K / 8), q = c - r * (K / 8);
+    *reinterpret_cast<uint4*>(sW + r * K + ((q ^ (r & 15)) * 8)) = *reinterpret_cast<const uint4*>(a.WhhT + (size_t)(nb * 32 + r) * K + q * 8);
+  }
+  union Frag {
+    u32x4 w;
+    bf16x8 v;
+  };
+  // X stream weights: this wave's k blocks [wave KQ, (wave + 1) KQ) of the rows of units 0-15 / 16-31 of the block
+  Frag xw0[KQ], xw1[KQ];
+  const bool has_x = a.xW != nullptr;
+  if (has_x) {
+#pragma unroll
+    for (int it = 0; it < KQ; ++it) {
+      xw0[it].w = *reinterpret_cast<const u32x4*>(a.xW + (size_t)(nb * 32 + (lane & 15)) * K + (wave * KQ + it) * 32 + kofs);
+      xw1[it].w = *reinterpret_cast<const u32x4*>(a.xW + (size_t)(nb * 32 + 16 + (lane & 15)) * K + (wave * KQ + it) * 32 + kofs);
+    }
+  }
+  const int u = nb * 32 + wu * 16 + (lane & 15);
+  const int ucol = nb * 128 + wu * 16 + (lane & 15);
+  const int rbase = rb * 32 + wr * 16 + 4 * (lane >> 4);
+  float dcs[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.dc_io) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dcs[r] = a.dc_io[(size_t)(rbase + r) * H + u];
+  }
+  if (tid == 0) s_okp[1] = xcd_group_is_colocated(group_word, nmember, a.timeout);
+  __syncthreads();
+  if (s_okp[1] < 0) return;
+  const int fast = force_cross_xcd ? 0 : s_okp[1];
+  const bool dbg_on = (a.dbg && rb == 0 && nb == 0 && tid == 0);
+  const int dbg_base = has_x ? 8 : 0;
+  u64_t stamp_ = dbg_on ? wall_clock64() : 0;
+
+  auto wait_ctr = [&](unsigned* ctr, int slot) -> bool {
+    if (tid == 0) {
+      unsigned spins = 0;
+      int ok = 1;
+      for (;;) {
+        unsigned v;
+        if (fast) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+        else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= (unsigned)nunit_blocks) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 8000000u) {
+          __hip_atomic_store(a.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+      s_okp[slot] = ok;
+    }
+    __syncthreads();
+    return s_okp[slot] != 0;
+  };
+  // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
+  int swz[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) swz[q] = ((q * 4 + (lane >> 4)) ^ (lane & 15)) * 8;
+  const bf16_t* w0 = sW + (lane & 15) * K;
+  const bf16_t* w1 = sW + (16 + (lane & 15)) * K;
+  // hand-off tiles: k block kbi (32 gate columns) of a row block = one contiguous 2 KB slab [32 rows][32 cols]; this wave's quarter
+  const size_t tile_elems = (size_t)KB * 1024;
+  const int lane_off = (lane & 15) * 32 + kofs;
+
+  for (int t = a.T - 1; t >= 0; --t) {
+    // everything the cell backward needs from this block's own saved activations (overlaps the waits)
+    float g4[4][4], cc[4], cpv[4], dov[4];
+    if (a.frag) {
+      const int fw = wu * 2 + ((lane & 15) >> 3), fl = (lane >> 4) * 16 + wr * 8 + (lane & 7);
+      const size_t blk = (size_t)rb * nunit_blocks + nb, nblk = (size_t)nrb * nunit_blocks;
+      const f32x4* gb = reinterpret_cast<const f32x4*>(a.gates) + ((size_t)t * nblk + blk) * 1024 + (size_t)fw * 256 + fl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 v = gb[r * 64];
+        g4[r][0] = v[0];
+        g4[r][1] = v[1];
+        g4[r][2] = v[2];
+        g4[r][3] = v[3];
+      }
+      const f32x4 cv = reinterpret_cast<const f32x4*>(a.cseq)[((size_t)t * nblk + blk) * 256 + fw * 64 + fl];
+      f32x4 pv = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t > 0) pv = reinterpret_cast<const f32x4*>(a.cseq)[((size_t)(t - 1) * nblk + blk) * 256 + fw * 64 + fl];
+      else if (a.c0) pv = reinterpret_cast<const f32x4*>(a.c0)[blk * 256 + fw * 64 + fl];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        cc[r] = cv[r];
+        cpv[r] = pv[r];
+        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + rbase + r) * H + u] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + r;
+        const float* gp = a.gates + ((size_t)t * a.Bn + row) * K + ucol;
+        g4[r][0] = gp[0];
+        g4[r][1] = gp[32];
+        g4[r][2] = gp[64];
+        g4[r][3] = gp[96];
+        cc[r] = a.cseq[((size_t)t * a.Bn + row) * H + u];
+        cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
+        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
+      }
+    }
+    f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+    Frag fr0[KQ], fr1[KQ];
+    // this wave's quarter of a tile: 16-byte sc1 loads (L1 bypass; the agent-scope load of the gfx942 / gfx950 memory model)
+    auto load_quarter = [&](const bf16_t* tile) {
+      const bf16_t* b0 = tile + (size_t)wave * KQ * 1024 + lane_off;
+#pragma unroll
+      for (int it = 0; it < KQ; ++it) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr0[it].w) : "v"(b0 + (size_t)it * 1024));
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr1[it].w) : "v"(b0 + (size_t)it * 1024 + 512));
+      }
+    };
+    bool any = false;
+    if (has_x) {     // X stream: dG^{l+1}_t of the layer above (published one step ago when it leads) x W_ih^{l+1}
+      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0)) return;
+      LSTM_STAMP(dbg_base + 0)   // wait for the layer above
+      load_quarter(a.xin + ((size_t)t * nrb + rb) * tile_elems);
+      constexpr int QI = KQ / 4;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {   // loads return in order: a quarter of the k blocks at a time, MFMAs overlap the rest
+        if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * QI) : "memory");
+        if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QI) : "memory");
+        if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QI) : "memory");
+        if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < KQ; ++it)
+          if (it >= qd * QI && it < (qd + 1) * QI) {
+            asm volatile("" : "+v"(fr0[it].w));
+            asm volatile("" : "+v"(fr1[it].w));
+            p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, xw0[it].v, p00, 0, 0, 0);
+            p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, xw1[it].v, p01, 0, 0, 0);
+            p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, xw0[it].v, p10, 0, 0, 0);
+            p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, xw1[it].v, p11, 0, 0, 0);
+          }
+      }
+      any = true;
+      LSTM_STAMP(dbg_base + 1)   // X tile loads + MFMAs
+    }
+    if (t < a.T - 1 || a.has_next) {
+      if (t < a.T - 1) {
+        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2)) return;
+      } else {
+        __syncthreads();
+      }
+      LSTM_STAMP(dbg_base + 2)   // wait for dG_{t+1}
+      if (t < a.T - 1) {
+        load_quarter(a.xchg + ((size_t)(t + 1) * nrb + rb) * tile_elems);
+      } else {   // the following chunk's first step: row-major, written by an earlier launch
+        const int row0 = rb * 32 + (lane & 15), row1 = row0 + 16;
+#pragma unroll
+        for (int it = 0; it < KQ; ++it) {
+          fr0[it].v = *reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row0) * K + (wave * KQ + it) * 32 + kofs);
+          fr1[it].v = *reinterpret_cast<const bf16x8*>(a.dG + ((size_t)(t + 1) * a.Bn + row1) * K + (wave * KQ + it) * 32 + kofs);
+        }
+      }
+      constexpr int QI = KQ / 4;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (t < a.T - 1) {
+          if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * QI) : "memory");
+          if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QI) : "memory");
+          if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QI) : "memory");
+          if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int it = 0; it < KQ; ++it)
+          if (it >= qd * QI && it < (qd + 1) * QI) {
+            if (t < a.T - 1) {
+              asm volatile("" : "+v"(fr0[it].w));
+              asm volatile("" : "+v"(fr1[it].w));
+            }
+            const int kbi = wave * KQ + it;
+            const bf16x8 fb0 = *reinterpret_cast<const bf16x8*>(w0 + (kbi >> 2) * 128 + swz[it & 3]);
+            const bf16x8 fb1 = *reinterpret_cast<const bf16x8*>(w1 + (kbi >> 2) * 128 + swz[it & 3]);
+            p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb0, p00, 0, 0, 0);
+            p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, fb1, p01, 0, 0, 0);
+            p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb0, p10, 0, 0, 0);
+            p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, fb1, p11, 0, 0, 0);
+          }
+      }
+      any = true;
+      LSTM_STAMP(dbg_base + 3)   // dG tile loads + MFMAs
+    }
+    f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (any) {   // K-split reduction: sRed[wave][tile][lane] (f32x4), tile = wr * 2 + wu
+      f32x4* sRed = reinterpret_cast<f32x4*>(s_okp + 4);
+      sRed[(wave * 4 + 0) * 64 + lane] = p00;
+      sRed[(wave * 4 + 1) * 64 + lane] = p01;
+      sRed[(wave * 4 + 2) * 64 + lane] = p10;
+      sRed[(wave * 4 + 3) * 64 + lane] = p11;
+      __syncthreads();
+      const int tile = wr * 2 + wu;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const f32x4 v = sRed[(w * 4 + tile) * 64 + lane];
+        accf[0] += v[0];
+        accf[1] += v[1];
+        accf[2] += v[2];
+        accf[3] += v[3];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float gi = g4[r][0], gf = g4[r][1], gg = g4[r][2], go = g4[r][3];
+      const float dh = dov[r] + accf[r];
+      const float tc = tanhf_(cc[r]);
+      const float d_o = dh * tc;
+      const float dct = dcs[r] + dh * go * (1.f - tc * tc);
+      dcs[r] = dct * gf;
+      bf16_t* sp = sG + (wr * 16 + 4 * (lane >> 4) + r) * 136 + wu * 16 + (lane & 15);
+      sp[0] = f2bf(dct * gg * gi * (1.f - gi));
+      sp[32] = f2bf(dct * cpv[r] * gf * (1.f - gf));
+      sp[64] = f2bf(dct * gi * (1.f - gg * gg));
+      sp[96] = f2bf(d_o * go * (1.f - go));
+    }
+    __syncthreads();
+    LSTM_STAMP(dbg_base + 4)   // K-split reduction + cell backward + dG tile to LDS
+    const bool pub = t > 0 || a.feeds;
+    if (pub) {
+      // hand-off copy: 4 slabs [32 rows][32 cols] = 8 KB linear (piece c -> bytes [8c, 8c + 8)); consumed by step t - 1 / the layer below
+      bf16_t* xo = a.xchg + (((size_t)t * nrb + rb) * KB + 4 * nb) * 1024;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 256, r = (c >> 3) & 31, qq = c & 7;   // slab it, row r, 8-byte piece qq
+        xchg_store8(reinterpret_cast<u64_t*>(xo + c * 4), *reinterpret_cast<const u64_t*>(sG + r * 136 + it * 32 + qq * 4), fast);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+    }
+    // row-major copy for the weight-gradient GEMMs: off the other workgroups' critical path
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = tid + it * 256, r = c >> 5, q = c & 31;
+      *reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + rb * 32 + r) * K + nb * 128 + q * 4) = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+    }
+    LSTM_STAMP(dbg_base + 5)   // publish: stores, drain, signal
+  }
+  if (a.dc_io) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a.dc_io[(size_t)(rbase + r) * H + u] = dcs[r];
+  }
+}
+
+// records [net][layer index from the top: 0 = top layer]; a record with xW takes its X stream from the record before it
+struct LstmFusedBwdArgsN {
+  LstmFusedBwdArgs r[6];
+  int nnet, nl, nrb, nunit;
+  u64_t* group_words;
+  int force_cross_xcd;
+  unsigned* zero_ptr;
+  int zero_words;
+};
+
+template <int KB>
+__global__ __launch_bounds__(256) void lstm_fused_bwd_kernel(LstmFusedBwdArgsN m) {
+  if (blockIdx.x == 0 && m.zero_ptr)
+    for (int i = threadIdx.x; i < m.zero_words; i += 256) m.zero_ptr[i] = 0u;
+  const int L = blockIdx.x, s = L >> 3;
+  const int per = m.nl * m.nunit;
+  const int p = s / per, within = s - p * per;
+  const int SG = (L & 7) + 8 * p;
+  if (SG >= m.nnet * m.nrb) return;
+  const int layer = within / m.nunit, nb = within - layer * m.nunit;
+  const int net = SG / m.nrb, rb = SG - net * m.nrb;
+  lstm_fused_bwd_body<KB>(m.r[net * m.nl + layer], rb, nb, m.nrb, m.nunit, m.group_words + SG, per, m.force_cross_xcd);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dueling head + masked argmax (R2D2Net.forward tail, r2d2.py:106-115; _duel :124-131).
 // heads fp32 [M, ldh]: columns [0, A) = advantage, column A = value.  legal fp32 [M, A].
 // pass 1: q = v + a*legal - mean_A(a*legal), qa = q[action], per-block min(q);  pass 2: greedy with the GLOBAL min.
@@ -2472,7 +2786,7 @@ __global__ void aux_xent_kernel(const float* __restrict__ heads, int ldh, const 
 
 // out[row_map ? row_map[r] : r][:] = sum over the n split-K slabs of ws[z][r][:]   (N % 4 == 0, 16-byte aligned rows)
 __global__ void sum_slabs_kernel(const float* __restrict__ ws, int n, int M, int N, float* __restrict__ out, int ldc,
-                                 const int32_t* __restrict__ row_map) {
+                                 const int32_t* __restrict__ row_map, int accumulate) {
   const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n4 = N / 4;
   if (i4 >= (size_t)M * n4) return;
@@ -2486,6 +2800,12 @@ __global__ void sum_slabs_kernel(const float* __restrict__ ws, int n, int M, int
     a.w += b.w;
   }
   float* p = out + (size_t)(row_map ? row_map[r] : r) * ldc + c;
+  if (accumulate) {      // (one writer per element and launch: launches on one stream add up in order)
+    a.x += p[0];
+    a.y += p[1];
+    a.z += p[2];
+    a.w += p[3];
+  }
   p[0] = a.x;
   p[1] = a.y;
   p[2] = a.z;
@@ -2981,8 +3301,19 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
                      0, nullptr, stream);
 }
 
+static int gemm_splitk_impl(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                           float* C32, int ldc, const int32_t* row_map, int accumulate, void* stream);
 int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
                              float* C32, int ldc, const int32_t* row_map, void* stream) {
+  return gemm_splitk_impl(A, lda, B, ldb, M, N, K, split_k, workspace, C32, ldc, row_map, 0, stream);
+}
+/* the same, ADDED to C32 (deterministic: slabs, then one adding pass): the contraction arrives in pieces, e.g. per time chunk */
+int hsad_gemm_nt_bf16_splitk_acc(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                                 float* C32, int ldc, const int32_t* row_map, void* stream) {
+  return gemm_splitk_impl(A, lda, B, ldb, M, N, K, split_k, workspace, C32, ldc, row_map, 1, stream);
+}
+static int gemm_splitk_impl(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                           float* C32, int ldc, const int32_t* row_map, int accumulate, void* stream) {
   if (!workspace || !C32 || split_k < 1 || (N & 3) || (ldc & 3) || ((uintptr_t)workspace & 15))
     return nfail(HSAD_ERR_INVALID, "gemm_splitk: needs a workspace, N and ldc multiples of 4");
   int n_split = 1;
@@ -2991,7 +3322,7 @@ int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int
   if (rc) return rc;
   const size_t n4 = (size_t)M * (N / 4);
   hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, M,
-                     N, C32, ldc, row_map);
+                     N, C32, ldc, row_map, accumulate);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -3706,6 +4037,71 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     g_fused_timing.ev.push_back({te0, te1});
     g_fused_timing.flop.push_back((double)nrec * 2.0 * T * Bn * 4.0 * H * 2.0 * H);      // [x | h] [W_ih | W_hh]^T per recurrence
   }
+  return HSAD_OK;
+}
+
+// Fused persistent BPTT (lstm_fused_bwd_kernel): nnet nets x nlayer stacked layers over a chunk of Tc steps in one launch; records
+// [net][layer counted from the TOP]; a record with WihT_above_blocked takes dO from the tiles of the record before it.
+int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch,
+                             void* next_sync_scratch, void* stream) {
+  const int nrec = nnet * nlayer;
+  if (nnet < 1 || nlayer < 1 || nrec > 6 || !recs || !sync_scratch || Tc < 1) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: bad arguments");
+  if (!((H == 256 || H == 512) && Bn >= 32 && Bn % 32 == 0)) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: needs H in {256,512}, rows a multiple of 32");
+  hipStream_t s = (hipStream_t)stream;
+  const int nrb = Bn / 32, nunit = H / 32, nsg = nnet * nrb;
+  const int grid = 8 * nlayer * nunit * ((nsg + 7) / 8);
+  if (grid > device_cus())
+    return nfail(HSAD_ERR_INVALID, "fused persistent BPTT launch needs %d co-resident workgroups per XCD, the device has %d", grid / 8, device_cus() / 8);
+  unsigned* sync = (unsigned*)sync_scratch;
+  unsigned* counters = sync + 2 * nrec * nrb;
+  const size_t words = seq_sync_words(nrec, Tc, nrb);
+  if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
+  LstmFusedBwdArgsN m{};
+  for (int i = 0; i < nrec; ++i) {
+    const hsad_lstm_fused_bwd_rec& r = recs[i];
+    const int layer = i % nlayer;
+    if (!r.WhhT_blocked || !r.gates || !r.cseq || !r.dG16 || !r.dc_io || !r.xchg || (r.WihT_above_blocked && layer == 0))
+      return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: null pointer in record %d (or an X stream on the top layer)", i);
+    bf16_t* dG = (bf16_t*)r.dG16;
+    if (!r.has_next && !r.tail_is_zero) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
+    LstmFusedBwdArgs& q = m.r[i];
+    q.WhhT = (const bf16_t*)r.WhhT_blocked;
+    q.xW = (const bf16_t*)r.WihT_above_blocked;
+    q.xin = r.WihT_above_blocked ? (const bf16_t*)recs[i - 1].xchg : nullptr;
+    q.xin_counters = r.WihT_above_blocked ? counters + (size_t)(i - 1) * Tc * nrb : nullptr;
+    q.gates = r.gates;
+    q.cseq = r.cseq;
+    q.c0 = r.c_before;
+    q.dO = r.dO;
+    q.dG = dG;
+    q.xchg = (bf16_t*)r.xchg;
+    q.counters = counters + (size_t)i * Tc * nrb;
+    q.timeout = counters + (size_t)nrec * Tc * nrb;
+    q.dc_io = r.dc_io;
+    q.dbg = g_lstm_dbg_enable;
+    q.T = Tc;
+    q.Bn = Bn;
+    q.has_next = r.has_next;
+    q.frag = r.saved_frag_major;
+    q.feeds = (layer + 1 < nlayer && recs[i + 1].WihT_above_blocked) ? 1 : 0;
+  }
+  m.nnet = nnet;
+  m.nl = nlayer;
+  m.nrb = nrb;
+  m.nunit = nunit;
+  m.group_words = reinterpret_cast<u64_t*>(sync);
+  m.force_cross_xcd = g_force_cross_xcd;
+  m.zero_ptr = (unsigned*)next_sync_scratch;
+  m.zero_words = next_sync_scratch ? (int)words : 0;
+  const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
+  if (H == 512) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_fused_bwd_kernel<64>, dim3(grid), dim3(256), lds, s, m);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_bwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(lstm_fused_bwd_kernel<32>, dim3(grid), dim3(256), lds, s, m);
+  }
+  HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
 

@@ -392,6 +392,9 @@ int hsad_gemm_nt_bf16_ex(const void* A, int lda, const void* B, int ldb, int M, 
  * C32[row_map ? row_map[r] : r] (overwritten).  N and ldc multiples of 4. */
 int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
                              float* C32, int ldc, const int32_t* row_map, void* stream);
+/* the same, ADDED to C32 instead of overwriting it (slabs, then one adding pass: deterministic) -- a contraction that arrives in pieces */
+int hsad_gemm_nt_bf16_splitk_acc(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
+                                 float* C32, int ldc, const int32_t* row_map, void* stream);
 /* hsad_transpose_bf16 that also accumulates (atomically) the column sums of src into colsum[col_map ? col_map[c] : c]
  * (and colsum2): the bias gradients come for free while the weight-gradient operand is transposed */
 int hsad_transpose_bf16_colsum(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, float* colsum, float* colsum2,
@@ -531,6 +534,29 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
  * launch duration, the algorithmic FLOP per launch (2 T Bn 4H 2H per recurrence) and the launch count, synchronises, clears */
 int hsad_lstm_fused_timing(int enable);
 int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches);
+/* FUSED persistent BPTT (round 3): the stacked layers of nnet nets over a chunk of Tc steps in ONE launch, one step apart; the gradient a
+ * lower layer receives from the layer above, dO = dG_above W_ih_above (a stand-alone GEMM per chunk in hsad_lstm_backward_chunk_multi's
+ * schedule), is computed inside the lower layer's recurrence from the hand-off tiles the layer above publishes (W_ih_above^T slice
+ * register-resident, W_hh^T slice in LDS).  recs[net * nlayer + k], k = 0 the TOP layer of the launch (dO = the fp32 gradient from
+ * outside, e.g. the heads), k > 0: WihT_above_blocked = the [H,4H] transposed gate-blocked W_ih of record k - 1's layer, dO NULL.
+ * Other fields as hsad_lstm_bwd_rec (xchg required).  Needs nlayer * (H/32) * ceil(nnet * Bn/32 / 8) <= CUs / 8, H in {256, 512},
+ * Bn % 32 == 0.  sync_scratch: uint32 [nnet*nlayer*(Tc+2)*Bn/32 + 4], ping-pong convention of hsad_lstm_forward_chunk_multi. */
+typedef struct hsad_lstm_fused_bwd_rec {
+  const void* WhhT_blocked;
+  const void* WihT_above_blocked;
+  const float* gates;
+  const float* cseq;
+  const float* c_before;
+  const float* dO;
+  void* dG16;
+  float* dc_io;
+  int has_next;
+  void* xchg;
+  int saved_frag_major;
+  int tail_is_zero;
+} hsad_lstm_fused_bwd_rec;
+int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch,
+                             void* next_sync_scratch, void* stream);
 /* Chunked persistent recurrences for layer pipelining (one launch per chunk of Tc steps, state carried across
  * launches): h_prev16 bf16 [Bn,H] / c_prev fp32 [Bn,H] = state entering the chunk (c_prev NULL = zeros). */
 int hsad_lstm_forward_chunk(int Tc, int Bn, int H, float* gates, const void* Whh_blocked, const void* h_prev16,

@@ -16,7 +16,7 @@ batch = {"priv_s": (torch.rand(T, B, F, device=dev) < 0.15).float() * mask.unsqu
          "seq_len": seq_len, "own_hand": torch.zeros(T, B, 15, device=dev)}
 weight = torch.ones(B, device=dev)
 lr = CompositeLearner(W, W, 3, 0.999, device=dev)
-for fused in (1, 3, 0, 1, 3):
+for fused in (1, 3, 0, 1 | (1 << 8), 1 | (2 << 8), 1 | (4 << 8), 3):
     lr.set_fused(fused)
     def upd():
         lr.loss(batch, weight, 0.0); lr.optimizer_step()
@@ -31,5 +31,5 @@ for fused in (1, 3, 0, 1, 3):
     e0.record()
     for _ in range(50): lr.loss(batch, weight, 0.0, compute_grad=False)
     e1.record(); torch.cuda.synchronize()
-    print("fused=%d  %.3f ms/update  (host issue %.3f ms)  %.1f k sequences/s   forward only %.3f ms" % (fused, dt * 1e3, t_issue * 1e3, B / dt / 1e3, e0.elapsed_time(e1) / 50), flush=True)
+    print("fused=0x%x  %.3f ms/update  (host issue %.3f ms)  %.1f k sequences/s   forward only %.3f ms" % (fused, dt * 1e3, t_issue * 1e3, B / dt / 1e3, e0.elapsed_time(e1) / 50), flush=True)
 lr.check_sync()
