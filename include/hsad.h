@@ -633,9 +633,13 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
                              float lr, float eps, float grad_clip, hsad_r2d2_learner** out);
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* learner);
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int wgrad_split);
-/* fused_fwd != 0 (the default): the forward recurrences of hsad_r2d2_loss_fwd run as whole-sequence fused launches
- * (hsad_lstm_forward_fused: projection inside the recurrence, layers one step apart, online + target net together) when the shape
- * allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s workgroups fit an XCD); 0: the chunk-pipelined schedule.  Synchronises. */
+/* Recurrence schedule of a learner (flags; the default is 1 with one BPTT chunk).  Synchronises.
+ *   bit 0      the forward recurrences of hsad_r2d2_loss_fwd run as whole-sequence fused launches (hsad_lstm_forward_fused: projection inside
+ *              the recurrence, layers one step apart, online + target net together) and BPTT as hsad_lstm_backward_fused launches (both layers,
+ *              dO of the lower layer inside its recurrence) when the shape allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s
+ *              workgroups fit an XCD); 0: the chunk-pipelined schedule of rounds 1-2 (stand-alone projection / dO GEMMs between chunk launches)
+ *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
+ *   bits 8-15  time chunks of the fused BPTT, 1..8 (the weight gradients are added up per chunk); 0 keeps the current setting */
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);

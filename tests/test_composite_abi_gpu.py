@@ -307,7 +307,7 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
     W, Wt = _rand_net(F, H, A, seed=13), _rand_net(F, H, A, seed=14)
     batch, weight = _rand_batch(T, B, F, A)
     L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
-    modes = {"fused": 1, "fused fwd + chunked bwd": 3, "fused, BPTT in 2 chunks": 1 | (2 << 8), "chunked": 0}
+    modes = {"fused": 1 | (1 << 8), "fused fwd + chunked bwd": 3, "fused, BPTT in 2 chunks": 1 | (2 << 8), "chunked": 0}   # (bits 8-15 = BPTT chunks; 0 keeps the last setting)
     res = {}
     for rep in range(2):
         for name, flags in modes.items():
