@@ -1102,7 +1102,7 @@ typedef unsigned long long u64_t;
 
 // developer phase timers of the persistent recurrences (hsad_lstm_debug_timing): wall-clock ticks (100 MHz) summed over
 // the steps of ONE workgroup (row block 0, unit block 0); slots 0-7 forward, 8-15 backward
-__device__ u64_t g_lstm_dbg[16];
+__device__ u64_t g_lstm_dbg[32];   // 0-15 forward kernels (and the chunked backward at 8-15), 16-31 fused backward
 #define LSTM_STAMP(slot)                                      \
   if (dbg_on) {                                               \
     const u64_t now_ = wall_clock64();                        \
@@ -2140,17 +2140,25 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
   if (s_okp[1] < 0) return;
   const int fast = force_cross_xcd ? 0 : s_okp[1];
   const bool dbg_on = (a.dbg && rb == 0 && nb == 0 && tid == 0);
-  const int dbg_base = has_x ? 8 : 0;
+  const int dbg_base = has_x ? 24 : 16;
   u64_t stamp_ = dbg_on ? wall_clock64() : 0;
 
-  auto wait_ctr = [&](unsigned* ctr, int slot) -> bool {
+  // probe (optional): a second counter whose value is fetched by the SAME scalar round trip as the first poll -- "has the layer above
+  // already published the step after this one?" -> s_okp[3]: the next step then starts its X loads without a poll of its own
+  auto wait_ctr = [&](unsigned* ctr, int slot, unsigned* probe) -> bool {
     if (tid == 0) {
       unsigned spins = 0;
       int ok = 1;
-      for (;;) {
+      unsigned pv = 0;
+      for (bool first = true;; first = false) {
         unsigned v;
-        if (fast) asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
-        else v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fast) {
+          if (first && probe) asm volatile("s_load_dword %0, %2, 0x0 glc\n\ts_load_dword %1, %3, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v), "=&s"(pv) : "s"(ctr), "s"(probe) : "memory");
+          else asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
+        } else {
+          v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (first && probe) pv = __hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (v >= (unsigned)nunit_blocks) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > 8000000u) {
@@ -2160,10 +2168,12 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
         }
       }
       s_okp[slot] = ok;
+      s_okp[3] = pv >= (unsigned)nunit_blocks;
     }
     __syncthreads();
     return s_okp[slot] != 0;
   };
+  bool x_ready = false;      // the layer above is known to have published this step's tile (seen by the previous step's poll)
   // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
   int swz[4];
 #pragma unroll
@@ -2226,7 +2236,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     };
     bool any = false;
     if (has_x) {     // X stream: dG^{l+1}_t of the layer above (published one step ago when it leads) x W_ih^{l+1}
-      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0)) return;
+      if (!x_ready && !wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0, nullptr)) return;
       LSTM_STAMP(dbg_base + 0)   // wait for the layer above
       load_quarter(a.xin + ((size_t)t * nrb + rb) * tile_elems);
       constexpr int QI = KQ / 4;
@@ -2251,8 +2261,10 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
       LSTM_STAMP(dbg_base + 1)   // X tile loads + MFMAs
     }
     if (t < a.T - 1 || a.has_next) {
+      x_ready = false;
       if (t < a.T - 1) {
-        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2)) return;
+        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2, (has_x && t > 0) ? a.xin_counters + (size_t)(t - 1) * nrb + rb : nullptr)) return;
+        x_ready = has_x && t > 0 && s_okp[3] != 0;
       } else {
         __syncthreads();
       }
@@ -3610,7 +3622,16 @@ int hsad_lstm_debug_enable(int enable) {
 int hsad_lstm_debug_timing(uint64_t* out16, int reset) {
   if (out16) HIP_TRY(hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lstm_dbg), sizeof(uint64_t) * 16));
   if (reset) {
-    const uint64_t z[16] = {0};
+    const uint64_t z[32] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_dbg), z, sizeof(z)));
+  }
+  return HSAD_OK;
+}
+/* all 32 slots: 0-15 as hsad_lstm_debug_timing, 16-21 / 24-29 the fused BPTT kernel's top / lower layer */
+int hsad_lstm_debug_timing32(uint64_t* out32, int reset) {
+  if (out32) HIP_TRY(hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_lstm_dbg), sizeof(uint64_t) * 32));
+  if (reset) {
+    const uint64_t z[32] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_dbg), z, sizeof(z)));
   }
   return HSAD_OK;

@@ -358,6 +358,7 @@ int hsad_lstm_set_exchange_mode(int force_cross_xcd);
  * 0-5 forward: wait, h loads, MFMA, cell update, publish, state stores; 8-11 backward: wait, loads+MFMA, cell backward,
  * publish); out16 may be NULL; reset != 0 clears them */
 int hsad_lstm_debug_timing(uint64_t* out16, int reset);
+int hsad_lstm_debug_timing32(uint64_t* out32, int reset);   /* + slots 16-31: the fused BPTT kernel (top layer 16-21, lower layer 24-29) */
 /* phase timers of the FUSED persistent kernels (off by default: a stamp costs ~0.1 us of the ~5 us step it measures) */
 int hsad_lstm_debug_enable(int enable);
 /* measurement hook for the fused cell kernel (hsad_lstm_cell_fused, i.e. every LSTM layer of an acting step): while enabled, each
