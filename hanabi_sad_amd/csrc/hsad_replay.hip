@@ -1032,31 +1032,84 @@ __global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err)
 
 }  // namespace
 
-// Ordering across two streams without the caller's help: the flush of finished sequences may be issued on a side stream (the actor
-// loop overlaps its single-workgroup scans with the next step's network passes); it arms this fence, and the next operation on the
-// same object that arrives on ANOTHER stream first makes its stream wait for the flush.  One event record per flush, one wait per
-// consumer stream -- not a marker per call.
+// Ordering across streams without the caller's help.  The flush of finished sequences may be issued on a side stream (the actor loop
+// overlaps its single-workgroup scans with the next step's network passes) while the object's other operations -- push, add, sample,
+// serve, update_priority ... ("consumers") -- arrive on the actor's main stream, a learner's compute stream, an exchange stream:
+//   * flush -> consumers: arm() records an event per flush (a new GENERATION); every consumer stream waits for the current generation
+//     ONCE (pass(): a small per-stream table, so a second and third consumer stream are ordered behind the flush, too);
+//   * consumers -> next flush: FenceUse (RAII, at the top of every consumer entry point) records a per-stream event when the
+//     operation has been enqueued; begin_flush() makes the flush's stream wait for every such event recorded since the last flush.
+// Operations on the flush's own stream need neither (stream order).
 struct StreamFence {
+  static constexpr int kMax = 8;            // distinct streams per object; a ninth is refused
   hipEvent_t ev = nullptr;
   hipStream_t stream = nullptr;
-  bool armed = false;
-  hipError_t arm(hipStream_t s) {
+  uint64_t gen = 0;
+  hipStream_t seen_s[kMax];
+  uint64_t seen_g[kMax];
+  int nseen = 0;
+  hipStream_t cons_s[kMax];
+  hipEvent_t cons_ev[kMax];
+  bool cons_dirty[kMax];
+  int ncons = 0;
+  hipError_t arm(hipStream_t s) {           // the flush has been enqueued on s
     if (!ev) {
       hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
       if (e != hipSuccess) return e;
     }
     stream = s;
-    armed = true;
+    ++gen;
     return hipEventRecord(ev, s);
   }
-  hipError_t pass(hipStream_t s) {        // call at the top of every operation that touches what the flush touches
-    if (!armed || s == stream) return hipSuccess;
-    armed = false;                        // later work on `s` is ordered behind this wait
+  hipError_t pass(hipStream_t s) {          // an operation is about to be enqueued on s: order it behind the current flush, once per stream
+    if (!gen || s == stream) return hipSuccess;
+    for (int i = 0; i < nseen; ++i)
+      if (seen_s[i] == s) {
+        if (seen_g[i] == gen) return hipSuccess;
+        seen_g[i] = gen;
+        return hipStreamWaitEvent(s, ev, 0);
+      }
+    if (nseen == kMax) return hipErrorInvalidValue;
+    seen_s[nseen] = s;
+    seen_g[nseen++] = gen;
     return hipStreamWaitEvent(s, ev, 0);
+  }
+  hipError_t begin_flush(hipStream_t s) {   // a flush is about to be enqueued on s: behind every consumer operation on other streams since the last one
+    for (int i = 0; i < ncons; ++i)
+      if (cons_dirty[i] && cons_s[i] != s) {
+        hipError_t e = hipStreamWaitEvent(s, cons_ev[i], 0);
+        if (e != hipSuccess) return e;
+        cons_dirty[i] = false;
+      }
+    return hipSuccess;
+  }
+  void consumed(hipStream_t s) {            // a consumer operation has been enqueued on s
+    if (gen && s == stream) return;         // the flush stream itself: stream order
+    int k = -1;
+    for (int i = 0; i < ncons; ++i)
+      if (cons_s[i] == s) k = i;
+    if (k < 0) {
+      if (ncons == kMax) return;            // (pass() already refused a ninth stream)
+      if (hipEventCreateWithFlags(&cons_ev[ncons], hipEventDisableTiming) != hipSuccess) return;
+      k = ncons++;
+      cons_s[k] = s;
+    }
+    cons_dirty[k] = hipEventRecord(cons_ev[k], s) == hipSuccess;
   }
   void destroy() {
     if (ev) (void)hipEventDestroy(ev);
     ev = nullptr;
+    for (int i = 0; i < ncons; ++i) (void)hipEventDestroy(cons_ev[i]);
+    ncons = 0;
+  }
+};
+struct FenceUse {      // `FenceUse use(obj->fence, stream);` after the arguments were validated: pass() now, consumed() when the entry point returns
+  StreamFence& f;
+  hipStream_t s;
+  hipError_t err;
+  FenceUse(StreamFence& fence, hipStream_t stream) : f(fence), s(stream), err(fence.pass(stream)) {}
+  ~FenceUse() {
+    if (err == hipSuccess) f.consumed(s);
   }
 };
 
@@ -1228,7 +1281,8 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
   if (n < 1) return HSAD_OK;
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, n, n_dev, priority);
   FieldPtrs fp;
   for (int k = 0; k < kMaxFields; ++k) fp.p[k] = k < r->L.n_fields ? fields[k] : nullptr;
@@ -1247,7 +1301,8 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "batch must be 1..%d", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   // canonical uniforms exactly as std::uniform_real_distribution<float> would draw them (libstdc++:
   // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
   // the segment depends on the device-side running sum)
@@ -1291,7 +1346,8 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (n < 0 || n > kMaxBatch || (n > 0 && (!targets_host || !raw_weight))) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   if (n > 0) {
     int slot;
     float* hc = canon_slot(r, &slot);
@@ -1316,7 +1372,8 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
   if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
   if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
   r->last_stream = (hipStream_t)stream;
-  HIP_TRY(r->fence.pass((hipStream_t)stream));
+  FenceUse use_r(r->fence, (hipStream_t)stream);
+  HIP_TRY(use_r.err);
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -1325,7 +1382,8 @@ int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch
 // ---- the sharded draw without host round trips (kernels above; choreography: hanabi_sad_amd/dist.py ReplayLink) ----
 int hsad_replay_stats(hsad_replay* r, double* out2, void* stream) {
   if (!r || !out2) return rfail(HSAD_ERR_INVALID, "null argument");
-  HIP_TRY(r->fence.pass((hipStream_t)stream));
+  FenceUse use_r(r->fence, (hipStream_t)stream);
+  HIP_TRY(use_r.err);
   hipLaunchKernelGGL(replay_stats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, r->rd, out2);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
@@ -1340,7 +1398,8 @@ int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const doubl
     return rfail(HSAD_ERR_INVALID, "serve: batch 1..%d, world 1..64, rank inside it", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   float* raw_w = r->d_shard + kMaxBatch;
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch);
   hipLaunchKernelGGL(shard_targets_kernel, dim3(1), dim3(1024), 0, s, all_stats, world, rank, canon, batch, owner_out, r->d_canon, n_mine);
@@ -1357,7 +1416,8 @@ int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, c
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch) + 1;
   hipLaunchKernelGGL(compact_owned_kernel, dim3(1), dim3(1024), 0, s, priority, owner, batch, rank, r->d_shard, n_mine);
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_shard, n_mine);
@@ -1431,7 +1491,8 @@ int hsad_replay_get(hsad_replay* r, int idx, void* const* out_fields, float* rew
                     float* bootstrap, float* seq_len, void* stream) {
   if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
   hipStream_t s = (hipStream_t)stream;
-  HIP_TRY(r->fence.pass(s));
+  FenceUse use_r(r->fence, s);
+  HIP_TRY(use_r.err);
   hipLaunchKernelGGL(ids_from_head_kernel, dim3(1), dim3(1), 0, s, r->rd, idx, r->d_tmp_id);
   const FieldOut fp = field_out(r->L, out_fields);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, 1, r->T, r->d_tmp_id, 0,
@@ -1600,7 +1661,8 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
 int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream) {
   if (!w || !priority) return rfail(HSAD_ERR_INVALID, "null argument");
   if (!w->pending) return rfail(HSAD_ERR_STATE, "no popped transition to push");
-  HIP_TRY(w->fence.pass((hipStream_t)stream));   // the previous flush (possibly on another stream) resets the cursors this reads
+  FenceUse use_w(w->fence, (hipStream_t)stream);   // the previous flush (possibly on another stream) resets the cursors this reads
+  HIP_TRY(use_w.err);
   if (w->L.row_bytes <= 256)
     hipLaunchKernelGGL(seq_push_kernel<16>, dim3((w->sd.E + 15) / 16), dim3(256), 0, (hipStream_t)stream, w->sd, w->L.row_bytes,
                        w->pend_slot, priority, w->d_err);
@@ -1618,8 +1680,10 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
     return rfail(HSAD_ERR_INVALID, "sequence writer and replay were created with different layouts");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(w->fence.pass(s));
+  HIP_TRY(w->fence.pass(s));           // behind the previous flush ...
   HIP_TRY(r->fence.pass(s));
+  HIP_TRY(w->fence.begin_flush(s));    // ... and behind every push / add / sample / serve / update issued on another stream since
+  HIP_TRY(r->fence.begin_flush(s));
   const SeqDev& sd = w->sd;
   const float c1m = (float)(1.0 - (double)eta);
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);

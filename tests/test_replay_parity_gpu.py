@@ -349,3 +349,64 @@ def test_running_sum_drift_of_large_blocks_is_repaired():
         drift.append(abs(after - before))
     rep.check_errors()                        # no draw ever fell beyond the cumulative weight
     assert max(drift) > 0.05                  # ... although the running sum did drift (a repair shows as a jump at a sample without eviction)
+
+
+def test_three_streams_are_ordered_by_the_library_fence():
+    """the flush of finished sequences runs on a side stream, pushes on the actor's main stream, sample on an exchange
+    stream and update_priority on a compute stream.  The library's StreamFence must order every consumer stream behind the flush
+    (not just the first one) and the next flush behind the consumers -- with no host synchronisation between the calls the run must
+    end in exactly the state of the same calls on one stream."""
+    from hanabi_sad_amd.replay import DeviceReplay, SequenceWriter
+    E, d, n, T, gamma, eta, B, cap = 256, 24, 3, 12, 0.99, 0.9, 32, 1024
+    fields = [("s", d, torch.float32), ("a", 1, torch.int64)]
+
+    def run(multi):
+        rng = np.random.default_rng(3)
+        torch.manual_seed(0)
+        w = SequenceWriter(E, n, gamma, T, fields, DEV)
+        rep = DeviceReplay(cap, 7, 0.9, 0.6, 0, T, fields, DEV)
+        main = torch.cuda.current_stream()
+        side, exch, comp = (torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()) if multi else (main, main, main)
+        nfin = torch.zeros(1, dtype=torch.int32, device=DEV)
+        # inputs prepared up front (the streams only see library calls)
+        steps = 160
+        obs = torch.rand(steps, E, d, device=DEV)
+        act = torch.randint(0, 5, (steps, E, 1), device=DEV)
+        rew = torch.rand(steps, E, device=DEV)
+        term = ((torch.arange(steps, device=DEV).view(-1, 1) + torch.arange(E, device=DEV).view(1, -1) % 5) % 9 == 8).to(torch.uint8)   # episodes of 9 steps <= T
+        prio = torch.rand(steps, E, device=DEV) * 2 + 0.01
+        newp = torch.rand(steps, B, device=DEV) + 0.05
+        torch.cuda.synchronize()
+        sampled = 0
+        for t in range(steps):
+            w.push_obs_action({"s": obs[t], "a": act[t]})
+            w.push_reward_terminal(rew[t], term[t])
+            if not w.can_pop():
+                continue
+            w.pop_transition(want_fields=False)
+            w.push_sequence(prio[t])
+            with torch.cuda.stream(side):
+                if multi:
+                    side.wait_stream(main)          # what actor.DeviceActor does: the flush reads what the push just wrote
+                w.flush_to_replay(rep, eta, out=nfin)
+            if t % 7 == 6 and t > 40:               # no host sync in between: only the library orders sample / update vs the flush
+                with torch.cuda.stream(exch):
+                    rep.sample(B)
+                with torch.cuda.stream(comp):
+                    if multi:
+                        comp.wait_stream(exch)      # (the learner's data dependency: priorities come from the sampled batch)
+                    rep.update_priority(newp[t])
+                sampled += 1
+        torch.cuda.synchronize()
+        rep.check_errors()
+        assert sampled >= 10
+        state = [rep.size(), rep.num_add(), float(rep.priority_sum()[0])]
+        for idx in (0, rep.size() // 3, rep.size() - 1):
+            f, r_, t_, b_, sl = rep.get(idx)
+            state.append((f["s"].cpu(), f["a"].cpu(), r_.cpu(), float(sl.item())))
+        return state
+
+    one, many = run(False), run(True)
+    assert one[:2] == many[:2] and abs(one[2] - many[2]) <= 1e-6 * abs(one[2])
+    for a, b in zip(one[3:], many[3:]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
