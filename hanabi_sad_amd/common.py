@@ -55,13 +55,17 @@ class Logger:
 
 
 class TopkSaver:
-    """keeps the `topk` best-scoring weight files model0.pthw .. model{k-1}.pthw in save_dir, plus forced names
-    (model_epochN.pthw) and latest.pthw on request; save() returns whether the candidate entered the top k
-    (common_utils/saver.py:17-61; called selfplay.py:267-273 with model=None, the online net's state_dict and the eval score)"""
+    """the reference's checkpoint bookkeeping (common_utils/saver.py:17-61; called selfplay.py:267-273 with model=None, the online
+    net's state_dict and the eval score), slot for slot -- including its quirks, so that a save_dir is comparable file by file:
+    the score list starts as [-inf]; while it is shorter than `topk` every accepted candidate is written to the CURRENT worst slot
+    (slot 0, whose -inf entry is only replaced once the list is full) and appended; from then on a candidate replaces the worst slot
+    iff it beats it strictly, and the first minimal entry becomes the next worst slot.  Forced names (model_epochN) and latest are
+    written first, whatever the score.  Returns whether the candidate was written to a model{i} slot."""
 
     def __init__(self, save_dir, topk):
         self.save_dir, self.topk = save_dir, int(topk)
-        self.perfs = []              # score of slot i = model{i}.pthw
+        self.perfs = [-float("inf")]
+        self.worst, self.worst_slot = self.perfs[0], 0
         os.makedirs(save_dir, exist_ok=True)
 
     def _write(self, model, state_dict, stem):
@@ -75,15 +79,15 @@ class TopkSaver:
             self._write(model, state_dict, force_save_name)
         if save_latest:
             self._write(model, state_dict, "latest")
-        if len(self.perfs) < self.topk:
-            slot = len(self.perfs)
+        if perf <= self.worst:
+            return False
+        self._write(model, state_dict, "model%d" % self.worst_slot)
+        if len(self.perfs) < self.topk:          # still filling: the list grows, the worst slot stays where it is
             self.perfs.append(perf)
-        else:
-            slot = int(np.argmin(self.perfs))
-            if perf <= self.perfs[slot]:
-                return False
-            self.perfs[slot] = perf
-        self._write(model, state_dict, "model%d" % slot)
+            return True
+        self.perfs[self.worst_slot] = perf
+        self.worst = min(self.perfs)
+        self.worst_slot = self.perfs.index(self.worst)      # first minimal entry
         return True
 
 

@@ -265,7 +265,11 @@ class Context:
 
     def __init__(self):
         self.loops, self._thread, self._paused, self._stop, self._error = [], None, False, False, None
-        self._parked = threading.Event()      # set by the loop thread while it sits between two steps with _paused seen
+        # pause protocol: every pause() takes a ticket; the loop thread acknowledges the ticket it has SEEN while parked between two
+        # steps, so a pause() can only return on an acknowledgement of its own request (an Event could still be set from the
+        # previous pause when a resume / pause pair follows within the thread's 1 ms nap)
+        self._cv = threading.Condition()
+        self._pause_ticket, self._parked_ticket, self._done = 0, 0, False
 
     def push_env_thread(self, loop):
         self.loops.append(loop)
@@ -276,10 +280,12 @@ class Context:
         try:
             while not self._stop:
                 if self._paused:
-                    self._parked.set()
+                    with self._cv:
+                        if self._paused and self._parked_ticket != self._pause_ticket:
+                            self._parked_ticket = self._pause_ticket
+                            self._cv.notify_all()
                     time.sleep(0.001)
                     continue
-                self._parked.clear()
                 busy = False
                 for lp in self.loops:
                     if self._paused or self._stop:
@@ -293,7 +299,9 @@ class Context:
         except Exception as e:   # surfaced by the next Context call from the driver's thread
             self._error = e
         finally:
-            self._parked.set()
+            with self._cv:
+                self._done = True
+                self._cv.notify_all()
 
     def _check(self):
         if self._error is not None:
@@ -334,15 +342,18 @@ class Context:
         """blocks until the loop thread is parked between two steps, like the reference's pause (rela/context.h:52-60 waits
         for every ThreadLoop to reach waitUntilResume)"""
         self._check()
-        self._paused = True
-        if self._thread is not None and self._thread.is_alive():
-            self._parked.wait()
+        with self._cv:
+            self._pause_ticket += 1
+            ticket = self._pause_ticket
+            self._paused = True
+            if self._thread is not None and self._thread.is_alive():
+                self._cv.wait_for(lambda: self._done or self._parked_ticket == ticket)
         self._check()
 
     def resume(self):
         self._check()
-        self._parked.clear()
-        self._paused = False
+        with self._cv:
+            self._paused = False
 
     def terminate(self):
         self._stop = True

@@ -418,7 +418,19 @@ def main(argv=None):
         print("*****loading pretrained model*****")
         load_weight(tr.learner.online.w, args.load_model)        # online net only, like selfplay.py:143-146
         tr.learner.online.refresh()
+        # the reference loads BEFORE ActGroup clones the agent (selfplay.py:143-171): burn-in data and its priorities come from the loaded
+        # model.  Here the acting nets already exist: bring the target in line like at update 0 (selfplay.py:209-210) and hand both to
+        # the actors now (several GPUs: the first parameter round carries them before the actors' burn-in, run_link_learner)
+        tr.learner.sync_target_with_online()
+        tr.update_actor_model()
         print("*****done*****")
+    elif args.load_model:
+        # an actor rank of a multi-GPU job: it reads the file itself, so that its burn-in runs on the loaded model as well instead of
+        # on the random initialisation until the first parameter round
+        from .checkpoint import load_weight
+        for net in (tr.act_online, tr.act_target):
+            load_weight(net.w, args.load_model, verbose=False)
+            net.refresh()
     if world > 1:
         link = make_link(tr, args)
         if rank != 0:

@@ -26,18 +26,25 @@ def test_every_reference_flag_is_accepted():
         parse_args(["--shuffle_obs", "1"])
 
 
-def test_topk_saver_keeps_the_best_k(tmp_path):
+def test_topk_saver_follows_the_reference_slot_for_slot(tmp_path):
+    """tests/golden/topk_saver_trace.json: the reference's TopkSaver driven with fixed score sequences (make_topk_trace.py): per call the
+    returned flag and which model{i}.pthw holds which score afterwards -- quirks included (the -inf seed entry, slot 0 rewritten while
+    the list fills, strict comparison)"""
+    import json
     from hanabi_sad_amd.common import TopkSaver
-    s = TopkSaver(str(tmp_path / "ck"), 3)
-    sd = lambda v: {"w": torch.tensor([float(v)])}
-    assert [s.save(None, sd(p), p) for p in (5.0, 1.0, 3.0)] == [True, True, True]
-    assert s.save(None, sd(0.5), 0.5) is False                     # worse than everything kept
-    assert s.save(None, sd(4.0), 4.0, force_save_name="model_epoch50") is True   # replaces the 1.0
-    kept = sorted(float(torch.load(str(tmp_path / "ck" / ("model%d.pthw" % i)))["w"]) for i in range(3))
-    assert kept == [3.0, 4.0, 5.0]
-    assert float(torch.load(str(tmp_path / "ck" / "model_epoch50.pthw"))["w"]) == 4.0
-    s.save(None, sd(0.1), 0.1, save_latest=True)
-    assert float(torch.load(str(tmp_path / "ck" / "latest.pthw"))["w"]) == pytest.approx(0.1)
+    trace = json.load(open(os.path.join(GOLD, "topk_saver_trace.json")))
+    for name, case in trace.items():
+        d = tmp_path / name
+        s = TopkSaver(str(d), case["topk"])
+        for i, step in enumerate(case["steps"]):
+            flag = s.save(None, {"w": torch.tensor([step["score"]])}, step["score"])
+            assert flag is step["saved"], (name, i)
+            files = {f: float(torch.load(str(d / f))["w"]) for f in sorted(os.listdir(d)) if f.startswith("model")}
+            assert files == pytest.approx(step["files"]), (name, i)
+    s = TopkSaver(str(tmp_path / "forced"), 2)
+    assert s.save(None, {"w": torch.tensor([0.1])}, 0.1, save_latest=True, force_save_name="model_epoch50") is True
+    assert float(torch.load(str(tmp_path / "forced" / "model_epoch50.pthw"))["w"]) == pytest.approx(0.1)
+    assert float(torch.load(str(tmp_path / "forced" / "latest.pthw"))["w"]) == pytest.approx(0.1)
 
 
 def test_stopwatch_multicounter_tachometer_output(capsys):
