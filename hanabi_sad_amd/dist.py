@@ -406,7 +406,8 @@ class ReplayLink:
         assert self.is_learner and self._result is None
         flags = (self.PARAMS if params else 0) | (self.STOP if stop else 0) | (self.HAS_PRIO if prio is not None else 0)
         r = self.opened
-        self.store.set("hsad/link/flags/%d" % (r % self.FLAG_SLOTS), str(flags))
+        # the flag ring is only safe while no rank is FLAG_SLOTS rounds behind; the value carries its round so that poll() can tell
+        self.store.set("hsad/link/flags/%d" % (r % self.FLAG_SLOTS), "%d %d" % (r, flags))
         self.store.add(self.ROUND_KEY, 1)
         self.opened += 1
         B, k = self.B, r % 4
@@ -443,11 +444,25 @@ class ReplayLink:
         return res
 
     # -- actors --
+    poll_every = 1         # ask the rendezvous store only every k-th call (an acting step is ~1 ms; a store round trip goes to rank 0's server)
+
     def poll(self):
-        """has the learner opened a round this rank has not served yet?  -> its flags, or None.  Host-side only (one store query)"""
-        if int(self.store.add(self.ROUND_KEY, 0)) <= self.served:
-            return None
-        return int(self.store.get("hsad/link/flags/%d" % (self.served % self.FLAG_SLOTS)))
+        """has the learner opened a round this rank has not served yet?  -> its flags, or None.  Host-side only (one store query every
+        `poll_every` calls; a known backlog is served without asking again)"""
+        self._polls = getattr(self, "_polls", 0) + 1
+        if getattr(self, "_known_open", 0) <= self.served:
+            if self._polls % max(int(self.poll_every), 1):
+                return None
+            self._known_open = int(self.store.add(self.ROUND_KEY, 0))
+            if self._known_open <= self.served:
+                return None
+        if self._known_open - self.served >= self.FLAG_SLOTS:
+            raise RuntimeError("ReplayLink: rank %d is %d rounds behind the learner -- the %d-slot flag ring has wrapped" %
+                               (self.rank, self._known_open - self.served, self.FLAG_SLOTS))
+        r, flags = self.store.get("hsad/link/flags/%d" % (self.served % self.FLAG_SLOTS)).decode().split()
+        if int(r) != self.served:
+            raise RuntimeError("ReplayLink: flag slot of round %d holds round %s" % (self.served, r))
+        return int(flags)
 
     def serve(self, flags):
         """serve the round `poll` announced, on the current stream.  After a PARAMS round the new [online | target] parameters are in
