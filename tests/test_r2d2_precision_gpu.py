@@ -181,31 +181,57 @@ def test_vdn_learner_and_priority_against_golden(precision):
     assert max(rel.values()) <= 2 * tol["grad_rel"], rel
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16-composite"])
 def test_full_size_learner_against_fp32_autograd(precision):
     """BASELINE configs[2] shapes (F=838, H=512, A=21, T=80, B=128, aux task on): loss, priorities and every gradient vs
-    torch autograd on the fp32 restatement the golden vectors pin"""
+    torch autograd on the fp32 restatement the golden vectors pin.  bf16-composite = the product path (library composite entry
+    points, fused recurrences); bf16 = the Python-orchestrated chunk-pipelined schedule.
+
+    Every value is held to the tolerance on the MAXIMUM -- except where the reference itself has a near-tie: a TD error at (t, b) reads
+    Q_target(s_{t+n}, argmax_a Q_online(s_{t+n}, a)); if the two best legal Q_online values of the REFERENCE at (t+n, b) are closer than
+    the Q tolerance, either action is a legitimate answer of a finite-precision implementation and the priority at (t, b) (and the loss
+    of sequence b) may differ by O(0.1).  Every outlier must be such a provable near-tie; anything else fails, in fp32 mode as well."""
     from hanabi_sad_amd.r2d2 import R2D2Learner, check_sync
     from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
-    tol = TOL[precision]
+    composite = precision.endswith("composite")
+    tol = TOL["bf16" if composite else precision]
+    n = 3
     F, A, H, T, B = 838, 21, 512, 80, 128
     W, Wt = _rand_net(F, H, A, seed=3), _rand_net(F, H, A, seed=4)
     batch, weight = _rand_batch(T, B, F, A)
-    lr = R2D2Learner(W, Wt, 3, 0.999, device=DEV, precision=precision)
+    if composite:
+        from hanabi_sad_amd.composite import CompositeLearner
+        lr = CompositeLearner(W, Wt, n, 0.999, device=DEV)
+    else:
+        lr = R2D2Learner(W, Wt, n, 0.999, device=DEV, precision=precision)
     loss, prio = lr.loss(batch, weight, 0.25)
     torch.cuda.synchronize()
-    check_sync()
+    lr.check_sync() if composite else check_sync()
     Wd = {k: v.to(DEV).requires_grad_(True) for k, v in W.items()}
-    rloss, rprio = ref.loss(Wd, {k: v.to(DEV) for k, v in Wt.items()}, batch, 3, 0.999, 0.25)
+    rloss, rprio = ref.loss(Wd, {k: v.to(DEV) for k, v in Wt.items()}, batch, n, 0.999, 0.25)
     (rloss * weight).mean().backward()
-    # a near-tie may flip one greedy action (and with it one target Q, in one sequence): priorities are compared at the
-    # 99.9th percentile, per-sequence losses at the 90th (of 128)
-    dl = (loss - rloss.detach()).abs().flatten()
-    e_l = float(dl.kthvalue(int(0.9 * dl.numel())).values)
-    dp = (prio - rprio.detach()).abs().flatten()
-    e_p = float(dp.kthvalue(int(0.999 * dp.numel())).values)
+    # the reference's own Q_online and the gap between its two best legal values per (t, b)
+    with torch.no_grad():
+        h0 = torch.zeros(2, B, H, device=DEV)
+        _, _, rq, _ = ref.net_forward({k: v.detach() for k, v in Wd.items()}, batch["priv_s"], batch["legal_move"], batch["a"], h0, h0.clone())
+        top2 = ((1 + rq - rq.min()) * batch["legal_move"]).topk(2, dim=2).values
+        gap = top2[..., 0] - top2[..., 1]                                   # [T, B]
+    tie = 2 * tol["full_q"]
+    dp = (prio - rprio.detach()).abs()
+    out_p = torch.nonzero(dp > tol["full_q"])
+    for t, b in out_p.tolist():
+        assert t + n < T and float(gap[t + n, b]) < tie, ("priority outlier without a near-tie", t, b, float(dp[t, b]), float(gap[min(t + n, T - 1), b]))
+    dl = (loss - rloss.detach()).abs()
+    seq_with_tie = set(b for _, b in out_p.tolist())
+    for b in torch.nonzero(dl > tol["full_loss"]).flatten().tolist():
+        assert b in seq_with_tie, ("loss outlier without a near-tie in its sequence", b, float(dl[b]))
+    clean_p = dp.clone()
+    clean_p[dp > tol["full_q"]] = 0
+    clean_l = dl.clone()
+    clean_l[dl > tol["full_loss"]] = 0
     rel = {k: relerr(lr.grad[k], Wd[k].grad) for k in Wd if Wd[k].grad is not None and float(Wd[k].grad.norm()) > 0}
-    record(precision, "full_size_learner", loss_p90=e_l, loss_max=float(dl.max()), priority_p999=e_p, priority_max=float(dp.max()), grad_rel_max=max(rel.values()),
+    record(precision, "full_size_learner", loss_max_excl_ties=float(clean_l.max()), loss_max=float(dl.max()), priority_max_excl_ties=float(clean_p.max()),
+           priority_max=float(dp.max()), near_tie_priorities=int(out_p.shape[0]), grad_rel_max=max(rel.values()),
            **{"grad_rel." + k: v for k, v in rel.items()})
-    assert e_l <= tol["full_loss"] and e_p <= tol["full_q"], (e_l, e_p)
+    assert out_p.shape[0] <= (0 if precision == "fp32" else 8), out_p.shape[0]          # measured: 0 (fp32), 1-2 (bf16) of 10,240
     assert max(rel.values()) <= tol["full_grad_rel"], rel
