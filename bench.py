@@ -42,7 +42,9 @@ def measured_traffic_bytes(G, mode, chunk=0):
     iterations per launch) from the committed rocprofv3 PMC passes (profiles/, collected with separate --pmc WRITE_SIZE /
     FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py).  Only valid for the configuration
     it was measured at; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
     try:
         for k, rec in json.load(open(path))["env"].items():
             if chunk > 0:
@@ -59,7 +61,8 @@ def measured_traffic_bytes(G, mode, chunk=0):
 def gemm_traffic_bytes():
     """HBM bytes per launch of the learner's LSTM input-projection GEMM (10240x2048x512) from the committed PMC passes"""
     try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))["gemm"]
+        path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
+        rec = json.load(open(path if os.path.exists(path) else os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))["gemm"]
         for k, v in rec.items():
             if k.startswith("gemm_nt_bf16_kernel"):
                 return v["hbm_bytes_per_launch"]
@@ -346,6 +349,18 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128):
     return out
 
 
+def env5_traffic_bytes(games, chunk):
+    """HBM bytes per launch of env_rollout_kernel<5,4> at configs[4]'s per-GPU size from the committed PMC passes"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["env5"]
+        for k, v in rec.items():
+            if k.startswith("env_rollout_kernel<5,4>") and games == 16384:
+                return v["hbm_bytes_per_iteration"] * chunk
+    except Exception:
+        pass
+    return None
+
+
 def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50):
     """BASELINE configs[4] at its per-GPU size (131,072 games over 8 GPUs = 16,384 per GPU): 5 players, hand 4, SAD, colour shuffle
     (F = 1439, A = 49) through the same persistent rollout kernel, timed with events like the headline run"""
@@ -369,7 +384,7 @@ def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50):
                                   "random-legal policy, persistent fused kernel, %d iterations per launch" % (games, env.F, env.A, chunk),
                       "games_per_workgroup": env.games_per_workgroup},
            "roofline": {"bound": "hbm", "kernel": "env_rollout_kernel<5,4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_env_step": bps}}
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": env5_traffic_bytes(games, chunk), "algorithmic_bytes_per_env_step": bps}}
     del env
     torch.cuda.empty_cache()
     return out

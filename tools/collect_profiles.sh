@@ -3,12 +3,12 @@
 # Outputs land in gpurun_out/ ; the summaries are also written into profiles/ (copy them back from gpurun_out/ afterwards).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RN=${ROUND:-r02}
+RN=${ROUND:-r03}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 SPEC=""
-for leg in env gemm learner actor; do
+for leg in env env5 gemm learner actor; do
   rm -rf /tmp/pw_$leg /tmp/pf_$leg
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw_$leg -o w -- python $R/tools/pmc_probe.py $leg > $O/pmc_write_$leg.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_$leg -o f -- python $R/tools/pmc_probe.py $leg > $O/pmc_fetch_$leg.log 2>&1
@@ -25,4 +25,10 @@ cp $(find /tmp/ps -name "*kernel_stats.csv" | head -1) $O/${RN}_bench_kernel_sta
 # ... and of the whole default command (env + learner + actor legs)
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o r2 -- python $R/bench.py --no-cpu-baseline > $O/${RN}_bench_full_under_rocprof.json 2> $O/rocprof_stats_full.err
 cp $(find /tmp/ps2 -name "*kernel_stats.csv" | head -1) $O/${RN}_bench_full_kernel_stats.csv
+# one learner update, kernel by kernel (what the in-update figures of bench.py can be recomputed from without bench.py)
+rm -rf /tmp/pl
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pl -o l -- python $R/tools/learner_update_breakdown.py 20 > $O/learner_breakdown.log 2>&1
+cp $(find /tmp/pl -name "*kernel_stats.csv" | head -1) $O/${RN}_learner_update_kernel_stats.csv
+python $R/tools/update_timeline.py $(find /tmp/pl -name "*kernel_trace.csv" | head -1) > $O/${RN}_learner_update_timeline.txt 2>&1
+cp $O/${RN}_learner_update_kernel_stats.csv $O/${RN}_learner_update_timeline.txt $R/profiles/ 2>/dev/null
 tail -c 2500 $O/${RN}_bench.json; echo; head -8 $O/${RN}_bench_kernel_stats.csv | cut -c1-160; cat $O/pmc_summary.txt | head -60

@@ -15,6 +15,13 @@ CAL_BYTES = 65536 * 2 * 783 * 4
 G, P, F, A, H = 65536, 2, 783, 21, 5
 ALGO_ENV = (P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 + 256) * G     # SURVEY.md §8(d) bytes per env-step x G
 GEMM_ALGO = 10240 * 512 * 2 + 2048 * 512 * 2 + 10240 * 2048 * 4    # A + B read (bf16), C written (fp32)
+ALGO_ENV5 = (5 * (1439 + 49 + 12 + 1) * 4 + 5 + 5 * 8 * 2 + 256) * 16384        # configs[4] per GPU: 5p hand 4 SAD, 16,384 games
+# fused forward recurrence of a learner update (T=80, B=128, H=512, 2 nets x 2 layers): weights 8 x 2 MB, inputs 2 x 10 MB, outputs: bf16 h
+# of 4 recurrences, fp32 gates + c of the online net's 2 layers (the h tiles exchanged between workgroups stay in L2: not algorithmic HBM bytes)
+_MH = 80 * 128 * 512
+FUSED_FWD_ALGO = 8 * 2048 * 512 * 2 + 2 * _MH * 2 + 4 * _MH * 2 + 2 * (_MH * 4 * 4 + _MH * 4)
+# fused BPTT (online net, 2 layers): weights 3 x 2 MB, saved gates + c read (2 layers), dO of the top layer (fp32), dG written (bf16, 2 layers)
+FUSED_BWD_ALGO = 3 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + 2 * _MH * 4 * 2
 
 
 def per_kernel(path, counter):
@@ -58,8 +65,13 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
             ("env_kernel<3,2,5> fused reset+policy+step+observe (rollout), G=65536 in 3 partition launches", r"env_kernel<3, 2, 5>", ALGO_ENV / 3, ""),
             ("env_kernel<1,2,5> step+observe, G=65536", r"env_kernel<1, 2, 5>", ALGO_ENV, ""),
             ("env_kernel<0,2,5> reset-terminated, G=65536", r"env_kernel<0, 2, 5>", None, "")],
+    "env5": [("env_rollout_kernel<5,4> persistent fused rollout, configs[4] per GPU: G=16384 5-player hand-4 SAD + colour shuffle, 50 iterations per launch",
+              r"env_rollout_kernel<5, 4>", ALGO_ENV5 * 50, "iterations_per_launch=50")],
     "gemm": [("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
-    "learner": [("learner update: gemm_nt_bf16_kernel<128,128> (all shapes of an update)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
+    "learner": [("learner update: lstm_fused_fwd_kernel<16> (2 nets x 2 layers x 80 steps per launch)", r"lstm_fused_fwd_kernel<16>", FUSED_FWD_ALGO, ""),
+                ("learner update: lstm_fused_bwd_kernel<64> (2 layers x 80 steps per launch)", r"lstm_fused_bwd_kernel<64>", FUSED_BWD_ALGO, ""),
+                ("learner update: loss_tail_kernel", r"loss_tail_kernel", None, ""),
+                ("learner update: gemm_nt_bf16_kernel<128,128> (all shapes of an update)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
                 ("learner update: gemm_nt_bf16_kernel<128,64>", r"gemm_nt_bf16_kernel<128, 64>", None, ""),
                 ("learner update: lstm_seq_fwd_kernel<16> (4 recurrences x 20 steps per launch)", r"lstm_seq_fwd_kernel<16>", None, ""),
                 ("learner update: lstm_seq_bwd_kernel<64> (2 recurrences x 20 steps per launch)", r"lstm_seq_bwd_kernel<64>", None, ""),
