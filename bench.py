@@ -245,6 +245,17 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     dt = (time.perf_counter() - t0) / steps
     tr.env.check_errors()
     tr.replay.check_errors()
+    # host issue time per step: the CPU time of the calls themselves (no device wait inside; the queue is drained first and the
+    # 40 steps stay well inside the HIP queue depth), for the library's actor body and for the Python body of rounds 1-2
+    def issue_us(actor_obj, k=40):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k):
+            actor_obj.step()
+        h = (time.perf_counter() - t) / k * 1e6
+        torch.cuda.synchronize()
+        return h
+    host_issue_us = issue_us(tr.actor)
     # the dominant kernel of a step (four launches: two LSTM layers x online / target net) where it runs: HIP events around every
     # launch of the fused GEMM + cell kernel during 40 more steps, on the stream it is launched on
     import ctypes as C
@@ -273,6 +284,8 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
         tr.learner.check_sync()
         tr.replay.check_errors()
     out = {"value": games * 2 / dt, "unit": "acts/s", "ms_per_step": dt * 1e3, "game_steps_per_sec": games / dt,
+           "loop_body": "hsad_actor_step (C ABI, one call per step)" if tr.actor.c_actor is not None else "python (actor.DeviceActor.step)",
+           "host_issue_us_per_step": host_issue_us,
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
            "roofline": {"bound": "mfma", "kernel": "lstm_cell_gemm256_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d; "
                                                    "4 launches per step)" % (games * 2, 2048, 1024),

@@ -7,7 +7,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libhsad.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip", "hsad_agent.hip", "hsad_comm.hip")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("hsad_env.hip", "hsad_replay.hip", "hsad_r2d2.hip", "hsad_r2d2_f32.hip", "hsad_agent.hip", "hsad_comm.hip",
+                                                      "hsad_actor.hip")]
 _lib = None
 
 
@@ -42,6 +43,17 @@ class LstmBwdRec(C.Structure):
     _fields_ = [("gates", C.c_void_p), ("cseq", C.c_void_p), ("c_before", C.c_void_p), ("WhhT_blocked", C.c_void_p),
                 ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int), ("xchg", C.c_void_p),
                 ("saved_frag_major", C.c_int), ("tail_is_zero", C.c_int)]
+
+
+class ActorConfig(C.Structure):
+    """hsad_actor_config (include/hsad.h)"""
+    _fields_ = [("vdn", C.c_int32), ("multi_step", C.c_int32), ("seq_len", C.c_int32), ("hand_size", C.c_int32), ("hid_dim", C.c_int32),
+                ("gamma", C.c_float), ("eta", C.c_float), ("seed", C.c_uint64)]
+
+
+class ActorIO(C.Structure):
+    """hsad_actor_io (include/hsad.h)"""
+    _fields_ = [(k, C.c_void_p) for k in ("legal_move", "own_hand", "eps", "reward", "terminal", "priv_bits", "legal_bits", "own_bits", "priv_s_bf16")]
 
 
 class LstmFusedBwdRec(C.Structure):
@@ -179,6 +191,16 @@ SIGNATURES = {
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,
                                 C.c_int, C.c_int, _P, C.c_int, _P, _P]),
+    "hsad_actor_create": (C.c_int, [_P, _P, _P, _P, C.POINTER(ActorConfig), C.POINTER(ActorIO), C.POINTER(_P)]),
+    "hsad_actor_destroy": (None, [_P]),
+    "hsad_actor_step": (C.c_int, [_P, _P]),
+    "hsad_actor_num_act": (C.c_int64, [_P]),
+    "hsad_actor_num_redo": (C.c_int64, [_P]),
+    "hsad_actor_n_finished_dev": (_P, [_P]),
+    "hsad_actor_writer": (_P, [_P]),
+    "hsad_actor_state": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "hsad_actor_last_actions": (_P, [_P, C.POINTER(_P)]),
+    "hsad_actor_last_priority": (_P, [_P, C.POINTER(C.c_int32)]),
     "hsad_r2d2_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "hsad_r2d2_net_create_ex": (C.c_int, [C.c_int] * 9 + [C.POINTER(_P)]),
     "hsad_r2d2_net_num_params": (C.c_int, [_P]),

@@ -29,7 +29,7 @@ def transition_fields(env, vdn=False):
 
 class DeviceActor:
     def __init__(self, env: BatchedHanabiEnv, agent: R2D2Agent, replay: DeviceReplay, multi_step, gamma, eta, seq_len,
-                 vdn=False, packed_obs=None):
+                 vdn=False, packed_obs=None, native=None):
         self.env, self.agent, self.replay = env, agent, replay
         self.G, self.P = env.G, env.P
         self.N = self.G * self.P              # agent rows (hidden state [L, N, H]) in both layouts
@@ -60,6 +60,64 @@ class DeviceActor:
         self._side = torch.cuda.Stream(env.device) if self.cached_q else None      # reset of ended games, see _reset_terminated
         self._side_flush = torch.cuda.Stream(env.device) if self.cached_q else None   # flush of finished sequences, see _flush
         self._reset_pending = False
+        # The loop body itself lives in the library (include/hsad.h hsad_actor_*, csrc/hsad_actor.hip): with the library's composite
+        # agent and the packed observation path, step() is ONE C call and this class only holds the objects it drives.  The Python
+        # body below remains for models behind the reference's contract (rela.ContractAgent), for the Python-orchestrated agent
+        # and for the priority cross-check of the tests (verify_cached_priority).
+        self.c_actor = None
+        if native is None:
+            native = self.packed_obs and hasattr(agent, "online") and hasattr(agent.online, "h") and hasattr(agent, "lib") and not getattr(agent.online, "skip", False)
+        if native:
+            self._make_native(multi_step, gamma, seq_len)
+
+    def _make_native(self, multi_step, gamma, seq_len):
+        import ctypes as C
+        from . import _lib
+        env, agent = self.env, self.agent
+        self.writer.close()                       # the library's actor owns its own sequence writer
+        cfg = _lib.ActorConfig(int(self.vdn), int(multi_step), int(seq_len), int(env.H), int(agent.online.H), float(gamma), float(self.eta),
+                               int(agent.seed))
+        io = _lib.ActorIO(env.legal_move.data_ptr(), env.own_hand.data_ptr(), env.eps.data_ptr(), env.reward.data_ptr(), env.terminal.data_ptr(),
+                          env.priv_bits.data_ptr(), env.legal_bits.data_ptr(), env.own_bits.data_ptr(), env.priv_s_bf16.data_ptr())
+        h = C.c_void_p()
+        _lib.check(agent.lib.hsad_actor_create(env.h, agent.online.h, agent.target.h, self.replay.h, C.byref(cfg), C.byref(io), C.byref(h)))
+        self.c_actor, self._lib = h, agent.lib
+        nf = agent.lib.hsad_actor_n_finished_dev(h)
+        from .composite import _view
+        self.n_finished = _view(nf, 1, env.device, self, dtype=torch.int32)
+
+    def close(self):
+        if getattr(self, "c_actor", None):
+            self._lib.hsad_actor_destroy(self.c_actor)
+            self.c_actor = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def last_reply(self):
+        """{a, greedy_a} int64 [N] of the last step (native loop: views of the library's buffers)"""
+        import ctypes as C
+        from .composite import _view
+        g = C.c_void_p()
+        a = self._lib.hsad_actor_last_actions(self.c_actor, C.byref(g))
+        return {"a": _view(a, self.N, self.env.device, self, dtype=torch.int64), "greedy_a": _view(g.value, self.N, self.env.device, self, dtype=torch.int64)}
+
+    @property
+    def last_priority(self):
+        """float32 [E] n-step priorities pushed by the last step, None while the n-step window was still filling (native loop)"""
+        import ctypes as C
+        from .composite import _view
+        n = C.c_int32()
+        p = self._lib.hsad_actor_last_priority(self.c_actor, C.byref(n))
+        return _view(p, n.value, self.env.device, self) if p else None
+
+    @property
+    def num_redo(self):
+        return int(self._lib.hsad_actor_num_redo(self.c_actor)) if self.c_actor is not None else self.n_checked_stale
 
     def _rows(self):
         e, N = self.env, self.N
@@ -95,6 +153,12 @@ class DeviceActor:
 
     def step(self):
         """one iteration of the thread-loop body: reset-terminated -> act -> step -> postAct"""
+        if self.c_actor is not None and not self.verify_cached_priority:
+            from . import _lib
+            from .composite import _s
+            _lib.check(self._lib.hsad_actor_step(self.c_actor, _s(self.env.device)))
+            self.num_act = int(self._lib.hsad_actor_num_act(self.c_actor))
+            return
         env, agent, P = self.env, self.agent, self.P
         self._reset_terminated()
         obs = self._rows()

@@ -20,13 +20,16 @@ def _s(dev):
 class _DevArray:
     """exposes a library-owned device allocation to torch (no copy) through __cuda_array_interface__"""
 
-    def __init__(self, ptr, n, owner):
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    def __init__(self, ptr, n, owner, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
         self.owner = owner
 
 
-def _view(ptr, n, device, owner):
-    return torch.as_tensor(_DevArray(ptr, n, owner), device=device)
+_TYPESTR = {torch.float32: "<f4", torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1", torch.int16: "<i2"}
+
+
+def _view(ptr, n, device, owner, dtype=torch.float32):
+    return torch.as_tensor(_DevArray(ptr, n, owner, _TYPESTR[dtype]), device=device)
 
 
 def param_names(net=None):

@@ -95,7 +95,7 @@ class Trainer:
         from .dist import ShardedReplay
         self.sharded = ShardedReplay(self.replay, args.priority_weight, device, learner_rank=0) if world == 1 else None
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
-                                 vdn=self.vdn) if self.acting else None
+                                 vdn=self.vdn, native=None if getattr(args, "native_actor", 1) else False) if self.acting else None
         self.num_update = 0
 
     def update_actor_model(self):
@@ -197,6 +197,9 @@ def parse_args(argv=None):
     p.add_argument("--act_steps_per_update", type=int, default=1)
     p.add_argument("--num_eval_game", type=int, default=1000)
     p.add_argument("--stopwatch", type=int, default=0, help="1 = time the reference's five learner sections (adds device syncs)")
+    p.add_argument("--native_actor", type=int, default=1,
+                   help="1: the actor-loop body is the library's hsad_actor_step (one C call per step); 0: the same body in Python "
+                   "(actor.DeviceActor.step; the priority cross-check of the tests and contract models use it)")
     p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"],
                    help="bf16 = production kernels (bf16 MFMA operands, fp32 accumulate/state); fp32 = the exact mode (the "
                         "reference's arithmetic type, for validation: ~20x slower)")

@@ -713,6 +713,57 @@ int hsad_heads_backward_f32(const float* dqa, const float* legal, const int64_t*
                             const float* own_hand, const float* weight, int M, int B, int A, int NP, float pred_scale,
                             float* out32, int ldo, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * ACTOR LOOP BODY (csrc/hsad_actor.hip): one iteration of HanabiThreadLoop::mainLoop (cpp/thread_loop.h:42-88) with
+ * R2D2Actor::act / postAct (rela/r2d2_actor.h:61-172) for ALL games of an env object, as ONE call: reset the games that ended ->
+ * act (hsad_r2d2_act with cached Q-values) -> push observation + action -> env step -> push reward / terminal -> zero the carried
+ * state of ended games -> pop the transition that left the n-step window -> priority from the cached Q-values (the online pass on
+ * s_{t-n} redone if the weights were synced in between) -> sequence push -> flush finished sequences into the replay.  The library
+ * owns the carried hidden state, the Q-value ring, the sequence writer and the side streams (reset and flush overlap the rest);
+ * env, nets, replay and the env's output buffers belong to the caller.  IQL (one transition per (game, player)) and VDN (one per
+ * game) layouts of the reference's create.py:98-131.  Needs the packed env outputs (hsad_env_bind_packed, keep_float32_obs = 0 is
+ * fine) and a replay created with the transition layout below.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct hsad_actor hsad_actor;
+typedef struct hsad_actor_config {
+  int32_t vdn;         /* 1: one transition per game with the players' rows concatenated; 0: one per (game, player) */
+  int32_t multi_step;  /* n of the n-step return */
+  int32_t seq_len;     /* R2D2Buffer length (--max_len) */
+  int32_t hand_size;
+  int32_t hid_dim;
+  float gamma;
+  float eta;           /* aggregatePriority */
+  uint64_t seed;       /* eps-greedy stream (hsad_r2d2_act) */
+} hsad_actor_config;
+/* what the caller bound to the env (hsad_env_bind_outputs / hsad_env_bind_packed); layout of the transition fields the replay must
+ * have been created with: priv_s BITS(m*F), legal_move BITS(m*A), eps F32(m), own_hand BITS(m*3*hand), a I64(m), greedy_a I64(m),
+ * m = players (VDN) or 1 (IQL), bit fields in m segments */
+typedef struct hsad_actor_io {
+  const float* legal_move;
+  const float* own_hand;
+  const float* eps;
+  const float* reward;
+  const uint8_t* terminal;
+  const uint64_t* priv_bits;
+  const uint64_t* legal_bits;
+  const uint64_t* own_bits;
+  const void* priv_s_bf16;   /* [G*P, hsad_r2d2_net_in_dim_padded(online)] */
+} hsad_actor_io;
+int hsad_actor_create(hsad_env* env, hsad_r2d2_net* online, hsad_r2d2_net* target, hsad_replay* replay, const hsad_actor_config* cfg,
+                      const hsad_actor_io* io, hsad_actor** out);
+void hsad_actor_destroy(hsad_actor* actor);
+/* one iteration for every game; everything is enqueued on `stream` and the actor's two side streams, the host never waits */
+int hsad_actor_step(hsad_actor* actor, void* stream);
+int64_t hsad_actor_num_act(const hsad_actor* actor);        /* R2D2Actor::numAct summed over the per-player actors */
+int64_t hsad_actor_num_redo(const hsad_actor* actor);       /* steps whose Q_online(s_{t-n}, a) pass was redone after a weight sync */
+const int32_t* hsad_actor_n_finished_dev(const hsad_actor* actor);   /* device counter: sequences flushed by the last step */
+hsad_seqwriter* hsad_actor_writer(hsad_actor* actor);
+int hsad_actor_state(hsad_actor* actor, float** h, float** c);       /* the carried state entering the next step, fp32 [L, G*P, H] */
+const int64_t* hsad_actor_last_actions(const hsad_actor* actor, const int64_t** greedy);   /* int64 [G*P] of the last step */
+/* n-step priorities the last step pushed, float32 [*n] (per (game, player) row, VDN: per game); NULL when that step was still
+ * filling the n-step window */
+const float* hsad_actor_last_priority(const hsad_actor* actor, int32_t* n);
+
 #ifdef __cplusplus
 }
 #endif

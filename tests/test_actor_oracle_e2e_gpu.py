@@ -40,9 +40,11 @@ def _pack(P, obs_list, a, g, vdn):
     return np.ascontiguousarray(np.stack(rows), np.float32)
 
 
-@pytest.mark.parametrize("method,players,hand,sad,shuffle", [("iql", 2, 5, True, False), ("vdn", 2, 5, True, True),
-                                                             ("iql", 3, 5, False, True)])
-def test_device_actor_loop_equals_oracle_env_plus_reference_buffers(method, players, hand, sad, shuffle):
+@pytest.mark.parametrize("method,players,hand,sad,shuffle,native", [("iql", 2, 5, True, False, 1), ("vdn", 2, 5, True, True, 1),
+                                                                    ("iql", 3, 5, False, True, 1), ("vdn", 2, 5, True, True, 0)])
+def test_device_actor_loop_equals_oracle_env_plus_reference_buffers(method, players, hand, sad, shuffle, native):
+    """native = 1: the loop body is the library's hsad_actor_step (include/hsad.h) -- the actions and priorities are read back through
+    hsad_actor_last_actions / hsad_actor_last_priority; native = 0: the same body in Python (actor.DeviceActor.step)"""
     if not ref_rela.available():
         pytest.skip("oracle/_ref/libref_rela.so not built")
     from hanabi_sad_amd.selfplay import Trainer, parse_args
@@ -50,26 +52,39 @@ def test_device_actor_loop_equals_oracle_env_plus_reference_buffers(method, play
     args = parse_args(["--num_game", str(G), "--rnn_hid_dim", "64", "--batchsize", "8", "--replay_buffer_size", "8192",
                        "--max_len", str(T), "--act_base_eps", "0.5", "--num_eps", "7", "--sad", str(int(sad)),
                        "--shuffle_color", str(int(shuffle)), "--method", method, "--num_player", str(players),
-                       "--hand_size", str(hand), "--multi_step", str(NSTEP), "--seed", str(SEED), "--gamma", "0.97"])
+                       "--hand_size", str(hand), "--multi_step", str(NSTEP), "--seed", str(SEED), "--gamma", "0.97",
+                       "--native_actor", str(native)])
     if method == "vdn":
         args.replay_buffer_size = 8192     # (main() would have divided it by num_player; Trainer is driven directly here)
     tr = Trainer(args, DEV)
     env, actor, vdn, P = tr.env, tr.actor, method == "vdn", players
     rec_a, rec_g, rec_p = [], [], []
-    orig_act, orig_push = actor.agent.act, actor.writer.push_sequence
+    assert (actor.c_actor is not None) == bool(native)
+    if native:
+        for _ in range(STEPS):
+            actor.step()
+            r = actor.last_reply
+            rec_a.append(r["a"].view(G, P).cpu().numpy().copy())
+            rec_g.append(r["greedy_a"].view(G, P).cpu().numpy().copy())
+            pr = actor.last_priority
+            if pr is not None:
+                rec_p.append(pr.cpu().numpy().copy())
+        assert actor.num_act == STEPS * G * P
+    else:
+        orig_act, orig_push = actor.agent.act, actor.writer.push_sequence
 
-    def act(obs, hid, with_q=False, **kw):
-        reply, nh = orig_act(obs, hid, with_q=with_q, **kw)
-        rec_a.append(reply["a"].view(G, P).cpu().numpy().copy())
-        rec_g.append(reply["greedy_a"].view(G, P).cpu().numpy().copy())
-        return reply, nh
+        def act(obs, hid, with_q=False, **kw):
+            reply, nh = orig_act(obs, hid, with_q=with_q, **kw)
+            rec_a.append(reply["a"].view(G, P).cpu().numpy().copy())
+            rec_g.append(reply["greedy_a"].view(G, P).cpu().numpy().copy())
+            return reply, nh
 
-    def push(prio):
-        rec_p.append(prio.cpu().numpy().copy())
-        orig_push(prio)
-    actor.agent.act, actor.writer.push_sequence = act, push
-    for _ in range(STEPS):
-        actor.step()
+        def push(prio):
+            rec_p.append(prio.cpu().numpy().copy())
+            orig_push(prio)
+        actor.agent.act, actor.writer.push_sequence = act, push
+        for _ in range(STEPS):
+            actor.step()
     torch.cuda.synchronize()
     env.check_errors()
     tr.replay.check_errors()

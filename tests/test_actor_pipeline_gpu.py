@@ -61,7 +61,7 @@ def test_cached_q_priorities_on_the_fused_cell_kernels(games):
     8,192 rows: 256 x 256 tiles), where the hidden state also carries its bf16 copy from step to step"""
     from hanabi_sad_amd.selfplay import Trainer, parse_args
     args = parse_args(["--num_game", str(games), "--batchsize", "16", "--replay_buffer_size", "4096", "--burn_in_frames", "64",
-                       "--act_base_eps", "0.4", "--sad", "1"])
+                       "--act_base_eps", "0.4", "--sad", "1", "--native_actor", "0"])
     tr = Trainer(args, "cuda:0")
     tr.actor.verify_cached_priority = True
     for it in range(24):
@@ -85,7 +85,7 @@ def test_actor_priorities_from_cached_q_equal_compute_priority_bit_for_bit(metho
     from hanabi_sad_amd.selfplay import Trainer, parse_args
     args = parse_args(["--num_game", "64", "--rnn_hid_dim", "64", "--batchsize", "16", "--replay_buffer_size", "1024",
                        "--burn_in_frames", "64", "--max_len", "40", "--act_base_eps", "0.4", "--sad", "1",
-                       "--method", method])
+                       "--method", method, "--native_actor", "0"])
     tr = Trainer(args, "cuda:0")
     tr.actor.verify_cached_priority = True
     for it in range(60):
@@ -153,3 +153,58 @@ def test_batched_greedy_evaluation_and_checkpoint_roundtrip(tmp_path):
     assert len(scores) == 200 and all(0 <= s <= 25 for s in scores) and 0 <= mean <= 25
     mean2, _, scores2, _ = evaluate(W2, 200, seed=9917, bomb=0, sad=True, device="cuda:0")
     assert scores == scores2                      # deterministic: greedy policy, fixed seeds
+
+
+@pytest.mark.parametrize("method,games,hid", [("iql", 64, 64), ("vdn", 64, 64), ("iql", 1024, 512)])
+def test_library_actor_step_equals_the_python_body_bit_for_bit(method, games, hid):
+    """hsad_actor_step (include/hsad.h; csrc/hsad_actor.hip) against actor.DeviceActor's Python body on the same seeds: the actions of every
+    step, the priorities of every step -- across actor weight syncs inside the n-step window, where the library redoes the online pass
+    on the unpacked transition -- the carried state, and every sequence that reached the replay must be identical bits.  The Python body
+    is in turn pinned to the reference's compute_priority (tests above) and to the oracle env + reference buffers (test_actor_oracle_e2e)."""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    common = ["--num_game", str(games), "--rnn_hid_dim", str(hid), "--batchsize", "16", "--replay_buffer_size", "8192", "--burn_in_frames", "64",
+              "--max_len", "30", "--act_base_eps", "0.4", "--sad", "1", "--method", method, "--seed", "11"]
+    trs = [Trainer(parse_args(common + ["--native_actor", str(k)]), "cuda:0") for k in (1, 0)]
+    nat, py = trs[0].actor, trs[1].actor
+    assert nat.c_actor is not None and py.c_actor is None
+    rec_p = []
+    orig_push = py.writer.push_sequence
+
+    def push(prio):
+        rec_p.append(prio.clone())
+        orig_push(prio)
+    py.writer.push_sequence = push
+    steps = 50
+    for it in range(steps):
+        if it in (20, 21, 35):
+            for tr in trs:
+                for net in (tr.act_online, tr.act_target):
+                    net.w["fc_a.weight"].mul_(1.02)
+                    net.w["lstm.weight_hh_l0"].mul_(0.99)
+                    net.refresh()
+        rec_p.clear()
+        nat.step()
+        py.step()
+        pr = nat.last_priority
+        assert (pr is None) == (len(rec_p) == 0), it
+        if pr is not None:
+            assert torch.equal(pr, rec_p[0]), it
+    torch.cuda.synchronize()
+    assert 6 <= nat.num_redo <= 9 and nat.num_act == py.num_act == steps * nat.N
+    import ctypes as C
+    h, c = C.c_void_p(), C.c_void_p()
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.composite import _view
+    _lib.check(nat._lib.hsad_actor_state(nat.c_actor, C.byref(h), C.byref(c)))
+    n = py.hid["h0"].numel()
+    assert torch.equal(_view(h.value, n, "cuda:0", nat), py.hid["h0"].reshape(-1)) and torch.equal(_view(c.value, n, "cuda:0", nat), py.hid["c0"].reshape(-1))
+    for tr in trs:
+        tr.env.check_errors()
+        tr.replay.check_errors()
+    ra, rb = trs[0].replay, trs[1].replay
+    assert ra.size() == rb.size() > 0 and ra.num_add() == rb.num_add()
+    assert ra.priority_sum() == rb.priority_sum()
+    for i in range(0, ra.size(), max(1, ra.size() // 97)):
+        fa, rwa, ta, ba, sa = ra.get(i)
+        fb, rwb, tb, bb, sb = rb.get(i)
+        assert all(torch.equal(fa[k], fb[k]) for k in fa) and torch.equal(rwa, rwb) and torch.equal(ta, tb) and torch.equal(ba, bb) and torch.equal(sa, sb), i
