@@ -59,6 +59,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round to nearest even
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// the same rounding without the NaN branch (a select): for epilogues where the branch would split the instruction stream
+__device__ __forceinline__ bf16_t f2bf_sel(float f) {
+  const uint32_t u = __float_as_uint(f);
+  const uint32_t r = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16, q = (u >> 16) | 0x40u;
+  return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? q : r);
+}
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float((uint32_t)b << 16); }
 
 constexpr int kBK = 64;            // K per LDS tile (one barrier pair per 64-deep step)
@@ -857,6 +863,78 @@ __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
 // each wave a 128 x 64 sub-tile (4 x 2 MFMA tiles, 128 accumulator registers), one workgroup per CU with both 64 KB operand
 // buffers in its LDS.  Per staged byte this does twice the MFMA work of the 128 x 128 kernel (whose k loop is bound by the
 // cost of moving operands into LDS, not by the matrix cores) and 0.75 instead of 1 fragment reads per MFMA.
+// cache policy of the state stores (c, h fp32, h bf16) of the 256 x 256 cell kernels: nt (aux = 2).  The stores of a tile round
+// (5 MB per XCD) otherwise push the weight panel (4 MB at H = 512 = the whole L2 of an XCD) out between rounds: measured -5 % per call;
+// sc1 (write-through): +6 %; nt on the c_prev loads or on the activation tiles: no gain alone, slower combined.
+constexpr int kCellStoreAux = 2;
+
+// Epilogue of the 256 x 256 cell kernels: the cell update of a wave's 128 x 64 accumulator tile (rows cm0 + 128 wm .., gate16
+// columns cn0 + 64 wn ..).  Lanes with (lane & 16) == 0 hold {i, g}, the others {f, o} of unit (lane & 15), for 16 rows each.
+// v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the accumulator
+// pair (k, 8 + k) it leaves {i, f} (second tile: {g, o}) of row k on the lo lanes and of row 8 + k on the hi lanes -- every lane
+// finishes 8 of its 16 rows with all four gates, no LDS round trip and no selects.  State rows go through buffer descriptors:
+// rows past Bn read 0 / drop their stores in the address unit (no branches, 32-bit offsets), and all 32 c_prev loads of the
+// tile are in flight before the first cell update.  AUXS / AUXL: cache policy of the state stores / c_prev loads.
+template <bool STATE, int AUXS, int AUXL>
+__device__ __forceinline__ void cell_epilogue_256(const LstmCellArgs& a, f32x16 (&acc)[4][2], int cm0, int cn0, int wm, int wn, int lane) {
+  const int H = a.H;
+  const bool hi = (lane & 16) != 0;
+  const int unit = (cn0 + wn * 64) / 4 + (lane & 15);
+  const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
+  const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
+  const int rsub = 4 * (lane >> 5) + (hi ? 16 : 0);
+  const uint32_t state_bytes = (uint32_t)a.Bn * (uint32_t)H * 4u;
+  const __amdgpu_buffer_rsrc_t rs_cp = __builtin_amdgcn_make_buffer_rsrc((void*)a.c_prev, 0, (int)state_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_co = __builtin_amdgcn_make_buffer_rsrc((void*)a.c_out, 0, a.c_out ? (int)state_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h32 = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_out32, 0, a.h_out32 ? (int)state_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_h16 = __builtin_amdgcn_make_buffer_rsrc((void*)a.h_out16, 0, a.h_out16 ? (int)(state_bytes / 2u) : 0, 0x00020000);
+  const uint32_t vo = (uint32_t)((cm0 + wm * 128 + rsub) * H + unit) * 4u;
+  const uint32_t rowb = (uint32_t)H * 4u;
+  float cp[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      cp[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_cp, vo + (uint32_t)(i * 32 + (k & 3) + 8 * (k >> 2)) * rowb, 0, AUXL));
+  const f32x2_t vbi = {bi, bi}, vbf = {bf_, bf_}, vbg = {bg, bg}, vbo = {bo, bo};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {      // two rows per round: packed fp32 arithmetic in the cell update
+      f32x2_t vpi, vpf, vpg, vpo, vcp, c2, h2;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kk = k + u;
+        // (__builtin_bit_cast on a vector ELEMENT reads element 0 with this compiler: go through scalars)
+        const float x0 = acc[i][0][kk], y0 = acc[i][0][8 + kk], x1 = acc[i][1][kk], y1 = acc[i][1][8 + kk];
+        const auto s0 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x0), __float_as_uint(y0), false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x1), __float_as_uint(y1), false, false);
+        vpi[u] = __uint_as_float(s0[0]);
+        vpf[u] = __uint_as_float(s0[1]);
+        vpg[u] = __uint_as_float(s1[0]);
+        vpo[u] = __uint_as_float(s1[1]);
+        vcp[u] = cp[i][kk];
+      }
+      lstm_cell_shared_rcp_x2(vpi + vbi, vpf + vbf, vpg + vbg, vpo + vbo, vcp, c2, h2);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int kk = k + u;
+        const uint32_t off = vo + (uint32_t)(i * 32 + (kk & 3) + 8 * (kk >> 2)) * rowb;
+        if (STATE) {     // (a null output has an empty descriptor: its stores are dropped in the address unit)
+          const float cu = c2[u], hu = h2[u];
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cu), rs_co, off, 0, AUXS);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hu), rs_h32, off, 0, AUXS);
+        }
+        __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_sel(h2[u]), rs_h16, off >> 1, 0, AUXS);
+      }
+    }
+  }
+}
+
+typedef unsigned long long u64_t;
+__device__ u64_t g_lstm_dbg[32];   // 0-15 forward kernels (and the chunked backward at 8-15), 16-31 fused backward; see LSTM_STAMP
+
+template <bool STATE, bool DBG = false>   // STATE: the new fp32 state (c, h) leaves the kernel next to the bf16 layer output; false: only h_out16 (target pass)
 __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) {
   constexpr int BM = 256, BN = 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
@@ -911,6 +989,14 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
   set_rows();
   issue_tile(0, 0);
   const int nk = K / kBK;
+  u64_t stamp_ = DBG ? wall_clock64() : 0;
+  auto stamp = [&](int slot) {       // developer timers (hsad_lstm_debug_enable): ticks of workgroup 0 per phase
+    if (DBG && blockIdx.x == 0 && tid == 0) {
+      const u64_t now_ = wall_clock64();
+      atomicAdd(&g_lstm_dbg[slot], now_ - stamp_);
+      stamp_ = now_;
+    }
+  };
   for (;;) {
     f32x16 acc[4][2];
 #pragma unroll
@@ -923,6 +1009,7 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
       const int cur = kt & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      stamp(2);
       if (kt + 1 < nk) issue_tile((kt + 1) * kBK, cur ^ 1);
       const bf16_t* pa = sA + cur * BM * kBK;
       const bf16_t* pb = sB + cur * BN * kBK;
@@ -938,14 +1025,11 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
+      stamp(3);
     }
-    // ---- epilogue (as lstm_cell_gemm_kernel: lo lanes hold {i, g}, hi lanes {f, o} of unit (lane & 15)) ----
+    stamp(0);
+    // ---- epilogue (cell_epilogue_256) ----
     const int cm0 = m0, cn0 = n0;
-    const bool hi = (lane & 16) != 0;
-    const int unit = (cn0 + wn * 64) / 4 + (lane & 15);
-    const float* bp = a.bias + cn0 + wn * 64 + (lane & 15);
-    const float bi = bp[0], bf_ = bp[16], bg = bp[32], bo = bp[48];
-    const int rsub = 4 * (lane >> 5) + (hi ? 16 : 0);
     seq += per_xcd;
     const bool more = set_tile(seq);
     if (more) {                                // buffer 0 was last read in step nk - 2 when nk is even
@@ -953,47 +1037,247 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
       set_rows();
       issue_tile(0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float cp[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int row = cm0 + wm * 128 + i * 32 + (k & 3) + 8 * (k >> 2) + rsub;
-        cp[k] = row < a.Bn ? a.c_prev[(size_t)row * H + unit] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k += 2) {      // two units per round: packed fp32 arithmetic in the cell update
-        f32x2_t vpi, vpf, vpg, vpo, vcp, c2, h2;
-        int rows[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int kk = k + u;
-          float l0 = acc[i][0][kk], h0 = acc[i][0][8 + kk], l1 = acc[i][1][kk], h1 = acc[i][1][8 + kk];
-          asm volatile("" : "+v"(l0), "+v"(h0), "+v"(l1), "+v"(h1));
-          const float g0 = __shfl_xor(hi ? l0 : h0, 16, 64);
-          const float g1 = __shfl_xor(hi ? l1 : h1, 16, 64);
-          rows[u] = cm0 + wm * 128 + i * 32 + (kk & 3) + 8 * (kk >> 2) + rsub;
-          const float m0v = hi ? h0 : l0, m1v = hi ? h1 : l1;
-          vpi[u] = hi ? g0 : m0v;
-          vpg[u] = hi ? g1 : m1v;
-          vpf[u] = hi ? m0v : g0;
-          vpo[u] = hi ? m1v : g1;
-          vcp[u] = cp[kk];
-        }
-        const f32x2_t vbi = {bi, bi}, vbf = {bf_, bf_}, vbg = {bg, bg}, vbo = {bo, bo};
-        lstm_cell_shared_rcp_x2(vpi + vbi, vpf + vbf, vpg + vbg, vpo + vbo, vcp, c2, h2);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int row = rows[u];
-          if (row >= a.Bn) continue;
-          if (a.c_out) a.c_out[(size_t)row * H + unit] = c2[u];
-          if (a.h_out32) a.h_out32[(size_t)row * H + unit] = h2[u];
-          if (a.h_out16) a.h_out16[(size_t)row * H + unit] = f2bf(h2[u]);
-        }
-      }
-    }
+    cell_epilogue_256<STATE, kCellStoreAux, 0>(a, acc, cm0, cn0, wm, wn, lane);
+    stamp(1);
     if (!more) break;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The 256 x 256 cell kernel with a phase-interleaved k loop ("ping-pong"): same tile, same wave grid (2 x 4 waves of 128 x 64), same
+// accumulator layout and epilogue as lstm_cell_gemm256_kernel, but
+//   * the operand tiles live in LDS as HALF tiles (A0 / A1: 2 x 64 rows of each wave row block; B0 / B1: the [i f] / [g o] column halves
+//     of each wave's 64 gate columns; 16 KB each, two k tiles resident = 128 KB), and one half tile is re-filled per phase, six half
+//     tiles ahead of its use: 48-64 KB of LDS-DMA are in flight per CU at any time instead of one 64 KB burst per k step that must
+//     land before the next barrier (measured there: 0.64 us of a 2.15 us k step spent waiting for it);
+//   * a k tile is four phases -- (A0,B0) (A0,B1) (A1,B1) (A1,B0), 8 MFMAs each, operand fragments read at most once per k tile -- and a
+//     phase is  L: fragment reads + one half-tile DMA + counted vmcnt | barrier | M: 8 MFMAs | barrier;  the wave row wm = 1 runs one
+//     barrier behind wm = 0, and the two waves of a SIMD are one of each: while one issues its MFMAs the other does its LDS reads and
+//     its share of the DMA, so the matrix pipe sees one MFMA cluster after the other.
+// Hazards (all by barrier count, never by timing):  RAW -- the vmcnt in phase c - 1 (both wave rows, before their barrier) retires the
+// half tiles read in phase c;  WAR -- a wave's fragment reads of phase c are retired before its MFMAs of phase c, i.e. before its barrier
+// that ends M (the later wave row: global barrier 2c + 3), and a half tile is re-filled no earlier than two phases after the phase that
+// read it (the earlier wave row issues that DMA behind global barrier 2c + 4).  Needs Bn % 256 == 0 (no row clamping in the DMA offsets).
+// ---------------------------------------------------------------------------------------------------
+template <bool STATE, int ABL = 0>   // ABL (developer instantiations; 1-8: results are garbage): 1 no DMA, 2 no MFMA, 4 no stagger, 8 no fragment reads, 128 phase timers
+__global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
+  constexpr int BM = 256, BN = 256;
+  constexpr uint32_t kHalf = 128 * kBK * 2;               // bytes of a half tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int H = a.H, K = a.Kx + H, N4 = 4 * H;
+  const int tiles_n = N4 / BN, tiles_m = a.Bn / BM;
+  const bool xcd_order = (gridDim.x % 8) == 0;
+  const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
+  const int per_xcd = gridDim.x / n_xcd;
+  auto tile_of = [&](int sq, int& m0, int& n0) -> bool {      // tile order of lstm_cell_gemm256_kernel
+    const int mt = (sq / tiles_n) * n_xcd + xcd;
+    n0 = (sq % tiles_n) * BN;
+    m0 = mt * BM;
+    return mt < tiles_m;
+  };
+  const int nk = K / kBK;
+
+  // ---- producer: half tile u = 4 T + {A0, B0, B1, A1} of the k tile stream T = 0, 1, .. over this workgroup's output tiles ----
+  // LDS rows: A half p row q = 64 wm' + r  <->  tile row 128 wm' + 64 p + r;  B half p row q = 32 wn' + c  <->  tile column 64 wn' + 32 p + c
+  // this lane's source byte offsets (swizzled chunk, see glds16) for the two 8-row pieces (wave, wave + 8) of each half tile; named
+  // scalars, not arrays: a dynamically indexed array would live in scratch memory
+  auto src_off = [&](int hp, int e, int ld, bool is_a) -> uint32_t {
+    const int q = (wave + 8 * e) * 8 + (lane >> 3);
+    const int ch = swz_chunk(q, lane & 7) * 8;
+    const int r = is_a ? (q >> 6) * 128 + hp * 64 + (q & 63) : (q >> 5) * 64 + hp * 32 + (q & 31);
+    return (uint32_t)(r * ld + ch) * 2u;
+  };
+  const uint32_t ax00 = src_off(0, 0, a.ldx, true), ax01 = src_off(0, 1, a.ldx, true), ax10 = src_off(1, 0, a.ldx, true), ax11 = src_off(1, 1, a.ldx, true);
+  const uint32_t ah00 = src_off(0, 0, H, true), ah01 = src_off(0, 1, H, true), ah10 = src_off(1, 0, H, true), ah11 = src_off(1, 1, H, true);
+  const uint32_t b00 = src_off(0, 0, K, false), b01 = src_off(0, 1, K, false), b10 = src_off(1, 0, K, false), b11 = src_off(1, 1, K, false);
+  int p_seq = blockIdx.x / n_xcd, p_m0 = 0, p_n0 = 0, p_kt = 0, p_T = 0;
+  bool p_valid = tile_of(p_seq, p_m0, p_n0);
+  if (!p_valid) return;
+  unsigned char* const dst_w = smem_cell + wave * 1024;
+  // one half tile = two LDS-DMA instructions per wave.  kind: 0 A0, 1 B0, 2 B1, 3 A1 -- a compile-time constant at every call site:
+  // consumer phase c issues half tile c + 6, i.e. P1 -> B1, P2 -> A1 (next k tile), P3 -> A0, P4 -> B0 (the one after)
+  auto issue = [&](auto kind_c) {
+    constexpr int kind = decltype(kind_c)::value;
+    if (!p_valid) return;
+    if ((ABL & 1) && p_T >= 2) {
+      if (kind == 3 && (++p_T, ++p_kt == nk)) { p_kt = 0; p_seq += per_xcd; p_valid = tile_of(p_seq, p_m0, p_n0); }
+      return;
+    }
+    const int k0 = p_kt * kBK;
+    const uint32_t slot = (uint32_t)(p_T & 1) * 4u * kHalf;
+    if (kind == 0 || kind == 3) {
+      const bool part2 = k0 >= a.Kx;
+      const char* abase = part2 ? reinterpret_cast<const char*>(a.h_prev16 + (size_t)p_m0 * H + (k0 - a.Kx))
+                                : reinterpret_cast<const char*>(a.x + (size_t)p_m0 * a.ldx + k0);
+      const uint32_t o0 = kind == 0 ? (part2 ? ah00 : ax00) : (part2 ? ah10 : ax10), o1 = kind == 0 ? (part2 ? ah01 : ax01) : (part2 ? ah11 : ax11);
+      const uint32_t d = slot + (kind == 0 ? 0u : kHalf);
+      glds16(reinterpret_cast<const bf16_t*>(abase + o0), reinterpret_cast<bf16_t*>(dst_w + d));
+      glds16(reinterpret_cast<const bf16_t*>(abase + o1), reinterpret_cast<bf16_t*>(dst_w + d + 8192u));
+    } else {
+      const char* bbase = reinterpret_cast<const char*>(a.Wcat + (size_t)p_n0 * K + k0);
+      const uint32_t d = slot + (kind == 1 ? 2u : 3u) * kHalf;
+      glds16(reinterpret_cast<const bf16_t*>(bbase + (kind == 1 ? b00 : b10)), reinterpret_cast<bf16_t*>(dst_w + d));
+      glds16(reinterpret_cast<const bf16_t*>(bbase + (kind == 1 ? b01 : b11)), reinterpret_cast<bf16_t*>(dst_w + d + 8192u));
+    }
+    if (kind == 3) {          // the k tile is complete: next one, next output tile after the last
+      ++p_T;
+      if (++p_kt == nk) {
+        p_kt = 0;
+        p_seq += per_xcd;
+        p_valid = tile_of(p_seq, p_m0, p_n0);
+      }
+    }
+  };
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  // counted wait at the end of a phase's L part, after this phase's DMA (half tile c + 6): everything but the four newest half tiles
+  // (eight instructions of this wave) has landed, i.e. the half tiles <= c + 2 that phase c + 1 reads; P3 leaves only three in flight,
+  // because P4 reads B0 of the NEXT k tile (half tile c + 2 of its own index)
+  auto wait_ahead = [&](auto n_c) {
+    constexpr int n = decltype(n_c)::value;
+    if (!p_valid) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+  using W8 = std::integral_constant<int, 8>;
+  using W6 = std::integral_constant<int, 6>;
+
+  // ---- consumer: this lane's fragment read offsets inside a half tile (row 32 i' + (lane & 31) of the wave's 64 / 32 rows) ----
+  uint32_t fragA[4], fragB[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int qa = wm * 64 + (lane & 31), qb = wn * 32 + (lane & 31);
+    fragA[kk] = (uint32_t)(qa * kBK + swz_chunk(qa, kk * 2 + (lane >> 5)) * 8) * 2u;      // (+ 32 rows: + 4096 bytes, same swizzle)
+    fragB[kk] = (uint32_t)(qb * kBK + swz_chunk(qb, kk * 2 + (lane >> 5)) * 8) * 2u;
+  }
+  auto ldfrag = [&](uint32_t byte_off) -> bf16x8 {
+    if (ABL & 8) { bf16x8 z; asm volatile("" : "=v"(z)); return z; }
+    return *reinterpret_cast<const bf16x8*>(smem_cell + byte_off);
+  };
+  auto mma = [&](const bf16x8& x, const bf16x8& y, f32x16& c) {
+    if (ABL & 2) { asm volatile("" :: "v"(x), "v"(y)); return; }
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+  };
+
+  int seq = blockIdx.x / n_xcd, m0 = 0, n0 = 0;
+  (void)tile_of(seq, m0, n0);
+  // prologue: half tiles 0 .. 5 (k tile 0 and A0, B0 of k tile 1)
+  issue(K0{}); issue(K1{}); issue(K2{}); issue(K3{});
+  issue(K0{}); issue(K1{});
+  wait_ahead(W8{});
+  __builtin_amdgcn_s_barrier();
+  if (wm == 1 && !(ABL & 4)) __builtin_amdgcn_s_barrier();              // the second wave row runs one barrier behind the first
+  int T = 0;
+  u64_t tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = (ABL & 128) ? clock64() : 0;   // developer timers: L | wait at L barrier | M | wait at M barrier | epilogue
+  bf16x8 fb0n[4];               // B0 fragments of the NEXT k tile
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fb0n[kk] = ldfrag(2u * kHalf + fragB[kk]);
+  for (;;) {
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt, ++T) {
+      const uint32_t slot = (uint32_t)(T & 1) * 4u * kHalf;
+      bf16x8 fa[2][4], fb0[4], fb1[4];
+      // one phase: L (reads, DMA, waits) | barrier | M | barrier
+#define PP_PIN(x) asm volatile("" : "+v"(x))
+#define PP_STAMP(k)                                       \
+  if (ABL & 128) {                                        \
+    const u64_t now_ = clock64();                         \
+    tacc[k] += now_ - tlast;                              \
+    tlast = now_;                                         \
+  }
+#define PP_END_L(KIND, WN, c0, c1)                        \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  PP_STAMP(5)                                             \
+  issue(KIND{});                                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  PP_STAMP(6)                                             \
+  wait_ahead(WN{});                                       \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  PP_STAMP(0)                                             \
+  __builtin_amdgcn_s_barrier();                           \
+  PP_STAMP(1)                                             \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  PP_PIN(c0); PP_PIN(c1);          /* the MFMAs of this phase cannot be scheduled ahead of the barrier ... */ \
+  __builtin_amdgcn_s_setprio(1);
+#define PP_END_M(c0, c1)                                  \
+  PP_PIN(c0); PP_PIN(c1);          /* ... nor behind the one that ends the phase */ \
+  __builtin_amdgcn_s_setprio(0);                          \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  PP_STAMP(2)                                             \
+  __builtin_amdgcn_s_barrier();                           \
+  PP_STAMP(3)                                             \
+  __builtin_amdgcn_sched_barrier(0);
+      // P1: (A0, B0)     [B0's fragments were read during P4 of the previous k tile]
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        fb0[kk] = fb0n[kk];
+        fa[0][kk] = ldfrag(slot + fragA[kk]);
+        fa[1][kk] = ldfrag(slot + fragA[kk] + 4096u);
+      }
+      PP_END_L(K2, W8, acc[0][0], acc[1][0])
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        mma(fa[0][kk], fb0[kk], acc[0][0]);
+        mma(fa[1][kk], fb0[kk], acc[1][0]);
+      }
+      PP_END_M(acc[0][0], acc[1][0])
+      // P2: (A0, B1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) fb1[kk] = ldfrag(slot + 3u * kHalf + fragB[kk]);
+      PP_END_L(K3, W8, acc[0][1], acc[1][1])
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        mma(fa[0][kk], fb1[kk], acc[0][1]);
+        mma(fa[1][kk], fb1[kk], acc[1][1]);
+      }
+      PP_END_M(acc[0][1], acc[1][1])
+      // P3: (A1, B1)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        fa[0][kk] = ldfrag(slot + kHalf + fragA[kk]);
+        fa[1][kk] = ldfrag(slot + kHalf + fragA[kk] + 4096u);
+      }
+      PP_END_L(K0, W6, acc[2][1], acc[3][1])
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        mma(fa[0][kk], fb1[kk], acc[2][1]);
+        mma(fa[1][kk], fb1[kk], acc[3][1]);
+      }
+      PP_END_M(acc[2][1], acc[3][1])
+      // P4: (A1, B0) -- both operands are in registers; B0 of the next k tile (other slot) is read here for its P1
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) fb0n[kk] = ldfrag((slot ^ (4u * kHalf)) + 2u * kHalf + fragB[kk]);
+      PP_END_L(K1, W8, acc[2][0], acc[3][0])
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        mma(fa[0][kk], fb0[kk], acc[2][0]);
+        mma(fa[1][kk], fb0[kk], acc[3][0]);
+      }
+      PP_END_M(acc[2][0], acc[3][0])
+#undef PP_END_L
+#undef PP_END_M
+#undef PP_PIN
+    }
+    cell_epilogue_256<STATE, kCellStoreAux, 0>(a, acc, m0, n0, wm, wn, lane);
+    PP_STAMP(4)
+    seq += per_xcd;
+    if (!tile_of(seq, m0, n0)) break;
+  }
+  if ((ABL & 128) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+    for (int k = 0; k < 7; ++k) atomicAdd(&g_lstm_dbg[(wave ? 8 : 0) + k], tacc[k]);
+#undef PP_STAMP
+  if (wm == 0 && !(ABL & 4)) __builtin_amdgcn_s_barrier();              // balances the stagger barrier of the second wave row
 }
 
 // Small-batch variant (learner: Bn = 128): block = 32 rows x 32 hidden units, 4 waves in a 2x2 grid, each wave
@@ -1098,11 +1382,9 @@ __global__ __launch_bounds__(256) void lstm_step_small_kernel(LstmStepArgs a) {
 // exchange can stay inside that L2 -- plain stores + L2 atomics instead of write-through stores + memory-side atomics
 // (`fast`).  A group that is NOT co-located keeps the cross-XCD protocol: correctness never depends on placement.
 // ---------------------------------------------------------------------------------------------------
-typedef unsigned long long u64_t;
-
-// developer phase timers of the persistent recurrences (hsad_lstm_debug_timing): wall-clock ticks (100 MHz) summed over
-// the steps of ONE workgroup (row block 0, unit block 0); slots 0-7 forward, 8-15 backward
-__device__ u64_t g_lstm_dbg[32];   // 0-15 forward kernels (and the chunked backward at 8-15), 16-31 fused backward
+// developer phase timers of the persistent recurrences: g_lstm_dbg (declared next to the fused cell kernel, which uses slots 0-2 in
+// its DBG instantiation); wall-clock ticks (100 MHz) summed over the steps of ONE workgroup (row block 0, unit block 0);
+// slots 0-7 forward, 8-15 backward
 #define LSTM_STAMP(slot)                                      \
   if (dbg_on) {                                               \
     const u64_t now_ = wall_clock64();                        \
@@ -3575,7 +3857,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
   }
   LstmCellArgs a{(const bf16_t*)x16, (const bf16_t*)h_prev16, (const bf16_t*)Wcat_gate16, bias_gate16, c_prev, c_out, h_out32, (bf16_t*)h_out16,
                  Bn, H, Kx, ldx};
-  if ((size_t)Bn * (size_t)std::max(ldx, H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
+  if (((size_t)Bn + 256) * (size_t)std::max(ldx, 2 * H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands of 4 GB and more are not supported (32-bit offsets)");
   hipEvent_t t_e0 = nullptr, t_e1 = nullptr;
   if (g_cell_timing.on) {
@@ -3587,11 +3869,33 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
   const bool big = force_tile ? force_tile == 256 : (Bn >= 4096 && (4 * H) % 256 == 0);
   if (big && (4 * H) % 256 == 0) {
     const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)(4 * H / 256) * ((Bn + 255) / 256);
     long grid = std::min<long>(tiles, (long)n_cu);
     if (grid >= 64) grid &= ~7L;
-    hipLaunchKernelGGL(lstm_cell_gemm256_kernel, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+    // developer switch HSAD_CELL_PP: 0 the one-barrier k loop, 1 (default) the phase-interleaved one; 11 / 12 / 14 / 19: its ablations
+    static const int pp = getenv("HSAD_CELL_PP") ? atoi(getenv("HSAD_CELL_PP")) : 1;
+    if (pp && Bn % 256 == 0) {
+      const bool st = c_out || h_out32;
+      auto kp = st ? lstm_cell_pp_kernel<true> : lstm_cell_pp_kernel<false>;
+      if (pp == 11) kp = lstm_cell_pp_kernel<true, 1>;
+      if (pp == 12) kp = lstm_cell_pp_kernel<true, 2>;
+      if (pp == 14) kp = lstm_cell_pp_kernel<true, 4>;
+      if (pp == 19) kp = lstm_cell_pp_kernel<true, 9>;
+      if (g_lstm_dbg_enable) kp = lstm_cell_pp_kernel<true, 128>;
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+      HIP_TRY(hipGetLastError());
+      if (t_e0) {
+        HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
+        g_cell_timing.ev.push_back({t_e0, t_e1});
+        g_cell_timing.flop.push_back(2.0 * Bn * 4.0 * H * (Kx + H));
+      }
+      return HSAD_OK;
+    }
+    auto kern = g_lstm_dbg_enable ? ((c_out || h_out32) ? lstm_cell_gemm256_kernel<true, true> : lstm_cell_gemm256_kernel<false, true>)
+                                  : ((c_out || h_out32) ? lstm_cell_gemm256_kernel<true> : lstm_cell_gemm256_kernel<false>);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
   } else {
     const size_t lds = (size_t)2 * (128 + 128) * kBK * sizeof(bf16_t);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_cell_gemm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
