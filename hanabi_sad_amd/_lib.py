@@ -165,6 +165,8 @@ SIGNATURES = {
     "hsad_colsum_acc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, _P, _P]),
+    "hsad_adam_step_zero_grad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,
+                                          C.POINTER(_P), _P]),
     "hsad_act_select": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P]),
     "hsad_nstep_priority": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_double, C.c_int, _P, _P]),
     "hsad_zero_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
@@ -239,6 +241,7 @@ SIGNATURES = {
     "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
     "hsad_r2d2_loss_bwd": (C.c_int, [_P, _P]),
     "hsad_r2d2_optimizer_step": (C.c_int, [_P, C.c_float, C.c_float, C.POINTER(_P), _P]),
+    "hsad_r2d2_learner_grad_norm_dev": (_P, [_P]),
     "hsad_r2d2_sync_target_with_online": (C.c_int, [_P, _P]),
     "hsad_eltwise_mul": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),
     "hsad_lstm_cell_f32_forward": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),

@@ -269,9 +269,9 @@ class CompositeLearner:
         return loss, prio
 
     def optimizer_step(self, beta1=0.9, beta2=0.999):
-        gp = C.c_void_p()
-        _lib.check(self.lib.hsad_r2d2_optimizer_step(self.h, beta1, beta2, C.byref(gp), _s(self.device)))
-        return torch.sqrt(_view(gp.value, 1, self.device, self)[0])
+        """-> the pre-clip global gradient norm (device scalar: a view of the library's ring of the last twelve steps' norms; no torch op)"""
+        _lib.check(self.lib.hsad_r2d2_optimizer_step(self.h, beta1, beta2, None, _s(self.device)))
+        return _view(self.lib.hsad_r2d2_learner_grad_norm_dev(self.h), 1, self.device, self)[0]
 
     def sync_target_with_online(self):
         if self.h is None:

@@ -25,6 +25,12 @@
 #include "hsad.h"
 
 extern "C" int hsad_internal_set_error(int code, const char* msg);
+// hsad_loss_tail with a buffer the launch clears on the side (csrc/hsad_r2d2.hip)
+extern "C" int hsad_internal_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
+                                       const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
+                                       const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step,
+                                       double gamma, float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss,
+                                       float* xent_sum, float* dqa, void* dheads16, int ldo, float* zero_buf, int64_t zero_n, void* stream);
 
 namespace {
 
@@ -616,6 +622,8 @@ struct hsad_r2d2_learner {
   size_t fbsync_words;
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
+  bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
+  bool gflat_zero = true;     // the gradient buffer is all zero (creation; optimizer_step clears it behind Adam, as optim.zero_grad() does)
   unsigned* fsync[3][2];      // ping-pong counter blocks of the fused launches: [log2(recurrences per launch)][flip]
   int fflip[3] = {0, 0, 0};
   size_t fsync_words[3];
@@ -787,7 +795,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   for (int l = 1; l < NL; ++l) L->dc[l] = L->dc[0] + (size_t)l * B * H;
   for (int q = 0; q < 2; ++q) L->xin[q] = nfc == 2 ? L->x2[q] : L->x1[q];
   // optimizer state + gradient
-  const size_t np = online->n_param;
+  const size_t np = (online->n_param + 3) & ~(size_t)3;      // (each of the three flat buffers 16-byte aligned)
   if (L->opt.need(np * 4 * 3 + 64)) {
     delete L;
     return HSAD_ERR_NOMEM;
@@ -1039,13 +1047,18 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
                             L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
   L->dheads_ready = false;
+  L->dc01_zero = false;
   if (num_player == 1) {
     // IQL: the online Q-head, then everything up to d loss / d heads in ONE launch (hsad_loss_tail)
     CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, nullptr, L->qscratch, stream));
-    CK(hsad_loss_tail(L->heads, L->heads_t, NH, legal_move, L->q, L->qa, L->qscratch + 1, (M + 255) / 256, reward, bootstrap, seq_len, weight,
-                      pred_weight > 0 ? own_hand : nullptr, a, T, B, A, L->on->NP, L->multi_step, L->gamma, pred_weight, L->greedy, L->tqa, L->err,
-                      priority, loss, L->xs, want_grad ? L->dqa : nullptr, want_grad ? L->dheads : nullptr, L->on->NHp, stream));
+    // (with a gradient to follow, the launch also clears d loss / d c_T of the two fused-BPTT layers: one memset less in front of the BPTT)
+    const bool zero_dc = want_grad && NL >= 2;
+    CK(hsad_internal_loss_tail(L->heads, L->heads_t, NH, legal_move, L->q, L->qa, L->qscratch + 1, (M + 255) / 256, reward, bootstrap, seq_len, weight,
+                               pred_weight > 0 ? own_hand : nullptr, a, T, B, A, L->on->NP, L->multi_step, L->gamma, pred_weight, L->greedy, L->tqa,
+                               L->err, priority, loss, L->xs, want_grad ? L->dqa : nullptr, want_grad ? L->dheads : nullptr, L->on->NHp,
+                               zero_dc ? L->dc[0] : nullptr, zero_dc ? (int64_t)2 * B * H : 0, stream));
     L->dheads_ready = want_grad != 0;
+    L->dc01_zero = zero_dc;
     L->b_legal = legal_move;
     L->b_a = a;
     L->b_own = pred_weight > 0 ? own_hand : nullptr;
@@ -1104,7 +1117,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
                            L->dheads, NHp, stream));
   CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO[top], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
-  HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
+  if (!L->gflat_zero) HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
+  L->gflat_zero = false;
   float* g[kMaxP];
   for (int i = 0; i < on->np; ++i) g[i] = L->gflat + on->off[i];
   const bool pipe = can_pipeline(L);
@@ -1167,7 +1181,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     // chunks) run on the side stream next to the following chunk's launch -- the launch occupies 4 of the 8 XCDs.
     const int Tc = T / nbc;
     const size_t Mc = (size_t)Tc * B;
-    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
+    if (!L->dc01_zero) HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
+    L->dc01_zero = false;
     chunk_wgrad = [=](int l, int c, void* st, bf16_t* dGT, float* wsp) -> int {
       const size_t m0 = (size_t)c * Mc;
       CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
@@ -1213,7 +1228,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   } else if (pipe) {
     const int Tc = T / nch, nrb = nrb_of(B);
     const size_t Mc = (size_t)Tc * B;
-    HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
+    if (!L->dc01_zero) HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
+    L->dc01_zero = false;
     const int per_launch = std::max(1, std::min(2, L->n_cu / ((H / 32) * nrb)));
     auto brec = [&](int l, int c) {
         const size_t t0 = (size_t)c * Tc;
@@ -1306,11 +1322,15 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
 int hsad_r2d2_optimizer_step(hsad_r2d2_learner* L, float beta1, float beta2, float** grad_norm_sq_dev, void* stream) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");
   L->step_count++;
-  CK(hsad_adam_step(L->on->flat, L->gflat, L->m, L->v, (int64_t)L->on->n_param, L->clip, L->lr, beta1, beta2, L->adam_eps, L->step_count, L->osc,
-                    stream));
-  if (grad_norm_sq_dev) *grad_norm_sq_dev = L->osc;
+  float* slot = nullptr;
+  CK(hsad_adam_step_zero_grad(L->on->flat, L->gflat, L->m, L->v, (int64_t)L->on->n_param, L->clip, L->lr, beta1, beta2, L->adam_eps, L->step_count,
+                              L->osc, &slot, stream));
+  L->gflat_zero = true;
+  if (grad_norm_sq_dev) *grad_norm_sq_dev = slot;
   return net_refresh(L->on, (hipStream_t)stream);
 }
+
+const float* hsad_r2d2_learner_grad_norm_dev(const hsad_r2d2_learner* L) { return L ? L->osc + 4 + L->step_count % 12 : nullptr; }
 
 int hsad_r2d2_sync_target_with_online(hsad_r2d2_learner* L, void* stream) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");

@@ -2939,8 +2939,11 @@ struct LossTailArgs {
   float *target_qa, *err, *priority, *loss, *xent_sum, *dqa;
   bf16_t* dheads;
   int ldo;
+  float* zero_buf;      // optional: a buffer this launch clears on the side (the learner's d loss / d c_T = 0 of the BPTT that follows)
+  unsigned zero_n;
 };
 __global__ void loss_tail_kernel(LossTailArgs p) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_n; i += gridDim.x * blockDim.x) p.zero_buf[i] = 0.f;
   extern __shared__ float s_lt[];
   float* s_tq = s_lt;                 // [T] Q_target(s_t, greedy_t)
   float* s_x = s_lt + p.T;            // [T] aux cross-entropy of step t
@@ -3152,10 +3155,13 @@ __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* __res
   if ((((uintptr_t)g) & 15) == 0) {            // 16-byte loads, two in flight per thread
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const size_t n4 = n >> 2;
-    for (size_t i = tid; i < n4; i += 2 * nth) {
-      const float4 a = g4[i];
-      const float4 b = i + nth < n4 ? g4[i + nth] : make_float4(0.f, 0.f, 0.f, 0.f);
-      acc += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = tid; i < n4; i += 8 * nth) {          // eight 16-byte loads in flight per thread
+      float4 q[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) q[k] = i + k * nth < n4 ? g4[i + k * nth] : z4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += q[k].x * q[k].x + q[k].y * q[k].y + q[k].z * q[k].z + q[k].w * q[k].w;
     }
     for (size_t i = (n4 << 2) + tid; i < n; i += nth) acc += g[i] * g[i];
   } else {
@@ -3171,20 +3177,42 @@ __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float* __res
 }
 
 // torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (selfplay.py:231-235)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            size_t n, const float* __restrict__ sumsq, float max_norm, float lr, float beta1, float beta2,
-                            float eps, float bc1, float bc2_sqrt) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+template <bool ZERO_GRAD>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            size_t n, const float* __restrict__ sumsq, float* __restrict__ clear_slot, float* __restrict__ norm_out, float max_norm,
+                            float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // four consecutive elements per thread (16-byte accesses)
   const float total_norm = sqrtf(sumsq[0]);
+  if (i4 == 0) {
+    if (clear_slot) *clear_slot = 0.f;                // the sum-of-squares slot of the NEXT step (nobody reads or writes it now)
+    if (norm_out) *norm_out = total_norm;             // clip_grad_norm_'s return value
+  }
   const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.f);
-  const float gi = g[i] * coef;
-  const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-  const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-  m[i] = mi;
-  v[i] = vi;
-  const float denom = sqrtf(vi) / bc2_sqrt + eps;
-  p[i] -= (lr / bc1) * (mi / denom);
+  auto one = [&](float& pi, float& gi_, float& mi_, float& vi_) {
+    const float gi = gi_ * coef;
+    if (ZERO_GRAD) gi_ = 0.f;                         // optim.zero_grad() right behind optim.step() (selfplay.py:234-235)
+    const float mi = beta1 * mi_ + (1.f - beta1) * gi;
+    const float vi = beta2 * vi_ + (1.f - beta2) * gi * gi;
+    mi_ = mi;
+    vi_ = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= (lr / bc1) * (mi / denom);
+  };
+  const size_t i = i4 * 4;
+  if (i + 4 <= n) {
+    float4 P = reinterpret_cast<float4*>(p)[i4], G = reinterpret_cast<float4*>(g)[i4], M = reinterpret_cast<float4*>(m)[i4],
+           V = reinterpret_cast<float4*>(v)[i4];
+    one(P.x, G.x, M.x, V.x);
+    one(P.y, G.y, M.y, V.y);
+    one(P.z, G.z, M.z, V.z);
+    one(P.w, G.w, M.w, V.w);
+    reinterpret_cast<float4*>(p)[i4] = P;
+    reinterpret_cast<float4*>(m)[i4] = M;
+    reinterpret_cast<float4*>(v)[i4] = V;
+    if (ZERO_GRAD) reinterpret_cast<float4*>(g)[i4] = G;
+  } else {
+    for (size_t k = i; k < n; ++k) one(p[k], g[k], m[k], v[k]);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3539,7 +3567,10 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
   }
   // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
   const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz * np;
-  if (N <= 64 || tiles128 < n_cu) {
+  // (developer switch: the limit in percent of the CU count.  Measured at 150: the K = 2048 input-layer backward GEMM, 320 tiles,
+  // 69 -> 87 us with 128 x 64 tiles -- the narrow tile's lower rate outweighs the evener spread)
+  static const int narrow_upto = getenv("HSAD_GEMM_NARROW_UPTO") ? atoi(getenv("HSAD_GEMM_NARROW_UPTO")) : 100;   // percent of the CU count
+  if (N <= 64 || tiles128 * 100 < (long)n_cu * narrow_upto) {
     const size_t lds = gemm_lds_bytes(128, 64);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel<128, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long tiles = (long)((N + 63) / 64) * ((M + 127) / 128) * gz * np;
@@ -4056,11 +4087,11 @@ int hsad_aux_xent(const float* heads, int ldh, const float* own_hand, int T, int
   return HSAD_OK;
 }
 
-int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
+int hsad_internal_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
                    const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
                    const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step, double gamma,
                    float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss, float* xent_sum, float* dqa,
-                   void* dheads16, int ldo, void* stream) {
+                   void* dheads16, int ldo, float* zero_buf, int64_t zero_n, void* stream) {
   if (!heads || !heads_t || !legal || !q_online || !online_qa || !block_min || !reward || !bootstrap || !seq_len || !greedy || !target_qa || !err ||
       !priority || !loss || n_block_min < 1 || T < 1 || B < 1)
     return nfail(HSAD_ERR_INVALID, "loss_tail: null argument");
@@ -4074,10 +4105,20 @@ int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const floa
     gamma_n = (float)g;
   }
   LossTailArgs p{heads, heads_t, legal, q_online, online_qa, block_min, reward, bootstrap, seq_len, weight, own_hand, action, ldh, n_block_min, T, B, A, NP,
-                 multi_step, gamma_n, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, (bf16_t*)dheads16, ldo};
+                 multi_step, gamma_n, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, (bf16_t*)dheads16, ldo, zero_buf, (unsigned)zero_n};
   hipLaunchKernelGGL(loss_tail_kernel, dim3(B), dim3(128), (size_t)(2 * T + 128) * 4, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
+}
+
+int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const float* legal, const float* q_online, const float* online_qa,
+                   const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
+                   const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step, double gamma,
+                   float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss, float* xent_sum, float* dqa,
+                   void* dheads16, int ldo, void* stream) {
+  return hsad_internal_loss_tail(heads, heads_t, ldh, legal, q_online, online_qa, block_min, n_block_min, reward, bootstrap, seq_len, weight, own_hand,
+                                 action, T, B, A, NP, multi_step, gamma, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, dheads16,
+                                 ldo, nullptr, 0, stream);
 }
 
 int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream) {
@@ -4115,9 +4156,29 @@ int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
   hipLaunchKernelGGL(sumsq_kernel, dim3(1024), dim3(256), 0, s, grad, (size_t)n, scratch);
   const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);  // torch: beta ** step
   const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
-                     (size_t)n, scratch, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15))
+    return nfail(HSAD_ERR_INVALID, "adam_step: the flat buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel<false>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, param, const_cast<float*>(grad), exp_avg, exp_avg_sq,
+                     (size_t)n, scratch, (float*)nullptr, (float*)nullptr, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
   HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+int hsad_adam_step_zero_grad(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm, float lr,
+                             float beta1, float beta2, float eps, int step, float* scratch2, float** grad_norm_sq, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !scratch2 || n < 1 || step < 1)
+    return nfail(HSAD_ERR_INVALID, "adam_step_zero_grad: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  float* slot = scratch2 + (step & 1);          // zero: cleared by the previous step's kernel (by the caller before the first step)
+  hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, s, grad, (size_t)n, slot);     // (one atomic per block: ~11 ns each on one address)
+  const double b1p = pow((double)beta1, (double)step), b2p = pow((double)beta2, (double)step);
+  const float bc1 = (float)(1.0 - b1p), bc2s = (float)sqrt(1.0 - b2p);
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15))
+    return nfail(HSAD_ERR_INVALID, "adam_step_zero_grad: the flat buffers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel<true>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, (size_t)n, slot,
+                     scratch2 + ((step & 1) ^ 1), scratch2 + 4 + step % 12, max_grad_norm, lr, beta1, beta2, eps, bc1, bc2s);
+  HIP_TRY(hipGetLastError());
+  if (grad_norm_sq) *grad_norm_sq = slot;
   return HSAD_OK;
 }
 

@@ -449,6 +449,13 @@ int hsad_colsum_acc(const void* src, int is_bf16, int M, int N, int ld, float* o
  * scratch: fp32 [1]. */
 int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
                    float lr, float beta1, float beta2, float eps, int step, float* scratch, void* stream);
+/* The same followed by optim.zero_grad() (selfplay.py:234-235) in the same two launches: `grad` is left all zero, and no memset is
+ * issued -- scratch2 is SIXTEEN floats, zeroed once by the caller; step k sums into slot k & 1 and clears the other one for step k + 1;
+ * scratch2[4 + k % 12] receives the pre-clip global norm itself (clip_grad_norm_'s return value; a ring, so that a caller may read
+ * it up to eleven steps late).
+ * *grad_norm_sq (may be NULL) = the slot that holds this step's squared pre-clip norm (valid until step k + 2's kernel clears it). */
+int hsad_adam_step_zero_grad(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm, float lr,
+                             float beta1, float beta2, float eps, int step, float* scratch2, float** grad_norm_sq, void* stream);
 /* R2D2Agent.act tail (r2d2.py:235-277): heads fp32 [N,ldh] (advantage in columns [0,A)), legal fp32 [N,A], eps fp32 [N]
  * (NULL = greedy) -> a, greedy_a int64 [N].  scratch fp32 [2 + ceil(N/256)].  Exploration draws come from a counter-based
  * hash of (seed, row, counter). */
@@ -657,6 +664,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* learner, void* stream);
 /* clip_grad_norm_ + Adam.step + operand refresh; grad_norm_sq_dev (may be NULL) receives a device pointer to the squared
  * pre-clip gradient norm */
 int hsad_r2d2_optimizer_step(hsad_r2d2_learner* learner, float beta1, float beta2, float** grad_norm_sq_dev, void* stream);
+/* device float: the pre-clip global gradient norm of the last hsad_r2d2_optimizer_step (what clip_grad_norm_ returns, selfplay.py:231);
+ * the location stays untouched for the next eleven steps */
+const float* hsad_r2d2_learner_grad_norm_dev(const hsad_r2d2_learner* L);
 int hsad_r2d2_sync_target_with_online(hsad_r2d2_learner* learner, void* stream);
 
 /* ------------------------------------------------------------------------------------------
