@@ -120,9 +120,15 @@ struct hsad_r2d2_net {
   float *bg[kMaxL], *bheads, *bias16[kMaxL];
   int32_t *perm32, *perm16;
   uint64_t version = 0;
+  // split refresh (net_refresh_split): the LSTM operands are re-derived on a side stream; whoever reads them next waits for this
+  hipEvent_t ev_refresh = nullptr;
+  bool split_pending = false;
   // acting workspace (grows with the row count)
   Buf ws;
   float* w(int i) const { return flat + off[i]; }
+  ~hsad_r2d2_net() {
+    if (ev_refresh) (void)hipEventDestroy(ev_refresh);
+  }
 };
 
 namespace {
@@ -171,43 +177,74 @@ void net_build_table(hsad_r2d2_net* n) {
   n->np = k;
 }
 
-int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
+// part: 1 = the input MLP, the heads and every bias (small), 2 = the LSTM weight matrices (forward and transposed layouts), 3 = both
+int net_refresh_part(hsad_r2d2_net* n, hipStream_t s, int part) {
   const int H = n->H;
-  n->version++;
   // every derived operand in one launch: weight jobs first, then the biases
   CK(hsad_refresh_begin());
-  CK(hsad_refresh_add_weight(n->w(n->iW1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0));
-  if (n->nfc == 2) CK(hsad_refresh_add_weight(n->w(n->iW2), H, H, H, nullptr, n->W2, H, n->with_backward ? n->W2T : nullptr, H));
-  for (int l = 0; l < n->L; ++l) {
-    const float* wih = n->w(n->iWih[l]);
-    const float* whh = n->w(n->iWhh[l]);
-    CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H));
-    CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H));
-    if (n->Wcat16[l] && !n->with_backward) {
-      CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm16, n->Wcat16[l], 2 * H, nullptr, 0));
-      CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0));
+  if (part & 1) {
+    CK(hsad_refresh_add_weight(n->w(n->iW1), H, n->F, n->F, nullptr, n->W1, n->Fp, nullptr, 0));
+    if (n->nfc == 2) CK(hsad_refresh_add_weight(n->w(n->iW2), H, H, H, nullptr, n->W2, H, n->with_backward ? n->W2T : nullptr, H));
+  }
+  if (part & 2)
+    for (int l = 0; l < n->L; ++l) {
+      const float* wih = n->w(n->iWih[l]);
+      const float* whh = n->w(n->iWhh[l]);
+      CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm32, n->Wih[l], H, n->with_backward ? n->WihT[l] : nullptr, 4 * H));
+      CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm32, n->Whh[l], H, n->with_backward ? n->WhhT[l] : nullptr, 4 * H));
+      if (n->Wcat16[l] && !n->with_backward) {
+        CK(hsad_refresh_add_weight(wih, 4 * H, H, H, n->perm16, n->Wcat16[l], 2 * H, nullptr, 0));
+        CK(hsad_refresh_add_weight(whh, 4 * H, H, H, n->perm16, n->Wcat16[l] + H, 2 * H, nullptr, 0));
+      }
     }
-  }
-  const int wi[3] = {n->iWA, n->iWV, n->iWP}, bi[3] = {n->iBA, n->iBV, n->iBP}, rows[3] = {n->A, 1, n->NP};
-  int r0 = 0;
-  for (int k = 0; k < 3; ++k) {
-    CK(hsad_refresh_add_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
-                               n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp));
-    r0 += rows[k];
-  }
-  for (int l = 0; l < n->L; ++l) {
-    const float* bih = n->w(n->iBih[l]);
-    const float* bhh = n->w(n->iBhh[l]);
-    CK(hsad_refresh_add_bias(bih, bhh, n->perm32, n->bg[l], 4 * H));
-    if (n->Wcat16[l] && !n->with_backward) CK(hsad_refresh_add_bias(bih, bhh, n->perm16, n->bias16[l], 4 * H));
-  }
-  r0 = 0;
-  for (int k = 0; k < 3; ++k) {
-    CK(hsad_refresh_add_bias(n->w(bi[k]), nullptr, nullptr, n->bheads + r0, rows[k]));
-    r0 += rows[k];
+  if (part & 1) {
+    const int wi[3] = {n->iWA, n->iWV, n->iWP}, bi[3] = {n->iBA, n->iBV, n->iBP}, rows[3] = {n->A, 1, n->NP};
+    int r0 = 0;
+    for (int k = 0; k < 3; ++k) {
+      CK(hsad_refresh_add_weight(n->w(wi[k]), rows[k], H, H, nullptr, n->Wheads + (size_t)r0 * H, H,
+                                 n->with_backward ? n->WheadsT + r0 : nullptr, n->NHp));
+      r0 += rows[k];
+    }
+    for (int l = 0; l < n->L; ++l) {
+      const float* bih = n->w(n->iBih[l]);
+      const float* bhh = n->w(n->iBhh[l]);
+      CK(hsad_refresh_add_bias(bih, bhh, n->perm32, n->bg[l], 4 * H));
+      if (n->Wcat16[l] && !n->with_backward) CK(hsad_refresh_add_bias(bih, bhh, n->perm16, n->bias16[l], 4 * H));
+    }
+    r0 = 0;
+    for (int k = 0; k < 3; ++k) {
+      CK(hsad_refresh_add_bias(n->w(bi[k]), nullptr, nullptr, n->bheads + r0, rows[k]));
+      r0 += rows[k];
+    }
   }
   CK(hsad_refresh_launch((void*)s));
   return 0;
+}
+
+// a stream about to read the net's LSTM operands: behind the side-stream half of the last split refresh
+int net_wait(hsad_r2d2_net* n, hipStream_t s) {
+  if (n->split_pending && hipStreamWaitEvent(s, n->ev_refresh, 0) != hipSuccess) return afail(HSAD_ERR_HIP, "hipStreamWaitEvent(refresh) failed");
+  return 0;
+}
+
+int net_refresh(hsad_r2d2_net* n, hipStream_t s) {
+  CK(net_wait(n, s));          // (the pending half writes the same buffers)
+  n->version++;
+  return net_refresh_part(n, s, 3);
+}
+
+// the same with the big half (LSTM matrices, ~95 % of the bytes) on `side`, ordered behind everything enqueued on `s` so far; `s` only
+// carries the small half, so the next update's input layer starts ~13 us earlier and the LSTM half runs next to it
+int net_refresh_split(hsad_r2d2_net* n, hipStream_t s, hipStream_t side, hipEvent_t ev_tmp) {
+  CK(net_wait(n, s));
+  if (!n->ev_refresh && hipEventCreateWithFlags(&n->ev_refresh, hipEventDisableTiming) != hipSuccess) return afail(HSAD_ERR_HIP, "hipEventCreate failed");
+  n->version++;
+  HIP_TRY(hipEventRecord(ev_tmp, s));
+  HIP_TRY(hipStreamWaitEvent(side, ev_tmp, 0));
+  CK(net_refresh_part(n, side, 2));
+  HIP_TRY(hipEventRecord(n->ev_refresh, side));
+  n->split_pending = true;
+  return net_refresh_part(n, s, 1);
 }
 
 __global__ void add_bf16_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out, size_t n) {
@@ -437,6 +474,8 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
                   const float* legal_move, const float* eps, const float* h0, const float* c0, const void* h0_bf16, uint64_t seed, uint64_t counter,
                   int64_t* a, int64_t* greedy_a, float* h_out, float* c_out, void* h_out_bf16, float* q_online_a,
                   float* q_target_greedy, void* stream) {
+  if (online) CK(net_wait(online, (hipStream_t)stream));
+  if (target) CK(net_wait(target, (hipStream_t)stream));
   if (!online || (!priv_s && !priv_s_bf16) || !legal_move || !h0 || !c0 || !a || !greedy_a || !h_out || !c_out || N < 1)
     return afail(HSAD_ERR_INVALID, "r2d2_act: null argument");
   if (q_target_greedy && (!q_online_a || !target))
@@ -507,6 +546,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
 // (which only needs the online half's actions) before it and run the two side by side (actor.DeviceActor does)
 int hsad_r2d2_target_q(hsad_r2d2_net* target, int N, const float* priv_s, const void* priv_s_bf16, const float* legal_move,
                        const float* h0, const float* c0, const void* h0_bf16, const int64_t* greedy_a, float* q_target_greedy, void* stream) {
+  if (target) CK(net_wait(target, (hipStream_t)stream));
   if (!target || (!priv_s && !priv_s_bf16) || !legal_move || !h0 || !c0 || !greedy_a || !q_target_greedy || N < 1)
     return afail(HSAD_ERR_INVALID, "r2d2_target_q: null argument");
   hsad_r2d2_net* n = target;
@@ -563,6 +603,7 @@ static int net_q_of(hsad_r2d2_net* n, int N, const float* priv_s, const float* l
 // Q_net(s, action) [N] for one step from the carried hidden state (one network pass; the pieces compute_priority is made of)
 int hsad_r2d2_q_of(hsad_r2d2_net* net, int N, const float* priv_s, const float* legal_move, const int64_t* action, const float* h0,
                    const float* c0, float* qa, void* stream) {
+  if (net) CK(net_wait(net, (hipStream_t)stream));
   if (!net || !priv_s || !legal_move || !action || !h0 || !c0 || !qa || N < 1) return afail(HSAD_ERR_INVALID, "r2d2_q_of: null argument");
   return net_q_of(net, N, priv_s, legal_move, action, h0, c0, qa, nullptr, (hipStream_t)stream);
 }
@@ -575,6 +616,8 @@ int hsad_r2d2_compute_priority(hsad_r2d2_net* online, hsad_r2d2_net* target, int
                                const float* h0, const float* c0, const float* next_h0, const float* next_c0, const float* reward,
                                const float* bootstrap, int multi_step, double gamma, const int64_t* next_greedy_a, float* priority,
                                void* stream) {
+  if (online) CK(net_wait(online, (hipStream_t)stream));
+  if (target) CK(net_wait(target, (hipStream_t)stream));
   if (!online || !target || !priv_s || !legal_move || !a || !next_priv_s || !next_legal_move || !h0 || !c0 || !next_h0 || !next_c0 ||
       !reward || !bootstrap || !priority || N < 1 || num_player < 1 || N % num_player)
     return afail(HSAD_ERR_INVALID, "r2d2_compute_priority: bad arguments");
@@ -623,6 +666,8 @@ struct hsad_r2d2_learner {
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
+  bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
+                              // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides
   bool gflat_zero = true;     // the gradient buffer is all zero (creation; optimizer_step clears it behind Adam, as optim.zero_grad() does)
   unsigned* fsync[3][2];      // ping-pong counter blocks of the fused launches: [log2(recurrences per launch)][flip]
   int fflip[3] = {0, 0, 0};
@@ -899,6 +944,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->fused_bwd = (fused_fwd & 1) != 0 && !(fused_fwd & 2);      // bit 1: keep the chunk-pipelined BPTT with its dO GEMMs (A/B)
   const int bc = (fused_fwd >> 8) & 0xff;                       // bits 8-15: time chunks of the fused BPTT (0 = keep)
   if (bc >= 1 && bc <= 8) L->bchunks = bc;
+  L->split_refresh = (fused_fwd & 4) != 0;                      // bit 2: LSTM operands re-derived on the side stream (A/B; slower)
   return 0;
 }
 /* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
@@ -965,6 +1011,9 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   if (nfc == 2)
     CK(hsad_gemm_nt_bf16_pair(L->x1[0], L->x1[1], H, nets[0]->W2, nets[1]->W2, H, M, H, H, nets[0]->w(nets[0]->iB2), nets[1]->w(nets[1]->iB2),
                               nullptr, nullptr, 0, L->x2[0], L->x2[1], H, 1, stream));
+  // (the LSTM operands may still be in the side-stream half of the last optimizer step's refresh: the input layer above did not need them)
+  CK(net_wait(nets[0], s));
+  CK(net_wait(nets[1], s));
   const FusePlan fp = fuse_plan(L);
   L->fwd_frag = fp.nets > 0;
   if (fp.nets) {
@@ -1099,6 +1148,7 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
 // BPTT of the last loss_fwd(want_grad = 1) of mean_b(weight_b * loss_b) into the learner's flat gradient (order = the net's
 // parameter vector).  The batch tensors given to loss_fwd must still be alive.
 int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
+  if (L) CK(net_wait(L->on, (hipStream_t)stream));
   if (!L || !L->have_fwd) return afail(HSAD_ERR_STATE, "r2d2_loss_bwd: call loss_fwd(want_grad = 1) first");
   L->have_fwd = false;
   hsad_r2d2_net* on = L->on;
@@ -1327,6 +1377,7 @@ int hsad_r2d2_optimizer_step(hsad_r2d2_learner* L, float beta1, float beta2, flo
                               L->osc, &slot, stream));
   L->gflat_zero = true;
   if (grad_norm_sq_dev) *grad_norm_sq_dev = slot;
+  if (L->side && L->split_refresh) return net_refresh_split(L->on, (hipStream_t)stream, L->side, L->ev_b);
   return net_refresh(L->on, (hipStream_t)stream);
 }
 

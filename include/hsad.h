@@ -647,6 +647,9 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *              dO of the lower layer inside its recurrence) when the shape allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s
  *              workgroups fit an XCD); 0: the chunk-pipelined schedule of rounds 1-2 (stand-alone projection / dO GEMMs between chunk launches)
  *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
+ *   bit 2      hsad_r2d2_optimizer_step re-derives the LSTM matrices (95 % of the operand bytes) on the learner's side stream, next to the
+ *              following update's input layer; every entry point that reads a net's LSTM operands waits for that half first (an event, no
+ *              host synchronisation).  Off by default: measured 1.521 against 1.504 ms per update with everything in line
  *   bits 8-15  time chunks of the fused BPTT, 1..8 (the weight gradients are added up per chunk); 0 keeps the current setting */
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
