@@ -650,6 +650,13 @@ int hsad_r2d2_compute_priority(hsad_r2d2_net* online, hsad_r2d2_net* target, int
 // =====================================================================================================================
 // Learner: loss forward (online + target net), BPTT, clip + Adam  (pyhanabi/selfplay.py:208-244, r2d2.py:383-499)
 // =====================================================================================================================
+// events that only order device work between the learner's two streams: device-scope release (developer switch HSAD_EVENT_SYSTEM=1: the
+// runtime's default)
+static unsigned learner_event_flags() {
+  static const unsigned f = hipEventDisableTiming | ((getenv("HSAD_EVENT_SYSTEM") && atoi(getenv("HSAD_EVENT_SYSTEM"))) ? 0u : (unsigned)hipEventReleaseToDevice);
+  return f;
+}
+
 struct hsad_r2d2_learner {
   hsad_r2d2_net *on, *tg;
   int T, B, M, multi_step, n_cu, step_count = 0;
@@ -892,14 +899,14 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   }
   for (int i = 0; i < 8; ++i) {
     L->ev_ck[i] = nullptr;
-    if (hipEventCreateWithFlags(&L->ev_ck[i], hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&L->ev_ck[i], learner_event_flags()) != hipSuccess) {
       delete L;
       return afail(HSAD_ERR_HIP, "r2d2_learner_create: event creation failed");
     }
   }
-  if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&L->ev_b, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&L->ev_d, hipEventDisableTiming) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, learner_event_flags()) != hipSuccess ||
+      hipEventCreateWithFlags(&L->ev_b, learner_event_flags()) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, learner_event_flags()) != hipSuccess ||
+      hipEventCreateWithFlags(&L->ev_d, learner_event_flags()) != hipSuccess) {
     delete L;
     return afail(HSAD_ERR_HIP, "r2d2_learner_create: stream / event creation failed");
   }
