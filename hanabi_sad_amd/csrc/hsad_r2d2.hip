@@ -3871,6 +3871,26 @@ int hsad_lstm_cell_timing_read(double* avg_ms, double* avg_flop, int32_t* launch
   return HSAD_OK;
 }
 
+// which kernel hsad_lstm_cell_fused launches: environment (HSAD_CELL_TILE, HSAD_CELL_PP) at first use, or hsad_lstm_cell_set_variant
+static struct CellVariant {
+  int tile_ = -1, pp_ = -1;
+  int tile() {
+    if (tile_ < 0) tile_ = getenv("HSAD_CELL_TILE") ? atoi(getenv("HSAD_CELL_TILE")) : 0;
+    return tile_;
+  }
+  int pp() {
+    if (pp_ < 0) pp_ = getenv("HSAD_CELL_PP") ? atoi(getenv("HSAD_CELL_PP")) : 1;
+    return pp_;
+  }
+} g_cell_variant;
+
+int hsad_lstm_cell_set_variant(int tile, int pp) {
+  if ((tile != 0 && tile != 128 && tile != 256) || pp < 0) return nfail(HSAD_ERR_INVALID, "lstm_cell_set_variant: tile 0 | 128 | 256, pp >= 0");
+  g_cell_variant.tile_ = tile;
+  g_cell_variant.pp_ = pp;
+  return HSAD_OK;
+}
+
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream) {
@@ -3896,7 +3916,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     HIP_TRY(hipEventCreate(&t_e1));
     HIP_TRY(hipEventRecord(t_e0, (hipStream_t)stream));
   }
-  static const int force_tile = getenv("HSAD_CELL_TILE") ? atoi(getenv("HSAD_CELL_TILE")) : 0;   // developer switch: 128 | 256
+  const int force_tile = g_cell_variant.tile();   // developer switch: 128 | 256
   const bool big = force_tile ? force_tile == 256 : (Bn >= 4096 && (4 * H) % 256 == 0);
   if (big && (4 * H) % 256 == 0) {
     const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
@@ -3904,7 +3924,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     long grid = std::min<long>(tiles, (long)n_cu);
     if (grid >= 64) grid &= ~7L;
     // developer switch HSAD_CELL_PP: 0 the one-barrier k loop, 1 (default) the phase-interleaved one; 11 / 12 / 14 / 19: its ablations
-    static const int pp = getenv("HSAD_CELL_PP") ? atoi(getenv("HSAD_CELL_PP")) : 1;
+    const int pp = g_cell_variant.pp();
     if (pp && Bn % 256 == 0) {
       const bool st = c_out || h_out32;
       auto kp = st ? lstm_cell_pp_kernel<true> : lstm_cell_pp_kernel<false>;

@@ -351,6 +351,10 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream);
+/* Developer switch (tests, A/B tools): which kernel hsad_lstm_cell_fused launches.  tile: 0 by size (256 x 256 tiles from 4,096 rows on),
+ * 128 | 256 forced; pp: 1 (default) the phase-interleaved k loop (lstm_cell_pp_kernel; rows % 256 == 0), 0 the one-barrier k loop,
+ * 11 / 12 / 14 / 19 timing ablations of the former (garbage results).  All real variants give identical bits. */
+int hsad_lstm_cell_set_variant(int tile, int pp);
 /* testing: force_cross_xcd != 0 makes every persistent recurrence use the cross-XCD hand-off protocol even when its
  * workgroups are co-located (the default, 0, picks per group at start-up); results must not depend on it */
 int hsad_lstm_set_exchange_mode(int force_cross_xcd);

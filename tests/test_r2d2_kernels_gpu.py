@@ -424,3 +424,91 @@ def test_gemm_pair_launch_equals_two_launches(M, N, K, out):
     ref = torch.empty(M, N, dtype=dt, device=DEV)
     gemm_nt(A[0], Bm[1], M, N, K, bias=bias[1], **({"out16": ref, "relu": True} if relu else {"out32": ref}))
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], ref)
+
+
+@pytest.mark.parametrize("N,H,state", [(4096, 512, True), (8192, 256, True), (4096, 512, False), (12288, 512, True)])
+def test_fused_cell_kernel_variants_give_identical_bits(N, H, state):
+    """hsad_lstm_cell_fused launches one of three kernels: 128 x 128 tiles, 256 x 256 tiles with one barrier per k step, 256 x 256 tiles
+    with the phase-interleaved k loop (half-tile LDS-DMA ring, counted vmcnt, two wave rows a barrier apart; the default from 4,096 rows
+    on when rows % 256 == 0).  Same k order per accumulator and the same epilogue arithmetic: all outputs must agree to the bit, with
+    and without the fp32 state outputs (the target pass of an acting step only takes the bf16 layer output), and match fp32 torch
+    on the bf16-rounded operands."""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    g = torch.Generator(device="cpu").manual_seed(N + H)
+    x = (torch.randn(N, H, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    h16 = (torch.randn(N, H, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    Wn = torch.randn(4 * H, 2 * H, generator=g) / (2 * H) ** 0.5            # natural gate order [i f g o] x H, columns [W_ih | W_hh]
+    b = (torch.randn(4 * H, generator=g) * 0.1)
+    c0 = (torch.randn(N, H, generator=g) * 0.5).to(DEV)
+    # gate16 order: output column 64 q + 16 gate + u  <->  natural row gate * H + 16 q + u
+    idx = torch.tensor([(c % 64) // 16 * H + (c // 64) * 16 + c % 16 for c in range(4 * H)])
+    W16 = Wn[idx].to(DEV).to(torch.bfloat16).contiguous()
+    b16 = b[idx].to(DEV).contiguous()
+    outs = {}
+    try:
+        for name, (tile, pp) in {"pp": (256, 1), "one-barrier": (256, 0), "128": (128, 0)}.items():
+            _lib.check(lib.hsad_lstm_cell_set_variant(tile, pp))
+            c1 = torch.full((N, H), 7.0, device=DEV)
+            h1 = torch.full((N, H), 7.0, device=DEV)
+            o16 = torch.full((N, H), 7.0, device=DEV, dtype=torch.bfloat16)
+            _lib.check(lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), H, h16.data_ptr(), W16.data_ptr(), b16.data_ptr(), c0.data_ptr(),
+                                                c1.data_ptr() if state else None, h1.data_ptr() if state else None, o16.data_ptr(), _s(torch.device(DEV))))
+            torch.cuda.synchronize()
+            outs[name] = (c1, h1, o16)
+    finally:
+        _lib.check(lib.hsad_lstm_cell_set_variant(0, 1))
+    for name in ("one-barrier", "128"):
+        for a, bb in zip(outs["pp"], outs[name]):
+            assert torch.equal(a, bb), name
+    c1, h1, o16 = outs["pp"]
+    gates = torch.cat([x.float(), h16.float()], 1) @ Wn.to(DEV).to(torch.bfloat16).float().t() + b.to(DEV)
+    i, f, gg, o = gates.chunk(4, 1)
+    c = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    if state:
+        assert torch.allclose(c1, c, atol=2e-3, rtol=2e-3) and torch.allclose(h1, h, atol=2e-3, rtol=2e-3)
+        assert torch.equal(o16, h1.to(torch.bfloat16))
+    else:
+        assert float(c1.min()) == 7.0 and float(h1.min()) == 7.0            # untouched
+    assert torch.allclose(o16.float(), h, atol=1e-2, rtol=1e-2)
+
+
+def test_adam_step_zero_grad_matches_torch_and_leaves_a_zero_gradient():
+    """hsad_adam_step_zero_grad = clip_grad_norm_ + Adam.step + zero_grad (selfplay.py:231-235) in two launches: parameters and the
+    returned norm against torch over several steps (odd length: the scalar tail of the 16-byte kernel), the gradient buffer all zero
+    afterwards, the norm ring readable late"""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    n = 1_000_003
+    g = torch.Generator(device="cpu").manual_seed(5)
+    buf = torch.zeros(3 * 1_000_004 + 16, device=DEV)                       # [param | m | v | scratch], each 16-byte aligned
+    p0 = torch.randn(n, generator=g).to(DEV)
+    flat = p0.clone()
+    m, v, scratch = buf[:n], buf[1_000_004:1_000_004 + n], buf[3 * 1_000_004:]
+    grad = torch.empty(n, device=DEV)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=1e-3, eps=1.5e-5)
+    norms = []
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g).to(DEV) * (0.02 if step != 3 else 1e-5)     # step 3: below the clip threshold
+        grad.copy_(gr)
+        pt.grad = gr.clone()
+        want = torch.nn.utils.clip_grad_norm_([pt], 5.0)
+        opt.step()
+        slot = C.c_void_p()
+        _lib.check(lib.hsad_adam_step_zero_grad(flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, 5.0, 1e-3, 0.9, 0.999, 1.5e-5,
+                                                step, scratch.data_ptr(), C.byref(slot), _s(torch.device(DEV))))
+        torch.cuda.synchronize()
+        assert slot.value == scratch.data_ptr() + 4 * (step & 1)
+        norms.append(float(want))
+        assert abs(float(scratch[step & 1]) ** 0.5 - float(want)) < 1e-4 * float(want)
+        assert float(scratch[(step & 1) ^ 1]) == 0.0                                  # cleared for the next step
+        assert float(grad.abs().max()) == 0.0                                         # optim.zero_grad()
+        assert torch.allclose(flat, pt.data, rtol=1e-5, atol=1e-7)
+    for step in range(1, 6):                                                          # the ring: every step's norm is still there
+        assert abs(float(scratch[4 + step % 12]) - norms[step - 1]) < 1e-4 * norms[step - 1]
