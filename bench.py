@@ -287,8 +287,8 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "loop_body": "hsad_actor_step (C ABI, one call per step)" if tr.actor.c_actor is not None else "python (actor.DeviceActor.step)",
            "host_issue_us_per_step": host_issue_us,
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
-           "roofline": {"bound": "mfma", "kernel": "lstm_cell_gemm256_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d; "
-                                                   "4 launches per step)" % (games * 2, 2048, 1024),
+           "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
+                                                   "phase-interleaved k loop; 4 launches per step)" % (games * 2, 2048, 1024),
                         "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": None,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
                         "share_of_step": 4 * ms.value / (dt * 1e3)},

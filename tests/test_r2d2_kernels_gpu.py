@@ -512,3 +512,40 @@ def test_adam_step_zero_grad_matches_torch_and_leaves_a_zero_gradient():
         assert torch.allclose(flat, pt.data, rtol=1e-5, atol=1e-7)
     for step in range(1, 6):                                                          # the ring: every step's norm is still there
         assert abs(float(scratch[4 + step % 12]) - norms[step - 1]) < 1e-4 * norms[step - 1]
+
+
+def test_phase_interleaved_cell_kernel_race_screen():
+    """the phase-interleaved k loop orders its LDS-DMA ring by barrier count and counted vmcnt only; a misplaced wait would pass a single
+    comparison whenever the DMA happens to land first.  60 launches on fresh operands (different values, so a stale half tile cannot
+    coincide with the right one), each compared bit for bit with the one-barrier kernel; every second one with other work on a second
+    stream competing for the memory system."""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    N, H = 8192, 512
+    dev = torch.device(DEV)
+    g = torch.Generator(device=DEV).manual_seed(99)
+    W16 = (torch.randn(4 * H, 2 * H, generator=g, device=DEV) / 32).to(torch.bfloat16)
+    b16 = torch.randn(4 * H, generator=g, device=DEV) * 0.1
+    side, junk = torch.cuda.Stream(dev), torch.empty(64 << 20, device=DEV)
+    try:
+        for it in range(60):
+            x = (torch.randn(N, H, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+            h16 = (torch.randn(N, H, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+            c0 = torch.randn(N, H, generator=g, device=DEV) * 0.5
+            res = []
+            for pp in (1, 0):
+                _lib.check(lib.hsad_lstm_cell_set_variant(256, pp))
+                c1, h1, o16 = torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV, dtype=torch.bfloat16)
+                if pp and it % 2:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        junk.add_(1.0)
+                _lib.check(lib.hsad_lstm_cell_fused(N, H, H, x.data_ptr(), H, h16.data_ptr(), W16.data_ptr(), b16.data_ptr(), c0.data_ptr(),
+                                                    c1.data_ptr(), h1.data_ptr(), o16.data_ptr(), _s(dev)))
+                res.append((c1, h1, o16))
+            torch.cuda.synchronize()
+            assert all(torch.equal(a, bb) for a, bb in zip(*res)), it
+    finally:
+        _lib.check(lib.hsad_lstm_cell_set_variant(0, 1))
