@@ -143,6 +143,7 @@ class HanabiThreadLoop:
         self.vec_envs = [vec_env]
         self.eval_mode = bool(eval_mode)
         self.master, self.impl, self.env, self.done = None, None, None, False
+        self._train_steps = 0
         self._built = False
         if not vec_env.envs:
             raise RuntimeError("HanabiThreadLoop over an empty HanabiVecEnv")
@@ -210,6 +211,9 @@ class HanabiThreadLoop:
             replay = a0[0].replay.bind_schema(fields, a0[0].seq_len, run.device)
             self.impl = DeviceActor(self.env, self.agent, replay, a0[0].multi_step, a0[0].gamma, a0[0].eta, a0[0].seq_len,
                                     vdn=self.vdn)
+            for group, v in zip(self.per_thread, self._thread_sizes()):
+                for a in group:
+                    a._loop, a._per_step = self, v
 
     def step(self):
         if self.master is not None:
@@ -218,10 +222,8 @@ class HanabiThreadLoop:
             self._build()
         if not self.eval_mode:
             self.impl.step()
-            for group, v in zip(self.per_thread, self._thread_sizes()):
-                for a in group:                     # R2D2Actor::numAct_ += num_envs per act() (r2d2_actor.h:98)
-                    a._num_act += v
-            return
+            self._train_steps += 1                  # R2D2Actor::numAct_ += num_envs per act() (r2d2_actor.h:98): R2D2Actor.num_act() multiplies
+            return                                  # (no per-actor Python work in the loop: 160 actors cost 25 us per step)
         if self.done:
             return
         env, G, P = self.env, self.env.G, self.env.P

@@ -18,6 +18,19 @@ from .replay import DeviceReplay, aggregate_priority as _aggregate_priority
 # run one step on mixed weights)
 _MODEL_LOCK = threading.RLock()
 
+# The Context threads of a device issue on ONE stream of their own, so that the driver's thread (sampling, the learner's update on its
+# current stream) and the rollout overlap on the GPU -- e.g. acting steps next to the learner's BPTT, which occupies half of the XCDs.
+# Replay and writer calls from either side are ordered by the library's stream fence; weight updates (BatchRunner.update_model) are
+# enqueued ON this stream between two rollout steps; pause() / resume() / terminate() join the two streams.
+_ACTOR_STREAMS = {}
+
+
+def _actor_stream(device):
+    key = str(torch.device(device))
+    if key not in _ACTOR_STREAMS:
+        _ACTOR_STREAMS[key] = torch.cuda.Stream(torch.device(device))
+    return _ACTOR_STREAMS[key]
+
 
 class RNNTransition:
     """rela.RNNTransition fields (rela/pybind.cc:25-32): obs/action dicts of [T,B,*] tensors, reward, terminal,
@@ -218,10 +231,28 @@ class BatchRunner:
                 skip = bool(getattr(getattr(py_model, "online_net", None), "skip_connect", False))
                 self.online, self.target = CNet(on, self.device, skip_connect=skip), CNet(tg, self.device, skip_connect=skip)    # library-owned nets
                 return
+            st = _ACTOR_STREAMS.get(str(torch.device(self.device)))
+            if st is None:
+                for net, sd in ((self.online, on), (self.target, tg)):
+                    for k, v in sd.items():
+                        net.w[k].copy_(v)
+                    net.refresh()
+                return
+            # A rollout stream exists: the acting nets are read there.  Snapshot the new weights on the caller's stream (the learner may go
+            # on changing them), then copy + re-derive the kernel operands ON the rollout stream -- the lock puts that between two steps.
+            cur = torch.cuda.current_stream(st.device)
+            snaps = []
             for net, sd in ((self.online, on), (self.target, tg)):
-                for k, v in sd.items():
-                    net.w[k].copy_(v)
-                net.refresh()
+                snap = {k: v.detach().to(net.w[k].device, torch.float32, copy=True) for k, v in sd.items()}
+                for t in snap.values():
+                    t.record_stream(st)
+                snaps.append((net, snap))
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                for net, snap in snaps:
+                    for k, v in snap.items():
+                        net.w[k].copy_(v)
+                    net.refresh()
 
     def start(self):
         pass
@@ -255,7 +286,8 @@ class R2D2Actor:
                             "num_player, replay)")
 
     def num_act(self):
-        return self._num_act
+        lp = getattr(self, "_loop", None)          # a training loop counts its steps; this actor's share is num_envs per step
+        return self._num_act + (lp._train_steps * self._per_step if lp is not None else 0)
 
 
 class Context:
@@ -265,6 +297,7 @@ class Context:
 
     def __init__(self):
         self.loops, self._thread, self._paused, self._stop, self._error = [], None, False, False, None
+        self._stream = None        # the rollout stream of start() (see _ACTOR_STREAMS); step() from the caller's thread uses the caller's
         # pause protocol: every pause() takes a ticket; the loop thread acknowledges the ticket it has SEEN while parked between two
         # steps, so a pause() can only return on an acknowledgement of its own request (an Event could still be set from the
         # previous pause when a resume / pause pair follows within the thread's 1 ms nap)
@@ -292,7 +325,11 @@ class Context:
                         break
                     if not (hasattr(lp, "finished") and lp.finished()):
                         with _MODEL_LOCK:
-                            lp.step()
+                            if self._stream is not None:
+                                with torch.cuda.stream(self._stream):
+                                    lp.step()
+                            else:
+                                lp.step()
                         busy = True
                 if not busy and not self._paused:
                     break
@@ -323,9 +360,30 @@ class Context:
             else:
                 last[key] = lp
 
+    def _device(self):
+        for lp in self.loops:
+            for v in getattr(lp, "vec_envs", []):
+                if v.envs:
+                    return v.envs[0].device
+        return None
+
+    def _join_streams(self, to_actor):
+        """device-side order between the caller's current stream and the rollout stream (no host synchronisation)"""
+        if self._stream is None:
+            return
+        cur = torch.cuda.current_stream(self._stream.device)
+        if to_actor:
+            self._stream.wait_stream(cur)
+        else:
+            cur.wait_stream(self._stream)
+
     def start(self):
         import threading
         self._coalesce()
+        dev = self._device()
+        if self._thread is None and dev is not None and torch.device(dev).type == "cuda":
+            self._stream = _actor_stream(dev)
+            self._join_streams(True)          # everything the driver set up so far (envs, nets, replay) precedes the first step
         if self._thread is None:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
@@ -348,10 +406,12 @@ class Context:
             self._paused = True
             if self._thread is not None and self._thread.is_alive():
                 self._cv.wait_for(lambda: self._done or self._parked_ticket == ticket)
+        self._join_streams(False)             # what the caller reads next (env state, scores, replay) is behind the last rollout step
         self._check()
 
     def resume(self):
         self._check()
+        self._join_streams(True)
         with self._cv:
             self._paused = False
 
@@ -359,6 +419,7 @@ class Context:
         self._stop = True
         if self._thread is not None:
             self._thread.join()
+        self._join_streams(False)
         self._check()
 
     def terminated(self):

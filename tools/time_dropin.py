@@ -7,7 +7,9 @@ num_thread x num_game_per_thread = 64 x 256).
     python tools/time_dropin.py [games_per_thread] [threads] [seconds]
 
 Prints: acting rate of the Context thread (acts / s = games x players x steps / s, utils.Tachometer's unit, pyhanabi/utils.py:229-236)
-with the trainer idle, and with the trainer sampling / updating priorities concurrently; then the native loop's rate."""
+with the trainer idle, and with the real learner loop on the driver's thread (its own stream: the rollout issues on the Context's); then
+the native loop's rate.  Compare the Speed line with the one `python -m hanabi_sad_amd.selfplay` prints for the same game count (rollout
+and update interleaved on one stream)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -67,25 +69,57 @@ n0, t0 = num_act(), time.perf_counter()
 time.sleep(SEC)
 n1, t1 = num_act(), time.perf_counter()
 idle_rate = (n1 - n0) / (t1 - t0)
-# the trainer's side of selfplay.py:208-244 next to the running Context: sample -> (loss) -> update_priority, model sync every 10th
-it = 0
-n0, t0 = num_act(), time.perf_counter()
-while time.perf_counter() - t0 < SEC:
+# the trainer's side of selfplay.py:208-244 next to the running Context, on the driver's thread and stream: sample -> loss -> backward ->
+# clip + Adam -> update_priority; actor model sync every 10 updates, target sync every 2,500 (the reference's defaults)
+from hanabi_sad_amd.composite import CompositeLearner
+learner = CompositeLearner(W, W, NSTEP, GAMMA, device=DEV, T=T, rows=128)
+
+
+class LearnerAgent:
+    def state_dict(self):
+        d = {"online_net." + k: v for k, v in learner.online.w.items()}
+        d.update({"target_net." + k: v for k, v in learner.target.w.items()})
+        return d
+
+
+def one_update(u):
+    if u % 2500 == 0:
+        learner.sync_target_with_online()
+    if u % 10 == 0:
+        runner.update_model(LearnerAgent())
     batch, weight = replay.sample(128, DEV)
-    replay.update_priority(torch.rand(128, device=DEV))
-    it += 1
-    if it % 10 == 0:
-        runner.update_model(Agent(W))
-torch.cuda.synchronize()
-n1, t1 = num_act(), time.perf_counter()
-busy_rate, sample_rate = (n1 - n0) / (t1 - t0), it / (t1 - t0)
+    b = {"priv_s": batch.obs["priv_s"], "legal_move": batch.obs["legal_move"], "a": batch.action["a"], "reward": batch.reward,
+         "bootstrap": batch.bootstrap, "seq_len": batch.seq_len, "own_hand": batch.obs["own_hand"]}
+    loss, prio = learner.loss(b, weight, 0.0)                     # priority [T, B] per step (r2d2.py:488-499)
+    learner.optimizer_step()
+    replay.update_priority(rela.aggregate_priority(prio, batch.seq_len, ETA))     # selfplay.py:236-240
+
+
+results = []
+for label, stream in (("default-priority stream", torch.cuda.Stream(DEV)), ("high-priority stream   ", torch.cuda.Stream(DEV, priority=-1))):
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):
+        for u in range(20):
+            one_update(u + 1)
+        torch.cuda.synchronize()
+        n0, t0, it = num_act(), time.perf_counter(), 0
+        while time.perf_counter() - t0 < SEC:
+            for _ in range(10):
+                it += 1
+                one_update(it)
+        torch.cuda.synchronize()
+        n1, t1 = num_act(), time.perf_counter()
+    torch.cuda.current_stream().wait_stream(stream)
+    results.append((label, it * 128 / (t1 - t0), (n1 - n0) / (t1 - t0), replay.size()))
+learner.check_sync()
 ctx.pause()
 ctx.terminate()
 print("drop-in API (hanalearn / rela mirrors): %d threads x %d games = %d games built in %.2f s, merged into %d batched loop(s)"
       % (NT, GPT, G, t_build, sum(1 for l in loops if l.master is None)))
 print("  Context thread alone        : %.2f M acts/s  (%.3f ms per step of all games)" % (idle_rate / 1e6, G * P / idle_rate * 1e3))
-print("  + trainer sample/update loop: %.2f M acts/s  with %.0f sample+update_priority iterations/s and update_model every 10th" % (busy_rate / 1e6, sample_rate))
-del ctx, loops, runner, replay
+for label, train_rate, busy_rate, size in results:
+    print("  + learner on the driver thread, %s: Speed: train: %.1f, act: %.1f, buffer_size: %d   (sequences/s, acts/s)" % (label, train_rate, busy_rate, size))
+del ctx, loops, runner, replay, learner
 torch.cuda.empty_cache()
 args = parse_args(["--num_game", str(G), "--replay_buffer_size", "65536", "--sad", "1"])
 tr = Trainer(args, DEV)
