@@ -673,6 +673,9 @@ struct hsad_r2d2_learner {
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
+  int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
+  bool split_bptt = false;    // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
+  bool fb_split = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
                               // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides
   bool gflat_zero = true;     // the gradient buffer is all zero (creation; optimizer_step clears it behind Adam, as optim.zero_grad() does)
@@ -690,7 +693,7 @@ struct hsad_r2d2_learner {
   float *heads, *heads_t, *q, *qa, *tqa, *qa_s, *tqa_s, *err, *dqa, *dqa_r, *w_r, *xs, *qscratch;
   int64_t* greedy;
   // backward
-  bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL];
+  bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL], *xout_b = nullptr;
   int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
   float *dO[kMaxL], *dc[kMaxL], *wgrad_ws, *wgrad_ws2;
   bf16_t* dGT2;           // second transposed-gradient operand: layer 0's weight gradients on the main stream next to layer 1's on the side stream
@@ -818,6 +821,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     want(&L->hpT[l], pipe0 ? 256 : H * Mp * 2);
     want(&L->xchg_b[l], pipe0 ? xb * 2 : 256);
   }
+  want(&L->xout_b, pipe0 ? xb * 2 : 256);      // second hand-off buffer of the top layer (split placement of the fused BPTT)
   want(&L->dx1, M * H * 2);
   want(&L->x1T, H * Mp * 2);
   if (nfc == 2) {
@@ -870,7 +874,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     L->fsync_words[k] = ((size_t)1 << k) * nrb * ((size_t)T + 2) + 4;
     fw += 2 * L->fsync_words[k];
   }
-  L->fbsync_words = (size_t)2 * nrb * ((size_t)T + 2) + 4;
+  L->fbsync_words = (size_t)4 * nrb * ((size_t)T + 2) + 4;      // (twice the two recurrences': the split placement's second counter set)
   fw += 2 * L->fbsync_words;
   if (L->sync_buf.need((sw + s1 + fw) * 4)) {
     delete L;
@@ -952,6 +956,8 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   const int bc = (fused_fwd >> 8) & 0xff;                       // bits 8-15: time chunks of the fused BPTT (0 = keep)
   if (bc >= 1 && bc <= 8) L->bchunks = bc;
   L->split_refresh = (fused_fwd & 4) != 0;                      // bit 2: LSTM operands re-derived on the side stream (A/B; slower)
+  L->split_bptt = (fused_fwd & 8) != 0;                         // bit 3: split placement of the fused BPTT
+  L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   return 0;
 }
 /* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
@@ -977,7 +983,7 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
   if (L->fb_tc)
     for (int f = 0; f < 2; ++f) {
       unsigned v = 0;
-      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)2 * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? 4 : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
       *timed_out |= (int32_t)v;
     }
   {
@@ -1231,25 +1237,46 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
   std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;
   bool defer_l0 = false;
+  int input_done_above = 0;          // steps >= this have their input-layer backward done on the side stream (0 = none)
   const bool fbwd = pipe && L->fused_bwd && L->fwd_frag && B % 32 == 0 && 2 * (H / 32) * ((nrb_of(B) + 7) / 8) <= L->n_cu / 8 && nbc <= 8;
   if (fbwd) {
     // Both layers of a time chunk in ONE persistent launch (hsad_lstm_backward_fused): layer 0 runs a step behind layer 1 and computes
     // its dO = dG1 W_ih1 inside the recurrence.  The chunk's weight gradients (contraction over its T/nbc * B rows, added up over the
     // chunks) run on the side stream next to the following chunk's launch -- the launch occupies 4 of the 8 XCDs.
-    const int Tc = T / nbc;
-    const size_t Mc = (size_t)Tc * B;
+    // chunk c = steps [cut[c], cut[c + 1]); equal chunks, or (set_fused bits 16-23) a long chunk [tail, T) first and the short head [0, tail)
+    // last: the long chunk's weight gradients hide behind the head's recurrence and only the head's (and the input layer's) are left for
+    // the tail of the update
+    int cut[9];
+    const int tail = (L->btail > 0 && L->btail < T) ? L->btail : 0;
+    if (tail) nbc = 2;
+    for (int c = 0; c <= nbc; ++c) cut[c] = tail ? (c == 0 ? 0 : c == 1 ? tail : T) : c * (T / nbc);
+    int TL = 0;
+    for (int c = 0; c < nbc; ++c) TL = std::max(TL, cut[c + 1] - cut[c]);
     if (!L->dc01_zero) HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
     L->dc01_zero = false;
     chunk_wgrad = [=](int l, int c, void* st, bf16_t* dGT, float* wsp) -> int {
-      const size_t m0 = (size_t)c * Mc;
+      const size_t m0 = (size_t)cut[c] * B, Mc = (size_t)(cut[c + 1] - cut[c]) * B;
       CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
       const bf16_t* inT = l ? hs_x[l - 1] + m0 : xinT + m0;
       CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, inT, l ? ldh : Mp, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWih[l]], H, on->perm32, st));
       CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, hs_d[l] + m0, ldh, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWhh[l]], H, on->perm32, st));
       return 0;
     };
+    // ... and so does the chunk's share of the input layer's backward pass (one fc layer): d x1 = dG0 W_ih0 masked by the ReLU for the
+    // chunk's rows, its transpose (+ bias column sums) and its contribution to dW1 (split-K atomics add up over the chunks)
+    const bool chunk_input = nfc == 1 && nbc > 1 && M % 4 == 0 && H % 4 == 0 && L->wgrad_split > 1;
+    auto input_chunk = [=](int c, void* st) -> int {
+      const size_t m0 = (size_t)cut[c] * B, Mc = (size_t)(cut[c + 1] - cut[c]) * B;
+      CK(hsad_gemm_nt_bf16_ex(L->dG[0] + m0 * H4, H4, on->WihT[0], H4, (int)Mc, H, H4, nullptr, nullptr, 0, L->dx1 + m0 * H, H, 0, 0, 1,
+                              L->xin[0] + m0 * H, H, nullptr, st));
+      CK(transpose16(L->dx1 + m0 * H, (int)Mc, H, H, L->dx1T + m0, Mp, g[on->iB1], nullptr, nullptr, st));
+      CK(hsad_gemm_nt_bf16_ex(L->dx1T + m0, Mp, L->a16T + m0, Mp, H, F, (int)Mc, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0,
+                              nullptr, st));
+      return 0;
+    };
     for (int c = nbc - 1; c >= 0; --c) {
-      const size_t t0 = (size_t)c * Tc;
+      const size_t t0 = (size_t)cut[c];
+      const int Tc = cut[c + 1] - cut[c];
       hsad_lstm_fused_bwd_rec recs[2];
       for (int k = 0; k < 2; ++k) {
         const int l = 1 - k;
@@ -1266,11 +1293,14 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.xchg = L->xchg_b[l];
         r.saved_frag_major = 1;
         r.tail_is_zero = 1;
+        r.xout = (L->split_bptt && k == 0) ? L->xout_b : nullptr;
+        r.layout_steps = TL;
       }
-      if (L->fb_tc != Tc) {      // another chunk length: the blocks' layout changes, start from clean ones
+      if (L->fb_tc != TL || L->fb_split != L->split_bptt) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
+        L->fb_split = L->split_bptt;
         HIP_TRY(hipMemsetAsync(L->fbsync[0], 0, 2 * L->fbsync_words * 4, s));
         L->fbflip = 0;
-        L->fb_tc = Tc;
+        L->fb_tc = TL;
       }
       int& f = L->fbflip;
       CK(hsad_lstm_backward_fused(1, 2, Tc, B, H, recs, L->fbsync[f], L->fbsync[f ^ 1], stream));
@@ -1281,6 +1311,10 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
       // the last chunk's layer-0 gradients run on the caller's stream behind the input-MLP chain: two streams share the tail
       if (c > 0) CK(chunk_wgrad(0, c, wst, L->dGT, L->wgrad_ws));
       else defer_l0 = true;
+      if (chunk_input && c > 0) {        // (reads x^T-side operands a16^T: behind ev_d on the same stream; writes dx1 / dx1T rows of its own)
+        CK(input_chunk(c, wst));
+        input_done_above = cut[1];       // the head chunk's rows are what is left for the caller's stream
+      }
     }
   } else if (pipe) {
     const int Tc = T / nch, nrb = nrb_of(B);
@@ -1347,6 +1381,18 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   if (pipe) HIP_TRY(hipStreamWaitEvent(s, L->ev_d, 0));
   bf16_t* dxl = nfc == 2 ? L->dx2 : L->dx1;
   bf16_t* dxlT = nfc == 2 ? L->dx2T : L->dx1T;
+  if (input_done_above > 0) {      // one fc layer, chunked BPTT: only the head chunk's rows are left
+    const int Mh = input_done_above * B;
+    CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, Mh, H, H4, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
+    CK(transpose16(L->dx1, Mh, H, H, L->dx1T, Mp, g[on->iB1], nullptr, nullptr, stream));
+    CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mh, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+    if (defer_l0) CK(chunk_wgrad(0, 0, stream, L->dGT2, L->wgrad_ws2));
+    if (pipe) {
+      HIP_TRY(hipEventRecord(L->ev_a, ws));
+      HIP_TRY(hipStreamWaitEvent(s, L->ev_a, 0));
+    }
+    return 0;
+  }
   CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, dxl, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
   const bool fast_cs = M % 4 == 0 && H % 4 == 0;
   if (nfc == 2) {

@@ -2377,6 +2377,12 @@ struct LstmFusedBwdArgs {
   float* dc_io;
   int dbg;
   int T, Bn, has_next, frag, feeds;   // feeds: a layer below consumes this layer's tiles (publish + signal step 0, too)
+  // split placement (the layers of a row block on DIFFERENT XCDs, 16 workgroups each, so that half of every XCD stays free for the weight-
+  // gradient GEMMs of the previous time chunk): a feeding layer publishes its tile a second time, written through (sc1) with an agent-scope
+  // counter, for the layer below; its own recurrence keeps the L2-local exchange.  split_x: this layer's X stream is such a cross-XCD one.
+  bf16_t* xout;
+  unsigned* xout_counters;
+  int split_x;
 };
 
 template <int KB>  // KB = 4H / 32
@@ -2427,20 +2433,21 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
 
   // probe (optional): a second counter whose value is fetched by the SAME scalar round trip as the first poll -- "has the layer above
   // already published the step after this one?" -> s_okp[3]: the next step then starts its X loads without a poll of its own
-  auto wait_ctr = [&](unsigned* ctr, int slot, unsigned* probe) -> bool {
+  // ctr_fast / probe_fast: the counter lives in this XCD's L2 (scalar glc load) or was written from another XCD (agent-scope load)
+  auto wait_ctr = [&](unsigned* ctr, int slot, unsigned* probe, int ctr_fast, int probe_fast) -> bool {
     if (tid == 0) {
       unsigned spins = 0;
       int ok = 1;
       unsigned pv = 0;
       for (bool first = true;; first = false) {
         unsigned v;
-        if (fast) {
-          if (first && probe) asm volatile("s_load_dword %0, %2, 0x0 glc\n\ts_load_dword %1, %3, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v), "=&s"(pv) : "s"(ctr), "s"(probe) : "memory");
+        if (ctr_fast) {
+          if (first && probe && probe_fast) asm volatile("s_load_dword %0, %2, 0x0 glc\n\ts_load_dword %1, %3, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v), "=&s"(pv) : "s"(ctr), "s"(probe) : "memory");
           else asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ctr) : "memory");
         } else {
           v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (first && probe) pv = __hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (first && probe && !(ctr_fast && probe_fast)) pv = __hip_atomic_load(probe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (v >= (unsigned)nunit_blocks) break;
         __builtin_amdgcn_s_sleep(1);
         if (++spins > 8000000u) {
@@ -2455,6 +2462,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     __syncthreads();
     return s_okp[slot] != 0;
   };
+  const int fast_x = a.split_x ? 0 : fast;
   bool x_ready = false;      // the layer above is known to have published this step's tile (seen by the previous step's poll)
   // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
   int swz[4];
@@ -2518,7 +2526,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     };
     bool any = false;
     if (has_x) {     // X stream: dG^{l+1}_t of the layer above (published one step ago when it leads) x W_ih^{l+1}
-      if (!x_ready && !wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0, nullptr)) return;
+      if (!x_ready && !wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0, nullptr, fast_x, fast_x)) return;
       LSTM_STAMP(dbg_base + 0)   // wait for the layer above
       load_quarter(a.xin + ((size_t)t * nrb + rb) * tile_elems);
       constexpr int QI = KQ / 4;
@@ -2545,7 +2553,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     if (t < a.T - 1 || a.has_next) {
       x_ready = false;
       if (t < a.T - 1) {
-        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2, (has_x && t > 0) ? a.xin_counters + (size_t)(t - 1) * nrb + rb : nullptr)) return;
+        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2, (has_x && t > 0) ? a.xin_counters + (size_t)(t - 1) * nrb + rb : nullptr, fast, fast_x)) return;
         x_ready = has_x && t > 0 && s_okp[3] != 0;
       } else {
         __syncthreads();
@@ -2630,11 +2638,16 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int c = tid + it * 256, r = (c >> 3) & 31, qq = c & 7;   // slab it, row r, 8-byte piece qq
-        xchg_store8(reinterpret_cast<u64_t*>(xo + c * 4), *reinterpret_cast<const u64_t*>(sG + r * 136 + it * 32 + qq * 4), fast);
+        const u64_t v8 = *reinterpret_cast<const u64_t*>(sG + r * 136 + it * 32 + qq * 4);
+        xchg_store8(reinterpret_cast<u64_t*>(xo + c * 4), v8, fast);
+        if (a.xout) xchg_store8(reinterpret_cast<u64_t*>(a.xout + (((size_t)t * nrb + rb) * KB + 4 * nb) * 1024 + c * 4), v8, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+      if (tid == 0) {
+        xchg_signal(a.counters + (size_t)t * nrb + rb, fast);
+        if (a.xout) xchg_signal(a.xout_counters + (size_t)t * nrb + rb, 0);
+      }
     }
     // row-major copy for the weight-gradient GEMMs: off the other workgroups' critical path
 #pragma unroll
@@ -2658,6 +2671,7 @@ struct LstmFusedBwdArgsN {
   int force_cross_xcd;
   unsigned* zero_ptr;
   int zero_words;
+  int split;
 };
 
 template <int KB>
@@ -2665,6 +2679,15 @@ __global__ __launch_bounds__(256) void lstm_fused_bwd_kernel(LstmFusedBwdArgsN m
   if (blockIdx.x == 0 && m.zero_ptr)
     for (int i = threadIdx.x; i < m.zero_words; i += 256) m.zero_ptr[i] = 0u;
   const int L = blockIdx.x, s = L >> 3;
+  if (m.split) {     // one (net, row block, layer) per XCD slot: 16 workgroups of an XCD, the layers of a row block on different XCDs
+    const int p = s / m.nunit, nb = s - p * m.nunit;
+    const int g = (L & 7) + 8 * p;
+    if (g >= m.nnet * m.nrb * m.nl) return;
+    const int SG = g / m.nl, layer = g - SG * m.nl;
+    const int net = SG / m.nrb, rb = SG - net * m.nrb;
+    lstm_fused_bwd_body<KB>(m.r[net * m.nl + layer], rb, nb, m.nrb, m.nunit, m.group_words + g, m.nunit, m.force_cross_xcd);
+    return;
+  }
   const int per = m.nl * m.nunit;
   const int p = s / per, within = s - p * per;
   const int SG = (L & 7) + 8 * p;
@@ -4455,12 +4478,25 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
   if (!((H == 256 || H == 512) && Bn >= 32 && Bn % 32 == 0)) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: needs H in {256,512}, rows a multiple of 32");
   hipStream_t s = (hipStream_t)stream;
   const int nrb = Bn / 32, nunit = H / 32, nsg = nnet * nrb;
-  const int grid = 8 * nlayer * nunit * ((nsg + 7) / 8);
+  // split placement: every record that feeds a layer below brings a second hand-off buffer (xout)
+  bool split = false;
+  for (int i = 0; i + 1 < nrec; ++i)
+    if ((i + 1) % nlayer && recs[i + 1].WihT_above_blocked && recs[i].xout) split = true;
+  if (split)
+    for (int i = 0; i + 1 < nrec; ++i)
+      if ((i + 1) % nlayer && recs[i + 1].WihT_above_blocked && !recs[i].xout)
+        return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: split placement needs xout on every record that feeds a layer below");
+  const int grid = split ? 8 * nunit * ((nsg * nlayer + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
   if (grid > device_cus())
     return nfail(HSAD_ERR_INVALID, "fused persistent BPTT launch needs %d co-resident workgroups per XCD, the device has %d", grid / 8, device_cus() / 8);
+  // sync scratch: [group words 2 * R * nrb][step counters R * Tc * nrb][timeout], R = nrec (2 * nrec with split placement: the second
+  // half of the counters belongs to the xout copies)
+  const int R = split ? 2 * nrec : nrec;
+  // (chunks of different lengths share one block layout: the counters of record i start at i * TL * nrb, TL = the longest chunk)
+  const int TL = recs[0].layout_steps > Tc ? recs[0].layout_steps : Tc;
   unsigned* sync = (unsigned*)sync_scratch;
-  unsigned* counters = sync + 2 * nrec * nrb;
-  const size_t words = seq_sync_words(nrec, Tc, nrb);
+  unsigned* counters = sync + 2 * R * nrb;
+  const size_t words = seq_sync_words(R, TL, nrb);
   if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
   LstmFusedBwdArgsN m{};
   for (int i = 0; i < nrec; ++i) {
@@ -4473,16 +4509,17 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     LstmFusedBwdArgs& q = m.r[i];
     q.WhhT = (const bf16_t*)r.WhhT_blocked;
     q.xW = (const bf16_t*)r.WihT_above_blocked;
-    q.xin = r.WihT_above_blocked ? (const bf16_t*)recs[i - 1].xchg : nullptr;
-    q.xin_counters = r.WihT_above_blocked ? counters + (size_t)(i - 1) * Tc * nrb : nullptr;
+    q.xin = r.WihT_above_blocked ? (const bf16_t*)(split ? recs[i - 1].xout : recs[i - 1].xchg) : nullptr;
+    q.xin_counters = r.WihT_above_blocked ? counters + (size_t)((split ? nrec : 0) + i - 1) * TL * nrb : nullptr;
+    q.split_x = split && r.WihT_above_blocked;
     q.gates = r.gates;
     q.cseq = r.cseq;
     q.c0 = r.c_before;
     q.dO = r.dO;
     q.dG = dG;
     q.xchg = (bf16_t*)r.xchg;
-    q.counters = counters + (size_t)i * Tc * nrb;
-    q.timeout = counters + (size_t)nrec * Tc * nrb;
+    q.counters = counters + (size_t)i * TL * nrb;
+    q.timeout = counters + (size_t)R * TL * nrb;
     q.dc_io = r.dc_io;
     q.dbg = g_lstm_dbg_enable;
     q.T = Tc;
@@ -4490,7 +4527,10 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.has_next = r.has_next;
     q.frag = r.saved_frag_major;
     q.feeds = (layer + 1 < nlayer && recs[i + 1].WihT_above_blocked) ? 1 : 0;
+    q.xout = (split && q.feeds) ? (bf16_t*)r.xout : nullptr;
+    q.xout_counters = q.xout ? counters + (size_t)(nrec + i) * TL * nrb : nullptr;
   }
+  m.split = split ? 1 : 0;
   m.nnet = nnet;
   m.nl = nlayer;
   m.nrb = nrb;

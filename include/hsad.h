@@ -566,6 +566,14 @@ typedef struct hsad_lstm_fused_bwd_rec {
   void* xchg;
   int saved_frag_major;
   int tail_is_zero;
+  void* xout;   /* split placement (NULL = off): a second hand-off buffer, laid out like xchg, on every record that feeds a layer below.
+                 * The layers of a (net, row block) then run on DIFFERENT XCDs -- H/32 workgroups per XCD, half of a 32-CU XCD stays free
+                 * for the weight-gradient GEMMs of the previous time chunk -- the feeding layer publishes its tile a second time, written
+                 * through with an agent-scope counter; its own recurrence keeps the L2-local exchange.  Same bits either way.
+                 * sync_scratch then holds uint32 [2 * nnet*nlayer*(Tc+2)*Bn/32 + 4]; grid = 8 * (H/32) * ceil(nnet*nlayer*Bn/32 / 8). */
+  int layout_steps;   /* record 0 only; 0 = Tc.  Chunks of different lengths that share (ping-pong) sync blocks pass the LONGEST chunk length
+                       * here: counters and the sticky timeout word then sit at the same place for every launch (read the timeout with
+                       * that length), and a launch clears its partner block for any of them. */
 } hsad_lstm_fused_bwd_rec;
 int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch,
                              void* next_sync_scratch, void* stream);
@@ -651,6 +659,10 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *              dO of the lower layer inside its recurrence) when the shape allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s
  *              workgroups fit an XCD); 0: the chunk-pipelined schedule of rounds 1-2 (stand-alone projection / dO GEMMs between chunk launches)
  *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
+ *   bits 16-23 fused BPTT in TWO unequal chunks: steps [n, T) first, the head [0, n) last (0 = equal chunks per bits 8-15) -- the long
+ *              chunk's weight gradients run next to the head's recurrence, only the head's are left for the end of the update
+ *   bit 3      split placement of the fused BPTT (hsad_lstm_fused_bwd_rec.xout): the two layers of a row block on different XCDs, half of
+ *              every XCD free for the chunk-wise weight gradients on the side stream; meant for bits 8-15 >= 2
  *   bit 2      hsad_r2d2_optimizer_step re-derives the LSTM matrices (95 % of the operand bytes) on the learner's side stream, next to the
  *              following update's input layer; every entry point that reads a net's LSTM operands waits for that half first (an event, no
  *              host synchronisation).  Off by default: measured 1.521 against 1.504 ms per update with everything in line

@@ -1,4 +1,4 @@
-"""rocprofv3 --kernel-trace --stats -- python tools/learner_update_breakdown.py N : kernels of N composite learner updates"""
+"""rocprofv3 --kernel-trace --stats -- python tools/learner_update_breakdown.py N [set_fused flags] : kernels of N composite learner updates"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 F, H, A, T, B = 838, 512, 21, 80, 128
 W = init_weights(F, H, A, 5, 1)
 L = CompositeLearner(W, W, 3, 0.999, device="cuda:0")
+if len(sys.argv) > 2:
+    L.set_fused(int(sys.argv[2], 0))
 batch, weight = _rand_batch(T, B, F, A)
 b16 = dict(batch); del b16["priv_s"]
 b16["priv_s_bf16"] = torch.zeros(T, B, 1, 896, dtype=torch.bfloat16, device="cuda:0")

@@ -16,7 +16,7 @@ batch = {"priv_s": (torch.rand(T, B, F, device=dev) < 0.15).float() * mask.unsqu
          "seq_len": seq_len, "own_hand": torch.zeros(T, B, 15, device=dev)}
 weight = torch.ones(B, device=dev)
 lr = CompositeLearner(W, W, 3, 0.999, device=dev)
-for fused in (1 | (1 << 8), 5 | (1 << 8), 3 | (1 << 8), 0, 1 | (2 << 8), 1 | (4 << 8), 1 | (1 << 8)):
+for fused in [int(x, 0) for x in sys.argv[1:]] or (1 | (1 << 8), 9 | (1 << 8), 9 | (2 << 8), 9 | (4 << 8), 1 | (2 << 8), 1 | (4 << 8), 3 | (1 << 8), 0, 5 | (1 << 8), 1 | (1 << 8)):
     lr.set_fused(fused)
     def upd():
         lr.loss(batch, weight, 0.0); lr.optimizer_step()
