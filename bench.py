@@ -84,6 +84,17 @@ def fused_traffic_bytes():
     return None
 
 
+def cell_traffic_bytes():
+    """HBM bytes per launch of the fused cell kernel inside an acting step (mean of the online pass, which also writes the fp32 state, and
+    the target pass), from the committed PMC passes"""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["actor"]
+        v = [x["hbm_bytes_per_launch"] for k, x in rec.items() if "lstm_cell_pp_kernel" in k]
+        return sum(v) / len(v) if v else None
+    except Exception:
+        return None
+
+
 def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     """Second half of BASELINE.json's metric: R2D2 learner samples/sec at configs[2] (2p SAD IQL, F=838, A=21,
     H=512, 2-layer LSTM, B=128, T=80, n=3): sample-shaped synthetic batch -> loss fwd (online+target) -> BPTT ->
@@ -289,7 +300,8 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
            "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
                                                    "phase-interleaved k loop; 4 launches per step)" % (games * 2, 2048, 1024),
-                        "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": None,
+                        "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": cell_traffic_bytes(),
+                        "algorithmic_bytes_per_launch": (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + games * 2 * 512 * 4,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
                         "share_of_step": 4 * ms.value / (dt * 1e3)},
            "observation_path": "packed (bit words + bf16 rows from the env kernel)" if tr.actor.packed_obs else "float32",

@@ -30,7 +30,7 @@ for dbg in (0, 1):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
     _lib.check(lib.hsad_lstm_debug_timing(buf, 1))
     print("debug %d: %.1f us per launch (%.0f TF)" % (dbg, dt * 1e6, 2 * N * 2048 * 1024 / dt / 1e12))
-    if dbg and os.environ.get("HSAD_CELL_PP"):
+    if dbg and os.environ.get("HSAD_CELL_PP", "1") != "0":
         for g, o in (("wave 0 (early row)", 0), ("wave 4 (late row)", 8)):
             cyc = [buf[o + i] / K for i in range(7)]
             print("  %s cycles per launch: sum %.0f, epilogue %.0f;  per phase: reads %.0f | DMA issue %.0f | vmcnt wait %.0f | wait L-barrier %.0f | M %.0f | wait M-barrier %.0f"

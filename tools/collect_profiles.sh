@@ -31,4 +31,12 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /
 cp $(find /tmp/pl -name "*kernel_stats.csv" | head -1) $O/${RN}_learner_update_kernel_stats.csv
 python $R/tools/update_timeline.py $(find /tmp/pl -name "*kernel_trace.csv" | head -1) > $O/${RN}_learner_update_timeline.txt 2>&1
 cp $O/${RN}_learner_update_kernel_stats.csv $O/${RN}_learner_update_timeline.txt $R/profiles/ 2>/dev/null
+# 200 steady-state actor steps, kernel by kernel (per-step figures = TotalDurationNs / 200)
+rm -rf /tmp/pa
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pa -o a -- python $R/tools/actor_step_breakdown.py 200 > $O/actor_breakdown.log 2>&1
+cp $(find /tmp/pa -name "*kernel_stats.csv" | head -1) $O/${RN}_actor_200_steps_kernel_stats.csv
+cp $O/${RN}_actor_200_steps_kernel_stats.csv $R/profiles/ 2>/dev/null
+# the fused cell kernel's phase timers and ablations
+cd $R && (timeout 200 python tools/cell_variants.py 32768 pp0 pp1 pp11 pp12 pp14 pp19 pp0 pp1; HSAD_CELL_PP=1 timeout 100 python tools/cell_phases.py 32768 1; HSAD_CELL_PP=0 timeout 100 python tools/cell_phases.py 32768 1) 2>&1 | grep -v amdgpu.ids > $O/${RN}_cell_kernel_ablations.txt
+cp $O/${RN}_cell_kernel_ablations.txt $R/profiles/ 2>/dev/null
 tail -c 2500 $O/${RN}_bench.json; echo; head -8 $O/${RN}_bench_kernel_stats.csv | cut -c1-160; cat $O/pmc_summary.txt | head -60

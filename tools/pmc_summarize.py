@@ -21,6 +21,11 @@ ALGO_ENV5 = (5 * (1439 + 49 + 12 + 1) * 4 + 5 + 5 * 8 * 2 + 256) * 16384        
 _MH = 80 * 128 * 512
 FUSED_FWD_ALGO = 8 * 2048 * 512 * 2 + 2 * _MH * 2 + 4 * _MH * 2 + 2 * (_MH * 4 * 4 + _MH * 4)
 # fused BPTT (online net, 2 layers): weights 3 x 2 MB, saved gates + c read (2 layers), dO of the top layer (fp32), dG written (bf16, 2 layers)
+# fused inference cell, 32,768 rows, H = 512: x and h_prev bf16 read once, the [2048 x 1024] weight panel once, c_prev fp32 read; written: the
+# bf16 layer output (+ c and h fp32 for the online pass)
+_NH = 32768 * 512
+CELL_ALGO_NOSTATE = 2 * _NH * 2 + 2048 * 1024 * 2 + _NH * 4 + _NH * 2
+CELL_ALGO_STATE = CELL_ALGO_NOSTATE + 2 * _NH * 4
 FUSED_BWD_ALGO = 3 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + 2 * _MH * 4 * 2
 
 
@@ -78,7 +83,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
                 ("learner update: transpose_bf16_kernel", r"transpose_bf16_kernel", None, ""),
                 ("learner update: sum_slabs_kernel", r"sum_slabs_kernel", None, ""),
                 ("learner update: adam_kernel", r"adam_kernel", None, "")],
-    "actor": [("actor step: lstm_cell_gemm256_kernel (32,768 rows x 2048 x 1024)", r"lstm_cell_gemm256_kernel", None, ""),
+    "actor": [("actor step: lstm_cell_pp_kernel<true> (online pass: 32,768 rows x 2048 x 1024, fp32 state + bf16 layer output written)", r"lstm_cell_pp_kernel<true", CELL_ALGO_STATE, ""),
+              ("actor step: lstm_cell_pp_kernel<false> (target pass: bf16 layer output only)", r"lstm_cell_pp_kernel<false", CELL_ALGO_NOSTATE, ""),
               ("actor step: gemm_nt_bf16_kernel<128,128> (input linear / heads)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
               ("actor step: env_kernel<1,2,5> G=16384", r"env_kernel<1, 2, 5>", None, ""),
               ("actor step: cast_pad_bf16_vec8_kernel", r"cast_pad_bf16_vec8_kernel", None, ""),
