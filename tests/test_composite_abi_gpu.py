@@ -344,3 +344,39 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
                 assert torch.equal(res[a][2][k], res[b][2][k]), (b, k)
             else:
                 assert relerr(res[a][2][k], res[b][2][k]) < 1e-5, (b, k)
+
+
+def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
+    """stress target for the counter / hand-off protocols of the persistent fused launches (forward: 4 recurrences x 80 steps, BPTT: 2 x 80):
+    a stale tile, a counter read too early or a lost wake-up changes bits (or trips the sticky timeout flag).  360 evaluations of the full-size
+    update on the same weights and batch -- default placement, split placement, two time chunks, and the cross-XCD protocol forced on
+    co-located groups -- must ALL reproduce the first evaluation's loss, priorities and (deterministic) LSTM weight gradients exactly."""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    lib = _lib.load_library()
+    F, A, H, T, B = 838, 21, 512, 80, 128
+    W, Wt = _rand_net(F, H, A, seed=21), _rand_net(F, H, A, seed=22)
+    batch, weight = _rand_batch(T, B, F, A, seed=5)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    ref_lp, ref_g = None, {}          # loss / priorities: one reference for everything; weight gradients: per chunk count (the chunks' partial
+    try:                              # sums are added up in another order)
+        for flags, cross, reps in ((1 | (1 << 8), 0, 150), (9 | (1 << 8), 0, 80), (9 | (2 << 8), 0, 50), (1 | (1 << 8), 1, 40), (9 | (1 << 8), 1, 40)):
+            _lib.check(lib.hsad_lstm_set_exchange_mode(cross))
+            L.set_fused(flags)
+            chunks = (flags >> 8) & 0xff
+            bad = torch.zeros((), dtype=torch.int64, device=DEV)
+            for it in range(reps):
+                loss, prio = L.loss(batch, weight, 0.25)
+                got_lp, got_g = (loss, prio), (L.grad["lstm.weight_hh_l0"], L.grad["lstm.weight_ih_l1"])
+                if ref_lp is None:
+                    ref_lp = tuple(t.clone() for t in got_lp)
+                if chunks not in ref_g:
+                    ref_g[chunks] = tuple(t.clone() for t in got_g)
+                # every evaluation is compared on the device; the host looks once per configuration
+                for a, b in zip(got_lp + got_g, ref_lp + ref_g[chunks]):
+                    bad += (a != b).any()
+            assert int(bad) == 0, (hex(flags), cross)
+    finally:
+        lib.hsad_lstm_set_exchange_mode(0)
+    L.check_sync()
