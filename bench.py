@@ -299,11 +299,11 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "host_issue_us_per_step": host_issue_us,
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
            "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
-                                                   "phase-interleaved k loop; 4 launches per step)" % (games * 2, 2048, 1024),
+                                                   "phase-interleaved k loop; the online and the target net's cell of a layer are ONE launch of two problems: 2 launches per step)" % (games * 2, 2048, 1024),
                         "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": cell_traffic_bytes(),
                         "algorithmic_bytes_per_launch": (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + games * 2 * 512 * 4,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
-                        "share_of_step": 4 * ms.value / (dt * 1e3)},
+                        "launches_per_step": nl.value / 40.0, "share_of_step": nl.value / 40.0 * ms.value / (dt * 1e3)},
            "observation_path": "packed (bit words + bf16 rows from the env kernel)" if tr.actor.packed_obs else "float32",
            "config": {"workload": "%d concurrent 2-player SAD games, IQL R2D2 agent (F=838 A=21 H=512 L=2) in the loop, n-step 3, "
                                   "max_len 80, priorities from online+target nets, finished sequences flushed into a "

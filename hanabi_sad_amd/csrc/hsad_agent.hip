@@ -334,6 +334,38 @@ int net_step(hsad_r2d2_net* n, int N, const bf16_t* a16, const float* h0, const 
   return 0;
 }
 
+// The trunks of the online and the target net of an acting step, layer by layer as ONE launch of two cell problems
+// (hsad_lstm_cell_fused_pair): input layers already in the heads of the two workspaces, both nets on the fused inference path, same
+// shape, no skip connection.  Workspace layout and results as two net_step calls (the target reads the online pass's bf16 state).
+int net_step_pair(hsad_r2d2_net* n, hsad_r2d2_net* tg, int N, const float* h0, const float* c0, const bf16_t* h16_in, float* h_out, float* c_out,
+                  char* ws_on, char* ws_tg, StepOut* so, StepOut* st, hipStream_t s, bf16_t* h16_dst) {
+  const int H = n->H, L = n->L;
+  void* stp = (void*)s;
+  const size_t NH_ = (size_t)N * H;
+  bf16_t* x_on = reinterpret_cast<bf16_t*>(ws_on);
+  bf16_t* x_tg = reinterpret_cast<bf16_t*>(ws_tg);
+  bf16_t* h16 = reinterpret_cast<bf16_t*>(ws_on + 2 * NH_ * 2);
+  bf16_t* h16n_on = h16_dst ? h16_dst : reinterpret_cast<bf16_t*>(ws_on + 2 * NH_ * 2 + L * NH_ * 2);
+  bf16_t* h16n_tg = reinterpret_cast<bf16_t*>(ws_tg + 2 * NH_ * 2 + L * NH_ * 2);
+  if (!h16_in) {
+    CK(hsad_cast_pad_bf16(h0, L * N, H, H, h16, H, stp));
+    h16_in = h16;
+  }
+  const bf16_t *xin_on = x_on, *xin_tg = x_tg;
+  for (int l = 0; l < L; ++l) {
+    CK(hsad_lstm_cell_fused_pair(N, H, H, H, xin_on, xin_tg, h16_in + (size_t)l * NH_, h16_in + (size_t)l * NH_, n->Wcat16[l], tg->Wcat16[l], n->bias16[l],
+                                 tg->bias16[l], c0 + (size_t)l * NH_, c0 + (size_t)l * NH_, c_out ? c_out + (size_t)l * NH_ : nullptr, nullptr,
+                                 h_out ? h_out + (size_t)l * NH_ : nullptr, nullptr, h16n_on + (size_t)l * NH_, h16n_tg + (size_t)l * NH_, stp));
+    xin_on = h16n_on + (size_t)l * NH_;
+    xin_tg = h16n_tg + (size_t)l * NH_;
+  }
+  so->o16 = h16n_on + (size_t)(L - 1) * NH_;
+  so->h16_new = h16n_on;
+  st->o16 = h16n_tg + (size_t)(L - 1) * NH_;
+  st->h16_new = h16n_tg;
+  return 0;
+}
+
 size_t step_ws_bytes(const hsad_r2d2_net* n, int N) {
   const size_t NH_ = (size_t)N * n->H, L = n->L;
   return 2 * NH_ * 2 + std::max<size_t>(2 * L * NH_ * 2, (size_t)N * 4 * n->H * 4 + (L + 1) * NH_ * 2 + 2 * L * NH_ * 4) + 256;
@@ -512,6 +544,18 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
   if (pair_in)
     CK(hsad_gemm_nt_bf16_pair(a16, a16, n->Fp, n->W1, target->W1, n->Fp, N, H, n->Fp, n->w(n->iB1), target->w(target->iB1), nullptr, nullptr, 0,
                               ws_on, ws_tg, H, 1, stream));
+  // ... so are the LSTM layers (one launch of two cell problems per layer) when both nets take the fused inference path ...
+  const bool pair_trunk = pair_in && hd_b % 16 == 0 && N >= 1024 && n->Wcat16[0] && target->Wcat16[0] && !n->with_backward && !target->with_backward &&
+                          n->L == target->L && !n->skip && !target->skip;
+  if (pair_trunk) {
+    StepOut st{};
+    CK(net_step_pair(n, target, N, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, ws_tg, &so, &st, s, (bf16_t*)h_out_bf16));
+    CK(hsad_gemm_nt_bf16_pair(so.o16, st.o16, H, n->Wheads, target->Wheads, H, N, NH, H, n->bheads, target->bheads, hd, hd_t, NH, nullptr,
+                              nullptr, 0, 0, stream));
+    CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
+    CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
+    return 0;
+  }
   CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in, true));
   if (pair_in && hd_b % 16 == 0) {
     // ... and so are their head layers (N = A + 1 + 3 hand: one problem alone leaves half of the chip without a tile); the target's

@@ -1059,8 +1059,10 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
 // that ends M (the later wave row: global barrier 2c + 3), and a half tile is re-filled no earlier than two phases after the phase that
 // read it (the earlier wave row issues that DMA behind global barrier 2c + 4).  Needs Bn % 256 == 0 (no row clamping in the DMA offsets).
 // ---------------------------------------------------------------------------------------------------
+// np = 2: TWO problems of the same shape in one launch (a2: the target net's cell next to the online net's, hsad_lstm_cell_fused_pair) --
+// problem 1's row tiles follow problem 0's in the tile order, the operand stream runs across the boundary like across any tile switch.
 template <bool STATE, int ABL = 0>   // ABL (developer instantiations; 1-8: results are garbage): 1 no DMA, 2 no MFMA, 4 no stagger, 8 no fragment reads, 128 phase timers
-__global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
+__global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a, LstmCellArgs a2, int np) {
   constexpr int BM = 256, BN = 256;
   constexpr uint32_t kHalf = 128 * kBK * 2;               // bytes of a half tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
@@ -1071,11 +1073,12 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
   const bool xcd_order = (gridDim.x % 8) == 0;
   const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
   const int per_xcd = gridDim.x / n_xcd;
-  auto tile_of = [&](int sq, int& m0, int& n0) -> bool {      // tile order of lstm_cell_gemm256_kernel
+  auto tile_of = [&](int sq, int& m0, int& n0, int& prob) -> bool {      // tile order of lstm_cell_gemm256_kernel (row tiles of problem 1 behind problem 0's)
     const int mt = (sq / tiles_n) * n_xcd + xcd;
     n0 = (sq % tiles_n) * BN;
-    m0 = mt * BM;
-    return mt < tiles_m;
+    prob = mt >= tiles_m ? 1 : 0;
+    m0 = (mt - prob * tiles_m) * BM;
+    return mt < np * tiles_m;
   };
   const int nk = K / kBK;
 
@@ -1092,8 +1095,8 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
   const uint32_t ax00 = src_off(0, 0, a.ldx, true), ax01 = src_off(0, 1, a.ldx, true), ax10 = src_off(1, 0, a.ldx, true), ax11 = src_off(1, 1, a.ldx, true);
   const uint32_t ah00 = src_off(0, 0, H, true), ah01 = src_off(0, 1, H, true), ah10 = src_off(1, 0, H, true), ah11 = src_off(1, 1, H, true);
   const uint32_t b00 = src_off(0, 0, K, false), b01 = src_off(0, 1, K, false), b10 = src_off(1, 0, K, false), b11 = src_off(1, 1, K, false);
-  int p_seq = blockIdx.x / n_xcd, p_m0 = 0, p_n0 = 0, p_kt = 0, p_T = 0;
-  bool p_valid = tile_of(p_seq, p_m0, p_n0);
+  int p_seq = blockIdx.x / n_xcd, p_m0 = 0, p_n0 = 0, p_kt = 0, p_T = 0, p_prob = 0;
+  bool p_valid = tile_of(p_seq, p_m0, p_n0, p_prob);
   if (!p_valid) return;
   unsigned char* const dst_w = smem_cell + wave * 1024;
   // one half tile = two LDS-DMA instructions per wave.  kind: 0 A0, 1 B0, 2 B1, 3 A1 -- a compile-time constant at every call site:
@@ -1102,21 +1105,23 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
     constexpr int kind = decltype(kind_c)::value;
     if (!p_valid) return;
     if ((ABL & 1) && p_T >= 2) {
-      if (kind == 3 && (++p_T, ++p_kt == nk)) { p_kt = 0; p_seq += per_xcd; p_valid = tile_of(p_seq, p_m0, p_n0); }
+      if (kind == 3 && (++p_T, ++p_kt == nk)) { p_kt = 0; p_seq += per_xcd; p_valid = tile_of(p_seq, p_m0, p_n0, p_prob); }
       return;
     }
     const int k0 = p_kt * kBK;
     const uint32_t slot = (uint32_t)(p_T & 1) * 4u * kHalf;
     if (kind == 0 || kind == 3) {
       const bool part2 = k0 >= a.Kx;
-      const char* abase = part2 ? reinterpret_cast<const char*>(a.h_prev16 + (size_t)p_m0 * H + (k0 - a.Kx))
-                                : reinterpret_cast<const char*>(a.x + (size_t)p_m0 * a.ldx + k0);
+      const bf16_t* hp = p_prob ? a2.h_prev16 : a.h_prev16;
+      const bf16_t* xp = p_prob ? a2.x : a.x;
+      const char* abase = part2 ? reinterpret_cast<const char*>(hp + (size_t)p_m0 * H + (k0 - a.Kx))
+                                : reinterpret_cast<const char*>(xp + (size_t)p_m0 * a.ldx + k0);
       const uint32_t o0 = kind == 0 ? (part2 ? ah00 : ax00) : (part2 ? ah10 : ax10), o1 = kind == 0 ? (part2 ? ah01 : ax01) : (part2 ? ah11 : ax11);
       const uint32_t d = slot + (kind == 0 ? 0u : kHalf);
       glds16(reinterpret_cast<const bf16_t*>(abase + o0), reinterpret_cast<bf16_t*>(dst_w + d));
       glds16(reinterpret_cast<const bf16_t*>(abase + o1), reinterpret_cast<bf16_t*>(dst_w + d + 8192u));
     } else {
-      const char* bbase = reinterpret_cast<const char*>(a.Wcat + (size_t)p_n0 * K + k0);
+      const char* bbase = reinterpret_cast<const char*>((p_prob ? a2.Wcat : a.Wcat) + (size_t)p_n0 * K + k0);
       const uint32_t d = slot + (kind == 1 ? 2u : 3u) * kHalf;
       glds16(reinterpret_cast<const bf16_t*>(bbase + (kind == 1 ? b00 : b10)), reinterpret_cast<bf16_t*>(dst_w + d));
       glds16(reinterpret_cast<const bf16_t*>(bbase + (kind == 1 ? b01 : b11)), reinterpret_cast<bf16_t*>(dst_w + d + 8192u));
@@ -1126,7 +1131,7 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
       if (++p_kt == nk) {
         p_kt = 0;
         p_seq += per_xcd;
-        p_valid = tile_of(p_seq, p_m0, p_n0);
+        p_valid = tile_of(p_seq, p_m0, p_n0, p_prob);
       }
     }
   };
@@ -1163,8 +1168,8 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
   };
 
-  int seq = blockIdx.x / n_xcd, m0 = 0, n0 = 0;
-  (void)tile_of(seq, m0, n0);
+  int seq = blockIdx.x / n_xcd, m0 = 0, n0 = 0, prob = 0;
+  (void)tile_of(seq, m0, n0, prob);
   // prologue: half tiles 0 .. 5 (k tile 0 and A0, B0 of k tile 1)
   issue(K0{}); issue(K1{}); issue(K2{}); issue(K3{});
   issue(K0{}); issue(K1{});
@@ -1269,10 +1274,10 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a) {
 #undef PP_END_M
 #undef PP_PIN
     }
-    cell_epilogue_256<STATE, kCellStoreAux, 0>(a, acc, m0, n0, wm, wn, lane);
+    cell_epilogue_256<STATE, kCellStoreAux, 0>(prob ? a2 : a, acc, m0, n0, wm, wn, lane);
     PP_STAMP(4)
     seq += per_xcd;
-    if (!tile_of(seq, m0, n0)) break;
+    if (!tile_of(seq, m0, n0, prob)) break;
   }
   if ((ABL & 128) && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
     for (int k = 0; k < 7; ++k) atomicAdd(&g_lstm_dbg[(wave ? 8 : 0) + k], tacc[k]);
@@ -3957,7 +3962,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
       if (pp == 19) kp = lstm_cell_pp_kernel<true, 9>;
       if (g_lstm_dbg_enable) kp = lstm_cell_pp_kernel<true, 128>;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
+      hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a, a, 1);
       HIP_TRY(hipGetLastError());
       if (t_e0) {
         HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
@@ -3983,6 +3988,57 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
     g_cell_timing.ev.push_back({t_e0, t_e1});
     g_cell_timing.flop.push_back(2.0 * Bn * 4.0 * H * (Kx + H));
+  }
+  return HSAD_OK;
+}
+
+/* Two cells of the same shape in ONE launch (the online and the target net's layer of an acting step: different x / weights / bias,
+ * possibly the same h_prev16 and c_prev; problem B usually writes only its bf16 output).  Falls back to two launches of
+ * hsad_lstm_cell_fused when the phase-interleaved 256 x 256 kernel does not apply (rows % 256, rows < 4096, 4H % 256, variant switch).
+ * Same bits as two launches. */
+int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a, const void* x16_b, const void* h_prev16_a, const void* h_prev16_b,
+                              const void* Wcat_a, const void* Wcat_b, const float* bias_a, const float* bias_b, const float* c_prev_a,
+                              const float* c_prev_b, float* c_out_a, float* c_out_b, float* h_out32_a, float* h_out32_b, void* h_out16_a,
+                              void* h_out16_b, void* stream) {
+  const bool pp_ok = g_cell_variant.pp() == 1 && g_cell_variant.tile() != 128 && Bn >= 4096 && Bn % 256 == 0 && (4 * H) % 256 == 0 && !g_lstm_dbg_enable &&
+                     x16_a && x16_b && h_prev16_a && h_prev16_b && Wcat_a && Wcat_b && bias_a && bias_b && c_prev_a && c_prev_b &&
+                     (c_out_a || h_out32_a || h_out16_a) && (c_out_b || h_out32_b || h_out16_b) && H >= 64 && H % kBK == 0 && Kx >= kBK && Kx % kBK == 0 &&
+                     ldx % 8 == 0 &&
+                     !(((uintptr_t)x16_a | (uintptr_t)x16_b | (uintptr_t)Wcat_a | (uintptr_t)Wcat_b | (uintptr_t)h_prev16_a | (uintptr_t)h_prev16_b) & 15) &&
+                     ((size_t)Bn + 256) * (size_t)std::max(ldx, 2 * H) * 2 < ((size_t)1 << 32) && (size_t)4 * H * (Kx + H) * 2 < ((size_t)1 << 32);
+  if (!pp_ok) {
+    const int rc = hsad_lstm_cell_fused(Bn, H, Kx, x16_a, ldx, h_prev16_a, Wcat_a, bias_a, c_prev_a, c_out_a, h_out32_a, h_out16_a, stream);
+    if (rc) return rc;
+    return hsad_lstm_cell_fused(Bn, H, Kx, x16_b, ldx, h_prev16_b, Wcat_b, bias_b, c_prev_b, c_out_b, h_out32_b, h_out16_b, stream);
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  LstmCellArgs a{(const bf16_t*)x16_a, (const bf16_t*)h_prev16_a, (const bf16_t*)Wcat_a, bias_a, c_prev_a, c_out_a, h_out32_a, (bf16_t*)h_out16_a, Bn, H, Kx, ldx};
+  LstmCellArgs b{(const bf16_t*)x16_b, (const bf16_t*)h_prev16_b, (const bf16_t*)Wcat_b, bias_b, c_prev_b, c_out_b, h_out32_b, (bf16_t*)h_out16_b, Bn, H, Kx, ldx};
+  hipEvent_t t_e0 = nullptr, t_e1 = nullptr;
+  if (g_cell_timing.on) {
+    HIP_TRY(hipEventCreate(&t_e0));
+    HIP_TRY(hipEventCreate(&t_e1));
+    HIP_TRY(hipEventRecord(t_e0, (hipStream_t)stream));
+  }
+  const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
+  const long tiles = 2L * (4 * H / 256) * (Bn / 256);
+  long grid = std::min<long>(tiles, (long)n_cu);
+  if (grid >= 64) grid &= ~7L;
+  // (a problem without fp32 state outputs has empty descriptors: its state stores are dropped in the address unit)
+  const bool st = c_out_a || h_out32_a || c_out_b || h_out32_b;
+  auto kp = st ? lstm_cell_pp_kernel<true> : lstm_cell_pp_kernel<false>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a, b, 2);
+  HIP_TRY(hipGetLastError());
+  if (t_e0) {
+    HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
+    g_cell_timing.ev.push_back({t_e0, t_e1});
+    g_cell_timing.flop.push_back(2.0 * 2.0 * Bn * 4.0 * H * (Kx + H));
   }
   return HSAD_OK;
 }

@@ -351,6 +351,13 @@ int hsad_lstm_layer_forward(int T, int Bn, int H, float* gates, const void* Whh_
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream);
+/* Two cells of the same shape in ONE launch: problem a and problem b (e.g. the online and the target net's layer of an acting step; b
+ * typically with c_out / h_out32 NULL).  Same bits as two hsad_lstm_cell_fused calls, which is also the fallback when the
+ * phase-interleaved 256 x 256 kernel does not apply (rows < 4096 or rows % 256 != 0). */
+int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a, const void* x16_b, const void* h_prev16_a, const void* h_prev16_b,
+                              const void* Wcat_a, const void* Wcat_b, const float* bias_a, const float* bias_b, const float* c_prev_a,
+                              const float* c_prev_b, float* c_out_a, float* c_out_b, float* h_out32_a, float* h_out32_b, void* h_out16_a,
+                              void* h_out16_b, void* stream);
 /* Developer switch (tests, A/B tools): which kernel hsad_lstm_cell_fused launches.  tile: 0 by size (256 x 256 tiles from 4,096 rows on),
  * 128 | 256 forced; pp: 1 (default) the phase-interleaved k loop (lstm_cell_pp_kernel; rows % 256 == 0), 0 the one-barrier k loop,
  * 11 / 12 / 14 / 19 timing ablations of the former (garbage results).  All real variants give identical bits. */

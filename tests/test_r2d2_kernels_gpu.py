@@ -549,3 +549,34 @@ def test_phase_interleaved_cell_kernel_race_screen():
             assert all(torch.equal(a, bb) for a, bb in zip(*res)), it
     finally:
         _lib.check(lib.hsad_lstm_cell_set_variant(0, 1))
+
+
+@pytest.mark.parametrize("N,H", [(4096, 512), (8192, 256), (3000, 512)])
+def test_fused_cell_pair_launch_equals_two_launches(N, H):
+    """hsad_lstm_cell_fused_pair: the online and the target net's cell of an acting step as ONE launch of two problems (problem b without fp32
+    state outputs, sharing h_prev / c_prev with problem a) -- the same bits as two hsad_lstm_cell_fused launches; 3,000 rows take the
+    fallback (two launches inside)"""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    g = torch.Generator(device=DEV).manual_seed(N * 3 + H)
+    mk16 = lambda *shape: (torch.randn(*shape, generator=g, device=DEV) * 0.5).to(torch.bfloat16)
+    xa, xb, h16 = mk16(N, H), mk16(N, H), mk16(N, H)
+    Wa, Wb = (mk16(4 * H, 2 * H).float() / 16).to(torch.bfloat16), (mk16(4 * H, 2 * H).float() / 16).to(torch.bfloat16)
+    ba, bb = torch.randn(4 * H, generator=g, device=DEV) * 0.1, torch.randn(4 * H, generator=g, device=DEV) * 0.1
+    c0 = torch.randn(N, H, generator=g, device=DEV) * 0.5
+    st = _s(torch.device(DEV))
+    new = lambda dt=torch.float32: torch.full((N, H), 3.0, device=DEV, dtype=dt)
+    c1, h1, oa, ob = new(), new(), new(torch.bfloat16), new(torch.bfloat16)
+    _lib.check(lib.hsad_lstm_cell_fused(N, H, H, xa.data_ptr(), H, h16.data_ptr(), Wa.data_ptr(), ba.data_ptr(), c0.data_ptr(), c1.data_ptr(),
+                                        h1.data_ptr(), oa.data_ptr(), st))
+    _lib.check(lib.hsad_lstm_cell_fused(N, H, H, xb.data_ptr(), H, h16.data_ptr(), Wb.data_ptr(), bb.data_ptr(), c0.data_ptr(), None, None,
+                                        ob.data_ptr(), st))
+    c2, h2, oa2, ob2 = new(), new(), new(torch.bfloat16), new(torch.bfloat16)
+    _lib.check(lib.hsad_lstm_cell_fused_pair(N, H, H, H, xa.data_ptr(), xb.data_ptr(), h16.data_ptr(), h16.data_ptr(), Wa.data_ptr(), Wb.data_ptr(),
+                                             ba.data_ptr(), bb.data_ptr(), c0.data_ptr(), c0.data_ptr(), c2.data_ptr(), None, h2.data_ptr(), None,
+                                             oa2.data_ptr(), ob2.data_ptr(), st))
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c2) and torch.equal(h1, h2) and torch.equal(oa, oa2) and torch.equal(ob, ob2)
+    assert not torch.equal(oa, ob) and float(oa.float().abs().max()) < 1.0
