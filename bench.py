@@ -85,8 +85,8 @@ def fused_traffic_bytes():
 
 
 def cell_traffic_bytes():
-    """HBM bytes per launch of the fused cell kernel inside an acting step (mean of the online pass, which also writes the fp32 state, and
-    the target pass), from the committed PMC passes"""
+    """HBM bytes per launch of the fused cell kernel inside an acting step (one launch = the online net's cell, which also writes the fp32
+    state, and the target net's), from the committed PMC passes"""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["actor"]
         v = [x["hbm_bytes_per_launch"] for k, x in rec.items() if "lstm_cell_pp_kernel" in k]
@@ -301,7 +301,7 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
                                                    "phase-interleaved k loop; the online and the target net's cell of a layer are ONE launch of two problems: 2 launches per step)" % (games * 2, 2048, 1024),
                         "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": cell_traffic_bytes(),
-                        "algorithmic_bytes_per_launch": (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + games * 2 * 512 * 4,
+                        "algorithmic_bytes_per_launch": 2 * (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + 2 * games * 2 * 512 * 4,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
                         "launches_per_step": nl.value / 40.0, "share_of_step": nl.value / 40.0 * ms.value / (dt * 1e3)},
            "observation_path": "packed (bit words + bf16 rows from the env kernel)" if tr.actor.packed_obs else "float32",

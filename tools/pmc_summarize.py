@@ -83,8 +83,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
                 ("learner update: transpose_bf16_kernel", r"transpose_bf16_kernel", None, ""),
                 ("learner update: sum_slabs_kernel", r"sum_slabs_kernel", None, ""),
                 ("learner update: adam_kernel", r"adam_kernel", None, "")],
-    "actor": [("actor step: lstm_cell_pp_kernel<true> (online pass: 32,768 rows x 2048 x 1024, fp32 state + bf16 layer output written)", r"lstm_cell_pp_kernel<true", CELL_ALGO_STATE, ""),
-              ("actor step: lstm_cell_pp_kernel<false> (target pass: bf16 layer output only)", r"lstm_cell_pp_kernel<false", CELL_ALGO_NOSTATE, ""),
+    "actor": [("actor step: lstm_cell_pp_kernel<true> (one launch = the online AND the target net's cell of a layer: 2 x 32,768 rows x 2048 x 1024; "
+               "online pass writes fp32 state + bf16 output, target pass bf16 output only)", r"lstm_cell_pp_kernel<true", CELL_ALGO_STATE + CELL_ALGO_NOSTATE, ""),
               ("actor step: gemm_nt_bf16_kernel<128,128> (input linear / heads)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
               ("actor step: env_kernel<1,2,5> G=16384", r"env_kernel<1, 2, 5>", None, ""),
               ("actor step: cast_pad_bf16_vec8_kernel", r"cast_pad_bf16_vec8_kernel", None, ""),
