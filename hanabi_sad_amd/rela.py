@@ -23,12 +23,18 @@ _MODEL_LOCK = threading.RLock()
 # Replay and writer calls from either side are ordered by the library's stream fence; weight updates (BatchRunner.update_model) are
 # enqueued ON this stream between two rollout steps; pause() / resume() / terminate() join the two streams.
 _ACTOR_STREAMS = {}
+_LIVE_CONTEXTS = {}       # device -> number of Context threads currently issuing on its rollout stream
+
+
+def _dev_key(device):
+    d = torch.device(device)
+    return "%s:%d" % (d.type, d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else 0))
 
 
 def _actor_stream(device):
-    key = str(torch.device(device))
+    key = _dev_key(device)
     if key not in _ACTOR_STREAMS:
-        _ACTOR_STREAMS[key] = torch.cuda.Stream(torch.device(device))
+        _ACTOR_STREAMS[key] = torch.cuda.Stream(torch.device(key))
     return _ACTOR_STREAMS[key]
 
 
@@ -231,7 +237,13 @@ class BatchRunner:
                 skip = bool(getattr(getattr(py_model, "online_net", None), "skip_connect", False))
                 self.online, self.target = CNet(on, self.device, skip_connect=skip), CNet(tg, self.device, skip_connect=skip)    # library-owned nets
                 return
-            st = _ACTOR_STREAMS.get(str(torch.device(self.device)))
+            key = _dev_key(self.device)
+            st = _ACTOR_STREAMS.get(key)
+            if st is not None and not _LIVE_CONTEXTS.get(key, 0):
+                # a rollout stream exists but no Context thread is running: whoever acts next does so on its own current stream --
+                # drain the rollout stream's backlog into this one and update in line
+                torch.cuda.current_stream(st.device).wait_stream(st)
+                st = None
             if st is None:
                 for net, sd in ((self.online, on), (self.target, tg)):
                     for k, v in sd.items():
@@ -336,6 +348,10 @@ class Context:
         except Exception as e:   # surfaced by the next Context call from the driver's thread
             self._error = e
         finally:
+            if self._stream is not None:
+                with _MODEL_LOCK:
+                    key = _dev_key(self._stream.device)
+                    _LIVE_CONTEXTS[key] = max(0, _LIVE_CONTEXTS.get(key, 0) - 1)
             with self._cv:
                 self._done = True
                 self._cv.notify_all()
@@ -384,6 +400,9 @@ class Context:
         if self._thread is None and dev is not None and torch.device(dev).type == "cuda":
             self._stream = _actor_stream(dev)
             self._join_streams(True)          # everything the driver set up so far (envs, nets, replay) precedes the first step
+            with _MODEL_LOCK:
+                key = _dev_key(self._stream.device)
+                _LIVE_CONTEXTS[key] = _LIVE_CONTEXTS.get(key, 0) + 1
         if self._thread is None:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()
