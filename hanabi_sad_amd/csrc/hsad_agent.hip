@@ -719,7 +719,8 @@ struct hsad_r2d2_learner {
   bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
   int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
   bool split_bptt = false;    // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
-  bool fb_split = false;      // layout of the fbsync blocks in use
+  bool proj_bptt = false;     // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3)
+  bool fb_split = false, fb_proj = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
                               // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides
   bool gflat_zero = true;     // the gradient buffer is all zero (creation; optimizer_step clears it behind Adam, as optim.zero_grad() does)
@@ -918,7 +919,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     L->fsync_words[k] = ((size_t)1 << k) * nrb * ((size_t)T + 2) + 4;
     fw += 2 * L->fsync_words[k];
   }
-  L->fbsync_words = (size_t)4 * nrb * ((size_t)T + 2) + 4;      // (twice the two recurrences': the split placement's second counter set)
+  L->fbsync_words = (size_t)6 * nrb * ((size_t)T + 2) + 4;      // (split placement: two counter sets for the two recurrences + a projection stage)
   fw += 2 * L->fbsync_words;
   if (L->sync_buf.need((sw + s1 + fw) * 4)) {
     delete L;
@@ -1001,6 +1002,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   if (bc >= 1 && bc <= 8) L->bchunks = bc;
   L->split_refresh = (fused_fwd & 4) != 0;                      // bit 2: LSTM operands re-derived on the side stream (A/B; slower)
   L->split_bptt = (fused_fwd & 8) != 0;                         // bit 3: split placement of the fused BPTT
+  L->proj_bptt = L->split_bptt && (fused_fwd & 16) != 0;        // bit 4: + projection stage
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   return 0;
 }
@@ -1027,7 +1029,7 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
   if (L->fb_tc)
     for (int f = 0; f < 2; ++f) {
       unsigned v = 0;
-      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? 4 : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? (L->fb_proj ? 6 : 4) : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
       *timed_out |= (int32_t)v;
     }
   {
@@ -1318,6 +1320,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
                               nullptr, st));
       return 0;
     };
+    // split placement / projection stage only when their 16-workgroup groups (2 or 3 per row block) fit the chip
+    const bool use_split = L->split_bptt && nrb_of(B) * 2 * (H / 32) <= L->n_cu;
+    const bool use_proj = use_split && L->proj_bptt && nrb_of(B) * 3 * (H / 32) <= L->n_cu;
     for (int c = nbc - 1; c >= 0; --c) {
       const size_t t0 = (size_t)cut[c];
       const int Tc = cut[c + 1] - cut[c];
@@ -1337,11 +1342,13 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.xchg = L->xchg_b[l];
         r.saved_frag_major = 1;
         r.tail_is_zero = 1;
-        r.xout = (L->split_bptt && k == 0) ? L->xout_b : nullptr;
+        r.xout = (use_split && k == 0) ? L->xout_b : nullptr;
+        r.dO_stage = (use_proj && k == 1) ? L->dO[0] + t0 * B * H : nullptr;
         r.layout_steps = TL;
       }
-      if (L->fb_tc != TL || L->fb_split != L->split_bptt) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
-        L->fb_split = L->split_bptt;
+      if (L->fb_tc != TL || L->fb_split != use_split || L->fb_proj != use_proj) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
+        L->fb_split = use_split;
+        L->fb_proj = use_proj;
         HIP_TRY(hipMemsetAsync(L->fbsync[0], 0, 2 * L->fbsync_words * 4, s));
         L->fbflip = 0;
         L->fb_tc = TL;

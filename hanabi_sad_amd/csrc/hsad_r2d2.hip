@@ -2388,6 +2388,14 @@ struct LstmFusedBwdArgs {
   bf16_t* xout;
   unsigned* xout_counters;
   int split_x;
+  // projection stage (split placement only): a record with proj_only has no recurrence -- per step it forms dO = dG^{l+1}_t W_ih^{l+1} from
+  // the tiles of the layer above (the X stream) and publishes it as fp32 rows dO_out [T,Bn,H] with a written-through store and an
+  // agent-scope counter; the layer below then is an ordinary top-style layer whose dO arrives step by step (dO_counters).  The lower
+  // layer's step loses its X stream (2.3 of 8.3 us) to 16 more workgroups that run ahead with the top layer.
+  float* dO_out;
+  unsigned* dO_out_counters;
+  unsigned* dO_counters;
+  int proj_only;
 };
 
 template <int KB>  // KB = 4H / 32
@@ -2469,6 +2477,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
   };
   const int fast_x = a.split_x ? 0 : fast;
   bool x_ready = false;      // the layer above is known to have published this step's tile (seen by the previous step's poll)
+  bool dO_seen = false;      // ... the projection stage this step's dO rows (seen by this step's poll of the own counter)
   // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
   int swz[4];
 #pragma unroll
@@ -2478,6 +2487,62 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
   // hand-off tiles: k block kbi (32 gate columns) of a row block = one contiguous 2 KB slab [32 rows][32 cols]; this wave's quarter
   const size_t tile_elems = (size_t)KB * 1024;
   const int lane_off = (lane & 15) * 32 + kofs;
+
+  if (a.proj_only) {
+    f32x4* sRed = reinterpret_cast<f32x4*>(s_okp + 4);
+    const int tile = wr * 2 + wu;
+    Frag fr0[KQ], fr1[KQ];
+    for (int t = a.T - 1; t >= 0; --t) {
+      if (!wait_ctr(a.xin_counters + (size_t)t * nrb + rb, 0, nullptr, fast_x, fast_x)) return;
+      const bf16_t* b0 = a.xin + ((size_t)t * nrb + rb) * tile_elems + (size_t)wave * KQ * 1024 + lane_off;
+#pragma unroll
+      for (int it = 0; it < KQ; ++it) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr0[it].w) : "v"(b0 + (size_t)it * 1024));
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(fr1[it].w) : "v"(b0 + (size_t)it * 1024 + 512));
+      }
+      f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
+      constexpr int QI = KQ / 4;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        if (qd == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * QI) : "memory");
+        if (qd == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * QI) : "memory");
+        if (qd == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * QI) : "memory");
+        if (qd == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < KQ; ++it)
+          if (it >= qd * QI && it < (qd + 1) * QI) {
+            asm volatile("" : "+v"(fr0[it].w));
+            asm volatile("" : "+v"(fr1[it].w));
+            p00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, xw0[it].v, p00, 0, 0, 0);
+            p01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr0[it].v, xw1[it].v, p01, 0, 0, 0);
+            p10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, xw0[it].v, p10, 0, 0, 0);
+            p11 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr1[it].v, xw1[it].v, p11, 0, 0, 0);
+          }
+      }
+      sRed[(wave * 4 + 0) * 64 + lane] = p00;
+      sRed[(wave * 4 + 1) * 64 + lane] = p01;
+      sRed[(wave * 4 + 2) * 64 + lane] = p10;
+      sRed[(wave * 4 + 3) * 64 + lane] = p11;
+      __syncthreads();
+      f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const f32x4 v = sRed[(w * 4 + tile) * 64 + lane];
+        accf[0] += v[0];
+        accf[1] += v[1];
+        accf[2] += v[2];
+        accf[3] += v[3];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)      // written through: the reader sits on another XCD
+        __hip_atomic_store(a.dO_out + ((size_t)t * a.Bn + rbase + r) * H + u, accf[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) xchg_signal(a.dO_out_counters + (size_t)t * nrb + rb, 0);
+    }
+    return;
+  }
+  const bool has_dOc = a.dO_counters != nullptr;
 
   for (int t = a.T - 1; t >= 0; --t) {
     // everything the cell backward needs from this block's own saved activations (overlaps the waits)
@@ -2502,7 +2567,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
       for (int r = 0; r < 4; ++r) {
         cc[r] = cv[r];
         cpv[r] = pv[r];
-        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + rbase + r) * H + u] : 0.f;
+        dov[r] = (a.dO && !has_dOc) ? a.dO[((size_t)t * a.Bn + rbase + r) * H + u] : 0.f;
       }
     } else {
 #pragma unroll
@@ -2515,7 +2580,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
         g4[r][3] = gp[96];
         cc[r] = a.cseq[((size_t)t * a.Bn + row) * H + u];
         cpv[r] = t > 0 ? a.cseq[((size_t)(t - 1) * a.Bn + row) * H + u] : (a.c0 ? a.c0[(size_t)row * H + u] : 0.f);
-        dov[r] = a.dO ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
+        dov[r] = (a.dO && !has_dOc) ? a.dO[((size_t)t * a.Bn + row) * H + u] : 0.f;
       }
     }
     f32x4 p00 = f32x4{0.f, 0.f, 0.f, 0.f}, p01 = p00, p10 = p00, p11 = p00;
@@ -2558,8 +2623,10 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     if (t < a.T - 1 || a.has_next) {
       x_ready = false;
       if (t < a.T - 1) {
-        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2, (has_x && t > 0) ? a.xin_counters + (size_t)(t - 1) * nrb + rb : nullptr, fast, fast_x)) return;
+        unsigned* probe = (has_x && t > 0) ? a.xin_counters + (size_t)(t - 1) * nrb + rb : has_dOc ? a.dO_counters + (size_t)t * nrb + rb : nullptr;
+        if (!wait_ctr(a.counters + (size_t)(t + 1) * nrb + rb, 2, probe, fast, has_dOc ? 0 : fast_x)) return;
         x_ready = has_x && t > 0 && s_okp[3] != 0;
+        dO_seen = has_dOc && s_okp[3] != 0;
       } else {
         __syncthreads();
       }
@@ -2601,6 +2668,12 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
       }
       any = true;
       LSTM_STAMP(dbg_base + 3)   // dG tile loads + MFMAs
+    }
+    if (has_dOc) {     // this step's dO rows from the projection stage (it runs ahead with the layer above: normally already seen)
+      if (!dO_seen && !wait_ctr(a.dO_counters + (size_t)t * nrb + rb, 0, nullptr, 0, 0)) return;
+      dO_seen = false;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dov[r] = __hip_atomic_load(a.dO + ((size_t)t * a.Bn + rbase + r) * H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     f32x4 accf = f32x4{0.f, 0.f, 0.f, 0.f};
     if (any) {   // K-split reduction: sRed[wave][tile][lane] (f32x4), tile = wr * 2 + wu
@@ -4535,19 +4608,30 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
   hipStream_t s = (hipStream_t)stream;
   const int nrb = Bn / 32, nunit = H / 32, nsg = nnet * nrb;
   // split placement: every record that feeds a layer below brings a second hand-off buffer (xout)
-  bool split = false;
+  bool split = false, proj = false;
   for (int i = 0; i + 1 < nrec; ++i)
     if ((i + 1) % nlayer && recs[i + 1].WihT_above_blocked && recs[i].xout) split = true;
+  for (int i = 0; i < nrec; ++i)
+    if (recs[i].WihT_above_blocked && recs[i].dO_stage) proj = true;
   if (split)
     for (int i = 0; i + 1 < nrec; ++i)
       if ((i + 1) % nlayer && recs[i + 1].WihT_above_blocked && !recs[i].xout)
         return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: split placement needs xout on every record that feeds a layer below");
-  const int grid = split ? 8 * nunit * ((nsg * nlayer + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
+  if (proj) {
+    if (!split) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: a projection stage (dO_stage) needs the split placement (xout)");
+    for (int i = 0; i < nrec; ++i)
+      if (recs[i].WihT_above_blocked && !recs[i].dO_stage)
+        return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: dO_stage must be given for every record with an X stream, or for none");
+  }
+  // internal records: [net][stage]; with projection stages every layer that has an X stream is preceded by the stage that computes its dO
+  const int nl_int = proj ? 2 * nlayer - 1 : nlayer, nint = nnet * nl_int;
+  if (nint > 6) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: %d pipeline stages per launch (at most 6)", nint);
+  const int grid = split ? 8 * nunit * ((nsg * nl_int + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
   if (grid > device_cus())
     return nfail(HSAD_ERR_INVALID, "fused persistent BPTT launch needs %d co-resident workgroups per XCD, the device has %d", grid / 8, device_cus() / 8);
-  // sync scratch: [group words 2 * R * nrb][step counters R * Tc * nrb][timeout], R = nrec (2 * nrec with split placement: the second
-  // half of the counters belongs to the xout copies)
-  const int R = split ? 2 * nrec : nrec;
+  // sync scratch: [group words 2 * R * nrb][step counters R * TL * nrb][timeout], R = nrec (split placement: 2 * internal records -- the
+  // second half of the counters belongs to the xout copies)
+  const int R = split ? 2 * nint : nrec;
   // (chunks of different lengths share one block layout: the counters of record i start at i * TL * nrb, TL = the longest chunk)
   const int TL = recs[0].layout_steps > Tc ? recs[0].layout_steps : Tc;
   unsigned* sync = (unsigned*)sync_scratch;
@@ -4555,6 +4639,8 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
   const size_t words = seq_sync_words(R, TL, nrb);
   if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
   LstmFusedBwdArgsN m{};
+  int j = 0;                 // internal record index
+  int j_of[6];               // internal index of layer record i
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fused_bwd_rec& r = recs[i];
     const int layer = i % nlayer;
@@ -4562,19 +4648,42 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
       return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: null pointer in record %d (or an X stream on the top layer)", i);
     bf16_t* dG = (bf16_t*)r.dG16;
     if (!r.has_next && !r.tail_is_zero) HIP_TRY(hipMemsetAsync(dG + (size_t)Tc * Bn * 4 * H, 0, (size_t)Bn * 4 * H * 2, s));
-    LstmFusedBwdArgs& q = m.r[i];
+    const bool staged = proj && r.WihT_above_blocked;
+    const int jp = j_of[i ? i - 1 : 0];      // the feeding layer's internal record (valid when r has an X stream)
+    if (staged) {     // the projection stage of this layer
+      LstmFusedBwdArgs& q = m.r[j];
+      q = LstmFusedBwdArgs{};
+      q.WhhT = (const bf16_t*)r.WhhT_blocked;      // (staged into LDS like everywhere; unused)
+      q.xW = (const bf16_t*)r.WihT_above_blocked;
+      q.xin = (const bf16_t*)recs[i - 1].xout;
+      q.xin_counters = counters + (size_t)(nint + jp) * TL * nrb;
+      q.split_x = 1;
+      q.proj_only = 1;
+      q.dO_out = r.dO_stage;
+      q.dO_out_counters = counters + (size_t)j * TL * nrb;
+      q.counters = q.dO_out_counters;
+      q.timeout = counters + (size_t)R * TL * nrb;
+      q.dbg = 0;
+      q.T = Tc;
+      q.Bn = Bn;
+      ++j;
+    }
+    LstmFusedBwdArgs& q = m.r[j];
+    q = LstmFusedBwdArgs{};
+    j_of[i] = j;
     q.WhhT = (const bf16_t*)r.WhhT_blocked;
-    q.xW = (const bf16_t*)r.WihT_above_blocked;
-    q.xin = r.WihT_above_blocked ? (const bf16_t*)(split ? recs[i - 1].xout : recs[i - 1].xchg) : nullptr;
-    q.xin_counters = r.WihT_above_blocked ? counters + (size_t)((split ? nrec : 0) + i - 1) * TL * nrb : nullptr;
-    q.split_x = split && r.WihT_above_blocked;
+    q.xW = staged ? nullptr : (const bf16_t*)r.WihT_above_blocked;
+    q.xin = (r.WihT_above_blocked && !staged) ? (const bf16_t*)(split ? recs[i - 1].xout : recs[i - 1].xchg) : nullptr;
+    q.xin_counters = (r.WihT_above_blocked && !staged) ? counters + (size_t)((split ? nint : 0) + jp) * TL * nrb : nullptr;
+    q.split_x = split && r.WihT_above_blocked && !staged;
     q.gates = r.gates;
     q.cseq = r.cseq;
     q.c0 = r.c_before;
-    q.dO = r.dO;
+    q.dO = staged ? r.dO_stage : r.dO;
+    q.dO_counters = staged ? counters + (size_t)(j - 1) * TL * nrb : nullptr;
     q.dG = dG;
     q.xchg = (bf16_t*)r.xchg;
-    q.counters = counters + (size_t)i * TL * nrb;
+    q.counters = counters + (size_t)j * TL * nrb;
     q.timeout = counters + (size_t)R * TL * nrb;
     q.dc_io = r.dc_io;
     q.dbg = g_lstm_dbg_enable;
@@ -4584,11 +4693,12 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.frag = r.saved_frag_major;
     q.feeds = (layer + 1 < nlayer && recs[i + 1].WihT_above_blocked) ? 1 : 0;
     q.xout = (split && q.feeds) ? (bf16_t*)r.xout : nullptr;
-    q.xout_counters = q.xout ? counters + (size_t)(nrec + i) * TL * nrb : nullptr;
+    q.xout_counters = q.xout ? counters + (size_t)(nint + j) * TL * nrb : nullptr;
+    ++j;
   }
   m.split = split ? 1 : 0;
   m.nnet = nnet;
-  m.nl = nlayer;
+  m.nl = nl_int;
   m.nrb = nrb;
   m.nunit = nunit;
   m.group_words = reinterpret_cast<u64_t*>(sync);

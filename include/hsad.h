@@ -578,6 +578,11 @@ typedef struct hsad_lstm_fused_bwd_rec {
                  * for the weight-gradient GEMMs of the previous time chunk -- the feeding layer publishes its tile a second time, written
                  * through with an agent-scope counter; its own recurrence keeps the L2-local exchange.  Same bits either way.
                  * sync_scratch then holds uint32 [2 * nnet*nlayer*(Tc+2)*Bn/32 + 4]; grid = 8 * (H/32) * ceil(nnet*nlayer*Bn/32 / 8). */
+  float* dO_stage;    /* split placement only (NULL = off), on a record WITH an X stream: fp32 [Tc, Bn, H].  The record's dO = dG^{l+1} W_ih^{l+1} is
+                       * then computed by a projection stage of its own -- H/32 more workgroups per row block, a third pipeline stage between
+                       * the two layers -- written here step by step, and the layer itself runs like a top layer whose dO arrives by counter:
+                       * its step loses the X stream.  Give it for every record with an X stream or for none.  Sync scratch and timeout word
+                       * are laid out for 2 * (records + projection stages). */
   int layout_steps;   /* record 0 only; 0 = Tc.  Chunks of different lengths that share (ping-pong) sync blocks pass the LONGEST chunk length
                        * here: counters and the sticky timeout word then sit at the same place for every launch (read the timeout with
                        * that length), and a launch clears its partner block for any of them. */
@@ -668,6 +673,7 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
  *   bits 16-23 fused BPTT in TWO unequal chunks: steps [n, T) first, the head [0, n) last (0 = equal chunks per bits 8-15) -- the long
  *              chunk's weight gradients run next to the head's recurrence, only the head's are left for the end of the update
+ *   bit 4      with bit 3: the lower layer's dO = dG1 W_ih1 in a projection stage of its own (hsad_lstm_fused_bwd_rec.dO_stage)
  *   bit 3      split placement of the fused BPTT (hsad_lstm_fused_bwd_rec.xout): the two layers of a row block on different XCDs, half of
  *              every XCD free for the chunk-wise weight gradients on the side stream; meant for bits 8-15 >= 2
  *   bit 2      hsad_r2d2_optimizer_step re-derives the LSTM matrices (95 % of the operand bytes) on the learner's side stream, next to the

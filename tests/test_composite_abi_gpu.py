@@ -308,7 +308,8 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
     batch, weight = _rand_batch(T, B, F, A)
     L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
     modes = {"fused": 1 | (1 << 8), "fused fwd + chunked bwd": 3, "fused, BPTT in 2 chunks": 1 | (2 << 8), "chunked": 0,   # (bits 8-15 = BPTT chunks; 0 keeps the last setting)
-             "fused, split placement": 9 | (1 << 8), "fused, split placement, 2 chunks": 9 | (2 << 8)}
+             "fused, split placement": 9 | (1 << 8), "fused, split placement, 2 chunks": 9 | (2 << 8),
+             "fused, split placement + projection stage": 25 | (1 << 8), "fused, split + projection, 2 chunks": 25 | (2 << 8)}
     res = {}
     for rep in range(2):
         for name, flags in modes.items():
@@ -337,6 +338,11 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
         assert relerr(res["fused"][2][k], res["fused, BPTT in 2 chunks"][2][k]) < 1e-4, k
     # split placement (the two layers of a row block on different XCDs, second written-through hand-off copy): the same arithmetic in the
     # same order -> loss, priorities and the deterministic LSTM weight gradients are the SAME BITS as with both layers on one XCD
+    # projection stage: dO of the lower layer is summed over the K split separately from the layer's own stream -- another fp32 order
+    for a, b in (("fused", "fused, split placement + projection stage"), ("fused, BPTT in 2 chunks", "fused, split + projection, 2 chunks")):
+        assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
+        for k in gc:
+            assert relerr(res[a][2][k], res[b][2][k]) < 3e-4, (b, k, relerr(res[a][2][k], res[b][2][k]))    # (bf16 roundings of dG flip)
     for a, b in (("fused", "fused, split placement"), ("fused, BPTT in 2 chunks", "fused, split placement, 2 chunks")):
         assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
         for k in gc:

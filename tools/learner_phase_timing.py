@@ -10,6 +10,8 @@ F, H, A, T, B = 838, 512, 21, 80, 128
 lib = _lib.load_library()
 W = init_weights(F, H, A, 5, 1)
 L = CompositeLearner(W, W, 3, 0.999, device="cuda:0")
+if len(sys.argv) > 1:
+    L.set_fused(int(sys.argv[1], 0))
 batch, weight = _rand_batch(T, B, F, A)
 for _ in range(3):
     L.loss(batch, weight, 0.0); L.optimizer_step()
