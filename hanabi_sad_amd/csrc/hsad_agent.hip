@@ -718,8 +718,8 @@ struct hsad_r2d2_learner {
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
   int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
-  bool split_bptt = false;    // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
-  bool proj_bptt = false;     // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3)
+  bool split_bptt = true;     // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
+  bool proj_bptt = true;      // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3): default, 1.51 -> 1.46 ms
   bool fb_split = false, fb_proj = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
                               // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides

@@ -665,7 +665,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
                              float lr, float eps, float grad_clip, hsad_r2d2_learner** out);
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* learner);
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int wgrad_split);
-/* Recurrence schedule of a learner (flags; the default is 1 with one BPTT chunk).  Synchronises.
+/* Recurrence schedule of a learner (flags; the default is 0x19 = bits 0, 3, 4 with one BPTT chunk: bits 3 / 4 fall back to off when their
+ * 16-workgroup groups -- 2 / 3 per 32-row block -- do not fit the chip).  Synchronises.
  *   bit 0      the forward recurrences of hsad_r2d2_loss_fwd run as whole-sequence fused launches (hsad_lstm_forward_fused: projection inside
  *              the recurrence, layers one step apart, online + target net together) and BPTT as hsad_lstm_backward_fused launches (both layers,
  *              dO of the lower layer inside its recurrence) when the shape allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s

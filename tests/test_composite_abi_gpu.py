@@ -365,12 +365,13 @@ def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
     W, Wt = _rand_net(F, H, A, seed=21), _rand_net(F, H, A, seed=22)
     batch, weight = _rand_batch(T, B, F, A, seed=5)
     L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
-    ref_lp, ref_g = None, {}          # loss / priorities: one reference for everything; weight gradients: per chunk count (the chunks' partial
+    ref_lp, ref_g = None, {}          # loss / priorities: one reference for everything; weight gradients: per chunk count / stage layout (partial
     try:                              # sums are added up in another order)
-        for flags, cross, reps in ((1 | (1 << 8), 0, 150), (9 | (1 << 8), 0, 80), (9 | (2 << 8), 0, 50), (1 | (1 << 8), 1, 40), (9 | (1 << 8), 1, 40)):
+        for flags, cross, reps in ((1 | (1 << 8), 0, 150), (9 | (1 << 8), 0, 80), (9 | (2 << 8), 0, 50), (1 | (1 << 8), 1, 40), (9 | (1 << 8), 1, 40),
+                                   (25 | (1 << 8), 0, 120), (25 | (1 << 8), 1, 40)):
             _lib.check(lib.hsad_lstm_set_exchange_mode(cross))
             L.set_fused(flags)
-            chunks = (flags >> 8) & 0xff
+            chunks = ((flags >> 8) & 0xff) + 100 * ((flags >> 4) & 1)      # (the projection stage sums dO in another order)
             bad = torch.zeros((), dtype=torch.int64, device=DEV)
             for it in range(reps):
                 loss, prio = L.loss(batch, weight, 0.25)
