@@ -207,7 +207,7 @@ class CompositeLearner:
         self.h, self.shape = None, None
         self.flat = self.online.flat
         self.chunks, self.wgrad_split = 4, 8
-        self.fused = True          # whole-sequence fused forward recurrences when the shape allows (hsad_r2d2_learner_set_fused)
+        self.fused = self.FUSED_DEFAULT    # flag word of hsad_r2d2_learner_set_fused: fused recurrences, split placement + projection stage in the BPTT
         self.grad = {}
         if T is not None:
             self._ensure(T, rows)
@@ -229,10 +229,12 @@ class CompositeLearner:
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.online.h, i), self.lib.hsad_r2d2_net_param_size(self.online.h, i)
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
 
+    FUSED_DEFAULT = 0x19 | (1 << 8)
+
     def set_fused(self, on):
-        """fused forward recurrences on / off (off = the chunk-pipelined schedule, the A/B reference of the fused kernels); 3 = fused
-        forward with the joint two-recurrence BPTT launches instead of the two stream chains (A/B of the backward schedule)"""
-        self.fused = int(on)
+        """True = the default schedule; False / 0 = the chunk-pipelined schedule of rounds 1-2 (the A/B reference of the fused kernels);
+        any other int = the flag word of hsad_r2d2_learner_set_fused (include/hsad.h)"""
+        self.fused = self.FUSED_DEFAULT if on is True else int(on)
         if self.h is not None:
             _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
 
