@@ -26,7 +26,9 @@ FUSED_FWD_ALGO = 8 * 2048 * 512 * 2 + 2 * _MH * 2 + 4 * _MH * 2 + 2 * (_MH * 4 *
 _NH = 32768 * 512
 CELL_ALGO_NOSTATE = 2 * _NH * 2 + 2048 * 1024 * 2 + _NH * 4 + _NH * 2
 CELL_ALGO_STATE = CELL_ALGO_NOSTATE + 2 * _NH * 4
-FUSED_BWD_ALGO = 3 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + 2 * _MH * 4 * 2
+# (+ the default schedule's split placement / projection stage: the top layer's second, written-through tile copy and the fp32 dO rows of
+# the projection stage, written once and read once)
+FUSED_BWD_ALGO = 3 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + 2 * _MH * 4 * 2 + _MH * 4 * 2 + 2 * _MH * 4
 
 
 def per_kernel(path, counter):
