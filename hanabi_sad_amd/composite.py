@@ -229,7 +229,7 @@ class CompositeLearner:
             o, sz = self.lib.hsad_r2d2_net_param_offset(self.online.h, i), self.lib.hsad_r2d2_net_param_size(self.online.h, i)
             self.grad[name] = self.gflat[o:o + sz].view(self.online.w[name].shape)
 
-    FUSED_DEFAULT = 0x19 | (1 << 8)
+    FUSED_DEFAULT = 0x39 | (1 << 8)
 
     def set_fused(self, on):
         """True = the default schedule; False / 0 = the chunk-pipelined schedule of rounds 1-2 (the A/B reference of the fused kernels);

@@ -720,7 +720,8 @@ struct hsad_r2d2_learner {
   int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
   bool split_bptt = true;     // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
   bool proj_bptt = true;      // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3): default, 1.51 -> 1.46 ms
-  bool fb_split = false, fb_proj = false;      // layout of the fbsync blocks in use
+  bool sink_bptt = true;      // ... and the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage (set_fused bit 5; needs bits 3, 4)
+  bool fb_split = false, fb_proj = false, fb_sink = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
                               // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides
   bool gflat_zero = true;     // the gradient buffer is all zero (creation; optimizer_step clears it behind Adam, as optim.zero_grad() does)
@@ -738,7 +739,7 @@ struct hsad_r2d2_learner {
   float *heads, *heads_t, *q, *qa, *tqa, *qa_s, *tqa_s, *err, *dqa, *dqa_r, *w_r, *xs, *qscratch;
   int64_t* greedy;
   // backward
-  bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL], *xout_b = nullptr;
+  bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL], *xout_b = nullptr, *xout_b2 = nullptr;
   int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
   float *dO[kMaxL], *dc[kMaxL], *wgrad_ws, *wgrad_ws2;
   bf16_t* dGT2;           // second transposed-gradient operand: layer 0's weight gradients on the main stream next to layer 1's on the side stream
@@ -867,6 +868,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     want(&L->xchg_b[l], pipe0 ? xb * 2 : 256);
   }
   want(&L->xout_b, pipe0 ? xb * 2 : 256);      // second hand-off buffer of the top layer (split placement of the fused BPTT)
+  want(&L->xout_b2, pipe0 ? xb * 2 : 256);     // ... and of the lower layer (sink stage)
   want(&L->dx1, M * H * 2);
   want(&L->x1T, H * Mp * 2);
   if (nfc == 2) {
@@ -919,7 +921,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     L->fsync_words[k] = ((size_t)1 << k) * nrb * ((size_t)T + 2) + 4;
     fw += 2 * L->fsync_words[k];
   }
-  L->fbsync_words = (size_t)6 * nrb * ((size_t)T + 2) + 4;      // (split placement: two counter sets for the two recurrences + a projection stage)
+  L->fbsync_words = (size_t)8 * nrb * ((size_t)T + 2) + 4;      // (split placement: two counter sets for the two recurrences + a projection stage)
   fw += 2 * L->fbsync_words;
   if (L->sync_buf.need((sw + s1 + fw) * 4)) {
     delete L;
@@ -1003,6 +1005,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->split_refresh = (fused_fwd & 4) != 0;                      // bit 2: LSTM operands re-derived on the side stream (A/B; slower)
   L->split_bptt = (fused_fwd & 8) != 0;                         // bit 3: split placement of the fused BPTT
   L->proj_bptt = L->split_bptt && (fused_fwd & 16) != 0;        // bit 4: + projection stage
+  L->sink_bptt = L->proj_bptt && (fused_fwd & 32) != 0;         // bit 5: + sink stage (input layer's d x)
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   return 0;
 }
@@ -1029,7 +1032,7 @@ int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
   if (L->fb_tc)
     for (int f = 0; f < 2; ++f) {
       unsigned v = 0;
-      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? (L->fb_proj ? 6 : 4) : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? (L->fb_proj ? (L->fb_sink ? 8 : 6) : 4) : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
       *timed_out |= (int32_t)v;
     }
   {
@@ -1284,6 +1287,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;
   bool defer_l0 = false;
   int input_done_above = 0;          // steps >= this have their input-layer backward done on the side stream (0 = none)
+  bool sink_used = false;            // the BPTT launch(es) already wrote d x of the input layer (sink stage)
   const bool fbwd = pipe && L->fused_bwd && L->fwd_frag && B % 32 == 0 && 2 * (H / 32) * ((nrb_of(B) + 7) / 8) <= L->n_cu / 8 && nbc <= 8;
   if (fbwd) {
     // Both layers of a time chunk in ONE persistent launch (hsad_lstm_backward_fused): layer 0 runs a step behind layer 1 and computes
@@ -1313,8 +1317,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     const bool chunk_input = nfc == 1 && nbc > 1 && M % 4 == 0 && H % 4 == 0 && L->wgrad_split > 1;
     auto input_chunk = [=](int c, void* st) -> int {
       const size_t m0 = (size_t)cut[c] * B, Mc = (size_t)(cut[c + 1] - cut[c]) * B;
-      CK(hsad_gemm_nt_bf16_ex(L->dG[0] + m0 * H4, H4, on->WihT[0], H4, (int)Mc, H, H4, nullptr, nullptr, 0, L->dx1 + m0 * H, H, 0, 0, 1,
-                              L->xin[0] + m0 * H, H, nullptr, st));
+      if (!(L->sink_bptt && L->proj_bptt && L->split_bptt && nrb_of(B) * 4 * (H / 32) <= L->n_cu))
+        CK(hsad_gemm_nt_bf16_ex(L->dG[0] + m0 * H4, H4, on->WihT[0], H4, (int)Mc, H, H4, nullptr, nullptr, 0, L->dx1 + m0 * H, H, 0, 0, 1,
+                                L->xin[0] + m0 * H, H, nullptr, st));
       CK(transpose16(L->dx1 + m0 * H, (int)Mc, H, H, L->dx1T + m0, Mp, g[on->iB1], nullptr, nullptr, st));
       CK(hsad_gemm_nt_bf16_ex(L->dx1T + m0, Mp, L->a16T + m0, Mp, H, F, (int)Mc, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0,
                               nullptr, st));
@@ -1323,6 +1328,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     // split placement / projection stage only when their 16-workgroup groups (2 or 3 per row block) fit the chip
     const bool use_split = L->split_bptt && nrb_of(B) * 2 * (H / 32) <= L->n_cu;
     const bool use_proj = use_split && L->proj_bptt && nrb_of(B) * 3 * (H / 32) <= L->n_cu;
+    const bool use_sink = use_proj && L->sink_bptt && nrb_of(B) * 4 * (H / 32) <= L->n_cu;
+    sink_used = use_sink;
     for (int c = nbc - 1; c >= 0; --c) {
       const size_t t0 = (size_t)cut[c];
       const int Tc = cut[c + 1] - cut[c];
@@ -1344,11 +1351,17 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.tail_is_zero = 1;
         r.xout = (use_split && k == 0) ? L->xout_b : nullptr;
         r.dO_stage = (use_proj && k == 1) ? L->dO[0] + t0 * B * H : nullptr;
+        const bool snk = use_sink && k == 1;
+        r.sink_WT = snk ? on->WihT[0] : nullptr;
+        r.sink_out16 = snk ? (nfc == 2 ? L->dx2 : L->dx1) + t0 * B * H : nullptr;
+        r.sink_mask16 = snk ? L->xin[0] + t0 * B * H : nullptr;
+        r.sink_xout = snk ? L->xout_b2 : nullptr;
         r.layout_steps = TL;
       }
-      if (L->fb_tc != TL || L->fb_split != use_split || L->fb_proj != use_proj) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
+      if (L->fb_tc != TL || L->fb_split != use_split || L->fb_proj != use_proj || L->fb_sink != use_sink) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
         L->fb_split = use_split;
         L->fb_proj = use_proj;
+        L->fb_sink = use_sink;
         HIP_TRY(hipMemsetAsync(L->fbsync[0], 0, 2 * L->fbsync_words * 4, s));
         L->fbflip = 0;
         L->fb_tc = TL;
@@ -1434,7 +1447,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   bf16_t* dxlT = nfc == 2 ? L->dx2T : L->dx1T;
   if (input_done_above > 0) {      // one fc layer, chunked BPTT: only the head chunk's rows are left
     const int Mh = input_done_above * B;
-    CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, Mh, H, H4, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
+    if (!sink_used)
+      CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, Mh, H, H4, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
     CK(transpose16(L->dx1, Mh, H, H, L->dx1T, Mp, g[on->iB1], nullptr, nullptr, stream));
     CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mh, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
     if (defer_l0) CK(chunk_wgrad(0, 0, stream, L->dGT2, L->wgrad_ws2));
@@ -1444,7 +1458,8 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     }
     return 0;
   }
-  CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, dxl, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
+  if (!sink_used)
+    CK(hsad_gemm_nt_bf16_ex(L->dG[0], H4, on->WihT[0], H4, M, H, H4, nullptr, nullptr, 0, dxl, H, 0, 0, 1, L->xin[0], H, nullptr, stream));
   const bool fast_cs = M % 4 == 0 && H % 4 == 0;
   if (nfc == 2) {
     if (fast_cs) {

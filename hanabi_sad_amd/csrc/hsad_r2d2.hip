@@ -2396,6 +2396,11 @@ struct LstmFusedBwdArgs {
   unsigned* dO_out_counters;
   unsigned* dO_counters;
   int proj_only;
+  // sink variant of a projection stage (below the LAST layer): the product is the gradient wrt the layer's input sequence, written as bf16
+  // rows [T,Bn,H] with the ReLU mask of that input applied (mask16 > 0) -- what the input-MLP backward GEMM produced after the launch.
+  // Read after the launch by ordinary kernels: plain stores, no counter.
+  bf16_t* dx_out16;
+  const bf16_t* dx_mask16;
 };
 
 template <int KB>  // KB = 4H / 32
@@ -2532,6 +2537,16 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
         accf[1] += v[1];
         accf[2] += v[2];
         accf[3] += v[3];
+      }
+      if (a.dx_out16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t o = ((size_t)t * a.Bn + rbase + r) * H + u;
+          const bool on = !a.dx_mask16 || bf2f(a.dx_mask16[o]) > 0.f;
+          a.dx_out16[o] = on ? f2bf(accf[r]) : (bf16_t)0;
+        }
+        __syncthreads();       // (sRed is rewritten by the next step)
+        continue;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r)      // written through: the reader sits on another XCD
@@ -4624,7 +4639,18 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
         return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: dO_stage must be given for every record with an X stream, or for none");
   }
   // internal records: [net][stage]; with projection stages every layer that has an X stream is preceded by the stage that computes its dO
-  const int nl_int = proj ? 2 * nlayer - 1 : nlayer, nint = nnet * nl_int;
+  // ... and a sink stage below the last layer (sink_WT on that record): the gradient wrt the layer's input sequence
+  bool sink = false;
+  for (int i = 0; i < nrec; ++i)
+    if (recs[i].sink_WT) {
+      if (!proj || i % nlayer != nlayer - 1 || !recs[i].sink_out16 || !recs[i].sink_xout)
+        return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: a sink stage belongs to the last layer's record, with sink_out16 and sink_xout, next to projection stages");
+      sink = true;
+    }
+  if (sink)
+    for (int n = 0; n < nnet; ++n)
+      if (!recs[n * nlayer + nlayer - 1].sink_WT) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: sink stage on every net or on none");
+  const int nl_int = (proj ? 2 * nlayer - 1 : nlayer) + (sink ? 1 : 0), nint = nnet * nl_int;
   if (nint > 6) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: %d pipeline stages per launch (at most 6)", nint);
   const int grid = split ? 8 * nunit * ((nsg * nl_int + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
   if (grid > device_cus())
@@ -4691,10 +4717,27 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.Bn = Bn;
     q.has_next = r.has_next;
     q.frag = r.saved_frag_major;
-    q.feeds = (layer + 1 < nlayer && recs[i + 1].WihT_above_blocked) ? 1 : 0;
-    q.xout = (split && q.feeds) ? (bf16_t*)r.xout : nullptr;
+    q.feeds = ((layer + 1 < nlayer && recs[i + 1].WihT_above_blocked) || (sink && layer == nlayer - 1)) ? 1 : 0;
+    q.xout = (split && q.feeds) ? (bf16_t*)(layer == nlayer - 1 ? r.sink_xout : r.xout) : nullptr;
     q.xout_counters = q.xout ? counters + (size_t)(nint + j) * TL * nrb : nullptr;
     ++j;
+    if (sink && layer == nlayer - 1) {      // the sink stage of this net
+      LstmFusedBwdArgs& z = m.r[j];
+      z = LstmFusedBwdArgs{};
+      z.WhhT = (const bf16_t*)r.WhhT_blocked;      // (staged into LDS like everywhere; unused)
+      z.xW = (const bf16_t*)r.sink_WT;
+      z.xin = (const bf16_t*)r.sink_xout;
+      z.xin_counters = counters + (size_t)(nint + j - 1) * TL * nrb;
+      z.split_x = 1;
+      z.proj_only = 1;
+      z.dx_out16 = (bf16_t*)r.sink_out16;
+      z.dx_mask16 = (const bf16_t*)r.sink_mask16;
+      z.counters = counters + (size_t)j * TL * nrb;
+      z.timeout = counters + (size_t)R * TL * nrb;
+      z.T = Tc;
+      z.Bn = Bn;
+      ++j;
+    }
   }
   m.split = split ? 1 : 0;
   m.nnet = nnet;

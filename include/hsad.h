@@ -583,6 +583,14 @@ typedef struct hsad_lstm_fused_bwd_rec {
                        * the two layers -- written here step by step, and the layer itself runs like a top layer whose dO arrives by counter:
                        * its step loses the X stream.  Give it for every record with an X stream or for none.  Sync scratch and timeout word
                        * are laid out for 2 * (records + projection stages). */
+  /* sink stage (with projection stages only; on the LAST layer's record of every net, or of none): the gradient wrt the layer's input
+   * sequence, dG W_ih (sink_WT = W_ih^T of THIS layer, blocked like WihT_above_blocked), as one more pipeline stage that writes bf16 rows
+   * sink_out16 [Tc, Bn, H], zero where sink_mask16 [Tc, Bn, H] (bf16; NULL = no mask) is not > 0 -- the input-MLP backward GEMM with its
+   * ReLU mask, off the tail of the update.  sink_xout: a hand-off buffer like xout for this layer's tiles. */
+  const void* sink_WT;
+  void* sink_out16;
+  const void* sink_mask16;
+  void* sink_xout;
   int layout_steps;   /* record 0 only; 0 = Tc.  Chunks of different lengths that share (ping-pong) sync blocks pass the LONGEST chunk length
                        * here: counters and the sticky timeout word then sit at the same place for every launch (read the timeout with
                        * that length), and a launch clears its partner block for any of them. */
@@ -665,8 +673,8 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
                              float lr, float eps, float grad_clip, hsad_r2d2_learner** out);
 void hsad_r2d2_learner_destroy(hsad_r2d2_learner* learner);
 int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int wgrad_split);
-/* Recurrence schedule of a learner (flags; the default is 0x19 = bits 0, 3, 4 with one BPTT chunk: bits 3 / 4 fall back to off when their
- * 16-workgroup groups -- 2 / 3 per 32-row block -- do not fit the chip).  Synchronises.
+/* Recurrence schedule of a learner (flags; the default is 0x39 = bits 0, 3, 4, 5 with one BPTT chunk: bits 3 / 4 / 5 fall back to off when
+ * their 16-workgroup groups -- 2 / 3 / 4 per 32-row block -- do not fit the chip).  Synchronises.
  *   bit 0      the forward recurrences of hsad_r2d2_loss_fwd run as whole-sequence fused launches (hsad_lstm_forward_fused: projection inside
  *              the recurrence, layers one step apart, online + target net together) and BPTT as hsad_lstm_backward_fused launches (both layers,
  *              dO of the lower layer inside its recurrence) when the shape allows (H in {256, 512}, rows % 32 == 0, a (net, row block)'s
@@ -674,6 +682,7 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
  *   bits 16-23 fused BPTT in TWO unequal chunks: steps [n, T) first, the head [0, n) last (0 = equal chunks per bits 8-15) -- the long
  *              chunk's weight gradients run next to the head's recurrence, only the head's are left for the end of the update
+ *   bit 5      with bits 3, 4: the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage of the BPTT launch (one fc layer)
  *   bit 4      with bit 3: the lower layer's dO = dG1 W_ih1 in a projection stage of its own (hsad_lstm_fused_bwd_rec.dO_stage)
  *   bit 3      split placement of the fused BPTT (hsad_lstm_fused_bwd_rec.xout): the two layers of a row block on different XCDs, half of
  *              every XCD free for the chunk-wise weight gradients on the side stream; meant for bits 8-15 >= 2

@@ -309,7 +309,8 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
     L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
     modes = {"fused": 1 | (1 << 8), "fused fwd + chunked bwd": 3, "fused, BPTT in 2 chunks": 1 | (2 << 8), "chunked": 0,   # (bits 8-15 = BPTT chunks; 0 keeps the last setting)
              "fused, split placement": 9 | (1 << 8), "fused, split placement, 2 chunks": 9 | (2 << 8),
-             "fused, split placement + projection stage": 25 | (1 << 8), "fused, split + projection, 2 chunks": 25 | (2 << 8)}
+             "fused, split placement + projection stage": 25 | (1 << 8), "fused, split + projection, 2 chunks": 25 | (2 << 8),
+             "fused, split + projection + sink stage": 57 | (1 << 8), "fused, split + projection + sink, 2 chunks": 57 | (2 << 8)}
     res = {}
     for rep in range(2):
         for name, flags in modes.items():
@@ -339,7 +340,9 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
     # split placement (the two layers of a row block on different XCDs, second written-through hand-off copy): the same arithmetic in the
     # same order -> loss, priorities and the deterministic LSTM weight gradients are the SAME BITS as with both layers on one XCD
     # projection stage: dO of the lower layer is summed over the K split separately from the layer's own stream -- another fp32 order
-    for a, b in (("fused", "fused, split placement + projection stage"), ("fused, BPTT in 2 chunks", "fused, split + projection, 2 chunks")):
+    # (sink stage: d x of the input layer summed over the K split per wave instead of in the GEMM's k order, then rounded to bf16)
+    for a, b in (("fused", "fused, split placement + projection stage"), ("fused, BPTT in 2 chunks", "fused, split + projection, 2 chunks"),
+                 ("fused", "fused, split + projection + sink stage"), ("fused, BPTT in 2 chunks", "fused, split + projection + sink, 2 chunks")):
         assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
         for k in gc:
             assert relerr(res[a][2][k], res[b][2][k]) < 3e-4, (b, k, relerr(res[a][2][k], res[b][2][k]))    # (bf16 roundings of dG flip)
@@ -368,10 +371,10 @@ def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
     ref_lp, ref_g = None, {}          # loss / priorities: one reference for everything; weight gradients: per chunk count / stage layout (partial
     try:                              # sums are added up in another order)
         for flags, cross, reps in ((1 | (1 << 8), 0, 150), (9 | (1 << 8), 0, 80), (9 | (2 << 8), 0, 50), (1 | (1 << 8), 1, 40), (9 | (1 << 8), 1, 40),
-                                   (25 | (1 << 8), 0, 120), (25 | (1 << 8), 1, 40)):
+                                   (25 | (1 << 8), 0, 60), (57 | (1 << 8), 0, 120), (57 | (1 << 8), 1, 40)):
             _lib.check(lib.hsad_lstm_set_exchange_mode(cross))
             L.set_fused(flags)
-            chunks = ((flags >> 8) & 0xff) + 100 * ((flags >> 4) & 1)      # (the projection stage sums dO in another order)
+            chunks = ((flags >> 8) & 0xff) + 100 * ((flags >> 4) & 3)      # (the projection / sink stages sum in another order)
             bad = torch.zeros((), dtype=torch.int64, device=DEV)
             for it in range(reps):
                 loss, prio = L.loss(batch, weight, 0.25)
