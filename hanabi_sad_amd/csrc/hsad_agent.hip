@@ -731,7 +731,8 @@ struct hsad_r2d2_learner {
   Buf arena, opt, sync_buf;
   float *gflat, *m, *v, *osc;
   hipStream_t side = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_e = nullptr;
+  bool pre_T = false;         // loss_fwd already issued the transposes of the forward activations on the side stream
   // activations (q = 0 online, 1 target).  xin = the LSTM's input = the last layer of the input MLP (x1, or x2 with two fc layers)
   bf16_t *a16, *x1[2], *x2[2], *xin[2], *hseq[2][kMaxL], *xchg_f[2][kMaxL], *zero16, *sc16;
   const bf16_t* a16_in = nullptr;  // the input operand of the update in flight: a16 (cast here) or the caller's bf16 batch
@@ -957,7 +958,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   }
   if (hipStreamCreateWithFlags(&L->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L->ev_a, learner_event_flags()) != hipSuccess ||
       hipEventCreateWithFlags(&L->ev_b, learner_event_flags()) != hipSuccess || hipEventCreateWithFlags(&L->ev_c, learner_event_flags()) != hipSuccess ||
-      hipEventCreateWithFlags(&L->ev_d, learner_event_flags()) != hipSuccess) {
+      hipEventCreateWithFlags(&L->ev_d, learner_event_flags()) != hipSuccess || hipEventCreateWithFlags(&L->ev_e, learner_event_flags()) != hipSuccess) {
     delete L;
     return afail(HSAD_ERR_HIP, "r2d2_learner_create: stream / event creation failed");
   }
@@ -970,7 +971,7 @@ void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
   if (L->side) (void)hipStreamDestroy(L->side);
   for (int i = 0; i < 8; ++i)
     if (L->ev_ck[i]) (void)hipEventDestroy(L->ev_ck[i]);
-  for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c, L->ev_d})
+  for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c, L->ev_d, L->ev_e})
     if (e) (void)hipEventDestroy(e);
   delete L;
 }
@@ -1155,6 +1156,19 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
   }
   // heads, Q-values, double-DQN target
   // (the two head layers are one pair launch: N = A + 1 + 3 hand columns, one problem alone is 80 workgroups)
+  // With a backward pass to follow: the transposed copies of the forward activations (operands of the weight-gradient GEMMs) start NOW on
+  // the side stream, next to the heads / loss chain -- once the BPTT launch holds every CU they would wait for its end
+  L->pre_T = false;
+  if (want_grad && can_pipeline(L) && L->side && L->Mp == M) {
+    void* wst = (void*)L->side;
+    HIP_TRY(hipEventRecord(L->ev_e, s));
+    HIP_TRY(hipStreamWaitEvent(L->side, L->ev_e, 0));
+    for (int l = 0; l < NL; ++l) CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l] + B, B + M, nullptr, nullptr, nullptr, wst));
+    CK(transpose16(L->x1[0], M, H, H, L->x1T, L->Mp, nullptr, nullptr, nullptr, wst));
+    if (nfc == 2) CK(transpose16(L->x2[0], M, H, H, L->x2T, L->Mp, nullptr, nullptr, nullptr, wst));
+    CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, L->Mp, nullptr, nullptr, nullptr, wst));
+    L->pre_T = true;
+  }
   CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
                             L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
   L->dheads_ready = false;
@@ -1265,7 +1279,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     HIP_TRY(hipEventRecord(L->ev_a, s));
     HIP_TRY(hipStreamWaitEvent(ws, L->ev_a, 0));
   }
-  for (int l = 0; l < NL; ++l) {
+  const bool pre_T = L->pre_T && pipe;      // (issued by loss_fwd on the same side stream)
+  L->pre_T = false;
+  for (int l = 0; l < NL && !pre_T; ++l) {
     // (the first B columns of the delayed copy -- h_{-1} = 0 -- are zero since the arena was created and nothing writes them)
     if (pipe) {
       CK(transpose16(L->hseq[0][l], M, H, H, L->hsT[l] + B, B + M, nullptr, nullptr, nullptr, wst));
@@ -1274,14 +1290,18 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
       if (M > B) CK(transpose16(L->hseq[0][l], M - B, H, H, L->hpT[l] + B, Mp, nullptr, nullptr, nullptr, wst));
     }
   }
-  CK(transpose16(L->x1[0], M, H, H, L->x1T, Mp, nullptr, nullptr, nullptr, wst));
-  if (nfc == 2) CK(transpose16(L->x2[0], M, H, H, L->x2T, Mp, nullptr, nullptr, nullptr, wst));
+  if (!pre_T) {
+    CK(transpose16(L->x1[0], M, H, H, L->x1T, Mp, nullptr, nullptr, nullptr, wst));
+    if (nfc == 2) CK(transpose16(L->x2[0], M, H, H, L->x2T, Mp, nullptr, nullptr, nullptr, wst));
+  }
   const bf16_t* xinT = nfc == 2 ? L->x2T : L->x1T;
-  CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
+  if (!pre_T) CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, Mp, nullptr, nullptr, nullptr, wst));
+  // the transposed operands of the input MLP (x^T, a16^T) exist: recorded BEFORE the heads' weight gradient below, which waits behind the
+  // BPTT launch for a free CU -- the input-MLP chain on the caller's stream must not wait for that
+  if (pipe) HIP_TRY(hipEventRecord(L->ev_d, ws));
   CK(transpose16(L->dheads, M, NHp, NHp, L->dheadsT, Mp, nullptr, nullptr, nullptr, wst));
   CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
   CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
-  if (pipe) HIP_TRY(hipEventRecord(L->ev_d, ws));      // the transposed operands of the input MLP (x^T, a16^T) exist
   int nbc = L->bchunks;
   while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
   std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;
