@@ -720,6 +720,7 @@ struct hsad_r2d2_learner {
   int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
   bool split_bptt = true;     // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
   bool proj_bptt = true;      // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3): default, 1.51 -> 1.46 ms
+  bool dgt_in_kernel = true;  // single-chunk fused BPTT writes dG transposed + the bias gradients itself (set_fused bit 6 = off, A/B)
   bool sink_bptt = true;      // ... and the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage (set_fused bit 5; needs bits 3, 4)
   bool fb_split = false, fb_proj = false, fb_sink = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
@@ -1007,6 +1008,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->split_bptt = (fused_fwd & 8) != 0;                         // bit 3: split placement of the fused BPTT
   L->proj_bptt = L->split_bptt && (fused_fwd & 16) != 0;        // bit 4: + projection stage
   L->sink_bptt = L->proj_bptt && (fused_fwd & 32) != 0;         // bit 5: + sink stage (input layer's d x)
+  L->dgt_in_kernel = !(fused_fwd & 64);                         // bit 6: transpose passes behind the BPTT launch instead (A/B)
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   return 0;
 }
@@ -1324,9 +1326,17 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     for (int c = 0; c < nbc; ++c) TL = std::max(TL, cut[c + 1] - cut[c]);
     if (!L->dc01_zero) HIP_TRY(hipMemsetAsync(L->dc[0], 0, (size_t)2 * B * H * 4, s));
     L->dc01_zero = false;
+    // split placement / projection stage only when their 16-workgroup groups (2 or 3 per row block) fit the chip
+    const bool use_split = L->split_bptt && nrb_of(B) * 2 * (H / 32) <= L->n_cu;
+    const bool use_proj = use_split && L->proj_bptt && nrb_of(B) * 3 * (H / 32) <= L->n_cu;
+    const bool use_sink = use_proj && L->sink_bptt && nrb_of(B) * 4 * (H / 32) <= L->n_cu;
+    sink_used = use_sink;
+    // one chunk: the launch writes dG transposed (and the bias gradients) itself -- no transpose passes in the tail of the update.  The
+    // row-major dG is not written then, so this needs the sink stage (otherwise the input layer's backward GEMM reads dG0 row-major)
+    const bool dgt_in_kernel = nbc == 1 && L->dgt_in_kernel && use_sink;
     chunk_wgrad = [=](int l, int c, void* st, bf16_t* dGT, float* wsp) -> int {
       const size_t m0 = (size_t)cut[c] * B, Mc = (size_t)(cut[c + 1] - cut[c]) * B;
-      CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
+      if (!dgt_in_kernel) CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
       const bf16_t* inT = l ? hs_x[l - 1] + m0 : xinT + m0;
       CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, inT, l ? ldh : Mp, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWih[l]], H, on->perm32, st));
       CK(hsad_gemm_nt_bf16_splitk_acc(dGT, Mp, hs_d[l] + m0, ldh, H4, H, (int)Mc, L->wgrad_split, wsp, g[on->iWhh[l]], H, on->perm32, st));
@@ -1345,11 +1355,6 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
                               nullptr, st));
       return 0;
     };
-    // split placement / projection stage only when their 16-workgroup groups (2 or 3 per row block) fit the chip
-    const bool use_split = L->split_bptt && nrb_of(B) * 2 * (H / 32) <= L->n_cu;
-    const bool use_proj = use_split && L->proj_bptt && nrb_of(B) * 3 * (H / 32) <= L->n_cu;
-    const bool use_sink = use_proj && L->sink_bptt && nrb_of(B) * 4 * (H / 32) <= L->n_cu;
-    sink_used = use_sink;
     for (int c = nbc - 1; c >= 0; --c) {
       const size_t t0 = (size_t)cut[c];
       const int Tc = cut[c + 1] - cut[c];
@@ -1371,6 +1376,11 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.tail_is_zero = 1;
         r.xout = (use_split && k == 0) ? L->xout_b : nullptr;
         r.dO_stage = (use_proj && k == 1) ? L->dO[0] + t0 * B * H : nullptr;
+        r.dGT16 = dgt_in_kernel ? (l == 1 ? L->dGT : L->dGT2) : nullptr;
+        r.ldT = Mp;
+        r.bias_grad0 = dgt_in_kernel ? g[on->iBih[l]] : nullptr;
+        r.bias_grad1 = dgt_in_kernel ? g[on->iBhh[l]] : nullptr;
+        r.bias_col_map = on->perm32;
         const bool snk = use_sink && k == 1;
         r.sink_WT = snk ? on->WihT[0] : nullptr;
         r.sink_out16 = snk ? (nfc == 2 ? L->dx2 : L->dx1) + t0 * B * H : nullptr;

@@ -2401,6 +2401,13 @@ struct LstmFusedBwdArgs {
   // Read after the launch by ordinary kernels: plain stores, no counter.
   bf16_t* dx_out16;
   const bf16_t* dx_mask16;
+  // dGT (optional, instead of the row-major dG copy): the TRANSPOSED gradient tile, dGT[gate column][t * Bn + row] with row stride ldT --
+  // the A operand of the weight-gradient GEMMs as they want it, no transpose pass behind the launch -- and the bias gradients, i.e. the
+  // column sums of dG over rows and steps, added to bsum0 / bsum1 [colmap[column]] at the end of the launch
+  bf16_t* dGT;
+  int ldT;
+  float *bsum0, *bsum1;
+  const int32_t* colmap;
 };
 
 template <int KB>  // KB = 4H / 32
@@ -2483,6 +2490,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
   const int fast_x = a.split_x ? 0 : fast;
   bool x_ready = false;      // the layer above is known to have published this step's tile (seen by the previous step's poll)
   bool dO_seen = false;      // ... the projection stage this step's dO rows (seen by this step's poll of the own counter)
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of this workgroup's dG tiles over all steps (bias gradients), see dGT
   // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
   int swz[4];
 #pragma unroll
@@ -2742,13 +2750,40 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
         if (a.xout) xchg_signal(a.xout_counters + (size_t)t * nrb + rb, 0);
       }
     }
-    // row-major copy for the weight-gradient GEMMs: off the other workgroups' critical path
+    // copy for the weight-gradient GEMMs, off the other workgroups' critical path: transposed (4 consecutive rows of one gate column per
+    // thread: 8 threads = one 64-byte run) with the column sums on the way, or row-major
+    if (a.dGT) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int c = tid + it * 256, r = c >> 5, q = c & 31;
-      *reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + rb * 32 + r) * K + nb * 128 + q * 4) = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 256, j = c >> 3, rg = c & 7;
+        const bf16_t v0 = sG[(rg * 4 + 0) * 136 + j], v1 = sG[(rg * 4 + 1) * 136 + j], v2 = sG[(rg * 4 + 2) * 136 + j], v3 = sG[(rg * 4 + 3) * 136 + j];
+        csum[it] += (bf2f(v0) + bf2f(v1)) + (bf2f(v2) + bf2f(v3));
+        const u64_t pk = (u64_t)v0 | ((u64_t)v1 << 16) | ((u64_t)v2 << 32) | ((u64_t)v3 << 48);
+        *reinterpret_cast<u64_t*>(a.dGT + (size_t)(nb * 128 + j) * a.ldT + (size_t)t * a.Bn + rb * 32 + rg * 4) = pk;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int c = tid + it * 256, r = c >> 5, q = c & 31;
+        *reinterpret_cast<u64_t*>(a.dG + ((size_t)t * a.Bn + rb * 32 + r) * K + nb * 128 + q * 4) = *reinterpret_cast<const u64_t*>(sG + r * 136 + q * 4);
+      }
     }
     LSTM_STAMP(dbg_base + 5)   // publish: stores, drain, signal
+  }
+  if (a.dGT && a.bsum0) {       // bias gradients: this workgroup's 32 rows x all steps of its 128 gate columns
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float v = csum[it];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if ((tid & 7) == 0) {
+        const int col = nb * 128 + ((tid + it * 256) >> 3);
+        const int o = a.colmap ? a.colmap[col] : col;
+        atomicAdd(a.bsum0 + o, v);
+        if (a.bsum1) atomicAdd(a.bsum1 + o, v);
+      }
+    }
   }
   if (a.dc_io) {
 #pragma unroll
@@ -4708,6 +4743,11 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.dO = staged ? r.dO_stage : r.dO;
     q.dO_counters = staged ? counters + (size_t)(j - 1) * TL * nrb : nullptr;
     q.dG = dG;
+    q.dGT = (bf16_t*)r.dGT16;
+    q.ldT = r.ldT;
+    q.bsum0 = r.bias_grad0;
+    q.bsum1 = r.bias_grad1;
+    q.colmap = r.bias_col_map;
     q.xchg = (bf16_t*)r.xchg;
     q.counters = counters + (size_t)j * TL * nrb;
     q.timeout = counters + (size_t)R * TL * nrb;

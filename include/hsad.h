@@ -591,6 +591,14 @@ typedef struct hsad_lstm_fused_bwd_rec {
   void* sink_out16;
   const void* sink_mask16;
   void* sink_xout;
+  /* dGT16 (optional): the gradient wrt the gate pre-activations written TRANSPOSED, bf16 [4H][ldT] with element (gate-blocked column,
+   * t * Bn + row) -- the A operand of the weight-gradient GEMMs, no transpose pass behind the launch -- INSTEAD of the row-major dG16
+   * (which then only serves has_next; use with a single time chunk).  bias_grad0 / bias_grad1 (optional, fp32 [4H]): the column sums of dG
+   * over all rows and steps are ADDED there at [bias_col_map[column]] (bias_col_map NULL = identity): the two LSTM bias gradients. */
+  void* dGT16;
+  int ldT;
+  float *bias_grad0, *bias_grad1;
+  const int32_t* bias_col_map;
   int layout_steps;   /* record 0 only; 0 = Tc.  Chunks of different lengths that share (ping-pong) sync blocks pass the LONGEST chunk length
                        * here: counters and the sticky timeout word then sit at the same place for every launch (read the timeout with
                        * that length), and a launch clears its partner block for any of them. */
@@ -682,6 +690,8 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *   bit 1      with bit 0: keep the chunk-pipelined BPTT (A/B of the backward schedule)
  *   bits 16-23 fused BPTT in TWO unequal chunks: steps [n, T) first, the head [0, n) last (0 = equal chunks per bits 8-15) -- the long
  *              chunk's weight gradients run next to the head's recurrence, only the head's are left for the end of the update
+ *   bit 6      the single-chunk fused BPTT leaves dG row-major and two transpose passes (+ bias column sums) follow it, as in every
+ *              chunked schedule; 0 (default): the launch writes dG transposed and adds the bias gradients itself
  *   bit 5      with bits 3, 4: the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage of the BPTT launch (one fc layer)
  *   bit 4      with bit 3: the lower layer's dO = dG1 W_ih1 in a projection stage of its own (hsad_lstm_fused_bwd_rec.dO_stage)
  *   bit 3      split placement of the fused BPTT (hsad_lstm_fused_bwd_rec.xout): the two layers of a row block on different XCDs, half of
