@@ -1310,6 +1310,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   bool defer_l0 = false;
   int input_done_above = 0;          // steps >= this have their input-layer backward done on the side stream (0 = none)
   bool sink_used = false;            // the BPTT launch(es) already wrote d x of the input layer (sink stage)
+  bool sink_T = false;               // ... transposed, with the bias gradient of net.0
   const bool fbwd = pipe && L->fused_bwd && L->fwd_frag && B % 32 == 0 && 2 * (H / 32) * ((nrb_of(B) + 7) / 8) <= L->n_cu / 8 && nbc <= 8;
   if (fbwd) {
     // Both layers of a time chunk in ONE persistent launch (hsad_lstm_backward_fused): layer 0 runs a step behind layer 1 and computes
@@ -1386,6 +1387,11 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
         r.sink_out16 = snk ? (nfc == 2 ? L->dx2 : L->dx1) + t0 * B * H : nullptr;
         r.sink_mask16 = snk ? L->xin[0] + t0 * B * H : nullptr;
         r.sink_xout = snk ? L->xout_b2 : nullptr;
+        const bool snkT = snk && dgt_in_kernel && nfc == 1;      // one fc layer: d x1 is only ever read transposed
+        r.sink_outT16 = snkT ? L->dx1T + t0 * B : nullptr;
+        r.sink_ldT = Mp;
+        r.sink_bias_grad = snkT ? g[on->iB1] : nullptr;
+        sink_T = snkT;
         r.layout_steps = TL;
       }
       if (L->fb_tc != TL || L->fb_split != use_split || L->fb_proj != use_proj || L->fb_sink != use_sink) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
@@ -1501,7 +1507,9 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     CK(hsad_gemm_nt_bf16_ex(dxlT, Mp, L->x1T, Mp, H, H, Mp, nullptr, g[on->iW2], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
     CK(hsad_gemm_nt_bf16_ex(dxl, H, on->W2T, H, M, H, H, nullptr, nullptr, 0, L->dx1, H, 0, 0, 1, L->x1[0], H, nullptr, stream));
   }
-  if (fast_cs) {
+  if (sink_T) {
+    // (dx1T and the bias gradient came out of the BPTT launch)
+  } else if (fast_cs) {
     CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, g[on->iB1], nullptr, nullptr, stream));
   } else {
     CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, nullptr, nullptr, nullptr, stream));

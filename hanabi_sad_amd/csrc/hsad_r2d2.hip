@@ -2488,9 +2488,9 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
     return s_okp[slot] != 0;
   };
   const int fast_x = a.split_x ? 0 : fast;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of this workgroup's dG tiles over all steps (bias gradients), see dGT
   bool x_ready = false;      // the layer above is known to have published this step's tile (seen by the previous step's poll)
   bool dO_seen = false;      // ... the projection stage this step's dO rows (seen by this step's poll of the own counter)
-  float csum[4] = {0.f, 0.f, 0.f, 0.f};      // column sums of this workgroup's dG tiles over all steps (bias gradients), see dGT
   // swizzled fragment addresses of the LDS W_hh^T slice: k block kbi = 4 (kbi >> 2) + q at chunk ((4 q + g) ^ (lane & 15)) of window kbi >> 2
   int swz[4];
 #pragma unroll
@@ -2547,12 +2547,18 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
         accf[3] += v[3];
       }
       if (a.dx_out16) {
+        bf16_t v4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t o = ((size_t)t * a.Bn + rbase + r) * H + u;
           const bool on = !a.dx_mask16 || bf2f(a.dx_mask16[o]) > 0.f;
-          a.dx_out16[o] = on ? f2bf(accf[r]) : (bf16_t)0;
+          v4[r] = on ? f2bf(accf[r]) : (bf16_t)0;
+          csum[0] += bf2f(v4[r]);
+          if (!a.dGT) a.dx_out16[o] = v4[r];
         }
+        if (a.dGT)      // transposed instead: this lane's four consecutive rows of unit u are one 8-byte store
+          *reinterpret_cast<u64_t*>(a.dGT + (size_t)u * a.ldT + (size_t)t * a.Bn + rbase) =
+              (u64_t)v4[0] | ((u64_t)v4[1] << 16) | ((u64_t)v4[2] << 32) | ((u64_t)v4[3] << 48);
         __syncthreads();       // (sRed is rewritten by the next step)
         continue;
       }
@@ -2563,6 +2569,7 @@ __device__ __forceinline__ void lstm_fused_bwd_body(const LstmFusedBwdArgs& a, c
       __syncthreads();
       if (tid == 0) xchg_signal(a.dO_out_counters + (size_t)t * nrb + rb, 0);
     }
+    if (a.dx_out16 && a.bsum0) atomicAdd(a.bsum0 + u, csum[0]);      // the bias gradient of the masked layer: column sums of d x
     return;
   }
   const bool has_dOc = a.dO_counters != nullptr;
@@ -4772,6 +4779,9 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
       z.proj_only = 1;
       z.dx_out16 = (bf16_t*)r.sink_out16;
       z.dx_mask16 = (const bf16_t*)r.sink_mask16;
+      z.dGT = (bf16_t*)r.sink_outT16;
+      z.ldT = r.sink_ldT;
+      z.bsum0 = r.sink_bias_grad;
       z.counters = counters + (size_t)j * TL * nrb;
       z.timeout = counters + (size_t)R * TL * nrb;
       z.T = Tc;

@@ -591,6 +591,9 @@ typedef struct hsad_lstm_fused_bwd_rec {
   void* sink_out16;
   const void* sink_mask16;
   void* sink_xout;
+  void* sink_outT16;       /* optional: write the sink's rows TRANSPOSED instead, bf16 [H][sink_ldT] (element (unit, t * Bn + row)); sink_out16 is */
+  int sink_ldT;            /* then not written (pass any non-NULL pointer) */
+  float* sink_bias_grad;   /* optional fp32 [H]: column sums of the (masked) rows over rows and steps are ADDED here */
   /* dGT16 (optional): the gradient wrt the gate pre-activations written TRANSPOSED, bf16 [4H][ldT] with element (gate-blocked column,
    * t * Bn + row) -- the A operand of the weight-gradient GEMMs, no transpose pass behind the launch -- INSTEAD of the row-major dG16
    * (which then only serves has_next; use with a single time chunk).  bias_grad0 / bias_grad1 (optional, fp32 [4H]): the column sums of dG
