@@ -26,9 +26,10 @@ FUSED_FWD_ALGO = 8 * 2048 * 512 * 2 + 2 * _MH * 2 + 4 * _MH * 2 + 2 * (_MH * 4 *
 _NH = 32768 * 512
 CELL_ALGO_NOSTATE = 2 * _NH * 2 + 2048 * 1024 * 2 + _NH * 4 + _NH * 2
 CELL_ALGO_STATE = CELL_ALGO_NOSTATE + 2 * _NH * 4
-# (+ the default schedule's split placement / projection stage: the top layer's second, written-through tile copy and the fp32 dO rows of
-# the projection stage, written once and read once)
-FUSED_BWD_ALGO = 3 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + 2 * _MH * 4 * 2 + _MH * 4 * 2 + 2 * _MH * 4
+# default schedule (four pipeline stages): four weight slices; per layer the saved gates (fp32 x 4) and c of two steps; dO of the top layer,
+# the ReLU mask of the sink; written: dG transposed (2 layers, bf16), the written-through second tile copies of both layers, the fp32 dO rows
+# of the projection stage (written once, read once), d x1 transposed
+FUSED_BWD_ALGO = (4 * 2048 * 512 * 2 + 2 * (_MH * 4 * 4 + 2 * _MH * 4) + _MH * 4 + _MH * 2 + 2 * _MH * 4 * 2 + 2 * _MH * 4 * 2 + 2 * _MH * 4 + _MH * 2)
 
 
 def per_kernel(path, counter):
