@@ -1302,7 +1302,10 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   // BPTT launch for a free CU -- the input-MLP chain on the caller's stream must not wait for that
   if (pipe) HIP_TRY(hipEventRecord(L->ev_d, ws));
   CK(transpose16(L->dheads, M, NHp, NHp, L->dheadsT, Mp, nullptr, nullptr, nullptr, wst));
-  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, wst));
+  // (NH = A + 1 + 3 hand rows: one row tile -- four column tiles x split; a deeper split than the big weight gradients' fills more CUs:
+  // 30 -> 18 us, and with it the whole side-stream chain behind the BPTT launch starts earlier: 1.385 -> 1.362 ms per update)
+  const int heads_split = (Mp % (64 * 4 * L->wgrad_split) == 0) ? 4 * L->wgrad_split : L->wgrad_split;
+  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, heads_split, nullptr, 0, nullptr, wst));
   CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
   int nbc = L->bchunks;
   while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
