@@ -390,3 +390,32 @@ def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
     finally:
         lib.hsad_lstm_set_exchange_mode(0)
     L.check_sync()
+
+
+def test_fused_recurrences_next_to_foreign_work_on_another_stream():
+    """the persistent fused launches need every one of their workgroups resident (the four-stage BPTT launch: one per CU).  Foreign kernels on
+    another stream -- what the rollout thread of the drop-in driver, or any co-tenant of the GPU, amounts to -- may hold CUs when a launch
+    starts: its workgroups then arrive late, the others spin (bounded) and nothing may change but the time.  30 evaluations next to a
+    stream of large matmuls: identical bits to the quiet evaluation, no sticky timeout."""
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    F, A, H, T, B = 838, 21, 512, 80, 128
+    W, Wt = _rand_net(F, H, A, seed=31), _rand_net(F, H, A, seed=32)
+    batch, weight = _rand_batch(T, B, F, A, seed=6)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    loss, prio = L.loss(batch, weight, 0.25)
+    ref = (loss.clone(), prio.clone(), L.grad["lstm.weight_hh_l0"].clone(), L.grad["lstm.weight_ih_l1"].clone())
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(DEV)
+    a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    for it in range(30):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                a @ a                      # ~1 ms of full-chip work per launch, in flight while the learner's launches are issued
+        loss, prio = L.loss(batch, weight, 0.25)
+        for x, y in zip((loss, prio, L.grad["lstm.weight_hh_l0"], L.grad["lstm.weight_ih_l1"]), ref):
+            bad += (x != y).any()
+    torch.cuda.synchronize()
+    assert int(bad) == 0
+    L.check_sync()
