@@ -316,7 +316,7 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
 EXCHANGE_TIMEOUT_S = int(os.environ.get("HSAD_BENCH_EXCHANGE_TIMEOUT", "180"))
 
 
-def exchange_bench(dev, rank, world, rounds=60, batch=128):
+def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
     """--gpus N > 1: the learner <-> actor exchange of a multi-GPU self-play job (hanabi_sad_amd/dist.py ReplayLink) over RCCL, timed
     per section with HIP events on the learner's exchange stream.  Rank 0 is the dedicated learner (empty shard), every other rank
     an actor whose shard holds 2,048 synthetic 80-step sequences in the real transition layout (2p SAD: bit-packed 838-plane
@@ -339,7 +339,7 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128):
             z = torch.zeros(n, T, device=dev)
             shard.add(f, z, z.to(torch.uint8), z + 1, torch.full((n,), float(T), device=dev), torch.rand(n, device=dev, generator=g) + 0.1)
     shard.set_field_output("priv_s", "bf16", 896)
-    link = ReplayLink(shard, batch, 0.6, dev, learner_rank=0, depth=2, param_numel=n_param)
+    link = ReplayLink(shard, batch, 0.6, dev, learner_rank=0, depth=2, param_numel=n_param, mode=mode, name="bench_" + mode)
     torch.cuda.synchronize()
     out = None
     if rank == 0:
@@ -356,11 +356,13 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128):
             prios.append(torch.rand(batch, device=dev) + 0.05)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / rounds * 1e3
-        out = {"world": world, "rounds": rounds, "batch": batch, "wire_bytes_per_sequence": shard.wire_bytes(),
+        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "wire_bytes_per_sequence": shard.wire_bytes(),
                "batch_bytes_per_rank_message": shard.wire_bytes() * batch, "param_bucket_bytes": n_param * 4,
                "round_wall_ms": wall, "per_round_ms": link.timings(),
-               "note": "sections are HIP-event times on the learner's exchange stream, averaged over all rounds (param_bcast_ms: "
-                       "the parameter rounds' time spread over all rounds); actors serve a round between two polls of the store"}
+               "note": "sections are HIP-event times on the learner's exchange stream, averaged over all rounds (param_send_ms / "
+                       "param_bcast_ms: the parameter rounds' time spread over all rounds); actors serve a round between two polls "
+                       "of the store; round_shape star = point-to-point learner <-> actor messages only (HSAD_LINK_MODE=collective: "
+                       "the world-wide collectives of rounds 1-2)"}
     else:
         while True:
             flags = link.poll()
@@ -659,7 +661,8 @@ def main():
 
         def give_up():
             if rank == 0:
-                out["exchange"] = {"error": "the exchange leg did not finish within %d s" % EXCHANGE_TIMEOUT_S}
+                out["exchange" if "exchange" not in out else "exchange_ab"] = {
+                    "error": "the exchange leg did not finish within %d s" % EXCHANGE_TIMEOUT_S}
                 print(json.dumps(out), flush=True)
             os._exit(0)
         watchdog = threading.Timer(EXCHANGE_TIMEOUT_S, give_up)
@@ -667,13 +670,20 @@ def main():
         watchdog.start()
         del env
         torch.cuda.empty_cache()
-        try:
-            exchange = exchange_bench(dev, rank, world)
-        except Exception as e:               # (a failure on ONE rank: the others meet the watchdog)
-            exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+        # the product's round shape first (point-to-point), then its A/B twin (world-wide collectives); a leg that finished is in
+        # `out` before the next one starts, so the watchdog's line keeps it
+        for key, mode in (("exchange", os.environ.get("HSAD_LINK_MODE", "star")), ("exchange_ab", None)):
+            if mode is None:
+                mode = "collective" if out_mode == "star" else "star"
+            out_mode = mode
+            try:
+                exchange = exchange_bench(dev, rank, world, mode=mode)
+            except Exception as e:               # (a failure on ONE rank: the others meet the watchdog)
+                exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rank == 0:
+                out[key] = exchange
+            torch.cuda.empty_cache()
         watchdog.cancel()
-        if rank == 0:
-            out["exchange"] = exchange
     if rank == 0:
         if world == 1 and not args.no_actor:
             out["env_configs4"] = env_config4_bench(dev)

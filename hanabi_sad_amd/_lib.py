@@ -200,6 +200,7 @@ SIGNATURES = {
     "hsad_actor_create": (C.c_int, [_P, _P, _P, _P, C.POINTER(ActorConfig), C.POINTER(ActorIO), C.POINTER(_P)]),
     "hsad_actor_destroy": (None, [_P]),
     "hsad_actor_step": (C.c_int, [_P, _P]),
+    "hsad_actor_set_run_ahead": (C.c_int, [_P, C.c_int]),
     "hsad_actor_num_act": (C.c_int64, [_P]),
     "hsad_actor_num_redo": (C.c_int64, [_P]),
     "hsad_actor_n_finished_dev": (_P, [_P]),

@@ -151,6 +151,25 @@ class DeviceActor:
         if self._reset_pending:
             torch.cuda.current_stream(self.env.device).wait_stream(self._side)
 
+    def set_run_ahead(self, steps):
+        """bound how far the host may run ahead of the device (hsad_actor_set_run_ahead; 0 = unbounded): an actor rank of a multi-GPU
+        job must be able to serve the learner's round within a few steps, not behind hundreds of queued ones"""
+        self._run_ahead, self._step_events = int(steps), []
+        if self.c_actor is not None:
+            from . import _lib
+            _lib.check(self._lib.hsad_actor_set_run_ahead(self.c_actor, int(steps)))
+
+    def _bound_run_ahead(self):
+        """the Python body's twin of the library's bound (polling, never a blocking wait)"""
+        import time
+        e = torch.cuda.Event()
+        e.record()
+        self._step_events.append(e)
+        if len(self._step_events) > self._run_ahead:
+            old = self._step_events.pop(0)
+            while not old.query():
+                time.sleep(0)
+
     def step(self):
         """one iteration of the thread-loop body: reset-terminated -> act -> step -> postAct"""
         if self.c_actor is not None and not self.verify_cached_priority:
@@ -159,6 +178,8 @@ class DeviceActor:
             _lib.check(self._lib.hsad_actor_step(self.c_actor, _s(self.env.device)))
             self.num_act = int(self._lib.hsad_actor_num_act(self.c_actor))
             return
+        if getattr(self, "_run_ahead", 0) > 0:
+            self._bound_run_ahead()
         env, agent, P = self.env, self.agent, self.P
         self._reset_terminated()
         obs = self._rows()

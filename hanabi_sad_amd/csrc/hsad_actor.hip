@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <thread>
 #include <vector>
 
 #include "hsad.h"
@@ -88,6 +89,9 @@ struct hsad_actor {
   bool reset_pending = false;
   hipStream_t side_reset = nullptr, side_flush = nullptr;
   hipEvent_t ev_main = nullptr, ev_reset = nullptr, ev_flush = nullptr;
+  // hsad_actor_set_run_ahead: the host may be at most `run_ahead` steps ahead of the device (0 = unbounded)
+  int run_ahead = 0;
+  hipEvent_t ev_step[8] = {};
 };
 
 extern "C" {
@@ -190,6 +194,8 @@ void hsad_actor_destroy(hsad_actor* ac) {
   if (ac->side_flush) (void)hipStreamDestroy(ac->side_flush);
   for (hipEvent_t e : {ac->ev_main, ac->ev_reset, ac->ev_flush})
     if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ac->ev_step)
+    if (e) (void)hipEventDestroy(e);
   delete ac;
 }
 
@@ -217,9 +223,27 @@ const float* hsad_actor_last_priority(const hsad_actor* ac, int32_t* n) {
 
 // One iteration of the thread-loop body for every game (see the file header).  Everything is enqueued on `stream` and the two side
 // streams; the host never waits for the device.
+int hsad_actor_set_run_ahead(hsad_actor* ac, int steps) {
+  if (!ac || steps < 0 || steps > 7) return xfail(HSAD_ERR_INVALID, "actor_set_run_ahead: 0 (unbounded) .. 7 steps");
+  for (int i = 0; i < 8 && steps > 0; ++i)
+    if (!ac->ev_step[i]) HIP_TRY(hipEventCreateWithFlags(&ac->ev_step[i], hipEventDisableTiming));
+  ac->run_ahead = steps;
+  return HSAD_OK;
+}
+
 int hsad_actor_step(hsad_actor* ac, void* stream) {
   if (!ac) return xfail(HSAD_ERR_INVALID, "actor_step: null actor");
   hipStream_t s = (hipStream_t)stream;
+  // An actor's host issues a step in ~0.1 ms, the device runs it in ~0.9 ms: left alone the stream fills up with hundreds of
+  // steps, and anything stream-ordered behind them -- serving a learner's round (dist.ReplayLink), new parameters -- waits that
+  // long.  With a bound the host idles (polling: hipEventSynchronize has been seen to return only with the stream's NEWEST work)
+  // until step t - run_ahead has left the device; the device never runs dry while run_ahead >= 2.
+  if (ac->run_ahead > 0 && ac->step_no >= ac->run_ahead) {
+    hipEvent_t old = ac->ev_step[(ac->step_no - ac->run_ahead) & 7];
+    hipError_t q;
+    while ((q = hipEventQuery(old)) == hipErrorNotReady) std::this_thread::yield();
+    HIP_TRY(q);
+  }
   const int N = ac->N, P = ac->P, L = ac->L, Hd = ac->Hd, n = ac->multi_step;
   const int cur = ac->cur, nxt = (cur + 1) % ac->nslot;
   // `if (terminated) reset` (thread_loop.h:46-52): issued behind the previous env step on a side stream and joined at the end of
@@ -288,6 +312,7 @@ int hsad_actor_step(hsad_actor* ac, void* stream) {
     CK(hsad_seqwriter_flush_to_replay(ac->writer, ac->replay, ac->eta, ac->n_finished, (void*)ac->side_flush));
   }
   HIP_TRY(hipStreamWaitEvent(s, ac->ev_reset, 0));      // nothing outside a step ever runs next to the reset
+  if (ac->run_ahead > 0) HIP_TRY(hipEventRecord(ac->ev_step[(ac->step_no - 1) & 7], s));
   return 0;
 }
 

@@ -262,9 +262,16 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(RowLayout L, const uns
 // dist.stratified_positions) cut into per-shard targets (dist.split_positions): owner[i] = first shard whose inclusive weight
 // prefix reaches position i (never an empty shard), local target = position minus the weight of the shards before it.  The
 // positions this rank owns are compacted (they form one contiguous run, positions ascend) into local_mine[0 .. *n_mine).
+//
+// The statistics may be OLDER than the shard (the star-shaped round of dist.ReplayLink sends every actor the sums its previous
+// reply carried, so that no actor waits for another one's statistics; the actor has pushed sequences since): this rank's share
+// [0, stats sum) is then stretched onto its present weight sum `*cur_sum`, and `*wscale` = stats sum / present sum is what the raw
+// weights going out are multiplied with, so that raw / (sum of the stats sums) stays the probability the sequence was drawn with:
+// (stats sum / total) * (w / present sum).  Equal sums (the collective round; a shard nobody pushed to) give the factor 1.0 exactly.
 __global__ __launch_bounds__(1024) void shard_targets_kernel(const double* __restrict__ stats, int world, int rank,
                                                              const float* __restrict__ canon, int B, int* __restrict__ owner,
-                                                             float* __restrict__ local_mine, int* __restrict__ n_mine) {
+                                                             float* __restrict__ local_mine, int* __restrict__ n_mine,
+                                                             const double* __restrict__ cur_sum, float* __restrict__ wscale) {
   __shared__ double s_incl[64];
   __shared__ int s_wtot[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -293,8 +300,15 @@ __global__ __launch_bounds__(1024) void shard_targets_kernel(const double* __res
       k = best < 0 ? k : best;
     }
     own = k;
-    local = fmaxf((float)((double)pos - (k > 0 ? s_incl[k - 1] : 0.0)), 0.f);
+    double loc = fmax((double)pos - (k > 0 ? s_incl[k - 1] : 0.0), 0.0);
+    const double told = stats[2 * rank], tnow = *cur_sum;
+    if (told > 0.0 && tnow > 0.0 && told != tnow) loc *= tnow / told;
+    local = (float)loc;
     owner[tid] = own;
+  }
+  if (tid == 0) {
+    const double told = stats[2 * rank], tnow = *cur_sum;
+    *wscale = (told > 0.0 && tnow > 0.0) ? (float)(told / tnow) : 1.f;
   }
   const bool mine = own == rank;
   const unsigned long long m = __ballot(mine);
@@ -352,7 +366,8 @@ __global__ __launch_bounds__(256) void wire_pack_kernel(WireLayout W, const unsi
                                                         const int* __restrict__ n_dev, const int* __restrict__ valid_rows,
                                                         const float* __restrict__ reward, const unsigned char* __restrict__ terminal,
                                                         const float* __restrict__ bootstrap, const float* __restrict__ seq_len,
-                                                        const float* __restrict__ raw_w, unsigned char* __restrict__ wire, int B) {
+                                                        const float* __restrict__ raw_w, unsigned char* __restrict__ wire, int B,
+                                                        const float* __restrict__ wscale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= B * W.T) return;
   const int j = row / W.T, t = row - j * W.T;
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256) void wire_pack_kernel(WireLayout W, const unsi
     slot[W.off_terminal + t] = pad ? (unsigned char)1 : terminal[s];
     if (t == 0) {
       reinterpret_cast<float*>(slot + W.off_tail)[0] = seq_len[id];
-      reinterpret_cast<float*>(slot + W.off_tail)[1] = raw_w[j];
+      reinterpret_cast<float*>(slot + W.off_tail)[1] = raw_w[j] * *wscale;
     }
   }
 }
@@ -1139,7 +1154,7 @@ struct hsad_replay {
   int* d_tmp_id;
   StreamFence fence;
   int last_err_kind = 0;
-  float* d_shard = nullptr;  // sharded draw scratch: compacted priorities [kMaxBatch] | raw weights [kMaxBatch] | counts (2 ints)
+  float* d_shard = nullptr;  // sharded draw scratch: compacted priorities [kMaxBatch] | raw weights [kMaxBatch] | counts (2 ints) | weight factor of a draw from older statistics
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
   int out_ld[kMaxFields] = {};
   std::mt19937 rng;
@@ -1402,11 +1417,14 @@ int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const doubl
   HIP_TRY(use_r.err);
   float* raw_w = r->d_shard + kMaxBatch;
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch);
-  hipLaunchKernelGGL(shard_targets_kernel, dim3(1), dim3(1024), 0, s, all_stats, world, rank, canon, batch, owner_out, r->d_canon, n_mine);
+  float* wscale = r->d_shard + 2 * kMaxBatch + 2;
+  const double* cur_sum = reinterpret_cast<const double*>(reinterpret_cast<const char*>(r->rd.ctl) + offsetof(ReplayCtl, sum));
+  hipLaunchKernelGGL(shard_targets_kernel, dim3(1), dim3(1024), 0, s, all_stats, world, rank, canon, batch, owner_out, r->d_canon, n_mine,
+                     cur_sum, wscale);
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, raw_w, r->d_canon, n_mine);
   const WireLayout W = wire_layout(r->L, r->T);
   hipLaunchKernelGGL(wire_pack_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, W, r->rows, r->rd.sampled_ids, n_mine, r->rd.valid_rows,
-                     r->reward, r->terminal, r->bootstrap, r->seq_len, raw_w, wire_out, batch);
+                     r->reward, r->terminal, r->bootstrap, r->seq_len, raw_w, wire_out, batch, wscale);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

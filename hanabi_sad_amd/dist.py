@@ -292,15 +292,38 @@ class ReplayLink:
       * parameters go out as one persistent flat bucket [online | target], staged by the learner on its compute stream
         (`stage_params`) and broadcast inside a round whose flags say so.
 
+    Two shapes of a round (`mode`, default "star"; HSAD_LINK_MODE overrides):
+
+      "star"        every message is point-to-point between the learner and ONE actor, so no actor ever waits for another actor:
+                    learner -> actor   header [canonical uniforms | late priorities | (sum, size) of EVERY shard]
+                    actor -> learner   its rows of the draw, then its (sum, size) after this round
+                    learner -> actor   the parameter bucket, in a PARAMS round
+                    The statistics the draw is cut with are the ones the PREVIOUS replies carried (the very first round collects
+                    them up front): a shard that has pushed sequences since stretches its share of the positions onto its present
+                    weight sum and scales the raw weights it sends, so that raw / (sum of the header's sums) is still the
+                    probability the sequence was drawn with (hsad_replay_serve); a shard nobody pushed to is served bit for bit
+                    as the collective round serves it.  An actor serves the draw BEFORE it writes the late priorities back (the
+                    header's statistics describe the shard before them), so one more drawn batch is outstanding per shard.
+                    7 x 1.7 MB arrive at the learner over 7 xGMI links at once; the 39 MB bucket leaves over the same 7 links.
+      "collective"  header broadcast, all-gather of the statistics, gather of the rows, parameter broadcast over the whole world
+                    on every actor's stream: the statistics are fresh, but an actor that notices the round early has its stream
+                    wait inside the first collective for the last one to join (kept as the A/B twin).
+
     `shard`: hanabi_sad_amd.replay.DeviceReplay, or any stand-in with stats / wire_bytes / serve / answer / assemble /
     draw_canonical / set_outstanding (the gloo CPU tests)."""
 
     ROUND_KEY = "hsad/link/round"
     FLAG_SLOTS = 64        # flags of round r live in key r % 64: the learner's host is never more than four rounds ahead of its own
-    PARAMS, STOP, HAS_PRIO = 1, 2, 4   # exchange stream (hdr_ev below) and that stream cannot pass a round an actor has not served
+    PARAMS, STOP, HAS_PRIO, PRIME = 1, 2, 4, 8   # exchange stream (hdr_ev below) and that stream cannot pass a round an actor has not served
 
-    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None):
+    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None, mode=None, name=""):
+        import os
         import torch.distributed as dist
+        self._keys = "hsad/link/%s" % (name + "/" if name else "")     # a second link of the same job (bench.py's A/B) has its own keys
+        self.ROUND_KEY = self._keys + "round"
+        self.mode = mode or os.environ.get("HSAD_LINK_MODE", "star")
+        if self.mode not in ("star", "collective"):
+            raise ValueError("ReplayLink mode must be 'star' or 'collective', not %r" % (self.mode,))
         self.shard, self.B, self.beta = shard, int(batch), float(beta)
         self.device = torch.device(device)
         self.learner = int(learner_rank)
@@ -309,10 +332,16 @@ class ReplayLink:
         self.comm = comm_device_for(self.device)
         self.staged = self.comm != self.device           # gloo with GPU shards (smoke runs): tensors travel through host memory
         self.store = store if store is not None else _default_store()
-        shard.set_outstanding(depth)
+        star = self.mode == "star"
+        shard.set_outstanding(depth + 1 if star else depth)
         B, wb, d = self.B, shard.wire_bytes(), self.device
-        self.hdr = torch.zeros(2 * B, dtype=torch.float32, device=d)             # canonical uniforms | priorities of an earlier batch
-        self.all_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d)
+        if star:     # canonical uniforms | priorities of an earlier batch | every shard's (sum, size) as float64 pairs
+            self.hdr = torch.zeros(2 * B + 4 * self.world, dtype=torch.float32, device=d)
+            self.all_stats = self.hdr[2 * B:].view(torch.float64).view(self.world, 2)
+            self.next_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d) if self.is_learner else None
+        else:
+            self.hdr = torch.zeros(2 * B, dtype=torch.float32, device=d)
+            self.all_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d)
         self.wire = torch.zeros(B, wb, dtype=torch.uint8, device=d)
         self.wire_all = torch.zeros(self.world, B, wb, dtype=torch.uint8, device=d) if self.is_learner else None
         self.bucket = torch.zeros(int(param_numel), dtype=torch.float32, device=d) if param_numel else None
@@ -355,8 +384,79 @@ class ReplayLink:
         if self.is_learner:
             self.wire_all.copy_(torch.stack(parts))
 
+    def _p2p_begin(self, ops):
+        """ops: [("send" | "recv", tensor, peer)] -> one grouped launch (ncclGroupStart / End in RCCL: the learner's sends to and
+        receives from all actors progress at once; two messages between the same pair are matched in the order given)"""
+        import torch.distributed as dist
+        if not ops:
+            return None
+        staged = [(kind, t, peer, (t.cpu() if kind == "send" else torch.empty(t.shape, dtype=t.dtype)) if self.staged else t)
+                  for kind, t, peer in ops]
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer)
+                                        for kind, _, peer, buf in staged])
+        return works, staged
+
+    def _p2p_end(self, pending):
+        if pending is None:
+            return
+        works, staged = pending
+        for w in works:
+            w.wait()             # RCCL: the current stream waits, the host does not
+        if self.staged:
+            for kind, t, _, buf in staged:
+                if kind == "recv":
+                    t.copy_(buf)
+
+    def _p2p(self, ops):
+        self._p2p_end(self._p2p_begin(ops))
+
+    def _round_star(self, flags):
+        """one point-to-point round (class docstring), stream-ordered on the caller's current stream"""
+        B, L, me = self.B, self.learner, self.rank
+        if not self.is_learner:
+            if flags & self.PRIME:
+                self._p2p([("send", self.shard.stats(), L)])
+            self._p2p([("recv", self.hdr, L)])
+            self.shard.serve(self.hdr[:B], self.all_stats, me, self.wire)
+            if flags & self.HAS_PRIO:
+                self.shard.answer(self.hdr[B:2 * B], me)
+            self._p2p([("send", self.wire, L), ("send", self.shard.stats(), L)])
+            if flags & self.PARAMS:
+                self._p2p([("recv", self.bucket, L)])
+            self.served += 1
+            return None
+        t, peers = self.timer, [k for k in range(self.world) if k != L]
+        t.start()
+        if flags & self.PRIME:
+            self._p2p([("recv", self.next_stats[k], k) for k in peers])
+            self.next_stats[L].copy_(self.shard.stats())
+        self.all_stats.copy_(self.next_stats)           # = the tail of the header going out
+        used = self.all_stats.clone()
+        pending = self._p2p_begin([("send", self.hdr, k) for k in peers] + [("recv", self.wire_all[k], k) for k in peers] +
+                                  [("recv", self.next_stats[k], k) for k in peers])
+        owner = self.shard.serve(self.hdr[:B], self.all_stats, me, self.wire_all[L])
+        if flags & self.HAS_PRIO:
+            self.shard.answer(self.hdr[B:2 * B], me)
+        self.next_stats[L].copy_(self.shard.stats())
+        t.mark("serve_ms")
+        self._p2p_end(pending)
+        t.mark("exchange_ms")
+        if flags & self.PARAMS:
+            self._p2p([("send", self.bucket, k) for k in peers])
+            t.mark("param_send_ms")
+        batch, raw_w = self.shard.assemble(self.wire_all, owner)
+        total = used[:, 0].sum().to(torch.float32)
+        n_total = used[:, 1].sum().to(torch.float32)
+        y = torch.pow(n_total * (raw_w / total), -self.beta)
+        t.mark("assemble_ms")
+        t.stop()
+        self.served += 1
+        return (batch, y / y.max())
+
     # -- one round, every rank (stream-ordered on the caller's current stream) --
     def _round(self, flags):
+        if self.mode == "star":
+            return self._round_star(flags)
         B, t = self.B, self.timer if self.is_learner else None
         if t:
             t.start()
@@ -364,7 +464,7 @@ class ReplayLink:
         if t:
             t.mark("header_bcast_ms")
         if flags & self.HAS_PRIO:
-            self.shard.answer(self.hdr[B:], self.rank)
+            self.shard.answer(self.hdr[B:2 * B], self.rank)
         self._all_gather_stats(self.shard.stats())
         if t:
             t.mark("stats_allgather_ms")
@@ -406,8 +506,10 @@ class ReplayLink:
         assert self.is_learner and self._result is None
         flags = (self.PARAMS if params else 0) | (self.STOP if stop else 0) | (self.HAS_PRIO if prio is not None else 0)
         r = self.opened
+        if r == 0 and self.mode == "star":
+            flags |= self.PRIME                   # nobody has told the learner a (sum, size) yet: the actors send theirs first
         # the flag ring is only safe while no rank is FLAG_SLOTS rounds behind; the value carries its round so that poll() can tell
-        self.store.set("hsad/link/flags/%d" % (r % self.FLAG_SLOTS), "%d %d" % (r, flags))
+        self.store.set(self._keys + "flags/%d" % (r % self.FLAG_SLOTS), "%d %d" % (r, flags))
         self.store.add(self.ROUND_KEY, 1)
         self.opened += 1
         B, k = self.B, r % 4
@@ -423,12 +525,12 @@ class ReplayLink:
                 self.hdr_ev[k].record()
                 if prio is not None:
                     prio.record_stream(self.xs)           # allocated on the compute stream, read here
-                    self.hdr[B:].copy_(prio)
+                    self.hdr[B:2 * B].copy_(prio)
                 self._result = self._round(flags)
         else:
             self.hdr[:B].copy_(canon)
             if prio is not None:
-                self.hdr[B:].copy_(prio)
+                self.hdr[B:2 * B].copy_(prio)
             self._result = self._round(flags)
 
     def finish(self):
@@ -459,7 +561,7 @@ class ReplayLink:
         if self._known_open - self.served >= self.FLAG_SLOTS:
             raise RuntimeError("ReplayLink: rank %d is %d rounds behind the learner -- the %d-slot flag ring has wrapped" %
                                (self.rank, self._known_open - self.served, self.FLAG_SLOTS))
-        r, flags = self.store.get("hsad/link/flags/%d" % (self.served % self.FLAG_SLOTS)).decode().split()
+        r, flags = self.store.get(self._keys + "flags/%d" % (self.served % self.FLAG_SLOTS)).decode().split()
         if int(r) != self.served:
             raise RuntimeError("ReplayLink: flag slot of round %d holds round %s" % (self.served, r))
         return int(flags)

@@ -817,8 +817,14 @@ typedef struct hsad_actor_io {
 int hsad_actor_create(hsad_env* env, hsad_r2d2_net* online, hsad_r2d2_net* target, hsad_replay* replay, const hsad_actor_config* cfg,
                       const hsad_actor_io* io, hsad_actor** out);
 void hsad_actor_destroy(hsad_actor* actor);
-/* one iteration for every game; everything is enqueued on `stream` and the actor's two side streams, the host never waits */
+/* one iteration for every game; everything is enqueued on `stream` and the actor's two side streams, the host never waits
+ * (unless hsad_actor_set_run_ahead bounds it) */
 int hsad_actor_step(hsad_actor* actor, void* stream);
+/* steps (0 = unbounded, the default; 1..7) the host may be ahead of the device: hsad_actor_step then waits, polling an event, until
+ * step t - steps has left the device.  An actor rank of a multi-GPU job sets 2-3: whatever is stream-ordered behind its steps -- the
+ * learner's sampling round (rela/prioritized_replay.h:208-257 across processes), new parameters (batch_runner.h:74-77) -- is at most
+ * that many steps away, and the device still never runs dry. */
+int hsad_actor_set_run_ahead(hsad_actor* actor, int steps);
 int64_t hsad_actor_num_act(const hsad_actor* actor);        /* R2D2Actor::numAct summed over the per-player actors */
 int64_t hsad_actor_num_redo(const hsad_actor* actor);       /* steps whose Q_online(s_{t-n}, a) pass was redone after a weight sync */
 const int32_t* hsad_actor_n_finished_dev(const hsad_actor* actor);   /* device counter: sequences flushed by the last step */

@@ -167,6 +167,9 @@ def test_library_actor_step_equals_the_python_body_bit_for_bit(method, games, hi
     trs = [Trainer(parse_args(common + ["--native_actor", str(k)]), "cuda:0") for k in (1, 0)]
     nat, py = trs[0].actor, trs[1].actor
     assert nat.c_actor is not None and py.c_actor is None
+    if games == 1024:                        # the multi-GPU actor loop's bound on the host's run-ahead changes no result
+        nat.set_run_ahead(2)
+        py.set_run_ahead(2)
     rec_p = []
     orig_push = py.writer.push_sequence
 
@@ -208,3 +211,29 @@ def test_library_actor_step_equals_the_python_body_bit_for_bit(method, games, hi
         fa, rwa, ta, ba, sa = ra.get(i)
         fb, rwb, tb, bb, sb = rb.get(i)
         assert all(torch.equal(fa[k], fb[k]) for k in fa) and torch.equal(rwa, rwb) and torch.equal(ta, tb) and torch.equal(ba, bb) and torch.equal(sa, sb), i
+
+
+def test_run_ahead_bound_keeps_the_host_within_a_few_steps_of_the_device():
+    """hsad_actor_set_run_ahead(k): when hsad_actor_step(t) returns, step t - k has left the device (an actor rank serves a learner's
+    round behind at most k queued steps instead of behind everything its host managed to enqueue)"""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    tr = Trainer(parse_args(["--num_game", "4096", "--rnn_hid_dim", "512", "--batchsize", "16", "--replay_buffer_size", "16384",
+                             "--burn_in_frames", "64", "--sad", "1", "--seed", "3"]), "cuda:0")
+    act = tr.actor
+    assert act.c_actor is not None
+    act.set_run_ahead(2)
+    marks = []
+    for it in range(40):
+        act.step()
+        e = torch.cuda.Event()
+        e.record()
+        marks.append(e)
+        if it >= 3:
+            assert marks[it - 3].query(), it
+    act.set_run_ahead(0)
+    for it in range(5):
+        act.step()
+    torch.cuda.synchronize()
+    tr.env.check_errors()
+    tr.replay.check_errors()
+

@@ -19,6 +19,7 @@ from hanabi_sad_amd.dist import ReplayLink, rank_world, split_positions, stratif
 
 ALPHA, BETA, B, ROUNDS = 0.9, 0.6, 16, 7
 SIZES = %(sizes)r                     # elements per shard; the learner's (rank 0) may be empty: a dedicated learner
+MODE, GROW = %(mode)r, %(grow)r       # shape of a round; elements an actor shard pushes between two rounds (star only: older statistics)
 
 def initial(k):
     return (np.random.default_rng(100 + k).random(SIZES[k]).astype(np.float32) * 2 + 0.05) ** np.float32(ALPHA)
@@ -36,13 +37,17 @@ class HostShard:
         sums = all_stats[:, 0].numpy()
         pos = stratified_positions(canon.numpy(), float(np.sum(sums)), len(canon))
         owner, local = split_positions(pos, list(sums))
+        now, told = float(np.sum(self.w.astype(np.float64))), float(sums[rank])
+        scale = np.float32(told / now) if told > 0 and now > 0 else np.float32(1)     # hsad_replay_serve: older statistics
+        if told > 0 and now > 0 and told != now:
+            local = (local.astype(np.float64) * (now / told)).astype(np.float32)
         acc = np.cumsum(self.w.astype(np.float64))
         ids = [int(min(np.searchsorted(acc, np.float64(t), side="left"), len(self.w) - 1)) for t in local[owner == rank]]
         assert len(self.queue) < self.depth
         self.queue.append((owner, ids))
         slots = wire_out.view(torch.float32).view(-1, 4)
         for j, i in enumerate(ids):
-            slots[j, 0], slots[j, 1] = 1000.0 * self.k + i, float(self.w[i])
+            slots[j, 0], slots[j, 1] = 1000.0 * self.k + i, float(self.w[i] * scale)
         return torch.from_numpy(owner.astype(np.int32))
     def answer(self, prio, rank):
         owner, ids = self.queue.pop(0)
@@ -61,7 +66,8 @@ class HostShard:
 rank, world = rank_world()
 dist.init_process_group("gloo", rank=rank, world_size=world)
 NP = 1000
-link = ReplayLink(HostShard(rank), B, BETA, "cpu", learner_rank=0, depth=2, param_numel=NP)
+link = ReplayLink(HostShard(rank), B, BETA, "cpu", learner_rank=0, depth=2, param_numel=NP, mode=MODE)
+assert link.mode == MODE and link.shard.depth == (3 if MODE == "star" else 2)
 link.FLAG_SLOTS = 4                                        # fewer flag keys than rounds: the ring of store keys wraps in this test
 if rank == 0:
     model = [initial(k) for k in range(world)]            # the single-buffer emulation: every shard's weights, updated when the priorities ARRIVE
@@ -69,16 +75,27 @@ if rank == 0:
     drawn, batches = [], []
     for r in range(ROUNDS):
         prio = None
-        if r >= 2:                                         # update r-2 is the newest finished one when round r is opened
-            prio = torch.tensor(drawn[r - 2][1])
+        def write_back():
             for t, p in zip(drawn[r - 2][0], drawn[r - 2][1]):        # sequential: the last duplicate wins
                 model[int(t) // 1000][int(t) %% 1000] = np.float32(p) ** np.float32(ALPHA)
+        if r >= 2:                                         # update r-2 is the newest finished one when round r is opened
+            prio = torch.tensor(drawn[r - 2][1])
+            if MODE == "collective":                       # ... and is written back before the draw there, after it in a star round
+                write_back()
         params = r == 3
         if params:
             link.stage_params(torch.arange(NP // 2, dtype=torch.float32), torch.arange(NP // 2, dtype=torch.float32) + 0.5)
         link.begin(prio, params=params, stop=(r == ROUNDS - 1))
         time.sleep(0.02)                                   # "update r-1 runs here"
         (f, *_ , seq_len), weight = link.finish()
+        if GROW:                                           # shards that push between rounds: properties only (the exact rescaling
+            got = f["tag"].numpy()                         # is pinned on the device kernels, tests/test_sharded_replay_gpu.py)
+            rng.random(B, dtype=np.float32)
+            assert all(0 <= int(t) %% 1000 < SIZES[int(t) // 1000] + GROW * (r + 1) and SIZES[int(t) // 1000] > 0 for t in got), got
+            w = weight.numpy()
+            assert np.all(np.isfinite(w)) and np.all(w > 0) and abs(float(w.max()) - 1.0) < 1e-6
+            drawn.append((got, (got %% 7 + 0.5 + r).astype(np.float32)))
+            continue
         # what ONE buffer over the concatenation draws from the same uniforms
         cat = np.concatenate(model)
         tags = np.concatenate([1000 * k + np.arange(len(model[k])) for k in range(world)])
@@ -94,9 +111,13 @@ if rank == 0:
         raw = np.array([model[int(t) // 1000][int(t) %% 1000] for t in got], dtype=np.float32)
         y = (np.float32(len(cat)) * (raw / np.float32(total))) ** np.float32(-BETA)
         assert np.allclose(weight.numpy(), y / y.max(), rtol=1e-5), (r, weight, y / y.max())
+        if r >= 2 and MODE == "star":
+            write_back()
         drawn.append((got, (got %% 7 + 0.5 + r).astype(np.float32)))
     t = link.timings()
-    assert set(t) >= {"header_bcast_ms", "stats_allgather_ms", "serve_ms", "batch_gather_ms", "param_bcast_ms", "assemble_ms"}, t
+    keys = {"serve_ms", "exchange_ms", "param_send_ms", "assemble_ms"} if MODE == "star" else \
+        {"header_bcast_ms", "stats_allgather_ms", "serve_ms", "batch_gather_ms", "param_bcast_ms", "assemble_ms"}
+    assert set(t) >= keys, t
     final = torch.from_numpy(np.concatenate(model))
 else:
     n_poll = n_act = 0
@@ -109,6 +130,8 @@ else:
             time.sleep(0.001)
             continue
         stop = link.serve(flags)
+        if GROW and link.shard.w.size:                     # "the actor pushed GROW sequences since"
+            link.shard.w = np.concatenate([link.shard.w, (np.arange(GROW, dtype=np.float32) + 1.0 + link.served) / 8])
         if flags & ReplayLink.PARAMS:
             assert torch.equal(link.bucket[:NP // 2], torch.arange(NP // 2, dtype=torch.float32))
             assert torch.equal(link.bucket[NP // 2:], torch.arange(NP // 2, dtype=torch.float32) + 0.5)
@@ -120,7 +143,7 @@ else:
 dist.broadcast(final, src=0)
 lo = sum(SIZES[:rank])
 # the late priorities reached exactly the owning elements of every shard (rounds 0 .. ROUNDS-3 were answered)
-assert np.array_equal(link.shard.w, final.numpy()[lo:lo + SIZES[rank]]), rank
+assert GROW or np.array_equal(link.shard.w, final.numpy()[lo:lo + SIZES[rank]]), rank
 assert len(link.shard.queue) == 2                           # the last two draws are still waiting for theirs
 dist.barrier()
 dist.destroy_process_group()
@@ -135,10 +158,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("sizes", [[0, 40], [12, 0, 50], [0, 30, 25]])
-def test_replay_link_rounds_gloo(tmp_path, sizes):
+@pytest.mark.parametrize("sizes,mode,grow", [([0, 40], "star", 0), ([12, 0, 50], "star", 0), ([0, 30, 25], "star", 0),
+                                             ([0, 30, 25], "star", 3), ([0, 40], "collective", 0), ([12, 0, 50], "collective", 0)])
+def test_replay_link_rounds_gloo(tmp_path, sizes, mode, grow):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT, "sizes": sizes, "out": str(tmp_path)})
+    script.write_text(WORKER % {"root": ROOT, "sizes": sizes, "out": str(tmp_path), "mode": mode, "grow": grow})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % len(sizes), "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), str(script)]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)

@@ -104,7 +104,7 @@ def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path, extra):
            "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo", "--actor_sync_freq", "10"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and "batch_gather_ms" in out.stdout
+    assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and ("exchange_ms" in out.stdout or "batch_gather_ms" in out.stdout)
 
 
 def test_device_side_sharded_draw_equals_the_host_choreography():
@@ -160,6 +160,59 @@ def test_device_side_sharded_draw_equals_the_host_choreography():
         s.check_errors()
 
 
+def test_serve_from_older_statistics_stretches_the_share_and_scales_the_weights():
+    """the star-shaped round of dist.ReplayLink cuts a draw with the (sum, size) every shard reported one round earlier; a shard that
+    has pushed since must map its share [0, old sum) onto its present weights and send raw weights scaled by old / present sum, so
+    that raw / total is the probability the element was drawn with.  Dyadic priorities, alpha = 1: every number is exact."""
+    from hanabi_sad_amd.dist import split_positions, stratified_positions
+    from hanabi_sad_amd.replay import DeviceReplay
+    B, W = 32, 2
+    rng = np.random.default_rng(21)
+    shards = [DeviceReplay(96, 5, 1.0, 0.6, 0, T, FIELDS, DEV) for _ in range(W)]
+    w = []
+    for k, s in enumerate(shards):
+        r = list(make_rows(rng, 30, 100 * k))
+        prio = (rng.integers(1, 64, 30) / 16.0).astype(np.float32)
+        r[5] = torch.tensor(prio, device=DEV)
+        s.add(*r)
+        w.append(prio)
+    old_stats = torch.stack([s.stats() for s in shards])
+    more = list(make_rows(rng, 20, 100 + 30))                                # shard 1 pushes 20 sequences after it reported
+    prio = (rng.integers(1, 64, 20) / 16.0).astype(np.float32)
+    more[5] = torch.tensor(prio, device=DEV)
+    shards[1].add(*more)
+    w[1] = np.concatenate([w[1], prio])
+    wb = shards[0].wire_bytes()
+    canon = rng.random(B, dtype=np.float32)
+    wire_all = torch.zeros(W, B, wb, dtype=torch.uint8, device=DEV)
+    owner = [s.serve(torch.tensor(canon, device=DEV), old_stats, k, wire_all[k]) for k, s in enumerate(shards)][0]
+    sums_old = old_stats[:, 0].cpu().numpy()
+    pos = stratified_positions(canon, float(sums_old.sum()), B)
+    owner_h, _ = split_positions(pos, list(sums_old))
+    assert np.array_equal(owner.cpu().numpy(), owner_h) and 0 < int((owner_h == 1).sum()) < B
+    (f, *_), raw_w = shards[0].assemble(wire_all, owner)
+    tags, raw = f["a"][0, :, 0].cpu().numpy(), raw_w.cpu().numpy()
+    prefix = np.concatenate([[0.0], np.cumsum(sums_old)])
+    saw_new = False
+    for b in range(B):
+        k = int(owner_h[b])
+        now, told = float(w[k].astype(np.float64).sum()), float(sums_old[k])
+        loc = max(float(pos[b]) - prefix[k], 0.0)
+        if now != told:
+            loc *= now / told
+        target = min(max(np.float32(loc), np.float32(0)), np.float32(now) * (np.float32(1) - np.float32(1e-6)))
+        i = int(np.searchsorted(np.cumsum(w[k].astype(np.float64)), np.float64(target), side="left"))
+        assert tags[b] == (100 * k + i if k == 0 or i < 30 else 100 + i), (b, k, i, tags[b])
+        assert raw[b] == np.float32(w[k][i] * np.float32(told / now)), (b, raw[b], w[k][i])
+        saw_new |= k == 1 and i >= 30
+    assert saw_new                                                           # the sequences pushed after the report can be drawn
+    # the probabilities of shard 1's elements under (old share) x (present weights) sum to the old share
+    p1 = (sums_old[1] / sums_old.sum()) * (w[1].astype(np.float64) / w[1].astype(np.float64).sum())
+    assert abs(p1.sum() - sums_old[1] / sums_old.sum()) < 1e-12
+    for s in shards:
+        s.check_errors()
+
+
 def test_late_priorities_reach_exactly_the_owned_elements():
     """two shards, depth 2: serve A, serve B, answer A, answer B -- the running sums follow a host model of the weights"""
     from hanabi_sad_amd.replay import DeviceReplay
@@ -199,11 +252,14 @@ def test_late_priorities_reach_exactly_the_owned_elements():
         s.check_errors()
 
 
-def test_replay_link_over_rccl_single_rank_equals_plain_sampling():
+@pytest.mark.parametrize("mode", ["star", "collective"])
+def test_replay_link_over_rccl_single_rank_equals_plain_sampling(mode):
     """dist.ReplayLink with the RCCL backend ("nccl") on this box's one GPU: the learner is the only rank and serves its own shard.
-    Every transport call of a round (broadcast, all_gather_into_tensor, gather, parameter bucket) goes through RCCL on the exchange
-    stream; the assembled batches must equal what hsad_replay_sample draws from an identical replay with the same uniforms, and
-    the late priorities must leave both replays in the same state."""
+    In a collective round every transport call (broadcast, all_gather_into_tensor, gather, parameter bucket) goes through RCCL on
+    the exchange stream; a star round has no peer to talk to here and runs the learner's own serve -> answer -> statistics order.
+    The assembled batches must equal what hsad_replay_sample draws from an identical replay with the same uniforms, and the late
+    priorities (written back before the draw in a collective round, after it in a star round) must leave both replays in the
+    same state."""
     import os
     import socket
     import torch.distributed as dist
@@ -217,21 +273,23 @@ def test_replay_link_over_rccl_single_rank_equals_plain_sampling():
         B, cap = 16, 48
         plain = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
         shard = DeviceReplay(cap, 11, 0.9, 0.6, 0, T, FIELDS, DEV)
-        plain.set_outstanding(2)
+        plain.set_outstanding(3 if mode == "star" else 2)
         rng = np.random.default_rng(0)
         rows = make_rows(rng, 40, 0)
         plain.add(*rows)
         shard.add(*rows)
-        link = ReplayLink(shard, B, 0.6, DEV, learner_rank=0, depth=2, param_numel=64)
+        link = ReplayLink(shard, B, 0.6, DEV, learner_rank=0, depth=2, param_numel=64, mode=mode)
         prios, got = [], []
         for r in range(6):
             prio = prios[r - 2] if r >= 2 else None
             if r == 3:
                 link.stage_params(torch.arange(64, dtype=torch.float32, device=DEV))
             link.begin(prio, params=(r == 3))
-            if prio is not None:
+            if prio is not None and mode == "collective":
                 plain.update_priority(prio)                 # answers the oldest outstanding draw, like the shard does
             x = plain.sample(B)
+            if prio is not None and mode == "star":
+                plain.update_priority(prio)
             y = link.finish()
             same_batch(x, y)
             prios.append(torch.tensor((rng.random(B) * 2 + 0.05).astype(np.float32), device=DEV))
@@ -239,7 +297,7 @@ def test_replay_link_over_rccl_single_rank_equals_plain_sampling():
         assert plain.priority_sum() == shard.priority_sum()
         assert torch.equal(link.bucket, torch.arange(64, dtype=torch.float32, device=DEV))
         t = link.timings()
-        assert t["batch_gather_ms"] > 0 and t["header_bcast_ms"] > 0, t
+        assert (t["exchange_ms"] >= 0 and t["serve_ms"] > 0) if mode == "star" else (t["batch_gather_ms"] > 0 and t["header_bcast_ms"] > 0), t
         plain.check_errors()
         shard.check_errors()
     finally:
