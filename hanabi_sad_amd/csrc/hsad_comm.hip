@@ -97,6 +97,7 @@ struct hsad_comm {
   double* my_stats = nullptr;   // [2]
   double* all_stats = nullptr;  // [world][2]
   float* prio = nullptr;        // [1024] broadcast landing zone of scatter_priority
+  double* next_stats = nullptr; // [world][2] root of a star round: what the replies of the previous round reported
 };
 
 extern "C" {
@@ -127,7 +128,8 @@ int hsad_comm_init(const void* unique_id, int rank, int world, int device, hsad_
     return cfail(HSAD_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString(r));
   }
   if (hipMalloc((void**)&c->my_stats, 16) != hipSuccess || hipMalloc((void**)&c->all_stats, 16 * (size_t)world) != hipSuccess ||
-      hipMalloc((void**)&c->prio, 4096) != hipSuccess) {
+      hipMalloc((void**)&c->prio, 4096) != hipSuccess || hipMalloc((void**)&c->next_stats, 16 * (size_t)world) != hipSuccess ||
+      hipMemset(c->next_stats, 0, 16 * (size_t)world) != hipSuccess) {
     hsad_comm_destroy(c);
     return cfail(HSAD_ERR_NOMEM, "hipMalloc failed for the communicator scratch");
   }
@@ -143,6 +145,7 @@ void hsad_comm_destroy(hsad_comm* c) {
   if (c->my_stats) (void)hipFree(c->my_stats);
   if (c->all_stats) (void)hipFree(c->all_stats);
   if (c->prio) (void)hipFree(c->prio);
+  if (c->next_stats) (void)hipFree(c->next_stats);
   delete c;
 }
 
@@ -190,6 +193,69 @@ int hsad_comm_scatter_priority(hsad_comm* c, hsad_replay* shard, int batch, cons
   hipStream_t s = (hipStream_t)stream;
   NCCL_TRY(R->Broadcast(c->rank == root ? priority : c->prio, c->prio, (size_t)batch, ncclFloat32, root, c->comm, s));
   return hsad_replay_update_owned(shard, batch, c->prio, owner, c->rank, stream);
+}
+
+// The star-shaped round of dist.ReplayLink (mode "star") for a host that is not Python: point-to-point messages between the root
+// (the learner) and each other rank only, so no actor waits for another one.
+//   root:   [PRIME: recv every rank's (sum, size)] -> header tail = the statistics the previous replies reported -> its own serve
+//           (+ late priorities) -> ONE group: header to every rank, every rank's rows and new statistics back -> [PARAMS: bucket out]
+//   others: [PRIME: send (sum, size)] -> recv header -> serve from the header's (older) statistics -> late priorities -> rows and
+//           new statistics to root -> [PARAMS: recv bucket]
+int hsad_comm_star_round(hsad_comm* c, hsad_replay* shard, int batch, float* hdr, int flags, int root, const int32_t* answer_owner,
+                         int32_t* owner_out, uint8_t* wire_mine, uint8_t* wire_all, float* params, int64_t param_count, void* stream) {
+  Rccl* R = rccl();
+  if (!R || !c || !shard || !hdr || !owner_out || !wire_mine || batch < 1 || batch > 1024 || root < 0 || root >= c->world ||
+      (c->rank == root && !wire_all) || ((flags & HSAD_LINK_HAS_PRIO) && !answer_owner) || ((flags & HSAD_LINK_PARAMS) && (!params || param_count < 1)))
+    return cfail(HSAD_ERR_INVALID, "comm_star_round: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int W = c->world, me = c->rank;
+  const size_t bytes = (size_t)batch * hsad_replay_wire_bytes(shard), hdr_n = 2 * (size_t)batch + 4 * (size_t)W;
+  double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
+  int rc;
+  if (me != root) {
+    if (flags & HSAD_LINK_PRIME) {
+      if ((rc = hsad_replay_stats(shard, c->my_stats, stream))) return rc;
+      NCCL_TRY(R->Send(c->my_stats, 2, ncclFloat64, root, c->comm, s));
+    }
+    NCCL_TRY(R->Recv(hdr, hdr_n, ncclFloat32, root, c->comm, s));
+    if ((rc = hsad_replay_serve(shard, batch, hdr, hdr_stats, W, me, owner_out, wire_mine, stream))) return rc;
+    if ((flags & HSAD_LINK_HAS_PRIO) && (rc = hsad_replay_update_owned(shard, batch, hdr + batch, answer_owner, me, stream))) return rc;
+    if ((rc = hsad_replay_stats(shard, c->my_stats, stream))) return rc;
+    NCCL_TRY(R->GroupStart());
+    NCCL_TRY(R->Send(wire_mine, bytes, ncclUint8, root, c->comm, s));
+    NCCL_TRY(R->Send(c->my_stats, 2, ncclFloat64, root, c->comm, s));
+    NCCL_TRY(R->GroupEnd());
+    if (flags & HSAD_LINK_PARAMS) NCCL_TRY(R->Recv(params, (size_t)param_count, ncclFloat32, root, c->comm, s));
+    return HSAD_OK;
+  }
+  if (flags & HSAD_LINK_PRIME) {
+    NCCL_TRY(R->GroupStart());
+    for (int k = 0; k < W; ++k)
+      if (k != root) NCCL_TRY(R->Recv(c->next_stats + 2 * k, 2, ncclFloat64, k, c->comm, s));
+    NCCL_TRY(R->GroupEnd());
+    if ((rc = hsad_replay_stats(shard, c->next_stats + 2 * root, stream))) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(hdr_stats, c->next_stats, 16 * (size_t)W, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(c->all_stats, c->next_stats, 16 * (size_t)W, hipMemcpyDeviceToDevice, s));   // hsad_comm_all_stats: what THIS draw was cut with
+  if ((rc = hsad_replay_serve(shard, batch, hdr, hdr_stats, W, me, owner_out, wire_mine, stream))) return rc;
+  if ((flags & HSAD_LINK_HAS_PRIO) && (rc = hsad_replay_update_owned(shard, batch, hdr + batch, answer_owner, me, stream))) return rc;
+  if ((rc = hsad_replay_stats(shard, c->next_stats + 2 * root, stream))) return rc;
+  HIP_TRY(hipMemcpyAsync(wire_all + (size_t)root * bytes, wire_mine, bytes, hipMemcpyDeviceToDevice, s));
+  NCCL_TRY(R->GroupStart());
+  for (int k = 0; k < W; ++k) {
+    if (k == root) continue;
+    NCCL_TRY(R->Send(hdr, hdr_n, ncclFloat32, k, c->comm, s));
+    NCCL_TRY(R->Recv(wire_all + (size_t)k * bytes, bytes, ncclUint8, k, c->comm, s));
+    NCCL_TRY(R->Recv(c->next_stats + 2 * k, 2, ncclFloat64, k, c->comm, s));
+  }
+  NCCL_TRY(R->GroupEnd());
+  if (flags & HSAD_LINK_PARAMS) {
+    NCCL_TRY(R->GroupStart());
+    for (int k = 0; k < W; ++k)
+      if (k != root) NCCL_TRY(R->Send(params, (size_t)param_count, ncclFloat32, k, c->comm, s));
+    NCCL_TRY(R->GroupEnd());
+  }
+  return HSAD_OK;
 }
 
 const double* hsad_comm_all_stats(const hsad_comm* c) { return c ? c->all_stats : nullptr; }

@@ -749,6 +749,25 @@ int hsad_comm_gather_batch(hsad_comm* comm, hsad_replay* shard, int batch, const
  * shard writes back the positions it owned (hsad_replay_update_owned) */
 int hsad_comm_scatter_priority(hsad_comm* comm, hsad_replay* shard, int batch, const float* priority, const int32_t* owner, int root,
                                void* stream);
+/* ONE point-to-point ("star") round, the shape hanabi_sad_amd/dist.py ReplayLink runs by default: every message is between root (the
+ * learner) and one other rank, so no actor waits for another actor's statistics or rows.
+ *   hdr     device float32 [2 * batch + 4 * world]: canonical uniforms | priorities of the oldest outstanding draw | (sum, size) of
+ *           every shard as float64 pairs.  root fills the first two parts; the library fills the third with what the replies of the
+ *           PREVIOUS round reported (HSAD_LINK_PRIME, the first round: collected up front) and sends the whole header to every rank.
+ *   flags   HSAD_LINK_* ; the same value on every rank (the host's own signalling: dist.py uses the rendezvous store).
+ *   answer_owner   owner[] of the draw the priorities belong to (HSAD_LINK_HAS_PRIO; each rank keeps its owner_out of earlier rounds).
+ *   every rank serves from the header's statistics (hsad_replay_serve stretches its share onto the shard's present weight sum and
+ *   scales the raw weights), THEN writes the late priorities back, so hsad_replay_set_outstanding needs one draw more than rounds
+ *   are pipelined.  root: wire_all [world][batch][bytes] is ready for hsad_replay_assemble, hsad_comm_all_stats = what the draw was
+ *   cut with.  HSAD_LINK_PARAMS: params [param_count] leave root for every rank behind the rows.
+ *   reference: PrioritizedReplay::sample / updatePriority (rela/prioritized_replay.h:208-257), BatchRunner::updateModel
+ *   (rela/batch_runner.h:74-77) across processes. */
+#define HSAD_LINK_PARAMS 1
+#define HSAD_LINK_STOP 2
+#define HSAD_LINK_HAS_PRIO 4
+#define HSAD_LINK_PRIME 8
+int hsad_comm_star_round(hsad_comm* comm, hsad_replay* shard, int batch, float* hdr, int flags, int root, const int32_t* answer_owner,
+                         int32_t* owner_out, uint8_t* wire_mine, uint8_t* wire_all, float* params, int64_t param_count, void* stream);
 const double* hsad_comm_all_stats(const hsad_comm* comm);   /* device [world][2] (sum, size) of the last gather: the importance weights' N and sum */
 
 /* ------------------------------------------------------------------------------------------

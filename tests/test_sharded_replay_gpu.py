@@ -305,7 +305,7 @@ def test_replay_link_over_rccl_single_rank_equals_plain_sampling(mode):
 
 
 def test_hsad_comm_c_entry_points_single_rank():
-    """hsad_comm_{unique_id, init, bcast_params, gather_batch, scatter_priority} (csrc/hsad_comm.hip: RCCL bound with dlopen, no
+    """hsad_comm_{unique_id, init, bcast_params, gather_batch, scatter_priority, star_round} (csrc/hsad_comm.hip: RCCL bound with dlopen, no
     torch.distributed) on the one GPU of this box: a world of one rank, every call through the real RCCL communicator; the drawn
     batch and the shard state afterwards equal the plain sampler's on an identical replay"""
     import ctypes as C
@@ -345,6 +345,35 @@ def test_hsad_comm_c_entry_points_single_rank():
             _lib.check(lib.hsad_comm_scatter_priority(comm, shard.h, B, newp.data_ptr(), owner.data_ptr(), 0, st))
             plain.update_priority(newp)
             assert plain.priority_sum() == shard.priority_sum()
+        # the point-to-point round shape (hsad_comm_star_round): header = uniforms | late priorities | statistics; a rank serves
+        # BEFORE it writes the late priorities back, so one more draw is outstanding (a world of one: the root's own part)
+        plain.set_outstanding(3)
+        shard.set_outstanding(3)
+        PRIME, HAS_PRIO, PARAMS = 8, 4, 1
+        hdr = torch.zeros(2 * B + 4, dtype=torch.float32, device=DEV)
+        owners, prios = [], []
+        for it in range(5):
+            hdr[:B] = torch.tensor(shard.draw_canonical(B), device=DEV)
+            flags = (PRIME if it == 0 else 0) | (PARAMS if it == 2 else 0)
+            if it >= 2:
+                hdr[B:2 * B] = prios[it - 2]
+                flags |= HAS_PRIO
+            owner = torch.empty(B, dtype=torch.int32, device=DEV)
+            wire, wire_all = torch.zeros(B, wb, dtype=torch.uint8, device=DEV), torch.zeros(1, B, wb, dtype=torch.uint8, device=DEV)
+            _lib.check(lib.hsad_comm_star_round(comm, shard.h, B, hdr.data_ptr(), flags, 0, owners[it - 2].data_ptr() if it >= 2 else None,
+                                                owner.data_ptr(), wire.data_ptr(), wire_all.data_ptr(), params.data_ptr(), 1000, st))
+            stats = hdr[2 * B:].view(torch.float64).cpu().numpy()
+            batch, raw_w = shard.assemble(wire_all, owner)
+            (fx, rx, tx, bx, lx), wx = plain.sample(B)
+            if it >= 2:
+                plain.update_priority(prios[it - 2])
+            assert torch.equal(batch[0]["a"], fx["a"]) and torch.equal(batch[0]["s"], fx["s"]) and torch.equal(batch[1], rx)
+            assert torch.equal(batch[4], lx) and (owner == 0).all() and stats[1] == 40.0
+            assert plain.priority_sum() == shard.priority_sum()
+            owners.append(owner)
+            prios.append(torch.tensor((rng.random(B) * 2 + 0.05).astype(np.float32), device=DEV))
+        assert torch.equal(params, torch.arange(1000, dtype=torch.float32, device=DEV))
+        plain.check_errors()
         shard.check_errors()
     finally:
         lib.hsad_comm_destroy(comm)
