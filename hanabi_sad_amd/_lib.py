@@ -150,6 +150,7 @@ SIGNATURES = {
     "hsad_lstm_layer_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "hsad_lstm_cell_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_cell_set_variant": (C.c_int, [C.c_int, C.c_int]),
+    "hsad_gemm_set_pp": (C.c_int, [C.c_int]),
     "hsad_lstm_cell_fused_pair": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_P] * 17),
     "hsad_lstm_set_exchange_mode": (C.c_int, [C.c_int]),
     "hsad_lstm_debug_timing": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),

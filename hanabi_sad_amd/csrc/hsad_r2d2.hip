@@ -710,6 +710,7 @@ struct LstmCellArgs {
   float* h_out32;        // [Bn, H]
   bf16_t* h_out16;       // optional [Bn, H]
   int Bn, H, Kx, ldx;
+  int ldo, relu;         // only the plain-GEMM instantiation of lstm_cell_pp_kernel: row stride of h_out16 (= C16), ReLU flag
 };
 
 __global__ __launch_bounds__(256) void lstm_cell_gemm_kernel(LstmCellArgs a) {
@@ -1043,6 +1044,53 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
   }
 }
 
+// Epilogue of the PLAIN instantiation of lstm_cell_pp_kernel (C16 = act(A B^T + bias), gemm_launch routes the big bf16-output GEMMs
+// of an acting step there).  The MFMA operands are swapped in that instantiation, so a lane holds ONE output row (lane & 31) and, per
+// accumulator tile, the columns 8 g + 4 (lane >> 5) + e (g = r >> 2, e = r & 3): v_permlane32_swap of the register pair (g, g + 1)
+// leaves the 8 contiguous columns of group g on the lower half-wave and of group g + 1 on the upper one -- one 16-byte store per lane
+// and pair, no LDS round trip (the operand ring owns the LDS and keeps streaming the next tile meanwhile).  Same products, same
+// k order, same rounding as gemm_nt_bf16_kernel: identical bits.
+__device__ __forceinline__ void plain_epilogue_256(const LstmCellArgs& a, f32x16 (&acc)[4][2], int cm0, int cn0, int wm, int wn, int lane) {
+  const bool up = lane >= 32;
+  const int row0 = cm0 + wm * 128 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int gp = 0; gp < 2; ++gp) {
+      const int col = cn0 + wn * 64 + j * 32 + 8 * (2 * gp + (up ? 1 : 0));
+      float b[8];
+      if (a.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + col), b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
+        b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[e] = 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[i][j][8 * gp + e], y = acc[i][j][8 * gp + 4 + e];
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+          v[e] = __uint_as_float(sw[0]) + b[e];
+          v[4 + e] = __uint_as_float(sw[1]) + b[4 + e];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        uint4 o;
+        o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+        o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+        o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+        o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+        *reinterpret_cast<uint4*>(a.h_out16 + (size_t)(row0 + i * 32) * a.ldo + col) = o;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The 256 x 256 cell kernel with a phase-interleaved k loop ("ping-pong"): same tile, same wave grid (2 x 4 waves of 128 x 64), same
 // accumulator layout and epilogue as lstm_cell_gemm256_kernel, but
@@ -1061,14 +1109,16 @@ __global__ __launch_bounds__(512) void lstm_cell_gemm256_kernel(LstmCellArgs a) 
 // ---------------------------------------------------------------------------------------------------
 // np = 2: TWO problems of the same shape in one launch (a2: the target net's cell next to the online net's, hsad_lstm_cell_fused_pair) --
 // problem 1's row tiles follow problem 0's in the tile order, the operand stream runs across the boundary like across any tile switch.
-template <bool STATE, int ABL = 0>   // ABL (developer instantiations; 1-8: results are garbage): 1 no DMA, 2 no MFMA, 4 no stagger, 8 no fragment reads, 128 phase timers
+// PLAIN: the same operand stream and k loop as a plain GEMM  h_out16 [Bn, ldo] = act(x [Bn, Kx] Wcat [H, Kx]^T + bias)  -- a.H is then
+// the number of output COLUMNS, there is no recurrent part, and the epilogue is plain_epilogue_256.
+template <bool STATE, int ABL = 0, bool PLAIN = false>   // ABL (developer instantiations; 1-8: results are garbage): 1 no DMA, 2 no MFMA, 4 no stagger, 8 no fragment reads, 128 phase timers
 __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a, LstmCellArgs a2, int np) {
   constexpr int BM = 256, BN = 256;
   constexpr uint32_t kHalf = 128 * kBK * 2;               // bytes of a half tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_cell[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int H = a.H, K = a.Kx + H, N4 = 4 * H;
+  const int H = a.H, K = PLAIN ? a.Kx : a.Kx + H, N4 = PLAIN ? H : 4 * H;
   const int tiles_n = N4 / BN, tiles_m = a.Bn / BM;
   const bool xcd_order = (gridDim.x % 8) == 0;
   const int xcd = xcd_order ? (int)(blockIdx.x & 7) : 0, n_xcd = xcd_order ? 8 : 1;
@@ -1111,7 +1161,7 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a, LstmC
     const int k0 = p_kt * kBK;
     const uint32_t slot = (uint32_t)(p_T & 1) * 4u * kHalf;
     if (kind == 0 || kind == 3) {
-      const bool part2 = k0 >= a.Kx;
+      const bool part2 = !PLAIN && k0 >= a.Kx;
       const bf16_t* hp = p_prob ? a2.h_prev16 : a.h_prev16;
       const bf16_t* xp = p_prob ? a2.x : a.x;
       const char* abase = part2 ? reinterpret_cast<const char*>(hp + (size_t)p_m0 * H + (k0 - a.Kx))
@@ -1165,7 +1215,8 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a, LstmC
   };
   auto mma = [&](const bf16x8& x, const bf16x8& y, f32x16& c) {
     if (ABL & 2) { asm volatile("" :: "v"(x), "v"(y)); return; }
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    if (PLAIN) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y, x, c, 0, 0, 0);     // transposed accumulator tile: a lane holds one output ROW
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
   };
 
   int seq = blockIdx.x / n_xcd, m0 = 0, n0 = 0, prob = 0;
@@ -1274,7 +1325,8 @@ __global__ __launch_bounds__(512) void lstm_cell_pp_kernel(LstmCellArgs a, LstmC
 #undef PP_END_M
 #undef PP_PIN
     }
-    cell_epilogue_256<STATE, kCellStoreAux, 0>(prob ? a2 : a, acc, m0, n0, wm, wn, lane);
+    if (PLAIN) plain_epilogue_256(prob ? a2 : a, acc, m0, n0, wm, wn, lane);
+    else cell_epilogue_256<STATE, kCellStoreAux, 0>(prob ? a2 : a, acc, m0, n0, wm, wn, lane);
     PP_STAMP(4)
     seq += per_xcd;
     if (!tile_of(seq, m0, n0, prob)) break;
@@ -3678,6 +3730,12 @@ struct GemmTiming {
   std::vector<GemmTimingRec> recs;
 } g_gemm_timing;
 }  // namespace
+static int g_gemm_pp = getenv("HSAD_GEMM_PP") ? atoi(getenv("HSAD_GEMM_PP")) : 1;    // developer switch, hsad_gemm_set_pp
+int hsad_gemm_set_pp(int on) {
+  g_gemm_pp = on != 0;
+  return HSAD_OK;
+}
+
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* C32,
                        int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k, const void* relu_mask16,
                        int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream,
@@ -3722,6 +3780,35 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     HIP_TRY(hipEventCreate(&trec.e0));
     HIP_TRY(hipEventCreate(&trec.e1));
     HIP_TRY(hipEventRecord(trec.e0, s));
+  }
+  // Big bf16-output GEMMs (the input layer of an acting step: 32768 x 512 x 896, online + target) run on the 256 x 256 phase-interleaved
+  // kernel of the fused cell in its PLAIN instantiation: identical bits, 89 -> ~60 us for that pair.  Needs whole 256 x 256 tiles, at
+  // least one per CU, B rows of exactly K elements, no split / mask / row map / fp32 output.
+  if (g_gemm_pp && C16 && !C32 && gz == 1 && !accumulate && !relu_mask16 && !row_map && M % 256 == 0 && N % 256 == 0 && K % kBK == 0 &&
+      K >= 2 * kBK && ldb == K && (long)(M / 256) * (N / 256) * np >= n_cu && !(lda & 7) && !(ldc16 & 7) &&
+      !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C16) & 15) && (!bias || !((uintptr_t)bias & 15)) &&
+      ((size_t)M + 256) * (size_t)lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32) &&
+      (np == 1 || !((g.dA | g.dB | g.dC16) & 15))) {
+    LstmCellArgs a{(const bf16_t*)A, nullptr, (const bf16_t*)B, bias, nullptr, nullptr, nullptr, (bf16_t*)C16, M, N, K, lda, ldc16, relu};
+    LstmCellArgs a2 = a;
+    if (np == 2) {
+      a2.x = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(A) + g.dA);
+      a2.Wcat = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(B) + g.dB);
+      a2.bias = bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + g.dbias) : nullptr;
+      a2.h_out16 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(C16) + g.dC16);
+    }
+    const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
+    long grid = std::min<long>((long)(M / 256) * (N / 256) * np, (long)n_cu);
+    if (grid >= 64) grid &= ~7L;
+    auto kp = lstm_cell_pp_kernel<false, 0, true>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, s, a, a2, np);
+    HIP_TRY(hipGetLastError());
+    if (trec.e0) {
+      HIP_TRY(hipEventRecord(trec.e1, s));
+      g_gemm_timing.recs.push_back(trec);
+    }
+    return HSAD_OK;
   }
   // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
   const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz * np;

@@ -324,6 +324,10 @@ int hsad_gemm_nt_bf16(const void* A, int lda, const void* B, int ldb, int M, int
 int hsad_gemm_nt_bf16_pair(const void* A0, const void* A1, int lda, const void* B0, const void* B1, int ldb, int M, int N, int K,
                            const float* bias0, const float* bias1, float* C32_0, float* C32_1, int ldc, void* C16_0, void* C16_1,
                            int ldc16, int relu, void* stream);
+/* developer switch (default 1; env HSAD_GEMM_PP): bf16-output GEMMs of whole 256 x 256 tiles, at least one per CU, run on the
+ * phase-interleaved 256 x 256 kernel (the fused cell kernel's operand stream with a plain epilogue) -- identical bits, 0 = the
+ * 128 x 128 kernel everywhere */
+int hsad_gemm_set_pp(int on);
 /* fp32 [M,K] (row stride ld_src) -> bf16 [M,Kp] zero padded */
 int hsad_cast_pad_bf16(const float* src, int M, int K, int ld_src, void* dst, int Kp, void* stream);
 /* bf16 [R,C] -> [C,R] */

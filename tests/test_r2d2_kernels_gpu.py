@@ -426,6 +426,43 @@ def test_gemm_pair_launch_equals_two_launches(M, N, K, out):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], ref)
 
 
+@pytest.mark.parametrize("M,N,K,pair,relu,with_bias", [(32768, 512, 896, True, True, True), (16384, 512, 128, True, False, True),
+                                                       (65536, 256, 192, False, True, False), (16384, 1024, 512, False, True, True)])
+def test_big_bf16_output_gemm_on_the_phase_interleaved_kernel_gives_identical_bits(M, N, K, pair, relu, with_bias):
+    """bf16-output GEMMs of whole 256 x 256 tiles (>= one per CU: the input layer of an acting step, 32768 x 512 x 896 for the online +
+    target pair) are routed to the fused cell kernel's phase-interleaved operand stream with a plain epilogue (operands swapped in the
+    MFMA, v_permlane32_swap, 16-byte stores).  Same products, same k order, same rounding: the output must equal the 128 x 128
+    kernel's to the bit -- single and paired launches (shared A: one observation, two nets), with / without bias and ReLU."""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    Bm = [(torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).to(torch.bfloat16) for _ in range(2)]
+    bias = [torch.randn(N, generator=g).to(DEV) for _ in range(2)]
+    st, p = _s(torch.device(DEV)), (lambda t: t.data_ptr())
+    outs = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.hsad_gemm_set_pp(on))
+            o = [torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+            if pair:
+                _lib.check(lib.hsad_gemm_nt_bf16_pair(p(A), p(A), K, p(Bm[0]), p(Bm[1]), K, M, N, K, p(bias[0]) if with_bias else None,
+                                                      p(bias[1]) if with_bias else None, None, None, 0, p(o[0]), p(o[1]), N, int(relu), st))
+            else:
+                _lib.check(lib.hsad_gemm_nt_bf16(p(A), K, p(Bm[0]), K, M, N, K, p(bias[0]) if with_bias else None, None, 0, p(o[0]), N, int(relu), 0, st))
+            torch.cuda.synchronize()
+            outs[on] = o
+    finally:
+        lib.hsad_gemm_set_pp(1)
+    for q in range(2 if pair else 1):
+        assert torch.equal(outs[1][q], outs[0][q]), (q, (outs[1][q].float() - outs[0][q].float()).abs().max())
+        rows = torch.arange(0, M, 997, device=DEV)
+        want = A[rows].float() @ Bm[q].float().T + (bias[q] if with_bias else 0)
+        want = torch.relu(want) if relu else want
+        assert torch.allclose(outs[1][q][rows].float(), want, rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("N,H,state", [(4096, 512, True), (8192, 256, True), (4096, 512, False), (12288, 512, True)])
 def test_fused_cell_kernel_variants_give_identical_bits(N, H, state):
     """hsad_lstm_cell_fused launches one of three kernels: 128 x 128 tiles, 256 x 256 tiles with one barrier per k step, 256 x 256 tiles
