@@ -66,7 +66,10 @@ class RNNPrioritizedReplay:
     def num_add(self):
         return 0 if self.impl is None else self.impl.num_add()
 
+    num_sample = 0         # sample() calls so far: the clock Context.set_pace runs the rollout by
+
     def sample(self, batchsize, device=None):
+        self.num_sample += 1
         (f, reward, terminal, bootstrap, seq_len), weight = self.impl.sample(batchsize)
         obs = {k: v for k, v in f.items() if k not in self.ACTION_KEYS}
         action = {k: v.squeeze(2) for k, v in f.items() if k in self.ACTION_KEYS}
@@ -315,6 +318,38 @@ class Context:
         # previous pause when a resume / pause pair follows within the thread's 1 ms nap)
         self._cv = threading.Condition()
         self._pause_ticket, self._parked_ticket, self._done = 0, 0, False
+        self._pace = None          # (replay, steps per sample() call), see set_pace
+        self._run_ahead, self._marks = 0, []
+
+    def set_pace(self, replay, steps_per_sample=1.0, run_ahead=2):
+        """NOT in the reference (rela/context.h free-runs; so does this class until set_pace is called).  On ONE GPU a free-running
+        rollout thread and a training loop share the device very unevenly: the rollout's full-chip kernels are always queued, and the
+        learner's persistent launches wait behind each of them.  With a pace the loop thread issues
+        `steps_per_sample` rollout steps per `replay.sample()` call of the training loop, once that loop has started sampling (the
+        burn-in before it free-runs), and its host never gets more than `run_ahead` steps ahead of the device -- the operating point
+        of selfplay's explicit interleave through the reference's two-thread API: rollout on the Context's stream, next to the
+        update on the driver's.  set_pace(None) returns to free-running."""
+        self._pace = None if replay is None else (replay, float(steps_per_sample), [None, 0.0])
+        self._run_ahead = int(run_ahead) if replay is not None else 0
+
+    def _may_step(self):
+        """pace gate of the loop thread: True = issue a step now"""
+        if self._run_ahead > 0 and len(self._marks) > self._run_ahead:
+            if not self._marks[0].query():
+                return False
+            self._marks.pop(0)
+        if self._pace is None:
+            return True
+        replay, per, st = self._pace
+        n = replay.num_sample
+        if n == 0:
+            return True                          # the training loop has not started: burn-in
+        if st[0] is None:
+            st[0] = n - 1                        # credits count from the first sample() the thread notices
+        if st[1] >= (n - st[0]) * per:
+            return False
+        st[1] += 1.0
+        return True
 
     def push_env_thread(self, loop):
         self.loops.append(loop)
@@ -331,6 +366,9 @@ class Context:
                             self._cv.notify_all()
                     time.sleep(0.001)
                     continue
+                if (self._pace is not None or self._run_ahead > 0) and not self._may_step():
+                    time.sleep(0)                # yield: the driver's thread is issuing the update this step waits for
+                    continue
                 busy = False
                 for lp in self.loops:
                     if self._paused or self._stop:
@@ -343,6 +381,10 @@ class Context:
                             else:
                                 lp.step()
                         busy = True
+                if self._run_ahead > 0 and self._stream is not None:
+                    e = torch.cuda.Event()
+                    e.record(self._stream)
+                    self._marks.append(e)
                 if not busy and not self._paused:
                     break
         except Exception as e:   # surfaced by the next Context call from the driver's thread

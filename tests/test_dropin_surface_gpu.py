@@ -94,6 +94,60 @@ def test_reference_shaped_training_driver(method):
     assert len(set(per_actor)) == 1 and per_actor[0] % per_thread == 0          # R2D2Actor::numAct_ += num_envs per act()
 
 
+def test_context_pace_runs_the_rollout_by_the_training_loops_samples():
+    """rela.Context.set_pace (an addition to the reference's free-running Context for one-GPU jobs): the loop thread free-runs while
+    nobody samples (burn-in), then issues `steps_per_sample` rollout steps per replay.sample() call of the training loop and stops
+    when that loop stops; set_pace(None) returns to free-running"""
+    import hanalearn
+    import rela
+    from hanabi_sad_amd.selfplay import generate_explore_eps
+    per_thread, P, hand, n, gamma, eta, T, B = 64, 2, 5, 3, 0.999, 0.9, 80, 16
+    eps = generate_explore_eps(0.1, 7, 80)
+    games = create_envs(hanalearn, per_thread, 11, P, hand, 0, eps, T, True)
+    agent = TinyAgent(games[0].feature_size(), 128, games[0].num_action(), hand, 3)
+    replay = rela.RNNPrioritizedReplay(2048, 1, 0.9, 0.6, 3)
+    runner = rela.BatchRunner(agent, DEV, 100, ["act", "compute_priority"])
+    acts = [rela.R2D2Actor(runner, n, per_thread, gamma, eta, T, 1, replay) for _ in range(P)]
+    env = hanalearn.HanabiVecEnv()
+    for g in games:
+        env.append(g)
+    context = rela.Context()
+    context.push_env_thread(hanalearn.HanabiThreadLoop(acts, env, False))
+    context.set_pace(replay, 2.0)
+    context.start()
+    steps = lambda: acts[0].num_act() // per_thread
+    t0 = time.time()
+    while replay.size() < 4 * B:                       # nobody samples yet: free-running burn-in
+        assert time.time() - t0 < 120
+        time.sleep(0.02)
+
+    def settled():
+        a = steps()
+        time.sleep(0.3)
+        return a if steps() == a else None
+    replay.sample(B, DEV)                               # the first sample() starts the clock: two steps of credit
+    replay.update_priority(torch.ones(B, device=DEV))
+    t0 = time.time()
+    while (base := settled()) is None:                  # the thread spends its credit, then waits
+        assert time.time() - t0 < 60
+    for k in range(1, 6):
+        replay.sample(B, DEV)
+        replay.update_priority(torch.ones(B, device=DEV))
+        t0 = time.time()
+        while steps() < base + 2 * k:
+            assert time.time() - t0 < 60
+            time.sleep(0.005)
+        time.sleep(0.2)
+        assert steps() == base + 2 * k, (k, steps(), base)     # exactly two more steps per sample, never a third
+    context.set_pace(None)
+    t0 = time.time()
+    while steps() < base + 40:                          # free-running again
+        assert time.time() - t0 < 60
+        time.sleep(0.01)
+    context.pause()
+    context.terminate()
+
+
 def test_reference_shaped_eval_driver():
     """eval.py:25-66: one game per env, greedy actors, poll context.terminated(), read game.last_score()"""
     from hanabi_sad_amd import hanalearn, rela

@@ -96,7 +96,11 @@ def one_update(u):
 
 
 results = []
-for label, stream in (("default-priority stream", torch.cuda.Stream(DEV)), ("high-priority stream   ", torch.cuda.Stream(DEV, priority=-1))):
+for label, stream, pace in (("free-running rollout, default-priority stream", torch.cuda.Stream(DEV), None),
+                            ("free-running rollout, high-priority stream   ", torch.cuda.Stream(DEV, priority=-1), None),
+                            ("Context.set_pace(replay, 1 step per sample)  ", torch.cuda.Stream(DEV), 1.0),
+                            ("Context.set_pace(replay, 2 steps per sample) ", torch.cuda.Stream(DEV), 2.0)):
+    ctx.set_pace(replay if pace else None, pace or 1.0)
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         for u in range(20):
