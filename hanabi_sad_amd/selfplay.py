@@ -9,6 +9,7 @@ the learner: its batches are assembled from ALL shards (stratified over their co
 back to the owning shards, and the online/target parameters are broadcast over RCCL every --actor_sync_freq updates
  — see hanabi_sad_amd/dist.py."""
 import argparse
+import contextlib
 import time
 
 import numpy as np
@@ -97,14 +98,40 @@ class Trainer:
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
                                  vdn=self.vdn, native=None if getattr(args, "native_actor", 1) else False) if self.acting else None
         self.num_update = 0
+        # --overlap_rollout: the rollout issues on a stream of its own, next to the update on the caller's stream (one host thread feeds
+        # both; replay and writer calls from the two sides are ordered by the library's stream fence).  The reference's actor threads
+        # run concurrently with its training thread the same way (selfplay.py:208-244, rela/context.h:43-50).
+        self.act_stream = None
+        if self.acting and self.learner is not None and getattr(args, "overlap_rollout", 0) and torch.device(device).type == "cuda":
+            self.act_stream = torch.cuda.Stream(torch.device(device))
+            self.act_stream.wait_stream(torch.cuda.current_stream(torch.device(device)))     # everything built so far precedes the first step
+
+    def act_step(self, n=1):
+        """n rollout steps, on the rollout stream when there is one"""
+        if self.act_stream is None:
+            for _ in range(n):
+                self.actor.step()
+            return
+        with torch.cuda.stream(self.act_stream):
+            for _ in range(n):
+                self.actor.step()
+
+    def join_rollout(self):
+        """the caller's stream waits for the rollout issued so far (before evaluation, checkpoints, error checks)"""
+        if self.act_stream is not None:
+            torch.cuda.current_stream(self.act_stream.device).wait_stream(self.act_stream)
 
     def update_actor_model(self):
-        if self.learner is not None:
-            for k in self.param_names:
-                self.act_online.w[k].copy_(self.learner.online.w[k])
-                self.act_target.w[k].copy_(self.learner.target.w[k])
-        self.act_online.refresh()
-        self.act_target.refresh()
+        if self.act_stream is not None:      # behind the optimizer step that wrote the weights, between two rollout steps
+            self.act_stream.wait_stream(torch.cuda.current_stream(self.act_stream.device))
+        with (torch.cuda.stream(self.act_stream) if self.act_stream is not None else contextlib.nullcontext()):
+            if self.learner is not None:
+                for k in self.param_names:
+                    self.act_online.w[k].copy_(self.learner.online.w[k])
+                    self.act_target.w[k].copy_(self.learner.target.w[k])
+            self.act_online.refresh()
+            self.act_target.refresh()
+        self.join_rollout()                  # the next update overwrites what the copy reads
 
     def learner_update(self, stopwatch=None):
         """one learner iteration (selfplay.py:208-244) of a single-GPU job (several GPUs: run_link_learner / run_link_actor below,
@@ -196,6 +223,8 @@ def parse_args(argv=None):
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
     p.add_argument("--num_eval_game", type=int, default=1000)
+    p.add_argument("--overlap_rollout", type=int, default=1, help="1: the rollout steps of a one-GPU job issue on a stream of their own, "
+                   "next to the update (like the reference's actor threads next to its training thread); 0: one stream, strictly alternating")
     p.add_argument("--stopwatch", type=int, default=0, help="1 = time the reference's five learner sections (adds device syncs)")
     p.add_argument("--native_actor", type=int, default=1,
                    help="1: the actor-loop body is the library's hsad_actor_step (one C call per step); 0: the same body in Python "
@@ -357,11 +386,11 @@ def run_epochs(tr, args, rank=0, link=None):
                 rows[b, 0], rows[b, 1] = loss, g_norm
             run_link_learner(tr, args, link, args.epoch_len, on_update=record, stop=False)
         for b in range(args.epoch_len if link is None else 0):
-            for _ in range(args.act_steps_per_update):
-                tr.actor.step()
+            tr.act_step(args.act_steps_per_update)
             loss, g_norm = tr.learner_update(sw if args.stopwatch else None)
             if loss is not None:
                 rows[b, 0], rows[b, 1] = loss, g_norm
+        tr.join_rollout()
         check_sync()
         if tr.learner is not None and hasattr(tr.learner, "check_sync"):
             tr.learner.check_sync()
@@ -457,8 +486,7 @@ def main(argv=None):
         return
     t0 = time.time()
     while tr.replay.size() < max(args.batchsize, args.burn_in_frames // world):   # per-shard share of the burn-in
-        for _ in range(10):
-            tr.actor.step()
+        tr.act_step(10)
     tr.env.check_errors()
     print("burn-in done: replay %d sequences after %d acts in %.1fs" % (tr.replay.size(), tr.actor.num_act, time.time() - t0))
     if args.num_epoch > 0:
@@ -467,8 +495,7 @@ def main(argv=None):
         return
     t0, acts0 = time.time(), tr.actor.num_act
     for u in range(args.num_update):
-        for _ in range(args.act_steps_per_update):
-            tr.actor.step()
+        tr.act_step(args.act_steps_per_update)
         loss, g_norm = tr.learner_update()
         if u % 20 == 0 and loss is not None:
             print("update %d loss %.4f grad_norm %.3f replay %d" % (u, float(loss), float(g_norm), tr.replay.size()))
