@@ -186,6 +186,7 @@ SIGNATURES = {
     "hsad_refresh_add_bias": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "hsad_refresh_launch": (C.c_int, [_P]),
     "hsad_act_select_q": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P]),
+    "hsad_act_select_q2": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P]),
     "hsad_q_at": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P]),
     "hsad_zero_state_rows": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "hsad_lstm_forward_chunk_multi": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),

@@ -552,8 +552,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     CK(net_step_pair(n, target, N, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, ws_tg, &so, &st, s, (bf16_t*)h_out_bf16));
     CK(hsad_gemm_nt_bf16_pair(so.o16, st.o16, H, n->Wheads, target->Wheads, H, N, NH, H, n->bheads, target->bheads, hd, hd_t, NH, nullptr,
                               nullptr, 0, 0, stream));
-    CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
-    CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
+    CK(hsad_act_select_q2(hd, hd_t, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, q_target_greedy, scratch, stream));
     return 0;
   }
   CK(net_step(n, N, a16, h0, c0, (const bf16_t*)h0_bf16, h_out, c_out, ws_on, &so, s, (bf16_t*)h_out_bf16, pair_in, true));
@@ -566,8 +565,7 @@ int hsad_r2d2_act(hsad_r2d2_net* online, hsad_r2d2_net* target, int N, const flo
     CK(net_step(target, N, a16, h0, c0, h16_shared, nullptr, nullptr, ws_tg, &st, s, nullptr, true));
     CK(hsad_gemm_nt_bf16_pair(so.o16, st.o16, H, n->Wheads, target->Wheads, H, N, NH, H, n->bheads, target->bheads, hd, hd_t, NH, nullptr,
                               nullptr, 0, 0, stream));
-    CK(hsad_act_select_q(hd, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, scratch, stream));
-    CK(hsad_q_at(hd_t, NH, legal_move, greedy_a, N, A, q_target_greedy, stream));
+    CK(hsad_act_select_q2(hd, hd_t, NH, legal_move, eps, N, A, seed, counter, a, greedy_a, q_online_a, q_target_greedy, scratch, stream));
     return 0;
   }
   CK(hsad_gemm_nt_bf16(so.o16, H, n->Wheads, H, N, NH, H, n->bheads, hd, NH, nullptr, 0, 0, 0, stream));

@@ -3497,14 +3497,18 @@ __global__ __launch_bounds__(256) void act_select_q_kernel(const float* __restri
                                                            const float* __restrict__ eps, const float* __restrict__ block_min, int nb,
                                                            int N, int A, unsigned long long seed, unsigned long long counter,
                                                            int64_t* __restrict__ a_out, int64_t* __restrict__ greedy_out,
-                                                           float* __restrict__ qa_out, int R) {
+                                                           float* __restrict__ qa_out, int R,
+                                                           const float* __restrict__ heads_t = nullptr, float* __restrict__ tq_out = nullptr) {
   extern __shared__ float s_act[];
   float* s_h = s_act;                    // [R][ldh]   (R <= 256 rows per block: what fits 60 KB of LDS)
   float* s_l = s_act + R * ldh;          // [R][A]
+  float* s_t = s_l + R * A;              // [R][ldh]   the TARGET net's heads (hsad_act_select_q2): Q_target(s, greedy) in the same pass
   __shared__ float s_red[256];
   const int tid = threadIdx.x, m0 = blockIdx.x * R, rows = min(R, N - m0);
   for (int i = tid; i < rows * ldh; i += 256) s_h[i] = heads[(size_t)m0 * ldh + i];
   for (int i = tid; i < rows * A; i += 256) s_l[i] = legal[(size_t)m0 * A + i];
+  if (heads_t)
+    for (int i = tid; i < rows * ldh; i += 256) s_t[i] = heads_t[(size_t)m0 * ldh + i];
   float mn = 3.4e38f;
   for (int i = tid; i < nb; i += 256) mn = fminf(mn, block_min[i]);
   s_red[tid] = mn;
@@ -3549,6 +3553,13 @@ __global__ __launch_bounds__(256) void act_select_q_kernel(const float* __restri
   if (qa_out) {
     mean /= (float)A;
     qa_out[m] = h[A] + h[act] * lg[act] - mean;     // q_head_kernel's v + a*legal - mean_A(a*legal) at the chosen action
+  }
+  if (heads_t) {                                    // q_at_kernel's arithmetic on the target heads at the greedy action
+    const float* ht = s_t + tid * ldh;
+    float mt = 0.f;
+    for (int j = 0; j < A; ++j) mt += ht[j] * lg[j];
+    mt /= (float)A;
+    tq_out[m] = ht[A] + ht[bi] * lg[bi] - mt;
   }
 }
 
@@ -4521,6 +4532,25 @@ int hsad_act_select_q(const float* heads, int ldh, const float* legal, const flo
   hipLaunchKernelGGL(adv_min_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, N, A, scratch + 1);
   hipLaunchKernelGGL(act_select_q_kernel, dim3((N + R - 1) / R), dim3(256), (size_t)R * (ldh + A) * 4, s, heads, ldh, legal, eps, scratch + 1,
                      nb, N, A, (unsigned long long)seed, (unsigned long long)counter, a_out, greedy_out, qa_out, R);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// hsad_act_select_q on the online heads AND hsad_q_at(target heads, greedy action) as one launch: the tail of an acting step whose
+// two nets' heads came out of one paired GEMM (identical bits to the two calls)
+int hsad_act_select_q2(const float* heads, const float* heads_target, int ldh, const float* legal, const float* eps, int N, int A,
+                       uint64_t seed, uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* q_target_greedy,
+                       float* scratch, void* stream) {
+  if (!heads || !heads_target || !legal || !a_out || !greedy_out || !q_target_greedy || !scratch)
+    return nfail(HSAD_ERR_INVALID, "act_select_q2: null");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = (N + 255) / 256;
+  const int R = std::min(256, (60 * 1024) / ((2 * ldh + A) * 4));
+  if (R < 1) return nfail(HSAD_ERR_INVALID, "act_select_q2: heads / legal rows too wide for the staged kernel");
+  hipLaunchKernelGGL(adv_min_kernel, dim3(nb), dim3(256), 0, s, heads, ldh, N, A, scratch + 1);
+  hipLaunchKernelGGL(act_select_q_kernel, dim3((N + R - 1) / R), dim3(256), (size_t)R * (2 * ldh + A) * 4, s, heads, ldh, legal, eps,
+                     scratch + 1, nb, N, A, (unsigned long long)seed, (unsigned long long)counter, a_out, greedy_out, qa_out, R, heads_target,
+                     q_target_greedy);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

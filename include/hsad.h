@@ -485,6 +485,11 @@ int hsad_zero_rows(float* x, const uint8_t* flag, int L, int N, int H, int rows_
  * (hsad_q_head's value at a_out; qa_out may be NULL), and Q(s, action) alone for the target pass */
 int hsad_act_select_q(const float* heads, int ldh, const float* legal, const float* eps, int N, int A, uint64_t seed,
                       uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* scratch, void* stream);
+/* the same plus hsad_q_at(heads_target, greedy action) in ONE launch: the tail of hsad_r2d2_act when the two nets' heads come out of one
+ * paired GEMM (Q_online(s, a) and Q_target(s, greedy) of r2d2.py:341-368 for the priorities); identical bits to the two calls */
+int hsad_act_select_q2(const float* heads, const float* heads_target, int ldh, const float* legal, const float* eps, int N, int A,
+                       uint64_t seed, uint64_t counter, int64_t* a_out, int64_t* greedy_out, float* qa_out, float* q_target_greedy,
+                       float* scratch, void* stream);
 int hsad_q_at(const float* heads, int ldh, const float* legal, const int64_t* action, int M, int A, float* qa, void* stream);
 /* hsad_zero_rows for the whole carried state at once: fp32 h / c [L,N,H] and (optional) the bf16 copy of h */
 int hsad_zero_state_rows(float* h, float* c, void* h_bf16, const uint8_t* flag, int L, int N, int H, int rows_per_flag, void* stream);

@@ -426,6 +426,33 @@ def test_gemm_pair_launch_equals_two_launches(M, N, K, out):
     assert torch.equal(got[0], want[0]) and torch.equal(got[1], ref)
 
 
+@pytest.mark.parametrize("N,A,ldh", [(32768, 21, 37), (1000, 21, 37), (4099, 49, 62)])
+def test_acting_tail_in_one_launch_equals_the_two_calls(N, A, ldh):
+    """hsad_act_select_q2 (eps-greedy action, greedy action, Q_online(s, a) from the online heads AND Q_target(s, greedy) from the
+    target heads in one launch) against hsad_act_select_q + hsad_q_at: identical actions and identical bits of both Q values, with
+    row tails and the 5-player head width"""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    g = torch.Generator(device="cpu").manual_seed(N + A)
+    hd = torch.randn(N, ldh, generator=g).to(DEV)
+    hd_t = torch.randn(N, ldh, generator=g).to(DEV)
+    legal = (torch.rand(N, A, generator=g) < 0.4).float()
+    legal[:, A - 1] = (legal[:, :A - 1].sum(1) == 0).float()
+    legal = legal.to(DEV)
+    eps = (torch.rand(N, generator=g) * 0.5).to(DEV)
+    st, p = _s(torch.device(DEV)), (lambda t: t.data_ptr())
+    mk = lambda dt: [torch.full((N,), 7, dtype=dt, device=DEV) for _ in range(2)]
+    a, gr, qa, tq = mk(torch.int64), mk(torch.int64), mk(torch.float32), mk(torch.float32)
+    scratch = torch.zeros(4096, device=DEV)
+    _lib.check(lib.hsad_act_select_q(p(hd), ldh, p(legal), p(eps), N, A, 5, 9, p(a[0]), p(gr[0]), p(qa[0]), p(scratch), st))
+    _lib.check(lib.hsad_q_at(p(hd_t), ldh, p(legal), p(gr[0]), N, A, p(tq[0]), st))
+    _lib.check(lib.hsad_act_select_q2(p(hd), p(hd_t), ldh, p(legal), p(eps), N, A, 5, 9, p(a[1]), p(gr[1]), p(qa[1]), p(tq[1]), p(scratch), st))
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], a[1]) and torch.equal(gr[0], gr[1]) and torch.equal(qa[0], qa[1]) and torch.equal(tq[0], tq[1])
+    assert (a[0] != gr[0]).any() and legal.gather(1, a[0].view(-1, 1)).min() == 1
+
+
 @pytest.mark.parametrize("M,N,K,pair,relu,with_bias", [(32768, 512, 896, True, True, True), (16384, 512, 128, True, False, True),
                                                        (65536, 256, 192, False, True, False), (16384, 1024, 512, False, True, True)])
 def test_big_bf16_output_gemm_on_the_phase_interleaved_kernel_gives_identical_bits(M, N, K, pair, relu, with_bias):
