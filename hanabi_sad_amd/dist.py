@@ -278,8 +278,8 @@ class ReplayLink:
 
       * actors never wait for the learner's compute.  A round is opened by the learner BEFORE it issues the kernels of the update
         in flight (`begin`), and runs on a side stream there; actor ranks notice it by polling a counter in the rendezvous store
-        between two of their own steps (`poll`) and serve it from their stream (`serve`) -- a header broadcast, a 16-byte-per-rank
-        all-gather, two small kernels and one send.
+        between two of their own steps (`poll`) and serve it from their stream (`serve`) -- one receive (the header), two small
+        kernels and one send in the default point-to-point shape (see "Two shapes of a round" below).
       * the priorities of batch k travel in the header of a LATER round (k + 2 when rounds are pipelined like that), next to the
         canonical uniforms of the new draw: no separate scatter, no message per shard.  Shards keep their drawn batches in a
         queue and answer the oldest (hsad_replay_set_outstanding = the reference's prefetch depth: its prefetched batches are
@@ -287,10 +287,12 @@ class ReplayLink:
       * nothing on an actor rank reads device memory from the host: shard statistics, stratification, ownership, the draw and the
         packing of the rows are kernels (hsad_replay_stats / _serve / _update_owned); message sizes are fixed ([B] slots of
         hsad_replay_wire_bytes: stored rows with the bit-packed observation, ~13 KB per sequence), so no size ever has to be known.
-      * every rank sends ONE buffer per round (gather to the learner = one grouped send / recv in RCCL); the learner unpacks all
+      * every rank sends ONE buffer per round (one grouped send / recv in RCCL at the learner); the learner unpacks all
         of them with one kernel (hsad_replay_assemble) straight into the batch tensors (bf16 observation operand included).
       * parameters go out as one persistent flat bucket [online | target], staged by the learner on its compute stream
-        (`stage_params`) and broadcast inside a round whose flags say so.
+        (`stage_params`) and sent inside a round whose flags say so.
+      * an actor keeps its host at most a few steps ahead of its device (hsad_actor_set_run_ahead, selfplay.run_link_actor):
+        a round is stream-ordered behind whatever the actor has queued.
 
     Two shapes of a round (`mode`, default "star"; HSAD_LINK_MODE overrides):
 
