@@ -148,6 +148,33 @@ def test_context_pace_runs_the_rollout_by_the_training_loops_samples():
     context.terminate()
 
 
+def test_action_matrix_tool_counts_like_the_reference_loop():
+    """hanabi_sad_amd.action_matrix (pyhanabi/tools/action_matrix.py:31-107): whole greedy self-play games collected in VDN layout
+    through rela / hanalearn, and the conditional action matrix computed over all sequences at once -- against the reference's
+    per-step loop (its analyze(), restated here) on the same dataset"""
+    from hanabi_sad_amd import action_matrix as am
+    from hanabi_sad_amd.selfplay import init_weights
+    W = init_weights(838, 128, 21, 5, 4)
+    dataset, context = am.create_dataset(W, True, DEV, dataset_size=48, num_game=12, max_len=80, seed=3)
+    assert dataset.size() == 48
+    normed, counts = am.analyze(dataset)
+    want = np.zeros((20, 20))
+    n_steps = 0
+    for i in range(dataset.size()):
+        ep = dataset.get(i)
+        action = ep.action["a"]
+        assert action.shape[1] == 2
+        for t in range(int(ep.seq_len.item()) - 1):
+            a0, a1 = (int(action[t][0]), int(action[t + 1][1])) if t % 2 == 0 else (int(action[t][1]), int(action[t + 1][0]))
+            assert a0 < 20 and a1 < 20                  # the mover never plays the noop
+            want[a0][a1] += 1
+            n_steps += 1
+    assert n_steps > 48 * 5 and np.array_equal(counts, want)
+    rows = want.sum(1) > 0
+    assert np.allclose(normed[rows], (want / want.sum(1, keepdims=True))[rows])
+    context.terminate()
+
+
 def test_reference_shaped_eval_driver():
     """eval.py:25-66: one game per env, greedy actors, poll context.terminated(), read game.last_score()"""
     from hanabi_sad_amd import hanalearn, rela
