@@ -124,3 +124,40 @@ def test_load_weight_semantics_on_files_written_by_the_reference(capsys):
         load_weight(init_weights(838, 32, 21, 5, 0), os.path.join(GOLD, "ref_small.pthw"))
     assert [op_model_arch(i) for i in (0, 2, 3, 5, 6, 8, 9, 11)] == [(1, False), (1, False), (1, True), (1, True), (2, False),
                                                                      (2, False), (2, True), (2, True)]
+
+
+def test_convert_model_exports_a_loadable_torchscript_net(tmp_path):
+    """hanabi_sad_amd.convert_model (pyhanabi/tools/convert_model.py): the exported module reloads with torch.jit.load and its forward
+    equals a plain torch evaluation of the same weights (ReLU(Linear) -> 2-layer LSTM step -> fc_a), state in batch-first layout"""
+    import torch
+    from hanabi_sad_amd.checkpoint import save_weights
+    from hanabi_sad_amd.convert_model import convert
+    g = torch.Generator().manual_seed(0)
+    F, H, A, L, B = 40, 16, 7, 2, 5
+    sd = {"net.0.weight": torch.randn(H, F, generator=g) * 0.2, "net.0.bias": torch.randn(H, generator=g) * 0.1,
+          "fc_v.weight": torch.randn(1, H, generator=g), "fc_v.bias": torch.randn(1, generator=g),
+          "fc_a.weight": torch.randn(A, H, generator=g), "fc_a.bias": torch.randn(A, generator=g),
+          "pred.weight": torch.randn(15, H, generator=g), "pred.bias": torch.randn(15, generator=g)}
+    for l in range(L):
+        sd["lstm.weight_ih_l%d" % l] = torch.randn(4 * H, H, generator=g) * 0.2
+        sd["lstm.weight_hh_l%d" % l] = torch.randn(4 * H, H, generator=g) * 0.2
+        sd["lstm.bias_ih_l%d" % l] = torch.randn(4 * H, generator=g) * 0.1
+        sd["lstm.bias_hh_l%d" % l] = torch.randn(4 * H, generator=g) * 0.1
+    path = str(tmp_path / "model0.pthw")
+    save_weights(sd, path)
+    _, out = convert(path)
+    assert out.endswith("model0.sparta")
+    m = torch.jit.load(out)
+    s, h0, c0 = torch.randn(B, F, generator=g), torch.randn(B, L, H, generator=g) * 0.3, torch.randn(B, L, H, generator=g) * 0.3
+    got = m({"s": s, "h0": h0, "c0": c0})
+    x = torch.relu(s @ sd["net.0.weight"].T + sd["net.0.bias"])
+    hs, cs = [], []
+    for l in range(L):
+        gates = x @ sd["lstm.weight_ih_l%d" % l].T + sd["lstm.bias_ih_l%d" % l] + h0[:, l] @ sd["lstm.weight_hh_l%d" % l].T + sd["lstm.bias_hh_l%d" % l]
+        i, f, gg, o = gates.chunk(4, 1)
+        c = torch.sigmoid(f) * c0[:, l] + torch.sigmoid(i) * torch.tanh(gg)
+        x = torch.sigmoid(o) * torch.tanh(c)
+        hs.append(x)
+        cs.append(c)
+    assert torch.allclose(got["a"], x @ sd["fc_a.weight"].T + sd["fc_a.bias"], atol=1e-5)
+    assert torch.allclose(got["h0"], torch.stack(hs, 1), atol=1e-5) and torch.allclose(got["c0"], torch.stack(cs, 1), atol=1e-5)
