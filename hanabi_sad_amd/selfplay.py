@@ -278,7 +278,8 @@ def run_link_actor(tr, args, link):
     training thread trains: rela/context.h:43-50, selfplay.py:208-244.)"""
     share = max(args.batchsize, args.burn_in_frames // max(link.world - 1, 1))
     announced = False
-    tr.actor.set_run_ahead(3)      # a round is served behind at most three queued steps (the host issues ~10x faster than the device runs)
+    tr.actor.set_run_ahead(2)      # a round is served behind at most two queued steps (the host issues ~10x faster than the device runs;
+                                   # two is the smallest bound that never lets the device run dry)
     n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else link.bucket.numel() // 2
     while True:
         tr.actor.step()
