@@ -102,3 +102,34 @@ def test_num_lstm_layer_flag_trains_and_saves_that_architecture(tmp_path, nl):
     assert sorted(k for k in w if k.startswith("lstm.weight_ih")) == ["lstm.weight_ih_l%d" % l for l in range(nl)]
     agent = agent_from_file(os.path.join(save_dir, "model0.pthw"), DEV)
     assert agent.get_h0(4)["h0"].shape[0] == nl
+
+
+def test_overlapped_rollout_sees_the_same_data_as_the_alternating_loop():
+    """selfplay --overlap_rollout 1 (the default): rollout steps on a stream of their own next to the update on the caller's.  Every
+    cross-stream dependency (sequence flush -> sample, sample / update_priority -> next flush, optimizer step -> actor weight sync ->
+    next update) is enforced in host issue order, so the overlapped loop must see exactly the data of the strictly alternating one: the
+    per-update losses agree (to the float-atomic bias sums of the BPTT launch) and the replay ends in the same state."""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    out = []
+    for overlap in (0, 1):
+        tr = Trainer(parse_args(["--num_game", "1024", "--sad", "1", "--seed", "5", "--burn_in_frames", "1000", "--replay_buffer_size", "8192",
+                                 "--batchsize", "64", "--overlap_rollout", str(overlap), "--actor_sync_freq", "5"]), "cuda:0")
+        assert (tr.act_stream is not None) == bool(overlap)
+        tr.act_step(120)                               # a fixed burn-in: the driver's polling loop depends on timing
+        losses = []
+        for u in range(40):
+            tr.act_step(1)
+            loss, g_norm = tr.learner_update()
+            losses.append(loss.detach().float())
+        tr.join_rollout()
+        torch.cuda.synchronize()
+        tr.env.check_errors()
+        tr.replay.check_errors()
+        tr.learner.check_sync()
+        out.append((torch.stack(losses).cpu(), tr.replay.num_add(), tr.replay.size(), tr.replay.priority_sum()[0], tr.actor.num_act))
+        del tr
+        torch.cuda.empty_cache()
+    (l0, *s0), (l1, *s1) = out
+    assert s0[0] == s1[0] and s0[1] == s1[1] and s0[3] == s1[3]
+    assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-5), (l0 - l1).abs().max()
+    assert abs(s0[2] - s1[2]) <= 1e-3 * abs(s0[2])
