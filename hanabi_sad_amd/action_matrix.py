@@ -41,6 +41,9 @@ def create_dataset(weights, sad, device="cuda:0", dataset_size=1000, num_game=10
     while replay.size() < dataset_size:
         time.sleep(0.05)
     context.pause()
+    for _ in range(2):                                  # the buffer holds more than its capacity until a draw evicts the oldest
+        _, w = replay.sample(min(10, dataset_size), device)       # (tools/action_matrix.py:78-82, prioritized_replay.h:291-299)
+        replay.update_priority(w.detach())
     return replay, context
 
 

@@ -171,7 +171,7 @@ def test_action_matrix_tool_counts_like_the_reference_loop():
             n_steps += 1
     assert n_steps > 48 * 5 and np.array_equal(counts, want)
     rows = want.sum(1) > 0
-    assert np.allclose(normed[rows], (want / want.sum(1, keepdims=True))[rows])
+    assert np.allclose(normed[rows], want[rows] / want[rows].sum(1, keepdims=True))
     context.terminate()
 
 
