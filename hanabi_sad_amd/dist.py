@@ -392,7 +392,12 @@ class ReplayLink:
         import torch.distributed as dist
         if not ops:
             return None
-        staged = [(kind, t, peer, (t.cpu() if kind == "send" else torch.empty(t.shape, dtype=t.dtype)) if self.staged else t)
+        host = {}                                # gloo with GPU shards: ONE host copy of a tensor that goes to several peers
+        def _h(t):
+            if id(t) not in host:
+                host[id(t)] = t.cpu()
+            return host[id(t)]
+        staged = [(kind, t, peer, (_h(t) if kind == "send" else torch.empty(t.shape, dtype=t.dtype)) if self.staged else t)
                   for kind, t, peer in ops]
         works = dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer)
                                         for kind, _, peer, buf in staged])
