@@ -234,7 +234,7 @@ class _Timer:
 
     def __init__(self, device):
         self.cuda = torch.device(device).type == "cuda"
-        self.ms, self.n, self.pending = {}, 0, None
+        self.ms, self.n, self.pending = {}, 0, []
         self.marks = []
 
     def start(self):
@@ -252,18 +252,19 @@ class _Timer:
             self.marks.append((name, time.perf_counter()))
 
     def stop(self):
-        self.pending, self.marks = self.marks, []
+        self.pending.append(self.marks)      # read later: a round still in flight is kept, not dropped
+        self.marks = []
 
     def _flush(self):
-        if not self.pending:
-            return
-        if self.cuda and not self.pending[-1][1].query():
-            return                       # still in flight: keep it for the next call
-        for (_, a), (name, b) in zip(self.pending[:-1], self.pending[1:]):
-            dt = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
-            self.ms[name] = self.ms.get(name, 0.0) + dt
-        self.n += 1
-        self.pending = None
+        while self.pending:
+            marks = self.pending[0]
+            if self.cuda and not marks[-1][1].query():
+                return                       # still in flight: keep it (and the rounds behind it) for the next call
+            for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+                dt = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+                self.ms[name] = self.ms.get(name, 0.0) + dt
+            self.n += 1
+            self.pending.pop(0)
 
     def summary(self):
         self._flush()
