@@ -37,62 +37,63 @@ def algorithmic_bytes_per_step(P, F, A, H, sad):
     return P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 * (1 + int(sad)) + 2 * 128
 
 
+# committed rocprofv3 PMC summaries, newest round first (profiles/, collected with separate --pmc WRITE_SIZE / FETCH_SIZE passes and
+# corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py); a leg is read from the newest file that holds it
+PMC_FILES = ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+
+
+def pmc_leg(leg):
+    for name in PMC_FILES:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name))).get(leg)
+            if rec:
+                return rec, name
+        except Exception:
+            pass
+    return {}, None
+
+
+def pmc_kernel(leg, needle, field="hbm_bytes_per_launch"):
+    """`field` of the kernels of a leg whose name contains `needle`, averaged (None when the leg was never measured)"""
+    rec, _ = pmc_leg(leg)
+    v = [x[field] for k, x in rec.items() if needle in k and isinstance(x, dict) and field in x]
+    return sum(v) / len(v) if v else None
+
+
 def measured_traffic_bytes(G, mode, chunk=0):
     """HBM bytes per launch of env_kernel<mode,2,5> (chunk > 0: of the persistent env_rollout_kernel<2,5> running `chunk`
-    iterations per launch) from the committed rocprofv3 PMC passes (profiles/, collected with separate --pmc WRITE_SIZE /
-    FETCH_SIZE runs and corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py).  Only valid for the configuration
-    it was measured at; None otherwise."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")
-    try:
-        for k, rec in json.load(open(path))["env"].items():
-            if chunk > 0:
-                if k.startswith("env_rollout_kernel<2,5>"):
-                    return rec["hbm_bytes_per_iteration"] * chunk if G == 65536 else None   # chunk = iterations per launch
-                continue
-            if k.startswith("env_kernel<%d,2,5>" % mode):
-                return rec["hbm_bytes_per_launch"] if G == 65536 else None
-    except Exception:
-        pass
-    return None
+    iterations per launch).  Only valid for the configuration it was measured at; None otherwise."""
+    if G != 65536:
+        return None
+    if chunk > 0:
+        v = pmc_kernel("env", "env_rollout_kernel<2,5>", "hbm_bytes_per_iteration")
+        return None if v is None else v * chunk                                    # chunk = iterations per launch
+    return pmc_kernel("env", "env_kernel<%d,2,5>" % mode)
 
 
 def gemm_traffic_bytes():
-    """HBM bytes per launch of the learner's LSTM input-projection GEMM (10240x2048x512) from the committed PMC passes"""
-    try:
-        path = os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")
-        rec = json.load(open(path if os.path.exists(path) else os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))["gemm"]
-        for k, v in rec.items():
-            if k.startswith("gemm_nt_bf16_kernel"):
-                return v["hbm_bytes_per_launch"]
-    except Exception:
-        pass
-    return None
+    """HBM bytes per launch of the learner's LSTM input-projection GEMM (10240x2048x512)"""
+    return pmc_kernel("gemm", "gemm_nt_bf16_kernel")
 
 
-def fused_traffic_bytes():
-    """HBM bytes per launch of the fused forward recurrence kernel inside a learner update, from the committed PMC passes"""
-    for name in ("r03_pmc_hbm_traffic.json",):
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", name)))["learner"]
-            for k, v in rec.items():
-                if "lstm_fused_fwd_kernel" in k:
-                    return v["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-    return None
+def fused_traffic_bytes(which="fwd"):
+    """HBM bytes per launch of the fused forward / BPTT recurrence kernel inside a learner update"""
+    return pmc_kernel("learner", "lstm_fused_%s_kernel" % which)
 
 
 def cell_traffic_bytes():
     """HBM bytes per launch of the fused cell kernel inside an acting step (one launch = the online net's cell, which also writes the fp32
-    state, and the target net's), from the committed PMC passes"""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["actor"]
-        v = [x["hbm_bytes_per_launch"] for k, x in rec.items() if "lstm_cell_pp_kernel" in k]
-        return sum(v) / len(v) if v else None
-    except Exception:
+    state, and the target net's)"""
+    return pmc_kernel("actor", "lstm_cell_pp_kernel")
+
+
+def env5_traffic_bytes(games, chunk, sad):
+    """HBM bytes per launch of env_rollout_kernel<5,4> at configs[4]'s per-GPU size (the leg "env5" is the SAD variant, "env5_literal"
+    the configuration as BASELINE.json states it)"""
+    if games != 16384:
         return None
+    v = pmc_kernel("env5" if sad else "env5_literal", "env_rollout_kernel<5,4>", "hbm_bytes_per_iteration")
+    return None if v is None else v * chunk
 
 
 def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
@@ -376,23 +377,12 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
     return out
 
 
-def env5_traffic_bytes(games, chunk):
-    """HBM bytes per launch of env_rollout_kernel<5,4> at configs[4]'s per-GPU size from the committed PMC passes"""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm_traffic.json")))["env5"]
-        for k, v in rec.items():
-            if k.startswith("env_rollout_kernel<5,4>") and games == 16384:
-                return v["hbm_bytes_per_iteration"] * chunk
-    except Exception:
-        pass
-    return None
-
-
-def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50):
-    """BASELINE configs[4] at its per-GPU size (131,072 games over 8 GPUs = 16,384 per GPU): 5 players, hand 4, SAD, colour shuffle
-    (F = 1439, A = 49) through the same persistent rollout kernel, timed with events like the headline run"""
+def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50, sad=False):
+    """BASELINE configs[4] at its per-GPU size (131,072 games over 8 GPUs = 16,384 per GPU): 5 players, hand 4, colour shuffle --
+    literally (no SAD: F = 1380, A = 49; SURVEY §8d "Config 5") or as the SAD variant (F = 1439) -- through the same persistent
+    rollout kernel, timed with events like the headline run"""
     from hanabi_sad_amd import BatchedHanabiEnv
-    env = BatchedHanabiEnv(games, players=5, hand_size=4, seed=7, eps_list=EPS, max_len=80, sad=True, shuffle_color=True, device=dev,
+    env = BatchedHanabiEnv(games, players=5, hand_size=4, seed=7, eps_list=EPS, max_len=80, sad=sad, shuffle_color=True, device=dev,
                            track_deck_history=False)
     env.set_rollout_chunk(chunk)
     env.rollout_random(warmup, 99)
@@ -404,14 +394,15 @@ def env_config4_bench(dev, games=16384, steps=100, warmup=50, chunk=50):
     torch.cuda.synchronize()
     env.check_errors()
     it_ms = e0.elapsed_time(e1) / steps
-    bps = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, True)
+    bps = algorithmic_bytes_per_step(env.P, env.F, env.A, env.H, sad)
     gbs = bps * games / (it_ms * 1e-3) / 1e9
     out = {"value": games / (it_ms * 1e-3), "unit": "env-steps/s", "iteration_ms": it_ms, "games": games,
-           "config": {"workload": "BASELINE configs[4] per GPU: %d concurrent 5-player games (hand 4, SAD, colour shuffle; F=%d A=%d), "
-                                  "random-legal policy, persistent fused kernel, %d iterations per launch" % (games, env.F, env.A, chunk),
+           "config": {"workload": "BASELINE configs[4] per GPU: %d concurrent 5-player games (hand 4, %s, colour shuffle; F=%d A=%d), "
+                                  "random-legal policy, persistent fused kernel, %d iterations per launch"
+                                  % (games, "SAD" if sad else "no SAD", env.F, env.A, chunk),
                       "games_per_workgroup": env.games_per_workgroup},
            "roofline": {"bound": "hbm", "kernel": "env_rollout_kernel<5,4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": env5_traffic_bytes(games, chunk), "algorithmic_bytes_per_env_step": bps}}
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": env5_traffic_bytes(games, chunk, sad), "algorithmic_bytes_per_env_step": bps}}
     del env
     torch.cuda.empty_cache()
     return out
@@ -686,7 +677,8 @@ def main():
         watchdog.cancel()
     if rank == 0:
         if world == 1 and not args.no_actor:
-            out["env_configs4"] = env_config4_bench(dev)
+            out["env_configs4"] = env_config4_bench(dev, sad=False)
+            out["env_configs4_sad"] = env_config4_bench(dev, sad=True)
         if world == 1 and not args.no_learner:
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:

@@ -2,8 +2,8 @@
 1,024-game slice of the same run:
   configs[1]  65,536 concurrent 2-player games (no SAD, no colour shuffle),
   the dev.sh / sad+op production shape: 65,536 2-player games with SAD and colour shuffle (64-game workgroups),
-  configs[4]  5 players, hand 4, colour shuffle, SAD, 16,384 games per GPU -- in BOTH kernel shapes (the automatic
-              32-game workgroups and the 64-game ones).
+  configs[4]  5 players, hand 4, colour shuffle, 16,384 games per GPU: the literal configuration (no SAD, F = 1380) and the
+              SAD variant (F = 1439) -- the latter in BOTH kernel shapes (the automatic 32-game workgroups and the 64-game ones).
 
 * card conservation and token ranges in every game after every block of steps (deck + hands + discards + fireworks = the
   50-card deck; 0 <= info <= 8; 0 <= life <= 3; score = sum of fireworks),
@@ -28,6 +28,8 @@ SHAPES = {
     "2p_sad_op_65536": dict(G=65536, players=2, hand_size=5, sad=True, shuffle_color=True, gpw=0, expect_gpw=64),
     "configs4_5p_16384_gpw32": dict(G=16384, players=5, hand_size=4, sad=True, shuffle_color=True, gpw=0, expect_gpw=32),
     "configs4_5p_16384_gpw64": dict(G=16384, players=5, hand_size=4, sad=True, shuffle_color=True, gpw=64, expect_gpw=64),
+    # configs[4] as BASELINE.json states it: Other-Play colour shuffle WITHOUT SAD (F = 1380, A = 49)
+    "configs4_literal_5p_nosad_16384": dict(G=16384, players=5, hand_size=4, sad=False, shuffle_color=True, gpw=0, expect_gpw=32),
 }
 
 

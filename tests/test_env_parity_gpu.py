@@ -25,6 +25,9 @@ CONFIGS = [
     dict(players=2, hand_size=5, sad=False, shuffle_color=False, knowledge_mode=0, bomb=0, max_len=80, G=70, iters=80,
          deal_mode=1),
     dict(players=5, hand_size=5, sad=True, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80, G=9, iters=60),
+    # BASELINE configs[4] literally (SURVEY §8d "Config 5"; pyhanabi/selfplay.py:44,47): 5 players, hand 4, colour shuffle,
+    # NO SAD -> F = 1380, A = 49
+    dict(players=5, hand_size=4, sad=False, shuffle_color=True, knowledge_mode=0, bomb=0, max_len=80, G=67, iters=100),
 ]
 
 

@@ -3,12 +3,12 @@
 # Outputs land in gpurun_out/ ; the summaries are also written into profiles/ (copy them back from gpurun_out/ afterwards).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RN=${ROUND:-r03}
+RN=${ROUND:-r04}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 SPEC=""
-for leg in env env5 gemm learner actor; do
+for leg in ${LEGS:-env env5 env5_literal gemm learner actor}; do
   rm -rf /tmp/pw_$leg /tmp/pf_$leg
   timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw_$leg -o w -- python $R/tools/pmc_probe.py $leg > $O/pmc_write_$leg.log 2>&1
   timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf_$leg -o f -- python $R/tools/pmc_probe.py $leg > $O/pmc_fetch_$leg.log 2>&1

@@ -2,7 +2,7 @@
 hot path per invocation plus two calibration kernels of known traffic IN THE SAME RUN (a plain streaming fill and a plain
 copy of exactly CAL_BYTES), so tools/pmc_summarize.py can correct the counters the way the guide prescribes.
 
-  python tools/pmc_probe.py env | env5 | gemm | learner | actor"""
+  python tools/pmc_probe.py env | env5 | env5_literal | gemm | learner | actor"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -36,10 +36,10 @@ if leg == "env":
         env.reset(); a, g = env.policy_random(5); env.step(a, g)
     torch.cuda.synchronize()
     env.check_errors()
-elif leg == "env5":
+elif leg in ("env5", "env5_literal"):             # configs[4] per GPU: the SAD variant / literally (no SAD, F = 1380)
     from hanabi_sad_amd import BatchedHanabiEnv
     EPS = [0.1 ** (1 + 7 * i / 79) for i in range(80)]
-    env = BatchedHanabiEnv(16384, players=5, hand_size=4, seed=7, eps_list=EPS, max_len=80, sad=True, shuffle_color=True, device=dev,
+    env = BatchedHanabiEnv(16384, players=5, hand_size=4, seed=7, eps_list=EPS, max_len=80, sad=(leg == "env5"), shuffle_color=True, device=dev,
                            track_deck_history=False)
     env.set_rollout_chunk(50)                    # bench.py env_config4_bench: one dispatch = 50 iterations of all 16,384 games
     env.rollout_random(200, 99)

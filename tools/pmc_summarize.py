@@ -16,6 +16,7 @@ G, P, F, A, H = 65536, 2, 783, 21, 5
 ALGO_ENV = (P * (F + A + 3 * H + 1) * 4 + 5 + P * 8 + 256) * G     # SURVEY.md §8(d) bytes per env-step x G
 GEMM_ALGO = 10240 * 512 * 2 + 2048 * 512 * 2 + 10240 * 2048 * 4    # A + B read (bf16), C written (fp32)
 ALGO_ENV5 = (5 * (1439 + 49 + 12 + 1) * 4 + 5 + 5 * 8 * 2 + 256) * 16384        # configs[4] per GPU: 5p hand 4 SAD, 16,384 games
+ALGO_ENV5_LITERAL = (5 * (1380 + 49 + 12 + 1) * 4 + 5 + 5 * 8 + 256) * 16384     # configs[4] literally: no SAD
 # fused forward recurrence of a learner update (T=80, B=128, H=512, 2 nets x 2 layers): weights 8 x 2 MB, inputs 2 x 10 MB, outputs: bf16 h
 # of 4 recurrences, fp32 gates + c of the online net's 2 layers (the h tiles exchanged between workgroups stay in L2: not algorithmic HBM bytes)
 _MH = 80 * 128 * 512
@@ -75,6 +76,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
             ("env_kernel<0,2,5> reset-terminated, G=65536", r"env_kernel<0, 2, 5>", None, "")],
     "env5": [("env_rollout_kernel<5,4> persistent fused rollout, configs[4] per GPU: G=16384 5-player hand-4 SAD + colour shuffle, 50 iterations per launch",
               r"env_rollout_kernel<5, 4>", ALGO_ENV5 * 50, "iterations_per_launch=50")],
+    "env5_literal": [("env_rollout_kernel<5,4> persistent fused rollout, configs[4] literally: G=16384 5-player hand-4 colour shuffle, no SAD, "
+                      "50 iterations per launch", r"env_rollout_kernel<5, 4>", ALGO_ENV5_LITERAL * 50, "iterations_per_launch=50")],
     "gemm": [("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
     "learner": [("learner update: lstm_fused_fwd_kernel<16> (2 nets x 2 layers x 80 steps per launch)", r"lstm_fused_fwd_kernel<16>", FUSED_FWD_ALGO, ""),
                 ("learner update: lstm_fused_bwd_kernel<64> (2 layers x 80 steps per launch)", r"lstm_fused_bwd_kernel<64>", FUSED_BWD_ALGO, ""),
