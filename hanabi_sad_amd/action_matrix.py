@@ -98,8 +98,7 @@ def main(argv=None):
     p.add_argument("--save_npy", type=str, default="")
     p.add_argument("--device", type=str, default="cuda:0")
     args = p.parse_args(argv)
-    sd = load_weights(args.weight, args.device)
-    w = {k[len("online_net."):]: v for k, v in sd.items() if k.startswith("online_net.")} or sd
+    w = load_weights(args.weight, args.device)       # strips an agent file's online_net. prefix itself
     fname = args.weight.split("/")[-1]
     sad = ("sad" in fname or "aux" in fname) if args.sad < 0 else bool(args.sad)
     dataset, context = create_dataset(w, sad, args.device)

@@ -53,7 +53,7 @@ class DeviceActor:
         self.hid = agent.get_h0(self.N)
         self.history_hid = deque()
         self.q_hist = deque()                 # (Q_online(s_t, a_t), online weight version) per step still in the n-step window
-        self.verify_cached_priority = False   # tests: also run compute_priority on the unpacked transition and compare
+        self._verify_cached_priority = False   # tests: also run compute_priority on the unpacked transition and compare
         self.n_checked = self.n_checked_stale = 0
         self.num_act = 0          # R2D2Actor::numAct summed over the P per-player actors
         self.n_finished = torch.zeros(1, dtype=torch.int32, device=env.device)
@@ -69,6 +69,20 @@ class DeviceActor:
             native = self.packed_obs and hasattr(agent, "online") and hasattr(agent.online, "h") and hasattr(agent, "lib") and not getattr(agent.online, "skip", False)
         if native:
             self._make_native(multi_step, gamma, seq_len)
+
+    @property
+    def verify_cached_priority(self):
+        return self._verify_cached_priority
+
+    @verify_cached_priority.setter
+    def verify_cached_priority(self, on):
+        """the cross-check runs in the Python loop body, which pushes into this object's own sequence writer -- a native actor has
+        handed that role (and closed that writer) to the library's loop: refuse instead of stepping on a freed handle"""
+        if on and self.c_actor is not None:
+            from . import _lib
+            raise _lib.HsadError("verify_cached_priority needs the Python loop body: construct the DeviceActor with native=False "
+                                 "(selfplay: --native_actor 0); this actor runs hsad_actor_step and owns no Python-side sequence writer")
+        self._verify_cached_priority = bool(on)
 
     def _make_native(self, multi_step, gamma, seq_len):
         import ctypes as C
@@ -172,7 +186,7 @@ class DeviceActor:
 
     def step(self):
         """one iteration of the thread-loop body: reset-terminated -> act -> step -> postAct"""
-        if self.c_actor is not None and not self.verify_cached_priority:
+        if self.c_actor is not None:
             from . import _lib
             from .composite import _s
             _lib.check(self._lib.hsad_actor_step(self.c_actor, _s(self.env.device)))

@@ -24,7 +24,11 @@ def save_weights(weights, path):
 
 
 def load_weights(path, device="cpu"):
+    """-> {R2D2Net.state_dict() name: fp32 tensor}.  Accepts a bare net (what `save_weights` and the reference's savers write) or a
+    whole agent's state_dict (`online_net.*` / `target_net.*`: the online net is taken)."""
     sd = torch.load(path, map_location=device)
+    if any(k.startswith("online_net.") for k in sd):
+        sd = {k[len("online_net."):]: v for k, v in sd.items() if k.startswith("online_net.")}
     names = param_order(*arch_of(sd))
     missing = [k for k in names if k not in sd]
     if missing:

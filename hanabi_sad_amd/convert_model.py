@@ -15,10 +15,13 @@ class SearchNet(torch.jit.ScriptModule):
     """parameter names follow R2D2Net's state_dict (net.0, lstm, fc_v, fc_a: pyhanabi/r2d2.py:22-57) so that a trained file loads by
     name; the value head is carried but not evaluated (the consumer ranks actions by advantage)"""
 
-    def __init__(self, in_dim, hid_dim, out_dim, num_lstm_layer):
+    def __init__(self, in_dim, hid_dim, out_dim, num_lstm_layer, num_fc_layer=1):
         super().__init__()
         self.in_dim = in_dim
-        self.net = nn.Sequential(nn.Linear(in_dim, hid_dim), nn.ReLU())
+        layers = [nn.Linear(in_dim, hid_dim), nn.ReLU()]
+        for _ in range(1, num_fc_layer):         # R2D2Net's ff_layers (pyhanabi/r2d2.py:36-40): net.2, net.4, ...
+            layers += [nn.Linear(hid_dim, hid_dim), nn.ReLU()]
+        self.net = nn.Sequential(*layers)
         self.lstm = nn.LSTM(hid_dim, hid_dim, num_layers=num_lstm_layer)
         self.fc_v = nn.Linear(hid_dim, 1)
         self.fc_a = nn.Linear(hid_dim, out_dim)
@@ -34,18 +37,20 @@ class SearchNet(torch.jit.ScriptModule):
 
 def convert(model_path, device="cpu", save_path=None):
     """-> (module, path it was saved to).  Shapes come from the file: in_dim / hid from net.0.weight, A from fc_a.weight, the number of
-    LSTM layers from the lstm.weight_ih_l* keys; keys the module does not have (the auxiliary head `pred`) are skipped."""
+    fc layers from net.2.* and of LSTM layers from the lstm.weight_ih_l* keys (load_weights also accepts a whole agent's `online_net.*`
+    file); the auxiliary head `pred` is the ONLY part of the file the exported module may leave out."""
     from .checkpoint import load_weights
+    from .r2d2 import arch_of
     sd = load_weights(model_path, device)
-    sd = {k[len("online_net."):]: v for k, v in sd.items() if k.startswith("online_net.")} or sd
     hid, in_dim = sd["net.0.weight"].shape
     out_dim = sd["fc_a.weight"].shape[0]
-    layers = sum(1 for k in sd if k.startswith("lstm.weight_ih_l"))
-    m = SearchNet(int(in_dim), int(hid), int(out_dim), layers).to(device)
+    num_fc, layers = arch_of(sd)
+    m = SearchNet(int(in_dim), int(hid), int(out_dim), layers, num_fc).to(device)
     own = m.state_dict()
     missing = [k for k in own if k not in sd]
-    if missing:
-        raise KeyError("convert_model: %s lacks %s" % (model_path, missing))
+    dropped = [k for k in sd if k not in own and not k.startswith("pred.")]
+    if missing or dropped:
+        raise KeyError("convert_model: %s lacks %s / holds %s that the exported net would silently drop" % (model_path, missing, dropped))
     m.load_state_dict({k: sd[k].to(device) for k in own})
     save_path = save_path or model_path.rsplit(".", 1)[0] + ".sparta"
     torch.jit.save(m, save_path)

@@ -18,6 +18,7 @@
 //    four MFMA accumulators of a lane hold the four gates of the SAME (row, unit) and the cell update is
 //    pure per-lane fp32 math in the epilogue (no shuffles, no extra pass over HBM).
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <cmath>
 #include <type_traits>
@@ -3658,12 +3659,16 @@ static int g_lstm_dbg_enable = 0;   // hsad_lstm_debug_enable (fused kernels: th
 // CUs of the current device: the persistent recurrences spin on sibling workgroups, so a launch must fit the chip with one
 // workgroup per CU (their LDS footprint allows no second one)
 static int device_cus() {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
+  // cached PER DEVICE: one process may drive several GPUs (rela.BatchRunner on another device, evaluation loops on two devices)
+  static std::atomic<int> n_cu[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = n_cu[dev].load(std::memory_order_relaxed);
+  if (!n) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+    n_cu[dev].store(n, std::memory_order_relaxed);
   }
-  return n_cu > 0 ? n_cu : 256;
+  return n;
 }
 static inline int seq_grid(int nrec, int H, int nrb) { return 8 * (H / 32) * ((nrec * nrb + 7) / 8); }
 
@@ -3780,12 +3785,7 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
   g.slab_stride = gz > 1 ? slab_stride : 0;
   if (n_split_out) *n_split_out = gz;
   hipStream_t s = (hipStream_t)stream;
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int n_cu = device_cus();
   GemmTimingRec trec{nullptr, nullptr, M, N, K, np};
   if (g_gemm_timing.on) {
     HIP_TRY(hipEventCreate(&trec.e0));
@@ -4156,12 +4156,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: H and Kx must be multiples of 64, ldx of 8");
   if ((((uintptr_t)x16 | (uintptr_t)Wcat_gate16 | (uintptr_t)h_prev16) & 15))
     return nfail(HSAD_ERR_INVALID, "lstm_cell_fused: operands must be 16-byte aligned");
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int n_cu = device_cus();
   LstmCellArgs a{(const bf16_t*)x16, (const bf16_t*)h_prev16, (const bf16_t*)Wcat_gate16, bias_gate16, c_prev, c_out, h_out32, (bf16_t*)h_out16,
                  Bn, H, Kx, ldx};
   if (((size_t)Bn + 256) * (size_t)std::max(ldx, 2 * H) * 2 >= ((size_t)1 << 32) || (size_t)4 * H * (Kx + H) * 2 >= ((size_t)1 << 32))
@@ -4239,12 +4234,7 @@ int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a,
     if (rc) return rc;
     return hsad_lstm_cell_fused(Bn, H, Kx, x16_b, ldx, h_prev16_b, Wcat_b, bias_b, c_prev_b, c_out_b, h_out32_b, h_out16_b, stream);
   }
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
+  const int n_cu = device_cus();
   LstmCellArgs a{(const bf16_t*)x16_a, (const bf16_t*)h_prev16_a, (const bf16_t*)Wcat_a, bias_a, c_prev_a, c_out_a, h_out32_a, (bf16_t*)h_out16_a, Bn, H, Kx, ldx};
   LstmCellArgs b{(const bf16_t*)x16_b, (const bf16_t*)h_prev16_b, (const bf16_t*)Wcat_b, bias_b, c_prev_b, c_out_b, h_out32_b, (bf16_t*)h_out16_b, Bn, H, Kx, ldx};
   hipEvent_t t_e0 = nullptr, t_e1 = nullptr;

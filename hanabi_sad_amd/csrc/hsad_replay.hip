@@ -21,6 +21,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <random>
 #include <string>
@@ -1056,66 +1057,72 @@ __global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err)
 //     operation has been enqueued; begin_flush() makes the flush's stream wait for every such event recorded since the last flush.
 // Operations on the flush's own stream need neither (stream order).
 struct StreamFence {
-  static constexpr int kMax = 8;            // distinct streams per object; a ninth is refused
+  // No limit on the number of distinct streams (every non-coalesced thread loop flushes on a side stream of its own, and stream
+  // handles are recreated over a long-lived replay).  Both tables only ever hold what the CURRENT generation needs: the seen table is
+  // emptied by every arm() (an entry of an older generation means the same as no entry: "wait for the current flush"), and a consumer
+  // slot whose event the last flush has waited for is reused for whichever stream comes next.  (What stays undetectable: a stream
+  // destroyed and re-created with the same handle value between two flushes inherits the old stream's "has waited" mark.)
+  struct Cons { hipStream_t s; hipEvent_t ev; bool dirty; };
   hipEvent_t ev = nullptr;
   hipStream_t stream = nullptr;
   uint64_t gen = 0;
-  hipStream_t seen_s[kMax];
-  uint64_t seen_g[kMax];
-  int nseen = 0;
-  hipStream_t cons_s[kMax];
-  hipEvent_t cons_ev[kMax];
-  bool cons_dirty[kMax];
-  int ncons = 0;
+  std::vector<hipStream_t> seen;            // streams that already wait for generation `gen`
+  std::vector<Cons> cons;
+  std::mutex mu;                            // the rollout thread (rela.Context) and the training thread enter the same replay
   hipError_t arm(hipStream_t s) {           // the flush has been enqueued on s
+    std::lock_guard<std::mutex> g(mu);
     if (!ev) {
       hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
       if (e != hipSuccess) return e;
     }
     stream = s;
     ++gen;
+    seen.clear();
     return hipEventRecord(ev, s);
   }
   hipError_t pass(hipStream_t s) {          // an operation is about to be enqueued on s: order it behind the current flush, once per stream
+    std::lock_guard<std::mutex> g(mu);
     if (!gen || s == stream) return hipSuccess;
-    for (int i = 0; i < nseen; ++i)
-      if (seen_s[i] == s) {
-        if (seen_g[i] == gen) return hipSuccess;
-        seen_g[i] = gen;
-        return hipStreamWaitEvent(s, ev, 0);
-      }
-    if (nseen == kMax) return hipErrorInvalidValue;
-    seen_s[nseen] = s;
-    seen_g[nseen++] = gen;
-    return hipStreamWaitEvent(s, ev, 0);
+    for (hipStream_t t : seen)
+      if (t == s) return hipSuccess;
+    hipError_t e = hipStreamWaitEvent(s, ev, 0);
+    if (e == hipSuccess) seen.push_back(s);
+    return e;
   }
   hipError_t begin_flush(hipStream_t s) {   // a flush is about to be enqueued on s: behind every consumer operation on other streams since the last one
-    for (int i = 0; i < ncons; ++i)
-      if (cons_dirty[i] && cons_s[i] != s) {
-        hipError_t e = hipStreamWaitEvent(s, cons_ev[i], 0);
+    std::lock_guard<std::mutex> g(mu);
+    for (Cons& c : cons)
+      if (c.dirty && c.s != s) {
+        hipError_t e = hipStreamWaitEvent(s, c.ev, 0);
         if (e != hipSuccess) return e;
-        cons_dirty[i] = false;
+        c.dirty = false;
       }
     return hipSuccess;
   }
   void consumed(hipStream_t s) {            // a consumer operation has been enqueued on s
+    std::lock_guard<std::mutex> g(mu);
     if (gen && s == stream) return;         // the flush stream itself: stream order
-    int k = -1;
-    for (int i = 0; i < ncons; ++i)
-      if (cons_s[i] == s) k = i;
-    if (k < 0) {
-      if (ncons == kMax) return;            // (pass() already refused a ninth stream)
-      if (hipEventCreateWithFlags(&cons_ev[ncons], hipEventDisableTiming) != hipSuccess) return;
-      k = ncons++;
-      cons_s[k] = s;
+    Cons* k = nullptr;
+    for (Cons& c : cons)
+      if (c.s == s) k = &c;
+    if (!k)
+      for (Cons& c : cons)
+        if (!c.dirty) { k = &c; break; }    // a slot the last flush is already ordered behind: its event is free to be re-recorded
+    if (!k) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
+      cons.push_back(Cons{s, e, false});
+      k = &cons.back();
     }
-    cons_dirty[k] = hipEventRecord(cons_ev[k], s) == hipSuccess;
+    k->s = s;
+    k->dirty = hipEventRecord(k->ev, s) == hipSuccess;
   }
   void destroy() {
     if (ev) (void)hipEventDestroy(ev);
     ev = nullptr;
-    for (int i = 0; i < ncons; ++i) (void)hipEventDestroy(cons_ev[i]);
-    ncons = 0;
+    for (Cons& c : cons) (void)hipEventDestroy(c.ev);
+    cons.clear();
+    seen.clear();
   }
 };
 struct FenceUse {      // `FenceUse use(obj->fence, stream);` after the arguments were validated: pass() now, consumed() when the entry point returns

@@ -6,14 +6,15 @@ should create one `BatchedHanabiEnv` for all games instead of a Python list of t
 import torch
 
 from .env import BatchedHanabiEnv
+from .rela import ThreadLoop, _dev_key
 
 
 class HanabiEnv:
-    def __init__(self, params, eps_list, max_len, sad, shuffle_obs, shuffle_color, verbose, device="cuda:0"):
+    def __init__(self, params, eps_list, max_len, sad, shuffle_obs, shuffle_color, verbose, device=None):
         self.cfg = dict(players=int(params["players"]), hand_size=int(params.get("hand_size", 5)),
                         seed=int(params.get("seed", 1)), bomb=int(params.get("bomb", 0)), eps_list=tuple(eps_list),
                         max_len=int(max_len), sad=bool(sad), shuffle_obs=bool(shuffle_obs), shuffle_color=bool(shuffle_color))
-        self.device = device
+        self.device = device   # None: the current device when driven standalone; the model runner's device inside a thread loop
         self._impl = None      # a 1-game device env, created on first standalone use
         self._vec = None       # (HanabiVecEnv, index) once appended to a vector env: the game then lives in ITS batch
         if verbose:
@@ -22,7 +23,8 @@ class HanabiEnv:
     @property
     def impl(self):
         if self._impl is None:
-            self._impl = BatchedHanabiEnv(1, device=self.device, **self.cfg)
+            dev = self.device if self.device is not None else "cuda:%d" % torch.cuda.current_device()
+            self._impl = BatchedHanabiEnv(1, device=dev, **self.cfg)
         return self._impl
 
     def feature_size(self):
@@ -125,8 +127,9 @@ class HanabiVecEnv:
         return self.impl
 
 
-class HanabiThreadLoop:
-    """hanalearn.HanabiThreadLoop(actor | [actor per player], vec_env, eval) (cpp/thread_loop.h:14-88).  There is no thread:
+class HanabiThreadLoop(ThreadLoop):
+    """hanalearn.HanabiThreadLoop(actor | [actor per player], vec_env, eval) (cpp/thread_loop.h:14-88; bound as a subclass of
+    rela.ThreadLoop, cpp/pybind.cc:45-47).  There is no thread:
     `step()` is one iteration of the loop body for all games of the vector env, driven by rela.Context.  Training mode =
     actor.DeviceActor (IQL when given a list of per-player actors, VDN for a single actor with num_player = P); eval mode =
     every player acts greedily with ITS actor's model (cross-play: one runner per seat, eval.py:43-46) until each game has
@@ -155,7 +158,7 @@ class HanabiThreadLoop:
         cfg = tuple((a.multi_step, a.num_envs if self.eval_mode else None, a.gamma, a.eta, a.seq_len, a.num_player, id(a.replay))
                     for a in a0)
         return (self.eval_mode, self.is_list, tuple(id(a.runner) for a in a0), cfg, tuple(sorted(c0.items())),
-                self.vec_envs[0].envs[0].device)
+                _dev_key(a0[0].runner.device))
 
     def seed_range(self):
         envs = [e for v in self.vec_envs for e in v.envs]

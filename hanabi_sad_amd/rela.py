@@ -31,11 +31,71 @@ def _dev_key(device):
     return "%s:%d" % (d.type, d.index if d.index is not None else (torch.cuda.current_device() if d.type == "cuda" else 0))
 
 
+def _loop_device(lp):
+    """device key of the GPU a thread loop acts on = its model runner's (pyhanabi/create.py:94-110 round-robins runners, hence
+    devices, over threads); None for loops that do not say"""
+    try:
+        return _dev_key(lp.per_thread[0][0].runner.device)
+    except (AttributeError, IndexError, TypeError):
+        d = getattr(lp, "device", None)
+        return None if d is None else _dev_key(d)
+
+
 def _actor_stream(device):
     key = _dev_key(device)
     if key not in _ACTOR_STREAMS:
         _ACTOR_STREAMS[key] = torch.cuda.Stream(torch.device(key))
     return _ACTOR_STREAMS[key]
+
+
+class MultiDeviceError(RuntimeError):
+    """One process acting on several GPUs into ONE replay (`--act_device cuda:1,cuda:2`, pyhanabi/create.py:94-101,110) is the
+    reference's multi-GPU mechanism because its replay lives in host memory.  Here the replay is device memory next to the games that
+    fill it, and the multi-GPU mechanism is one process per GPU with a replay shard each."""
+
+    def __init__(self, have, want):
+        super().__init__(
+            "this replay lives in the HBM of %s and cannot take sequences from a rollout on %s: a device replay is filled by the games of "
+            "its own GPU.  For several acting GPUs launch one process per GPU -- `python -m torch.distributed.run --nproc-per-node N -m "
+            "hanabi_sad_amd.selfplay ...` (rank 0 learns, ranks 1..N-1 act into their own replay shards; dist.ReplayLink) -- instead of "
+            "--act_device %s,%s in one process" % (have, want, have, want))
+
+
+class FFTransition:
+    """rela.FFTransition fields (rela/pybind.cc:17-23, rela/transition.h:16-35): one feed-forward transition batch.  The reference binds
+    the type and nothing produces it from Python (its FFPrioritizedReplay binding is commented out, pybind.cc:34-45); it is here
+    because the name is part of the module's surface, with `index` / `pad_like` semantics that follow transition.cc:9-27."""
+
+    def __init__(self, obs=None, action=None, reward=None, terminal=None, bootstrap=None, next_obs=None):
+        self.obs, self.action = obs if obs is not None else {}, action if action is not None else {}
+        self.reward, self.terminal, self.bootstrap = reward, terminal, bootstrap
+        self.next_obs = next_obs if next_obs is not None else {}
+
+    def index(self, i):
+        """FFTransition::index (rela/transition.cc:9-27): element i of every batched field"""
+        pick = lambda d: {k: v[i] for k, v in d.items()}
+        return FFTransition(pick(self.obs), pick(self.action), self.reward[i], self.terminal[i], self.bootstrap[i],
+                            pick(self.next_obs))
+
+    def to_dict(self):
+        """FFTransition::toDict (rela/transition.cc:29-47): obs and action keys, `next_`-prefixed next_obs, then the scalars"""
+        d = dict(self.obs)
+        d.update(self.action)
+        d.update({"next_" + k: v for k, v in self.next_obs.items()})
+        d.update(reward=self.reward, terminal=self.terminal, bootstrap=self.bootstrap)
+        return d
+
+
+class ThreadLoop:
+    """rela.ThreadLoop (rela/thread_loop.h:13-60, bound without methods at rela/pybind.cc:60): base of everything a Context runs.
+    Subclasses implement `step()` = one iteration of mainLoop's body, and may implement `finished()`; the pause / resume / terminate
+    protocol of the reference's class lives in rela.Context here, because one thread drives all loops."""
+
+    def step(self):
+        raise NotImplementedError("ThreadLoop.step: one iteration of the loop body (rela/thread_loop.h:20 mainLoop is pure virtual too)")
+
+    def finished(self):
+        return False
 
 
 class RNNTransition:
@@ -54,10 +114,14 @@ class RNNPrioritizedReplay:
         self.args = (int(capacity), int(seed), float(alpha), float(beta), int(prefetch))
         self.impl = None
 
-    def bind_schema(self, fields, seq_len, device="cuda:0"):
+    def bind_schema(self, fields, seq_len, device=None):
+        device = _dev_key(device if device is not None else "cuda")
         if self.impl is None:
             c, s, a, b, p = self.args
             self.impl = DeviceReplay(c, s, a, b, p, seq_len, fields, device)
+            self.device = device
+        elif device != self.device:
+            raise MultiDeviceError(self.device, device)
         return self.impl
 
     def size(self):
@@ -312,7 +376,7 @@ class Context:
 
     def __init__(self):
         self.loops, self._thread, self._paused, self._stop, self._error = [], None, False, False, None
-        self._stream = None        # the rollout stream of start() (see _ACTOR_STREAMS); step() from the caller's thread uses the caller's
+        self._streams = {}         # device key -> the rollout stream of start() (see _ACTOR_STREAMS); step() from the caller's thread uses the caller's
         # pause protocol: every pause() takes a ticket; the loop thread acknowledges the ticket it has SEEN while parked between two
         # steps, so a pause() can only return on an acknowledgement of its own request (an Event could still be set from the
         # previous pause when a resume / pause pair follows within the thread's 1 ms nap)
@@ -352,6 +416,21 @@ class Context:
         return True
 
     def push_env_thread(self, loop):
+        """Context::pushThreadLoop (rela/context.h:30-35).  A training loop whose model runner sits on another GPU than the replay it
+        feeds is refused HERE (MultiDeviceError), not at its first step on the Context thread."""
+        if not hasattr(loop, "step"):
+            raise TypeError("push_env_thread: %r is not a rela.ThreadLoop (no step())" % (loop,))
+        dev = _loop_device(loop)
+        if dev is not None and not getattr(loop, "eval_mode", True):
+            for a in getattr(loop, "actors", []):
+                rp = getattr(a, "replay", None)
+                if rp is None:
+                    continue
+                have = getattr(rp, "device", None) or getattr(rp, "_claimed", None)
+                if have is None:
+                    rp._claimed = dev            # the first training loop pushed for a replay decides where the replay will live
+                elif have != dev:
+                    raise MultiDeviceError(have, dev)
         self.loops.append(loop)
         return len(self.loops)
 
@@ -374,25 +453,26 @@ class Context:
                     if self._paused or self._stop:
                         break
                     if not (hasattr(lp, "finished") and lp.finished()):
+                        st = self._streams.get(_loop_device(lp))        # every loop issues on the rollout stream of ITS device
                         with _MODEL_LOCK:
-                            if self._stream is not None:
-                                with torch.cuda.stream(self._stream):
+                            if st is not None:
+                                with torch.cuda.stream(st):
                                     lp.step()
                             else:
                                 lp.step()
                         busy = True
-                if self._run_ahead > 0 and self._stream is not None:
-                    e = torch.cuda.Event()
-                    e.record(self._stream)
-                    self._marks.append(e)
+                if self._run_ahead > 0 and self._streams:
+                    for st in self._streams.values():
+                        e = torch.cuda.Event()
+                        e.record(st)
+                        self._marks.append(e)
                 if not busy and not self._paused:
                     break
         except Exception as e:   # surfaced by the next Context call from the driver's thread
             self._error = e
         finally:
-            if self._stream is not None:
-                with _MODEL_LOCK:
-                    key = _dev_key(self._stream.device)
+            with _MODEL_LOCK:
+                for key in self._streams:
                     _LIVE_CONTEXTS[key] = max(0, _LIVE_CONTEXTS.get(key, 0) - 1)
             with self._cv:
                 self._done = True
@@ -418,33 +498,36 @@ class Context:
             else:
                 last[key] = lp
 
-    def _device(self):
+    def _devices(self):
+        """the GPUs the attached loops act on, in push order (eval loops and cross-play may sit on several; training loops are held
+        to their replay's device by push_env_thread)"""
+        out = []
         for lp in self.loops:
-            for v in getattr(lp, "vec_envs", []):
-                if v.envs:
-                    return v.envs[0].device
-        return None
+            d = _loop_device(lp)
+            if d is not None and d not in out:
+                out.append(d)
+        return out
 
     def _join_streams(self, to_actor):
-        """device-side order between the caller's current stream and the rollout stream (no host synchronisation)"""
-        if self._stream is None:
-            return
-        cur = torch.cuda.current_stream(self._stream.device)
-        if to_actor:
-            self._stream.wait_stream(cur)
-        else:
-            cur.wait_stream(self._stream)
+        """device-side order between the caller's current stream and the rollout stream of every device (no host synchronisation)"""
+        for st in self._streams.values():
+            cur = torch.cuda.current_stream(st.device)
+            if to_actor:
+                st.wait_stream(cur)
+            else:
+                cur.wait_stream(st)
 
     def start(self):
         import threading
         self._coalesce()
-        dev = self._device()
-        if self._thread is None and dev is not None and torch.device(dev).type == "cuda":
-            self._stream = _actor_stream(dev)
+        if self._thread is None:
+            for dev in self._devices():
+                if torch.device(dev).type == "cuda":
+                    self._streams[dev] = _actor_stream(dev)
             self._join_streams(True)          # everything the driver set up so far (envs, nets, replay) precedes the first step
             with _MODEL_LOCK:
-                key = _dev_key(self._stream.device)
-                _LIVE_CONTEXTS[key] = _LIVE_CONTEXTS.get(key, 0) + 1
+                for key in self._streams:
+                    _LIVE_CONTEXTS[key] = _LIVE_CONTEXTS.get(key, 0) + 1
         if self._thread is None:
             self._thread = threading.Thread(target=self._run, daemon=True)
             self._thread.start()

@@ -158,3 +158,52 @@ def test_param_broadcast_world_size_2_gloo(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / "bcast0.ok").exists() and (tmp_path / "bcast1.ok").exists()
+
+
+def test_rela_module_surface_and_single_process_multi_device_acting_is_refused():
+    """rela/pybind.cc:16-93 binds FFTransition, RNNTransition, RNNPrioritizedReplay, ThreadLoop, Context, R2D2Actor (and the module
+    function aggregate_priority); cpp/pybind.cc:45-47 binds HanabiThreadLoop as a subclass of rela.ThreadLoop.  The reference's own
+    multi-GPU mechanism -- runners on several devices in ONE process feeding one replay (pyhanabi/create.py:94-110, --act_device
+    cuda:1,cuda:2) -- cannot exist with a device-resident replay: it is refused at push_env_thread with a pointer to the launcher."""
+    import hanalearn
+    import rela
+    for name in ("FFTransition", "RNNTransition", "RNNPrioritizedReplay", "ThreadLoop", "Context", "R2D2Actor", "BatchRunner",
+                 "aggregate_priority"):
+        assert hasattr(rela, name), name
+    assert issubclass(hanalearn.HanabiThreadLoop, rela.ThreadLoop)
+    t = rela.FFTransition({"s": torch.arange(6.).view(3, 2)}, {"a": torch.arange(3)}, torch.ones(3), torch.zeros(3), torch.ones(3),
+                          {"s": torch.arange(6.).view(3, 2) + 1})
+    for field in ("obs", "action", "reward", "terminal", "bootstrap", "next_obs"):      # rela/pybind.cc:18-23
+        assert hasattr(t, field)
+    one = t.index(1)
+    assert one.obs["s"].tolist() == [2.0, 3.0] and int(one.action["a"]) == 1 and one.next_obs["s"].tolist() == [3.0, 4.0]
+    assert set(t.to_dict()) == {"s", "a", "next_s", "reward", "terminal", "bootstrap"}
+    with pytest.raises(NotImplementedError):
+        rela.ThreadLoop().step()
+    with pytest.raises(TypeError):
+        rela.Context().push_env_thread(object())
+
+    class Runner:                     # stands for rela.BatchRunner(agent.clone(dev), dev, ...): only its device matters here
+        def __init__(self, device):
+            self.device = device
+
+    def loop(device, replay, seed):
+        vec = hanalearn.HanabiVecEnv()
+        vec.append(hanalearn.HanabiEnv({"players": "2", "seed": str(seed)}, [0.0], 80, True, False, False, False))
+        actors = [rela.R2D2Actor(Runner(device), 3, 1, 0.999, 0.9, 80, 1, replay) for _ in range(2)]
+        return hanalearn.HanabiThreadLoop(actors, vec, False)
+
+    replay = rela.RNNPrioritizedReplay(64, 1, 0.9, 0.6, 3)
+    ctx = rela.Context()
+    ctx.push_env_thread(loop("cuda:0", replay, 1))
+    ctx.push_env_thread(loop("cuda:0", replay, 2))
+    with pytest.raises(rela.MultiDeviceError) as e:
+        ctx.push_env_thread(loop("cuda:1", replay, 3))
+    assert "torch.distributed.run" in str(e.value) and "cuda:1" in str(e.value)
+    # evaluation loops carry no replay: loops on several devices may share a Context (one rollout stream per device)
+    ev = rela.Context()
+    for d in ("cuda:0", "cuda:1"):
+        vec = hanalearn.HanabiVecEnv()
+        vec.append(hanalearn.HanabiEnv({"players": "2", "seed": "1"}, [0.0], 80, True, False, False, False))
+        ev.push_env_thread(hanalearn.HanabiThreadLoop([rela.R2D2Actor(Runner(d), 1)] * 2, vec, True))
+    assert ev._devices() == ["cuda:0", "cuda:1"]

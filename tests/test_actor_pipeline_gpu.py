@@ -167,6 +167,10 @@ def test_library_actor_step_equals_the_python_body_bit_for_bit(method, games, hi
     trs = [Trainer(parse_args(common + ["--native_actor", str(k)]), "cuda:0") for k in (1, 0)]
     nat, py = trs[0].actor, trs[1].actor
     assert nat.c_actor is not None and py.c_actor is None
+    from hanabi_sad_amd import HsadError
+    with pytest.raises(HsadError):           # the Python cross-check cannot be switched on over the library's loop
+        nat.verify_cached_priority = True
+    assert nat.verify_cached_priority is False
     if games == 1024:                        # the multi-GPU actor loop's bound on the host's run-ahead changes no result
         nat.set_run_ahead(2)
         py.set_run_ahead(2)

@@ -161,3 +161,35 @@ def test_convert_model_exports_a_loadable_torchscript_net(tmp_path):
         cs.append(c)
     assert torch.allclose(got["a"], x @ sd["fc_a.weight"].T + sd["fc_a.bias"], atol=1e-5)
     assert torch.allclose(got["h0"], torch.stack(hs, 1), atol=1e-5) and torch.allclose(got["c0"], torch.stack(cs, 1), atol=1e-5)
+
+
+def test_convert_model_keeps_a_second_fc_layer_and_accepts_an_agent_file(tmp_path):
+    """a num_fc_layer = 2 checkpoint (net.2.*) must not lose net.2.* on export, and a whole agent's state_dict
+    (online_net.* / target_net.*) is accepted by load_weights, convert_model and action_matrix alike"""
+    import torch
+    from hanabi_sad_amd.checkpoint import load_weights
+    from hanabi_sad_amd.convert_model import convert
+    g = torch.Generator().manual_seed(1)
+    F, H, A, B = 24, 8, 5, 3
+    sd = {"net.0.weight": torch.randn(H, F, generator=g) * 0.3, "net.0.bias": torch.randn(H, generator=g) * 0.1,
+          "net.2.weight": torch.randn(H, H, generator=g) * 0.5, "net.2.bias": torch.randn(H, generator=g) * 0.1,
+          "fc_v.weight": torch.randn(1, H, generator=g), "fc_v.bias": torch.randn(1, generator=g),
+          "fc_a.weight": torch.randn(A, H, generator=g), "fc_a.bias": torch.randn(A, generator=g),
+          "pred.weight": torch.randn(15, H, generator=g), "pred.bias": torch.randn(15, generator=g),
+          "lstm.weight_ih_l0": torch.randn(4 * H, H, generator=g) * 0.3, "lstm.weight_hh_l0": torch.randn(4 * H, H, generator=g) * 0.3,
+          "lstm.bias_ih_l0": torch.randn(4 * H, generator=g) * 0.1, "lstm.bias_hh_l0": torch.randn(4 * H, generator=g) * 0.1}
+    agent = {"online_net." + k: v for k, v in sd.items()}
+    agent.update({"target_net." + k: v + 1 for k, v in sd.items()})
+    path = str(tmp_path / "agent.pthw")
+    torch.save(agent, path)
+    w = load_weights(path)
+    assert set(w) == set(sd) and all(torch.equal(w[k], sd[k]) for k in sd)          # the online net, prefix stripped
+    m, out = convert(path)
+    assert "net.2.weight" in m.state_dict() and torch.equal(m.state_dict()["net.2.weight"], sd["net.2.weight"])
+    s, h0, c0 = torch.randn(B, F, generator=g), torch.zeros(B, 1, H), torch.zeros(B, 1, H)
+    got = torch.jit.load(out)({"s": s, "h0": h0, "c0": c0})
+    x = torch.relu(torch.relu(s @ sd["net.0.weight"].T + sd["net.0.bias"]) @ sd["net.2.weight"].T + sd["net.2.bias"])
+    gates = x @ sd["lstm.weight_ih_l0"].T + sd["lstm.bias_ih_l0"] + sd["lstm.bias_hh_l0"]
+    i, f, gg, o = gates.chunk(4, 1)
+    h = torch.sigmoid(o) * torch.tanh(torch.sigmoid(i) * torch.tanh(gg))
+    assert torch.allclose(got["a"], h @ sd["fc_a.weight"].T + sd["fc_a.bias"], atol=1e-5)

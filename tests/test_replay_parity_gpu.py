@@ -410,3 +410,57 @@ def test_three_streams_are_ordered_by_the_library_fence():
     assert one[:2] == many[:2] and abs(one[2] - many[2]) <= 1e-6 * abs(one[2])
     for a, b in zip(one[3:], many[3:]):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+
+
+def test_the_stream_fence_takes_any_number_of_streams():
+    """the fence used to refuse a ninth distinct stream per object.  Twelve flush streams and twelve consumer streams over
+    ONE replay (what many non-coalesced thread loops produce), streams re-created every round: no error, and the final state equals
+    the single-stream run."""
+    from hanabi_sad_amd.replay import DeviceReplay, SequenceWriter
+    E, d, n, T, gamma, eta, B, cap = 64, 8, 3, 10, 0.99, 0.9, 16, 512
+    fields = [("s", d, torch.float32), ("a", 1, torch.int64)]
+
+    def run(multi):
+        torch.manual_seed(1)
+        w = SequenceWriter(E, n, gamma, T, fields, DEV)
+        rep = DeviceReplay(cap, 7, 0.9, 0.6, 0, T, fields, DEV)
+        main = torch.cuda.current_stream()
+        nfin = torch.zeros(1, dtype=torch.int32, device=DEV)
+        steps = 120
+        obs = torch.rand(steps, E, d, device=DEV)
+        act = torch.randint(0, 5, (steps, E, 1), device=DEV)
+        rew = torch.rand(steps, E, device=DEV)
+        term = ((torch.arange(steps, device=DEV).view(-1, 1) + torch.arange(E, device=DEV).view(1, -1) % 3) % 7 == 6).to(torch.uint8)
+        prio = torch.rand(steps, E, device=DEV) + 0.01
+        newp = torch.rand(steps, B, device=DEV) + 0.05
+        torch.cuda.synchronize()
+        streams = []
+        for t in range(steps):
+            if multi and t % 10 == 0:
+                torch.cuda.synchronize()
+                streams = [torch.cuda.Stream() for _ in range(24)]     # fresh handles: 12 flush + 12 consumer streams per round
+            w.push_obs_action({"s": obs[t], "a": act[t]})
+            w.push_reward_terminal(rew[t], term[t])
+            if not w.can_pop():
+                continue
+            w.pop_transition(want_fields=False)
+            w.push_sequence(prio[t])
+            side = streams[t % 12] if multi else main
+            with torch.cuda.stream(side):
+                if multi:
+                    side.wait_stream(main)
+                w.flush_to_replay(rep, eta, out=nfin)
+            if t > 30:
+                cons = streams[12 + t % 12] if multi else main
+                with torch.cuda.stream(cons):
+                    rep.sample(B)
+                    rep.update_priority(newp[t])
+        torch.cuda.synchronize()
+        rep.check_errors()
+        out = [rep.size(), rep.num_add(), float(rep.priority_sum()[0])]
+        f, r_, t_, b_, sl = rep.get(rep.size() - 1)
+        return out + [f["s"].cpu(), r_.cpu()]
+
+    one, many = run(False), run(True)
+    assert one[:2] == many[:2] and abs(one[2] - many[2]) <= 1e-6 * abs(one[2])
+    assert torch.equal(one[3], many[3]) and torch.equal(one[4], many[4])
