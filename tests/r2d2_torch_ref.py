@@ -41,15 +41,49 @@ def lstm(W, x, h0, c0):
     return inp, torch.stack(hs, 0), torch.stack(cs, 0)
 
 
-def mlp(W, priv_s):
-    x = F.relu(priv_s @ W["net.0.weight"].t() + W["net.0.bias"])          # r2d2.py:42-46
+def mlp(W, priv_s, masks=None):
+    """masks: None = ReLU; else one 0/1 tensor per fc layer that REPLACES the layer's own ReLU decision (x = a * mask) -- the fp32
+    network under the activation pattern of another arithmetic (bf16_relu_masks), see the two-fc-layer gradient tests"""
+    a = priv_s @ W["net.0.weight"].t() + W["net.0.bias"]                  # r2d2.py:42-46
+    x = F.relu(a) if masks is None else a * masks[0]
     if "net.2.weight" in W:                                               # num_fc_layer = 2
-        x = F.relu(x @ W["net.2.weight"].t() + W["net.2.bias"])
+        a = x @ W["net.2.weight"].t() + W["net.2.bias"]
+        x = F.relu(a) if masks is None else a * masks[1]
     return x
 
 
-def trunk(W, priv_s, h0, c0):
-    return lstm(W, mlp(W, priv_s), h0, c0)
+def bf16_relu_masks(W, priv_s):
+    """The activation pattern of the input MLP when its GEMM operands and stored activations are bf16 (fp32 accumulation, fp32 bias) --
+    the arithmetic of the production kernels -- next to the proof obligation that goes with it.  Returns (masks, flips): `masks` for
+    mlp(..., masks=), `flips` = per layer (n_flipped, worst |fp32 pre-activation| / bound over the flipped units), where `bound` is the
+    largest distance the bf16 arithmetic can move that unit's pre-activation: u * sum_k |x_k w_jk| for the operand roundings
+    (u = 2^-9 per rounded operand; 0/1 inputs are exact) + |W| |x_fp32 - x_bf16| for what the layer below handed up + fp32 summation
+    noise.  worst <= 1 means: every unit whose ReLU decision differs between the two arithmetics has an fp32 pre-activation within the
+    bf16 rounding of zero, i.e. the reference's own decision there is not robust to the rounding of its inputs."""
+    u, noise = 2.0 ** -9, 4e-6
+    r = lambda t: t.bfloat16().float()
+    with torch.no_grad():
+        masks, flips = [], []
+        x32, x16 = priv_s, r(priv_s)
+        exact_in = bool((x32 == x16).all())
+        for name in ("net.0", "net.2"):
+            if name + ".weight" not in W:
+                break
+            w, b = W[name + ".weight"].detach(), W[name + ".bias"].detach()
+            a32 = x32 @ w.t() + b
+            a16 = x16 @ r(w).t() + b
+            bound = ((1.0 if exact_in else 2.0) * u + noise) * (x16.abs() @ w.abs().t()) + (x32 - x16).abs() @ w.abs().t() + noise * b.abs()
+            flip = (a32 > 0) != (a16 > 0)
+            ratio = (a32.abs() / bound.clamp(min=1e-30))[flip]
+            flips.append((int(flip.sum()), float(ratio.max()) if ratio.numel() else 0.0))
+            masks.append((a16 > 0).float())
+            x32, x16 = F.relu(a32), r(F.relu(a16))
+            exact_in = False
+    return masks, flips
+
+
+def trunk(W, priv_s, h0, c0, masks=None):
+    return lstm(W, mlp(W, priv_s, masks), h0, c0)
 
 
 def net_act(W, priv_s, h0, c0, skip_connect=False):
@@ -61,9 +95,9 @@ def net_act(W, priv_s, h0, c0, skip_connect=False):
     return (o @ W["fc_a.weight"].t() + W["fc_a.bias"]).squeeze(0), h, c
 
 
-def net_forward(W, priv_s, legal_move, action, h0, c0):
+def net_forward(W, priv_s, legal_move, action, h0, c0, masks=None):
     """R2D2Net.forward (r2d2.py:80-122) on [T,N,*]: qa, greedy action, q, lstm output."""
-    o, _, _ = trunk(W, priv_s, h0, c0)
+    o, _, _ = trunk(W, priv_s, h0, c0, masks)
     a = o @ W["fc_a.weight"].t() + W["fc_a.bias"]
     v = o @ W["fc_v.weight"].t() + W["fc_v.bias"]
     legal_a = a * legal_move
@@ -85,7 +119,7 @@ def zeros_hid(W, n, like):
     return z, z.clone()
 
 
-def td_error(Won, Wtg, priv_s, legal_move, action, reward, bootstrap, seq_len, multi_step, gamma):
+def td_error(Won, Wtg, priv_s, legal_move, action, reward, bootstrap, seq_len, multi_step, gamma, online_masks=None):
     """R2D2Agent.td_error (r2d2.py:383-428): IQL layouts [T,B,*]; VDN layouts [T,B,P,*] are flattened to B*P rows
     (flat_4d, r2d2.py:363-381) and the Q-values summed over the players of a game."""
     T, B = priv_s.shape[:2]
@@ -94,7 +128,7 @@ def td_error(Won, Wtg, priv_s, legal_move, action, reward, bootstrap, seq_len, m
         P = priv_s.shape[2]
         priv_s, legal_move, action = priv_s.flatten(1, 2), legal_move.flatten(1, 2), action.flatten(1, 2)
     h0, c0 = zeros_hid(Won, priv_s.shape[1], priv_s)
-    online_qa, greedy_a, _, lstm_o = net_forward(Won, priv_s, legal_move, action, h0, c0)
+    online_qa, greedy_a, _, lstm_o = net_forward(Won, priv_s, legal_move, action, h0, c0, online_masks)
     with torch.no_grad():
         target_qa, _, _, _ = net_forward(Wtg, priv_s, legal_move, greedy_a, h0, c0)
     if P:
@@ -118,10 +152,10 @@ def aux_xent(W, lstm_o, own_hand, seq_len):
     return xent.sum(0), (xent.sum(0) / seq_len).mean()
 
 
-def loss(Won, Wtg, batch, multi_step, gamma, pred_weight):
+def loss(Won, Wtg, batch, multi_step, gamma, pred_weight, online_masks=None):
     """R2D2Agent.loss (r2d2.py:461-499) -> per-sequence loss [B], priority [T,B]."""
     err, lstm_o = td_error(Won, Wtg, batch["priv_s"], batch["legal_move"], batch["a"], batch["reward"],
-                           batch["bootstrap"], batch["seq_len"], multi_step, gamma)
+                           batch["bootstrap"], batch["seq_len"], multi_step, gamma, online_masks)
     rl = F.smooth_l1_loss(err, torch.zeros_like(err), reduction="none").sum(0)
     out = rl
     if pred_weight > 0:
