@@ -96,6 +96,25 @@ def env5_traffic_bytes(games, chunk, sad):
     return None if v is None else v * chunk
 
 
+def mfma_counters():
+    """MFMA-busy COUNTER figures of the three MFMA kernels from the committed rocprofv3 PMC pass (profiles/rNN_mfma_util.json, written by
+    tools/mfma_util.sh): {kernel: {mfma_busy, flop_frac, avg_duration_us}}; {} when never collected"""
+    for name in ("r04_mfma_util.json",):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+        gui = "mfma_busy_frac_if_gui_is_per_chip"
+        out = {}
+        for leg in ("learner", "actor"):
+            for k, r in rec.get(leg, {}).items():
+                key = k.split("<")[0]
+                out[key] = {"mfma_busy_at_2p4GHz_wall": r.get("mfma_busy_frac_at_2p4GHz_wall"), "mfma_busy_over_gui_active": r.get(gui),
+                            "flop_frac": r.get("flop_frac"), "avg_duration_us": r.get("avg_duration_us_uninstrumented"), "source": "profiles/" + name}
+        return out
+    return {}
+
+
 def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     """Second half of BASELINE.json's metric: R2D2 learner samples/sec at configs[2] (2p SAD IQL, F=838, A=21,
     H=512, 2-layer LSTM, B=128, T=80, n=3): sample-shaped synthetic batch -> loss fwd (online+target) -> BPTT ->
@@ -185,7 +204,9 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
         cl.loss(batch, weight, 0.0)
         cl.optimizer_step()
     f_ms, f_fl, f_n = C.c_double(0), C.c_double(0), C.c_int32(0)
-    _lib.check(lib.hsad_lstm_fused_timing_read(C.byref(f_ms), C.byref(f_fl), C.byref(f_n)))
+    b_ms, b_fl, b_n = C.c_double(0), C.c_double(0), C.c_int32(0)
+    _lib.check(lib.hsad_lstm_fused_timing_read_kind(0, C.byref(f_ms), C.byref(f_fl), C.byref(f_n)))
+    _lib.check(lib.hsad_lstm_fused_timing_read_kind(1, C.byref(b_ms), C.byref(b_fl), C.byref(b_n)))
     _lib.check(lib.hsad_lstm_fused_timing(0))
     # ... and the chunk-pipelined schedule of rounds 1-2 (stand-alone projection GEMMs + chunked recurrences) on the same learner
     cl.set_fused(False)
@@ -211,6 +232,8 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     gemm_ms = g_ms.value / max(g_np.value, 1)
     gemm_tf = 2.0 * M * N * K / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     fused_tf = f_fl.value / (f_ms.value * 1e-3) / 1e12 if f_ms.value > 0 else 0.0
+    bptt_tf = b_fl.value / (b_ms.value * 1e-3) / 1e12 if b_ms.value > 0 else 0.0
+    counters = mfma_counters()
     return {
         "value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3, "python_schedule_ms_per_update": dt_py * 1e3,
         "chunk_pipelined_schedule_ms_per_update": dt_chunked * 1e3,
@@ -220,14 +243,23 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
         "config": {"workload": "BASELINE configs[2]: 2p SAD IQL learner update, F=838 A=21 H=512 L=2 B=128 T=80 n=3, "
                                "synthetic batch, random-init nets, loss fwd + BPTT + clip + Adam"},
         "update_tflops": flop / dt / 1e12,
+        # the DOMINANT kernel of the update: the BPTT launch, timed where it runs
         "roofline": {"bound": "mfma",
+                     "kernel": "lstm_fused_bwd_kernel<64> (the BPTT of an update: both LSTM layers of the online net, the dO = dG1 W_ih1 projection "
+                               "stage and the input layer's dx = dG0 W_ih0 sink stage as four pipeline stages x %d steps in one persistent launch)" % T,
+                     "achieved": bptt_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": bptt_tf / 2500.0,
+                     "traffic": fused_traffic_bytes("bwd"), "avg_launch_ms": b_ms.value, "in_update_launches_timed": b_n.value,
+                     "algorithmic_flop_per_launch": b_fl.value, "share_of_update": b_ms.value / (dt * 1e3) if dt > 0 else None,
+                     "mfma_busy_counter": counters.get("lstm_fused_bwd_kernel"),
+                     "note": "a recurrence over B = 128 rows is latency-bound by construction (each of the 80 steps needs the previous one: its "
+                             "step time is the cross-workgroup exchange, not MFMA issue); the fraction is reported as what it is"},
+        "roofline_forward": {"bound": "mfma",
                      "kernel": "lstm_fused_fwd_kernel<16> (the forward LSTM of an update: 2 nets x 2 layers x %d steps, [x_t | h_t-1] [W_ih | W_hh]^T "
                                "inside the persistent recurrence; one launch per update)" % T,
                      "achieved": fused_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": fused_tf / 2500.0,
-                     "traffic": fused_traffic_bytes(), "avg_launch_ms": f_ms.value, "in_update_launches_timed": f_n.value,
-                     "algorithmic_flop_per_launch": f_fl.value,
-                     "note": "a recurrence over B = 128 rows is latency-bound by construction (each of the 80 steps needs the previous one); "
-                             "its MFMA fraction is what it is -- the point of the fusion is the update time, not this fraction"},
+                     "traffic": fused_traffic_bytes("fwd"), "avg_launch_ms": f_ms.value, "in_update_launches_timed": f_n.value,
+                     "algorithmic_flop_per_launch": f_fl.value, "share_of_update": f_ms.value / (dt * 1e3) if dt > 0 else None,
+                     "mfma_busy_counter": counters.get("lstm_fused_fwd_kernel")},
         "roofline_projection_gemm_rounds_1_2": {
             "bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d of the chunk-pipelined schedule; online + target "
                                        "net = one launch of two problems, avg_launch_ms is per problem)" % (M, N, K),
@@ -302,6 +334,7 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
                                                    "phase-interleaved k loop; the online and the target net's cell of a layer are ONE launch of two problems: 2 launches per step)" % (games * 2, 2048, 1024),
                         "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": cell_traffic_bytes(),
+                        "mfma_busy_counter": mfma_counters().get("lstm_cell_pp_kernel"),
                         "algorithmic_bytes_per_launch": 2 * (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + 2 * games * 2 * 512 * 4,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
                         "launches_per_step": nl.value / 40.0, "share_of_step": nl.value / 40.0 * ms.value / (dt * 1e3)},

@@ -195,6 +195,7 @@ SIGNATURES = {
     "hsad_lstm_backward_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hsad_lstm_fused_timing": (C.c_int, [C.c_int]),
     "hsad_lstm_fused_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "hsad_lstm_fused_timing_read_kind": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "hsad_lstm_forward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_backward_chunk": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "hsad_gemm_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int,

@@ -4658,6 +4658,7 @@ struct FusedTiming {
   bool on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   std::vector<double> flop;
+  std::vector<int> kind;       // 0 = lstm_fused_fwd_kernel, 1 = lstm_fused_bwd_kernel
 } g_fused_timing;
 }  // namespace
 
@@ -4667,25 +4668,37 @@ int hsad_lstm_fused_timing(int enable) {
   g_fused_timing.on = enable != 0;
   return HSAD_OK;
 }
-int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches) {
-  if (!avg_ms || !launches) return nfail(HSAD_ERR_INVALID, "fused_timing_read: null argument");
+// kind 0: the fused forward launches, 1: the fused BPTT launches recorded since the last read of that kind
+int hsad_lstm_fused_timing_read_kind(int kind, double* avg_ms, double* avg_flop, int32_t* launches) {
+  if (!avg_ms || !launches || kind < 0 || kind > 1) return nfail(HSAD_ERR_INVALID, "fused_timing_read: bad argument");
   HIP_TRY(hipDeviceSynchronize());
   double ms = 0.0, fl = 0.0;
+  size_t n = 0, keep = 0;
   for (size_t i = 0; i < g_fused_timing.ev.size(); ++i) {
+    if (g_fused_timing.kind[i] != kind) {      // the other kernel's records stay for their own read
+      g_fused_timing.ev[keep] = g_fused_timing.ev[i];
+      g_fused_timing.flop[keep] = g_fused_timing.flop[i];
+      g_fused_timing.kind[keep++] = g_fused_timing.kind[i];
+      continue;
+    }
     float t = 0.f;
     HIP_TRY(hipEventElapsedTime(&t, g_fused_timing.ev[i].first, g_fused_timing.ev[i].second));
     ms += t;
     fl += g_fused_timing.flop[i];
+    ++n;
     (void)hipEventDestroy(g_fused_timing.ev[i].first);
     (void)hipEventDestroy(g_fused_timing.ev[i].second);
   }
-  const size_t n = g_fused_timing.ev.size();
   *launches = (int32_t)n;
   *avg_ms = n ? ms / n : 0.0;
   if (avg_flop) *avg_flop = n ? fl / n : 0.0;
-  g_fused_timing.ev.clear();
-  g_fused_timing.flop.clear();
+  g_fused_timing.ev.resize(keep);
+  g_fused_timing.flop.resize(keep);
+  g_fused_timing.kind.resize(keep);
   return HSAD_OK;
+}
+int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches) {
+  return hsad_lstm_fused_timing_read_kind(0, avg_ms, avg_flop, launches);
 }
 
 // Fused persistent forward (lstm_fused_fwd_kernel): nnet independent nets x nlayer stacked layers over the WHOLE sequence in one
@@ -4758,6 +4771,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     HIP_TRY(hipEventRecord(te1, s));
     g_fused_timing.ev.push_back({te0, te1});
     g_fused_timing.flop.push_back((double)nrec * 2.0 * T * Bn * 4.0 * H * 2.0 * H);      // [x | h] [W_ih | W_hh]^T per recurrence
+    g_fused_timing.kind.push_back(0);
   }
   return HSAD_OK;
 }
@@ -4906,6 +4920,12 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
   const size_t lds = (size_t)(32 * (4 * H + 8) + 32 * 136) * sizeof(bf16_t) + 16 + 16 * 64 * 16;
+  hipEvent_t te0 = nullptr, te1 = nullptr;
+  if (g_fused_timing.on) {
+    HIP_TRY(hipEventCreate(&te0));
+    HIP_TRY(hipEventCreate(&te1));
+    HIP_TRY(hipEventRecord(te0, s));
+  }
   if (H == 512) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_fused_bwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(lstm_fused_bwd_kernel<64>, dim3(grid), dim3(256), lds, s, m);
@@ -4914,6 +4934,14 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     hipLaunchKernelGGL(lstm_fused_bwd_kernel<32>, dim3(grid), dim3(256), lds, s, m);
   }
   HIP_TRY(hipGetLastError());
+  if (te0) {
+    HIP_TRY(hipEventRecord(te1, s));
+    g_fused_timing.ev.push_back({te0, te1});
+    // every pipeline stage (a layer's dh = dG W_hh^T, a projection stage's dO = dG W_ih, the sink's dx = dG W_ih0) contracts a
+    // [Bn x 4H] tile with a [4H x H] slice per step
+    g_fused_timing.flop.push_back((double)nint * Tc * Bn * 4.0 * H * H * 2.0);
+    g_fused_timing.kind.push_back(1);
+  }
   return HSAD_OK;
 }
 

@@ -562,6 +562,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
  * launch duration, the algorithmic FLOP per launch (2 T Bn 4H 2H per recurrence) and the launch count, synchronises, clears */
 int hsad_lstm_fused_timing(int enable);
 int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches);
+/* kind 0: the fused forward launches, 1: the fused BPTT launches (lstm_fused_bwd_kernel) recorded since the last read of that kind */
+int hsad_lstm_fused_timing_read_kind(int kind, double* avg_ms, double* avg_flop, int32_t* launches);
 /* FUSED persistent BPTT (round 3): the stacked layers of nnet nets over a chunk of Tc steps in ONE launch, one step apart; the gradient a
  * lower layer receives from the layer above, dO = dG_above W_ih_above (a stand-alone GEMM per chunk in hsad_lstm_backward_chunk_multi's
  * schedule), is computed inside the lower layer's recurrence from the hand-off tiles the layer above publishes (W_ih_above^T slice
