@@ -7,7 +7,9 @@ machinery has no counterpart by design: all games advance in lock-step on the GP
 `hanalearn.HanabiThreadLoop`s from ONE background Python thread (ctypes releases the GIL during launches), so a driver
 written against the reference -- create_envs / create_threads / ActGroup / context.start() / replay.sample() -- works
 unchanged; `Context.step()` is there for drivers that prefer to interleave rollout and learning themselves."""
+import os
 import threading
+import time as _time
 
 import torch
 
@@ -130,10 +132,12 @@ class RNNPrioritizedReplay:
     def num_add(self):
         return 0 if self.impl is None else self.impl.num_add()
 
-    num_sample = 0         # sample() calls so far: the clock Context.set_pace runs the rollout by
+    num_sample = 0         # sample() calls so far: the clock Context's pacing runs the rollout by
+    last_sample_time = 0.0  # time.monotonic() of the latest sample(): how a Context notices that a training loop is (still) running
 
     def sample(self, batchsize, device=None):
         self.num_sample += 1
+        self.last_sample_time = _time.monotonic()
         (f, reward, terminal, bootstrap, seq_len), weight = self.impl.sample(batchsize)
         obs = {k: v for k, v in f.items() if k not in self.ACTION_KEYS}
         action = {k: v.squeeze(2) for k, v in f.items() if k in self.ACTION_KEYS}
@@ -382,29 +386,72 @@ class Context:
         # previous pause when a resume / pause pair follows within the thread's 1 ms nap)
         self._cv = threading.Condition()
         self._pause_ticket, self._parked_ticket, self._done = 0, 0, False
-        self._pace = None          # (replay, steps per sample() call), see set_pace
+        self._pace = None          # (replay, steps per sample() call, credit state): an explicit set_pace
         self._run_ahead, self._marks = 0, []
+        # the default: pace by whichever replay of the attached training loops is being sampled (see _auto_pace); HSAD_AUTO_PACE=0 or
+        # set_pace(False) give the reference's unconditional free-running
+        self.auto_pace_steps = float(os.environ.get("HSAD_AUTO_PACE", "2"))
+        self.auto_pace_idle_s = 0.1
+        self._auto, self._auto_replays, self._bound = None, None, 0
 
     def set_pace(self, replay, steps_per_sample=1.0, run_ahead=2):
-        """NOT in the reference (rela/context.h free-runs; so does this class until set_pace is called).  On ONE GPU a free-running
-        rollout thread and a training loop share the device very unevenly: the rollout's full-chip kernels are always queued, and the
-        learner's persistent launches wait behind each of them.  With a pace the loop thread issues
-        `steps_per_sample` rollout steps per `replay.sample()` call of the training loop, once that loop has started sampling (the
-        burn-in before it free-runs), and its host never gets more than `run_ahead` steps ahead of the device -- the operating point
-        of selfplay's explicit interleave through the reference's two-thread API: rollout on the Context's stream, next to the
-        update on the driver's.  set_pace(None) returns to free-running."""
+        """NOT in the reference (rela/context.h free-runs).  On ONE GPU a free-running rollout thread and a training loop share the
+        device very unevenly: the rollout's full-chip kernels are always queued, and the learner's persistent launches wait behind each
+        of them (16 k sequences/s instead of 65 k).  With a pace the loop thread issues `steps_per_sample` rollout
+        steps per `replay.sample()` call of the training loop, once that loop has started sampling (the burn-in before it free-runs),
+        and its host never gets more than `run_ahead` steps ahead of the device -- the operating point of selfplay's explicit interleave
+        through the reference's two-thread API: rollout on the Context's stream, next to the update on the driver's.
+
+        An unchanged reference driver never calls this and gets the pace anyway: by DEFAULT (set_pace(None), the state a Context is
+        created in) the loop thread paces itself by whichever replay of its training loops is being sampled (`auto_pace_steps` per
+        sample, default 2 = the measured best operating point) and free-runs whenever nobody has sampled for `auto_pace_idle_s` --
+        burn-in, evaluation pauses, a driver that only collects data.  set_pace(replay, k) pins the replay and the ratio (and then
+        WAITS for samples instead of falling back to free-running); set_pace(False) is the reference's unconditional free-running."""
+        self._auto = None
+        if replay is False:
+            self._pace, self._run_ahead, self.auto_pace_steps = None, 0, 0.0
+            return
         self._pace = None if replay is None else (replay, float(steps_per_sample), [None, 0.0])
         self._run_ahead = int(run_ahead) if replay is not None else 0
 
+    def _auto_pace(self):
+        """the default pace: -> (replay, steps per sample, credit state) while a training loop is sampling a replay that the attached loops
+        feed, else None (free-running)"""
+        if self.auto_pace_steps <= 0:
+            return None
+        if self._auto_replays is None:
+            seen = []
+            for lp in self.loops:
+                if getattr(lp, "eval_mode", True):
+                    continue
+                for a in getattr(lp, "actors", []):
+                    rp = getattr(a, "replay", None)
+                    if rp is not None and hasattr(rp, "num_sample") and not any(rp is x for x in seen):
+                        seen.append(rp)
+            self._auto_replays = seen
+        now = _time.monotonic()
+        for rp in self._auto_replays:
+            if rp.num_sample > 0 and now - rp.last_sample_time < self.auto_pace_idle_s:
+                if self._auto is None or self._auto[0] is not rp:
+                    self._auto = (rp, self.auto_pace_steps, [None, 0.0])
+                return self._auto
+        self._auto = None
+        return None
+
     def _may_step(self):
         """pace gate of the loop thread: True = issue a step now"""
-        if self._run_ahead > 0 and len(self._marks) > self._run_ahead:
+        pace = self._pace if self._pace is not None else self._auto_pace()
+        bound = self._run_ahead if self._pace is not None else (2 if pace is not None else 0)
+        self._bound = bound
+        if bound > 0 and len(self._marks) > bound:
             if not self._marks[0].query():
                 return False
             self._marks.pop(0)
-        if self._pace is None:
+        elif bound == 0 and self._marks:
+            del self._marks[:]
+        if pace is None:
             return True
-        replay, per, st = self._pace
+        replay, per, st = pace
         n = replay.num_sample
         if n == 0:
             return True                          # the training loop has not started: burn-in
@@ -445,7 +492,7 @@ class Context:
                             self._cv.notify_all()
                     time.sleep(0.001)
                     continue
-                if (self._pace is not None or self._run_ahead > 0) and not self._may_step():
+                if not self._may_step():
                     time.sleep(0)                # yield: the driver's thread is issuing the update this step waits for
                     continue
                 busy = False
@@ -461,7 +508,7 @@ class Context:
                             else:
                                 lp.step()
                         busy = True
-                if self._run_ahead > 0 and self._streams:
+                if self._bound > 0 and self._streams:
                     for st in self._streams.values():
                         e = torch.cuda.Event()
                         e.record(st)

@@ -148,6 +148,66 @@ def test_context_pace_runs_the_rollout_by_the_training_loops_samples():
     context.terminate()
 
 
+def test_an_unchanged_driver_is_paced_by_default():
+    """the reference's driver (selfplay.py:180-244) calls context.start() and then loops over replay.sample() --
+    nothing else.  Without any set_pace call the Context must run the rollout at its default ratio (2 steps per sample) while that
+    loop samples -- the measured operating point of tools/time_dropin.py -- and free-run before (burn-in) and after it."""
+    import hanalearn
+    import rela
+    from hanabi_sad_amd.selfplay import generate_explore_eps
+    per_thread, P, hand, n, gamma, eta, T, B = 64, 2, 5, 3, 0.999, 0.9, 80, 16
+    eps = generate_explore_eps(0.1, 7, 80)
+    games = create_envs(hanalearn, per_thread, 21, P, hand, 0, eps, T, True)
+    agent = TinyAgent(games[0].feature_size(), 128, games[0].num_action(), hand, 3)
+    replay = rela.RNNPrioritizedReplay(2048, 1, 0.9, 0.6, 3)
+    runner = rela.BatchRunner(agent, DEV, 100, ["act", "compute_priority"])
+    acts = [rela.R2D2Actor(runner, n, per_thread, gamma, eta, T, 1, replay) for _ in range(P)]
+    env = hanalearn.HanabiVecEnv()
+    for g in games:
+        env.append(g)
+    context = rela.Context()
+    context.push_env_thread(hanalearn.HanabiThreadLoop(acts, env, False))
+    assert context.auto_pace_steps == 2.0
+    context.start()                                     # ... and no set_pace
+    steps = lambda: acts[0].num_act() // per_thread
+    t0 = time.time()
+    while replay.size() < 4 * B:                        # burn-in free-runs
+        assert time.time() - t0 < 120
+        time.sleep(0.02)
+    a = steps()
+    time.sleep(0.3)
+    assert steps() > a + 10                             # still free-running: nobody samples
+    context.auto_pace_idle_s = 1.0                      # (a wide window so that the assertions below cannot race the fall-back)
+    N = 150
+    replay.sample(B, DEV)                               # the thread notices the training loop within one of its steps ...
+    replay.update_priority(torch.ones(B, device=DEV))
+    time.sleep(0.25)
+    s0 = steps()
+    time.sleep(0.1)
+    assert steps() == s0                                # ... spends that sample's credit and waits for the next one
+    for _ in range(N):                                  # from then on: two steps per sample, no more, no fewer
+        replay.sample(B, DEV)
+        replay.update_priority(torch.ones(B, device=DEV))
+    t0 = time.time()
+    while steps() < s0 + 2 * N:
+        assert time.time() - t0 < 0.9, (steps() - s0, N)
+        time.sleep(0.002)
+    time.sleep(0.05)
+    s1 = steps()
+    assert s1 - s0 == 2 * N, (s1 - s0, N)
+    time.sleep(1.5)                                     # the training loop has stopped: free-running again
+    assert steps() > s1 + 10
+    context.set_pace(False)                             # the reference's unconditional free-running stays available
+    b = steps()
+    for _ in range(20):
+        replay.sample(B, DEV)
+        replay.update_priority(torch.ones(B, device=DEV))
+        time.sleep(0.01)
+    assert steps() - b > 2 * 20 + 10
+    context.pause()
+    context.terminate()
+
+
 def test_action_matrix_tool_counts_like_the_reference_loop():
     """hanabi_sad_amd.action_matrix (pyhanabi/tools/action_matrix.py:31-107): whole greedy self-play games collected in VDN layout
     through rela / hanalearn, and the conditional action matrix computed over all sequences at once -- against the reference's

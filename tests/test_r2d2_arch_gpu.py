@@ -16,8 +16,9 @@ from tests.test_r2d2_precision_gpu import TOL, maxerr, record, relerr
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 DEV = "cuda:0"
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-# relative Frobenius error of any parameter's gradient at the larger shapes below = 2 x the worst measured on MI355X
-# (profiles/r04_r2d2_measured_errors.json "arch_fused.*"); two-fc nets are compared under the bf16 activation pattern, so no shape needs more
+# relative Frobenius error of any parameter's gradient at the larger shapes below = 2 x the worst measured on MI355X (0.0047, pred.weight
+# at H = 512, 3 layers: tools/arch_grad_errors.py, profiles/r04_r2d2_measured_errors.json "arch_fused.*"); net.* gradients are compared under
+# the bf16 activation pattern, so no architecture needs more
 ARCH_GRAD_REL = 1.0e-2
 CASES = ["r2d2_fc2_skip_small", "r2d2_skip_small", "r2d2_lstm1_small", "r2d2_lstm3_fc2_small"]
 
@@ -60,7 +61,6 @@ def test_act_and_compute_priority_against_golden(name, precision):
     # golden file does not store: the advantage margins behind each argmax
     Won, Wtg = ref.weights_from_npz(z, "online_net."), ref.weights_from_npz(z, "target_net.")
     skip, ms, gm = bool(z["arch"][2]), int(z["meta"][8]), float(z["gamma"][0])
-    cpu = lambda d: {k: v.cpu() for k, v in d.items()}
     adv, _, _ = ref.net_act(Won, obs["priv_s"].cpu(), h["h0"].cpu(), h["c0"].cpu(), skip)
     gap = top2_gap(adv, obs["legal_move"].cpu())
     flipped = torch.nonzero(reply["greedy_a"].cpu() != want_g).flatten().tolist()
@@ -111,7 +111,7 @@ def test_learner_loss_and_gradients_against_golden(name, precision):
         lr = CompositeLearner(Won, Wtg, ms, gm, device=DEV)
     t = lambda k: torch.tensor(z[k]).to(DEV)
     batch = {k: t("loss." + k) for k in ("priv_s", "legal_move", "a", "reward", "bootstrap", "seq_len", "own_hand")}
-    two_fc = int(z["arch"][1]) == 2
+    two_fc = True          # (the activation-pattern property below is applied to every architecture; it MATTERS with two fc layers)
     if two_fc and precision == "bf16":
         # Two fc layers in bf16: the ReLU decision of a first-layer unit whose pre-activation is within the bf16 rounding of zero comes
         # out the other way, and each such unit moves the net.* gradients by a whole term (2.3-3.4 % of their norm on these cases;
@@ -175,14 +175,15 @@ def test_fused_forward_schedules_for_other_depths(H, T, B, nl, nfc):
     (rloss * weight).mean().backward()
     want = {k: v.grad.clone() for k, v in Wd.items() if v.grad is not None}
     flips = []
-    if nfc == 2:       # net.* gradients against the fp32 network under the bf16 activation pattern, flips proven near zero (see the golden test)
-        masks, flips = ref.bf16_relu_masks(Wd, batch["priv_s"])
-        assert all(worst <= 1.0 for _, worst in flips), flips
-        for v in Wd.values():
-            v.grad = None
-        ml, _ = ref.loss(Wd, Wtd, batch, 3, 0.999, 0.25, online_masks=masks)
-        (ml * weight).mean().backward()
-        want.update({k: v.grad.clone() for k, v in Wd.items() if k.startswith("net.")})
+    # net.* gradients against the fp32 network under the bf16 activation pattern, every flipped unit proven to sit within the bf16 rounding
+    # of zero (see the golden test; one fc layer has the effect too: 150-2,000 flipped units move net.0.weight by 0.4-1.3 % at these sizes)
+    masks, flips = ref.bf16_relu_masks(Wd, batch["priv_s"])
+    assert all(worst <= 1.0 for _, worst in flips), flips
+    for v in Wd.values():
+        v.grad = None
+    ml, _ = ref.loss(Wd, Wtd, batch, 3, 0.999, 0.25, online_masks=masks)
+    (ml * weight).mean().backward()
+    want.update({k: v.grad.clone() for k, v in Wd.items() if k.startswith("net.")})
     with torch.no_grad():
         h0 = torch.zeros(nl, B, H, device=DEV)
         _, _, rq, _ = ref.net_forward({k: v.detach() for k, v in Wd.items()}, batch["priv_s"], batch["legal_move"], batch["a"], h0, h0.clone())

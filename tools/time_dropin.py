@@ -96,11 +96,20 @@ def one_update(u):
 
 
 results = []
-for label, stream, pace in (("free-running rollout, default-priority stream", torch.cuda.Stream(DEV), None),
-                            ("free-running rollout, high-priority stream   ", torch.cuda.Stream(DEV, priority=-1), None),
-                            ("Context.set_pace(replay, 1 step per sample)  ", torch.cuda.Stream(DEV), 1.0),
-                            ("Context.set_pace(replay, 2 steps per sample) ", torch.cuda.Stream(DEV), 2.0)):
-    ctx.set_pace(replay if pace else None, pace or 1.0)
+# the FIRST line is the unchanged reference driver: no pacing call of any kind (the Context paces itself by the replay's sample() calls)
+for label, stream, pace in (("UNCHANGED driver (no set_pace call: auto pace)  ", torch.cuda.Stream(DEV), "default"),
+                            ("set_pace(False): the reference's free-running   ", torch.cuda.Stream(DEV), False),
+                            ("free-running rollout, high-priority stream      ", torch.cuda.Stream(DEV, priority=-1), False),
+                            ("Context.set_pace(replay, 1 step per sample)     ", torch.cuda.Stream(DEV), 1.0),
+                            ("Context.set_pace(replay, 2 steps per sample)    ", torch.cuda.Stream(DEV), 2.0)):
+    if pace == "default":
+        pass                                            # what a driver written for the reference does: nothing
+    elif pace is False:
+        auto = ctx.auto_pace_steps
+        ctx.set_pace(False)
+    else:
+        ctx.auto_pace_steps = auto
+        ctx.set_pace(replay, pace)
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
         for u in range(20):
