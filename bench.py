@@ -373,24 +373,34 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
             z = torch.zeros(n, T, device=dev)
             shard.add(f, z, z.to(torch.uint8), z + 1, torch.full((n,), float(T), device=dev), torch.rand(n, device=dev, generator=g) + 0.1)
     shard.set_field_output("priv_s", "bf16", 896)
-    link = ReplayLink(shard, batch, 0.6, dev, learner_rank=0, depth=2, param_numel=n_param, mode=mode, name="bench_" + mode)
+    # star rounds are pipelined like selfplay.run_link_learner runs them: three rounds open at once (the reference's prefetch depth)
+    ahead = int(os.environ.get("HSAD_BENCH_ROUNDS_AHEAD", "3")) if mode == "star" else 1
+    link = ReplayLink(shard, batch, 0.6, dev, learner_rank=0, depth=2, param_numel=n_param, mode=mode, name="bench_" + mode, ahead=ahead)
     torch.cuda.synchronize()
     out = None
     if rank == 0:
         prios = []
         link.stage_params(torch.zeros(n_param, device=dev))
         t0 = None
+        for _ in range(ahead - 1):
+            link.begin(None)
+        lag = 2 if ahead == 1 else 1        # (one round open at a time: the priorities of batch r leave with round r + 2, as in rounds 1-3)
         for r in range(rounds + 5):
             if r == 5:                      # five warm-up rounds (communicator set-up, first-touch allocations)
                 torch.cuda.synchronize()
-                link.timer = type(link.timer)(dev)
+                link.timer, link.timer_down = type(link.timer)(dev), type(link.timer)(dev)
+                link.wait_ms, link.wait_n = 0.0, 0
                 t0 = time.perf_counter()
-            link.begin(prios.pop(0) if len(prios) >= 2 else None, params=(r % 10 == 5), stop=(r == rounds + 4))
+            link.begin(prios.pop(0) if len(prios) >= lag else None, params=(r % 10 == 5), stop=(r == rounds + 4))
             (f, *_), w = link.finish()
             prios.append(torch.rand(batch, device=dev) + 0.05)
         torch.cuda.synchronize()
-        wall = (time.perf_counter() - t0) / rounds * 1e3
-        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "wire_bytes_per_sequence": shard.wire_bytes(),
+        wall_end = time.perf_counter()
+        while link._rounds:
+            link.finish()
+        torch.cuda.synchronize()
+        wall = (wall_end - t0) / rounds * 1e3
+        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "rounds_open_at_once": ahead, "wire_bytes_per_sequence": shard.wire_bytes(),
                "batch_bytes_per_rank_message": shard.wire_bytes() * batch, "param_bucket_bytes": n_param * 4,
                "round_wall_ms": wall, "per_round_ms": link.timings(),
                "note": "sections are HIP-event times on the learner's exchange stream, averaged over all rounds (param_send_ms / "

@@ -236,6 +236,9 @@ SIGNATURES = {
     "hsad_comm_gather_batch": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P]),
     "hsad_comm_scatter_priority": (C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "hsad_comm_star_round": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "hsad_comm_star_open": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int64, _P, _P]),
+    "hsad_comm_star_collect": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "hsad_comm_star_serve": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int64, _P]),
     "hsad_comm_all_stats": (_P, [_P]),
     "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_q_of": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -258,6 +258,109 @@ int hsad_comm_star_round(hsad_comm* c, hsad_replay* shard, int batch, float* hdr
   return HSAD_OK;
 }
 
+// ---- the same round in two halves, for rounds that overlap (dist.py ReplayLink(ahead = 3); the reference's prefetch depth) --------
+// Operations on one RCCL communicator run in issue order and send / recv rendezvous: on ONE communicator the header of round r + 1
+// queues behind the receive of round r's replies.  So the root drives TWO communicators -- `down` (headers, parameters) on one stream,
+// `up` (rows, statistics) on another -- and keeps a ring of per-round buffers; an actor rank passes the same two communicators to
+// hsad_comm_star_serve and stays on its own stream.  hsad_comm_star_open: root, first half (header of THIS round out).
+// hsad_comm_star_collect: root, second half (own shard served, replies received into this round's buffers).
+int hsad_comm_star_open(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, const double* stats_known,
+                        double* stats_prime, float* params, int64_t param_count, void* stream_down, void* stream_up) {
+  Rccl* R = rccl();
+  if (!R || !down || !up || !shard || !hdr || batch < 1 || batch > 1024 || down->world != up->world || down->rank != up->rank ||
+      ((flags & HSAD_LINK_PRIME) ? !stats_prime : !stats_known) || ((flags & HSAD_LINK_PARAMS) && (!params || param_count < 1)))
+    return cfail(HSAD_ERR_INVALID, "comm_star_open: bad arguments");
+  hipStream_t sd = (hipStream_t)stream_down, su = (hipStream_t)stream_up;
+  const int W = down->world, root = down->rank;
+  const size_t hdr_n = 2 * (size_t)batch + 4 * (size_t)W;
+  double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
+  int rc;
+  if (flags & HSAD_LINK_PRIME) {        // nobody has reported a (sum, size) yet: collect them up front (up), then the header may leave
+    NCCL_TRY(R->GroupStart());
+    for (int k = 0; k < W; ++k)
+      if (k != root) NCCL_TRY(R->Recv(stats_prime + 2 * k, 2, ncclFloat64, k, up->comm, su));
+    NCCL_TRY(R->GroupEnd());
+    if ((rc = hsad_replay_stats(shard, stats_prime + 2 * root, stream_up))) return rc;
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e, su));
+    HIP_TRY(hipStreamWaitEvent(sd, e, 0));
+    HIP_TRY(hipEventDestroy(e));
+    stats_known = stats_prime;
+  }
+  HIP_TRY(hipMemcpyAsync(hdr_stats, stats_known, 16 * (size_t)W, hipMemcpyDeviceToDevice, sd));
+  NCCL_TRY(R->GroupStart());
+  for (int k = 0; k < W; ++k)
+    if (k != root) NCCL_TRY(R->Send(hdr, hdr_n, ncclFloat32, k, down->comm, sd));
+  NCCL_TRY(R->GroupEnd());
+  if (flags & HSAD_LINK_PARAMS) {
+    NCCL_TRY(R->GroupStart());
+    for (int k = 0; k < W; ++k)
+      if (k != root) NCCL_TRY(R->Send(params, (size_t)param_count, ncclFloat32, k, down->comm, sd));
+    NCCL_TRY(R->GroupEnd());
+  }
+  return HSAD_OK;
+}
+
+// root, second half: call it right behind hsad_comm_star_open (the up stream must see the finished header: pass an event, or let
+// stream_up wait for stream_down's header copy -- done here).  stats_reply [world][2]: where this round's replies put their statistics
+// (what a LATER hsad_comm_star_open passes as stats_known once the host has collected this round).
+int hsad_comm_star_collect(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, const int32_t* answer_owner,
+                           int32_t* owner_out, uint8_t* wire_all, double* stats_reply, void* stream_down, void* stream_up) {
+  Rccl* R = rccl();
+  if (!R || !down || !up || !shard || !hdr || !owner_out || !wire_all || !stats_reply || batch < 1 || batch > 1024 ||
+      ((flags & HSAD_LINK_HAS_PRIO) && !answer_owner))
+    return cfail(HSAD_ERR_INVALID, "comm_star_collect: bad arguments");
+  hipStream_t sd = (hipStream_t)stream_down, su = (hipStream_t)stream_up;
+  const int W = up->world, root = up->rank;
+  const size_t bytes = (size_t)batch * hsad_replay_wire_bytes(shard);
+  double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
+  int rc;
+  hipEvent_t e;                          // the header (uniforms, priorities, statistics) is complete on the down stream
+  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(e, sd));
+  HIP_TRY(hipStreamWaitEvent(su, e, 0));
+  HIP_TRY(hipEventDestroy(e));
+  NCCL_TRY(R->GroupStart());             // posted before the own shard is served: the replies travel meanwhile
+  for (int k = 0; k < W; ++k) {
+    if (k == root) continue;
+    NCCL_TRY(R->Recv(wire_all + (size_t)k * bytes, bytes, ncclUint8, k, up->comm, su));
+    NCCL_TRY(R->Recv(stats_reply + 2 * k, 2, ncclFloat64, k, up->comm, su));
+  }
+  NCCL_TRY(R->GroupEnd());
+  if ((rc = hsad_replay_serve(shard, batch, hdr, hdr_stats, W, root, owner_out, wire_all + (size_t)root * bytes, stream_up))) return rc;
+  if ((flags & HSAD_LINK_HAS_PRIO) && (rc = hsad_replay_update_owned(shard, batch, hdr + batch, answer_owner, root, stream_up))) return rc;
+  return hsad_replay_stats(shard, stats_reply + 2 * root, stream_up);
+}
+
+// an actor rank's side of a pipelined round (one stream; the two communicators only keep the root's two directions apart)
+int hsad_comm_star_serve(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, int root,
+                         const int32_t* answer_owner, int32_t* owner_out, uint8_t* wire_mine, float* params, int64_t param_count, void* stream) {
+  Rccl* R = rccl();
+  if (!R || !down || !up || !shard || !hdr || !owner_out || !wire_mine || batch < 1 || batch > 1024 || root < 0 || root >= up->world ||
+      up->rank == root || ((flags & HSAD_LINK_HAS_PRIO) && !answer_owner) || ((flags & HSAD_LINK_PARAMS) && (!params || param_count < 1)))
+    return cfail(HSAD_ERR_INVALID, "comm_star_serve: bad arguments (an actor rank's call)");
+  hipStream_t s = (hipStream_t)stream;
+  const int W = up->world, me = up->rank;
+  const size_t bytes = (size_t)batch * hsad_replay_wire_bytes(shard), hdr_n = 2 * (size_t)batch + 4 * (size_t)W;
+  double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
+  int rc;
+  if (flags & HSAD_LINK_PRIME) {
+    if ((rc = hsad_replay_stats(shard, up->my_stats, stream))) return rc;
+    NCCL_TRY(R->Send(up->my_stats, 2, ncclFloat64, root, up->comm, s));
+  }
+  NCCL_TRY(R->Recv(hdr, hdr_n, ncclFloat32, root, down->comm, s));
+  if ((rc = hsad_replay_serve(shard, batch, hdr, hdr_stats, W, me, owner_out, wire_mine, stream))) return rc;
+  if ((flags & HSAD_LINK_HAS_PRIO) && (rc = hsad_replay_update_owned(shard, batch, hdr + batch, answer_owner, me, stream))) return rc;
+  if ((rc = hsad_replay_stats(shard, up->my_stats, stream))) return rc;
+  NCCL_TRY(R->GroupStart());
+  NCCL_TRY(R->Send(wire_mine, bytes, ncclUint8, root, up->comm, s));
+  NCCL_TRY(R->Send(up->my_stats, 2, ncclFloat64, root, up->comm, s));
+  NCCL_TRY(R->GroupEnd());
+  if (flags & HSAD_LINK_PARAMS) NCCL_TRY(R->Recv(params, (size_t)param_count, ncclFloat32, root, down->comm, s));
+  return HSAD_OK;
+}
+
 const double* hsad_comm_all_stats(const hsad_comm* c) { return c ? c->all_stats : nullptr; }
 
 }  // extern "C"

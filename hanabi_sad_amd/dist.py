@@ -238,22 +238,27 @@ class _Timer:
         self.marks = []
 
     def start(self):
+        """-> the marks of a new timed section (pass it to mark / stop when several sections are open at once: rounds in flight)"""
         self._flush()
         self.marks = []
         self.mark(None)
+        return self.marks
 
-    def mark(self, name):
+    def mark(self, name, marks=None):
+        marks = self.marks if marks is None else marks
         if self.cuda:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
-            self.marks.append((name, e))
+            marks.append((name, e))
         else:
             import time
-            self.marks.append((name, time.perf_counter()))
+            marks.append((name, time.perf_counter()))
 
-    def stop(self):
-        self.pending.append(self.marks)      # read later: a round still in flight is kept, not dropped
-        self.marks = []
+    def stop(self, marks=None):
+        own = marks is None
+        self.pending.append(self.marks if own else marks)      # read later: a round still in flight is kept, not dropped
+        if own:
+            self.marks = []
 
     def _flush(self):
         while self.pending:
@@ -269,6 +274,14 @@ class _Timer:
     def summary(self):
         self._flush()
         return {k: v / max(self.n, 1) for k, v in self.ms.items()}
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class ReplayLink:
@@ -319,7 +332,7 @@ class ReplayLink:
     FLAG_SLOTS = 64        # flags of round r live in key r % 64: the learner's host is never more than four rounds ahead of its own
     PARAMS, STOP, HAS_PRIO, PRIME = 1, 2, 4, 8   # exchange stream (hdr_ev below) and that stream cannot pass a round an actor has not served
 
-    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None, mode=None, name=""):
+    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None, mode=None, name="", ahead=1):
         import os
         import torch.distributed as dist
         self._keys = "hsad/link/%s" % (name + "/" if name else "")     # a second link of the same job (bench.py's A/B) has its own keys
@@ -336,25 +349,51 @@ class ReplayLink:
         self.staged = self.comm != self.device           # gloo with GPU shards (smoke runs): tensors travel through host memory
         self.store = store if store is not None else _default_store()
         star = self.mode == "star"
-        shard.set_outstanding(depth + 1 if star else depth)
+        # `ahead` (star only): how many rounds the learner keeps open at once.  With 1, round u+1 is opened when update u is issued (rounds
+        # 1-3); an actor answers a round 1.7-2.6 ms after it was opened while an update takes 1.4 ms, so the learner would wait for rows
+        # every round.  With `ahead` = 3 (the reference's prefetch depth, rela/prioritized_replay.h:229-237, selfplay.py prefetch = 3) the
+        # batch of update u was requested three updates earlier.  The priorities of a batch then travel `ahead` + 1 rounds after its draw
+        # and every shard keeps that many drawn batches (+ the one served before the write-back) outstanding.
+        self.ahead = max(1, int(ahead)) if star else 1
+        self.lag = self.ahead + 1 if star else int(depth)
+        if star and self.ahead == 1:
+            self.lag = int(depth)
+        shard.set_outstanding(self.lag + 1 if star else self.lag)
         B, wb, d = self.B, shard.wire_bytes(), self.device
+        S = self.ahead + 1 if (star and self.is_learner) else 1       # round slots of the learner: a ring, one per round in flight (+ 1)
         if star:     # canonical uniforms | priorities of an earlier batch | every shard's (sum, size) as float64 pairs
-            self.hdr = torch.zeros(2 * B + 4 * self.world, dtype=torch.float32, device=d)
-            self.all_stats = self.hdr[2 * B:].view(torch.float64).view(self.world, 2)
-            self.next_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d) if self.is_learner else None
+            self.hdrs = [torch.zeros(2 * B + 4 * self.world, dtype=torch.float32, device=d) for _ in range(S)]
+            self.stats_in = [torch.zeros(self.world, 2, dtype=torch.float64, device=d) for _ in range(S)] if self.is_learner else None
         else:
-            self.hdr = torch.zeros(2 * B, dtype=torch.float32, device=d)
+            self.hdrs = [torch.zeros(2 * B, dtype=torch.float32, device=d)]
+            self.stats_in = None
             self.all_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d)
+        self.hdr = self.hdrs[0]
+        if star:
+            self.all_stats = self.hdr[2 * B:].view(torch.float64).view(self.world, 2)
         self.wire = torch.zeros(B, wb, dtype=torch.uint8, device=d)
-        self.wire_all = torch.zeros(self.world, B, wb, dtype=torch.uint8, device=d) if self.is_learner else None
+        self.wire_alls = [torch.zeros(self.world, B, wb, dtype=torch.uint8, device=d) for _ in range(S)] if self.is_learner else None
+        self.wire_all = self.wire_alls[0] if self.is_learner else None
         self.bucket = torch.zeros(int(param_numel), dtype=torch.float32, device=d) if param_numel else None
-        self.opened = self.served = 0
+        self.opened = self.served = self.finished = 0
         cuda = d.type == "cuda"
-        self.xs = torch.cuda.Stream(d) if (cuda and self.is_learner) else None
-        self.hdr_host = [torch.zeros(B, dtype=torch.float32).pin_memory() if cuda else torch.zeros(B) for _ in range(4)]
-        self.hdr_ev = [None] * 4
-        self.timer = _Timer(d)
-        self._result = None
+        # Two communicators and two streams at the learner (star): headers and parameters go DOWN, rows and statistics come UP.  Operations
+        # on one RCCL communicator run in issue order and send / recv rendezvous; with one communicator the header of round r + 1 would
+        # queue behind the receive of round r's replies and the rounds could never overlap.  (new_group is collective: every rank builds
+        # its link at the same point of the program.)
+        self.g_down = self.g_up = None
+        if star and self.world > 1:
+            self.g_down = dist.new_group(backend=dist.get_backend())
+            self.g_up = dist.new_group(backend=dist.get_backend())
+        self.xs = torch.cuda.Stream(d) if (cuda and self.is_learner) else None            # up / the collective round
+        self.xd = torch.cuda.Stream(d) if (cuda and self.is_learner and star) else None   # down
+        self.hdr_host = [torch.zeros(B, dtype=torch.float32).pin_memory() if cuda else torch.zeros(B) for _ in range(4 + S)]
+        self.hdr_ev = [None] * (4 + S)
+        self.timer, self.timer_down = _Timer(d), _Timer(d)
+        self._rounds = []           # learner: rounds begun and not yet finished, oldest first
+        self._done_ev = {}          # round -> event on the up stream: its replies are in and unpacked
+        self._bucket_ev = None      # the last parameter send has left the bucket
+        self.wait_ms, self.wait_n = 0.0, 0
 
     # -- transport (RCCL on the GPU; host staging only for gloo with GPU shards) --
     def _bcast(self, t):
@@ -387,7 +426,7 @@ class ReplayLink:
         if self.is_learner:
             self.wire_all.copy_(torch.stack(parts))
 
-    def _p2p_begin(self, ops):
+    def _p2p_begin(self, ops, group=None):
         """ops: [("send" | "recv", tensor, peer)] -> one grouped launch (ncclGroupStart / End in RCCL: the learner's sends to and
         receives from all actors progress at once; two messages between the same pair are matched in the order given)"""
         import torch.distributed as dist
@@ -400,7 +439,7 @@ class ReplayLink:
             return host[id(t)]
         staged = [(kind, t, peer, (_h(t) if kind == "send" else torch.empty(t.shape, dtype=t.dtype)) if self.staged else t)
                   for kind, t, peer in ops]
-        works = dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer)
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend if kind == "send" else dist.irecv, buf, peer, group)
                                         for kind, _, peer, buf in staged])
         return works, staged
 
@@ -415,56 +454,136 @@ class ReplayLink:
                 if kind == "recv":
                     t.copy_(buf)
 
-    def _p2p(self, ops):
-        self._p2p_end(self._p2p_begin(ops))
+    def _p2p(self, ops, group=None):
+        self._p2p_end(self._p2p_begin(ops, group))
 
     def _round_star(self, flags):
-        """one point-to-point round (class docstring), stream-ordered on the caller's current stream"""
+        """an ACTOR's side of one point-to-point round (class docstring), stream-ordered on the caller's current stream"""
         B, L, me = self.B, self.learner, self.rank
-        if not self.is_learner:
-            if flags & self.PRIME:
-                self._p2p([("send", self.shard.stats(), L)])
-            self._p2p([("recv", self.hdr, L)])
-            self.shard.serve(self.hdr[:B], self.all_stats, me, self.wire)
-            if flags & self.HAS_PRIO:
-                self.shard.answer(self.hdr[B:2 * B], me)
-            self._p2p([("send", self.wire, L), ("send", self.shard.stats(), L)])
-            if flags & self.PARAMS:
-                self._p2p([("recv", self.bucket, L)])
-            self.served += 1
-            return None
-        t, peers = self.timer, [k for k in range(self.world) if k != L]
-        t.start()
+        assert not self.is_learner
         if flags & self.PRIME:
-            self._p2p([("recv", self.next_stats[k], k) for k in peers])
-            self.next_stats[L].copy_(self.shard.stats())
-        self.all_stats.copy_(self.next_stats)           # = the tail of the header going out
-        used = self.all_stats.clone()
-        pending = self._p2p_begin([("send", self.hdr, k) for k in peers] + [("recv", self.wire_all[k], k) for k in peers] +
-                                  [("recv", self.next_stats[k], k) for k in peers])
-        owner = self.shard.serve(self.hdr[:B], self.all_stats, me, self.wire_all[L])
+            self._p2p([("send", self.shard.stats(), L)], self.g_up)
+        self._p2p([("recv", self.hdr, L)], self.g_down)
+        self.shard.serve(self.hdr[:B], self.all_stats, me, self.wire)
         if flags & self.HAS_PRIO:
             self.shard.answer(self.hdr[B:2 * B], me)
-        self.next_stats[L].copy_(self.shard.stats())
-        t.mark("serve_ms")
-        self._p2p_end(pending)
-        t.mark("exchange_ms")
+        self._p2p([("send", self.wire, L), ("send", self.shard.stats(), L)], self.g_up)
         if flags & self.PARAMS:
-            self._p2p([("send", self.bucket, k) for k in peers])
-            t.mark("param_send_ms")
-        batch, raw_w = self.shard.assemble(self.wire_all, owner)
-        total = used[:, 0].sum().to(torch.float32)
-        n_total = used[:, 1].sum().to(torch.float32)
-        y = torch.pow(n_total * (raw_w / total), -self.beta)
-        t.mark("assemble_ms")
-        t.stop()
+            self._p2p([("recv", self.bucket, L)], self.g_down)
         self.served += 1
-        return (batch, y / y.max())
+        return None
+
+    def _star_open(self, r, flags, canon, prio):
+        """the LEARNER's side of round r, first half -- header (and parameters) out on the down stream, the receives of the replies posted
+        and the own shard served on the up stream.  Returns the round's record; `_star_collect` finishes it."""
+        B, L, me = self.B, self.learner, self.rank
+        peers = [k for k in range(self.world) if k != L]
+        S = len(self.hdrs)
+        k = r % S
+        hdr, wire_all, stats_in = self.hdrs[k], self.wire_alls[k], self.stats_in[k]
+        cur = torch.cuda.current_stream(self.device) if self.xs is not None else None
+        down = torch.cuda.stream(self.xd) if self.xd is not None else _NullCtx()
+        up = torch.cuda.stream(self.xs) if self.xs is not None else _NullCtx()
+        td, t = self.timer_down, self.timer
+        rec = {"r": r, "slot": k, "flags": flags}
+        if flags & self.PRIME:          # nobody has told the learner a (sum, size) yet: the actors send theirs first (up)
+            self.prime_stats = torch.zeros_like(stats_in)
+            with up:
+                self._p2p([("recv", self.prime_stats[p], p) for p in peers], self.g_up)
+                self.prime_stats[L].copy_(self.shard.stats())
+            if self.xd is not None:
+                self.xd.wait_stream(self.xs)
+        if self.finished == 0:          # no round collected yet (the first `ahead` rounds): what the actors said up front
+            src_stats = self.prime_stats
+        else:                           # the statistics of the newest round this host has collected (`ahead` rounds old)
+            last = self.finished - 1
+            src_stats = self.stats_in[last % S]
+            if self.xd is not None and last in self._done_ev:
+                self.xd.wait_event(self._done_ev[last])
+        with down:
+            if self.xd is not None:
+                self.xd.wait_stream(cur)          # everything issued so far: the priorities, the staged bucket
+            td.start()
+            hdr[:B].copy_(canon, non_blocking=True)
+            if self.xd is not None:
+                self.hdr_ev[r % len(self.hdr_ev)] = torch.cuda.Event()
+                self.hdr_ev[r % len(self.hdr_ev)].record()
+            if prio is not None:
+                if self.xd is not None:
+                    prio.record_stream(self.xd)   # allocated on the compute stream, read here
+                hdr[B:2 * B].copy_(prio)
+            tail = hdr[2 * B:].view(torch.float64).view(self.world, 2)
+            tail.copy_(src_stats)
+            rec["used"] = tail.clone()
+            built = None
+            if self.xd is not None:
+                built = torch.cuda.Event()
+                built.record()
+            nccl = self.xd is not None and not self.staged
+            rec["send"] = self._p2p_begin([("send", hdr, p) for p in peers], self.g_down)
+            if nccl or not peers:                 # RCCL: the down stream waits; gloo: the works are waited for when the round is collected
+                self._p2p_end(rec.pop("send"))
+            td.mark("header_send_ms")
+            if flags & self.PARAMS:
+                ps = self._p2p_begin([("send", self.bucket, p) for p in peers], self.g_down)
+                if nccl or not peers:
+                    self._p2p_end(ps)
+                    if nccl:
+                        self._bucket_ev = torch.cuda.Event()
+                        self._bucket_ev.record()
+                else:
+                    rec["psend"] = ps
+                td.mark("param_send_ms")
+            td.stop()
+        with up:
+            if self.xs is not None:
+                self.xs.wait_event(built)
+            rec["marks"] = t.start()
+            rec["recv"] = self._p2p_begin([("recv", wire_all[p], p) for p in peers] + [("recv", stats_in[p], p) for p in peers], self.g_up)
+            rec["owner"] = self.shard.serve(hdr[:B], tail, me, wire_all[L])
+            if flags & self.HAS_PRIO:
+                self.shard.answer(hdr[B:2 * B], me)
+            stats_in[L].copy_(self.shard.stats())
+            t.mark("serve_ms", rec["marks"])
+        if self.xs is not None and not self.staged:   # RCCL: the stream waits for the replies, the host does not -- the whole round is enqueued now
+            self._star_collect(rec)
+        return rec
+
+    def _star_collect(self, rec, host_wait=False):
+        """second half: replies in, rows unpacked (on the up stream; gloo: called from finish(), the host waits here)"""
+        if "result" in rec:
+            return
+        t, m = self.timer, rec.pop("marks")
+        k = rec["slot"]
+        with (torch.cuda.stream(self.xs) if self.xs is not None else _NullCtx()):
+            import time
+            t0 = time.perf_counter()
+            self._p2p_end(rec.pop("recv"))
+            for key in ("send", "psend"):
+                if key in rec:
+                    self._p2p_end(rec.pop(key))
+            if host_wait:                         # gloo: the host sat here until the last reply was in (RCCL: see finish())
+                self.wait_ms += (time.perf_counter() - t0) * 1e3
+                self.wait_n += 1
+            t.mark("exchange_ms", m)
+            batch, raw_w = self.shard.assemble(self.wire_alls[k], rec["owner"])
+            used = rec["used"]
+            total = used[:, 0].sum().to(torch.float32)
+            n_total = used[:, 1].sum().to(torch.float32)
+            y = torch.pow(n_total * (raw_w / total), -self.beta)
+            t.mark("assemble_ms", m)
+            t.stop(m)
+            if self.xs is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                self._done_ev[rec["r"]] = ev
+                self._done_ev.pop(rec["r"] - 2 * len(self.hdrs), None)
+        rec["result"] = (batch, y / y.max())
 
     # -- one round, every rank (stream-ordered on the caller's current stream) --
     def _round(self, flags):
         if self.mode == "star":
-            return self._round_star(flags)
+            return self._round_star(flags)          # (actors; the learner's side is _star_open / _star_collect)
         B, t = self.B, self.timer if self.is_learner else None
         if t:
             t.start()
@@ -503,15 +622,18 @@ class ReplayLink:
     def stage_params(self, *flats):
         """copy the parameter vectors (online, target) into the persistent bucket on the CURRENT stream; the next begin(params=True)
         broadcasts that snapshot while later updates already change the live parameters"""
+        if self._bucket_ev is not None:      # the previous snapshot may still be leaving (rounds are opened several updates ahead)
+            torch.cuda.current_stream(self.device).wait_event(self._bucket_ev)
         off = 0
         for f in flats:
             self.bucket[off:off + f.numel()].copy_(f.reshape(-1))
             off += f.numel()
 
     def begin(self, prio=None, params=False, stop=False):
-        """open a round: tell the actors (store), then run the learner's side on the exchange stream.  Call it BEFORE issuing the
-        kernels of the update that will run meanwhile; `prio` [B] = aggregated priorities of the OLDEST batch still unanswered."""
-        assert self.is_learner and self._result is None
+        """open a round: tell the actors (store), then run the learner's side on the exchange streams.  Call it BEFORE issuing the
+        kernels of the update that will run meanwhile; `prio` [B] = aggregated priorities of the OLDEST batch still unanswered.  Up to
+        `ahead` rounds may be open at once (star); finish() returns them oldest first."""
+        assert self.is_learner and len(self._rounds) < self.ahead, "ReplayLink.begin: %d rounds already open (ahead = %d)" % (len(self._rounds), self.ahead)
         flags = (self.PARAMS if params else 0) | (self.STOP if stop else 0) | (self.HAS_PRIO if prio is not None else 0)
         r = self.opened
         if r == 0 and self.mode == "star":
@@ -520,11 +642,14 @@ class ReplayLink:
         self.store.set(self._keys + "flags/%d" % (r % self.FLAG_SLOTS), "%d %d" % (r, flags))
         self.store.add(self.ROUND_KEY, 1)
         self.opened += 1
-        B, k = self.B, r % 4
+        B, k = self.B, r % len(self.hdr_host)
         canon = self.hdr_host[k]
         if self.hdr_ev[k] is not None and not self.hdr_ev[k].query():
-            self.hdr_ev[k].synchronize()          # the copy that last read this pinned slot (four rounds ago) -- normally long done
+            self.hdr_ev[k].synchronize()          # the copy that last read this pinned slot (several rounds ago) -- normally long done
         canon.copy_(torch.from_numpy(self.shard.draw_canonical(B)))
+        if self.mode == "star":
+            self._rounds.append(self._star_open(r, flags, canon, prio))
+            return
         if self.xs is not None:
             self.xs.wait_stream(torch.cuda.current_stream(self.device))   # everything issued so far (the priorities, the staged bucket)
             with torch.cuda.stream(self.xs):
@@ -534,23 +659,43 @@ class ReplayLink:
                 if prio is not None:
                     prio.record_stream(self.xs)           # allocated on the compute stream, read here
                     self.hdr[B:2 * B].copy_(prio)
-                self._result = self._round(flags)
+                self._rounds.append({"r": r, "result": self._round(flags)})
         else:
             self.hdr[:B].copy_(canon)
             if prio is not None:
                 self.hdr[B:2 * B].copy_(prio)
-            self._result = self._round(flags)
+            self._rounds.append({"r": r, "result": self._round(flags)})
 
     def finish(self):
-        """-> ((fields, reward, terminal, bootstrap, seq_len), weight) of the round opened by the last begin(); the current stream
-        waits for the exchange stream, the host does not"""
-        res, self._result = self._result, None
+        """-> ((fields, reward, terminal, bootstrap, seq_len), weight) of the OLDEST open round; the current stream waits for the
+        exchange stream, the host does not (gloo: the host waits for the replies here).  `wait_for_batch_ms` in timings() is how long
+        that wait was: zero when the round was opened early enough."""
+        rec = self._rounds.pop(0)
+        if self.mode == "star" and "result" not in rec:
+            self._star_collect(rec, host_wait=True)
+        res = rec["result"]
+        self.finished += 1
         if self.xs is not None:
             cur = torch.cuda.current_stream(self.device)
-            cur.wait_stream(self.xs)
+            ev = self._done_ev.get(rec["r"]) if self.mode == "star" else None
+            if ev is not None:
+                # how long the compute stream will sit in front of this batch: the event pair (arrival on the compute stream, replies
+                # unpacked on the up stream) is read one call later, when both have certainly happened
+                here = torch.cuda.Event(enable_timing=True)
+                here.record(cur)
+                self._wait_probe = getattr(self, "_wait_probe", [])
+                self._wait_probe.append((here, ev))
+                while self._wait_probe and self._wait_probe[0][0].query() and self._wait_probe[0][1].query():
+                    h, e = self._wait_probe.pop(0)
+                    self.wait_ms += max(0.0, h.elapsed_time(e))
+                    self.wait_n += 1
+                cur.wait_event(ev)
+            else:
+                cur.wait_stream(self.xs)
             (f, reward, terminal, bootstrap, seq_len), w = res
             for x in list(f.values()) + [reward, terminal, bootstrap, seq_len, w]:
-                x.record_stream(cur)
+                if x is not None:
+                    x.record_stream(cur)
         return res
 
     # -- actors --
@@ -582,4 +727,9 @@ class ReplayLink:
         return bool(flags & self.STOP)
 
     def timings(self):
-        return self.timer.summary()
+        out = self.timer.summary()
+        out.update(self.timer_down.summary())
+        out.setdefault("param_send_ms", 0.0)
+        out["wait_for_batch_ms"] = self.wait_ms / max(self.wait_n, 1)
+        out["rounds_ahead"] = self.ahead
+        return out

@@ -234,6 +234,8 @@ def parse_args(argv=None):
                         "reference's arithmetic type, for validation: ~20x slower)")
     p.add_argument("--python_schedule", type=int, default=0, help="1 = drive the bf16 kernels from r2d2.py instead of the "
                    "library's composite entry points (same kernels, same order; for A/B tests)")
+    p.add_argument("--rounds_ahead", type=int, default=3, help="multi-GPU: how many exchange rounds the learner keeps open (a batch is requested "
+                   "this many updates before it is trained on; the reference's replay prefetch, selfplay.py prefetch = 3)")
     p.add_argument("--dist_backend", type=str, default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (smoke runs "
                    "with several ranks sharing a GPU: tensors are staged through host memory)")
     args = p.parse_args(argv)
@@ -252,7 +254,10 @@ def parse_args(argv=None):
 def make_link(tr, args):
     from .dist import ReplayLink
     n = tr.act_online.flat.numel() if hasattr(tr.act_online, "flat") else sum(v.numel() for v in tr.act_online.w.values())
-    return ReplayLink(tr.replay, args.batchsize, args.priority_weight, tr.device, learner_rank=0, depth=2, param_numel=2 * n)
+    # rounds are opened `rounds_ahead` updates before their batch is trained on (the reference's sampler prefetches 3 batches the same way:
+    # selfplay.py prefetch = 3, rela/prioritized_replay.h:229-237): an actor answers a round 1.7-2.6 ms after it was opened, an update takes 1.4
+    return ReplayLink(tr.replay, args.batchsize, args.priority_weight, tr.device, learner_rank=0, param_numel=2 * n,
+                      ahead=max(1, int(getattr(args, "rounds_ahead", 3))))
 
 
 def _flat_of(net):
@@ -313,7 +318,8 @@ def run_link_learner(tr, args, link, num_update, on_update=None, stop=True):
     first = tr.num_update == 0
     if first:
         link.stage_params(_flat_of(L.online), _flat_of(L.target))
-        link.begin(None, params=True)
+        for i in range(link.ahead):               # the batches of the first `ahead` updates are requested up front
+            link.begin(None, params=(i == 0))
         tr._cur, tr._prios = link.finish(), []
     for u in range(num_update):
         if tr.num_update % a.num_update_between_sync == 0:
@@ -331,6 +337,8 @@ def run_link_learner(tr, args, link, num_update, on_update=None, stop=True):
         tr._cur = link.finish()
         tr.num_update += 1
     if stop:
+        while link._rounds:                       # batches requested ahead that will not be trained on any more
+            link.finish()
         link.begin(tr._prios.pop(0) if tr._prios else None, stop=True)
         link.finish()
     torch.cuda.synchronize()

@@ -779,6 +779,23 @@ int hsad_comm_scatter_priority(hsad_comm* comm, hsad_replay* shard, int batch, c
 #define HSAD_LINK_PRIME 8
 int hsad_comm_star_round(hsad_comm* comm, hsad_replay* shard, int batch, float* hdr, int flags, int root, const int32_t* answer_owner,
                          int32_t* owner_out, uint8_t* wire_mine, uint8_t* wire_all, float* params, int64_t param_count, void* stream);
+/* The same round in two halves, so that rounds OVERLAP: the learner opens a round `ahead` updates before it trains on its batch (the
+ * reference's sampler prefetches like that: rela/prioritized_replay.h:229-237, pyhanabi/selfplay.py prefetch = 3).  The root drives two
+ * communicators -- `down` for headers and parameters, `up` for rows and statistics -- on two streams (on one communicator the header of
+ * round r + 1 would queue behind the receive of round r's replies) and a ring of per-round buffers (hdr, owner_out, wire_all,
+ * stats_reply); hsad_replay_set_outstanding(ahead + 2).
+ *   hsad_comm_star_open     root: statistics (stats_known: the stats_reply of the newest round the host has collected; HSAD_LINK_PRIME:
+ *                           collected into stats_prime first) -> header tail, header (and parameters) to every rank on `down`
+ *   hsad_comm_star_collect  root, right behind it: receives posted on `up`, own shard served, its statistics into stats_reply[root];
+ *                           when stream_up has passed this call, wire_all is ready for hsad_replay_assemble
+ *   hsad_comm_star_serve    every other rank, on its own stream: [PRIME: statistics up] header in (down) -> serve -> late priorities ->
+ *                           rows + statistics up -> [PARAMS: parameters in (down)] */
+int hsad_comm_star_open(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, const double* stats_known,
+                        double* stats_prime, float* params, int64_t param_count, void* stream_down, void* stream_up);
+int hsad_comm_star_collect(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, const int32_t* answer_owner,
+                           int32_t* owner_out, uint8_t* wire_all, double* stats_reply, void* stream_down, void* stream_up);
+int hsad_comm_star_serve(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, int root,
+                         const int32_t* answer_owner, int32_t* owner_out, uint8_t* wire_mine, float* params, int64_t param_count, void* stream);
 const double* hsad_comm_all_stats(const hsad_comm* comm);   /* device [world][2] (sum, size) of the last gather: the importance weights' N and sum */
 
 /* ------------------------------------------------------------------------------------------

@@ -168,3 +168,100 @@ def test_replay_link_rounds_gloo(tmp_path, sizes, mode, grow):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert all((tmp_path / ("link%d.ok" % r)).exists() for r in range(len(sizes)))
+
+
+PIPE_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from hanabi_sad_amd.dist import ReplayLink, rank_world, split_positions, stratified_positions
+exec(open(%(host_shard)r).read())                     # ALPHA, BETA, B, SIZES, initial(), HostShard: the stand-in shard of the test above
+
+AHEAD, UPDATES, UPDATE_S, DELAY_S = %(ahead)d, 40, 0.002, 0.003
+rank, world = rank_world()
+dist.init_process_group("gloo", rank=rank, world_size=world)
+NP = 64
+link = ReplayLink(HostShard(rank), B, BETA, "cpu", learner_rank=0, param_numel=NP, mode="star", ahead=AHEAD)
+assert link.ahead == AHEAD and link.shard.depth == AHEAD + 2       # drawn batches a shard keeps: `ahead` + 1 in flight + the one served before the write-back
+if rank == 0:
+    model = [initial(k) for k in range(world)]
+    sent, prios, answered = [], [], 0
+    link.stage_params(torch.arange(NP // 2, dtype=torch.float32), torch.arange(NP // 2, dtype=torch.float32) + 0.5)
+    for i in range(AHEAD):                             # selfplay.run_link_learner: `ahead` rounds are opened before the first update
+        link.begin(None, params=(i == 0))
+    cur = link.finish()
+    link.wait_ms, link.wait_n = 0.0, 0                 # (the very first batch has nothing to hide behind)
+    for u in range(UPDATES):
+        p = prios.pop(0) if prios else None
+        if p is not None:
+            sent.append(p)
+        link.begin(None if p is None else torch.tensor(p[1]), stop=False)
+        (f, *_), weight = cur
+        got = f["tag"].numpy()
+        w = weight.numpy()
+        assert np.all(np.isfinite(w)) and np.all(w > 0) and abs(float(w.max()) - 1.0) < 1e-6
+        assert all(0 <= int(t) %% 1000 < SIZES[int(t) // 1000] for t in got), got
+        time.sleep(UPDATE_S)                           # "update u runs here"
+        prios.append((got, (got %% 7 + 0.5 + u).astype(np.float32)))
+        cur = link.finish()
+    wait = link.timings()["wait_for_batch_ms"]
+    while link._rounds:                                # the rounds still open are collected, then everybody stops
+        link.finish()
+    link.begin(None, stop=True)
+    link.finish()
+    for tags, pr in sent:                              # what the shards must hold now: every priority that was SENT, in sending order
+        for t, p in zip(tags, pr):
+            model[int(t) // 1000][int(t) %% 1000] = np.float32(p) ** np.float32(ALPHA)
+    final = torch.from_numpy(np.concatenate(model))
+    open(os.path.join(%(out)r, "wait_ahead%%d.txt" %% AHEAD), "w").write("%%f" %% wait)
+else:
+    notice, n_step = [], 0
+    while True:
+        link.poll()
+        now = time.perf_counter()
+        while len(notice) < getattr(link, "_known_open", 0):
+            notice.append(now)                          # a round is NOTICED now and answered DELAY_S later: pure latency (queued steps in
+        if link.served < len(notice) and now >= notice[link.served] + DELAY_S:     # front of it), rounds behind it are served back to back
+            flags = link.poll()
+            assert flags is not None
+            if link.serve(flags):
+                break
+            continue
+        n_step += 1
+        time.sleep(0.0002)                              # an actor step would run here
+    assert n_step > UPDATES
+    final = torch.empty(sum(SIZES), dtype=torch.float32)
+dist.broadcast(final, src=0)
+lo = sum(SIZES[:rank])
+assert np.array_equal(link.shard.w, final.numpy()[lo:lo + SIZES[rank]]), rank     # late priorities landed on exactly the owned elements
+dist.barrier()
+dist.destroy_process_group()
+open(os.path.join(%(out)r, "pipe%%d.ok" %% rank), "w").write("ok")
+'''
+
+
+def test_rounds_opened_three_updates_ahead_hide_the_actors_reply_latency(tmp_path):
+    """VERDICT r3 item 7: an actor answers a round some milliseconds after it was opened (a notice + the steps queued in front of it)
+    while an update takes less.  Three ranks over gloo, actors that answer every round 3 ms late, 2 ms updates: with rounds opened ONE
+    update ahead the learner waits for rows every round; opened THREE ahead (the reference's prefetch depth) the wait disappears --
+    and every late priority still reaches exactly the element it was drawn from (priorities now travel four rounds after their draw,
+    shards keep five drawn batches)."""
+    sizes = [0, 30, 25]
+    shard_src = tmp_path / "host_shard.py"
+    head = WORKER.split("rank, world = rank_world()")[0].split("ALPHA, BETA, B, ROUNDS")[1]
+    shard_src.write_text(("ALPHA, BETA, B, ROUNDS" + head) % {"sizes": sizes, "mode": "star", "grow": 0, "root": ROOT, "out": str(tmp_path)})
+    waits = {}
+    for ahead in (1, 3):
+        script = tmp_path / ("pipe%d.py" % ahead)
+        script.write_text(PIPE_WORKER % {"root": ROOT, "out": str(tmp_path), "ahead": ahead, "host_shard": str(shard_src)})
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), str(script)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        assert all((tmp_path / ("pipe%d.ok" % r)).exists() for r in range(3))
+        for r in range(3):
+            (tmp_path / ("pipe%d.ok" % r)).unlink()
+        waits[ahead] = float((tmp_path / ("wait_ahead%d.txt" % ahead)).read_text())
+    # one round ahead: ~ latency - update >= 1 ms of waiting per round; three ahead: the reply has been in for a whole update
+    assert waits[1] > 0.6, waits
+    assert waits[3] < 0.35 * waits[1] and waits[3] < 0.5, waits

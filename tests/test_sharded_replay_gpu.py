@@ -377,3 +377,93 @@ def test_hsad_comm_c_entry_points_single_rank():
         shard.check_errors()
     finally:
         lib.hsad_comm_destroy(comm)
+
+
+def test_pipelined_star_round_halves_over_two_communicators_single_rank():
+    """hsad_comm_star_open / _collect (the star round in two halves, for rounds that overlap: ReplayLink(ahead = 3) for a non-Python host)
+    over TWO real RCCL communicators and two streams, three rounds open at once.  A world of one has no peers, so what runs is the
+    root's own part: statistics of an EARLIER round in the header, own shard served from them (share stretched onto the present sum),
+    late priorities written back four rounds after their draw.  Dyadic priorities, alpha = 1: the shard's weight sum must equal a host
+    model that applies every answered batch to the elements the assembled batches named."""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.replay import DeviceReplay
+    lib = _lib.load_library()
+    comms = []
+    for _ in range(2):
+        uid = (C.c_char * 256)()
+        _lib.check(lib.hsad_comm_unique_id(uid, 256))
+        c = C.c_void_p()
+        _lib.check(lib.hsad_comm_init(uid, 0, 1, torch.cuda.current_device(), C.byref(c)))
+        comms.append(c)
+    down, up = comms
+    try:
+        B, AHEAD, PRIME, HAS_PRIO = 16, 3, 8, 4
+        S = AHEAD + 1
+        rng = np.random.default_rng(4)
+        shard = DeviceReplay(64, 5, 1.0, 0.6, 0, T, FIELDS, DEV)
+        rows = list(make_rows(rng, 40, 0))
+        w = (rng.integers(1, 64, 40) / 16.0).astype(np.float32)
+        rows[5] = torch.tensor(w, device=DEV)
+        shard.add(*rows)
+        shard.set_outstanding(AHEAD + 2)
+        model = w.astype(np.float64).copy()
+        wb = shard.wire_bytes()
+        sd, su = torch.cuda.Stream(), torch.cuda.Stream()
+        hdrs = [torch.zeros(2 * B + 4, dtype=torch.float32, device=DEV) for _ in range(S)]
+        wires = [torch.zeros(1, B, wb, dtype=torch.uint8, device=DEV) for _ in range(S)]
+        replies = [torch.zeros(1, 2, dtype=torch.float64, device=DEV) for _ in range(S)]
+        prime = torch.zeros(1, 2, dtype=torch.float64, device=DEV)
+        owners, prios, tags, done, sums_at_reply = {}, {}, {}, {}, {}
+        collected = 0
+        torch.cuda.synchronize()
+
+        def open_round(r, answered):
+            k = r % S
+            hdrs[k][:B] = torch.tensor(shard.draw_canonical(B), device=DEV)
+            flags = PRIME if r == 0 else 0
+            if answered is not None:
+                hdrs[k][B:2 * B] = prios[answered]
+                flags |= HAS_PRIO
+            sd.wait_stream(torch.cuda.current_stream())
+            known = replies[(collected - 1) % S].data_ptr() if collected else prime.data_ptr()
+            owners[r] = torch.empty(B, dtype=torch.int32, device=DEV)
+            _lib.check(lib.hsad_comm_star_open(down, up, shard.h, B, hdrs[k].data_ptr(), flags, None if r == 0 else known, prime.data_ptr(),
+                                               None, 0, sd.cuda_stream, su.cuda_stream))
+            _lib.check(lib.hsad_comm_star_collect(down, up, shard.h, B, hdrs[k].data_ptr(), flags,
+                                                  owners[answered].data_ptr() if answered is not None else None, owners[r].data_ptr(),
+                                                  wires[k].data_ptr(), replies[k].data_ptr(), sd.cuda_stream, su.cuda_stream))
+            done[r] = torch.cuda.Event()
+            done[r].record(su)
+
+        for r in range(AHEAD):
+            open_round(r, None)
+        for u in range(8):
+            torch.cuda.current_stream().wait_event(done[u])
+            (f, *_), raw_w = shard.assemble(wires[u % S], owners[u])
+            tags[u] = f["a"][0, :, 0].cpu().numpy()
+            assert (owners[u] == 0).all() and tags[u].min() >= 0 and tags[u].max() < 40
+            st = hdrs[u % S][2 * B:].view(torch.float64).cpu().numpy()
+            assert st[1] == 40.0 and st[0] > 0                                   # the header carried a shard's (sum, size)
+            sums_at_reply[u] = float(replies[u % S][0, 0])
+            collected = u + 1
+            prios[u] = torch.tensor((rng.integers(1, 64, B) / 16.0).astype(np.float32), device=DEV)
+            open_round(u + AHEAD, u - 1 if u >= 1 else None)                      # batch u - 1's priorities leave with round u + AHEAD
+        torch.cuda.synchronize()
+        shard.check_errors()
+        # answered: batches 0 .. 6, in that order, each AFTER the draw of the round that carried it
+        for b in range(7):
+            for i, p in zip(tags[b], prios[b].cpu().numpy()):
+                model[int(i)] = float(p)
+        assert shard.priority_sum()[0] == float(model.sum())
+        # the statistics a reply reports are the shard's sum at that moment: round r answered batch r - AHEAD - 1
+        m = w.astype(np.float64).copy()
+        for r in range(8):
+            b = r - AHEAD - 1
+            if b >= 0:
+                for i, p in zip(tags[b], prios[b].cpu().numpy()):
+                    m[int(i)] = float(p)
+            assert sums_at_reply[r] == float(m.sum()), r
+    finally:
+        for c in comms:
+            lib.hsad_comm_destroy(c)
