@@ -35,7 +35,7 @@ namespace {
 
 constexpr int kMaxFields = 16;
 constexpr int kMaxBatch = 1024;
-constexpr int kMaxOutstanding = 4;  // = the size of ReplayCtl::q_n
+constexpr int kMaxOutstanding = 8;  // = the size of ReplayCtl::q_n (rounds opened 3-4 updates ahead keep 5-6 draws outstanding)
 
 int rfail(int code, const char* fmt, ...) {
   char buf[512];
@@ -440,7 +440,7 @@ struct ReplayCtl {
   // drawn batches whose priorities have not come back yet, oldest first (the reference's prefetch queue hands out up to
   // `prefetch` batches drawn before the priorities of the batches in training are written back: prioritized_replay.h:232-262)
   int q_head, q_count;
-  int q_n[4];
+  int q_n[kMaxOutstanding];
   int err_kind;   // OR of: 1 add larger than the ring, 2 draw beyond the weight sum, 4 update without a matching draw, 8 writer / packing
 };
 

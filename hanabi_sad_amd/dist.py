@@ -364,6 +364,7 @@ class ReplayLink:
         if star:     # canonical uniforms | priorities of an earlier batch | every shard's (sum, size) as float64 pairs
             self.hdrs = [torch.zeros(2 * B + 4 * self.world, dtype=torch.float32, device=d) for _ in range(S)]
             self.stats_in = [torch.zeros(self.world, 2, dtype=torch.float64, device=d) for _ in range(S)] if self.is_learner else None
+            self.prime_stats = torch.zeros(self.world, 2, dtype=torch.float64, device=d) if self.is_learner else None
         else:
             self.hdrs = [torch.zeros(2 * B, dtype=torch.float32, device=d)]
             self.stats_in = None
@@ -487,7 +488,8 @@ class ReplayLink:
         td, t = self.timer_down, self.timer
         rec = {"r": r, "slot": k, "flags": flags}
         if flags & self.PRIME:          # nobody has told the learner a (sum, size) yet: the actors send theirs first (up)
-            self.prime_stats = torch.zeros_like(stats_in)
+            if self.xs is not None:
+                self.xs.wait_stream(cur)          # (buffers of this link were zero-filled on the caller's stream)
             with up:
                 self._p2p([("recv", self.prime_stats[p], p) for p in peers], self.g_up)
                 self.prime_stats[L].copy_(self.shard.stats())

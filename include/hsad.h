@@ -268,7 +268,7 @@ int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const doubl
 int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, const int32_t* owner, int rank, void* stream);
 int hsad_replay_assemble(hsad_replay* r, int batch, int world, const uint8_t* wire_all, const int32_t* owner, void* const* out_fields,
                          float* reward, uint8_t* terminal, float* bootstrap, float* seq_len, float* raw_weight, void* stream);
-/* Drawn batches that may wait for their priorities at once (1..4, default 1 = strict alternation).  The reference's
+/* Drawn batches that may wait for their priorities at once (1..8, default 1 = strict alternation).  The reference's
  * prefetch queue (prioritized_replay.h:232-262, prefetch = 3 in selfplay.py) draws up to `prefetch` batches before the
  * priorities of the batches in training are written back; with depth k, hsad_replay_update_priority answers the OLDEST
  * outstanding draw, and elements evicted since their draw are skipped as in ConcurrentQueue::update.  A draw into a full
