@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "hsad.h"
+#include "hsad_stream_fence.h"
 
 extern "C" int hsad_internal_set_error(int code, const char* msg);
 
@@ -1048,92 +1049,21 @@ __global__ void seq_reset_finished_kernel(SeqDev sd, ReplayCtl* ctl, int* w_err)
 
 }  // namespace
 
-// Ordering across streams without the caller's help.  The flush of finished sequences may be issued on a side stream (the actor loop
-// overlaps its single-workgroup scans with the next step's network passes) while the object's other operations -- push, add, sample,
-// serve, update_priority ... ("consumers") -- arrive on the actor's main stream, a learner's compute stream, an exchange stream:
-//   * flush -> consumers: arm() records an event per flush (a new GENERATION); every consumer stream waits for the current generation
-//     ONCE (pass(): a small per-stream table, so a second and third consumer stream are ordered behind the flush, too);
-//   * consumers -> next flush: FenceUse (RAII, at the top of every consumer entry point) records a per-stream event when the
-//     operation has been enqueued; begin_flush() makes the flush's stream wait for every such event recorded since the last flush.
-// Operations on the flush's own stream need neither (stream order).
-struct StreamFence {
-  // No limit on the number of distinct streams (every non-coalesced thread loop flushes on a side stream of its own, and stream
-  // handles are recreated over a long-lived replay).  Both tables only ever hold what the CURRENT generation needs: the seen table is
-  // emptied by every arm() (an entry of an older generation means the same as no entry: "wait for the current flush"), and a consumer
-  // slot whose event the last flush has waited for is reused for whichever stream comes next.  (What stays undetectable: a stream
-  // destroyed and re-created with the same handle value between two flushes inherits the old stream's "has waited" mark.)
-  struct Cons { hipStream_t s; hipEvent_t ev; bool dirty; };
-  hipEvent_t ev = nullptr;
-  hipStream_t stream = nullptr;
-  uint64_t gen = 0;
-  std::vector<hipStream_t> seen;            // streams that already wait for generation `gen`
-  std::vector<Cons> cons;
-  std::mutex mu;                            // the rollout thread (rela.Context) and the training thread enter the same replay
-  hipError_t arm(hipStream_t s) {           // the flush has been enqueued on s
-    std::lock_guard<std::mutex> g(mu);
-    if (!ev) {
-      hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-      if (e != hipSuccess) return e;
-    }
-    stream = s;
-    ++gen;
-    seen.clear();
-    return hipEventRecord(ev, s);
-  }
-  hipError_t pass(hipStream_t s) {          // an operation is about to be enqueued on s: order it behind the current flush, once per stream
-    std::lock_guard<std::mutex> g(mu);
-    if (!gen || s == stream) return hipSuccess;
-    for (hipStream_t t : seen)
-      if (t == s) return hipSuccess;
-    hipError_t e = hipStreamWaitEvent(s, ev, 0);
-    if (e == hipSuccess) seen.push_back(s);
-    return e;
-  }
-  hipError_t begin_flush(hipStream_t s) {   // a flush is about to be enqueued on s: behind every consumer operation on other streams since the last one
-    std::lock_guard<std::mutex> g(mu);
-    for (Cons& c : cons)
-      if (c.dirty && c.s != s) {
-        hipError_t e = hipStreamWaitEvent(s, c.ev, 0);
-        if (e != hipSuccess) return e;
-        c.dirty = false;
-      }
-    return hipSuccess;
-  }
-  void consumed(hipStream_t s) {            // a consumer operation has been enqueued on s
-    std::lock_guard<std::mutex> g(mu);
-    if (gen && s == stream) return;         // the flush stream itself: stream order
-    Cons* k = nullptr;
-    for (Cons& c : cons)
-      if (c.s == s) k = &c;
-    if (!k)
-      for (Cons& c : cons)
-        if (!c.dirty) { k = &c; break; }    // a slot the last flush is already ordered behind: its event is free to be re-recorded
-    if (!k) {
-      hipEvent_t e = nullptr;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return;
-      cons.push_back(Cons{s, e, false});
-      k = &cons.back();
-    }
-    k->s = s;
-    k->dirty = hipEventRecord(k->ev, s) == hipSuccess;
-  }
-  void destroy() {
-    if (ev) (void)hipEventDestroy(ev);
-    ev = nullptr;
-    for (Cons& c : cons) (void)hipEventDestroy(c.ev);
-    cons.clear();
-    seen.clear();
-  }
+// Ordering across streams and host threads without the caller's help: csrc/hsad_stream_fence.h (compiled here against HIP, and against
+// a logical-clock model of streams under ThreadSanitizer by the CPU test suite).
+struct HipFenceRuntime {
+  using stream_t = hipStream_t;
+  using event_t = hipEvent_t;
+  using error_t = hipError_t;
+  static constexpr hipError_t ok = hipSuccess;
+  static hipError_t event_create(hipEvent_t* e) { return hipEventCreateWithFlags(e, hipEventDisableTiming); }
+  static hipError_t event_record(hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s); }
+  static hipError_t stream_wait_event(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0); }
+  static void event_destroy(hipEvent_t e) { (void)hipEventDestroy(e); }
 };
-struct FenceUse {      // `FenceUse use(obj->fence, stream);` after the arguments were validated: pass() now, consumed() when the entry point returns
-  StreamFence& f;
-  hipStream_t s;
-  hipError_t err;
-  FenceUse(StreamFence& fence, hipStream_t stream) : f(fence), s(stream), err(fence.pass(stream)) {}
-  ~FenceUse() {
-    if (err == hipSuccess) f.consumed(s);
-  }
-};
+using StreamFence = StreamFenceT<HipFenceRuntime>;
+using FenceUse = FenceUseT<HipFenceRuntime>;
+using FlushUse = FlushUseT<HipFenceRuntime>;
 
 // ===================================================================================================
 struct hsad_replay {
@@ -1705,10 +1635,10 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
     return rfail(HSAD_ERR_INVALID, "sequence writer and replay were created with different layouts");
   hipStream_t s = (hipStream_t)stream;
   r->last_stream = s;
-  HIP_TRY(w->fence.pass(s));           // behind the previous flush ...
-  HIP_TRY(r->fence.pass(s));
-  HIP_TRY(w->fence.begin_flush(s));    // ... and behind every push / add / sample / serve / update issued on another stream since
-  HIP_TRY(r->fence.begin_flush(s));
+  // both objects' guards for the whole flush; behind the previous flush and behind every push / add / sample / serve / update issued on
+  // another stream (by this or another host thread) since
+  FlushUse flush(&w->fence, &r->fence, s);
+  HIP_TRY(flush.begin());
   const SeqDev& sd = w->sd;
   const float c1m = (float)(1.0 - (double)eta);
   hipLaunchKernelGGL(seq_collect_kernel, dim3(1), dim3(1024), 0, s, sd, eta, c1m, n_finished_dev);
@@ -1719,8 +1649,7 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   hipLaunchKernelGGL(seq_reset_finished_kernel, dim3((sd.E + 255) / 256), dim3(256), 0, s, sd, r->rd.ctl, w->d_err);
   HIP_TRY(hipGetLastError());
   // whoever touches the writer's cursors or the replay next, on whatever stream, is ordered behind this flush
-  HIP_TRY(w->fence.arm(s));
-  HIP_TRY(r->fence.arm(s));
+  HIP_TRY(flush.arm());
   return HSAD_OK;
 }
 

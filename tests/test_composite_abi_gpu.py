@@ -419,3 +419,69 @@ def test_fused_recurrences_next_to_foreign_work_on_another_stream():
     torch.cuda.synchronize()
     assert int(bad) == 0
     L.check_sync()
+
+
+@pytest.mark.timeout(180)
+def test_fused_recurrences_stress_ten_seconds_of_randomly_timed_foreign_kernels():
+    """the spin protocols of the persistent fused launches (all-or-nothing co-residency, bounded spins, sticky timeout)
+    under a co-tenant that is NOT phase-locked to them: a host thread issues full-chip kernels of random kind (8192^2 matmuls ~1 ms, 1 GB
+    fills, bursts of small launches) on two other streams at random intervals for >= 10 s while full-size loss evaluations (forward
+    launch: 256 workgroups x 80 steps, four-stage BPTT launch: 256 x 80) run back to back.  Every evaluation must reproduce the quiet
+    evaluation's loss, priorities and LSTM weight gradients bit for bit, and hsad_lstm_sync_timed_out() must stay 0."""
+    import random
+    import threading
+    import time
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    F, A, H, T, B = 838, 21, 512, 80, 128
+    W, Wt = _rand_net(F, H, A, seed=41), _rand_net(F, H, A, seed=42)
+    batch, weight = _rand_batch(T, B, F, A, seed=7)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    loss, prio = L.loss(batch, weight, 0.25)
+    ref = (loss.clone(), prio.clone(), L.grad["lstm.weight_hh_l0"].clone(), L.grad["lstm.weight_ih_l1"].clone())
+    torch.cuda.synchronize()
+    stop, issued = threading.Event(), [0]
+
+    def foreign():
+        rnd = random.Random(1234)
+        streams = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+        a = torch.randn(8192, 8192, device=DEV, dtype=torch.bfloat16)
+        big = torch.empty(1 << 28, device=DEV)                      # 1 GiB
+        small = torch.zeros(4096, device=DEV)
+        while not stop.is_set():
+            with torch.cuda.stream(streams[rnd.randrange(2)]):
+                kind = rnd.randrange(4)
+                if kind == 0:
+                    for _ in range(rnd.randrange(1, 4)):
+                        a @ a
+                elif kind == 1:
+                    big.fill_(rnd.random())
+                elif kind == 2:
+                    for _ in range(rnd.randrange(5, 40)):
+                        small.add_(1.0)
+                else:
+                    (a[:2048] @ a).relu_()
+            issued[0] += 1
+            time.sleep(rnd.random() * 0.003)
+            if issued[0] % 64 == 0:
+                for st in streams:
+                    st.synchronize()                                 # (bounds the queue depth of the foreign streams)
+
+    th = threading.Thread(target=foreign, daemon=True)
+    th.start()
+    bad = torch.zeros((), dtype=torch.int64, device=DEV)
+    t0, evals = time.time(), 0
+    try:
+        while time.time() - t0 < 10.5:
+            for _ in range(20):
+                loss, prio = L.loss(batch, weight, 0.25)
+                for x, y in zip((loss, prio, L.grad["lstm.weight_hh_l0"], L.grad["lstm.weight_ih_l1"]), ref):
+                    bad += (x != y).any()
+                evals += 1
+            torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join()
+    torch.cuda.synchronize()
+    assert int(bad) == 0 and evals >= 200 and issued[0] >= 500, (int(bad), evals, issued[0])
+    L.check_sync()                                                   # hsad_lstm_sync_timed_out() == 0
