@@ -104,7 +104,7 @@ def mfma_counters():
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
             continue
-        gui = "mfma_busy_frac_if_gui_is_per_chip"
+        gui = "mfma_busy_frac_if_gui_is_summed_over_8_xcds"      # (what the calibration leg of tools/mfma_util.sh shows GRBM_GUI_ACTIVE to be)
         out = {}
         for leg in ("learner", "actor"):
             for k, r in rec.get(leg, {}).items():
