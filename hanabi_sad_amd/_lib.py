@@ -137,6 +137,8 @@ SIGNATURES = {
     "hsad_seqwriter_can_pop": (C.c_int, [_P]),
     "hsad_seqwriter_pop_transition": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P]),
     "hsad_seqwriter_push_sequence": (C.c_int, [_P, _P, _P]),
+    "hsad_seqwriter_step_tail": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_double, _P, _P, _P, _P]),
+    "hsad_seqwriter_step_tail_ready": (C.c_int, [_P]),
     "hsad_seqwriter_flush_to_replay": (C.c_int, [_P, _P, C.c_float, _P, _P]),
     "hsad_gemm_nt_bf16": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
                                     C.c_int, C.c_int, _P]),

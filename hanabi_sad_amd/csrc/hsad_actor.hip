@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -91,6 +92,7 @@ struct hsad_actor {
   hipEvent_t ev_main = nullptr, ev_reset = nullptr, ev_flush = nullptr;
   // hsad_actor_set_run_ahead: the host may be at most `run_ahead` steps ahead of the device (0 = unbounded)
   int run_ahead = 0;
+  bool fuse_tail = getenv("HSAD_ACTOR_FUSE_TAIL") ? atoi(getenv("HSAD_ACTOR_FUSE_TAIL")) != 0 : true;      // developer switch (A/B)
   hipEvent_t ev_step[8] = {};
 };
 
@@ -266,6 +268,25 @@ int hsad_actor_step(hsad_actor* ac, void* stream) {
   ac->reset_pending = true;
   ac->num_act += N;
   ac->step_no += 1;
+  // the per-env tail of the iteration -- reward / terminal push, n-step pop, priority from the cached Q-values, sequence push -- is ONE launch
+  // (hsad_seqwriter_step_tail) whenever the window is full, the cached Q_online is current and no sum over players is needed; the four
+  // separate entry points below remain for the first n steps, VDN, and the step after a weight sync
+  const int old_slot = (nxt + ac->nslot - 1 - n) % ac->nslot;       // the slot that entered act() n steps ago
+  const bool one_launch = ac->fuse_tail && !(ac->vdn && P > 1) && hsad_seqwriter_step_tail_ready(ac->writer) &&
+                          ac->qversion[old_slot] == hsad_r2d2_net_version(ac->online);
+  if (one_launch) {
+    CK(hsad_seqwriter_step_tail(ac->writer, ac->io.reward, ac->io.terminal, ac->vdn ? 1 : P, ac->qring[old_slot], ac->tq, n, (double)ac->gamma, ac->prio,
+                                ac->rew, ac->boot, stream));
+    CK(hsad_zero_state_rows(ac->h[nxt], ac->c[nxt], ac->fused_state ? ac->h16[nxt] : nullptr, ac->io.terminal, L, N, Hd, P, stream));
+    ac->cur = nxt;
+    ac->pushed = true;
+    HIP_TRY(hipEventRecord(ac->ev_flush, s));
+    HIP_TRY(hipStreamWaitEvent(ac->side_flush, ac->ev_flush, 0));
+    CK(hsad_seqwriter_flush_to_replay(ac->writer, ac->replay, ac->eta, ac->n_finished, (void*)ac->side_flush));
+    HIP_TRY(hipStreamWaitEvent(s, ac->ev_reset, 0));
+    if (ac->run_ahead > 0) HIP_TRY(hipEventRecord(ac->ev_step[(ac->step_no - 1) & 7], s));
+    return 0;
+  }
   CK(hsad_seqwriter_push_reward_terminal_rep(ac->writer, ac->io.reward, ac->io.terminal, ac->vdn ? 1 : P, stream));
   CK(hsad_zero_state_rows(ac->h[nxt], ac->c[nxt], ac->fused_state ? ac->h16[nxt] : nullptr, ac->io.terminal, L, N, Hd, P, stream));
   ac->cur = nxt;

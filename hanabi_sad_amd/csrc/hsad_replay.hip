@@ -911,6 +911,68 @@ __global__ __launch_bounds__(256) void seq_push_kernel(SeqDev sd, int row_bytes,
   }
 }
 
+// The per-env tail of a thread-loop iteration in ONE launch (round 4): MultiStepBuffer::pushRewardAndTerminal + popTransition
+// (rela/transition_buffer.h:38-99), the n-step priority |r + bootstrap gamma^n Q_target - Q_online| (r2d2.py:355-360) and R2D2Buffer::push
+// (:134-176) -- seq_push_rt_kernel, seq_pop_kernel, nstep_priority_kernel and seq_push_kernel<16> were four launches of 4-8 us each between
+// two full-chip network passes of an acting step.  Same expressions in the same order: bit-identical.  16 lanes per env (the row copy);
+// the scalars are computed by every lane of the group from broadcast reads.  The n-step window read here is [head, head + n): the slot
+// written here is head + n, nothing reads it in this launch.
+__global__ __launch_bounds__(256) void seq_step_tail_kernel(SeqDev sd, int row_bytes, int head, int slot_new, const float* __restrict__ reward,
+                                                            const unsigned char* __restrict__ terminal, int repeat, const float* __restrict__ qa,
+                                                            const float* __restrict__ tqa, float gamma_n, float* __restrict__ prio_out,
+                                                            float* __restrict__ o_reward, float* __restrict__ o_bootstrap, int* __restrict__ err) {
+  constexpr int LPE = 16;
+  const int e = (blockIdx.x * 256 + threadIdx.x) / LPE, lane = threadIdx.x % LPE;
+  if (e >= sd.E) return;
+  if (lane == 0) {
+    sd.hist_r[(size_t)slot_new * sd.E + e] = reward[e / repeat];
+    sd.hist_t[(size_t)slot_new * sd.E + e] = terminal[e / repeat];
+  }
+  float bootstrap = 1.f;
+  int next = sd.n;
+  for (int step = 0; step < sd.n; ++step) {
+    if (sd.hist_t[(size_t)((head + step) % sd.depth) * sd.E + e]) {
+      bootstrap = 0.f;
+      next = step;
+      break;
+    }
+  }
+  const int initial = bootstrap != 0.f ? sd.n - 1 : next;
+  float acc = 0.f;
+  for (int step = initial; step >= 0; --step) acc = sd.hist_r[(size_t)((head + step) % sd.depth) * sd.E + e] + sd.gamma * acc;
+  const unsigned char term = sd.hist_t[(size_t)head * sd.E + e];
+  const float prio = fabsf(acc + bootstrap * gamma_n * tqa[e] - qa[e]);
+  const int idx = sd.next_idx[e];
+  if (lane == 0) {
+    sd.pend_reward[e] = acc;
+    sd.pend_terminal[e] = term;
+    sd.pend_bootstrap[e] = bootstrap;
+    prio_out[e] = prio;
+    if (o_reward) o_reward[e] = acc;
+    if (o_bootstrap) o_bootstrap[e] = bootstrap;
+  }
+  if (idx >= sd.T || idx < 0) {  // assert(nextIdx < seqLen) in the reference
+    if (lane == 0) atomicAdd(err, 1);
+    return;
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(sd.hist_rows + ((size_t)head * sd.E + e) * row_bytes);
+  uint4* dst = reinterpret_cast<uint4*>(sd.st_rows + ((size_t)e * sd.T + idx) * row_bytes);
+  const int nq = row_bytes / 16;
+  for (int j = lane; j < nq; j += LPE) dst[j] = src[j];
+  if (lane == 0) {
+    sd.st_reward[(size_t)e * sd.T + idx] = acc;
+    sd.st_terminal[(size_t)e * sd.T + idx] = term;
+    sd.st_bootstrap[(size_t)e * sd.T + idx] = bootstrap;
+    sd.st_prio[(size_t)e * sd.T + idx] = prio;
+    if (term) {
+      sd.len[e] = idx + 1;
+      sd.next_idx[e] = sd.T;
+    } else {
+      sd.next_idx[e] = idx + 1;
+    }
+  }
+}
+
 // R2D2Buffer::popTransition bookkeeping: the finished envs, in ascending env order (the order the reference appends them in).
 // 16 wavefronts, each owns a contiguous sixteenth of the envs and reads it ONCE, 256 envs per step (one 16-byte load per lane,
 // all of a wavefront's loads issued before the first is used); a shuffle prefix sum over the lanes' counts gives the slots.
@@ -1627,6 +1689,35 @@ int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void*
   HIP_TRY(hipGetLastError());
   w->pending = false;
   return HSAD_OK;
+}
+
+// push_reward_terminal_rep + pop_transition + hsad_nstep_priority + push_sequence of one thread-loop iteration as ONE launch
+// (seq_step_tail_kernel).  Preconditions: the obs / action of this step were pushed, the history then holds n + 1 steps (otherwise
+// HSAD_ERR_STATE: call the four entry points), rows of at most 256 bytes (the bit-packed layout).  qa / target_qa [E]: Q_online(s_{t-n}, a_{t-n})
+// and Q_target(s_t, greedy_t); priority_out [E] receives what hsad_nstep_priority would have written.
+int hsad_seqwriter_step_tail(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, int repeat, const float* qa, const float* target_qa,
+                             int multi_step, double gamma, float* priority_out, float* reward_out, float* bootstrap_out, void* stream) {
+  if (!w || !reward || !terminal || !qa || !target_qa || !priority_out || repeat < 1 || w->sd.E % repeat)
+    return rfail(HSAD_ERR_INVALID, "seqwriter_step_tail: bad argument");
+  if (w->rt_count != w->count - 1 || w->count != w->sd.n + 1 || w->pending || w->L.row_bytes > 256 || multi_step != w->sd.n)
+    return rfail(HSAD_ERR_STATE, "seqwriter_step_tail: needs n + 1 pushed steps with the newest reward outstanding and rows <= 256 bytes");
+  FenceUse use_w(w->fence, (hipStream_t)stream);   // the previous flush (possibly on another stream) resets the cursors this reads
+  HIP_TRY(use_w.err);
+  double g = 1.0;
+  for (int i = 0; i < multi_step; ++i) g *= gamma;
+  const SeqDev& sd = w->sd;
+  const int slot_new = (w->head + w->rt_count) % sd.depth;
+  hipLaunchKernelGGL(seq_step_tail_kernel, dim3((sd.E + 15) / 16), dim3(256), 0, (hipStream_t)stream, sd, w->L.row_bytes, w->head, slot_new, reward,
+                     terminal, repeat, qa, target_qa, (float)g, priority_out, reward_out, bootstrap_out, w->d_err);
+  HIP_TRY(hipGetLastError());
+  w->pend_slot = w->head;              // (what the four calls leave behind)
+  w->pending = false;
+  w->head = (w->head + 1) % sd.depth;
+  w->count -= 1;
+  return HSAD_OK;
+}
+int hsad_seqwriter_step_tail_ready(const hsad_seqwriter* w) {
+  return w && w->rt_count == w->count - 1 && w->count == w->sd.n + 1 && !w->pending && w->L.row_bytes <= 256;
 }
 
 int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta, int32_t* n_finished_dev, void* stream) {

@@ -519,6 +519,7 @@ class ReplayLink:
             rec["used"] = tail.clone()
             built = None
             if self.xd is not None:
+                rec["used"].record_stream(self.xs)      # allocated on the down stream, read when the round is collected on the up stream
                 built = torch.cuda.Event()
                 built.record()
             nccl = self.xd is not None and not self.staged

@@ -308,6 +308,13 @@ int hsad_seqwriter_pop_transition(hsad_seqwriter* w, void* const* out_fields, vo
 int hsad_seqwriter_push_sequence(hsad_seqwriter* w, const float* priority, void* stream);
 /* R2D2Buffer::popTransition + aggregatePriority + PrioritizedReplay::add for every finished env (ascending env
  * order), entirely on the device; n_finished_dev (may be NULL) receives the count. */
+/* push_reward_terminal_rep + pop_transition + hsad_nstep_priority + push_sequence of one thread-loop iteration as ONE launch (what
+ * cpp/thread_loop.h:66-84 does per step through R2D2Actor::postAct, rela/r2d2_actor.h:101-172): needs the step's obs / action pushed and then
+ * n + 1 steps in the history (hsad_seqwriter_step_tail_ready; otherwise HSAD_ERR_STATE -- use the four entry points), rows <= 256 bytes.
+ * qa / target_qa [E] = Q_online(s_{t-n}, a_{t-n}) / Q_target(s_t, greedy_t); priority_out [E]; reward_out / bootstrap_out optional [E]. */
+int hsad_seqwriter_step_tail(hsad_seqwriter* w, const float* reward, const uint8_t* terminal, int repeat, const float* qa, const float* target_qa,
+                             int multi_step, double gamma, float* priority_out, float* reward_out, float* bootstrap_out, void* stream);
+int hsad_seqwriter_step_tail_ready(const hsad_seqwriter* w);
 int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta, int32_t* n_finished_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
