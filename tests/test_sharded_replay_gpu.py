@@ -304,6 +304,61 @@ def test_replay_link_over_rccl_single_rank_equals_plain_sampling(mode):
         dist.destroy_process_group()
 
 
+def test_replay_link_three_rounds_open_over_rccl_single_rank():
+    """dist.ReplayLink(ahead=3) on the RCCL backend with the learner as the only rank: the ring of round slots, the down / up streams and
+    their events, statistics `ahead` rounds old in the header, priorities `ahead` + 1 rounds after their draw -- everything but a peer.
+    Dyadic priorities, alpha = 1: the shard's weight sum must equal a host model that applies every answered batch to the elements the
+    assembled batches named; weights finite with maximum 1; the compute stream's wait for a batch is measured (timings)."""
+    import socket
+    import torch.distributed as dist
+    from hanabi_sad_amd.dist import ReplayLink
+    from hanabi_sad_amd.replay import DeviceReplay
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B, AHEAD, U = 16, 3, 12
+        rng = np.random.default_rng(2)
+        shard = DeviceReplay(64, 5, 1.0, 0.6, 0, T, FIELDS, DEV)
+        rows = list(make_rows(rng, 40, 0))
+        w = (rng.integers(1, 64, 40) / 16.0).astype(np.float32)
+        rows[5] = torch.tensor(w, device=DEV)
+        shard.add(*rows)
+        link = ReplayLink(shard, B, 0.6, DEV, learner_rank=0, param_numel=64, mode="star", ahead=AHEAD)
+        assert link.ahead == AHEAD and len(link.hdrs) == AHEAD + 1
+        link.stage_params(torch.arange(64, dtype=torch.float32, device=DEV))
+        for i in range(AHEAD):
+            link.begin(None, params=(i == 0))
+        cur = link.finish()
+        tags, prios, sent = [], [], []
+        for u in range(U):
+            p = prios.pop(0) if prios else None
+            if p is not None:
+                sent.append(p)
+            link.begin(None if p is None else p[1])
+            (f, *_), weight = cur
+            t = f["a"][0, :, 0].cpu().numpy()
+            wt = weight.cpu().numpy()
+            assert np.all(np.isfinite(wt)) and np.all(wt > 0) and abs(float(wt.max()) - 1.0) < 1e-6 and t.min() >= 0 and t.max() < 40
+            (torch.ones(2048, 2048, device=DEV) @ torch.ones(2048, 2048, device=DEV))          # "the update runs here"
+            prios.append((t, torch.tensor((rng.integers(1, 64, B) / 16.0).astype(np.float32), device=DEV)))
+            cur = link.finish()
+        while link._rounds:
+            link.finish()
+        torch.cuda.synchronize()
+        shard.check_errors()
+        model = w.astype(np.float64).copy()
+        for t, p in sent:
+            for i, v in zip(t, p.cpu().numpy()):
+                model[int(i)] = float(v)
+        assert shard.priority_sum()[0] == float(model.sum())
+        tm = link.timings()
+        assert tm["rounds_ahead"] == AHEAD and tm["wait_for_batch_ms"] >= 0 and tm["serve_ms"] > 0 and "header_send_ms" in tm, tm
+    finally:
+        dist.destroy_process_group()
+
+
 def test_hsad_comm_c_entry_points_single_rank():
     """hsad_comm_{unique_id, init, bcast_params, gather_batch, scatter_priority, star_round} (csrc/hsad_comm.hip: RCCL bound with dlopen, no
     torch.distributed) on the one GPU of this box: a world of one rank, every call through the real RCCL communicator; the drawn
