@@ -574,6 +574,7 @@ class ReplayLink:
             total = used[:, 0].sum().to(torch.float32)
             n_total = used[:, 1].sum().to(torch.float32)
             y = torch.pow(n_total * (raw_w / total), -self.beta)
+            weight = y / y.max()            # (inside the stream context: the compute stream only waits for `ev` below)
             t.mark("assemble_ms", m)
             t.stop(m)
             if self.xs is not None:
@@ -581,7 +582,7 @@ class ReplayLink:
                 ev.record()
                 self._done_ev[rec["r"]] = ev
                 self._done_ev.pop(rec["r"] - 2 * len(self.hdrs), None)
-        rec["result"] = (batch, y / y.max())
+        rec["result"] = (batch, weight)
 
     # -- one round, every rank (stream-ordered on the caller's current stream) --
     def _round(self, flags):

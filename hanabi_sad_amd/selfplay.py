@@ -10,6 +10,7 @@ back to the owning shards, and the online/target parameters are broadcast over R
  — see hanabi_sad_amd/dist.py."""
 import argparse
 import contextlib
+import os
 import time
 
 import numpy as np
@@ -329,7 +330,14 @@ def run_link_learner(tr, args, link, num_update, on_update=None, stop=True):
             link.stage_params(_flat_of(L.online), _flat_of(L.target))
         link.begin(tr._prios.pop(0) if tr._prios else None, params=params)
         batch, weight, seq_len = tr.batch_of(tr._cur)
+        if os.environ.get("HSAD_LINK_DEBUG"):
+            bad = [k for k, v in list(batch.items()) + [("weight", weight), ("seq_len", seq_len)] if v.is_floating_point() and not bool(torch.isfinite(v.float()).all())]
+            if bad or float(seq_len.min()) < 1:
+                print("LINK_DEBUG update %d: non-finite %s  weight min/max %s %s  seq_len min %s  timings %s" % (
+                    tr.num_update, bad, float(weight.min()), float(weight.max()), float(seq_len.min()), link.timings()), flush=True)
         loss, priority = L.loss(batch, weight, a.pred_weight)
+        if os.environ.get("HSAD_LINK_DEBUG") and not bool(torch.isfinite(loss).all()):
+            print("LINK_DEBUG update %d: loss non-finite; params finite: %s" % (tr.num_update, bool(torch.isfinite(_flat_of(L.online)).all())), flush=True)
         tr._prios.append(aggregate_priority(priority, seq_len, a.eta))
         g_norm = L.optimizer_step()
         if on_update is not None:
