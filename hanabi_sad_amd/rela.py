@@ -390,7 +390,7 @@ class Context:
         self._run_ahead, self._marks = 0, []
         # the default: pace by whichever replay of the attached training loops is being sampled (see _auto_pace); HSAD_AUTO_PACE=0 or
         # set_pace(False) give the reference's unconditional free-running
-        self.auto_pace_steps = float(os.environ.get("HSAD_AUTO_PACE", "2"))
+        self.auto_pace_steps = self._auto_default = float(os.environ.get("HSAD_AUTO_PACE", "2"))
         self.auto_pace_idle_s = 0.1
         self._auto, self._auto_replays, self._bound = None, None, 0
 
@@ -411,6 +411,8 @@ class Context:
         if replay is False:
             self._pace, self._run_ahead, self.auto_pace_steps = None, 0, 0.0
             return
+        if replay is None and self.auto_pace_steps <= 0:
+            self.auto_pace_steps = self._auto_default      # back to the default behaviour, also after a set_pace(False)
         self._pace = None if replay is None else (replay, float(steps_per_sample), [None, 0.0])
         self._run_ahead = int(run_ahead) if replay is not None else 0
 
