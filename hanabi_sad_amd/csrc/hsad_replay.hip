@@ -802,21 +802,28 @@ __global__ void ids_from_head_kernel(ReplayDev rd, int idx, int* out) {
 }
 
 // ---- aggregatePriority --------------------------------------------------------------------------------
-__global__ void aggregate_priority_kernel(const float* __restrict__ priority, const float* __restrict__ seq_len,
-                                          int T, int B, float eta, float c1m, float* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const float len = seq_len[b];
-  float mx = 0.f;
+// eight lanes per sequence (round 4: one thread per sequence walked its T = 80 steps as a chain of dependent loads and fp64 adds, 31 us for a
+// 128-sequence batch between the BPTT and the optimizer step): lane l takes steps l, l + 8, ...; fp64 partial sums and maxima meet in a
+// shuffle tree.  The reference sums in float32 through ATen (rela/r2d2_actor.h:10-21); fp64 in either order agrees with it to float rounding.
+__global__ __launch_bounds__(256) void aggregate_priority_kernel(const float* __restrict__ priority, const float* __restrict__ seq_len,
+                                                                 int T, int B, float eta, float c1m, float* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x, b = g >> 3, l = g & 7;
+  const bool live = b < B;
+  const float len = live ? seq_len[b] : 1.f;
+  float mx = -INFINITY;    // max over ALL T entries of the masked row, like the reference's
   double sum = 0.0;
-  bool first = true;
-  for (int t = 0; t < T; ++t) {
-    const float p = priority[(size_t)t * B + b] * ((float)t < len ? 1.f : 0.f);
-    sum += p;
-    mx = first ? p : fmaxf(mx, p);
-    first = false;
+  if (live)
+    for (int t = l; t < T; t += 8) {
+      const float p = priority[(size_t)t * B + b] * ((float)t < len ? 1.f : 0.f);
+      sum += p;
+      mx = fmaxf(mx, p);
+    }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 8);
+    mx = fmaxf(mx, __shfl_xor(mx, o, 8));
   }
-  out[b] = eta * mx + c1m * ((float)sum / len);
+  if (live && l == 0) out[b] = eta * mx + c1m * ((float)sum / len);
 }
 
 // ---- sequence writer (MultiStepBuffer + R2D2Buffer) ----------------------------------------------------------
@@ -1182,7 +1189,7 @@ int hsad_aggregate_priority(const float* priority, const float* seq_len, int T, 
   if (!priority || !seq_len || !out || T < 1 || B < 1) return rfail(HSAD_ERR_INVALID, "bad aggregate_priority args");
   // the reference computes `(1.0 - eta) * pMean` with a double scalar that ATen narrows to float
   const float c1m = (float)(1.0 - (double)eta);
-  hipLaunchKernelGGL(aggregate_priority_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, priority,
+  hipLaunchKernelGGL(aggregate_priority_kernel, dim3((B * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream, priority,
                      seq_len, T, B, eta, c1m, out);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
