@@ -37,6 +37,7 @@ namespace {
 #include "r2d2/common.inc"
 #include "r2d2/gemm.inc"
 #include "r2d2/lstm_cell.inc"
+#include "r2d2/gemm8.inc"
 #include "r2d2/lstm_seq_fwd.inc"
 #include "r2d2/lstm_fused_fwd.inc"
 #include "r2d2/lstm_seq_bwd.inc"
@@ -148,6 +149,29 @@ int hsad_gemm_set_pp(int on) {
   return HSAD_OK;
 }
 
+// one launch of the grouped 256 x 256 core over P.np problems (item_end / order are filled in here): a workgroup per CU, a multiple of 8
+// of them when there is enough work (XCD-aware tile order needs blockIdx & 7 == XCD for every item of a workgroup)
+static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
+  long items = 0;
+  bool rows8 = true;
+  for (int k = 0; k < P.np; ++k) {
+    G8Prob& q = P.p[k];
+    const long t = (long)(q.M / 256) * (q.N / 256);
+    if ((q.M / 256) % 8) rows8 = false;
+    items += t * q.ksplit;
+    q.item_end = (int)items;
+  }
+  long grid = std::min<long>(items, (long)n_cu);
+  if (grid >= 64) grid &= ~7L;
+  P.order = (rows8 && (grid % 8) == 0) ? 1 : 0;
+  const size_t lds = g8_lds_bytes(epi);
+  void (*kp)(G8Args) = epi == G8_BF16 ? gemm8_kernel<G8_BF16> : epi == G8_F32 ? gemm8_kernel<G8_F32> : epi == G8_CELL ? gemm8_kernel<G8_CELL> : gemm8_kernel<G8_CELL_NOSTATE>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, s, P);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
 static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, int N, int K, const float* bias, float* C32,
                        int ldc, void* C16, int ldc16, int relu, int accumulate, int split_k, const void* relu_mask16,
                        int ldmask, const int32_t* row_map, size_t slab_stride, int* n_split_out, void* stream,
@@ -188,34 +212,41 @@ static int gemm_launch(const void* A, int lda, const void* B, int ldb, int M, in
     HIP_TRY(hipEventCreate(&trec.e1));
     HIP_TRY(hipEventRecord(trec.e0, s));
   }
-  // Big bf16-output GEMMs (the input layer of an acting step: 32768 x 512 x 896, online + target) run on the 256 x 256 phase-interleaved
-  // kernel of the fused cell in its PLAIN instantiation: identical bits, 89 -> ~60 us for that pair.  Needs whole 256 x 256 tiles, at
-  // least one per CU, B rows of exactly K elements, no split / mask / row map / fp32 output.
-  if (g_gemm_pp && C16 && !C32 && gz == 1 && !accumulate && !relu_mask16 && !row_map && M % 256 == 0 && N % 256 == 0 && K % kBK == 0 &&
-      K >= 2 * kBK && ldb == K && (long)(M / 256) * (N / 256) * np >= n_cu && !(lda & 7) && !(ldc16 & 7) &&
-      !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C16) & 15) && (!bias || !((uintptr_t)bias & 15)) &&
-      ((size_t)M + 256) * (size_t)lda * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32) &&
-      (np == 1 || !((g.dA | g.dB | g.dC16) & 15))) {
-    LstmCellArgs a{(const bf16_t*)A, nullptr, (const bf16_t*)B, bias, nullptr, nullptr, nullptr, (bf16_t*)C16, M, N, K, lda, ldc16, relu};
-    LstmCellArgs a2 = a;
-    if (np == 2) {
-      a2.x = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(A) + g.dA);
-      a2.Wcat = reinterpret_cast<const bf16_t*>(reinterpret_cast<const char*>(B) + g.dB);
-      a2.bias = bias ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(bias) + g.dbias) : nullptr;
-      a2.h_out16 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(C16) + g.dC16);
+  // Big GEMMs of whole 256 x 256 tiles run on the phase-interleaved 256 x 256 core (gemm8_kernel): bf16 output (the input layer of an acting
+  // step: 32768 x 512 x 896, online + target -- identical bits to the 128 x 128 kernel) or fp32 output (plain, or split-K slabs).  Needs an even
+  // number of 64-deep k tiles per K range, at least half a tile per CU, no accumulate / mask / row map.
+  {
+    const int nkt = K / kBK, kchunk_t = gz > 1 ? g.k_chunk / kBK : nkt;
+    const bool one_out = (C16 != nullptr) != (C32 != nullptr);
+    const bool slabs_ok = gz == 1 || (C32 && slab_stride > 0 && (kchunk_t % 2) == 0 && ((nkt - (gz - 1) * kchunk_t) % 2) == 0);
+    if (g_gemm_pp && one_out && slabs_ok && !accumulate && !relu_mask16 && !row_map && M % 256 == 0 && N % 256 == 0 && (nkt % 2) == 0 &&
+        2L * (M / 256) * (N / 256) * np * gz >= n_cu && !(lda & 7) && !(ldb & 7) && !((C16 ? ldc16 : ldc) & 7) &&
+        !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C16 | (uintptr_t)C32) & 15) && (!bias || !((uintptr_t)bias & 15)) &&
+        (size_t)257 * (size_t)std::max(lda, ldb) * 2 + (size_t)K * 2 < ((size_t)1 << 31) && (np == 1 || !((g.dA | g.dB | g.dC16 | g.dC32 | g.dbias) & 15))) {
+      G8Args P{};
+      P.np = np;
+      for (int k = 0; k < np; ++k) {
+        G8Prob& q = P.p[k];
+        auto off = [&](const void* base, long long d) { return k ? (const char*)base + d : (const char*)base; };
+        q.A = (const bf16_t*)off(A, g.dA);
+        q.A2 = nullptr;
+        q.B = (const bf16_t*)off(B, g.dB);
+        q.bias = bias ? (const float*)off(bias, g.dbias) : nullptr;
+        q.C32 = C32 ? (float*)off(C32, g.dC32) : nullptr;
+        q.C16 = C16 ? (bf16_t*)off(C16, g.dC16) : nullptr;
+        q.M = M; q.N = N; q.nk1 = nkt; q.nk2 = 0;
+        q.lda = lda; q.lda2 = lda; q.ldb = ldb; q.ldc = C16 ? ldc16 : ldc;
+        q.relu = relu; q.ksplit = gz; q.kchunk = kchunk_t;
+        q.slab_stride = g.slab_stride;
+      }
+      const int rc = g8_launch(C16 ? G8_BF16 : G8_F32, P, n_cu, s);
+      if (rc) return rc;
+      if (trec.e0) {
+        HIP_TRY(hipEventRecord(trec.e1, s));
+        g_gemm_timing.recs.push_back(trec);
+      }
+      return HSAD_OK;
     }
-    const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
-    long grid = std::min<long>((long)(M / 256) * (N / 256) * np, (long)n_cu);
-    if (grid >= 64) grid &= ~7L;
-    auto kp = lstm_cell_pp_kernel<false, 0, true>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, s, a, a2, np);
-    HIP_TRY(hipGetLastError());
-    if (trec.e0) {
-      HIP_TRY(hipEventRecord(trec.e1, s));
-      g_gemm_timing.recs.push_back(trec);
-    }
-    return HSAD_OK;
   }
   // 128x64 tiles when N is narrow or when 128x128 tiles would leave most CUs without work
   const long tiles128 = (long)((N + 127) / 128) * ((M + 127) / 128) * gz * np;
@@ -543,6 +574,16 @@ int hsad_lstm_cell_set_variant(int tile, int pp) {
   return HSAD_OK;
 }
 
+static G8Prob cell_problem(const LstmCellArgs& a) {
+  G8Prob q{};
+  q.A = a.x; q.A2 = a.h_prev16; q.B = a.Wcat; q.bias = a.bias;
+  q.C32 = nullptr; q.C16 = a.h_out16; q.c_prev = a.c_prev; q.c_out = a.c_out; q.h_out32 = a.h_out32;
+  q.M = a.Bn; q.N = 4 * a.H; q.nk1 = a.Kx / kBK; q.nk2 = a.H / kBK;
+  q.lda = a.ldx; q.lda2 = a.H; q.ldb = a.Kx + a.H; q.ldc = a.H;
+  q.relu = 0; q.ksplit = 1; q.kchunk = q.nk1 + q.nk2;
+  return q;
+}
+
 int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const void* h_prev16, const void* Wcat_gate16,
                          const float* bias_gate16, const float* c_prev, float* c_out, float* h_out32, void* h_out16,
                          void* stream) {
@@ -570,19 +611,14 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     const long tiles = (long)(4 * H / 256) * ((Bn + 255) / 256);
     long grid = std::min<long>(tiles, (long)n_cu);
     if (grid >= 64) grid &= ~7L;
-    // developer switch HSAD_CELL_PP: 0 the one-barrier k loop, 1 (default) the phase-interleaved one; 11 / 12 / 14 / 19: its ablations
+    // developer switch HSAD_CELL_PP: 0 the one-barrier k loop, otherwise (default) the phase-interleaved 256 x 256 core (gemm8_kernel)
     const int pp = g_cell_variant.pp();
-    if (pp && Bn % 256 == 0) {
-      const bool st = c_out || h_out32;
-      auto kp = st ? lstm_cell_pp_kernel<true> : lstm_cell_pp_kernel<false>;
-      if (pp == 11) kp = lstm_cell_pp_kernel<true, 1>;
-      if (pp == 12) kp = lstm_cell_pp_kernel<true, 2>;
-      if (pp == 14) kp = lstm_cell_pp_kernel<true, 4>;
-      if (pp == 19) kp = lstm_cell_pp_kernel<true, 9>;
-      if (g_lstm_dbg_enable) kp = lstm_cell_pp_kernel<true, 128>;
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a, a, 1);
-      HIP_TRY(hipGetLastError());
+    if (pp && Bn % 256 == 0 && ((Kx + H) / kBK) % 2 == 0 && !g_lstm_dbg_enable) {
+      G8Args P{};
+      P.np = 1;
+      P.p[0] = cell_problem(a);
+      const int rc = g8_launch((c_out || h_out32) ? G8_CELL : G8_CELL_NOSTATE, P, n_cu, (hipStream_t)stream);
+      if (rc) return rc;
       if (t_e0) {
         HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
         g_cell_timing.ev.push_back({t_e0, t_e1});
@@ -619,7 +655,8 @@ int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a,
                               const void* Wcat_a, const void* Wcat_b, const float* bias_a, const float* bias_b, const float* c_prev_a,
                               const float* c_prev_b, float* c_out_a, float* c_out_b, float* h_out32_a, float* h_out32_b, void* h_out16_a,
                               void* h_out16_b, void* stream) {
-  const bool pp_ok = g_cell_variant.pp() == 1 && g_cell_variant.tile() != 128 && Bn >= 4096 && Bn % 256 == 0 && (4 * H) % 256 == 0 && !g_lstm_dbg_enable &&
+  const bool pp_ok = g_cell_variant.pp() != 0 && g_cell_variant.tile() != 128 && Bn >= 4096 && Bn % 256 == 0 && (4 * H) % 256 == 0 && !g_lstm_dbg_enable &&
+                     ((Kx + H) / kBK) % 2 == 0 &&
                      x16_a && x16_b && h_prev16_a && h_prev16_b && Wcat_a && Wcat_b && bias_a && bias_b && c_prev_a && c_prev_b &&
                      (c_out_a || h_out32_a || h_out16_a) && (c_out_b || h_out32_b || h_out16_b) && H >= 64 && H % kBK == 0 && Kx >= kBK && Kx % kBK == 0 &&
                      ldx % 8 == 0 &&
@@ -639,16 +676,16 @@ int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a,
     HIP_TRY(hipEventCreate(&t_e1));
     HIP_TRY(hipEventRecord(t_e0, (hipStream_t)stream));
   }
-  const size_t lds = (size_t)2 * (256 + 256) * kBK * sizeof(bf16_t);
-  const long tiles = 2L * (4 * H / 256) * (Bn / 256);
-  long grid = std::min<long>(tiles, (long)n_cu);
-  if (grid >= 64) grid &= ~7L;
   // (a problem without fp32 state outputs has empty descriptors: its state stores are dropped in the address unit)
   const bool st = c_out_a || h_out32_a || c_out_b || h_out32_b;
-  auto kp = st ? lstm_cell_pp_kernel<true> : lstm_cell_pp_kernel<false>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a, b, 2);
-  HIP_TRY(hipGetLastError());
+  G8Args P{};
+  P.np = 2;
+  P.p[0] = cell_problem(a);
+  P.p[1] = cell_problem(b);
+  {
+    const int rc = g8_launch(st ? G8_CELL : G8_CELL_NOSTATE, P, n_cu, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   if (t_e0) {
     HIP_TRY(hipEventRecord(t_e1, (hipStream_t)stream));
     g_cell_timing.ev.push_back({t_e0, t_e1});
