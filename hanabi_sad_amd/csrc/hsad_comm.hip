@@ -98,7 +98,16 @@ struct hsad_comm {
   double* all_stats = nullptr;  // [world][2]
   float* prio = nullptr;        // [1024] broadcast landing zone of scatter_priority
   double* next_stats = nullptr; // [world][2] root of a star round: what the replies of the previous round reported
+  // pipelined rounds (the `down` communicator owns them): hdr_ready = this round's header is complete on the down stream, recorded by
+  // hsad_comm_star_open BEFORE its sends; sync = scratch event of the prime leg.  Persistent: no create / destroy per round, none leaked
+  // on an error return
+  hipEvent_t hdr_ready = nullptr, sync = nullptr;
 };
+static int comm_events(hsad_comm* c) {
+  if (!c->hdr_ready && hipEventCreateWithFlags(&c->hdr_ready, hipEventDisableTiming) != hipSuccess) return HSAD_ERR_HIP;
+  if (!c->sync && hipEventCreateWithFlags(&c->sync, hipEventDisableTiming) != hipSuccess) return HSAD_ERR_HIP;
+  return HSAD_OK;
+}
 
 extern "C" {
 
@@ -146,6 +155,8 @@ void hsad_comm_destroy(hsad_comm* c) {
   if (c->all_stats) (void)hipFree(c->all_stats);
   if (c->prio) (void)hipFree(c->prio);
   if (c->next_stats) (void)hipFree(c->next_stats);
+  if (c->hdr_ready) (void)hipEventDestroy(c->hdr_ready);
+  if (c->sync) (void)hipEventDestroy(c->sync);
   delete c;
 }
 
@@ -275,20 +286,22 @@ int hsad_comm_star_open(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int 
   const size_t hdr_n = 2 * (size_t)batch + 4 * (size_t)W;
   double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
   int rc;
+  if ((rc = comm_events(down))) return cfail(rc, "comm_star_open: hipEventCreate failed");
   if (flags & HSAD_LINK_PRIME) {        // nobody has reported a (sum, size) yet: collect them up front (up), then the header may leave
     NCCL_TRY(R->GroupStart());
     for (int k = 0; k < W; ++k)
       if (k != root) NCCL_TRY(R->Recv(stats_prime + 2 * k, 2, ncclFloat64, k, up->comm, su));
     NCCL_TRY(R->GroupEnd());
     if ((rc = hsad_replay_stats(shard, stats_prime + 2 * root, stream_up))) return rc;
-    hipEvent_t e;
-    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(e, su));
-    HIP_TRY(hipStreamWaitEvent(sd, e, 0));
-    HIP_TRY(hipEventDestroy(e));
+    HIP_TRY(hipEventRecord(down->sync, su));
+    HIP_TRY(hipStreamWaitEvent(sd, down->sync, 0));
     stats_known = stats_prime;
   }
   HIP_TRY(hipMemcpyAsync(hdr_stats, stats_known, 16 * (size_t)W, hipMemcpyDeviceToDevice, sd));
+  // the header is complete HERE.  hsad_comm_star_collect makes the up stream wait for this point and not for the sends below: the root's
+  // receive of an actor's rows must not queue behind the parameter send to that actor -- the actor posts its parameter receive only after
+  // its row send has completed, and a 37 MB parameter send does not complete eagerly (a cycle with more than one rank)
+  HIP_TRY(hipEventRecord(down->hdr_ready, sd));
   NCCL_TRY(R->GroupStart());
   for (int k = 0; k < W; ++k)
     if (k != root) NCCL_TRY(R->Send(hdr, hdr_n, ncclFloat32, k, down->comm, sd));
@@ -302,8 +315,8 @@ int hsad_comm_star_open(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int 
   return HSAD_OK;
 }
 
-// root, second half: call it right behind hsad_comm_star_open (the up stream must see the finished header: pass an event, or let
-// stream_up wait for stream_down's header copy -- done here).  stats_reply [world][2]: where this round's replies put their statistics
+// root, second half: call it right behind hsad_comm_star_open (the up stream waits for the event that call recorded behind its header
+// copy and in front of its sends).  stats_reply [world][2]: where this round's replies put their statistics
 // (what a LATER hsad_comm_star_open passes as stats_known once the host has collected this round).
 int hsad_comm_star_collect(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int batch, float* hdr, int flags, const int32_t* answer_owner,
                            int32_t* owner_out, uint8_t* wire_all, double* stats_reply, void* stream_down, void* stream_up) {
@@ -316,11 +329,9 @@ int hsad_comm_star_collect(hsad_comm* down, hsad_comm* up, hsad_replay* shard, i
   const size_t bytes = (size_t)batch * hsad_replay_wire_bytes(shard);
   double* hdr_stats = reinterpret_cast<double*>(hdr + 2 * batch);
   int rc;
-  hipEvent_t e;                          // the header (uniforms, priorities, statistics) is complete on the down stream
-  HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(e, sd));
-  HIP_TRY(hipStreamWaitEvent(su, e, 0));
-  HIP_TRY(hipEventDestroy(e));
+  (void)sd;
+  if (!down->hdr_ready) return cfail(HSAD_ERR_STATE, "comm_star_collect: no hsad_comm_star_open before it on this communicator");
+  HIP_TRY(hipStreamWaitEvent(su, down->hdr_ready, 0));   // the header (uniforms, priorities, statistics) as star_open completed it, NOT its sends
   NCCL_TRY(R->GroupStart());             // posted before the own shard is served: the replies travel meanwhile
   for (int k = 0; k < W; ++k) {
     if (k == root) continue;

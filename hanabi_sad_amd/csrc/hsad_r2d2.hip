@@ -153,19 +153,42 @@ int hsad_gemm_set_pp(int on) {
 // of them when there is enough work (XCD-aware tile order needs blockIdx & 7 == XCD for every item of a workgroup)
 static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   long items = 0;
-  bool rows8 = true;
+  for (int k = 0; k < P.np; ++k) items += (long)(P.p[k].M / 256) * (P.p[k].N / 256) * P.p[k].ksplit;
+  long grid = std::min<long>(items, (long)n_cu);
+  if (grid >= 64) grid &= ~7L;
+  // tile order per problem (XCD-aware orders need item & 7 == blockIdx & 7 == XCD: a grid that is a multiple of 8, problems that start at one):
+  // patches of (32 / pn) x pn tiles per XCD round when the problem's tiles are whole rounds of the chip, else row tiles dealt to the XCDs
+  static const int force_order = getenv("HSAD_G8_ORDER") ? atoi(getenv("HSAD_G8_ORDER")) : -1;     // developer switch
+  items = 0;
   for (int k = 0; k < P.np; ++k) {
     G8Prob& q = P.p[k];
-    const long t = (long)(q.M / 256) * (q.N / 256);
-    if ((q.M / 256) % 8) rows8 = false;
+    const int tm = q.M / 256, tn = q.N / 256;
+    const long t = (long)tm * tn;
+    const bool xcd_ok = (grid % 8) == 0 && (items % 8) == 0;
+    q.pn = (tn % 4) == 0 ? 4 : (tn % 2) == 0 ? 2 : 1;
+    q.order = 0;
+    if (xcd_ok && (tm % 8) == 0) q.order = 1;
+    if (xcd_ok && (t % 256) == 0 && (tm % (32 / q.pn)) == 0 && force_order != 1) q.order = 2;
+    if (force_order == 0) q.order = 0;
     items += t * q.ksplit;
     q.item_end = (int)items;
   }
-  long grid = std::min<long>(items, (long)n_cu);
-  if (grid >= 64) grid &= ~7L;
-  P.order = (rows8 && (grid % 8) == 0) ? 1 : 0;
   const size_t lds = g8_lds_bytes(epi);
+  static const int cell_aux = getenv("HSAD_CELL_STORE_AUX") ? atoi(getenv("HSAD_CELL_STORE_AUX")) : kCellStoreAux;   // developer switch: 0 plain, 2 nt state stores
   void (*kp)(G8Args) = epi == G8_BF16 ? gemm8_kernel<G8_BF16> : epi == G8_F32 ? gemm8_kernel<G8_F32> : epi == G8_CELL ? gemm8_kernel<G8_CELL> : gemm8_kernel<G8_CELL_NOSTATE>;
+  static const int cell_wide = getenv("HSAD_CELL_WIDE") ? atoi(getenv("HSAD_CELL_WIDE")) : 0;                          // developer switch: state rows through LDS, 16-byte accesses
+  static const int stagger_pct = getenv("HSAD_G8_STAGGER") ? atoi(getenv("HSAD_G8_STAGGER")) : 0;                      // developer switch: start delay step in percent of an item's estimated time
+  if (cell_aux == 0 && epi == G8_CELL) kp = gemm8_kernel<G8_CELL, 0>;
+  if (cell_aux == 0 && epi == G8_CELL_NOSTATE) kp = gemm8_kernel<G8_CELL_NOSTATE, 0>;
+  if (cell_wide && epi == G8_CELL) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL, 0, true> : gemm8_kernel<G8_CELL, kCellStoreAux, true>;
+  if (cell_wide && epi == G8_CELL_NOSTATE) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL_NOSTATE, 0, true> : gemm8_kernel<G8_CELL_NOSTATE, kCellStoreAux, true>;
+  if (g_lstm_dbg_enable && epi == G8_CELL) kp = cell_wide ? gemm8_kernel<G8_CELL, kCellStoreAux, true, true> : gemm8_kernel<G8_CELL, kCellStoreAux, false, true>;
+  if (g_lstm_dbg_enable && epi == G8_BF16) kp = gemm8_kernel<G8_BF16, kCellStoreAux, false, true>;
+  P.stagger = 0;
+  if (stagger_pct > 0 && items >= 2L * grid) {
+    const double item_us = 1.55 * P.p[0].kchunk + 6.0;      // k tiles at the core's rate + an epilogue
+    P.stagger = (int)(item_us * 100.0 * stagger_pct / 100.0);   // 10 ns ticks
+  }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, s, P);
   HIP_TRY(hipGetLastError());
@@ -613,7 +636,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
     if (grid >= 64) grid &= ~7L;
     // developer switch HSAD_CELL_PP: 0 the one-barrier k loop, otherwise (default) the phase-interleaved 256 x 256 core (gemm8_kernel)
     const int pp = g_cell_variant.pp();
-    if (pp && Bn % 256 == 0 && ((Kx + H) / kBK) % 2 == 0 && !g_lstm_dbg_enable) {
+    if (pp && Bn % 256 == 0 && ((Kx + H) / kBK) % 2 == 0) {
       G8Args P{};
       P.np = 1;
       P.p[0] = cell_problem(a);
@@ -1130,8 +1153,18 @@ int hsad_lstm_fused_timing_read_kind(int kind, double* avg_ms, double* avg_flop,
   g_fused_timing.kind.resize(keep);
   return HSAD_OK;
 }
+// the one-kind API of round 3: reads the forward launches and DROPS the BPTT records taken meanwhile (a caller that only knows this entry
+// point would otherwise retain two events per BPTT launch for as long as timing is on)
 int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launches) {
-  return hsad_lstm_fused_timing_read_kind(0, avg_ms, avg_flop, launches);
+  const int rc = hsad_lstm_fused_timing_read_kind(0, avg_ms, avg_flop, launches);
+  for (auto& e : g_fused_timing.ev) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  g_fused_timing.ev.clear();
+  g_fused_timing.flop.clear();
+  g_fused_timing.kind.clear();
+  return rc;
 }
 
 // Fused persistent forward (lstm_fused_fwd_kernel): nnet independent nets x nlayer stacked layers over the WHOLE sequence in one

@@ -1164,7 +1164,7 @@ struct hsad_replay {
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
   int out_ld[kMaxFields] = {};
   std::mt19937 rng;
-  hipStream_t last_stream;
+  hipStream_t slot_stream[kCanonSlots];   // the stream of the draw that read each pinned slot last (written under the fence's guard)
   int64_t bytes;
 };
 
@@ -1212,7 +1212,7 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
   r->device = device;
   r->T = seq_len;
   r->rng.seed(seed);
-  r->last_stream = nullptr;
+  for (int k = 0; k < hsad_replay::kCanonSlots; ++k) r->slot_stream[k] = nullptr;
   ReplayDev& rd = r->rd;
   rd.ring = (int)(1.25 * capacity);
   if (rd.ring < 1) rd.ring = 1;
@@ -1280,12 +1280,16 @@ void hsad_replay_destroy(hsad_replay* r) {
 }
 
 // next pinned staging slot for n uniforms; upload_canon queues the copy to d_canon and marks the slot busy until it is done
-static float* canon_slot(hsad_replay* r, int* slot) {
+// (host state of the draws -- canon_next, slot_seq, slot_stream, draw_seq, the generator -- is only touched with the fence's guard held:
+// call it after the entry point's FenceUse)
+static float* canon_slot(hsad_replay* r, int* slot, hipStream_t s) {
   *slot = r->canon_next;
   r->canon_next = (r->canon_next + 1) % hsad_replay::kCanonSlots;
-  // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call
-  if (*r->h_done < r->slot_seq[*slot]) (void)hipStreamSynchronize(r->last_stream);
+  // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call; otherwise wait
+  // for THAT draw's stream (not for whichever stream the object saw last: a flush on a side stream is not what holds the slot)
+  if (*r->h_done < r->slot_seq[*slot] && r->slot_stream[*slot]) (void)hipStreamSynchronize(r->slot_stream[*slot]);
   r->slot_seq[*slot] = ++r->draw_seq;     // the draw about to be issued
+  r->slot_stream[*slot] = s;
   return r->h_canon_ring + (size_t)*slot * kMaxBatch;
 }
 static hipError_t upload_canon(hsad_replay* r, int slot, int n, hipStream_t s) {
@@ -1301,7 +1305,6 @@ int hsad_replay_add(hsad_replay* r, int n, const void* const* fields, const floa
     return rfail(HSAD_ERR_INVALID, "null argument");
   if (n < 1) return HSAD_OK;
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   hipLaunchKernelGGL(replay_add_ctl_kernel, dim3(1), dim3(256), 0, s, r->rd, n, n_dev, priority);
@@ -1321,14 +1324,13 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   if (!r || !out_fields || !weight) return rfail(HSAD_ERR_INVALID, "null argument");
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "batch must be 1..%d", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   // canonical uniforms exactly as std::uniform_real_distribution<float> would draw them (libstdc++:
   // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
   // the segment depends on the device-side running sum)
   int slot;
-  float* hc = canon_slot(r, &slot);
+  float* hc = canon_slot(r, &slot, s);
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
   HIP_TRY(upload_canon(r, slot, batch, s));
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight, (const float*)nullptr,
@@ -1366,12 +1368,11 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   if (!r || !out_fields) return rfail(HSAD_ERR_INVALID, "null argument");
   if (n < 0 || n > kMaxBatch || (n > 0 && (!targets_host || !raw_weight))) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   if (n > 0) {
     int slot;
-    float* hc = canon_slot(r, &slot);
+    float* hc = canon_slot(r, &slot, s);
     for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
     HIP_TRY(upload_canon(r, slot, n, s));
   }
@@ -1392,7 +1393,6 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
 int hsad_replay_update_priority(hsad_replay* r, const float* priority, int batch, void* stream) {
   if (!r) return rfail(HSAD_ERR_INVALID, "null replay");
   if (batch < 0 || batch > kMaxBatch || (batch > 0 && !priority)) return rfail(HSAD_ERR_INVALID, "bad batch");
-  r->last_stream = (hipStream_t)stream;
   FenceUse use_r(r->fence, (hipStream_t)stream);
   HIP_TRY(use_r.err);
   hipLaunchKernelGGL(replay_update_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, r->rd, batch, priority);
@@ -1418,7 +1418,6 @@ int hsad_replay_serve(hsad_replay* r, int batch, const float* canon, const doubl
   if (batch < 1 || batch > kMaxBatch || world < 1 || world > 64 || rank < 0 || rank >= world)
     return rfail(HSAD_ERR_INVALID, "serve: batch 1..%d, world 1..64, rank inside it", kMaxBatch);
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   float* raw_w = r->d_shard + kMaxBatch;
@@ -1439,7 +1438,6 @@ int hsad_replay_update_owned(hsad_replay* r, int batch, const float* priority, c
   if (!r || !priority || !owner) return rfail(HSAD_ERR_INVALID, "null argument");
   if (batch < 1 || batch > kMaxBatch) return rfail(HSAD_ERR_INVALID, "bad batch");
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   int* n_mine = reinterpret_cast<int*>(r->d_shard + 2 * kMaxBatch) + 1;
@@ -1732,7 +1730,6 @@ int hsad_seqwriter_flush_to_replay(hsad_seqwriter* w, hsad_replay* r, float eta,
   if (w->L.row_bytes != r->L.row_bytes || w->sd.T != r->T || w->L.n_fields != r->L.n_fields)
     return rfail(HSAD_ERR_INVALID, "sequence writer and replay were created with different layouts");
   hipStream_t s = (hipStream_t)stream;
-  r->last_stream = s;
   // both objects' guards for the whole flush; behind the previous flush and behind every push / add / sample / serve / update issued on
   // another stream (by this or another host thread) since
   FlushUse flush(&w->fence, &r->fence, s);

@@ -14,7 +14,7 @@
 //   * host threads: an entry point holds the object's guard from pass() to consumed() (FenceUse) and a flush from begin_flush() to
 //     arm() (FlushUse).  Without it a sample() enqueued by the training thread BETWEEN the rollout thread's begin_flush() and arm()
 //     would be ordered neither before nor behind that flush: two kernels on two streams over one ring.
-// Operations on the flush's own stream need neither wait (stream order).
+// Operations on the flush's own stream need no wait (stream order); they still leave their consumer event for a later flush elsewhere.
 //
 // RT: { using stream_t; using event_t; using error_t; static constexpr error_t ok;
 //       static error_t event_create(event_t*); static error_t event_record(event_t, stream_t);
@@ -80,7 +80,8 @@ struct StreamFenceT {
   }
   void consumed(stream_t s) {  // a consumer operation has been enqueued on s
     std::lock_guard<std::recursive_mutex> g(guard);
-    if (gen && s == stream) return;  // the flush stream itself: stream order
+    // (also on the current flush's own stream: THIS flush needs no event for it, but the next one may run on another stream and must be
+    // ordered behind this operation -- begin_flush() skips entries of the stream it flushes on, so same-stream flushes pay nothing)
     Cons* k = nullptr;
     for (Cons& c : cons)
       if (c.s == s) k = &c;

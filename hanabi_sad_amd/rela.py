@@ -373,6 +373,16 @@ class R2D2Actor:
         return self._num_act + (lp._train_steps * self._per_step if lp is not None else 0)
 
 
+class _MarkGroup:
+    """the rollout streams' events of one Context iteration: query() = all of them have been reached"""
+
+    def __init__(self, events):
+        self.events = events
+
+    def query(self):
+        return all(e.query() for e in self.events)
+
+
 class Context:
     """rela.Context (rela/context.h:18-80): push_env_thread / start / pause / resume / terminate / terminated.
     start() runs every attached loop from one background thread until terminate(); eval loops end by themselves, and
@@ -481,6 +491,7 @@ class Context:
                 elif have != dev:
                     raise MultiDeviceError(have, dev)
         self.loops.append(loop)
+        self._auto_replays = None                # the default pace looks at the replays of ALL attached loops: also of one pushed late
         return len(self.loops)
 
     def _run(self):
@@ -511,10 +522,14 @@ class Context:
                                 lp.step()
                         busy = True
                 if self._bound > 0 and self._streams:
+                    # ONE mark per iteration, whatever the number of device streams (the run-ahead bound counts steps): the events of
+                    # all rollout streams of this iteration, done when all of them are
+                    evs = []
                     for st in self._streams.values():
                         e = torch.cuda.Event()
                         e.record(st)
-                        self._marks.append(e)
+                        evs.append(e)
+                    self._marks.append(_MarkGroup(evs))
                 if not busy and not self._paused:
                     break
         except Exception as e:   # surfaced by the next Context call from the driver's thread

@@ -490,6 +490,42 @@ def test_big_bf16_output_gemm_on_the_phase_interleaved_kernel_gives_identical_bi
         assert torch.allclose(outs[1][q][rows].float(), want, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K,split_k,with_bias", [(8192, 2048, 1024, 1, True), (4096, 4096, 384, 1, False), (2048, 1024, 10240, 8, False),
+                                                     (2048, 512, 10240, 5, False), (16384, 256, 128, 1, True)])
+def test_big_fp32_output_gemm_on_the_phase_interleaved_kernel_gives_identical_bits(M, N, K, split_k, with_bias):
+    """fp32-output GEMMs of whole 256 x 256 tiles run on the same 256 x 256 core (gemm8_kernel<G8_F32>: accumulator tiles cross 4 KB of
+    wave-private LDS and leave as full 128-byte rows), plain or as split-K slabs summed by sum_slabs_kernel (the weight-gradient GEMMs'
+    shape: K = T x B = 10,240).  Same products, same k order, same k ranges per slab: the output must equal the 128 x 128 kernel's to the bit.
+    (4096 x 4096 x 384 has an odd number of k tiles and 2048 x 512 x 10240 / 5 an odd k range: both sides then run the 128 x 128 kernel.)"""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.r2d2 import _s
+    lib = _lib.load_library()
+    g = torch.Generator(device="cpu").manual_seed(M + N + K + split_k)
+    A = (torch.randn(M, K, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(DEV)
+    st, p = _s(torch.device(DEV)), (lambda t: t.data_ptr())
+    outs = {}
+    try:
+        for on in (1, 0):
+            _lib.check(lib.hsad_gemm_set_pp(on))
+            o = torch.full((M, N), 7.0, device=DEV)
+            if split_k == 1:
+                _lib.check(lib.hsad_gemm_nt_bf16(p(A), K, p(Bm), K, M, N, K, p(bias) if with_bias else None, p(o), N, None, 0, 0, 0, st))
+            else:
+                ws = torch.empty(split_k * M * N, device=DEV)
+                _lib.check(lib.hsad_gemm_nt_bf16_splitk(p(A), K, p(Bm), K, M, N, K, split_k, p(ws), p(o), N, None, st))
+            torch.cuda.synchronize()
+            outs[on] = o
+    finally:
+        lib.hsad_gemm_set_pp(1)
+    assert torch.equal(outs[1], outs[0]), (outs[1] - outs[0]).abs().max()
+    rows = torch.arange(0, M, 509, device=DEV)
+    want = A[rows].float() @ Bm.float().T + (bias if with_bias else 0)
+    assert torch.allclose(outs[1][rows], want, rtol=1e-3, atol=1e-3 * K ** 0.5)
+
+
 @pytest.mark.parametrize("N,H,state", [(4096, 512, True), (8192, 256, True), (4096, 512, False), (12288, 512, True)])
 def test_fused_cell_kernel_variants_give_identical_bits(N, H, state):
     """hsad_lstm_cell_fused launches one of three kernels: 128 x 128 tiles, 256 x 256 tiles with one barrier per k step, 256 x 256 tiles

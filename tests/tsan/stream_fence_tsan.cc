@@ -178,6 +178,9 @@ static long run(int iters, int n_train_threads) {
         model::RT::stream_wait_event(s, &e);
       }
       flush_op<GUARDED>(o, s);
+      // a consumer ON the stream that just flushed (flush A, consume A), with the next flush on whichever stream comes next (B): the
+      // consumer must leave an event although it needed no wait itself (consumed() used to return early here)
+      if (rng() % 4 == 0) consumer_op<GUARDED>(o, s, rng() % 2 == 0);
     }
   });
   for (int t = 0; t < n_train_threads; ++t)

@@ -1,4 +1,5 @@
-"""phase timers of the 256 x 256 fused cell kernel (developer instantiation, hsad_lstm_debug_enable): wall-clock time workgroup 0
+"""phase timers of the 256 x 256 fused cell kernels (developer instantiation, hsad_lstm_debug_enable): the phase-interleaved core (gemm8_kernel)
+reports shader clocks per item (k loop | epilogue | store drain); the one-barrier kernel (HSAD_CELL_PP=0) wall-clock time workgroup 0
 spends per launch in  wait = s_waitcnt + barrier at the top of a k step | mfma = fragment reads + MFMAs of a k step |
 epilogue = cell update + state loads / stores | rest.    python tools/cell_phases.py [rows] [state_outputs 0|1]"""
 import ctypes as C, os, sys, time
@@ -31,10 +32,12 @@ for dbg in (0, 1):
     _lib.check(lib.hsad_lstm_debug_timing(buf, 1))
     print("debug %d: %.1f us per launch (%.0f TF)" % (dbg, dt * 1e6, 2 * N * 2048 * 1024 / dt / 1e12))
     if dbg and os.environ.get("HSAD_CELL_PP", "1") != "0":
+        # gemm8_kernel's developer timers: shader clocks of workgroup 0 in its k loops | epilogues up to the last store issued | waiting for
+        # those stores (a vmcnt(0) the product does not have: it is what the next item's first counted waits would see) | items
         for g, o in (("wave 0 (early row)", 0), ("wave 4 (late row)", 8)):
-            cyc = [buf[o + i] / K for i in range(7)]
-            print("  %s cycles per launch: sum %.0f, epilogue %.0f;  per phase: reads %.0f | DMA issue %.0f | vmcnt wait %.0f | wait L-barrier %.0f | M %.0f | wait M-barrier %.0f"
-                  % (g, sum(cyc), cyc[4], cyc[5] / 256, cyc[6] / 256, cyc[0] / 256, cyc[1] / 256, cyc[2] / 256, cyc[3] / 256))
+            cyc = [buf[o + i] / K for i in range(4)]
+            n = max(cyc[3], 1)
+            print("  %s per launch: %d items; per item: k loop %.0f cycles | epilogue %.0f | store drain %.0f" % (g, n, cyc[0] / n, cyc[1] / n, cyc[2] / n))
     elif dbg:
         us = [buf[i] / K / 100.0 for i in range(4)]
         print("  workgroup 0 per launch: wait %.1f us | mfma %.1f us | epilogue %.1f us | rest %.1f us | sum %.1f us" % (us[2], us[3], us[1], us[0], sum(us)))
