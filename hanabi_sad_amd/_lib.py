@@ -153,6 +153,8 @@ SIGNATURES = {
     "hsad_lstm_cell_fused": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_lstm_cell_set_variant": (C.c_int, [C.c_int, C.c_int]),
     "hsad_gemm_set_pp": (C.c_int, [C.c_int]),
+    "hsad_gemm_group_workspace_floats": (C.c_int64, [C.c_int, _P]),
+    "hsad_gemm_nt_bf16_group_splitk": (C.c_int, [C.c_int, _P, _P, C.c_int64, _P]),
     "hsad_lstm_cell_fused_pair": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [_P] * 17),
     "hsad_lstm_set_exchange_mode": (C.c_int, [C.c_int]),
     "hsad_lstm_debug_timing": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
@@ -252,6 +254,7 @@ SIGNATURES = {
     "hsad_r2d2_learner_set_fused": (C.c_int, [_P, C.c_int]),
     "hsad_r2d2_learner_grad": (_P, [_P]),
     "hsad_r2d2_learner_timed_out": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "hsad_r2d2_learner_inject_timeout": (C.c_int, [_P, C.c_int]),
     "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
     "hsad_r2d2_loss_bwd": (C.c_int, [_P, _P]),
     "hsad_r2d2_optimizer_step": (C.c_int, [_P, C.c_float, C.c_float, C.POINTER(_P), _P]),

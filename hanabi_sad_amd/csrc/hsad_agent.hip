@@ -719,6 +719,13 @@ struct hsad_r2d2_learner {
   bool split_bptt = true;     // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
   bool proj_bptt = true;      // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3): default, 1.51 -> 1.46 ms
   bool dgt_in_kernel = true;  // single-chunk fused BPTT writes dG transposed + the bias gradients itself (set_fused bit 6 = off, A/B)
+  bool group_wgrad = true;    // single-chunk fused BPTT: the four LSTM weight gradients and the input layer's as ONE grouped split-K launch of the 256 x 256
+                              // core + one slab pass (hsad_gemm_nt_bf16_group_splitk; set_fused bit 7 = off, A/B)
+  int group_split_l = 3, group_split_in = 8;     // K ranges per LSTM problem / of the input layer's: (4 x 16 tiles) x 3 + 8 tiles x 8 = one item per CU
+  float* group_ws = nullptr;
+  int64_t group_ws_floats = 0;
+  volatile unsigned* h_timeout = nullptr;      // pinned, device-mapped: OR of the sticky timeout words as of the last gathered update (timeout_gather_kernel)
+  unsigned* d_timeout = nullptr;               // its device address
   bool sink_bptt = true;      // ... and the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage (set_fused bit 5; needs bits 3, 4)
   bool fb_split = false, fb_proj = false, fb_sink = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
@@ -883,6 +890,14 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->wgrad_ws, (size_t)L->wgrad_split * H4 * std::max(H, (size_t)online->F) * 4);
   want(&L->wgrad_ws2, pipe0 ? (size_t)L->wgrad_split * H4 * H * 4 : 256);
   want(&L->dGT2, pipe0 ? H4 * Mp * 2 : 256);
+  {
+    // the grouped weight-gradient launch: one work item per CU -- 3/4 of them for the four LSTM problems, 1/4 for the input layer's
+    const int tiles_l = 4 * (int)((H4 + 255) / 256) * (int)((H + 255) / 256), tiles_in = (int)((H + 255) / 256) * (int)((Fp + 255) / 256);
+    L->group_split_l = std::max(1, std::min(8, (3 * L->n_cu / 4) / std::max(1, tiles_l)));
+    L->group_split_in = std::max(1, std::min(16, (L->n_cu - tiles_l * L->group_split_l) / std::max(1, tiles_in)));
+    L->group_ws_floats = pipe0 ? (int64_t)4 * (L->group_split_l + 1) * H4 * H + (int64_t)(L->group_split_in + 1) * H * Fp : 64;
+    want(&L->group_ws, (size_t)L->group_ws_floats * 4);
+  }
   size_t total = 0;
   for (auto& e : plan) total += e.second;
   if (L->arena.need(total + 256)) {
@@ -961,6 +976,19 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
     delete L;
     return afail(HSAD_ERR_HIP, "r2d2_learner_create: stream / event creation failed");
   }
+  {
+    void* hp = nullptr;      // the host word the update's timeout_gather_kernel reports to (pinned + mapped: the kernel stores into host memory)
+    if (hipHostMalloc(&hp, 64, hipHostMallocMapped) == hipSuccess) {
+      *(volatile unsigned*)hp = 0;
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, hp, 0) == hipSuccess) {
+        L->h_timeout = (volatile unsigned*)hp;
+        L->d_timeout = (unsigned*)dp;
+      } else {
+        (void)hipHostFree(hp);
+      }
+    }
+  }
   *out = L;
   return 0;
 }
@@ -972,6 +1000,7 @@ void hsad_r2d2_learner_destroy(hsad_r2d2_learner* L) {
     if (L->ev_ck[i]) (void)hipEventDestroy(L->ev_ck[i]);
   for (hipEvent_t e : {L->ev_a, L->ev_b, L->ev_c, L->ev_d, L->ev_e})
     if (e) (void)hipEventDestroy(e);
+  if (L->h_timeout) (void)hipHostFree((void*)L->h_timeout);
   delete L;
 }
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* L) { return L ? L->gflat : nullptr; }
@@ -1007,51 +1036,86 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->proj_bptt = L->split_bptt && (fused_fwd & 16) != 0;        // bit 4: + projection stage
   L->sink_bptt = L->proj_bptt && (fused_fwd & 32) != 0;         // bit 5: + sink stage (input layer's d x)
   L->dgt_in_kernel = !(fused_fwd & 64);                         // bit 6: transpose passes behind the BPTT launch instead (A/B)
+  L->group_wgrad = !(fused_fwd & 128);                          // bit 7: the round-4 tail (six split-K GEMMs on two streams) instead of the grouped launch (A/B)
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   return 0;
 }
-/* sticky timeout words of the persistent launches (hsad_lstm_sync_timed_out semantics); synchronises */
-int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
-  if (!L || !timed_out) return afail(HSAD_ERR_INVALID, "null argument");
-  HIP_TRY(hipDeviceSynchronize());
-  *timed_out = 0;
+// the sticky timeout words of every counter block a launch of this learner may have used (hsad_lstm_sync_timed_out semantics): a bounded
+// spin that gave up leaves its word set, the kernel's outputs are then garbage
+namespace {
+struct TimeoutWords {
+  const unsigned* p[40];
+  int n;
+};
+__global__ void timeout_gather_kernel(TimeoutWords w, unsigned* host_flag) {
+  unsigned v = 0;
+  for (int i = 0; i < w.n; ++i) v |= w.p[i][0];
+  if (v) __hip_atomic_store(host_flag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+static TimeoutWords timeout_words(const hsad_r2d2_learner* L) {
+  TimeoutWords w;
+  w.n = 0;
   // the sticky word sits behind the counters of a launch: (recurrences) x (row blocks) x (chunk length + 2) words in
   const size_t Tc = (size_t)L->T / pick_chunks(L), nrb = nrb_of(L->B);
   for (int k = 0; k < 2; ++k)
     for (int r = 0; r < 4; ++r)
-      for (int f = 0; f < 2; ++f) {
-        unsigned v = 0;
-        HIP_TRY(hipMemcpy(&v, L->sync[k][r][f] + (size_t)(r + 1) * nrb * (Tc + 2), 4, hipMemcpyDeviceToHost));
-        *timed_out |= (int32_t)v;
-      }
+      for (int f = 0; f < 2; ++f) w.p[w.n++] = L->sync[k][r][f] + (size_t)(r + 1) * nrb * (Tc + 2);
   for (int k = 0; k < 3; ++k)
-    for (int f = 0; f < 2; ++f) {
-      unsigned v = 0;
-      HIP_TRY(hipMemcpy(&v, L->fsync[k][f] + L->fsync_words[k] - 4, 4, hipMemcpyDeviceToHost));
-      *timed_out |= (int32_t)v;
-    }
+    for (int f = 0; f < 2; ++f) w.p[w.n++] = L->fsync[k][f] + L->fsync_words[k] - 4;
   if (L->fb_tc)
-    for (int f = 0; f < 2; ++f) {
-      unsigned v = 0;
-      HIP_TRY(hipMemcpy(&v, L->fbsync[f] + (size_t)(L->fb_split ? (L->fb_proj ? (L->fb_sink ? 8 : 6) : 4) : 2) * nrb * (L->fb_tc + 2), 4, hipMemcpyDeviceToHost));
-      *timed_out |= (int32_t)v;
-    }
-  {
-    unsigned v = 0;      // unchunked single-recurrence launches
-    HIP_TRY(hipMemcpy(&v, L->sync1 + nrb * ((size_t)L->T + 2), 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < 2; ++f)
+      w.p[w.n++] = L->fbsync[f] + (size_t)(L->fb_split ? (L->fb_proj ? (L->fb_sink ? 8 : 6) : 4) : 2) * nrb * (L->fb_tc + 2);
+  w.p[w.n++] = L->sync1 + nrb * ((size_t)L->T + 2);      // unchunked single-recurrence launches
+  return w;
+}
+/* synchronises and reads the words */
+int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* L, int32_t* timed_out) {
+  if (!L || !timed_out) return afail(HSAD_ERR_INVALID, "null argument");
+  HIP_TRY(hipDeviceSynchronize());
+  *timed_out = 0;
+  const TimeoutWords w = timeout_words(L);
+  for (int i = 0; i < w.n; ++i) {
+    unsigned v = 0;
+    HIP_TRY(hipMemcpy(&v, w.p[i], 4, hipMemcpyDeviceToHost));
     *timed_out |= (int32_t)v;
   }
+  return 0;
+}
+// Failing loudly where it happens: every update ends with a one-thread kernel that ORs the sticky words into a pinned
+// host word; every entry point of the learner looks at that word first -- no synchronisation, so a timeout surfaces at the first call
+// made after the failed update has finished on the device (at the latest one update later), whoever drives the learner.
+static int timeout_gather(hsad_r2d2_learner* L, hipStream_t s) {
+  if (!L->d_timeout) return 0;
+  hipLaunchKernelGGL(timeout_gather_kernel, dim3(1), dim3(1), 0, s, timeout_words(L), L->d_timeout);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+static int timeout_check(const hsad_r2d2_learner* L, const char* where) {
+  if (L->h_timeout && *L->h_timeout)
+    return afail(HSAD_ERR_STATE, "%s: a persistent recurrence of an earlier update gave up waiting for a sibling workgroup (were the launch's workgroups "
+                                 "co-resident? foreign kernels on the device?) -- the losses, priorities and gradients since then are not valid", where);
+  return 0;
+}
+/* test hook (fault injection): sets the sticky word of the unchunked launches' block, as a spin that gave up would */
+int hsad_r2d2_learner_inject_timeout(hsad_r2d2_learner* L, int set) {
+  if (!L) return afail(HSAD_ERR_INVALID, "null learner");
+  HIP_TRY(hipDeviceSynchronize());
+  const unsigned v = set ? 1u : 0u;
+  HIP_TRY(hipMemcpy(L->sync1 + nrb_of(L->B) * ((size_t)L->T + 2), &v, 4, hipMemcpyHostToDevice));
+  if (!set && L->h_timeout) *L->h_timeout = 0;
   return 0;
 }
 
 // loss forward: batch tensors [T, rows, ...] with rows = B (IQL) or B_games * num_player (VDN: Q summed over a game's players;
 // reward / bootstrap [T, games], seq_len / weight / loss [games], priority [T, games]).  own_hand may be NULL (pred_weight = 0).
-int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* priv_s_bf16, const float* legal_move, const int64_t* a, const float* reward,
+static int loss_fwd_impl(hsad_r2d2_learner* L, const float* priv_s, const void* priv_s_bf16, const float* legal_move, const int64_t* a, const float* reward,
                        const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
                        float pred_weight, float* loss, float* priority, int want_grad, void* stream) {
   if (!L || (!priv_s && !priv_s_bf16) || !legal_move || !a || !reward || !bootstrap || !seq_len || !loss || !priority || num_player < 1 ||
       L->B % num_player)
     return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: bad arguments");
+  CK(timeout_check(L, "r2d2_loss_fwd"));
   if (pred_weight > 0 && num_player > 1)
     return afail(HSAD_ERR_INVALID, "VDN with the auxiliary task is broken in the reference (aux_task_vdn, SURVEY F6b) and has no defined behaviour");
   if (pred_weight > 0 && !own_hand) return afail(HSAD_ERR_INVALID, "r2d2_loss_fwd: pred_weight > 0 needs own_hand");
@@ -1223,9 +1287,19 @@ int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* pr
 
 // BPTT of the last loss_fwd(want_grad = 1) of mean_b(weight_b * loss_b) into the learner's flat gradient (order = the net's
 // parameter vector).  The batch tensors given to loss_fwd must still be alive.
-int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
+int hsad_r2d2_loss_fwd(hsad_r2d2_learner* L, const float* priv_s, const void* priv_s_bf16, const float* legal_move, const int64_t* a, const float* reward,
+                       const float* bootstrap, const float* seq_len, const float* own_hand, const float* weight, int num_player,
+                       float pred_weight, float* loss, float* priority, int want_grad, void* stream) {
+  const int rc = loss_fwd_impl(L, priv_s, priv_s_bf16, legal_move, a, reward, bootstrap, seq_len, own_hand, weight, num_player, pred_weight, loss, priority,
+                               want_grad, stream);
+  if (rc || want_grad) return rc;       // (with a backward pass to follow, hsad_r2d2_loss_bwd gathers for both)
+  return timeout_gather(L, (hipStream_t)stream);
+}
+
+static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
   if (L) CK(net_wait(L->on, (hipStream_t)stream));
   if (!L || !L->have_fwd) return afail(HSAD_ERR_STATE, "r2d2_loss_bwd: call loss_fwd(want_grad = 1) first");
+  CK(timeout_check(L, "r2d2_loss_bwd"));
   L->have_fwd = false;
   hsad_r2d2_net* on = L->on;
   hipStream_t s = (hipStream_t)stream;
@@ -1312,6 +1386,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   int input_done_above = 0;          // steps >= this have their input-layer backward done on the side stream (0 = none)
   bool sink_used = false;            // the BPTT launch(es) already wrote d x of the input layer (sink stage)
   bool sink_T = false;               // ... transposed, with the bias gradient of net.0
+  bool group = false;                // all weight gradients in one grouped launch (single-chunk fused BPTT)
   const bool fbwd = pipe && L->fused_bwd && L->fwd_frag && B % 32 == 0 && 2 * (H / 32) * ((nrb_of(B) + 7) / 8) <= L->n_cu / 8 && nbc <= 8;
   if (fbwd) {
     // Both layers of a time chunk in ONE persistent launch (hsad_lstm_backward_fused): layer 0 runs a step behind layer 1 and computes
@@ -1336,6 +1411,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     // one chunk: the launch writes dG transposed (and the bias gradients) itself -- no transpose passes in the tail of the update.  The
     // row-major dG is not written then, so this needs the sink stage (otherwise the input layer's backward GEMM reads dG0 row-major)
     const bool dgt_in_kernel = nbc == 1 && L->dgt_in_kernel && use_sink;
+    group = dgt_in_kernel && nfc == 1 && L->group_wgrad && (H4 % 256) == 0 && (H % 256) == 0 && (Mp % 128) == 0 && (Fp % 4) == 0;
     chunk_wgrad = [=](int l, int c, void* st, bf16_t* dGT, float* wsp) -> int {
       const size_t m0 = (size_t)cut[c] * B, Mc = (size_t)(cut[c + 1] - cut[c]) * B;
       if (!dgt_in_kernel) CK(transpose16(L->dG[l] + m0 * H4, (int)Mc, H4, H4, dGT, Mp, g[on->iBih[l]], g[on->iBhh[l]], on->perm32, st));
@@ -1408,6 +1484,7 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
       f ^= 1;
       HIP_TRY(hipEventRecord(L->ev_ck[c], s));
       HIP_TRY(hipStreamWaitEvent(ws, L->ev_ck[c], 0));
+      if (group) continue;               // (one chunk: every weight gradient of the update is one grouped launch behind the BPTT, below)
       CK(chunk_wgrad(1, c, wst, L->dGT, L->wgrad_ws));
       // the last chunk's layer-0 gradients run on the caller's stream behind the input-MLP chain: two streams share the tail
       if (c > 0) CK(chunk_wgrad(0, c, wst, L->dGT, L->wgrad_ws));
@@ -1516,8 +1593,32 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
     CK(transpose16(L->dx1, M, H, H, L->dx1T, Mp, nullptr, nullptr, nullptr, stream));
     CK(hsad_colsum_acc(L->dx1, 1, M, H, H, g[on->iB1], nullptr, nullptr, stream));
   }
-  CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
-  if (defer_l0) CK(chunk_wgrad(0, 0, stream, L->dGT2, L->wgrad_ws2));
+  if (group) {
+    // dW_ih1 | dW_hh1 | dW_ih0 | dW_hh0 = dG_l^T [x_l | h_l delayed]  (K = T x B, rows back in natural gate order through perm32) and
+    // dW_1 = dx1^T a16 -- 96 GFLOP in five problems of 8-16 tiles each: one launch, one item per CU, one slab pass (round 4: six launches
+    // on two streams + four slab passes, 0.22 ms)
+    hsad_gemm_group_item it[5];
+    for (int k = 0; k < 4; ++k) {
+      const int l = 1 - (k >> 1), hh = k & 1;
+      it[k].A = l == 1 ? L->dGT : L->dGT2;
+      it[k].lda = Mp;
+      it[k].B = hh ? hs_d[l] : (l ? hs_x[l - 1] : xinT);
+      it[k].ldb = (hh || l) ? ldh : Mp;
+      it[k].C = hh ? g[on->iWhh[l]] : g[on->iWih[l]];
+      it[k].ldc = H;
+      it[k].row_map = on->perm32;
+      it[k].M = H4; it[k].N = H; it[k].K = Mp; it[k].n_out = H;
+      it[k].split_k = L->group_split_l;
+      it[k].accumulate = 1;
+    }
+    it[4].A = L->dx1T; it[4].lda = Mp; it[4].B = L->a16T; it[4].ldb = Mp; it[4].C = g[on->iW1]; it[4].ldc = F; it[4].row_map = nullptr;
+    it[4].M = H; it[4].N = Fp; it[4].K = Mp; it[4].n_out = F; it[4].split_k = L->group_split_in; it[4].accumulate = 1;
+    if (hsad_gemm_group_workspace_floats(5, it) > L->group_ws_floats) return afail(HSAD_ERR_STATE, "loss_bwd: grouped weight-gradient workspace too small");
+    CK(hsad_gemm_nt_bf16_group_splitk(5, it, L->group_ws, L->group_ws_floats, stream));
+  } else {
+    CK(hsad_gemm_nt_bf16_ex(L->dx1T, Mp, L->a16T, Mp, H, F, Mp, nullptr, g[on->iW1], F, nullptr, 0, 0, 0, L->wgrad_split, nullptr, 0, nullptr, stream));
+    if (defer_l0) CK(chunk_wgrad(0, 0, stream, L->dGT2, L->wgrad_ws2));
+  }
   if (pipe) {
     HIP_TRY(hipEventRecord(L->ev_a, ws));
     HIP_TRY(hipStreamWaitEvent(s, L->ev_a, 0));
@@ -1527,8 +1628,14 @@ int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
 
 // torch.nn.utils.clip_grad_norm_ + Adam.step (selfplay.py:231-235) on the online net + re-derivation of its kernel operands.
 // grad_norm_sq_dev (may be NULL): device float that receives the squared pre-clip global gradient norm.
+int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
+  const int rc = loss_bwd_impl(L, stream);
+  return rc ? rc : timeout_gather(L, (hipStream_t)stream);      // the update's persistent launches are all enqueued: collect their sticky words behind them
+}
+
 int hsad_r2d2_optimizer_step(hsad_r2d2_learner* L, float beta1, float beta2, float** grad_norm_sq_dev, void* stream) {
   if (!L) return afail(HSAD_ERR_INVALID, "null learner");
+  CK(timeout_check(L, "r2d2_optimizer_step"));
   L->step_count++;
   float* slot = nullptr;
   CK(hsad_adam_step_zero_grad(L->on->flat, L->gflat, L->m, L->v, (int64_t)L->on->n_param, L->clip, L->lr, beta1, beta2, L->adam_eps, L->step_count,

@@ -153,7 +153,7 @@ int hsad_gemm_set_pp(int on) {
 // of them when there is enough work (XCD-aware tile order needs blockIdx & 7 == XCD for every item of a workgroup)
 static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   long items = 0;
-  for (int k = 0; k < P.np; ++k) items += (long)(P.p[k].M / 256) * (P.p[k].N / 256) * P.p[k].ksplit;
+  for (int k = 0; k < P.np; ++k) items += (long)(P.p[k].M / 256) * ((P.p[k].N + 255) / 256) * P.p[k].ksplit;
   long grid = std::min<long>(items, (long)n_cu);
   if (grid >= 64) grid &= ~7L;
   // tile order per problem (XCD-aware orders need item & 7 == blockIdx & 7 == XCD: a grid that is a multiple of 8, problems that start at one):
@@ -162,7 +162,7 @@ static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   items = 0;
   for (int k = 0; k < P.np; ++k) {
     G8Prob& q = P.p[k];
-    const int tm = q.M / 256, tn = q.N / 256;
+    const int tm = q.M / 256, tn = (q.N + 255) / 256;
     const long t = (long)tm * tn;
     const bool xcd_ok = (grid % 8) == 0 && (items % 8) == 0;
     q.pn = (tn % 4) == 0 ? 4 : (tn % 2) == 0 ? 2 : 1;
@@ -354,6 +354,75 @@ static int gemm_splitk_impl(const void* A, int lda, const void* B, int ldb, int 
   const size_t n4 = (size_t)M * (N / 4);
   hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, M,
                      N, C32, ldc, row_map, accumulate);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
+// k tiles per range of a grouped split: an even number, as the 256 x 256 core needs
+static inline int group_kchunk(int K, int split_k) {
+  const int nk = K / kBK;
+  int c = (nk + split_k - 1) / split_k;
+  c += c & 1;
+  return std::max(c, 2);
+}
+int64_t hsad_gemm_group_workspace_floats(int n, const hsad_gemm_group_item* items) {
+  if (!items || n < 1) return 0;
+  int64_t w = 0;
+  for (int k = 0; k < n; ++k) {
+    const hsad_gemm_group_item& it = items[k];
+    if (it.K < 128 || it.split_k < 1) return 0;
+    const int kc = group_kchunk(it.K, it.split_k);
+    w += (int64_t)((it.K / kBK + kc - 1) / kc) * it.M * it.N;
+  }
+  return w;
+}
+int hsad_gemm_nt_bf16_group_splitk(int n, const hsad_gemm_group_item* items, float* workspace, int64_t workspace_floats, void* stream) {
+  if (n < 1 || n > kG8MaxProb || !items || !workspace || ((uintptr_t)workspace & 15)) return nfail(HSAD_ERR_INVALID, "gemm_group: 1..%d items, an aligned workspace", kG8MaxProb);
+  if (workspace_floats < hsad_gemm_group_workspace_floats(n, items) || hsad_gemm_group_workspace_floats(n, items) == 0)
+    return nfail(HSAD_ERR_INVALID, "gemm_group: workspace too small (see hsad_gemm_group_workspace_floats) or a bad item");
+  hipStream_t s = (hipStream_t)stream;
+  const int n_cu = device_cus();
+  G8Args P{};
+  G8SumArgs S{};
+  P.np = S.n = n;
+  bool core = g_gemm_pp != 0;
+  float* ws = workspace;
+  int blocks = 0;
+  for (int k = 0; k < n; ++k) {
+    const hsad_gemm_group_item& it = items[k];
+    if (!it.A || !it.B || !it.C || it.M < 1 || it.N < 4 || (it.N & 3) || it.K < 128 || (it.K % 128) || (it.lda & 7) || (it.ldb & 7) || it.n_out < 1 || it.n_out > it.N ||
+        it.split_k < 1 || (((uintptr_t)it.A | (uintptr_t)it.B) & 15))
+      return nfail(HSAD_ERR_INVALID, "gemm_group: item %d: N a multiple of 4, K of 128, lda / ldb of 8, 16-byte aligned operands, 1 <= n_out <= N", k);
+    const int kc = group_kchunk(it.K, it.split_k), nsplit = (it.K / kBK + kc - 1) / kc;
+    if ((it.M % 256) || (size_t)257 * (size_t)std::max(it.lda, it.ldb) * 2 + (size_t)it.K * 2 >= ((size_t)1 << 31)) core = false;
+    G8Prob& q = P.p[k];
+    q.A = (const bf16_t*)it.A; q.A2 = nullptr; q.B = (const bf16_t*)it.B; q.bias = nullptr; q.C32 = ws; q.C16 = nullptr;
+    q.M = it.M; q.N = it.N; q.nk1 = it.K / kBK; q.nk2 = 0;
+    q.lda = it.lda; q.lda2 = it.lda; q.ldb = it.ldb; q.ldc = it.N;
+    q.relu = 0; q.ksplit = nsplit; q.kchunk = kc;
+    q.slab_stride = (unsigned long long)it.M * it.N;
+    G8SumItem& u = S.it[k];
+    u.ws = ws; u.out = it.C; u.row_map = it.row_map; u.M = it.M; u.n_out = it.n_out; u.ldw = it.N; u.ldc = it.ldc; u.nslab = nsplit;
+    u.accumulate = it.accumulate; u.slab_stride = q.slab_stride;
+    blocks += (int)(((long)it.M * ((it.n_out + 3) / 4) + 255) / 256);
+    u.blk_end = blocks;
+    ws += (size_t)nsplit * it.M * it.N;
+  }
+  if (core) {
+    const int rc = g8_launch(G8_F32, P, n_cu, s);
+    if (rc) return rc;
+  } else {
+    for (int k = 0; k < n; ++k) {       // the 128 x 128 kernel, one launch per item, same k ranges, same slabs
+      const hsad_gemm_group_item& it = items[k];
+      const G8Prob& q = P.p[k];
+      int n_split = 1;
+      const int rc = gemm_launch(it.A, it.lda, it.B, it.ldb, it.M, it.N, it.K, nullptr, q.C32, it.N, nullptr, 0, 0, 0, q.ksplit, nullptr, 0, nullptr,
+                                 (size_t)it.M * it.N, &n_split, stream);
+      if (rc) return rc;
+      if (n_split != q.ksplit) return nfail(HSAD_ERR_STATE, "gemm_group: item %d was cut into %d ranges, %d planned", k, n_split, q.ksplit);
+    }
+  }
+  hipLaunchKernelGGL(g8_sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, s, S);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

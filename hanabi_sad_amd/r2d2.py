@@ -131,6 +131,31 @@ def _launch_pair(fn, device, T, Bn, tag, nrec):
     sync_scratch_pair_commit(device, T, Bn, tag, nrec, True)
 
 
+_TIMEOUT_HOST = {}     # device -> pinned int32 [1]: OR of the sticky words as of the last gathered update
+
+
+def gather_timeouts(device):
+    """enqueue (current stream, no synchronisation) the OR of the sticky timeout words of this device's counter blocks into a pinned host
+    word: what poll_timeouts looks at.  R2D2Learner.loss calls it at its end."""
+    words = [b[k[3]:k[3] + 1] for k, b in _SYNC.items() if k[0] == str(device)]
+    if not words:
+        return
+    host = _TIMEOUT_HOST.get(str(device))
+    if host is None:
+        host = _TIMEOUT_HOST[str(device)] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    host.copy_(torch.cat(words).max().reshape(1), non_blocking=True)
+
+
+def poll_timeouts(device, where="R2D2Learner.loss"):
+    """no synchronisation: raise if a persistent recurrence of an update that has FINISHED on the device gave up waiting for a sibling
+    workgroup (its outputs are garbage).  A failure thus surfaces at the next call, whoever drives the learner, instead of at the driver's
+    per-epoch check_sync()."""
+    host = _TIMEOUT_HOST.get(str(device))
+    if host is not None and int(host[0]) != 0:
+        raise _lib.HsadError("%s: a persistent LSTM kernel of an earlier update timed out waiting for a sibling workgroup -- losses, "
+                             "priorities and gradients since then are not valid (check_sync() names the launch)" % where)
+
+
 def check_sync():
     """raise if any persistent recurrence launch gave up waiting for a sibling workgroup (synchronises)"""
     bad = [k for k, b in _SYNC.items() if int(b[k[3]].item()) != 0]
@@ -616,6 +641,13 @@ class R2D2Learner:
         if self.precision == "fp32":
             from .r2d2_f32 import loss_f32
             return loss_f32(self, batch, weight, pred_weight, compute_grad)
+        poll_timeouts(self.device)
+        try:
+            return self._loss(batch, weight, pred_weight, compute_grad)
+        finally:
+            gather_timeouts(self.device)
+
+    def _loss(self, batch, weight, pred_weight, compute_grad):
         lib = _lib.load_library()
         on, tg, d = self.online, self.target, self.device
         priv, legal, a = batch["priv_s"], batch["legal_move"], batch["a"]

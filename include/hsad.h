@@ -418,6 +418,26 @@ int hsad_gemm_nt_bf16_splitk(const void* A, int lda, const void* B, int ldb, int
 /* the same, ADDED to C32 instead of overwriting it (slabs, then one adding pass: deterministic) -- a contraction that arrives in pieces */
 int hsad_gemm_nt_bf16_splitk_acc(const void* A, int lda, const void* B, int ldb, int M, int N, int K, int split_k, float* workspace,
                                  float* C32, int ldc, const int32_t* row_map, void* stream);
+/* Several split-K GEMMs C_i (+)= A_i B_i^T (fp32 out) as ONE launch of the 256 x 256 core plus ONE slab-summing pass: the weight
+ * gradients of a learner update (reference: loss.backward() of pyhanabi/selfplay.py:226 -- dW = dG^T [x | h] for both LSTM layers and the
+ * input layer, K = T x B = 10,240) are a handful of problems that are each too small to fill the chip.  Every item's K is cut into
+ * split_k ranges (an even number of 64-deep k tiles each), every (problem, range, tile) is a work item of the same launch, partial
+ * results go to `workspace` (sum over items of ranges x M x N floats: hsad_gemm_group_workspace_floats) and are added up in range order
+ * (deterministic).  M a multiple of 256, N of 4, K of 128, lda / ldb of 8; B is read up to its row N - 1 only.  Items the core does not
+ * take (shape) run on the 128 x 128 kernel, one launch each, into the same slabs. */
+typedef struct hsad_gemm_group_item {
+  const void* A;            /* bf16 [M, K], row stride lda */
+  const void* B;            /* bf16 [N, K], row stride ldb */
+  float* C;                 /* fp32 [M, >= n_out], row stride ldc (any) */
+  const int32_t* row_map;   /* optional [M]: result row r is written to row row_map[r] of C */
+  int32_t lda, ldb, ldc;
+  int32_t M, N, K;
+  int32_t n_out;            /* columns of the result that are written to C (<= N; the operands may be zero-padded past it) */
+  int32_t split_k;
+  int32_t accumulate;       /* C += instead of C = */
+} hsad_gemm_group_item;
+int64_t hsad_gemm_group_workspace_floats(int n, const hsad_gemm_group_item* items);
+int hsad_gemm_nt_bf16_group_splitk(int n, const hsad_gemm_group_item* items, float* workspace, int64_t workspace_floats, void* stream);
 /* hsad_transpose_bf16 that also accumulates (atomically) the column sums of src into colsum[col_map ? col_map[c] : c]
  * (and colsum2): the bias gradients come for free while the weight-gradient operand is transposed */
 int hsad_transpose_bf16_colsum(const void* src, int R, int C, int ld_src, void* dst, int ld_dst, float* colsum, float* colsum2,
@@ -720,10 +740,16 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *   bit 2      hsad_r2d2_optimizer_step re-derives the LSTM matrices (95 % of the operand bytes) on the learner's side stream, next to the
  *              following update's input layer; every entry point that reads a net's LSTM operands waits for that half first (an event, no
  *              host synchronisation).  Off by default: measured 1.521 against 1.504 ms per update with everything in line
+ *   bit 7      off: the four LSTM weight gradients and the input layer's of a single-chunk fused BPTT as six split-K GEMMs on two streams
+ *              (round 4) instead of one grouped launch of the 256 x 256 core + one slab pass (hsad_gemm_nt_bf16_group_splitk)
  *   bits 8-15  time chunks of the fused BPTT, 1..8 (the weight gradients are added up per chunk); 0 keeps the current setting */
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
+/* (hsad_r2d2_loss_fwd / _loss_bwd / _optimizer_step fail with HSAD_ERR_STATE by themselves once an EARLIER update's persistent recurrence
+ * has given up waiting for a sibling workgroup: every update reports its sticky words to a pinned host word, looked at without a
+ * synchronisation.)  Test hook: set / clear such a word as a timed-out launch would. */
+int hsad_r2d2_learner_inject_timeout(hsad_r2d2_learner* learner, int set);
 /* R2D2Agent.loss forward: priv_s [T,rows,F], legal_move [T,rows,A], a int64 [T,rows], own_hand [T,rows,3*hand] (NULL without the
  * aux task); reward / bootstrap [T,B], seq_len / weight [B] with B = rows / num_player games -> loss [B], priority [T,B].
  * want_grad keeps what loss_bwd needs (weight required).  priv_s_bf16 (instead of priv_s): [T*rows, in_dim_padded] zero-padded bf16,

@@ -485,3 +485,48 @@ def test_fused_recurrences_stress_ten_seconds_of_randomly_timed_foreign_kernels(
     torch.cuda.synchronize()
     assert int(bad) == 0 and evals >= 200 and issued[0] >= 500, (int(bad), evals, issued[0])
     L.check_sync()                                                   # hsad_lstm_sync_timed_out() == 0
+
+
+def test_a_timed_out_recurrence_fails_the_next_call_of_any_driver():
+    """a persistent recurrence that gives up waiting leaves garbage, and only the repo's own driver polled the flag per
+    epoch.  Now every update reports its sticky words to a pinned host word and hsad_r2d2_loss_fwd / _loss_bwd / _optimizer_step look at it
+    first (no synchronisation): with a word set the way a timed-out launch sets it (fault-injection hook), the update in flight still
+    returns -- its kernels are already enqueued -- and the NEXT call raises, also through the Python-orchestrated learner's own check."""
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.composite import CompositeLearner
+    from hanabi_sad_amd import r2d2
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    F, A, H, T, B = 838, 21, 512, 16, 128
+    W, Wt = _rand_net(F, H, A, seed=3), _rand_net(F, H, A, seed=4)
+    batch, weight = _rand_batch(T, B, F, A)
+    cl = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    cl.loss(batch, weight, 0.0)
+    cl.optimizer_step()
+    torch.cuda.synchronize()
+    _lib.check(cl.lib.hsad_r2d2_learner_inject_timeout(cl.h, 1))
+    cl.loss(batch, weight, 0.0)          # enqueued before anybody could know; its gather kernel reports the word
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HsadError, match="gave up waiting"):
+        cl.optimizer_step()
+    with pytest.raises(_lib.HsadError, match="gave up waiting"):
+        cl.loss(batch, weight, 0.0)
+    _lib.check(cl.lib.hsad_r2d2_learner_inject_timeout(cl.h, 0))
+    cl.loss(batch, weight, 0.0)
+    cl.optimizer_step()
+    cl.check_sync()
+    # the Python-orchestrated schedule: the same protocol over its torch-owned counter blocks
+    pl = r2d2.R2D2Learner(W, Wt, 3, 0.999, device=DEV)
+    pl.loss(batch, weight, 0.0)
+    torch.cuda.synchronize()
+    key, blk = next((k, b) for k, b in r2d2._SYNC.items() if k[0] == str(torch.device(DEV)) or k[0] == DEV)
+    blk[key[3]] = 1
+    try:
+        pl.loss(batch, weight, 0.0)
+        torch.cuda.synchronize()
+        with pytest.raises(_lib.HsadError, match="timed out"):
+            pl.loss(batch, weight, 0.0)
+    finally:
+        blk[key[3]] = 0
+        r2d2.gather_timeouts(torch.device(DEV))
+        torch.cuda.synchronize()
+    pl.loss(batch, weight, 0.0)
