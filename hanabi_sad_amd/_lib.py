@@ -255,6 +255,8 @@ SIGNATURES = {
     "hsad_r2d2_learner_grad": (_P, [_P]),
     "hsad_r2d2_learner_timed_out": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "hsad_r2d2_learner_inject_timeout": (C.c_int, [_P, C.c_int]),
+    "hsad_r2d2_loss_bwd_weighted": (C.c_int, [_P, _P, _P, _P]),
+    "hsad_r2d2_learner_set_optim": (C.c_int, [_P, C.c_float, C.c_float, C.c_float]),
     "hsad_r2d2_loss_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, C.c_int, _P]),
     "hsad_r2d2_loss_bwd": (C.c_int, [_P, _P]),
     "hsad_r2d2_optimizer_step": (C.c_int, [_P, C.c_float, C.c_float, C.POINTER(_P), _P]),

@@ -198,10 +198,12 @@ class CompositeLearner:
 
     def __init__(self, online_weights, target_weights, multi_step, gamma, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device="cuda:0",
                  T=None, rows=None):
+        """online_weights / target_weights: state dicts (the learner then owns two new library nets) or existing CNets (the online one
+        created with_backward=True) -- what torch_r2d2.R2D2Agent passes, whose nn.Parameters alias those nets"""
         self.device = torch.device(device)
         self.lib = _lib.load_library()
-        self.online = CNet(online_weights, device, with_backward=True)
-        self.target = CNet(target_weights, device)
+        self.online = online_weights if isinstance(online_weights, CNet) else CNet(online_weights, device, with_backward=True)
+        self.target = target_weights if isinstance(target_weights, CNet) else CNet(target_weights, device)
         self.cfg = (int(multi_step), float(gamma), float(lr), float(eps), float(grad_clip))
         self.multi_step, self.gamma = int(multi_step), float(gamma)
         self.h, self.shape = None, None
@@ -222,6 +224,8 @@ class CompositeLearner:
         _lib.check(self.lib.hsad_r2d2_learner_create(self.online.h, self.target.h, int(T), int(rows), ms, gm, lr, eps, clip, C.byref(self.h)))
         _lib.check(self.lib.hsad_r2d2_learner_set_schedule(self.h, int(self.chunks), int(self.wgrad_split)))
         _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
+        if clip <= 0:
+            _lib.check(self.lib.hsad_r2d2_learner_set_optim(self.h, lr, eps, 0.0))      # no clipping
         self.shape = (T, rows)
         n = self.online.flat.numel()
         self.gflat = _view(self.lib.hsad_r2d2_learner_grad(self.h), n, self.device, self)
@@ -265,10 +269,23 @@ class CompositeLearner:
                                                keep[0].data_ptr() if p16 is not None else None, keep[1].data_ptr(), keep[2].data_ptr(), p(batch["reward"]),
                                                p(batch["bootstrap"]), p(batch["seq_len"]), None if own is None else keep[3].data_ptr(),
                                                keep[4].data_ptr(), P, float(pred_weight), loss.data_ptr(), prio.data_ptr(),
-                                               int(compute_grad), _s(d)))
-        if compute_grad:
+                                               1 if compute_grad else 0, _s(d)))
+        if compute_grad == "later":      # the autograd face: the importance weights arrive with the backward call (backward_weighted)
+            self._seq_len = batch["seq_len"].contiguous()
+        elif compute_grad:
             _lib.check(self.lib.hsad_r2d2_loss_bwd(self.h, _s(d)))
         return loss, prio
+
+    def backward_weighted(self, weight):
+        """BPTT of the last loss(..., compute_grad="later") for weight_b = B x d objective / d loss_b (hsad_r2d2_loss_bwd_weighted)"""
+        w = weight.contiguous().float()
+        self._alive.append(w)
+        _lib.check(self.lib.hsad_r2d2_loss_bwd_weighted(self.h, w.data_ptr(), self._seq_len.data_ptr(), _s(self.device)))
+
+    def set_optim(self, lr, eps, max_grad_norm):
+        self.cfg = self.cfg[:2] + (float(lr), float(eps), float(max_grad_norm) if max_grad_norm else 0.0)
+        if self.h is not None:
+            _lib.check(self.lib.hsad_r2d2_learner_set_optim(self.h, self.cfg[2], self.cfg[3], self.cfg[4]))
 
     def optimizer_step(self, beta1=0.9, beta2=0.999):
         """-> the pre-clip global gradient norm (device scalar: a view of the library's ring of the last twelve steps' norms; no torch op)"""

@@ -1628,6 +1628,45 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
 
 // torch.nn.utils.clip_grad_norm_ + Adam.step (selfplay.py:231-235) on the online net + re-derivation of its kernel operands.
 // grad_norm_sq_dev (may be NULL): device float that receives the squared pre-clip global gradient norm.
+namespace {
+// d mean_b(weight_b loss_b) / d online_qa from the TD errors of the last forward pass, for weights that arrive AFTER it (same arithmetic
+// as td_loss_kernel / loss_tail_kernel: -clamp(err, -1, 1) * mask * weight / B)
+__global__ void dqa_reweight_kernel(const float* __restrict__ err, const float* __restrict__ seq_len, const float* __restrict__ weight, int T, int B,
+                                    float* __restrict__ dqa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * B) return;
+  const int t = i / B, b = i - t * B;
+  const float mask = (float)t < seq_len[b] ? 1.f : 0.f;
+  const float g = fminf(fmaxf(err[i], -1.f), 1.f);
+  dqa[i] = -g * mask * weight[b] / (float)B;
+}
+}  // namespace
+
+/* loss_bwd with importance weights that were not known at loss_fwd time: torch.autograd hands d objective / d loss_b to the backward of
+ * R2D2Agent.loss (the reference driver forms (loss * weight).mean() AFTER agent.loss returned: pyhanabi/selfplay.py:226-228), i.e.
+ * weight_b = B * d objective / d loss_b.  Recomputes d loss / d qa from the saved TD errors and lets loss_bwd rebuild d loss / d heads
+ * (the un-fused heads-backward kernel: the same arithmetic as the fused loss tail).  weight, seq_len: [games], alive until the call returns
+ * its work to the stream. */
+int hsad_r2d2_loss_bwd_weighted(hsad_r2d2_learner* L, const float* weight, const float* seq_len, void* stream) {
+  if (!L || !weight || !seq_len) return afail(HSAD_ERR_INVALID, "r2d2_loss_bwd_weighted: null argument");
+  if (!L->have_fwd) return afail(HSAD_ERR_STATE, "r2d2_loss_bwd: call loss_fwd(want_grad = 1) first");
+  const int Bg = L->B / L->num_player, n = L->T * Bg;
+  hipLaunchKernelGGL(dqa_reweight_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L->err, seq_len, weight, L->T, Bg, L->dqa);
+  HIP_TRY(hipGetLastError());
+  L->b_weight = weight;
+  L->dheads_ready = false;
+  return hsad_r2d2_loss_bwd(L, stream);
+}
+
+/* learning rate, Adam epsilon and the clipping norm of hsad_r2d2_optimizer_step (<= 0: no clipping), changeable between steps */
+int hsad_r2d2_learner_set_optim(hsad_r2d2_learner* L, float lr, float eps, float max_grad_norm) {
+  if (!L || !(lr >= 0.f) || !(eps > 0.f)) return afail(HSAD_ERR_INVALID, "r2d2_learner_set_optim: bad argument");
+  L->lr = lr;
+  L->adam_eps = eps;
+  L->clip = max_grad_norm > 0.f ? max_grad_norm : 3.0e38f;
+  return 0;
+}
+
 int hsad_r2d2_loss_bwd(hsad_r2d2_learner* L, void* stream) {
   const int rc = loss_bwd_impl(L, stream);
   return rc ? rc : timeout_gather(L, (hipStream_t)stream);      // the update's persistent launches are all enqueued: collect their sticky words behind them

@@ -746,6 +746,11 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
+/* hsad_r2d2_loss_bwd with importance weights that arrive after the forward pass (the torch.autograd face of R2D2Agent.loss: the reference's
+ * driver multiplies by the weights after agent.loss() returned, pyhanabi/selfplay.py:226-228): weight_b = B x d objective / d loss_b */
+int hsad_r2d2_loss_bwd_weighted(hsad_r2d2_learner* learner, const float* weight, const float* seq_len, void* stream);
+/* learning rate / Adam epsilon / clipping norm (<= 0: none) of hsad_r2d2_optimizer_step */
+int hsad_r2d2_learner_set_optim(hsad_r2d2_learner* learner, float lr, float eps, float max_grad_norm);
 /* (hsad_r2d2_loss_fwd / _loss_bwd / _optimizer_step fail with HSAD_ERR_STATE by themselves once an EARLIER update's persistent recurrence
  * has given up waiting for a sibling workgroup: every update reports its sticky words to a pinned host word, looked at without a
  * synchronisation.)  Test hook: set / clear such a word as a timed-out launch would. */

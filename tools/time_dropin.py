@@ -71,28 +71,28 @@ n1, t1 = num_act(), time.perf_counter()
 idle_rate = (n1 - n0) / (t1 - t0)
 # the trainer's side of selfplay.py:208-244 next to the running Context, on the driver's thread and stream: sample -> loss -> backward ->
 # clip + Adam -> update_priority; actor model sync every 10 updates, target sync every 2,500 (the reference's defaults)
-from hanabi_sad_amd.composite import CompositeLearner
-learner = CompositeLearner(W, W, NSTEP, GAMMA, device=DEV, T=T, rows=128)
-
-
-class LearnerAgent:
-    def state_dict(self):
-        d = {"online_net." + k: v for k, v in learner.online.w.items()}
-        d.update({"target_net." + k: v for k, v in learner.target.w.items()})
-        return d
+# -- with the reference's OWN agent calls (pyhanabi/selfplay.py:128-149, 218-241): `import r2d2` is the torch face over the kernels
+import r2d2
+agent = r2d2.R2D2Agent(False, NSTEP, GAMMA, ETA, DEV, F, 512, A, 2, 5, False)
+sd0 = {"online_net." + k: v for k, v in W.items()}
+sd0.update({"target_net." + k: v for k, v in W.items()})
+agent.load_state_dict(sd0)
+optim = torch.optim.Adam(agent.online_net.parameters(), lr=6.25e-5, eps=1.5e-5)
 
 
 def one_update(u):
     if u % 2500 == 0:
-        learner.sync_target_with_online()
+        agent.sync_target_with_online()
     if u % 10 == 0:
-        runner.update_model(LearnerAgent())
+        runner.update_model(agent)
     batch, weight = replay.sample(128, DEV)
-    b = {"priv_s": batch.obs["priv_s"], "legal_move": batch.obs["legal_move"], "a": batch.action["a"], "reward": batch.reward,
-         "bootstrap": batch.bootstrap, "seq_len": batch.seq_len, "own_hand": batch.obs["own_hand"]}
-    loss, prio = learner.loss(b, weight, 0.0)                     # priority [T, B] per step (r2d2.py:488-499)
-    learner.optimizer_step()
-    replay.update_priority(rela.aggregate_priority(prio, batch.seq_len, ETA))     # selfplay.py:236-240
+    loss, priority = agent.loss(batch, 0.0, None)                 # priority [T, B] per step (r2d2.py:488-499)
+    loss = (loss * weight).mean()
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(agent.online_net.parameters(), 5.0)
+    optim.step()
+    optim.zero_grad()
+    replay.update_priority(rela.aggregate_priority(priority, batch.seq_len, ETA))     # selfplay.py:236-240
 
 
 results = []
@@ -124,7 +124,7 @@ for label, stream, pace in (("UNCHANGED driver (no set_pace call: auto pace)  ",
         n1, t1 = num_act(), time.perf_counter()
     torch.cuda.current_stream().wait_stream(stream)
     results.append((label, it * 128 / (t1 - t0), (n1 - n0) / (t1 - t0), replay.size()))
-learner.check_sync()
+agent._learner.check_sync()
 ctx.pause()
 ctx.terminate()
 print("drop-in API (hanalearn / rela mirrors): %d threads x %d games = %d games built in %.2f s, merged into %d batched loop(s)"
@@ -132,7 +132,7 @@ print("drop-in API (hanalearn / rela mirrors): %d threads x %d games = %d games 
 print("  Context thread alone        : %.2f M acts/s  (%.3f ms per step of all games)" % (idle_rate / 1e6, G * P / idle_rate * 1e3))
 for label, train_rate, busy_rate, size in results:
     print("  + learner on the driver thread, %s: Speed: train: %.1f, act: %.1f, buffer_size: %d   (sequences/s, acts/s)" % (label, train_rate, busy_rate, size))
-del ctx, loops, runner, replay, learner
+del ctx, loops, runner, replay, agent, optim
 torch.cuda.empty_cache()
 args = parse_args(["--num_game", str(G), "--replay_buffer_size", "65536", "--sad", "1"])
 tr = Trainer(args, DEV)
