@@ -400,7 +400,8 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
             link.finish()
         torch.cuda.synchronize()
         wall = (wall_end - t0) / rounds * 1e3
-        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "rounds_open_at_once": ahead, "wire_bytes_per_sequence": shard.wire_bytes(),
+        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "transport": link.transport, "rounds_open_at_once": ahead,
+               "wire_bytes_per_sequence": shard.wire_bytes(),
                "batch_bytes_per_rank_message": shard.wire_bytes() * batch, "param_bucket_bytes": n_param * 4,
                "round_wall_ms": wall, "per_round_ms": link.timings(),
                "note": "sections are HIP-event times on the learner's exchange stream, averaged over all rounds (param_send_ms / "

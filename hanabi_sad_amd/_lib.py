@@ -160,6 +160,7 @@ SIGNATURES = {
     "hsad_lstm_debug_timing": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "hsad_lstm_debug_timing32": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "hsad_lstm_debug_enable": (C.c_int, [C.c_int]),
+    "hsad_debug_resident_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "hsad_lstm_sync_timed_out": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "hsad_gemm_nt_bf16_ex": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, C.c_int,
@@ -244,6 +245,12 @@ SIGNATURES = {
     "hsad_comm_star_collect": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "hsad_comm_star_serve": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int64, _P]),
     "hsad_comm_all_stats": (_P, [_P]),
+    "hsad_ipc_handle_bytes": (C.c_int, []),
+    "hsad_ipc_alloc": (C.c_int, [C.c_int64, C.POINTER(_P), _P, C.c_int]),
+    "hsad_ipc_free": (C.c_int, [_P]),
+    "hsad_ipc_open": (C.c_int, [_P, C.POINTER(_P)]),
+    "hsad_ipc_close": (C.c_int, [_P]),
+    "hsad_ipc_put": (C.c_int, [_P, _P, C.c_int64, _P]),
     "hsad_r2d2_act": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_q_of": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "hsad_r2d2_compute_priority": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_double,

@@ -13,6 +13,7 @@
 // ships one) keeps using that copy.  Every call is stream-ordered; nothing here synchronises the host.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <rccl/rccl.h>
 
 #include <cstdarg>
@@ -369,6 +370,47 @@ int hsad_comm_star_serve(hsad_comm* down, hsad_comm* up, hsad_replay* shard, int
   NCCL_TRY(R->Send(up->my_stats, 2, ncclFloat64, root, up->comm, s));
   NCCL_TRY(R->GroupEnd());
   if (flags & HSAD_LINK_PARAMS) NCCL_TRY(R->Recv(params, (size_t)param_count, ncclFloat32, root, down->comm, s));
+  return HSAD_OK;
+}
+
+// ---- one-sided transport between the processes of a node: landing buffers exported by IPC handle, written by the SENDER with a plain
+// device-to-device copy (SDMA engines over xGMI between GPUs; no kernel resident on either side), announced through the rendezvous store.
+// dist.py ReplayLink(transport = "ipc") builds the learner <-> actor rounds on it: a posted RCCL receive is a kernel that sits on CUs until
+// its peer sends, and the learner's whole-chip persistent launches cannot start next to it (measured: tools/resident_probe.py) ----
+int hsad_ipc_alloc(int64_t bytes, void** dev_ptr, void* handle_out, int handle_bytes) {
+  if (bytes < 1 || !dev_ptr || !handle_out || handle_bytes < (int)sizeof(hipIpcMemHandle_t))
+    return cfail(HSAD_ERR_INVALID, "ipc_alloc: bad arguments (the handle needs %d bytes)", (int)sizeof(hipIpcMemHandle_t));
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, (size_t)bytes));
+  hipError_t e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(static_cast<hipIpcMemHandle_t*>(handle_out), p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return cfail(HSAD_ERR_HIP, "ipc_alloc: %s (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set for dmabuf IPC)", hipGetErrorString(e));
+  }
+  *dev_ptr = p;
+  return HSAD_OK;
+}
+int hsad_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+int hsad_ipc_free(void* dev_ptr) {
+  if (dev_ptr) HIP_TRY(hipFree(dev_ptr));
+  return HSAD_OK;
+}
+int hsad_ipc_open(const void* handle, void** dev_ptr) {
+  if (!handle || !dev_ptr) return cfail(HSAD_ERR_INVALID, "ipc_open: null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  HIP_TRY(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return HSAD_OK;
+}
+int hsad_ipc_close(void* dev_ptr) {
+  if (dev_ptr) HIP_TRY(hipIpcCloseMemHandle(dev_ptr));
+  return HSAD_OK;
+}
+/* the put: bytes from this process's device memory into a mapped landing buffer, stream-ordered on the sender */
+int hsad_ipc_put(void* dst_mapped, const void* src, int64_t bytes, void* stream) {
+  if (!dst_mapped || !src || bytes < 1) return cfail(HSAD_ERR_INVALID, "ipc_put: bad arguments");
+  HIP_TRY(hipMemcpyAsync(dst_mapped, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return HSAD_OK;
 }
 

@@ -791,6 +791,28 @@ int hsad_lstm_set_exchange_mode(int force_cross_xcd) {
   return HSAD_OK;
 }
 
+namespace {
+// residency stand-in of a pending communication kernel (an RCCL receive whose peer has not sent yet): every workgroup sleeps on its CU
+// until the host sets *flag (pinned host memory) or max_ticks of the 100 MHz clock have passed
+__global__ void resident_spin_kernel(const volatile uint32_t* flag, long long max_ticks) {
+  extern __shared__ unsigned char spin_lds[];
+  if (threadIdx.x == 0) spin_lds[0] = 1;
+  const long long t0 = (long long)wall_clock64();
+  while (!*flag && (long long)wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(64);
+}
+}  // namespace
+/* Developer / test hook: n_wg workgroups of `threads` threads holding lds_bytes of LDS stay RESIDENT on `stream`
+ * until *flag_host_mapped != 0 or max_us have passed -- what a posted RCCL receive looks like to the whole-chip persistent launches of
+ * the learner while its peer has not sent yet. */
+int hsad_debug_resident_kernel(int n_wg, int threads, int lds_bytes, const void* flag_host_mapped, int max_us, void* stream) {
+  if (n_wg < 1 || n_wg > 1024 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 65536 || !flag_host_mapped || max_us < 1 || max_us > 2000000)
+    return nfail(HSAD_ERR_INVALID, "debug_resident_kernel: bad arguments");
+  hipLaunchKernelGGL(resident_spin_kernel, dim3(n_wg), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, (const volatile uint32_t*)flag_host_mapped,
+                     (long long)max_us * 100);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
+}
+
 int hsad_lstm_debug_enable(int enable) {
   g_lstm_dbg_enable = enable != 0;
   return HSAD_OK;

@@ -284,6 +284,141 @@ class _NullCtx:
         return False
 
 
+class _IpcTransport:
+    """One-sided point-to-point messages between the ranks of ONE node without a communication kernel: every rank owns landing rings in
+    its own device memory (hsad_ipc_alloc), exported by IPC handle through the rendezvous store; a SEND is a plain device-to-device copy
+    from the sender's stream into the receiver's ring slot (SDMA over xGMI between GPUs) followed, once the copy has finished, by a key in
+    the store (a helper thread waits for the copy's event); a RECEIVE is the host waiting for that key and one local copy out of the slot.
+    Why not RCCL here: a posted receive is a kernel that stays resident on CUs until its peer sends, and the learner's fused recurrences
+    need every CU (tools/resident_probe.py: a 2.5 ms wait next to an update stretches it 1.5-2 x).  Messages between a pair are matched
+    in order, like RCCL's; a ring of `depth` slots per (source, destination, direction) bounds the sender's lead (the star round's own
+    causality keeps it far below that: a slot is reused `depth` messages later, after at least one full round trip)."""
+
+    def __init__(self, store, keys, rank, world, learner, device, down_bytes, up_bytes, depth):
+        import ctypes as C
+        import queue
+        import threading
+        from . import _lib
+        from .composite import _view
+        self.lib, self.store, self.keys = _lib.load_library(), store, keys + "ipc/"
+        self.rank, self.world, self.learner, self.device, self.depth = rank, world, learner, torch.device(device), int(depth)
+        align = lambda n: (int(n) + 255) // 256 * 256
+        self.slot = {"down": align(down_bytes), "up": align(up_bytes)}
+        # what this rank receives: the learner one "up" ring per actor, an actor one "down" ring from the learner
+        self.sources = [p for p in range(world) if p != learner] if rank == learner else [learner]
+        self.tag_in = "up" if rank == learner else "down"
+        nbytes = len(self.sources) * self.depth * self.slot[self.tag_in]
+        hb = self.lib.hsad_ipc_handle_bytes()
+        handle, ptr = (C.c_ubyte * hb)(), C.c_void_p()
+        # Every rank must end up on the same transport: allocate + export, open the peers' arenas, then agree through the store -- if any
+        # rank failed at either step (no dmabuf IPC, no peer access), ALL ranks give up (self.ok = False) and the link uses the backend
+        self.base, self.peer_base, self.ok, why = None, {}, True, ""
+        rc = self.lib.hsad_ipc_alloc(nbytes, C.byref(ptr), handle, hb)
+        if rc:
+            why = self.lib.hsad_last_error().decode()
+            store.set(self.keys + "handle/%d" % rank, b"")
+        else:
+            self.base, self.nbytes = ptr.value, nbytes
+            self.mine = _view(self.base, nbytes, self.device, self, dtype=torch.uint8)
+            store.set(self.keys + "handle/%d" % rank, bytes(handle))
+        mine_ok = rc == 0
+        for p in ([k for k in range(world) if k != learner] if rank == learner else [learner]):
+            h = store.get(self.keys + "handle/%d" % p)
+            if len(h) != hb:
+                mine_ok = False
+                continue
+            q = C.c_void_p()
+            if self.lib.hsad_ipc_open((C.c_ubyte * hb).from_buffer_copy(h), C.byref(q)):
+                mine_ok, why = False, self.lib.hsad_last_error().decode()
+            else:
+                self.peer_base[p] = q.value
+        store.set(self.keys + "ok/%d" % rank, b"1" if mine_ok else ("0 " + why).encode())
+        votes = [store.get(self.keys + "ok/%d" % p) for p in range(world)]
+        self.ok = all(v == b"1" for v in votes)
+        self.sent, self.got = {}, {}              # messages sent to / consumed from a peer so far
+        if not self.ok:
+            self.why = "; ".join("rank %d: %s" % (p, v.decode()[2:]) for p, v in enumerate(votes) if v != b"1")
+            for q in self.peer_base.values():
+                self.lib.hsad_ipc_close(C.c_void_p(q))
+            if self.base:
+                self.lib.hsad_ipc_free(C.c_void_p(self.base))
+            self.q = None
+            return
+        self.q = queue.Queue()
+        self.err = None
+        self.thread = threading.Thread(target=self._notify, daemon=True)
+        self.thread.start()
+
+    def _notify(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            ev, key, _keep = item
+            try:
+                ev.synchronize()
+                self.store.set(key, b"1")
+            except Exception as e:       # surfaced by the next send / recv of the owning thread
+                self.err = e
+                return
+
+    def _ring_index(self, owner, src):
+        """position of `src`'s ring inside `owner`'s arena"""
+        if owner == self.learner:
+            return [p for p in range(self.world) if p != self.learner].index(src)
+        return 0
+
+    def send(self, t, peer):
+        import ctypes as C
+        from . import _lib
+        if self.err is not None:
+            raise self.err
+        tag = "down" if self.rank == self.learner else "up"
+        n = self.sent.get(peer, 0)
+        self.sent[peer] = n + 1
+        nb = t.numel() * t.element_size()
+        assert t.is_contiguous() and nb <= self.slot[tag], (nb, self.slot[tag])
+        dst = self.peer_base[peer] + (self._ring_index(peer, self.rank) * self.depth + n % self.depth) * self.slot[tag]
+        st = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.hsad_ipc_put(C.c_void_p(dst), C.c_void_p(t.data_ptr()), nb, C.c_void_p(st.cuda_stream)))
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self.q.put((ev, self.keys + "m/%d/%d/%d" % (self.rank, peer, n), t))
+        return None
+
+    def recv(self, t, peer):
+        n = self.got.get(peer, 0)
+        self.got[peer] = n + 1
+        return (t, peer, n)
+
+    def wait(self, work):
+        """the host waits for the message, then enqueues the copy out of the landing slot on the current stream"""
+        if work is None:
+            return
+        if self.err is not None:
+            raise self.err
+        t, peer, n = work
+        key = self.keys + "m/%d/%d/%d" % (peer, self.rank, n)
+        # polled, not store.wait(): a blocking wait holds the store client's lock, and this process's notifier thread needs the same client
+        # to announce the message the peer is waiting for before it sends this one
+        import time
+        deadline = time.monotonic() + 300.0
+        while not self.store.check([key]):
+            if self.err is not None:
+                raise self.err
+            if time.monotonic() > deadline:
+                raise RuntimeError("ReplayLink ipc transport: rank %d waited 300 s for message %d of rank %d" % (self.rank, n, peer))
+            time.sleep(5e-5)
+        self.store.delete_key(key)
+        nb = t.numel() * t.element_size()
+        off = (self._ring_index(self.rank, peer) * self.depth + n % self.depth) * self.slot[self.tag_in]
+        t.view(torch.uint8).reshape(-1).copy_(self.mine[off:off + nb]) if t.dtype != torch.uint8 else t.reshape(-1).copy_(self.mine[off:off + nb])
+
+    def close(self):
+        if self.q is not None:
+            self.q.put(None)
+
+
 class ReplayLink:
     """The learner <-> actors exchange of a multi-GPU job, asynchronous and packed (the reference's
     PrioritizedReplay::sample / updatePriority + BatchRunner::updateModel across processes: rela/prioritized_replay.h:208-257,
@@ -332,7 +467,7 @@ class ReplayLink:
     FLAG_SLOTS = 64        # flags of round r live in key r % 64: the learner's host is never more than four rounds ahead of its own
     PARAMS, STOP, HAS_PRIO, PRIME = 1, 2, 4, 8   # exchange stream (hdr_ev below) and that stream cannot pass a round an actor has not served
 
-    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None, mode=None, name="", ahead=1):
+    def __init__(self, shard, batch, beta, device, learner_rank=0, depth=2, param_numel=0, store=None, mode=None, name="", ahead=1, transport=None):
         import os
         import torch.distributed as dist
         self._keys = "hsad/link/%s" % (name + "/" if name else "")     # a second link of the same job (bench.py's A/B) has its own keys
@@ -391,6 +526,26 @@ class ReplayLink:
         self.hdr_host = [torch.zeros(B, dtype=torch.float32).pin_memory() if cuda else torch.zeros(B) for _ in range(4 + S)]
         self.hdr_ev = [None] * (4 + S)
         self.timer, self.timer_down = _Timer(d), _Timer(d)
+        # transport of the star round's point-to-point messages: the process group's backend (RCCL kernels, or gloo through host memory), or
+        # "ipc" (HSAD_LINK_TRANSPORT): one-sided device-to-device copies into IPC-mapped landing rings + store flags, no communication kernel
+        # resident on any GPU (class _IpcTransport; one node only)
+        # Default ("auto"): ipc for an RCCL job whose ranks all sit on this node (what `bench.py --gpus N` / torchrun --nnodes=1 start), the
+        # backend otherwise (gloo smoke runs keep their host-staged path unless asked).
+        want = (transport if transport is not None else os.environ.get("HSAD_LINK_TRANSPORT", "")) or "auto"
+        if want not in ("auto", "backend", "ipc"):
+            raise ValueError("ReplayLink transport must be 'auto', 'backend' or 'ipc', not %r" % (want,))
+        if want == "auto":
+            one_node = int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) == self.world
+            want = "ipc" if (dist.get_backend() == "nccl" and one_node) else "backend"
+        self.transport, self.ipc = "backend", None
+        if want == "ipc" and star and self.world > 1 and cuda:
+            hdr_bytes = self.hdr.numel() * 4
+            ipc = _IpcTransport(self.store, self._keys, self.rank, self.world, self.learner, d, max(hdr_bytes, 4 * int(param_numel)),
+                                max(B * wb, 64), 2 * (self.ahead + 2))
+            if ipc.ok:
+                self.ipc, self.transport, self.staged = ipc, "ipc", False
+            elif self.rank == self.learner:
+                print("ReplayLink: the ipc transport is not available (%s) -- using the %s backend" % (ipc.why, dist.get_backend()), flush=True)
         self._rounds = []           # learner: rounds begun and not yet finished, oldest first
         self._done_ev = {}          # round -> event on the up stream: its replies are in and unpacked
         self._bucket_ev = None      # the last parameter send has left the bucket
@@ -433,6 +588,8 @@ class ReplayLink:
         import torch.distributed as dist
         if not ops:
             return None
+        if self.ipc is not None:
+            return ("ipc", [self.ipc.send(t.contiguous(), peer) if kind == "send" else self.ipc.recv(t, peer) for kind, t, peer in ops])
         host = {}                                # gloo with GPU shards: ONE host copy of a tensor that goes to several peers
         def _h(t):
             if id(t) not in host:
@@ -446,6 +603,10 @@ class ReplayLink:
 
     def _p2p_end(self, pending):
         if pending is None:
+            return
+        if pending[0] == "ipc":
+            for w in pending[1]:
+                self.ipc.wait(w)         # the HOST waits for the store key of the message (sends: nothing to wait for)
             return
         works, staged = pending
         for w in works:
@@ -522,7 +683,7 @@ class ReplayLink:
                 rec["used"].record_stream(self.xs)      # allocated on the down stream, read when the round is collected on the up stream
                 built = torch.cuda.Event()
                 built.record()
-            nccl = self.xd is not None and not self.staged
+            nccl = self.xd is not None and not self.staged and self.ipc is None
             rec["send"] = self._p2p_begin([("send", hdr, p) for p in peers], self.g_down)
             if nccl or not peers:                 # RCCL: the down stream waits; gloo: the works are waited for when the round is collected
                 self._p2p_end(rec.pop("send"))
@@ -548,7 +709,7 @@ class ReplayLink:
                 self.shard.answer(hdr[B:2 * B], me)
             stats_in[L].copy_(self.shard.stats())
             t.mark("serve_ms", rec["marks"])
-        if self.xs is not None and not self.staged:   # RCCL: the stream waits for the replies, the host does not -- the whole round is enqueued now
+        if self.xs is not None and not self.staged and self.ipc is None:   # RCCL: the stream waits for the replies, the host does not -- the whole round is enqueued now
             self._star_collect(rec)
         return rec
 
@@ -737,3 +898,7 @@ class ReplayLink:
         out["wait_for_batch_ms"] = self.wait_ms / max(self.wait_n, 1)
         out["rounds_ahead"] = self.ahead
         return out
+
+    def close(self):
+        if self.ipc is not None:
+            self.ipc.close()

@@ -497,7 +497,7 @@ def main(argv=None):
             run_link_learner(tr, args, link, args.num_update, on_update=show)
             dt, c = time.time() - t0, LinkCounters(link)
             print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt, c.num_act() / dt, c.size()))
-            print("exchange per round (ms): %s" % ", ".join("%s %.3f" % kv for kv in sorted(link.timings().items())))
+            print("exchange per round (ms), transport %s: %s" % (link.transport, ", ".join("%s %.3f" % kv for kv in sorted(link.timings().items()))))
         dist.barrier()
         dist.destroy_process_group()
         return

@@ -383,6 +383,9 @@ int hsad_lstm_debug_timing(uint64_t* out16, int reset);
 int hsad_lstm_debug_timing32(uint64_t* out32, int reset);   /* + slots 16-31: the fused BPTT kernel (top layer 16-21, lower layer 24-29) */
 /* phase timers of the FUSED persistent kernels (off by default: a stamp costs ~0.1 us of the ~5 us step it measures) */
 int hsad_lstm_debug_enable(int enable);
+/* test hook: n_wg workgroups (threads, lds_bytes each) resident on `stream` until *flag_host_mapped (pinned host word) != 0 or max_us --
+ * the footprint of a posted communication kernel whose peer has not answered, next to the learner's whole-chip persistent launches */
+int hsad_debug_resident_kernel(int n_wg, int threads, int lds_bytes, const void* flag_host_mapped, int max_us, void* stream);
 /* measurement hook for the fused cell kernel (hsad_lstm_cell_fused, i.e. every LSTM layer of an acting step): while enabled, each
  * launch is bracketed by HIP events on its own stream; _read returns the average duration and FLOP of the launches recorded since
  * the last read (synchronises) and clears the record.  bench.py's actor roofline. */
@@ -919,6 +922,17 @@ const int64_t* hsad_actor_last_actions(const hsad_actor* actor, const int64_t** 
 /* n-step priorities the last step pushed, float32 [*n] (per (game, player) row, VDN: per game); NULL when that step was still
  * filling the n-step window */
 const float* hsad_actor_last_priority(const hsad_actor* actor, int32_t* n);
+
+/* ---- one-sided intra-node transport (dist.py ReplayLink(transport = "ipc")): landing buffers exported by IPC handle and written by the
+ * SENDER with a device-to-device copy -- SDMA over xGMI, no kernel resident on either GPU while a peer has not answered (a posted RCCL
+ * receive is one, and the learner's whole-chip persistent launches cannot start next to it).  Completion is announced by the sender's
+ * host through the rendezvous store.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC). ---- */
+int hsad_ipc_handle_bytes(void);
+int hsad_ipc_alloc(int64_t bytes, void** dev_ptr, void* handle_out, int handle_bytes);   /* zero-filled device memory + its handle */
+int hsad_ipc_free(void* dev_ptr);
+int hsad_ipc_open(const void* handle, void** dev_ptr);                                    /* map a peer's allocation */
+int hsad_ipc_close(void* dev_ptr);
+int hsad_ipc_put(void* dst_mapped, const void* src, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

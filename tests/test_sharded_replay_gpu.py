@@ -111,6 +111,30 @@ def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path, extra):
     assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and ("exchange_ms" in out.stdout or "batch_gather_ms" in out.stdout)
 
 
+def test_three_rank_selfplay_over_the_kernel_free_ipc_transport():
+    """The same three-rank job with the star round's messages on ReplayLink(transport = "ipc") (HSAD_LINK_TRANSPORT): rows, statistics,
+    headers and the parameter bucket travel as one-sided device-to-device copies into IPC-mapped landing rings of the receiving process
+    (three processes, one GPU: hipIpcOpenMemHandle of another process's allocation on the same device), announced through the rendezvous
+    store -- no RCCL / gloo message carries data, no communication kernel waits on a CU (a posted RCCL receive would
+    sit next to the learner's whole-chip persistent launches).  The process group (gloo here) only provides the store."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "hanabi_sad_amd.selfplay", "--num_game", "512", "--num_update", "45",
+           "--burn_in_frames", "300", "--rnn_hid_dim", "256", "--batchsize", "64", "--dist_backend", "gloo", "--actor_sync_freq", "10"]
+    env = dict(os.environ, HSAD_LINK_DEBUG="1", HSAD_LINK_TRANSPORT="ipc", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "LINK_DEBUG" not in out.stdout, out.stdout[-2000:]
+    assert out.stdout.count("Speed: train:") == 1 and "update 40 loss" in out.stdout and "transport ipc" in out.stdout, out.stdout[-1500:]
+
+
 def test_device_side_sharded_draw_equals_the_host_choreography():
     """hsad_replay_stats / _serve / _assemble / _update_owned (what dist.ReplayLink runs, no host round trip) against the host path
     they replace (priority_sum -> stratified_positions / split_positions -> sample_at -> update_priority): same owners, same
