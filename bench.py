@@ -39,7 +39,7 @@ def algorithmic_bytes_per_step(P, F, A, H, sad):
 
 # committed rocprofv3 PMC summaries, newest round first (profiles/, collected with separate --pmc WRITE_SIZE / FETCH_SIZE passes and
 # corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py); a leg is read from the newest file that holds it
-PMC_FILES = ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+PMC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
 
 
 def pmc_leg(leg):
@@ -84,7 +84,7 @@ def fused_traffic_bytes(which="fwd"):
 def cell_traffic_bytes():
     """HBM bytes per launch of the fused cell kernel inside an acting step (one launch = the online net's cell, which also writes the fp32
     state, and the target net's)"""
-    return pmc_kernel("actor", "lstm_cell_pp_kernel")
+    return pmc_kernel("actor", "gemm8_kernel<2") or pmc_kernel("actor", "lstm_cell_pp_kernel")
 
 
 def env5_traffic_bytes(games, chunk, sad):
@@ -99,7 +99,7 @@ def env5_traffic_bytes(games, chunk, sad):
 def mfma_counters():
     """MFMA-busy COUNTER figures of the three MFMA kernels from the committed rocprofv3 PMC pass (profiles/rNN_mfma_util.json, written by
     tools/mfma_util.sh): {kernel: {mfma_busy, flop_frac, avg_duration_us}}; {} when never collected"""
-    for name in ("r04_mfma_util.json",):
+    for name in ("r05_mfma_util.json", "r04_mfma_util.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -269,6 +269,54 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     }
 
 
+def gemm_core_bench(dev, n=8192, reps=12):
+    """The 256 x 256 phase-interleaved MFMA core every GEMM-shaped kernel of the hot path now runs on (gemm8_kernel: the fused cell of an acting
+    step, the learner's weight gradients, the input layer), as a PLAIN bf16 GEMM of exactly known FLOP count on random operands (normal and
+    uniform [-1, 1): operand data moves the sustained clock) -- timed here, with HIP events on the launch stream; the MFMA-busy COUNTER of the
+    same GEMM is the `calib` leg of profiles/rNN_mfma_util.json."""
+    from hanabi_sad_amd.r2d2 import gemm_nt
+    out = {}
+    for fill in ("normal", "uniform"):
+        mk = (lambda *s: torch.randn(*s, device=dev)) if fill == "normal" else (lambda *s: torch.rand(*s, device=dev) * 2 - 1)
+        A, B = mk(n, n).to(torch.bfloat16), mk(n, n).to(torch.bfloat16)
+        for kind in ("fp32", "bf16"):
+            Cm = torch.empty(n, n, device=dev, dtype=torch.float32 if kind == "fp32" else torch.bfloat16)
+            f = (lambda: gemm_nt(A, B, n, n, n, out32=Cm)) if kind == "fp32" else (lambda: gemm_nt(A, B, n, n, n, out16=Cm))
+            for _ in range(4):
+                f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            out["%s_operands_%s_out" % (fill, kind)] = {"avg_launch_ms": ms, "tflops": 2.0 * n ** 3 / (ms * 1e-3) / 1e12}
+            del Cm
+        del A, B
+    best = out["normal_operands_fp32_out"]["tflops"]
+    torch.cuda.empty_cache()
+    return {"config": {"workload": "C = A B^T, %d^3, bf16 operands, fp32 accumulate, one launch of gemm8_kernel (256 workgroups, persistent over 1,024 tiles)" % n},
+            "runs": out,
+            "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<G8_F32> (fp32 output through wave-private LDS, full 128-byte rows), normal-distributed operands",
+                         "achieved": best, "peak": 2500.0, "unit": "TFLOP/s", "frac": best / 2500.0, "traffic": None,
+                         "algorithmic_flop_per_launch": 2.0 * n ** 3, "avg_launch_ms": out["normal_operands_fp32_out"]["avg_launch_ms"],
+                         "mfma_busy_counter": (mfma_calib() or None)}}
+
+
+def mfma_calib():
+    """the calibration GEMM's counter figures from the committed PMC pass (profiles/rNN_mfma_util.json, leg `calib`)"""
+    for name in ("r05_mfma_util.json", "r04_mfma_util.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name))).get("calib", {})
+        except Exception:
+            continue
+        for k, r in rec.items():
+            return {"kernel": k, "flop_frac": r.get("flop_frac"), "mfma_busy_over_gui_active": r.get("mfma_busy_frac_if_gui_is_summed_over_8_xcds"),
+                    "avg_duration_us": r.get("avg_duration_us_uninstrumented"), "source": "profiles/" + name}
+    return None
+
+
 def actor_bench(dev, games=16384, steps=160, warmup=120):
     """The rollout with the agent in the loop (SURVEY.md §8 rows a/f; what the reference's actor threads + BatchRunner do):
     one DeviceActor.step() = reset finished games -> observe -> R2D2 act (eps-greedy, SAD greedy action) -> env step ->
@@ -331,10 +379,10 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
            "loop_body": "hsad_actor_step (C ABI, one call per step)" if tr.actor.c_actor is not None else "python (actor.DeviceActor.step)",
            "host_issue_us_per_step": host_issue_us,
            "learner_iteration_ms_on_rollout_data": it_ms, "replay_bytes": tr.replay.bytes(),
-           "roofline": {"bound": "mfma", "kernel": "lstm_cell_pp_kernel (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
+           "roofline": {"bound": "mfma", "kernel": "gemm8_kernel<G8_CELL> (fused [x | h] [W_ih | W_hh]^T GEMM + LSTM cell update, %d x %d x %d, 256 x 256 tiles, "
                                                    "phase-interleaved k loop; the online and the target net's cell of a layer are ONE launch of two problems: 2 launches per step)" % (games * 2, 2048, 1024),
                         "achieved": cell_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": cell_tf / 2500.0, "traffic": cell_traffic_bytes(),
-                        "mfma_busy_counter": mfma_counters().get("lstm_cell_pp_kernel"),
+                        "mfma_busy_counter": mfma_counters().get("gemm8_kernel") or mfma_counters().get("lstm_cell_pp_kernel"),
                         "algorithmic_bytes_per_launch": 2 * (2 * games * 2 * 512 * 2 + 2048 * 1024 * 2 + games * 2 * 512 * 4 + games * 2 * 512 * 2) + 2 * games * 2 * 512 * 4,
                         "avg_launch_ms": ms.value, "in_step_launches_timed": nl.value, "algorithmic_flop_per_launch": fl.value,
                         "launches_per_step": nl.value / 40.0, "share_of_step": nl.value / 40.0 * ms.value / (dt * 1e3)},
@@ -724,11 +772,17 @@ def main():
             out["env_configs4"] = env_config4_bench(dev, sad=False)
             out["env_configs4_sad"] = env_config4_bench(dev, sad=True)
         if world == 1 and not args.no_learner:
+            out["gemm_core"] = gemm_core_bench(dev)
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:
             out["actor"] = actor_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        # what in this line is NOT measured by this run: the HBM-traffic and MFMA-busy counter figures are read from the committed rocprofv3
+        # PMC passes (a PMC pass cannot run inside the driver's command); every time, rate and fraction is measured here
+        out["profile_sources"] = {"every `traffic` field": "profiles/" + (pmc_leg("env")[1] or "-") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh)",
+                                  "every `mfma_busy_counter` field": "profiles/r05_mfma_util.json or r04 (rocprofv3 --pmc SQ_* pass, tools/mfma_util.sh)",
+                                  "everything else": "measured in this run"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

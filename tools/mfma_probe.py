@@ -1,8 +1,8 @@
 """One leg per invocation, run under rocprofv3 by tools/mfma_util.sh:
-  calib    a plain bf16 GEMM of known MFMA count (8192^3 on gemm_nt_bf16_kernel<128,128>: 2 * 8192^3 FLOP = 33,554,432 wave-level
+  calib    a plain bf16 GEMM of known MFMA count (8192^3 fp32-out on gemm8_kernel<G8_F32>, the 256 x 256 core: 2 * 8192^3 FLOP = 33,554,432 wave-level
            v_mfma_f32_32x32x16_bf16) -- pins what SQ_VALU_MFMA_BUSY_CYCLES counts per instruction on this chip in the same tool chain
   learner  composite learner updates at configs[2] (lstm_fused_fwd_kernel / lstm_fused_bwd_kernel inside real updates)
-  actor    steady-state acting steps at 16,384 games (lstm_cell_pp_kernel inside real steps)"""
+  actor    steady-state acting steps at 16,384 games (gemm8_kernel<G8_CELL> inside real steps)"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -89,8 +89,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
                 ("learner update: transpose_bf16_kernel", r"transpose_bf16_kernel", None, ""),
                 ("learner update: sum_slabs_kernel", r"sum_slabs_kernel", None, ""),
                 ("learner update: adam_kernel", r"adam_kernel", None, "")],
-    "actor": [("actor step: lstm_cell_pp_kernel<true> (one launch = the online AND the target net's cell of a layer: 2 x 32,768 rows x 2048 x 1024; "
-               "online pass writes fp32 state + bf16 output, target pass bf16 output only)", r"lstm_cell_pp_kernel<true", CELL_ALGO_STATE + CELL_ALGO_NOSTATE, ""),
+    "actor": [("actor step: gemm8_kernel<G8_CELL> (one launch = the online AND the target net's cell of a layer: 2 x 32,768 rows x 2048 x 1024; "
+               "online pass writes fp32 state + bf16 output, target pass bf16 output only)", r"gemm8_kernel<2", CELL_ALGO_STATE + CELL_ALGO_NOSTATE, ""),
               ("actor step: gemm_nt_bf16_kernel<128,128> (input linear / heads)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
               ("actor step: env_kernel<1,2,5> G=16384", r"env_kernel<1, 2, 5>", None, ""),
               ("actor step: cast_pad_bf16_vec8_kernel", r"cast_pad_bf16_vec8_kernel", None, ""),
