@@ -73,7 +73,7 @@ def measured_traffic_bytes(G, mode, chunk=0):
 
 def gemm_traffic_bytes():
     """HBM bytes per launch of the learner's LSTM input-projection GEMM (10240x2048x512)"""
-    return pmc_kernel("gemm", "gemm_nt_bf16_kernel")
+    return pmc_kernel("gemm", "gemm8_kernel") or pmc_kernel("gemm", "gemm_nt_bf16_kernel")
 
 
 def fused_traffic_bytes(which="fwd"):
@@ -261,7 +261,7 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
                      "algorithmic_flop_per_launch": f_fl.value, "share_of_update": f_ms.value / (dt * 1e3) if dt > 0 else None,
                      "mfma_busy_counter": counters.get("lstm_fused_fwd_kernel")},
         "roofline_projection_gemm_rounds_1_2": {
-            "bound": "mfma", "kernel": "gemm_nt_bf16_kernel<128,128> (LSTM input projection %dx%dx%d of the chunk-pipelined schedule; online + target "
+            "bound": "mfma", "kernel": "gemm8_kernel<G8_F32>, the 256 x 256 core since round 5 (LSTM input projection %dx%dx%d of the chunk-pipelined schedule; online + target "
                                        "net = one launch of two problems, avg_launch_ms is per problem)" % (M, N, K),
             "achieved": gemm_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": gemm_tf / 2500.0, "traffic": gemm_traffic_bytes(),
             "avg_launch_ms": gemm_ms, "in_update_launches_timed": g_n.value, "problems_per_launch": g_np.value,

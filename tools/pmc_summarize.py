@@ -78,7 +78,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
               r"env_rollout_kernel<5, 4>", ALGO_ENV5 * 50, "iterations_per_launch=50")],
     "env5_literal": [("env_rollout_kernel<5,4> persistent fused rollout, configs[4] literally: G=16384 5-player hand-4 colour shuffle, no SAD, "
                       "50 iterations per launch", r"env_rollout_kernel<5, 4>", ALGO_ENV5_LITERAL * 50, "iterations_per_launch=50")],
-    "gemm": [("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
+    "gemm": [("gemm8_kernel<G8_F32> (the 256 x 256 core) LSTM input projection 10240x2048x512, fp32 output", r"gemm8_kernel<1", GEMM_ALGO, ""),
+             ("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
     "learner": [("learner update: lstm_fused_fwd_kernel<16> (2 nets x 2 layers x 80 steps per launch)", r"lstm_fused_fwd_kernel<16>", FUSED_FWD_ALGO, ""),
                 ("learner update: lstm_fused_bwd_kernel<64> (2 layers x 80 steps per launch)", r"lstm_fused_bwd_kernel<64>", FUSED_BWD_ALGO, ""),
                 ("learner update: loss_tail_kernel", r"loss_tail_kernel", None, ""),
@@ -87,11 +88,15 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
                 ("learner update: lstm_seq_fwd_kernel<16> (4 recurrences x 20 steps per launch)", r"lstm_seq_fwd_kernel<16>", None, ""),
                 ("learner update: lstm_seq_bwd_kernel<64> (2 recurrences x 20 steps per launch)", r"lstm_seq_bwd_kernel<64>", None, ""),
                 ("learner update: transpose_bf16_kernel", r"transpose_bf16_kernel", None, ""),
-                ("learner update: sum_slabs_kernel", r"sum_slabs_kernel", None, ""),
+                ("learner update: sum_slabs_kernel", r"(?<!g8_)sum_slabs_kernel", None, ""),
+                ("learner update: gemm8_kernel<G8_F32> (the five weight-gradient problems, one grouped split-K launch)", r"gemm8_kernel<1", None, ""),
+                ("learner update: gemm8_kernel<G8_BF16> (input layer, online + target)", r"gemm8_kernel<0", None, ""),
+                ("learner update: g8_sum_slabs_kernel", r"g8_sum_slabs_kernel", None, ""),
                 ("learner update: adam_kernel", r"adam_kernel", None, "")],
     "actor": [("actor step: gemm8_kernel<G8_CELL> (one launch = the online AND the target net's cell of a layer: 2 x 32,768 rows x 2048 x 1024; "
                "online pass writes fp32 state + bf16 output, target pass bf16 output only)", r"gemm8_kernel<2", CELL_ALGO_STATE + CELL_ALGO_NOSTATE, ""),
-              ("actor step: gemm_nt_bf16_kernel<128,128> (input linear / heads)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
+              ("actor step: gemm8_kernel<G8_BF16> (input layer, online + target net in one launch)", r"gemm8_kernel<0", None, ""),
+              ("actor step: gemm_nt_bf16_kernel<128,64> (heads)", r"gemm_nt_bf16_kernel<128, 64>", None, ""),
               ("actor step: env_kernel<1,2,5> G=16384", r"env_kernel<1, 2, 5>", None, ""),
               ("actor step: cast_pad_bf16_vec8_kernel", r"cast_pad_bf16_vec8_kernel", None, ""),
               ("actor step: pack_rows_kernel", r"pack_rows_kernel", None, ""),
