@@ -234,8 +234,44 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
     fused_tf = f_fl.value / (f_ms.value * 1e-3) / 1e12 if f_ms.value > 0 else 0.0
     bptt_tf = b_fl.value / (b_ms.value * 1e-3) / 1e12 if b_ms.value > 0 else 0.0
     counters = mfma_counters()
+    # the same update through the reference's agent API (`import r2d2`: nn.Module R2D2Agent over the kernels, autograd loss, torch.optim.Adam +
+    # clip_grad_norm_ -- the calls of pyhanabi/selfplay.py:218-241 -- and with the fused HsadAdam)
+    face = {}
+    try:
+        import r2d2 as r2d2_face
+        import rela
+        rb = rela.RNNTransition({"priv_s": batch["priv_s"], "legal_move": batch["legal_move"], "own_hand": batch["own_hand"]}, {"a": batch["a"]},
+                                batch["reward"], torch.zeros_like(batch["reward"]), batch["bootstrap"], batch["seq_len"])
+        sd = {"online_net." + k: v for k, v in W.items()}
+        sd.update({"target_net." + k: v for k, v in W.items()})
+        for key, fused_opt in (("torch_adam_ms_per_update", False), ("hsad_adam_ms_per_update", True)):
+            ag = r2d2_face.R2D2Agent(False, 3, 0.999, 0.9, str(dev), F, H, A, 2, 5, False)
+            ag.load_state_dict(sd)
+            opt = r2d2_face.HsadAdam(ag.online_net.parameters(), ag, lr=6.25e-5, eps=1.5e-5, max_grad_norm=5.0) if fused_opt else \
+                torch.optim.Adam(ag.online_net.parameters(), lr=6.25e-5, eps=1.5e-5)
+
+            def upd_face():
+                l, _ = ag.loss(rb, 0.0, None)
+                (l * weight).mean().backward()
+                if not fused_opt:
+                    torch.nn.utils.clip_grad_norm_(ag.online_net.parameters(), 5.0)
+                opt.step()
+                opt.zero_grad()
+            for _ in range(warmup + 3):
+                upd_face()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(updates):
+                upd_face()
+            torch.cuda.synchronize()
+            face[key] = (time.perf_counter() - t0) / updates * 1e3
+            del ag, opt
+        face["share_of_composite_rate"] = {k.replace("_ms_per_update", ""): dt * 1e3 / v for k, v in face.items() if k.endswith("_ms_per_update")}
+    except Exception as e:      # (the face is a convenience layer: its absence must not cost the learner's number)
+        face = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
         "value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3, "python_schedule_ms_per_update": dt_py * 1e3,
+        "reference_agent_api": face,
         "chunk_pipelined_schedule_ms_per_update": dt_chunked * 1e3,
         "repeats": {"blocks": len(blocks), "updates_per_block": updates, "ms_per_update_median": per[len(per) // 2], "ms_per_update_min": per[0],
                     "ms_per_update_max": per[-1]},

@@ -19,6 +19,8 @@
 //    pure per-lane fp32 math in the epilogue (no shuffles, no extra pass over HBM).
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
+#include <vector>
 
 #include <cmath>
 #include <type_traits>
@@ -149,26 +151,6 @@ int hsad_gemm_set_pp(int on) {
   return HSAD_OK;
 }
 
-// counter blocks of the dynamically scheduled launches of the 256 x 256 core: 1,024 zero-initialised blocks of 16 ints per device, handed out
-// round-robin (two launches in flight on different streams never share one; a block is cleared by the last workgroup of the launch that used it)
-static int* g8_counter_block() {
-  static std::atomic<int*> base[64];
-  static std::atomic<unsigned> next[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  int* b = base[dev].load();
-  if (!b) {
-    void* p = nullptr;
-    if (hipMalloc(&p, 1024 * 16 * sizeof(int)) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, 1024 * 16 * sizeof(int));
-    (void)hipDeviceSynchronize();
-    int* expected = nullptr;
-    if (base[dev].compare_exchange_strong(expected, (int*)p)) b = (int*)p;
-    else { (void)hipFree(p); b = expected; }
-  }
-  return b + (size_t)(next[dev].fetch_add(1) % 1024) * 16;
-}
-
 // one launch of the grouped 256 x 256 core over P.np problems (item_end / order are filled in here): a workgroup per CU, a multiple of 8
 // of them when there is enough work (XCD-aware tile order needs blockIdx & 7 == XCD for every item of a workgroup)
 static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
@@ -204,15 +186,24 @@ static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   if (cell_wide && epi == G8_CELL_NOSTATE) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL_NOSTATE, 0, true> : gemm8_kernel<G8_CELL_NOSTATE, kCellStoreAux, true>;
   if (g_lstm_dbg_enable && epi == G8_CELL) kp = cell_wide ? gemm8_kernel<G8_CELL, kCellStoreAux, true, true> : gemm8_kernel<G8_CELL, kCellStoreAux, false, true>;
   if (g_lstm_dbg_enable && epi == G8_BF16) kp = gemm8_kernel<G8_BF16, kCellStoreAux, false, true>;
-  // work items claimed dynamically (default) or walked statically (HSAD_G8_DYNAMIC=0): results are identical, only who computes what changes
-  static const int dynamic = getenv("HSAD_G8_DYNAMIC") ? atoi(getenv("HSAD_G8_DYNAMIC")) : 1;
-  P.ctr = (dynamic && items > grid) ? g8_counter_block() : nullptr;
   P.stagger = 0;
   if (stagger_pct > 0 && items >= 2L * grid) {
     const double item_us = 1.55 * P.p[0].kchunk + 6.0;      // k tiles at the core's rate + an epilogue
     P.stagger = (int)(item_us * 100.0 * stagger_pct / 100.0);   // 10 ns ticks
   }
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  {
+    // (the attribute sticks per function and device: set once, not on every launch of the acting loop)
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(mu);
+    const std::pair<const void*, int> key(reinterpret_cast<const void*>(kp), dev);
+    if (std::find(done.begin(), done.end(), key) == done.end()) {
+      HIP_TRY(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done.push_back(key);
+    }
+  }
   hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(512), lds, s, P);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;

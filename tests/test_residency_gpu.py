@@ -90,3 +90,4 @@ def test_the_ipc_transports_copies_leave_the_update_at_its_speed():
     with_copies = _median_update(upd, round_traffic)
     lr.check_sync()
     assert with_copies <= 1.05 * base, "%.3f ms per update next to the round's copies against %.3f undisturbed" % (with_copies * 1e3, base * 1e3)
+
