@@ -186,6 +186,12 @@ static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   if (cell_wide && epi == G8_CELL_NOSTATE) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL_NOSTATE, 0, true> : gemm8_kernel<G8_CELL_NOSTATE, kCellStoreAux, true>;
   if (g_lstm_dbg_enable && epi == G8_CELL) kp = cell_wide ? gemm8_kernel<G8_CELL, kCellStoreAux, true, true> : gemm8_kernel<G8_CELL, kCellStoreAux, false, true>;
   if (g_lstm_dbg_enable && epi == G8_BF16) kp = gemm8_kernel<G8_BF16, kCellStoreAux, false, true>;
+  // pair launches of one shape: the problems' rounds interleaved per XCD (developer switch HSAD_G8_INTERLEAVE=0: problem 1 behind problem 0)
+  static const int interleave = getenv("HSAD_G8_INTERLEAVE") ? atoi(getenv("HSAD_G8_INTERLEAVE")) : 1;
+  P.interleave = 0;
+  if (interleave && P.np == 2 && (grid % 8) == 0 && P.p[0].ksplit == 1 && P.p[1].ksplit == 1 && P.p[0].M == P.p[1].M && P.p[0].N == P.p[1].N &&
+      P.p[0].nk1 + P.p[0].nk2 == P.p[1].nk1 + P.p[1].nk2 && P.p[0].item_end % 256 == 0 && P.p[0].order == P.p[1].order && P.p[0].order != 0)
+    P.interleave = 1;
   P.stagger = 0;
   if (stagger_pct > 0 && items >= 2L * grid) {
     const double item_us = 1.55 * P.p[0].kchunk + 6.0;      // k tiles at the core's rate + an epilogue
