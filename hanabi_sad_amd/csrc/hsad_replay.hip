@@ -1287,7 +1287,8 @@ static float* canon_slot(hsad_replay* r, int* slot, hipStream_t s) {
   r->canon_next = (r->canon_next + 1) % hsad_replay::kCanonSlots;
   // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call; otherwise wait
   // for THAT draw's stream (not for whichever stream the object saw last: a flush on a side stream is not what holds the slot)
-  if (*r->h_done < r->slot_seq[*slot] && r->slot_stream[*slot]) (void)hipStreamSynchronize(r->slot_stream[*slot]);
+  // (slot_seq 0 = never used; the stream itself may be the null stream, a valid one to wait for)
+  if (r->slot_seq[*slot] && *r->h_done < r->slot_seq[*slot]) (void)hipStreamSynchronize(r->slot_stream[*slot]);
   r->slot_seq[*slot] = ++r->draw_seq;     // the draw about to be issued
   r->slot_stream[*slot] = s;
   return r->h_canon_ring + (size_t)*slot * kMaxBatch;

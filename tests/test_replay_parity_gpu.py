@@ -464,3 +464,43 @@ def test_the_stream_fence_takes_any_number_of_streams():
     one, many = run(False), run(True)
     assert one[:2] == many[:2] and abs(one[2] - many[2]) <= 1e-6 * abs(one[2])
     assert torch.equal(one[3], many[3]) and torch.equal(one[4], many[4])
+
+
+@pytest.mark.parametrize("use_default_stream", [True, False])
+def test_a_host_running_many_draws_ahead_of_the_device_keeps_every_draws_uniforms(use_default_stream):
+    """The uniforms of a draw travel through a ring of eight pinned staging slots; a slot is rewritten only once the draw that read it
+    has run (hsad_replay.hip canon_slot).  The device is held back by a spinning kernel while the host issues twelve draws (outstanding
+    depth 8 twice over): every one of them must pick the sequences the same generator picks when the host waits after each draw.  On the
+    DEFAULT stream too -- its handle is the null pointer, which the slot bookkeeping once took for `no stream yet`."""
+    import ctypes as C
+    from hanabi_sad_amd import _lib
+    from hanabi_sad_amd.replay import DeviceReplay
+    lib = _lib.load_library()
+    T, d, cap, B, n_draws = 4, 3, 512, 32, 12
+    rng = np.random.default_rng(3)
+    obs, a, reward, terminal, bootstrap, seq_len = make_sequences(rng, cap, T, d, 0)
+    prio = (rng.integers(1, 64, cap) / 16.0).astype(np.float32)
+    stream = torch.cuda.default_stream(torch.device(DEV)) if use_default_stream else torch.cuda.Stream(torch.device(DEV))
+    flag = torch.zeros(16, dtype=torch.int32).pin_memory()
+    picked = []
+    for held in (False, True):
+        with torch.cuda.stream(stream):
+            rep = DeviceReplay(cap, 7, 1.0, 0.5, 0, T, [("s", d, torch.float32)], DEV)
+            rep.set_outstanding(8)
+            rep.add({"s": dev(obs)}, dev(reward), dev(terminal), dev(bootstrap), dev(seq_len), dev(prio))
+            torch.cuda.synchronize()
+            if held:        # 60 ms of device time in front of everything the host issues next
+                _lib.check(lib.hsad_debug_resident_kernel(1, 64, 0, C.c_void_p(flag.data_ptr()), 60000, C.c_void_p(stream.cuda_stream)))
+            tags = []
+            for k in range(n_draws):
+                if k == 8:  # eight draws outstanding: answer the four oldest so that four more may be drawn
+                    for _ in range(4):
+                        rep.update_priority(torch.ones(B, device=DEV))
+                (f, *_), w = rep.sample(B)
+                tags.append(f["s"][0, :, 0].clone())
+                if not held:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            rep.check_errors()
+        picked.append(torch.stack(tags).cpu())
+    assert torch.equal(picked[0], picked[1]), (picked[0] != picked[1]).any(1).nonzero().flatten().tolist()

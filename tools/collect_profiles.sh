@@ -37,6 +37,7 @@ cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /
 cp $(find /tmp/pa -name "*kernel_stats.csv" | head -1) $O/${RN}_actor_200_steps_kernel_stats.csv
 cp $O/${RN}_actor_200_steps_kernel_stats.csv $R/profiles/ 2>/dev/null
 # the fused cell kernel's phase timers and ablations
+cd $R && mkdir -p tools/bin && { [ -x tools/bin/gemm8_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm8_probe.hip -o tools/bin/gemm8_probe; }
 cd $R && (tools/bin/gemm8_probe; HSAD_CELL_PP=1 timeout 100 python tools/cell_phases.py 32768 1; HSAD_CELL_PP=1 timeout 100 python tools/cell_phases.py 32768 0; HSAD_CELL_PP=0 timeout 100 python tools/cell_phases.py 32768 1) 2>&1 | grep -v amdgpu.ids > $O/${RN}_cell_kernel_ablations.txt
 cp $O/${RN}_cell_kernel_ablations.txt $R/profiles/ 2>/dev/null
 tail -c 2500 $O/${RN}_bench.json; echo; head -8 $O/${RN}_bench_kernel_stats.csv | cut -c1-160; cat $O/pmc_summary.txt | head -60
