@@ -1,0 +1,36 @@
+"""rocprofv3 --kernel-trace --stats -- python tools/training_iteration_breakdown.py [N] [games] : the kernels of N whole learner iterations on
+rollout data (selfplay.Trainer.learner_update: prioritized sample -> loss fwd + BPTT -> clip + Adam -> priority write-back), what the
+`learner_iteration_ms_on_rollout_data` field of bench.py's actor leg times.  Also prints the host's issue time per iteration (the loop
+without a device wait) next to the device-paced time.  tools/update_timeline.py on the kernel trace gives one iteration as a timeline."""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hanabi_sad_amd.selfplay import Trainer, parse_args
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+games = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+tr = Trainer(parse_args(["--num_game", str(games), "--replay_buffer_size", "65536", "--sad", "1"]), "cuda:0")
+for _ in range(120):
+    tr.actor.step()
+assert tr.replay.size() >= tr.args.batchsize
+for _ in range(5):
+    tr.learner_update()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    tr.learner_update()
+t_issue = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print("iteration: %.3f ms device-paced, host issue %.3f ms (B = %d: %.1f k sequences/s)" % (t_all / N * 1e3, t_issue / N * 1e3, tr.args.batchsize,
+                                                                                      tr.args.batchsize / (t_all / N) / 1e3))
+# the host alone: with the queue drained before every call nothing the host does waits for the device
+hs = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    tr.learner_update()
+    hs.append(time.perf_counter() - t)
+hs.sort()
+print("host issue time of one iteration on an empty queue: median %.3f ms" % (hs[len(hs) // 2] * 1e3))
+tr.learner.check_sync()
+tr.replay.check_errors()
