@@ -30,7 +30,13 @@ extern "C" int hsad_internal_loss_tail(const float* heads, const float* heads_t,
                                        const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
                                        const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step,
                                        double gamma, float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss,
-                                       float* xent_sum, float* dqa, void* dheads16, int ldo, float* zero_buf, int64_t zero_n, void* stream);
+                                       float* xent_sum, float* dqa, void* dheads16, int ldo, float* zero_buf, int64_t zero_n, const void* WT16, float* dO32,
+                                       int H, void* stream);
+// both head layers + the online dueling head as one launch (csrc/hsad_r2d2.hip, heads_q_kernel)
+extern "C" int hsad_internal_heads_q_supported(int M, int H, int NH, int A, const void* legal, const void* q, const void* heads, const void* heads_t);
+extern "C" int hsad_internal_heads_q(const void* o16, const void* o16_t, const void* W16, const void* W16_t, const float* bias, const float* bias_t, int M,
+                                     int H, int NH, int A, float* heads, float* heads_t, const float* legal, const int64_t* action, float* q, float* qa,
+                                     float* block_min, void* stream);
 
 namespace {
 
@@ -715,6 +721,9 @@ struct hsad_r2d2_learner {
   bool fwd_frag = false;      // the last loss_fwd stored gates / cseq fragment-major
   bool dheads_ready = false;  // the last loss_fwd already produced d loss / d heads (hsad_loss_tail)
   bool dc01_zero = false;     // ... and cleared dc[0], dc[1] (contiguous)
+  bool dO_ready = false;      // ... and d loss / d o of the top layer (the dO product inside the loss tail launch)
+  bool fuse_heads = true;     // the chain between the recurrences as TWO launches (heads of both nets + dueling head; loss tail + dO product) instead of
+                              // four (GEMM pair, q_head, loss tail, dO GEMM): identical bits, 85 -> 45 us (set_fused bit 24 = off, A/B)
   int btail = 0;              // fused BPTT in two unequal chunks: steps [btail, T) first, [0, btail) last (set_fused bits 16-23; 0 = equal chunks)
   bool split_bptt = true;     // fused BPTT with the two layers of a row block on different XCDs (set_fused bit 3)
   bool proj_bptt = true;      // ... and the lower layer's dO in a projection stage of its own (set_fused bit 4; needs bit 3): default, 1.51 -> 1.46 ms
@@ -863,7 +872,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->dqa_r, M * 4);
   want(&L->w_r, B * 4);
   want(&L->xs, B * 4);
-  want(&L->qscratch, (8 + (M + 255) / 256) * 4);
+  want(&L->qscratch, (8 + (M + 127) / 128) * 4);
   want(&L->greedy, M * 8);
   want(&L->dheads, M * NHp * 2);
   for (int l = 0; l < NL; ++l) want(&L->dO[l], M * H * 4);
@@ -1038,6 +1047,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->dgt_in_kernel = !(fused_fwd & 64);                         // bit 6: transpose passes behind the BPTT launch instead (A/B)
   L->group_wgrad = !(fused_fwd & 128);                          // bit 7: the round-4 tail (six split-K GEMMs on two streams) instead of the grouped launch (A/B)
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
+  L->fuse_heads = !(fused_fwd & (1 << 24));                     // bit 24: the four-launch head / loss chain (A/B)
   return 0;
 }
 // the sticky timeout words of every counter block a launch of this learner may have used (hsad_lstm_sync_timed_out semantics): a bounded
@@ -1232,20 +1242,31 @@ static int loss_fwd_impl(hsad_r2d2_learner* L, const float* priv_s, const void* 
     CK(transpose16(L->a16_in, M, Fp, Fp, L->a16T, L->Mp, nullptr, nullptr, nullptr, wst));
     L->pre_T = true;
   }
-  CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
-                            L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
+  // IQL: both head layers and the online dueling head are ONE launch, then everything up to d loss / d heads AND d loss / d o in another
+  const bool one_launch_heads = num_player == 1 && L->fuse_heads &&
+                                hsad_internal_heads_q_supported(M, H, NH, A, legal_move, L->q, L->heads, L->heads_t) && T <= 352;
+  if (one_launch_heads)
+    CK(hsad_internal_heads_q(L->hseq[0][NL - 1], L->hseq[1][NL - 1], L->on->Wheads, L->tg->Wheads, L->on->bheads, L->tg->bheads, M, H, NH, A, L->heads,
+                             L->heads_t, legal_move, a, L->q, L->qa, L->qscratch + 1, stream));
+  else
+    CK(hsad_gemm_nt_bf16_pair(L->hseq[0][NL - 1], L->hseq[1][NL - 1], H, L->on->Wheads, L->tg->Wheads, H, M, NH, H, L->on->bheads, L->tg->bheads, L->heads,
+                              L->heads_t, NH, nullptr, nullptr, 0, 0, stream));
   L->dheads_ready = false;
+  L->dO_ready = false;
   L->dc01_zero = false;
   if (num_player == 1) {
     // IQL: the online Q-head, then everything up to d loss / d heads in ONE launch (hsad_loss_tail)
-    CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, nullptr, L->qscratch, stream));
+    if (!one_launch_heads) CK(hsad_q_head(L->heads, NH, legal_move, a, M, A, L->q, L->qa, nullptr, L->qscratch, stream));
     // (with a gradient to follow, the launch also clears d loss / d c_T of the two fused-BPTT layers: one memset less in front of the BPTT)
     const bool zero_dc = want_grad && NL >= 2;
-    CK(hsad_internal_loss_tail(L->heads, L->heads_t, NH, legal_move, L->q, L->qa, L->qscratch + 1, (M + 255) / 256, reward, bootstrap, seq_len, weight,
-                               pred_weight > 0 ? own_hand : nullptr, a, T, B, A, L->on->NP, L->multi_step, L->gamma, pred_weight, L->greedy, L->tqa,
-                               L->err, priority, loss, L->xs, want_grad ? L->dqa : nullptr, want_grad ? L->dheads : nullptr, L->on->NHp,
-                               zero_dc ? L->dc[0] : nullptr, zero_dc ? (int64_t)2 * B * H : 0, stream));
+    const bool fuse_do = one_launch_heads && want_grad && L->on->NHp == 64 && !(H & 31) && H <= (T <= 128 ? 512 : 256);
+    CK(hsad_internal_loss_tail(L->heads, L->heads_t, NH, legal_move, L->q, L->qa, L->qscratch + 1, one_launch_heads ? M / 128 : (M + 255) / 256, reward,
+                               bootstrap, seq_len, weight, pred_weight > 0 ? own_hand : nullptr, a, T, B, A, L->on->NP, L->multi_step, L->gamma,
+                               pred_weight, L->greedy, L->tqa, L->err, priority, loss, L->xs, want_grad ? L->dqa : nullptr,
+                               want_grad ? L->dheads : nullptr, L->on->NHp, zero_dc ? L->dc[0] : nullptr, zero_dc ? (int64_t)2 * B * H : 0,
+                               fuse_do ? L->on->WheadsT : nullptr, fuse_do ? L->dO[NL - 1] : nullptr, H, stream));
     L->dheads_ready = want_grad != 0;
+    L->dO_ready = fuse_do;
     L->dc01_zero = zero_dc;
     L->b_legal = legal_move;
     L->b_a = a;
@@ -1315,7 +1336,8 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
   if (!L->dheads_ready)
     CK(hsad_heads_backward(dqa, L->b_legal, L->b_a, L->heads, NH, L->b_own, weight, M, B, A, NP, L->b_own ? L->pred_weight / B : 0.f,
                            L->dheads, NHp, stream));
-  CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO[top], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
+  if (!(L->dheads_ready && L->dO_ready))      // (the loss tail launch of loss_fwd already formed it)
+    CK(hsad_gemm_nt_bf16_ex(L->dheads, NHp, on->WheadsT, NHp, M, H, NHp, nullptr, L->dO[top], H, nullptr, 0, 0, 0, 1, nullptr, 0, nullptr, stream));
   if (!L->gflat_zero) HIP_TRY(hipMemsetAsync(L->gflat, 0, on->n_param * 4, s));
   L->gflat_zero = false;
   float* g[kMaxP];

@@ -975,7 +975,7 @@ int hsad_internal_loss_tail(const float* heads, const float* heads_t, int ldh, c
                    const float* block_min, int n_block_min, const float* reward, const float* bootstrap, const float* seq_len,
                    const float* weight, const float* own_hand, const int64_t* action, int T, int B, int A, int NP, int multi_step, double gamma,
                    float pred_weight, int64_t* greedy, float* target_qa, float* err, float* priority, float* loss, float* xent_sum, float* dqa,
-                   void* dheads16, int ldo, float* zero_buf, int64_t zero_n, void* stream) {
+                   void* dheads16, int ldo, float* zero_buf, int64_t zero_n, const void* WT16, float* dO32, int H, void* stream) {
   if (!heads || !heads_t || !legal || !q_online || !online_qa || !block_min || !reward || !bootstrap || !seq_len || !greedy || !target_qa || !err ||
       !priority || !loss || n_block_min < 1 || T < 1 || B < 1)
     return nfail(HSAD_ERR_INVALID, "loss_tail: null argument");
@@ -989,8 +989,22 @@ int hsad_internal_loss_tail(const float* heads, const float* heads_t, int ldh, c
     gamma_n = (float)g;
   }
   LossTailArgs p{heads, heads_t, legal, q_online, online_qa, block_min, reward, bootstrap, seq_len, weight, own_hand, action, ldh, n_block_min, T, B, A, NP,
-                 multi_step, gamma_n, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, (bf16_t*)dheads16, ldo, zero_buf, (unsigned)zero_n};
-  hipLaunchKernelGGL(loss_tail_kernel, dim3(B), dim3(128), (size_t)(2 * T + 128) * 4, (hipStream_t)stream, p);
+                 multi_step, gamma_n, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, (bf16_t*)dheads16, ldo, zero_buf, (unsigned)zero_n,
+                 nullptr, nullptr, 0};
+  size_t lds = (size_t)(2 * T + 128) * 4;
+  int threads = 128;
+  if (dO32) {      // the dO product inside the launch: the sequence's dheads rows in LDS; four waves (with T <= 128 the
+    const int Tp = (T + 31) & ~31;       // Huber sum's tree only gains a level of zeros: same bits as with two)
+    threads = T <= 128 ? 256 : 128;
+    const size_t need = (((size_t)(2 * T + threads) + 3) & ~(size_t)3) * 4 + (size_t)Tp * kLtRowStride * 2;
+    if (!dheads16 || !WT16 || ldo != 64 || H < 32 || (H & 31) || H / 32 > kLtMaxCb * (threads / 64) || need > 64 * 1024 || ((uintptr_t)dO32 & 15) || ((uintptr_t)dheads16 & 15) || ((uintptr_t)WT16 & 15))
+      return nfail(HSAD_ERR_INVALID, "loss_tail: the fused dO product needs dheads, W_heads^T with 64 columns, H a multiple of 32 up to 512 (256 with T > 128), T <= 352, aligned buffers");
+    p.WT16 = (const bf16_t*)WT16;
+    p.dO32 = dO32;
+    p.H = H;
+    lds = need;
+  }
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, p);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
@@ -1002,7 +1016,41 @@ int hsad_loss_tail(const float* heads, const float* heads_t, int ldh, const floa
                    void* dheads16, int ldo, void* stream) {
   return hsad_internal_loss_tail(heads, heads_t, ldh, legal, q_online, online_qa, block_min, n_block_min, reward, bootstrap, seq_len, weight, own_hand,
                                  action, T, B, A, NP, multi_step, gamma, pred_weight, greedy, target_qa, err, priority, loss, xent_sum, dqa, dheads16,
-                                 ldo, nullptr, 0, stream);
+                                 ldo, nullptr, 0, nullptr, nullptr, 0, stream);
+}
+
+// library-internal (the learner's loss_fwd): the head layers of the online and the target net + the online dueling head as ONE launch
+// (heads_q_kernel).  block_min receives M / 128 minima.  -> HSAD_OK, or HSAD_ERR_INVALID when the shape is not the kernel's (the caller
+// then runs the GEMM pair + hsad_q_head)
+extern "C" int hsad_internal_heads_q_supported(int M, int H, int NH, int A, const void* legal, const void* q, const void* heads, const void* heads_t) {
+  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)4 * 32 * NH * 4 + (size_t)4 * 32 * A * 4;
+  return M >= 128 && !(M & 127) && H >= 16 && !(H & 15) && NH >= A + 1 && NH <= 64 && A >= 1 && lds <= 160 * 1024 - 64 &&
+         !(((uintptr_t)legal | (uintptr_t)q | (uintptr_t)heads | (uintptr_t)heads_t) & 15);
+}
+extern "C" int hsad_internal_heads_q(const void* o16, const void* o16_t, const void* W16, const void* W16_t, const float* bias, const float* bias_t, int M,
+                                     int H, int NH, int A, float* heads, float* heads_t, const float* legal, const int64_t* action, float* q, float* qa,
+                                     float* block_min, void* stream) {
+  if (!o16 || !W16 || !bias || !heads || !legal || !action || !q || !qa || !block_min) return nfail(HSAD_ERR_INVALID, "heads_q: null argument");
+  if (o16_t && (!W16_t || !bias_t || !heads_t)) return nfail(HSAD_ERR_INVALID, "heads_q: the target net needs its weights and its output");
+  if (!hsad_internal_heads_q_supported(M, H, NH, A, legal, q, heads, heads_t ? (const void*)heads_t : (const void*)heads))
+    return nfail(HSAD_ERR_INVALID, "heads_q: M must be a multiple of 128, H of 16, A + 1 <= NH <= 64, 16-byte aligned buffers");
+  HeadsQArgs p{{(const bf16_t*)o16, (const bf16_t*)o16_t}, {(const bf16_t*)W16, (const bf16_t*)W16_t}, {bias, bias_t}, {heads, heads_t}, legal, action, q, qa,
+               block_min, M, H, NH, A};
+  const size_t lds = (size_t)64 * (H + 8) * 2 + (size_t)4 * 32 * NH * 4 + (size_t)4 * 32 * A * 4;
+  static std::mutex mu;
+  static std::vector<int> done;
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> g(mu);
+    if (std::find(done.begin(), done.end(), dev) == done.end()) {
+      HIP_TRY(hipFuncSetAttribute((const void*)heads_q_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+      done.push_back(dev);
+    }
+  }
+  hipLaunchKernelGGL(heads_q_kernel, dim3((o16_t ? 2 : 1) * (M / 128)), dim3(256), lds, (hipStream_t)stream, p);
+  HIP_TRY(hipGetLastError());
+  return HSAD_OK;
 }
 
 int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream) {

@@ -530,3 +530,36 @@ def test_a_timed_out_recurrence_fails_the_next_call_of_any_driver():
         r2d2.gather_timeouts(torch.device(DEV))
         torch.cuda.synchronize()
     pl.loss(batch, weight, 0.0)
+
+
+@pytest.mark.parametrize("F,H,T,B,pw", [(838, 512, 80, 128, 0.25), (838, 512, 80, 128, 0.0), (838, 256, 24, 64, 0.25), (783, 512, 17, 128, 0.0)])
+def test_the_two_launch_head_chain_gives_the_bits_of_the_four_launch_one(F, H, T, B, pw):
+    """Between the two recurrences of an update: heads of both nets + the online dueling head in ONE launch (heads_q_kernel: the top layer's
+    rows straight into MFMA fragments, q_head_kernel's row arithmetic on the rows a wave holds) and the loss tail with d loss / d o formed
+    inside (loss_tail_kernel's MFMA section) -- against the GEMM pair -> q_head -> loss tail -> dO GEMM chain (set_fused bit 24).  Same MFMA,
+    same k order, the same scalar arithmetic per row: loss, priorities, the LSTM's and the input layer's weight gradients the same bits (the float-atomic
+    sums -- biases, the head layers' split-K products -- compared at 1e-5)."""
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    A = 21
+    W, Wt = _rand_net(F, H, A, seed=31), _rand_net(F, H, A, seed=32)
+    batch, weight = _rand_batch(T, B, F, A, seed=9)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    res = {}
+    for rep in range(2):
+        for name, flags in (("two launches", CompositeLearner.FUSED_DEFAULT), ("four launches", CompositeLearner.FUSED_DEFAULT | (1 << 24))):
+            L.set_fused(flags)
+            loss, prio = L.loss(batch, weight, pw)
+            torch.cuda.synchronize()
+            got = (loss.clone(), prio.clone(), {k: v.clone() for k, v in L.grad.items()})
+            if name in res:
+                assert torch.equal(got[0], res[name][0]) and torch.equal(got[1], res[name][1]), name
+            res[name] = got
+    L.check_sync()
+    (l2, p2, g2), (l4, p4, g4) = res["two launches"], res["four launches"]
+    assert torch.equal(l2, l4) and torch.equal(p2, p4)
+    for k in g4:
+        if k.startswith("lstm.weight") or k.startswith("net."):       # deterministic sums downstream of d loss / d o
+            if "bias" not in k:
+                assert torch.equal(g2[k], g4[k]), (k, relerr(g2[k], g4[k]))
+        assert relerr(g2[k], g4[k]) < 1e-5, (k, relerr(g2[k], g4[k]))     # (bias sums and the head layers' split-K sums are float atomics)
