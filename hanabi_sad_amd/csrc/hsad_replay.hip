@@ -15,6 +15,7 @@
 // std::uniform_real_distribution<float> the reference uses.
 
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <hip/hip_bf16.h>
 
 #include <algorithm>
@@ -592,38 +593,45 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
   // queue slot of this draw; a draw into a full queue replaces the newest entry (depth 1: the draw before it)
   const int q_full = c.q_count >= rd.depth;
   const int q_slot = (c.q_head + (q_full ? c.q_count - 1 : c.q_count)) % rd.depth;
-  // chunked prefix sums of the weights in ring order, accumulated in double like the reference's accSum
+  // chunked prefix sums of the weights in ring order, accumulated in double like the reference's accSum; the 1024 chunk sums are
+  // scanned by shuffles (ONE thread's serial scan over them was 15-20 of this kernel's 55 us; a double sum of <= 2^17 non-negative
+  // floats does not depend on the order of its additions to any bit a draw can see).
   const int C = (N + 1023) / 1024;
   {
-    // the chunk is one or two linear runs of the ring (it wraps at most once): eight independent loads in flight, added up in
-    // ring order like the sequential loop they replace (80 dependent-address loads per thread were 40 of this kernel's 66 us)
-    double local = 0.0;
-    const int k0 = tid * C, k1 = min(k0 + C, N);
-    int n = max(k1 - k0, 0), pos = (head + k0) % ring;
-    while (n > 0) {
-      const int run = min(n, ring - pos);
-      const float* wp = rd.weights + pos;
-      int k = 0;
-      for (; k + 8 <= run; k += 8) {
-        float v[8];
+    // thread j owns chunk j = queue positions [j C, (j + 1) C): one or two linear runs of the ring (it wraps at most once), sixteen
+    // independent loads in flight, added up in ring order
+    const int wave = tid >> 6, lane = tid & 63;
+    double mine = 0.0;
+    {
+      const int k0 = tid * C, k1 = min(k0 + C, N);
+      int n = max(k1 - k0, 0), pos = (head + k0) % ring;
+      while (n > 0) {
+        const int run = min(n, ring - pos);
+        const float* wp = rd.weights + pos;
+        int k = 0;
+        for (; k + 16 <= run; k += 16) {
+          float v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = wp[k + u];
+          for (int u = 0; u < 16; ++u) v[u] = wp[k + u];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) local += (double)v[u];
+          for (int u = 0; u < 16; ++u) mine += (double)v[u];
+        }
+        for (; k < run; ++k) mine += (double)wp[k];
+        n -= run;
+        pos = 0;
       }
-      for (; k < run; ++k) local += (double)wp[k];
-      n -= run;
-      pos = 0;
     }
-    s_incl[tid] = local;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    double acc = 0.0;
-    for (int j = 0; j < 1024; ++j) {
-      acc += s_incl[j];
-      s_incl[j] = acc;
+    // inclusive scan of the 1024 chunk sums: within the wave, then over the 16 wave totals
+    double incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const double up = __shfl_up(incl, o);
+      if (lane >= o) incl += up;
     }
+    if (lane == 63) s_red[wave] = incl;
+    __syncthreads();
+    double base = 0.0;
+    for (int w = 0; w < wave; ++w) base += s_red[w];
+    s_incl[tid] = base + incl;
   }
   __syncthreads();
   // The draw uses the RUNNING sum like the reference (sum_, maintained incrementally in blockAppend / blockPop / update).  That
@@ -658,12 +666,12 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     double acc = lo > 0 ? s_incl[lo - 1] : 0.0;
     int found = -1;
     float w = 0.f;
-    for (int k0 = lo * C; k0 < N && found < 0; k0 += 8) {      // eight loads in flight, examined in order
-      float v[8];
+    for (int k0 = lo * C; k0 < N && found < 0; k0 += 16) {      // sixteen loads in flight, examined in order
+      float v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = k0 + u < N ? rd.weights[(head + k0 + u) % ring] : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = k0 + u < N ? rd.weights[(head + k0 + u) % ring] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         if (found >= 0 || k0 + u >= N) continue;
         w = v[u];
         acc += (double)w;
@@ -707,10 +715,13 @@ __global__ __launch_bounds__(1024) void replay_sample_kernel(ReplayDev rd, int B
     s_y[tid] = powf((float)N * wn, -rd.beta);
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid < 64) {      // max over the batch (a maximum does not depend on the order)
     float m = B > 0 ? s_y[0] : 1.f;
-    for (int i = 1; i < B; ++i) m = fmaxf(m, s_y[i]);
-    s_max = m;
+    for (int i = tid; i < B; i += 64) m = fmaxf(m, s_y[i]);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (tid == 0) s_max = m;
+  }
+  if (tid == 0) {
     ReplayCtl cc = *rd.ctl;
     if (heal) cc.sum = exact;
     cc.sum -= s_red[0];
@@ -787,7 +798,16 @@ __global__ __launch_bounds__(1024) void replay_update_kernel(ReplayDev rd, int B
   __syncthreads();
   if (tid == 0) {
     double diff = 0.0;
-    for (int i = 0; i < B; ++i)
+    int i = 0;
+    for (; i + 8 <= B; i += 8) {           // same order of additions, the LDS reads of eight terms in flight
+      float d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = s_live[i + u] ? s_diff[i + u] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s_live[i + u]) diff += d[u];
+    }
+    for (; i < B; ++i)
       if (s_live[i]) diff += s_diff[i];
     c.sum += diff;
     c.q_head = (c.q_head + 1) % rd.depth;
@@ -1148,7 +1168,9 @@ struct hsad_replay {
   // pinned staging ring for the uniforms: an async copy from PAGEABLE memory makes the host wait for everything queued on
   // the stream before it (a whole actor step in the self-play loop); slot k is reused once the copy recorded in ev[k] is done
   static constexpr int kCanonSlots = 8;
-  float* h_canon_ring = nullptr;   // [kCanonSlots][kMaxBatch], hipHostMalloc
+  float* h_canon_ring = nullptr;   // [kCanonSlots][kMaxBatch], hipHostMalloc (mapped)
+  float* d_canon_ring = nullptr;   // its device address: the sampling kernel reads the slot's <= 512 bytes over the link itself (a copy
+                                   // into device memory was a blit launch + queue barriers in front of every draw)
   // a slot is free again once the draw that consumed its uniforms has run: the sampling kernel publishes the sequence number of
   // its draw into host-visible (fine-grained) memory, which the host reads without any HIP call.  (An event per slot made the host
   // wait: hipEventSynchronize on an old, long-complete marker returned only when the most recent work of the stream had finished.)
@@ -1246,7 +1268,8 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
     hsad_replay_destroy(r);
     return HSAD_ERR_NOMEM;
   }
-  he = hipHostMalloc((void**)&r->h_canon_ring, sizeof(float) * hsad_replay::kCanonSlots * kMaxBatch, hipHostMallocDefault);
+  he = hipHostMalloc((void**)&r->h_canon_ring, sizeof(float) * hsad_replay::kCanonSlots * kMaxBatch, hipHostMallocMapped | hipHostMallocCoherent);
+  if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&r->d_canon_ring, (void*)r->h_canon_ring, 0);
   if (he == hipSuccess) he = hipHostMalloc((void**)&r->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent);
   if (he == hipSuccess) {
     *r->h_done = 0ull;
@@ -1279,7 +1302,7 @@ void hsad_replay_destroy(hsad_replay* r) {
   delete r;
 }
 
-// next pinned staging slot for n uniforms; upload_canon queues the copy to d_canon and marks the slot busy until it is done
+// next pinned staging slot for n uniforms (the sampling kernel reads it in place: canon_dev); busy until that draw has run
 // (host state of the draws -- canon_next, slot_seq, slot_stream, draw_seq, the generator -- is only touched with the fence's guard held:
 // call it after the entry point's FenceUse)
 static float* canon_slot(hsad_replay* r, int* slot, hipStream_t s) {
@@ -1288,14 +1311,20 @@ static float* canon_slot(hsad_replay* r, int* slot, hipStream_t s) {
   // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call; otherwise wait
   // for THAT draw's stream (not for whichever stream the object saw last: a flush on a side stream is not what holds the slot)
   // (slot_seq 0 = never used; the stream itself may be the null stream, a valid one to wait for)
-  if (r->slot_seq[*slot] && *r->h_done < r->slot_seq[*slot]) (void)hipStreamSynchronize(r->slot_stream[*slot]);
+  // The host waits for THAT draw only (its sequence number appears in the host-visible word): draining the stream instead emptied the
+  // queue every eighth draw of a host that runs ahead, and the device then idled until the host had refilled it.  A stream that has gone
+  // idle without publishing the number (a failed launch) ends the wait.
+  if (r->slot_seq[*slot] && *r->h_done < r->slot_seq[*slot]) {
+    for (unsigned spins = 0; *r->h_done < r->slot_seq[*slot]; ++spins) {
+      if ((spins & 255) == 255 && hipStreamQuery(r->slot_stream[*slot]) != hipErrorNotReady) break;
+      std::this_thread::yield();
+    }
+  }
   r->slot_seq[*slot] = ++r->draw_seq;     // the draw about to be issued
   r->slot_stream[*slot] = s;
   return r->h_canon_ring + (size_t)*slot * kMaxBatch;
 }
-static hipError_t upload_canon(hsad_replay* r, int slot, int n, hipStream_t s) {
-  return hipMemcpyAsync(r->d_canon, r->h_canon_ring + (size_t)slot * kMaxBatch, sizeof(float) * n, hipMemcpyHostToDevice, s);
-}
+static const float* canon_dev(hsad_replay* r, int slot) { return r->d_canon_ring + (size_t)slot * kMaxBatch; }
 
 int64_t hsad_replay_bytes(const hsad_replay* r) { return r ? r->bytes : 0; }
 
@@ -1333,8 +1362,7 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   int slot;
   float* hc = canon_slot(r, &slot, s);
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
-  HIP_TRY(upload_canon(r, slot, batch, s));
-  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, r->d_canon, weight, (const float*)nullptr,
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, canon_dev(r, slot), weight, (const float*)nullptr,
                      (const int*)nullptr, r->d_done, r->slot_seq[slot]);
   const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
@@ -1371,13 +1399,14 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   hipStream_t s = (hipStream_t)stream;
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
+  const float* cv = r->d_canon;       // (n = 0: not read)
   if (n > 0) {
     int slot;
     float* hc = canon_slot(r, &slot, s);
     for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
-    HIP_TRY(upload_canon(r, slot, n, s));
+    cv = canon_dev(r, slot);
   }
-  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, r->d_canon, raw_weight, r->d_canon, (const int*)nullptr,
+  hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, cv, raw_weight, cv, (const int*)nullptr,
                      r->d_done, r->draw_seq);
   if (n > 0) {
     const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);

@@ -149,7 +149,7 @@ class DeviceReplay:
                                                bootstrap.data_ptr(), seq_len.data_ptr(), weight.data_ptr(),
                                                _stream(d)))
         fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
-        return (fields, reward, terminal.bool(), bootstrap, seq_len), weight
+        return (fields, reward, terminal.view(torch.bool), bootstrap, seq_len), weight
 
     # ---- shard interface used by hanabi_sad_amd.dist.ShardedReplay (one DeviceReplay per GPU) ----
     def priority_sum(self):
@@ -181,7 +181,7 @@ class DeviceReplay:
                                                   reward.data_ptr(), terminal.data_ptr(), bootstrap.data_ptr(),
                                                   seq_len.data_ptr(), raw_w.data_ptr(), _stream(d)))
         fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
-        return (fields, reward, terminal.bool(), bootstrap, seq_len), raw_w
+        return (fields, reward, terminal.view(torch.bool), bootstrap, seq_len), raw_w
 
     # ---- the same draw without host round trips: shard interface of hanabi_sad_amd.dist.ReplayLink ----
     def stats(self):
@@ -227,7 +227,7 @@ class DeviceReplay:
                                                  reward.data_ptr(), terminal.data_ptr(), bootstrap.data_ptr(), seq_len.data_ptr(),
                                                  raw_w.data_ptr(), _stream(d)))
         fields = {name: t for (name, _, _), t in zip(self.fields, outs)}
-        return (fields, reward, terminal.bool(), bootstrap, seq_len), raw_w
+        return (fields, reward, terminal.view(torch.bool), bootstrap, seq_len), raw_w
 
     def update_priority(self, priority):
         priority = priority.to(self.device, torch.float32).contiguous()
@@ -254,7 +254,7 @@ class DeviceReplay:
         seq_len = torch.empty(1, dtype=torch.float32, device=d)
         _lib.check(self.lib.hsad_replay_get(self.h, int(idx), _ptr_array(outs), reward.data_ptr(), terminal.data_ptr(),
                                             bootstrap.data_ptr(), seq_len.data_ptr(), _stream(d)))
-        return {name: t for (name, _, _), t in zip(self.fields, outs)}, reward, terminal.bool(), bootstrap, seq_len
+        return {name: t for (name, _, _), t in zip(self.fields, outs)}, reward, terminal.view(torch.bool), bootstrap, seq_len
 
     def set_outstanding(self, depth):
         """drawn batches that may wait for their priorities at once (the reference's prefetch queue); update_priority answers

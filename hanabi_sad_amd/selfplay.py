@@ -99,6 +99,7 @@ class Trainer:
         self.actor = DeviceActor(self.env, self.agent, self.replay, args.multi_step, args.gamma, args.eta, args.max_len,
                                  vdn=self.vdn, native=None if getattr(args, "native_actor", 1) else False) if self.acting else None
         self.num_update = 0
+        self._drawn = None           # the batch of the next update, drawn ahead (--draw_ahead)
         # --overlap_rollout: the rollout issues on a stream of its own, next to the update on the caller's stream (one host thread feeds
         # both; replay and writer calls from the two sides are ordered by the library's stream fence).  The reference's actor threads
         # run concurrently with its training thread the same way (selfplay.py:208-244, rela/context.h:43-50).
@@ -150,7 +151,13 @@ class Trainer:
         if self.num_update % a.actor_sync_freq == 0:
             self.update_actor_model()
         mark("sync and updating")
-        res = self.sharded.sample(a.batchsize)
+        # --draw_ahead 1 (default): this update's batch was drawn at the end of the previous one -- behind its priority write-back, in front
+        # of the rollout step issued since -- so that the draw (a chain of small dependent launches, 0.1 ms) runs next to that step instead
+        # of waiting for its flush.  The reference's sampler thread draws `prefetch` batches ahead of the training thread the same way
+        # (rela/prioritized_replay.h:229-237); 0 = draw here (the strictly alternating order of rounds 1-4).
+        res, self._drawn = self._drawn, None
+        if res is None:
+            res = self.sharded.sample(a.batchsize)
         mark("sample data", sync=False)
         batch, weight, seq_len = self.batch_of(res)
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
@@ -159,6 +166,8 @@ class Trainer:
         g_norm = self.learner.optimizer_step()
         mark("update model")
         self.sharded.update_priority(prio)
+        if getattr(a, "draw_ahead", 0):
+            self._drawn = self.sharded.sample(a.batchsize)
         mark("updating priority", sync=False)
         self.num_update += 1
         return (loss * weight).mean(), g_norm
@@ -224,6 +233,8 @@ def parse_args(argv=None):
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
     p.add_argument("--num_eval_game", type=int, default=1000)
+    p.add_argument("--draw_ahead", type=int, default=1, help="1: the batch of update u + 1 is drawn at the end of update u (behind its priority "
+                   "write-back), in front of the next rollout step, as the reference's prefetching sampler thread does; 0: at the start of update u + 1")
     p.add_argument("--overlap_rollout", type=int, default=1, help="1: the rollout steps of a one-GPU job issue on a stream of their own, "
                    "next to the update (like the reference's actor threads next to its training thread); 0: one stream, strictly alternating")
     p.add_argument("--stopwatch", type=int, default=0, help="1 = time the reference's five learner sections (adds device syncs)")
