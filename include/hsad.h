@@ -745,7 +745,9 @@ int hsad_r2d2_learner_set_schedule(hsad_r2d2_learner* learner, int chunks, int w
  *              host synchronisation).  Off by default: measured 1.521 against 1.504 ms per update with everything in line
  *   bit 7      off: the four LSTM weight gradients and the input layer's of a single-chunk fused BPTT as six split-K GEMMs on two streams
  *              (round 4) instead of one grouped launch of the 256 x 256 core + one slab pass (hsad_gemm_nt_bf16_group_splitk)
- *   bits 8-15  time chunks of the fused BPTT, 1..8 (the weight gradients are added up per chunk); 0 keeps the current setting */
+ *   bits 8-15  time chunks of the fused BPTT, 1..8 (the weight gradients are added up per chunk); 0 keeps the current setting
+ *   bit 24     off: the chain between the two recurrences as four launches (head GEMM pair, hsad_q_head, loss tail, dO GEMM) instead of two (both
+ *              nets' heads + the online dueling head in one launch; the loss tail forming d loss / d o itself) -- identical bits, A/B */
 int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* learner, int fused_fwd);
 float* hsad_r2d2_learner_grad(hsad_r2d2_learner* learner);            /* flat gradient, same layout as the net's parameters */
 int hsad_r2d2_learner_timed_out(hsad_r2d2_learner* learner, int32_t* timed_out);
