@@ -30,6 +30,7 @@
 
 #include "hsad.h"
 #include "hsad_stream_fence.h"
+#include "hsad_slot_ring.h"
 
 extern "C" int hsad_internal_set_error(int code, const char* msg);
 
@@ -1174,11 +1175,14 @@ struct hsad_replay {
   // a slot is free again once the draw that consumed its uniforms has run: the sampling kernel publishes the sequence number of
   // its draw into host-visible (fine-grained) memory, which the host reads without any HIP call.  (An event per slot made the host
   // wait: hipEventSynchronize on an old, long-complete marker returned only when the most recent work of the stream had finished.)
-  unsigned long long slot_seq[kCanonSlots] = {};
-  unsigned long long draw_seq = 0;
+  struct HipRingRuntime {
+    using stream_t = hipStream_t;
+    static bool stream_idle(hipStream_t s) { return hipStreamQuery(s) != hipErrorNotReady; }
+    static void yield() { std::this_thread::yield(); }
+  };
+  SlotRingT<HipRingRuntime, kCanonSlots> canon;      // which draw holds which slot (hsad_slot_ring.h)
   volatile unsigned long long* h_done = nullptr;   // hipHostMalloc (coherent), written by replay_sample_kernel
   unsigned long long* d_done = nullptr;            // device view of h_done
-  int canon_next = 0;
   int* d_tmp_id;
   StreamFence fence;
   int last_err_kind = 0;
@@ -1186,7 +1190,6 @@ struct hsad_replay {
   int out_kind[kMaxFields] = {};  // what sample() unpacks a bit field to (hsad_replay_set_field_output)
   int out_ld[kMaxFields] = {};
   std::mt19937 rng;
-  hipStream_t slot_stream[kCanonSlots];   // the stream of the draw that read each pinned slot last (written under the fence's guard)
   int64_t bytes;
 };
 
@@ -1234,7 +1237,6 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
   r->device = device;
   r->T = seq_len;
   r->rng.seed(seed);
-  for (int k = 0; k < hsad_replay::kCanonSlots; ++k) r->slot_stream[k] = nullptr;
   ReplayDev& rd = r->rd;
   rd.ring = (int)(1.25 * capacity);
   if (rd.ring < 1) rd.ring = 1;
@@ -1303,25 +1305,12 @@ void hsad_replay_destroy(hsad_replay* r) {
 }
 
 // next pinned staging slot for n uniforms (the sampling kernel reads it in place: canon_dev); busy until that draw has run
-// (host state of the draws -- canon_next, slot_seq, slot_stream, draw_seq, the generator -- is only touched with the fence's guard held:
+// (host state of the draws -- the slot ring, the generator -- is only touched with the fence's guard held:
 // call it after the entry point's FenceUse)
-static float* canon_slot(hsad_replay* r, int* slot, hipStream_t s) {
-  *slot = r->canon_next;
-  r->canon_next = (r->canon_next + 1) % hsad_replay::kCanonSlots;
-  // the draw that read this slot last (eight draws ago) must have run: normally long true, checked without a HIP call; otherwise wait
-  // for THAT draw's stream (not for whichever stream the object saw last: a flush on a side stream is not what holds the slot)
-  // (slot_seq 0 = never used; the stream itself may be the null stream, a valid one to wait for)
-  // The host waits for THAT draw only (its sequence number appears in the host-visible word): draining the stream instead emptied the
-  // queue every eighth draw of a host that runs ahead, and the device then idled until the host had refilled it.  A stream that has gone
-  // idle without publishing the number (a failed launch) ends the wait.
-  if (r->slot_seq[*slot] && *r->h_done < r->slot_seq[*slot]) {
-    for (unsigned spins = 0; *r->h_done < r->slot_seq[*slot]; ++spins) {
-      if ((spins & 255) == 255 && hipStreamQuery(r->slot_stream[*slot]) != hipErrorNotReady) break;
-      std::this_thread::yield();
-    }
-  }
-  r->slot_seq[*slot] = ++r->draw_seq;     // the draw about to be issued
-  r->slot_stream[*slot] = s;
+static float* canon_slot(hsad_replay* r, int* slot, unsigned long long* number, hipStream_t s) {
+  // the draw that read this slot last (eight draws ago) must have run: the ring waits for THAT draw's number in the host-visible word,
+  // not for the stream to drain
+  *slot = r->canon.acquire(s, r->h_done, number);
   return r->h_canon_ring + (size_t)*slot * kMaxBatch;
 }
 static const float* canon_dev(hsad_replay* r, int slot) { return r->d_canon_ring + (size_t)slot * kMaxBatch; }
@@ -1360,10 +1349,11 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   // generate_canonical<float,24>(rng) * (b - a) + a; the scaling by the segment happens on the device because
   // the segment depends on the device-side running sum)
   int slot;
-  float* hc = canon_slot(r, &slot, s);
+  unsigned long long number;
+  float* hc = canon_slot(r, &slot, &number, s);
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, canon_dev(r, slot), weight, (const float*)nullptr,
-                     (const int*)nullptr, r->d_done, r->slot_seq[slot]);
+                     (const int*)nullptr, r->d_done, number);
   const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
                      r->rd.sampled_ids, 0, r->rd.valid_rows);
@@ -1402,12 +1392,13 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   const float* cv = r->d_canon;       // (n = 0: not read)
   if (n > 0) {
     int slot;
-    float* hc = canon_slot(r, &slot, s);
+    unsigned long long number;
+    float* hc = canon_slot(r, &slot, &number, s);
     for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
     cv = canon_dev(r, slot);
   }
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, cv, raw_weight, cv, (const int*)nullptr,
-                     r->d_done, r->draw_seq);
+                     r->d_done, r->canon.issued);
   if (n > 0) {
     const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,

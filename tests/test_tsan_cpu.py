@@ -40,3 +40,39 @@ def test_the_harness_detects_entry_points_that_do_not_hold_the_guard(tmp_path):
     lines = out.stdout.strip().splitlines()
     assert lines[0].startswith("guarded entry points") and " 0 ordering violations" in lines[0]
     assert lines[1].startswith("unguarded entry points") and " 0 ordering violations" not in lines[1]
+
+
+RING_SRC = os.path.join(ROOT, "tests", "tsan", "slot_ring_tsan.cc")
+
+
+def _build_ring(tmp_path, name, flags):
+    exe = str(tmp_path / name)
+    out = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-I", INC, RING_SRC, "-o", exe, "-pthread"] + flags, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return exe
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_staging_slot_ring_never_refills_a_slot_of_a_queued_draw_under_tsan(tmp_path):
+    """hanabi_sad_amd/csrc/hsad_slot_ring.h (the ring of pinned slots the replay's draws read their uniforms from, in place) against a
+    model of two streams -- one with the NULL handle of HIP's default stream -- and a device that starts 30 ms late and dawdles: 3 x 3000
+    operations issued by a host that runs ahead; every operation must find its own payload in its slot, no data race on the slots, no
+    lost operation."""
+    exe = _build_ring(tmp_path, "ring_tsan", ["-fsanitize=thread"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_signal_unsafe=0")
+    out = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=300, env=env)
+    assert "ThreadSanitizer" not in out.stderr and out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "9000 operations, 0 slot violations" in out.stdout and out.stdout.strip().endswith("OK")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_the_ring_harness_sees_the_null_stream_bug_of_round_5(tmp_path):
+    """the bug this harness was written after: `slot never used` recognised by a null stream handle, so that on the default stream the host
+    never waited.  Built in (-DHSAD_SLOT_RING_BUG_NULL_STREAM) the model must report refilled slots, and ThreadSanitizer the race."""
+    exe = _build_ring(tmp_path, "ring_bug", ["-DHSAD_SLOT_RING_BUG_NULL_STREAM"])
+    out = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("BUG SEEN"), out.stdout[-2000:]
+    exe = _build_ring(tmp_path, "ring_bug_tsan", ["-DHSAD_SLOT_RING_BUG_NULL_STREAM", "-fsanitize=thread"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66 report_signal_unsafe=0")
+    out = subprocess.run([exe, "1000"], capture_output=True, text=True, timeout=300, env=env)
+    assert "ThreadSanitizer: data race" in out.stderr, out.stderr[-2000:]
