@@ -431,6 +431,42 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     return out
 
 
+def training_bench(dev, games=6400, iterations=150, warmup=20):
+    """One-GPU self-play training as `python -m hanabi_sad_amd.selfplay` runs it (the configuration of the committed convergence run: 6,400 games,
+    one rollout step per update on the rollout stream, B = 128 sequences drawn from the replay the rollout fills, draw ahead): rollout step ->
+    update (loss fwd + BPTT, clip + Adam, priorities written back) -> next draw, timed over whole iterations with the host running ahead."""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    args = parse_args(["--num_game", str(games), "--replay_buffer_size", "131072", "--sad", "1"])
+    tr = Trainer(args, str(dev))
+    tr.act_step(130)                                       # past the first episode ends: the replay holds > 2 batches
+    tr.join_rollout()
+
+    def iteration():
+        tr.act_step(1)
+        tr.learner_update()
+    for _ in range(warmup):
+        iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iterations):
+        iteration()
+    t_issue = time.perf_counter() - t0
+    tr.join_rollout()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iterations
+    tr.learner.check_sync()
+    tr.env.check_errors()
+    tr.replay.check_errors()
+    out = {"value": args.batchsize / dt, "unit": "sequences/s", "ms_per_iteration": dt * 1e3, "acts_per_sec": games * 2 / dt,
+           "host_issue_ms_per_iteration": t_issue / iterations * 1e3, "iterations": iterations,
+           "config": {"workload": "%d concurrent 2-player SAD games, one rollout step (reset + observe + act + env step + n-step / priority / sequence push + "
+                                  "flush into the prioritized replay) per learner update of %d sequences x 80 steps drawn from that replay; rollout on its own "
+                                  "stream, the next batch drawn at the end of an update (selfplay --overlap_rollout 1 --draw_ahead 1)" % (games, args.batchsize)}}
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
 EXCHANGE_TIMEOUT_S = int(os.environ.get("HSAD_BENCH_EXCHANGE_TIMEOUT", "180"))
 
 
@@ -812,6 +848,7 @@ def main():
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:
             out["actor"] = actor_bench(dev)
+            out["one_gpu_training"] = training_bench(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         # what in this line is NOT measured by this run: the HBM-traffic and MFMA-busy counter figures are read from the committed rocprofv3

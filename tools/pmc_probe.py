@@ -2,7 +2,7 @@
 hot path per invocation plus two calibration kernels of known traffic IN THE SAME RUN (a plain streaming fill and a plain
 copy of exactly CAL_BYTES), so tools/pmc_summarize.py can correct the counters the way the guide prescribes.
 
-  python tools/pmc_probe.py env | env5 | env5_literal | gemm | learner | actor"""
+  python tools/pmc_probe.py env | env5 | env5_literal | gemm | learner | learner_b<rows> | actor"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -57,6 +57,18 @@ elif leg == "gemm":
 elif leg == "learner":
     import bench
     bench.learner_bench(dev, updates=5, warmup=2, gemm_probe=False)
+elif leg.startswith("learner_b"):                # learner updates at B = <n> rows (tools/recurrence_traffic.sh: traffic of the recurrences vs batch rows)
+    from hanabi_sad_amd.composite import CompositeLearner
+    from hanabi_sad_amd.selfplay import init_weights
+    from tests.test_r2d2_kernels_gpu import _rand_batch
+    F, H, A, T, B = 838, 512, 21, 80, int(leg[len("learner_b"):])
+    W = init_weights(F, H, A, 5, 1)
+    L = CompositeLearner(W, W, 3, 0.999, device=dev)
+    batch, weight = _rand_batch(T, B, F, A)
+    for _ in range(6):
+        L.loss(batch, weight, 0.0); L.optimizer_step()
+    torch.cuda.synchronize()
+    L.check_sync()
 elif leg == "actor":
     import bench
     bench.actor_bench(dev, games=16384, steps=20, warmup=100)
