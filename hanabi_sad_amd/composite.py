@@ -7,6 +7,7 @@ classes only hand over pointers, so a C++ / pybind host replaces them with the s
 R2D2Net.state_dict()).  `CompositeAgent` / `CompositeLearner` offer the same call surface as r2d2.R2D2Agent / r2d2.R2D2Learner
 (hanabi_sad_amd/r2d2.py keeps the same schedule in Python for the fp32-exact mode and for A/B tests)."""
 import ctypes as C
+import os
 
 import torch
 
@@ -209,7 +210,7 @@ class CompositeLearner:
         self.h, self.shape = None, None
         self.flat = self.online.flat
         self.chunks, self.wgrad_split = 4, 8
-        self.fused = self.FUSED_DEFAULT    # flag word of hsad_r2d2_learner_set_fused: fused recurrences, split placement + projection stage in the BPTT
+        self.fused = int(os.environ.get("HSAD_LEARNER_FUSED", "0"), 0) or self.FUSED_DEFAULT    # (developer override) flag word of hsad_r2d2_learner_set_fused: fused recurrences, split placement + projection stage in the BPTT
         self.grad = {}
         if T is not None:
             self._ensure(T, rows)
