@@ -13,7 +13,7 @@ SETS=("FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_E
 for B in ${ROWS:-128 96 64 32}; do
   i=0
   for set in "${SETS[@]}"; do
-    rm -rf /tmp/rt_$B_$i
+    rm -rf /tmp/rt_${B}_$i
     timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/rt_${B}_$i -o c -- python $R/tools/pmc_probe.py learner_b$B > $O/log_${B}_$i.txt 2>&1
     f=$(find /tmp/rt_${B}_$i -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && cp $f $O/counters_b${B}_set$i.csv
