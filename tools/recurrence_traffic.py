@@ -1,7 +1,9 @@
 """python tools/recurrence_traffic.py <dir of counters_b<rows>_set<k>.csv> <out.json>: the memory-side traffic of lstm_fused_fwd_kernel / lstm_fused_bwd_kernel
 per launch as a function of the batch rows (tools/recurrence_traffic.sh collects the passes).  FETCH_SIZE is reported in KiB with 128-byte requests
 tallied at 64 (MI355X_MICROARCH.md, HBM): bytes are bracketed -- `lo` = counter x 1 (every request narrow), `hi` = counter x 2 (every request wide) --
-and, where the request counters exist, resolved: 32-byte requests from TCC_EA0_RDREQ_32B, the others at 64 bytes.  A least-squares line through
+and, where the request counters exist, the 32-byte requests are taken out (TCC_EA0_RDREQ_32B).  NOTE: that figure equals `lo` by construction
+(FETCH_SIZE = requests x 64 B) -- the counters cannot tell a 64-byte request from a 128-byte one tallied at 64; what does is the fit below: a read
+side whose per-row slope is under the bytes the kernel must at least fetch per row proves that requests are wide (`hi` applies).  A line through
 the four batch sizes splits every figure into a part per launch (weights: once per row block's XCD, counter blocks) and a part per batch row."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
