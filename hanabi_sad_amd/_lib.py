@@ -160,6 +160,7 @@ SIGNATURES = {
     "hsad_lstm_debug_timing": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "hsad_lstm_debug_timing32": (C.c_int, [C.POINTER(C.c_uint64), C.c_int]),
     "hsad_lstm_debug_enable": (C.c_int, [C.c_int]),
+    "hsad_lstm_debug_trace": (C.c_int, [C.POINTER(C.c_uint64), C.c_size_t]),
     "hsad_debug_resident_kernel": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "hsad_lstm_sync_timed_out": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "hsad_q_head": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

@@ -184,8 +184,8 @@ static int g8_launch(int epi, G8Args& P, int n_cu, hipStream_t s) {
   if (cell_aux == 0 && epi == G8_CELL_NOSTATE) kp = gemm8_kernel<G8_CELL_NOSTATE, 0>;
   if (cell_wide && epi == G8_CELL) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL, 0, true> : gemm8_kernel<G8_CELL, kCellStoreAux, true>;
   if (cell_wide && epi == G8_CELL_NOSTATE) kp = cell_aux == 0 ? gemm8_kernel<G8_CELL_NOSTATE, 0, true> : gemm8_kernel<G8_CELL_NOSTATE, kCellStoreAux, true>;
-  if (g_lstm_dbg_enable && epi == G8_CELL) kp = cell_wide ? gemm8_kernel<G8_CELL, kCellStoreAux, true, true> : gemm8_kernel<G8_CELL, kCellStoreAux, false, true>;
-  if (g_lstm_dbg_enable && epi == G8_BF16) kp = gemm8_kernel<G8_BF16, kCellStoreAux, false, true>;
+  if (g_lstm_dbg_enable == 1 && epi == G8_CELL) kp = cell_wide ? gemm8_kernel<G8_CELL, kCellStoreAux, true, true> : gemm8_kernel<G8_CELL, kCellStoreAux, false, true>;
+  if (g_lstm_dbg_enable == 1 && epi == G8_BF16) kp = gemm8_kernel<G8_BF16, kCellStoreAux, false, true>;
   // pair launches of one shape: the problems' rounds interleaved per XCD (developer switch HSAD_G8_INTERLEAVE=0: problem 1 behind problem 0)
   static const int interleave = getenv("HSAD_G8_INTERLEAVE") ? atoi(getenv("HSAD_G8_INTERLEAVE")) : 1;
   P.interleave = 0;
@@ -738,7 +738,7 @@ int hsad_lstm_cell_fused(int Bn, int H, int Kx, const void* x16, int ldx, const 
       }
       return HSAD_OK;
     }
-    auto kern = g_lstm_dbg_enable ? ((c_out || h_out32) ? lstm_cell_gemm256_kernel<true, true> : lstm_cell_gemm256_kernel<false, true>)
+    auto kern = g_lstm_dbg_enable == 1 ? ((c_out || h_out32) ? lstm_cell_gemm256_kernel<true, true> : lstm_cell_gemm256_kernel<false, true>)
                                   : ((c_out || h_out32) ? lstm_cell_gemm256_kernel<true> : lstm_cell_gemm256_kernel<false>);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, (hipStream_t)stream, a);
@@ -767,7 +767,7 @@ int hsad_lstm_cell_fused_pair(int Bn, int H, int Kx, int ldx, const void* x16_a,
                               const void* Wcat_a, const void* Wcat_b, const float* bias_a, const float* bias_b, const float* c_prev_a,
                               const float* c_prev_b, float* c_out_a, float* c_out_b, float* h_out32_a, float* h_out32_b, void* h_out16_a,
                               void* h_out16_b, void* stream) {
-  const bool pp_ok = g_cell_variant.pp() != 0 && g_cell_variant.tile() != 128 && Bn >= 4096 && Bn % 256 == 0 && (4 * H) % 256 == 0 && !g_lstm_dbg_enable &&
+  const bool pp_ok = g_cell_variant.pp() != 0 && g_cell_variant.tile() != 128 && Bn >= 4096 && Bn % 256 == 0 && (4 * H) % 256 == 0 && g_lstm_dbg_enable != 1 &&
                      ((Kx + H) / kBK) % 2 == 0 &&
                      x16_a && x16_b && h_prev16_a && h_prev16_b && Wcat_a && Wcat_b && bias_a && bias_b && c_prev_a && c_prev_b &&
                      (c_out_a || h_out32_a || h_out16_a) && (c_out_b || h_out32_b || h_out16_b) && H >= 64 && H % kBK == 0 && Kx >= kBK && Kx % kBK == 0 &&
@@ -833,8 +833,27 @@ int hsad_debug_resident_kernel(int n_wg, int threads, int lds_bytes, const void*
   return HSAD_OK;
 }
 
+static u64_t* g_lstm_trace_dev = nullptr;
+constexpr size_t kTraceWords = (size_t)2 * kTraceRec * kTraceNb * kTraceT * kTraceK;
+
 int hsad_lstm_debug_enable(int enable) {
-  g_lstm_dbg_enable = enable != 0;
+  if (enable == 2 && !g_lstm_trace_dev) {
+    HIP_TRY(hipMalloc(&g_lstm_trace_dev, kTraceWords * sizeof(u64_t)));
+    HIP_TRY(hipMemset(g_lstm_trace_dev, 0, kTraceWords * sizeof(u64_t)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_trace), &g_lstm_trace_dev, sizeof(g_lstm_trace_dev)));
+  }
+  g_lstm_dbg_enable = enable == 2 ? 2 : (enable != 0);
+  return HSAD_OK;
+}
+
+/* per-step trace of the fused recurrences (enable = 2): copies [2 kernels][6 records][16 unit blocks][96 steps][12 stamps] 100 MHz
+ * stamps of the LAST launches (synchronises), then clears the buffer */
+int hsad_lstm_debug_trace(uint64_t* out, size_t n_words) {
+  if (!out || n_words != kTraceWords) return nfail(HSAD_ERR_INVALID, "lstm_debug_trace: out must hold %zu words", kTraceWords);
+  if (!g_lstm_trace_dev) return nfail(HSAD_ERR_INVALID, "lstm_debug_trace: call hsad_lstm_debug_enable(2) first");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, g_lstm_trace_dev, kTraceWords * sizeof(u64_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(g_lstm_trace_dev, 0, kTraceWords * sizeof(u64_t)));
   return HSAD_OK;
 }
 
@@ -1367,7 +1386,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     q.timeout = counters + (size_t)nrec * T * nrb;
     q.T = T;
     q.Bn = Bn;
-    q.dbg = g_lstm_dbg_enable;
+    q.dbg = g_lstm_dbg_enable == 1;
+    q.trace_slot = g_lstm_dbg_enable == 2 ? i * kTraceNb : -1;
   }
   m.nnet = nnet;
   m.nl = nlayer;
@@ -1478,6 +1498,7 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
       q.counters = q.dO_out_counters;
       q.timeout = counters + (size_t)R * TL * nrb;
       q.dbg = 0;
+      q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + j) * kTraceNb : -1;
       q.T = Tc;
       q.Bn = Bn;
       ++j;
@@ -1505,7 +1526,8 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.counters = counters + (size_t)j * TL * nrb;
     q.timeout = counters + (size_t)R * TL * nrb;
     q.dc_io = r.dc_io;
-    q.dbg = g_lstm_dbg_enable;
+    q.dbg = g_lstm_dbg_enable == 1;
+    q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + j) * kTraceNb : -1;
     q.T = Tc;
     q.Bn = Bn;
     q.has_next = r.has_next;
@@ -1529,6 +1551,7 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
       z.ldT = r.sink_ldT;
       z.bsum0 = r.sink_bias_grad;
       z.counters = counters + (size_t)j * TL * nrb;
+      z.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + j) * kTraceNb : -1;
       z.timeout = counters + (size_t)R * TL * nrb;
       z.T = Tc;
       z.Bn = Bn;

@@ -14,6 +14,7 @@
 #ifndef HSAD_H_
 #define HSAD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -383,6 +384,10 @@ int hsad_lstm_debug_timing(uint64_t* out16, int reset);
 int hsad_lstm_debug_timing32(uint64_t* out32, int reset);   /* + slots 16-31: the fused BPTT kernel (top layer 16-21, lower layer 24-29) */
 /* phase timers of the FUSED persistent kernels (off by default: a stamp costs ~0.1 us of the ~5 us step it measures) */
 int hsad_lstm_debug_enable(int enable);
+/* enable = 2: per-step trace instead of the summed timers -- thread 0 of every workgroup of row block 0 of the fused recurrences
+ * stamps s_memrealtime (100 MHz, chip-wide) at its phase boundaries; hsad_lstm_debug_trace copies the last launches' stamps
+ * [kernel: 0 forward, 1 BPTT][record 6][unit block 16][step 96][stamp 12] (n_words must be 2*6*16*96*12) and clears them */
+int hsad_lstm_debug_trace(uint64_t* out, size_t n_words);
 /* test hook: n_wg workgroups (threads, lds_bytes each) resident on `stream` until *flag_host_mapped (pinned host word) != 0 or max_us --
  * the footprint of a posted communication kernel whose peer has not answered, next to the learner's whole-chip persistent launches */
 int hsad_debug_resident_kernel(int n_wg, int threads, int lds_bytes, const void* flag_host_mapped, int max_us, void* stream);
