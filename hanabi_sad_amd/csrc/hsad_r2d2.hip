@@ -1388,6 +1388,10 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     q.Bn = Bn;
     q.dbg = g_lstm_dbg_enable == 1;
     q.trace_slot = g_lstm_dbg_enable == 2 ? i * kTraceNb : -1;
+    static const int fwd_early = getenv("HSAD_FWD_EARLY") ? atoi(getenv("HSAD_FWD_EARLY")) : 1;     // developer switch: 0 = the round-3 schedule
+    q.early = fwd_early;
+    static const int fwd_keep_aux = getenv("HSAD_FWD_KEEP_AUX") ? atoi(getenv("HSAD_FWD_KEEP_AUX")) : 2;     // developer switch: 2 = nt (streaming) stores, 0 = plain (rounds 3-5)
+    q.keep_aux = fwd_keep_aux;
   }
   m.nnet = nnet;
   m.nl = nlayer;
@@ -1397,7 +1401,7 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
-  const size_t lds = (size_t)(4 * 32 * H + 32 * 40) * sizeof(bf16_t) + 16;   // h tile + ring of three X tiles + publish staging
+  const size_t lds = (size_t)(4 * 32 * H + 32 * 40) * sizeof(bf16_t) + 16 + 32;   // h tile + ring of three X tiles + publish staging + verdict / poll words
   hipEvent_t te0 = nullptr, te1 = nullptr;
   if (g_fused_timing.on) {
     HIP_TRY(hipEventCreate(&te0));
@@ -1528,6 +1532,8 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
     q.dc_io = r.dc_io;
     q.dbg = g_lstm_dbg_enable == 1;
     q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + j) * kTraceNb : -1;
+    static const int bwd_rot = getenv("HSAD_BWD_ROT") ? atoi(getenv("HSAD_BWD_ROT")) : 26;     // developer switches (bits): 1 rotated tile loads, 2 written-through copy behind the own signal, 4 no transposed copy (timing only!), 8 nt transposed stores, 16 nt loads of the saved activations
+    q.rot = bwd_rot;
     q.T = Tc;
     q.Bn = Bn;
     q.has_next = r.has_next;

@@ -75,6 +75,16 @@ def forward_budget(rec):
     mean_step = float(np.mean(rows["step"])) if rows["step"] else None
     out = {k: med(v) for k, v in rows.items()}
     out["step_mean"] = round(mean_step, 3) if mean_step else None
+    # which members publish late: mean offset of each unit block's signal behind the group's first, steps 20..T-2
+    offs = [np.mean([tr[0, rec][:, t, 6] - tr[0, rec][:, t, 6].min() for t in range(20, T - 1)], axis=0) for tr in traces if tr[0, rec][:, 1:T, 6].all()]
+    if offs:
+        out["member_signal_offset_us"] = [round(float(x), 2) for x in np.mean(offs, axis=0)]
+        # and where a late member loses it: mean of each phase per member
+        ph = {}
+        for name, k0, k1 in (("bg", 6, 7), ("h_mfma", 3, 4), ("cell", 4, 5), ("publish", 5, 6)):
+            ph[name] = [round(float(x), 2) for x in np.mean([np.mean([tr[0, rec][:, t, k1] - tr[0, rec][:, t, k0] for t in range(20, T - 1)], axis=0) for tr in traces], axis=0)]
+        ph["step_top_to_landed"] = [round(float(x), 2) for x in np.mean([np.mean([tr[0, rec][:, t, 3] - tr[0, rec][:, t, 0] for t in range(20, T - 1)], axis=0) for tr in traces], axis=0)]
+        out["member_phase_us"] = ph
     return out
 
 def backward_budget(jrec):
