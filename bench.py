@@ -538,6 +538,7 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
                 break
         torch.cuda.synchronize()
     shard.check_errors()
+    link.close()             # ipc transport: unmap the peers' arenas, free the landing ring (two links per A/B run)
     return out
 
 

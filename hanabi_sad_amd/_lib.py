@@ -62,7 +62,7 @@ class LstmFusedBwdRec(C.Structure):
                 ("c_before", C.c_void_p), ("dO", C.c_void_p), ("dG16", C.c_void_p), ("dc_io", C.c_void_p), ("has_next", C.c_int),
                 ("xchg", C.c_void_p), ("saved_frag_major", C.c_int), ("tail_is_zero", C.c_int), ("xout", C.c_void_p), ("dO_stage", C.c_void_p), ("sink_WT", C.c_void_p), ("sink_out16", C.c_void_p), ("sink_mask16", C.c_void_p),
                 ("sink_xout", C.c_void_p), ("sink_outT16", C.c_void_p), ("sink_ldT", C.c_int), ("sink_bias_grad", C.c_void_p), ("dGT16", C.c_void_p), ("ldT", C.c_int), ("bias_grad0", C.c_void_p), ("bias_grad1", C.c_void_p),
-                ("bias_col_map", C.c_void_p), ("layout_steps", C.c_int)]
+                ("bias_col_map", C.c_void_p), ("layout_steps", C.c_int), ("wide_blocks", C.c_int)]
 
 
 class LstmFusedRec(C.Structure):

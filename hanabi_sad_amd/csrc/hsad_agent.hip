@@ -736,6 +736,7 @@ struct hsad_r2d2_learner {
   volatile unsigned* h_timeout = nullptr;      // pinned, device-mapped: OR of the sticky timeout words as of the last gathered update (timeout_gather_kernel)
   unsigned* d_timeout = nullptr;               // its device address
   bool sink_bptt = true;      // ... and the input layer's d x = dG0 W_ih0 (ReLU-masked) as a sink stage (set_fused bit 5; needs bits 3, 4)
+  bool wide_bptt = true;      // the four-stage single-chunk launch in the 16-row x 64-unit blocking (lstm_bptt_wide_kernel; set_fused bit 25 = off, A/B)
   bool fb_split = false, fb_proj = false, fb_sink = false;      // layout of the fbsync blocks in use
   bool split_refresh = false; // optimizer_step re-derives the LSTM operands on the side stream (net_refresh_split): measured 1.521 vs 1.504 ms
                               // per update in line -- the refresh slows the input-layer GEMM it runs next to by more than it hides
@@ -1048,6 +1049,7 @@ int hsad_r2d2_learner_set_fused(hsad_r2d2_learner* L, int fused_fwd) {
   L->group_wgrad = !(fused_fwd & 128);                          // bit 7: the round-4 tail (six split-K GEMMs on two streams) instead of the grouped launch (A/B)
   L->btail = (fused_fwd >> 16) & 0xff;                          // bits 16-23: length of the head chunk [0, btail) processed last
   L->fuse_heads = !(fused_fwd & (1 << 24));                     // bit 24: the four-launch head / loss chain (A/B)
+  L->wide_bptt = !(fused_fwd & (1 << 25));                      // bit 25: the 32 x 32 blocking of the four-stage BPTT launch (A/B)
   return 0;
 }
 // the sticky timeout words of every counter block a launch of this learner may have used (hsad_lstm_sync_timed_out semantics): a bounded
@@ -1491,6 +1493,7 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
         r.sink_bias_grad = snkT ? g[on->iB1] : nullptr;
         sink_T = snkT;
         r.layout_steps = TL;
+        r.wide_blocks = (L->wide_bptt && dgt_in_kernel && use_sink) ? 1 : 0;
       }
       if (L->fb_tc != TL || L->fb_split != use_split || L->fb_proj != use_proj || L->fb_sink != use_sink) {      // another chunk length / placement: the blocks' layout changes, start from clean ones
         L->fb_split = use_split;

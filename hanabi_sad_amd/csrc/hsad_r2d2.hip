@@ -44,6 +44,7 @@ namespace {
 #include "r2d2/lstm_fused_fwd.inc"
 #include "r2d2/lstm_seq_bwd.inc"
 #include "r2d2/lstm_fused_bwd.inc"
+#include "r2d2/lstm_bptt_wide.inc"
 #include "r2d2/heads_loss_optim.inc"
 #include "r2d2/act.inc"
 }  // namespace
@@ -118,6 +119,8 @@ static int launch_seq_bwd(LstmSeqBwdArgsN m, int nrec, int H, int nrb, unsigned*
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }
+
+static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch, void* next_sync_scratch, hipStream_t s);
 
 extern "C" {
 
@@ -1464,6 +1467,14 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
       if (!recs[n * nlayer + nlayer - 1].sink_WT) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: sink stage on every net or on none");
   const int nl_int = (proj ? 2 * nlayer - 1 : nlayer) + (sink ? 1 : 0), nint = nnet * nl_int;
   if (nint > 6) return nfail(HSAD_ERR_INVALID, "lstm_backward_fused: %d pipeline stages per launch (at most 6)", nint);
+  // round 6: the four-stage launch of one two-layer net re-blocked as 16 rows x 64 units per workgroup (lstm_bptt_wide.inc) when the shape
+  // allows: whole sequence in one chunk, fragment-major saved activations, transposed dG written in the launch, <= 8 row blocks of 16 rows
+  // (one XCD each).  recs[0].wide_blocks = 0 keeps the 32 x 32 kernel (A/B).
+  if (recs[0].wide_blocks && nnet == 1 && nlayer == 2 && split && proj && sink && H == 512 && Bn / 16 <= 8 && device_cus() >= 256 && Tc >= 1 &&
+      !recs[0].has_next && !recs[1].has_next && recs[0].saved_frag_major && recs[1].saved_frag_major && recs[0].dGT16 && recs[1].dGT16 &&
+      recs[0].dO && recs[0].xchg && recs[1].xchg && recs[0].gates && recs[1].gates && recs[0].cseq && recs[1].cseq && recs[0].WhhT_blocked &&
+      recs[1].WhhT_blocked)
+    return lstm_bptt_wide_launch(Tc, Bn, recs, sync_scratch, next_sync_scratch, s);
   const int grid = split ? 8 * nunit * ((nsg * nl_int + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
   if (grid > device_cus())
     return nfail(HSAD_ERR_INVALID, "fused persistent BPTT launch needs %d co-resident workgroups per XCD, the device has %d", grid / 8, device_cus() / 8);
@@ -1607,3 +1618,87 @@ int hsad_lstm_backward_chunk(int Tc, int Bn, int H, const float* gates, const fl
 }
 
 }  // extern "C"
+
+// the 16-row x 64-unit blocking of the four-stage BPTT launch (lstm_bptt_wide_kernel): one net, two layers, H = 512, whole sequence.
+// Sync scratch: the block laid out for the 32 x 32 kernel's split placement with projection + sink stages (R = 8 counter rows of TL * Bn/32
+// words) is reused as [group words][4 stages x TL x Bn/16 counters][timeout] -- same size, the timeout word at the same place.
+static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch, void* next_sync_scratch, hipStream_t s) {
+  constexpr int H = 512;
+  const int nrb32 = Bn / 32, nrb = Bn / 16, R = 8;
+  const int TL = recs[0].layout_steps > Tc ? recs[0].layout_steps : Tc;
+  unsigned* sync = (unsigned*)sync_scratch;
+  unsigned* counters = sync + 2 * R * nrb32;
+  const size_t words = seq_sync_words(R, TL, nrb32);
+  if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
+  BpttWideArgs m{};
+  auto ctr = [&](int j) { return counters + (size_t)j * TL * nrb; };
+  for (int k = 0; k < 2; ++k) {      // the two recurrences: stage 0 = top layer, stage 2 = the layer below
+    const hsad_lstm_fused_bwd_rec& r = recs[k];
+    BpttWideStage& q = m.st[2 * k];
+    q.kind = 0;
+    q.WT = (const bf16_t*)r.WhhT_blocked;
+    q.counters = ctr(2 * k);
+    q.gates = r.gates;
+    q.cseq = r.cseq;
+    q.c0 = r.c_before;
+    q.dO = k ? r.dO_stage : r.dO;
+    q.dO_counters = k ? ctr(1) : nullptr;
+    q.xchg = (bf16_t*)r.xchg;
+    q.dc_io = r.dc_io;
+    q.dGT = (bf16_t*)r.dGT16;
+    q.ldT = r.ldT;
+    q.bsum0 = r.bias_grad0;
+    q.bsum1 = r.bias_grad1;
+    q.colmap = r.bias_col_map;
+    q.feeds = 1;
+    q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + 2 * k) * kTraceNb : -1;
+  }
+  {
+    BpttWideStage& q = m.st[1];      // projection stage: dO of the lower layer = dG_top W_ih_top
+    q.kind = 1;
+    q.WT = (const bf16_t*)recs[1].WihT_above_blocked;
+    q.tin = (const bf16_t*)recs[0].xchg;
+    q.tin_counters = ctr(0);
+    q.counters = ctr(1);
+    q.dO_out = recs[1].dO_stage;
+    q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + 1) * kTraceNb : -1;
+    BpttWideStage& z = m.st[3];      // sink stage: d x of the input layer = dG_lower W_ih_lower, ReLU-masked
+    z.kind = 2;
+    z.WT = (const bf16_t*)recs[1].sink_WT;
+    z.tin = (const bf16_t*)recs[1].xchg;
+    z.tin_counters = ctr(2);
+    z.counters = ctr(3);
+    z.dx_out16 = (bf16_t*)recs[1].sink_out16;
+    z.dxT = (bf16_t*)recs[1].sink_outT16;
+    z.ldT = recs[1].sink_ldT;
+    z.mask16 = (const bf16_t*)recs[1].sink_mask16;
+    z.bsum0 = recs[1].sink_bias_grad;
+    z.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + 3) * kTraceNb : -1;
+  }
+  m.nstage = 4;
+  m.nrb = nrb;
+  m.T = Tc;
+  m.Bn = Bn;
+  m.group_words = reinterpret_cast<u64_t*>(sync);
+  m.timeout = counters + (size_t)R * TL * nrb32;
+  m.force_cross_xcd = g_force_cross_xcd;
+  m.zero_ptr = (unsigned*)next_sync_scratch;
+  m.zero_words = next_sync_scratch ? (int)words : 0;
+  const size_t lds = (size_t)16 * 64 * 16 + (size_t)16 * (256 + 8) * sizeof(bf16_t) + 64;
+  hipEvent_t te0 = nullptr, te1 = nullptr;
+  if (g_fused_timing.on) {
+    HIP_TRY(hipEventCreate(&te0));
+    HIP_TRY(hipEventCreate(&te1));
+    HIP_TRY(hipEventRecord(te0, s));
+  }
+  hipLaunchKernelGGL(lstm_bptt_wide_kernel<64>, dim3(256), dim3(256), lds, s, m);
+  HIP_TRY(hipGetLastError());
+  if (te0) {
+    HIP_TRY(hipEventRecord(te1, s));
+    g_fused_timing.ev.push_back({te0, te1});
+    g_fused_timing.flop.push_back(4.0 * Tc * Bn * 4.0 * H * H * 2.0);
+    g_fused_timing.kind.push_back(1);
+  }
+  return HSAD_OK;
+}
+

@@ -1181,7 +1181,7 @@ struct hsad_replay {
     static void yield() { std::this_thread::yield(); }
   };
   SlotRingT<HipRingRuntime, kCanonSlots> canon;      // which draw holds which slot (hsad_slot_ring.h)
-  volatile unsigned long long* h_done = nullptr;   // hipHostMalloc (coherent), written by replay_sample_kernel
+  volatile unsigned long long* h_done = nullptr;   // [kCanonSlots] hipHostMalloc (coherent): slot k's word is written by the replay_sample_kernel that read slot k
   unsigned long long* d_done = nullptr;            // device view of h_done
   int* d_tmp_id;
   StreamFence fence;
@@ -1272,9 +1272,9 @@ int hsad_replay_create(int capacity, int seed, float alpha, float beta, int pref
   }
   he = hipHostMalloc((void**)&r->h_canon_ring, sizeof(float) * hsad_replay::kCanonSlots * kMaxBatch, hipHostMallocMapped | hipHostMallocCoherent);
   if (he == hipSuccess) he = hipHostGetDevicePointer((void**)&r->d_canon_ring, (void*)r->h_canon_ring, 0);
-  if (he == hipSuccess) he = hipHostMalloc((void**)&r->h_done, 64, hipHostMallocMapped | hipHostMallocCoherent);
+  if (he == hipSuccess) he = hipHostMalloc((void**)&r->h_done, sizeof(unsigned long long) * hsad_replay::kCanonSlots, hipHostMallocMapped | hipHostMallocCoherent);
   if (he == hipSuccess) {
-    *r->h_done = 0ull;
+    for (int k = 0; k < hsad_replay::kCanonSlots; ++k) r->h_done[k] = 0ull;
     he = hipHostGetDevicePointer((void**)&r->d_done, (void*)r->h_done, 0);
   }
   if (he != hipSuccess) {
@@ -1353,7 +1353,7 @@ int hsad_replay_sample(hsad_replay* r, int batch, void* const* out_fields, float
   float* hc = canon_slot(r, &slot, &number, s);
   for (int i = 0; i < batch; ++i) hc[i] = std::generate_canonical<float, 24>(r->rng);
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, batch, canon_dev(r, slot), weight, (const float*)nullptr,
-                     (const int*)nullptr, r->d_done, number);
+                     (const int*)nullptr, r->d_done + slot, number);
   const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
   hipLaunchKernelGGL(unpack_rows_kernel, dim3((batch * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, batch, r->T,
                      r->rd.sampled_ids, 0, r->rd.valid_rows);
@@ -1390,15 +1390,15 @@ int hsad_replay_sample_at(hsad_replay* r, int n, const float* targets_host, void
   FenceUse use_r(r->fence, s);
   HIP_TRY(use_r.err);
   const float* cv = r->d_canon;       // (n = 0: not read)
+  int slot = -1;                       // (n = 0 holds no staging slot and publishes nothing)
+  unsigned long long number = 0;
   if (n > 0) {
-    int slot;
-    unsigned long long number;
     float* hc = canon_slot(r, &slot, &number, s);
     for (int i = 0; i < n; ++i) hc[i] = targets_host[i];
     cv = canon_dev(r, slot);
   }
   hipLaunchKernelGGL(replay_sample_kernel, dim3(1), dim3(1024), 0, s, r->rd, n, cv, raw_weight, cv, (const int*)nullptr,
-                     r->d_done, r->canon.issued);
+                     slot >= 0 ? r->d_done + slot : (unsigned long long*)nullptr, number);
   if (n > 0) {
     const FieldOut fp = field_out(r->L, out_fields, r->out_kind, r->out_ld);
     hipLaunchKernelGGL(unpack_rows_kernel, dim3((n * r->T + 3) / 4), dim3(256), 0, s, r->L, r->rows, fp, n, r->T, r->rd.sampled_ids, 0,

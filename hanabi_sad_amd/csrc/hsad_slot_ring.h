@@ -1,7 +1,8 @@
 // A ring of K host staging slots whose contents asynchronous device operations read in place (the uniforms of a replay draw: the sampling
 // kernel reads the slot from mapped host memory, csrc/hsad_replay.hip).  The host fills slot k, enqueues operation number n = seq[k] that
-// reads it, and may refill the slot only after that operation has run; the operation publishes its number into a host-visible word when
-// it has read the slot.  Header-only and parametrised over the runtime like hsad_stream_fence.h: compiled against HIP in libhsad.so and
+// reads it, and may refill the slot only after that operation has run; the operation publishes its number into the SLOT's host-visible
+// word (done[k]) when it has read the slot -- one word per slot, so operations on different streams may finish in any order (round 6;
+// one shared word assumed completion in issue order, which two streams do not give).  Header-only and parametrised over the runtime like hsad_stream_fence.h: compiled against HIP in libhsad.so and
 // against a model of streams in the ThreadSanitizer harness (tests/tsan/slot_ring_tsan.cc), which drives a host that runs many
 // operations ahead of a slow device.
 //
@@ -23,7 +24,7 @@ struct SlotRingT {
   unsigned long long issued = 0;    // operations handed a slot so far
   int next = 0;
 
-  // -> the slot to fill for the operation about to be enqueued on s; *number is what that operation must publish into *done (release,
+  // -> the slot k to fill for the operation about to be enqueued on s; *number is what that operation must publish into done[k] (release,
   // system scope) once it has read the slot.  Blocks while the operation that read this slot last has not published its number --
   // normally long true, checked without a runtime call.  A stream that has gone idle without the number appearing (the operation
   // failed to launch) ends the wait instead of hanging the host.
@@ -35,7 +36,7 @@ struct SlotRingT {
 #else
     if (seq[k] && stream[k]) {      // (the round-5 bug, kept for the harness to prove it can see it)
 #endif
-      for (unsigned spins = 0; __atomic_load_n(done, __ATOMIC_ACQUIRE) < seq[k]; ++spins) {
+      for (unsigned spins = 0; __atomic_load_n(done + k, __ATOMIC_ACQUIRE) < seq[k]; ++spins) {
         if ((spins & 255) == 255 && RT::stream_idle(stream[k])) break;
         RT::yield();
       }

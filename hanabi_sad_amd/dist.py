@@ -415,8 +415,31 @@ class _IpcTransport:
         t.view(torch.uint8).reshape(-1).copy_(self.mine[off:off + nb]) if t.dtype != torch.uint8 else t.reshape(-1).copy_(self.mine[off:off + nb])
 
     def close(self):
-        if self.q is not None:
-            self.q.put(None)
+        """stop the notifier, then (all ranks, behind a store barrier: nobody unmaps an arena a peer may still be copying into) close the
+        peers' mappings and free the own landing arena"""
+        import ctypes as C
+        if self.q is None:
+            return
+        self.q.put(None)
+        self.thread.join(timeout=10.0)
+        self.q = None
+        try:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            self.store.set(self.keys + "closed/%d" % self.rank, b"1")
+            import time
+            deadline = time.monotonic() + 10.0
+            while not self.store.check([self.keys + "closed/%d" % p for p in range(self.world)]) and time.monotonic() < deadline:
+                time.sleep(1e-3)
+        except Exception:          # a peer (or the store's owner) is already gone: unmapping is all that is left to do
+            pass
+        for q in self.peer_base.values():
+            self.lib.hsad_ipc_close(C.c_void_p(q))
+        self.peer_base = {}
+        if self.base:
+            self.mine = None
+            self.lib.hsad_ipc_free(C.c_void_p(self.base))
+            self.base = None
 
 
 class ReplayLink:
@@ -697,6 +720,9 @@ class ReplayLink:
                         self._bucket_ev.record()
                 else:
                     rec["psend"] = ps
+                    if self.ipc is not None and self.xd is not None:   # ipc: the puts are async copies on the down stream -- the bucket is busy until the last has left
+                        self._bucket_ev = torch.cuda.Event()
+                        self._bucket_ev.record()
                 td.mark("param_send_ms")
             td.stop()
         with up:

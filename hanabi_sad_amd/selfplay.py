@@ -510,6 +510,7 @@ def main(argv=None):
             print("Speed: train: %.1f, act: %.1f, buffer_size: %d" % (args.num_update * args.batchsize / dt, c.num_act() / dt, c.size()))
             print("exchange per round (ms), transport %s: %s" % (link.transport, ", ".join("%s %.3f" % kv for kv in sorted(link.timings().items()))))
         dist.barrier()
+        link.close()
         dist.destroy_process_group()
         return
     t0 = time.time()

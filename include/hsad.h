@@ -651,6 +651,10 @@ typedef struct hsad_lstm_fused_bwd_rec {
   int layout_steps;   /* record 0 only; 0 = Tc.  Chunks of different lengths that share (ping-pong) sync blocks pass the LONGEST chunk length
                        * here: counters and the sticky timeout word then sit at the same place for every launch (read the timeout with
                        * that length), and a launch clears its partner block for any of them. */
+  int wide_blocks;    /* record 0 only (round 6).  Non-zero: a launch of ONE two-layer net (nnet 1, nlayer 2, H 512) with projection + sink
+                       * stages, fragment-major activations, dGT16 on both records, no has_next and Bn <= 128 runs the 16-row x 64-unit blocking
+                       * (lstm_bptt_wide_kernel: weight slices in registers, 64 KB tiles, the four stages of a row block on one XCD; xout /
+                       * sink_xout are then not used).  Same bits for dG, dO, d x.  0 = the 32 x 32 blocking (A/B); other shapes ignore it. */
 } hsad_lstm_fused_bwd_rec;
 int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const hsad_lstm_fused_bwd_rec* recs, void* sync_scratch,
                              void* next_sync_scratch, void* stream);

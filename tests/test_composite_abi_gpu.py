@@ -310,7 +310,9 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
     modes = {"fused": 1 | (1 << 8), "fused fwd + chunked bwd": 3, "fused, BPTT in 2 chunks": 1 | (2 << 8), "chunked": 0,   # (bits 8-15 = BPTT chunks; 0 keeps the last setting)
              "fused, split placement": 9 | (1 << 8), "fused, split placement, 2 chunks": 9 | (2 << 8),
              "fused, split placement + projection stage": 25 | (1 << 8), "fused, split + projection, 2 chunks": 25 | (2 << 8),
-             "fused, split + projection + sink stage": 57 | (1 << 8), "fused, split + projection + sink, 2 chunks": 57 | (2 << 8)}
+             "fused, split + projection + sink stage": 57 | (1 << 8), "fused, split + projection + sink, 2 chunks": 57 | (2 << 8),
+             # (bit 25 off = default: the four-stage single-chunk launch in the 16-row x 64-unit blocking where the shape allows -- H = 512, B <= 128)
+             "fused, split + projection + sink stage, 32 x 32 blocks": 57 | (1 << 8) | (1 << 25)}
     res = {}
     for rep in range(2):
         for name, flags in modes.items():
@@ -346,6 +348,15 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
         assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
         for k in gc:
             assert relerr(res[a][2][k], res[b][2][k]) < 3e-4, (b, k, relerr(res[a][2][k], res[b][2][k]))    # (bf16 roundings of dG flip)
+    # round 6: the 16-row x 64-unit blocking of the four-stage launch keeps every summation order of the 32 x 32 one: same loss, priorities,
+    # LSTM and input-layer weight gradients bit for bit; the bias gradients are atomics over other partial sums (16-row instead of 32-row)
+    a, b = "fused, split + projection + sink stage, 32 x 32 blocks", "fused, split + projection + sink stage"
+    assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
+    for k in gc:
+        if k.startswith("lstm.weight"):
+            assert torch.equal(res[a][2][k], res[b][2][k]), (b, k, relerr(res[a][2][k], res[b][2][k]))
+        else:       # (atomics: bias gradients, split-K sums of the other layers -- the heads' gradients do not pass through the BPTT at all)
+            assert relerr(res[a][2][k], res[b][2][k]) < (3e-4 if "bias" in k else 1e-5), (b, k, relerr(res[a][2][k], res[b][2][k]))
     for a, b in (("fused", "fused, split placement"), ("fused, BPTT in 2 chunks", "fused, split placement, 2 chunks")):
         assert torch.equal(res[a][0], res[b][0]) and torch.equal(res[a][1], res[b][1]), b
         for k in gc:
@@ -371,7 +382,8 @@ def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
     ref_lp, ref_g = None, {}          # loss / priorities: one reference for everything; weight gradients: per chunk count / stage layout (partial
     try:                              # sums are added up in another order)
         for flags, cross, reps in ((1 | (1 << 8), 0, 150), (9 | (1 << 8), 0, 80), (9 | (2 << 8), 0, 50), (1 | (1 << 8), 1, 40), (9 | (1 << 8), 1, 40),
-                                   (25 | (1 << 8), 0, 60), (57 | (1 << 8), 0, 120), (57 | (1 << 8), 1, 40)):
+                                   (25 | (1 << 8), 0, 60), (57 | (1 << 8), 0, 120), (57 | (1 << 8), 1, 40),
+                                   (57 | (1 << 8) | (1 << 25), 0, 40)):      # (bit 25: the 32 x 32 blocking of the four-stage launch -- same bits)
             _lib.check(lib.hsad_lstm_set_exchange_mode(cross))
             L.set_fused(flags)
             chunks = ((flags >> 8) & 0xff) + 100 * ((flags >> 4) & 3)      # (the projection / sink stages sum in another order)

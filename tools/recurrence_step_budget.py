@@ -94,7 +94,8 @@ def backward_budget(jrec):
                             "stores_drained_signalled", "transposed_copy", "loop_top_to_seen", "step")}
     for tr in traces:
         s = tr[1, jrec]
-        if not s[:, 1:T - 1, 5].all():
+        s = s[s[:, T // 2, 5] > 0]          # the members that ran (the 16-row x 64-unit blocking has 8 unit blocks per group, the 32 x 32 one 16)
+        if not len(s) or not s[:, 1:T - 1, 5].all():
             continue
         for t in range(T - 3, 1, -1):       # step t consumes the tiles of step t + 1
             sig = s[:, t + 1, 5]
@@ -121,7 +122,8 @@ def stage_budget(jrec):
     rows = {"seen_to_product_published": [], "step": []}
     for tr in traces:
         s = tr[1, jrec]
-        if not s[:, 1:T - 1, 5].all():
+        s = s[s[:, T // 2, 5] > 0]
+        if not len(s) or not s[:, 1:T - 1, 5].all():
             continue
         for t in range(T - 3, 1, -1):
             rows["seen_to_product_published"] += list(s[:, t, 5] - s[:, t, 2])

@@ -25,6 +25,7 @@ struct Args {
   u64_t* stamps;          // [256][T][4]: 0 step start, 1 seen, 2 tile fetched (all waves), 3 signalled
   unsigned* stats;
   int T, G, TB, mode, work;
+  int gpx;                // groups per XCD that run (the other workgroups of the 32 per XCD leave at once)
 };
 
 __device__ __forceinline__ u64_t wall_() {
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void tile_kernel(Args a) {
   const int L = blockIdx.x, slot = L >> 3, per = a.G, NG = 256 / per;
   const int g = (L & 7) + 8 * (slot / per), nb = slot % per;
   const int piece = a.TB / a.G;       // bytes this workgroup publishes per step
+  if (slot / per >= a.gpx) return;
 #define STAMP(k) if (tid == 0) sS[t * 4 + (k)] = wall_();
   if (tid == 0) {
     __hip_atomic_fetch_add(a.group_words + g, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -112,13 +114,14 @@ __global__ __launch_bounds__(256) void tile_kernel(Args a) {
   for (int i = tid; i < a.T * 4; i += 256) a.stamps[(size_t)blockIdx.x * a.T * 4 + i] = sS[i];
 }
 
-static void run(const char* name, int T, int G, int TB, int mode, int work) {
+static void run(const char* name, int T, int G, int TB, int mode, int work, int gpx = 99) {
   Args a{};
   a.T = T;
   a.G = G;
   a.TB = TB;
   a.mode = mode;
   a.work = work;
+  a.gpx = gpx;
   const int NG = 256 / G;
   CK(hipMalloc(&a.tiles, (size_t)T * NG * TB));
   CK(hipMalloc(&a.counters, (size_t)T * NG * 4));
@@ -128,7 +131,7 @@ static void run(const char* name, int T, int G, int TB, int mode, int work) {
   CK(hipMemset(a.stats, 0, 16));
   CK(hipMemset(a.tiles, 0, (size_t)T * NG * TB));
   const int lds = 64 + 4 * 8 * 512 + (mode ? TB : 0);
-  auto kern = TB == 131072 ? tile_kernel<32> : tile_kernel<16>;
+  auto kern = TB == 131072 ? tile_kernel<32> : TB == 65536 ? tile_kernel<16> : tile_kernel<8>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -184,5 +187,15 @@ int main(int argc, char** argv) {
     run("G=8, 64 KB tile into registers", T, 8, 65536, 0, work);
     run("G=8, 64 KB tile by LDS-DMA", T, 8, 65536, 1, work);
   }
+  // fetch time vs the number of workgroups of an XCD that fetch at once (is it the XCD's L2 -> CU bandwidth or the CU's own path?)
+  run("G=16, 128 KB, 1 group / XCD (16 workgroups)", T, 16, 131072, 0, 0, 1);
+  run("G=16, 128 KB, 2 groups / XCD (32 workgroups)", T, 16, 131072, 0, 0, 2);
+  run("G=8, 128 KB, 1 group / XCD (8 workgroups)", T, 8, 131072, 0, 0, 1);
+  run("G=8, 128 KB, 2 groups / XCD (16 workgroups)", T, 8, 131072, 0, 0, 2);
+  run("G=8, 128 KB, 4 groups / XCD (32 workgroups)", T, 8, 131072, 0, 0, 4);
+  run("G=8, 64 KB, 2 groups / XCD (16 workgroups)", T, 8, 65536, 0, 0, 2);
+  run("G=8, 64 KB, 4 groups / XCD (32 workgroups)", T, 8, 65536, 0, 0, 4);
+  run("G=4, 128 KB, 4 groups / XCD (16 workgroups)", T, 4, 131072, 0, 0, 4);
+  run("G=16, 32 KB, 2 groups / XCD (32 workgroups; the forward tile)", T, 16, 32768, 0, 0, 2);
   return 0;
 }
