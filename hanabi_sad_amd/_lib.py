@@ -283,7 +283,7 @@ def build_library(verbose=False):
     """Compile every HIP source for gfx950 into hanabi_sad_amd/libhsad.so (hipcc cross-compiles
     without a GPU)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-inline-asm",
            "-I" + os.path.join(_ROOT, "include")] + SOURCES + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

@@ -1684,7 +1684,13 @@ static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* 
   m.force_cross_xcd = g_force_cross_xcd;
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
+  // K-split reduction 16 KB + staging of the published block + verdict words
   const size_t lds = (size_t)16 * 64 * 16 + (size_t)16 * (256 + 8) * sizeof(bf16_t) + 64;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_bptt_wide_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
   hipEvent_t te0 = nullptr, te1 = nullptr;
   if (g_fused_timing.on) {
     HIP_TRY(hipEventCreate(&te0));

@@ -42,8 +42,9 @@ struct ModelRuntime {
 
 constexpr int K = 8, PAYLOAD = 64;
 static unsigned long long g_slots[K][PAYLOAD];          // the staging ring (plain memory: ordering must come from the protocol)
-static unsigned long long g_done = 0;                   // the host-visible word
+static unsigned long long g_done[K] = {};              // the host-visible words, one per slot (round 6: completion order across streams is free)
 static std::atomic<long> g_violations{0}, g_executed{0};
+static bool g_out_of_order = false;
 
 static void device_thread(int hold_ms, unsigned seed) {
   std::mt19937 rng(seed);
@@ -54,9 +55,10 @@ static void device_thread(int hold_ms, unsigned seed) {
       std::unique_lock<std::mutex> g(g_dev.mu);
       g_dev.cv.wait(g, [] { return g_dev.stop || !g_dev.q[0].empty() || !g_dev.q[1].empty(); });
       if (g_dev.q[0].empty() && g_dev.q[1].empty()) return;
-      // operations of the two streams are issued with increasing numbers and the owner orders them (the replay's draws are mutually
-      // ordered by their callers): execute the lowest number first
-      const int s = g_dev.q[1].empty() || (!g_dev.q[0].empty() && g_dev.q[0].front().number < g_dev.q[1].front().number) ? 0 : 1;
+      // in-order device (modes 0-2): the lowest number first; mode 3: the two streams progress independently -- whichever the coin picks
+      // (each stream in its own order), so a later-numbered operation may finish before an earlier one of the other stream
+      int s = g_dev.q[1].empty() || (!g_dev.q[0].empty() && g_dev.q[0].front().number < g_dev.q[1].front().number) ? 0 : 1;
+      if (g_out_of_order && !g_dev.q[0].empty() && !g_dev.q[1].empty()) s = (int)(rng() & 1);
       op = g_dev.q[s].front();
       g_dev.q[s].pop_front();
       g_dev.running[s] = 1;
@@ -66,7 +68,7 @@ static void device_thread(int hold_ms, unsigned seed) {
     for (int i = 0; i < PAYLOAD; ++i) ok = ok && g_slots[op.slot][i] == op.number * 1000 + i;
     if (!ok) g_violations++;
     g_executed++;
-    __atomic_store_n(&g_done, op.number, __ATOMIC_RELEASE);             // "the slot has been read"
+    __atomic_store_n(&g_done[op.slot], op.number, __ATOMIC_RELEASE);    // "the slot has been read"
     {
       std::lock_guard<std::mutex> g(g_dev.mu);
       g_dev.running[op.stream] = 0;
@@ -77,9 +79,11 @@ static void device_thread(int hold_ms, unsigned seed) {
 int main(int argc, char** argv) {
   const int n_ops = argc > 1 ? atoi(argv[1]) : 4000;
   long total_viol = 0;
-  // three schedules: everything on the null-handle stream, everything on stream 1, alternating runs of both
-  for (int mode = 0; mode < 3; ++mode) {
-    g_done = 0;
+  // four schedules: everything on the null-handle stream, everything on stream 1, alternating runs of both, and alternating runs on a
+  // device that executes the two streams in any relative order
+  for (int mode = 0; mode < 4; ++mode) {
+    for (auto& d : g_done) d = 0;
+    g_out_of_order = mode == 3;
     g_dev.stop = false;
     for (auto& row : g_slots)
       for (auto& v : row) v = 0;
@@ -87,9 +91,9 @@ int main(int argc, char** argv) {
     std::thread dev(device_thread, 30, 17u + mode);
     std::mt19937 rng(5 + mode);
     for (int i = 0; i < n_ops; ++i) {
-      const intptr_t s = mode == 0 ? 0 : mode == 1 ? 1 : (i / 37) & 1;
+      const intptr_t s = mode == 0 ? 0 : mode == 1 ? 1 : (i / (mode == 3 ? 5 : 37)) & 1;
       unsigned long long number = 0;
-      const int k = ring.acquire(s, &g_done, &number);
+      const int k = ring.acquire(s, g_done, &number);
       for (int j = 0; j < PAYLOAD; ++j) g_slots[k][j] = number * 1000 + j;
       {
         std::lock_guard<std::mutex> g(g_dev.mu);
@@ -108,7 +112,7 @@ int main(int argc, char** argv) {
     total_viol = g_violations.load();
   }
   printf("%ld operations, %ld slot violations\n", g_executed.load(), total_viol);
-  if (g_executed.load() != 3L * n_ops) {
+  if (g_executed.load() != 4L * n_ops) {
     printf("LOST OPERATIONS\n");
     return 2;
   }
