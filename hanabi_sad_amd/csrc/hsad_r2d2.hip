@@ -1472,7 +1472,7 @@ int hsad_lstm_backward_fused(int nnet, int nlayer, int Tc, int Bn, int H, const 
   // (one XCD each).  recs[0].wide_blocks = 0 keeps the 32 x 32 kernel (A/B).
   if (recs[0].wide_blocks && nnet == 1 && nlayer == 2 && split && proj && sink && H == 512 && Bn / 16 <= 8 && device_cus() >= 256 && Tc >= 1 &&
       !recs[0].has_next && !recs[1].has_next && recs[0].saved_frag_major && recs[1].saved_frag_major && recs[0].dGT16 && recs[1].dGT16 &&
-      recs[0].dO && recs[0].xchg && recs[1].xchg && recs[0].gates && recs[1].gates && recs[0].cseq && recs[1].cseq && recs[0].WhhT_blocked &&
+      recs[0].dO && recs[0].xchg && recs[1].xchg && recs[0].xout && recs[1].sink_xout && recs[0].gates && recs[1].gates && recs[0].cseq && recs[1].cseq && recs[0].WhhT_blocked &&
       recs[1].WhhT_blocked)
     return lstm_bptt_wide_launch(Tc, Bn, recs, sync_scratch, next_sync_scratch, s);
   const int grid = split ? 8 * nunit * ((nsg * nl_int + 7) / 8) : 8 * nlayer * nunit * ((nsg + 7) / 8);
@@ -1651,6 +1651,8 @@ static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* 
     q.bsum1 = r.bias_grad1;
     q.colmap = r.bias_col_map;
     q.feeds = 1;
+    q.bpart = (float*)(k ? r.sink_xout : r.xout);      // (the second hand-off buffers of the 32 x 32 kernel's split placement: not used for tiles here)
+    q.ticket = sync + 4 * nrb32 + k;
     q.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + 2 * k) * kTraceNb : -1;
   }
   {
@@ -1673,6 +1675,8 @@ static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* 
     z.ldT = recs[1].sink_ldT;
     z.mask16 = (const bf16_t*)recs[1].sink_mask16;
     z.bsum0 = recs[1].sink_bias_grad;
+    z.bpart = (float*)recs[1].sink_xout + (size_t)8 * 4 * H;
+    z.ticket = sync + 4 * nrb32 + 2;
     z.trace_slot = g_lstm_dbg_enable == 2 ? (kTraceRec + 3) * kTraceNb : -1;
   }
   m.nstage = 4;

@@ -3,7 +3,7 @@
 # Outputs land in gpurun_out/ ; the summaries are also written into profiles/ (copy them back from gpurun_out/ afterwards).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 O=$R/gpurun_out
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
@@ -22,6 +22,9 @@ cd $R && timeout 900 python bench.py > $O/${RN}_bench.json 2> $O/bench.err
 rm -rf /tmp/ps /tmp/ps2
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps -o r1 -- python $R/bench.py --no-cpu-baseline --no-learner --no-actor > $O/${RN}_bench_under_rocprof.json 2> $O/rocprof_stats.err
 cp $(find /tmp/ps -name "*kernel_stats.csv" | head -1) $O/${RN}_bench_kernel_stats.csv
+# same lease, same command: the line's avg_launch_ms against rocprof's AverageNs (exit code 1 = more than 5 % apart)
+python $R/tools/bench_vs_rocprof.py $O/${RN}_bench.json $O/${RN}_bench_under_rocprof.json $O/${RN}_bench_kernel_stats.csv $O/${RN}_bench_vs_rocprof.json > $O/bench_vs_rocprof.txt 2>&1; echo "bench vs rocprof: rc $?"
+cp $O/${RN}_bench_vs_rocprof.json $R/profiles/ 2>/dev/null
 # ... and of the whole default command (env + learner + actor legs)
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ps2 -o r2 -- python $R/bench.py --no-cpu-baseline > $O/${RN}_bench_full_under_rocprof.json 2> $O/rocprof_stats_full.err
 cp $(find /tmp/ps2 -name "*kernel_stats.csv" | head -1) $O/${RN}_bench_full_kernel_stats.csv
