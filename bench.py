@@ -39,7 +39,7 @@ def algorithmic_bytes_per_step(P, F, A, H, sad):
 
 # committed rocprofv3 PMC summaries, newest round first (profiles/, collected with separate --pmc WRITE_SIZE / FETCH_SIZE passes and
 # corrected per MI355X_MICROARCH.md §HBM by tools/pmc_summarize.py); a leg is read from the newest file that holds it
-PMC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
+PMC_FILES = ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json")
 
 
 def pmc_leg(leg):
@@ -78,7 +78,8 @@ def gemm_traffic_bytes():
 
 def fused_traffic_bytes(which="fwd"):
     """HBM bytes per launch of the fused forward / BPTT recurrence kernel inside a learner update"""
-    return pmc_kernel("learner", "lstm_fused_%s_kernel" % which)
+    # (the PMC file must be of the round whose kernel runs: the BPTT launch is lstm_bptt_wide_kernel since round 6)
+    return pmc_kernel("learner", "lstm_bptt_wide_kernel" if which == "bwd" else "lstm_fused_%s_kernel" % which)
 
 
 def cell_traffic_bytes():
@@ -99,7 +100,7 @@ def env5_traffic_bytes(games, chunk, sad):
 def mfma_counters():
     """MFMA-busy COUNTER figures of the three MFMA kernels from the committed rocprofv3 PMC pass (profiles/rNN_mfma_util.json, written by
     tools/mfma_util.sh): {kernel: {mfma_busy, flop_frac, avg_duration_us}}; {} when never collected"""
-    for name in ("r05_mfma_util.json", "r04_mfma_util.json"):
+    for name in ("r06_mfma_util.json", "r05_mfma_util.json", "r04_mfma_util.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name)))
         except Exception:
@@ -269,9 +270,34 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
         face["share_of_composite_rate"] = {k.replace("_ms_per_update", ""): dt * 1e3 / v for k, v in face.items() if k.endswith("_ms_per_update")}
     except Exception as e:      # (the face is a convenience layer: its absence must not cost the learner's number)
         face = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the fp32-exact mode (the reference learner's own arithmetic type, pyhanabi/selfplay.py:149: fp32 operands on v_mfma_f32_32x32x2_f32,
+    # csrc/hsad_r2d2_f32.hip; parity mode, orchestrated step by step from Python -- not the product path): the same update, a few repeats
+    try:
+        l32 = R2D2Learner(W, W, 3, 0.999, lr=6.25e-5, eps=1.5e-5, grad_clip=5.0, device=dev, precision="fp32")
+        for _ in range(2):
+            l32.loss(batch, weight, 0.0)
+            l32.optimizer_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n32 = 5
+        for _ in range(n32):
+            l32.loss(batch, weight, 0.0)
+            l32.optimizer_step()
+        torch.cuda.synchronize()
+        dt32 = (time.perf_counter() - t0) / n32
+        fp32_leg = {"value": B / dt32, "unit": "sequences/s", "ms_per_update": dt32 * 1e3, "updates_timed": n32,
+                    "dtype": "fp32 operands and accumulate (v_mfma_f32_32x32x2_f32), the reference learner's arithmetic type",
+                    "update_tflops": flop / dt32 / 1e12, "peak": 157.3, "unit_peak": "TFLOP/s (dense fp32 MFMA)", "frac": flop / dt32 / 1e12 / 157.3,
+                    "note": "parity mode (golden-vector tolerance 1e-6 against the reference's r2d2.py): one GEMM + one cell launch per time step "
+                            "issued from Python, no persistent recurrence -- reported next to the bf16-operand product path, not tuned",
+                    "bf16_path_speedup": dt32 / dt}
+        del l32
+    except Exception as e:
+        fp32_leg = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
         "value": B / dt, "unit": "sequences/s", "ms_per_update": dt * 1e3, "python_schedule_ms_per_update": dt_py * 1e3,
         "reference_agent_api": face,
+        "learner_fp32": fp32_leg,
         "chunk_pipelined_schedule_ms_per_update": dt_chunked * 1e3,
         "repeats": {"blocks": len(blocks), "updates_per_block": updates, "ms_per_update_median": per[len(per) // 2], "ms_per_update_min": per[0],
                     "ms_per_update_max": per[-1]},
@@ -281,12 +307,14 @@ def learner_bench(dev, updates=20, warmup=3, gemm_probe=True):
         "update_tflops": flop / dt / 1e12,
         # the DOMINANT kernel of the update: the BPTT launch, timed where it runs
         "roofline": {"bound": "mfma",
-                     "kernel": "lstm_fused_bwd_kernel<64> (the BPTT of an update: both LSTM layers of the online net, the dO = dG1 W_ih1 projection "
-                               "stage and the input layer's dx = dG0 W_ih0 sink stage as four pipeline stages x %d steps in one persistent launch)" % T,
+                     "kernel": "lstm_bptt_wide_kernel<64> (the BPTT of an update: both LSTM layers of the online net, the dO = dG1 W_ih1 projection "
+                               "stage and the input layer's dx = dG0 W_ih0 sink stage as four pipeline stages x %d steps in one persistent launch; "
+                               "round 6: 16 rows x 64 units per workgroup, weight slices in registers -- lstm_fused_bwd_kernel<64> is the 32 x 32 "
+                               "blocking of rounds 3-5)" % T,
                      "achieved": bptt_tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": bptt_tf / 2500.0,
                      "traffic": fused_traffic_bytes("bwd"), "avg_launch_ms": b_ms.value, "in_update_launches_timed": b_n.value,
                      "algorithmic_flop_per_launch": b_fl.value, "share_of_update": b_ms.value / (dt * 1e3) if dt > 0 else None,
-                     "mfma_busy_counter": counters.get("lstm_fused_bwd_kernel"),
+                     "mfma_busy_counter": counters.get("lstm_bptt_wide_kernel"),
                      "note": "a recurrence over B = 128 rows is latency-bound by construction (each of the 80 steps needs the previous one: its "
                              "step time is the cross-workgroup exchange, not MFMA issue); the fraction is reported as what it is"},
         "roofline_forward": {"bound": "mfma",
@@ -342,7 +370,7 @@ def gemm_core_bench(dev, n=8192, reps=12):
 
 def mfma_calib():
     """the calibration GEMM's counter figures from the committed PMC pass (profiles/rNN_mfma_util.json, leg `calib`)"""
-    for name in ("r05_mfma_util.json", "r04_mfma_util.json"):
+    for name in ("r06_mfma_util.json", "r05_mfma_util.json", "r04_mfma_util.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name))).get("calib", {})
         except Exception:
@@ -520,7 +548,8 @@ def exchange_bench(dev, rank, world, rounds=60, batch=128, mode="star"):
             link.finish()
         torch.cuda.synchronize()
         wall = (wall_end - t0) / rounds * 1e3
-        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "transport": link.transport, "rounds_open_at_once": ahead,
+        out = {"world": world, "rounds": rounds, "batch": batch, "round_shape": link.mode, "transport": link.transport, "transport_decision": link.transport_decision,
+               "rounds_open_at_once": ahead,
                "wire_bytes_per_sequence": shard.wire_bytes(),
                "batch_bytes_per_rank_message": shard.wire_bytes() * batch, "param_bucket_bytes": n_param * 4,
                "round_wall_ms": wall, "per_round_ms": link.timings(),
@@ -916,7 +945,7 @@ def main():
         # what in this line is NOT measured by this run: the HBM-traffic and MFMA-busy counter figures are read from the committed rocprofv3
         # PMC passes (a PMC pass cannot run inside the driver's command); every time, rate and fraction is measured here
         out["profile_sources"] = {"every `traffic` field": "profiles/" + (pmc_leg("env")[1] or "-") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh)",
-                                  "every `mfma_busy_counter` field": "profiles/r05_mfma_util.json or r04 (rocprofv3 --pmc SQ_* pass, tools/mfma_util.sh)",
+                                  "every `mfma_busy_counter` field": "profiles/r06_mfma_util.json or older (rocprofv3 --pmc SQ_* pass, tools/mfma_util.sh; the `source` key of each says which)",
                                   "everything else": "measured in this run"}
         print(json.dumps(out))
     if dist is not None:

@@ -561,18 +561,57 @@ class ReplayLink:
             one_node = int(os.environ.get("LOCAL_WORLD_SIZE", self.world)) == self.world
             want = "ipc" if (dist.get_backend() == "nccl" and one_node) else "backend"
         self.transport, self.ipc = "backend", None
+        self.transport_decision = {"asked": (transport if transport is not None else os.environ.get("HSAD_LINK_TRANSPORT", "")) or "auto", "wanted": want}
+        if want == "ipc" and star and self.world > 1 and cuda:
+            # peer access first (hipDeviceCanAccessPeer between the learner's device and every actor's, both directions, voted through the
+            # store so that every rank decides the same way): a pair without it cannot map the other's landing ring -- the backend then
+            why = self._peer_access_vote(d)
+            if why:
+                want = "backend"
+                self.transport_decision["peer_access"] = why
+                if self.rank == self.learner:
+                    print("ReplayLink: no peer access between the learner's and an actor's device (%s) -- using the %s backend" % (why, dist.get_backend()), flush=True)
+            else:
+                self.transport_decision["peer_access"] = "ok"
         if want == "ipc" and star and self.world > 1 and cuda:
             hdr_bytes = self.hdr.numel() * 4
             ipc = _IpcTransport(self.store, self._keys, self.rank, self.world, self.learner, d, max(hdr_bytes, 4 * int(param_numel)),
                                 max(B * wb, 64), 2 * (self.ahead + 2))
             if ipc.ok:
                 self.ipc, self.transport, self.staged = ipc, "ipc", False
-            elif self.rank == self.learner:
-                print("ReplayLink: the ipc transport is not available (%s) -- using the %s backend" % (ipc.why, dist.get_backend()), flush=True)
+            else:
+                self.transport_decision["ipc_open"] = ipc.why
+                if self.rank == self.learner:
+                    print("ReplayLink: the ipc transport is not available (%s) -- using the %s backend" % (ipc.why, dist.get_backend()), flush=True)
+        self.transport_decision["chosen"] = self.transport
+        self.transport_decision["backend"] = dist.get_backend() if self.world > 1 else None
         self._rounds = []           # learner: rounds begun and not yet finished, oldest first
         self._done_ev = {}          # round -> event on the up stream: its replies are in and unpacked
         self._bucket_ev = None      # the last parameter send has left the bucket
         self.wait_ms, self.wait_n = 0.0, 0
+
+    def _peer_access_vote(self, d):
+        """-> "" when every (learner, actor) pair of devices can access each other (or sits on one device), else the reason; every rank
+        publishes its device index and its own checks in the store and all read all votes: one decision for the job"""
+        idx = torch.device(d).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        st, k = self.store, self._keys + "peer/"
+        st.set(k + "dev/%d" % self.rank, str(idx))
+        others = [p for p in range(self.world) if p != self.learner] if self.is_learner else [self.learner]
+        bad = []
+        for p in others:
+            q = int(st.get(k + "dev/%d" % p).decode())
+            if q == idx:
+                continue                      # ranks sharing one device (tests): the same address space
+            try:
+                ok = q < torch.cuda.device_count() and torch.cuda.can_device_access_peer(idx, q)
+            except Exception as e:            # (a process that sees only its own device cannot ask: the ipc open vote decides)
+                ok = True
+            if not ok:
+                bad.append("rank %d device %d -> rank %d device %d" % (self.rank, idx, p, q))
+        st.set(k + "vote/%d" % self.rank, "; ".join(bad))
+        votes = [st.get(k + "vote/%d" % p).decode() for p in range(self.world)]
+        return "; ".join(v for v in votes if v)
 
     # -- transport (RCCL on the GPU; host staging only for gloo with GPU shards) --
     def _bcast(self, t):

@@ -8,6 +8,7 @@ machinery has no counterpart by design: all games advance in lock-step on the GP
 written against the reference -- create_envs / create_threads / ActGroup / context.start() / replay.sample() -- works
 unchanged; `Context.step()` is there for drivers that prefer to interleave rollout and learning themselves."""
 import os
+import sys
 import threading
 import time as _time
 
@@ -26,6 +27,7 @@ _MODEL_LOCK = threading.RLock()
 # enqueued ON this stream between two rollout steps; pause() / resume() / terminate() join the two streams.
 _ACTOR_STREAMS = {}
 _LIVE_CONTEXTS = {}       # device -> number of Context threads currently issuing on its rollout stream
+_PACE_NOTICE_SHOWN = False   # Context.start() says once per process that the default pace is on
 
 
 def _dev_key(device):
@@ -584,6 +586,15 @@ class Context:
     def start(self):
         import threading
         self._coalesce()
+        global _PACE_NOTICE_SHOWN
+        if (self._thread is None and not _PACE_NOTICE_SHOWN and self._pace is None and self.auto_pace_steps > 0 and not os.environ.get("HSAD_QUIET")
+                and any(not getattr(lp, "eval_mode", True) for lp in self.loops)):
+            # the one behavioural delta an unchanged reference driver gets without asking (rela/context.h:43-50 free-runs): say so, once
+            _PACE_NOTICE_SHOWN = True
+            print("hanabi_sad_amd.rela.Context: rollout paced by replay.sample() -- %g rollout steps per sample once the training loop samples, "
+                  "free-running before that and whenever nobody has sampled for %.1f s.  The reference's Context free-runs unconditionally: "
+                  "context.set_pace(False) or HSAD_AUTO_PACE=0 for that (HSAD_QUIET=1 silences this line)."
+                  % (self.auto_pace_steps, self.auto_pace_idle_s), file=sys.stderr, flush=True)
         if self._thread is None:
             for dev in self._devices():
                 if torch.device(dev).type == "cuda":

@@ -433,6 +433,7 @@ def test_fused_recurrences_next_to_foreign_work_on_another_stream():
     L.check_sync()
 
 
+@pytest.mark.slow          # (ten seconds by construction; the soak and the foreign-work tests above stay in the default set)
 @pytest.mark.timeout(180)
 def test_fused_recurrences_stress_ten_seconds_of_randomly_timed_foreign_kernels():
     """the spin protocols of the persistent fused launches (all-or-nothing co-residency, bounded spins, sticky timeout)

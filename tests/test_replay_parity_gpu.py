@@ -49,7 +49,9 @@ def random_stream(rng, E, d, T, steps, p_term=0.12, binary=False):
         yield obs, a, r, t
 
 
-FLOW_CASES = [(37, 11, 3, 20, 0.999), (5, 3, 1, 6, 0.9), (130, 40, 5, 80, 0.99), (4500, 2, 2, 6, 0.99)]
+# (the larger twin of a case is marked slow: same code paths, 2-4 x the rows -- the CPU reference harness dominates their time)
+FLOW_CASES = [(37, 11, 3, 20, 0.999), (5, 3, 1, 6, 0.9), (64, 40, 5, 80, 0.99), (1200, 2, 2, 6, 0.99),
+              pytest.param(130, 40, 5, 80, 0.99, marks=pytest.mark.slow), pytest.param(4500, 2, 2, 6, 0.99, marks=pytest.mark.slow)]
 
 
 def drive_actor_flow(E, d, n, T, gamma, with_device, bits=0):
@@ -136,8 +138,10 @@ def test_sequence_writer_and_replay_flow_matches_reference(E, d, n, T, gamma):
     drive_actor_flow(E, d, n, T, gamma, with_device=True)
 
 
-@pytest.mark.parametrize("E,d,n,T,gamma,seg", [(37, 11, 3, 20, 0.999, 1), (5, 130, 1, 6, 0.9, 2), (130, 838, 5, 80, 0.99, 1),
-                                               (33, 3 * 658, 3, 12, 0.99, 3)])
+@pytest.mark.parametrize("E,d,n,T,gamma,seg", [(37, 11, 3, 20, 0.999, 1), (5, 130, 1, 6, 0.9, 2), (40, 838, 5, 80, 0.99, 1),
+                                               (11, 3 * 658, 3, 12, 0.99, 3),
+                                               pytest.param(130, 838, 5, 80, 0.99, 1, marks=pytest.mark.slow),
+                                               pytest.param(33, 3 * 658, 3, 12, 0.99, 3, marks=pytest.mark.slow)])
 def test_bit_packed_observation_rows_match_reference(E, d, n, T, gamma, seg):
     """HSAD_BITS fields: the same flow with 0/1 observations stored one bit per value (widths that are not multiples of 64,
     segmented rows as VDN uses them) -- every tensor that comes back out is still bit-equal to the reference's"""

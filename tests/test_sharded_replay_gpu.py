@@ -86,7 +86,7 @@ def test_two_shards_on_one_gpu_draw_the_same_elements_as_one_buffer():
     assert int((got != want).sum()) <= 1, (got, want)
 
 
-@pytest.mark.parametrize("extra", [[], ["--method", "vdn"], ["--pred_weight", "0.25"]], ids=["iql", "vdn", "aux"])
+@pytest.mark.parametrize("extra", [[], pytest.param(["--method", "vdn"], marks=pytest.mark.slow), ["--pred_weight", "0.25"]], ids=["iql", "vdn", "aux"])
 def test_three_rank_selfplay_learner_and_free_running_actors(tmp_path, extra):
     """End to end on this box's single GPU: three ranks (gloo transport, tensors staged through host memory) -- rank 0 only learns,
     ranks 1 and 2 roll out their game shards into their own DeviceReplay shards and serve the learner's rounds between their steps

@@ -4,7 +4,7 @@
 # a second pass with --kernel-trace --stats for the un-instrumented durations of the same command, then tools/mfma_util_summarize.py.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RN=${ROUND:-r05}
+RN=${ROUND:-r06}
 O=$R/gpurun_out/mfma
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -21,6 +21,7 @@ FLOPS = {   # FLOP per launch (DESIGN section 3d / VERDICT r3's arithmetic)
     # fused forward: 2 nets x 2 layers x 80 steps x (128 rows x 2048 gates x (512 + 512) k) x 2
     "learner": [("lstm_fused_fwd_kernel", 2 * 2 * 80 * 128 * 2048 * 1024 * 2.0),
                 # BPTT: per step dh = dG W_hh^T (both layers), dO = dG1 W_ih1 (projection stage), dx = dG0 W_ih0 (sink): 4 stages x 128 x 2048 x 512 x 2
+                ("lstm_bptt_wide_kernel", 4 * 80 * 128 * 2048 * 512 * 2.0),      # round 6 blocking (16 rows x 64 units)
                 ("lstm_fused_bwd_kernel", 4 * 80 * 128 * 2048 * 512 * 2.0)],
     # one launch = online + target net's cell of one layer: 2 x 32768 rows x 2048 x 1024 x 2
     "actor": [("gemm8_kernel<2", 2 * 32768 * 2048 * 1024 * 2.0)],      # gemm8_kernel<G8_CELL>

@@ -81,7 +81,8 @@ KERNELS = {   # leg -> [(label, name regex, algorithmic bytes per launch or None
     "gemm": [("gemm8_kernel<G8_F32> (the 256 x 256 core) LSTM input projection 10240x2048x512, fp32 output", r"gemm8_kernel<1", GEMM_ALGO, ""),
              ("gemm_nt_bf16_kernel<128,128> LSTM input projection 10240x2048x512, fp32 output", r"gemm_nt_bf16_kernel<128, 128>", GEMM_ALGO, "")],
     "learner": [("learner update: lstm_fused_fwd_kernel<16> (2 nets x 2 layers x 80 steps per launch)", r"lstm_fused_fwd_kernel<16>", FUSED_FWD_ALGO, ""),
-                ("learner update: lstm_fused_bwd_kernel<64> (2 layers x 80 steps per launch)", r"lstm_fused_bwd_kernel<64>", FUSED_BWD_ALGO, ""),
+                ("learner update: lstm_bptt_wide_kernel<64> (round 6: 2 layers + projection + sink stage x 80 steps per launch, 16 rows x 64 units per workgroup)", r"lstm_bptt_wide_kernel<64>", FUSED_BWD_ALGO, ""),
+                ("learner update: lstm_fused_bwd_kernel<64> (the 32 x 32 blocking of rounds 3-5; 2 layers x 80 steps per launch)", r"lstm_fused_bwd_kernel<64>", FUSED_BWD_ALGO, ""),
                 ("learner update: loss_tail_kernel", r"loss_tail_kernel", None, ""),
                 ("learner update: gemm_nt_bf16_kernel<128,128> (all shapes of an update)", r"gemm_nt_bf16_kernel<128, 128>", None, ""),
                 ("learner update: gemm_nt_bf16_kernel<128,64>", r"gemm_nt_bf16_kernel<128, 64>", None, ""),

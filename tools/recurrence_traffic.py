@@ -9,7 +9,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
-KERNELS = {"forward": r"lstm_fused_fwd_kernel", "bptt": r"lstm_fused_bwd_kernel"}
+KERNELS = {"forward": r"lstm_fused_fwd_kernel", "bptt": r"lstm_bptt_wide_kernel|lstm_fused_bwd_kernel"}
 T, H = 80, 512
 # algorithmic bytes per launch as tools/pmc_summarize.py counts them, split the same way (per launch / per batch row)
 ALGO = {"forward": {"const": 8 * 2048 * H * 2, "per_row": T * H * (2 * 2 + 4 * 2 + 2 * (4 * 4 + 4)),

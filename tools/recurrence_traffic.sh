@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run ON THE GPU BOX (gpurun): memory-side traffic of the learner's two fused recurrence launches at B = 32 / 64 / 96 / 128 batch rows, one counter
 # set per pass (where the bytes above the algorithmic count come from).  tools/recurrence_traffic.py turns the csv files
-# into profiles/r05_recurrence_traffic.json: per launch a constant part (weights, per row block) and a part per batch row, read and write
+# into profiles/r06_recurrence_traffic.json: per launch a constant part (weights, per row block) and a part per batch row, read and write
 # side apart, request sizes where the counters exist.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,5 +20,5 @@ for B in ${ROWS:-128 96 64 32}; do
     i=$((i+1))
   done
 done
-python $R/tools/recurrence_traffic.py $O $R/gpurun_out/r05_recurrence_traffic.json > $O/summary.txt 2>&1
+python $R/tools/recurrence_traffic.py $O $R/gpurun_out/r06_recurrence_traffic.json > $O/summary.txt 2>&1
 cat $O/summary.txt
