@@ -706,6 +706,32 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one GPU per rank with the RCCL backend: fewer devices than ranks is said in ONE JSON line (rank 0 / the spawning parent) with rc 2 --
+    # not as a rank dying in hipSetDevice and the launcher's traceback
+    if args.gpus > 1 and args.dist_backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        if rank == 0:
+            print(json.dumps({"metric": "hanabi_env_steps_per_sec", "value": None, "unit": "env-steps/s", "n_gpus": args.gpus,
+                              "error": "--gpus %d with the nccl (= RCCL) backend needs %d devices, this node shows %d; "
+                                       "--dist-backend gloo smoke-tests the multi-rank path with ranks sharing a GPU"
+                                       % (args.gpus, args.gpus, torch.cuda.device_count())}), flush=True)
+        raise SystemExit(2)
+    stage = ["start"]           # where the run is: what a watchdog line names
+    if world > 1:
+        # per-rank watchdog: a rank that is wedged (a peer that never arrives at a barrier, a collective that never completes) ends with a
+        # JSON line carrying `error` on rank 0 -- and every rank with an exit code -- instead of sitting in the driver's timeout
+        import threading
+        limit = int(os.environ.get("HSAD_BENCH_TIMEOUT", "900"))
+
+        def wedged():
+            if rank == 0:
+                print(json.dumps({"metric": "hanabi_env_steps_per_sec", "value": None, "unit": "env-steps/s", "n_gpus": world,
+                                  "error": "rank 0 gave up after %d s in stage '%s' (HSAD_BENCH_TIMEOUT)" % (limit, stage[0])}), flush=True)
+            else:
+                print("bench.py: rank %d gave up after %d s in stage '%s'" % (rank, limit, stage[0]), file=sys.stderr, flush=True)
+            os._exit(3)
+        run_watchdog = threading.Timer(limit, wedged)
+        run_watchdog.daemon = True
+        run_watchdog.start()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: spawn the ranks ourselves (one process per GPU, torch.distributed.run on 127.0.0.1) and
         # pass their output through -- rank 0 prints the JSON line
@@ -724,6 +750,7 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = "cuda:%d" % local_dev
     dist = None
+    stage[0] = "init_process_group"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -754,8 +781,13 @@ def main():
         torch.cuda.synchronize()
 
     state_before = device_state(local_dev) if rank == 0 else None
+    stage[0] = "warm-up + barrier"
+    if os.environ.get("HSAD_BENCH_WEDGE_RANK") == str(rank) and world > 1:      # (fault injection for the watchdog's test: this rank never arrives)
+        time.sleep(10 ** 6)
     env.rollout_random(args.warmup, policy_seed)
     barrier()
+    stage[0] = "timed region"
+
     # the timed region launches the fused kernel (env_kernel<3,P,H>: reset-terminated + random-legal policy + step +
     # observe) once per iteration and partition; HIP events on the launch stream(s) give its average duration over exactly
     # this region
@@ -900,6 +932,7 @@ def main():
             out["ranks"] = info
             out["backend"] = args.dist_backend + (" (= RCCL)" if args.dist_backend == "nccl" else "")
             out["rccl_ranks"] = _d.get_world_size() if args.dist_backend == "nccl" else None
+    stage[0] = "exchange leg"
     if world > 1 and not os.environ.get("HSAD_BENCH_NO_EXCHANGE"):
         # the exchange leg is collective: a rank that never arrives would leave the others inside a collective for good and the
         # headline number, already measured, unprinted.  A watchdog prints the line without the leg and ends the process instead.
@@ -948,6 +981,7 @@ def main():
                                   "every `mfma_busy_counter` field": "profiles/r06_mfma_util.json or older (rocprofv3 --pmc SQ_* pass, tools/mfma_util.sh; the `source` key of each says which)",
                                   "everything else": "measured in this run"}
         print(json.dumps(out))
+    stage[0] = "final barrier"
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

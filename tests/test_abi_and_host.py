@@ -207,3 +207,28 @@ def test_rela_module_surface_and_single_process_multi_device_acting_is_refused()
         vec.append(hanalearn.HanabiEnv({"players": "2", "seed": "1"}, [0.0], 80, True, False, False, False))
         ev.push_env_thread(hanalearn.HanabiThreadLoop([rela.R2D2Actor(Runner(d), 1)] * 2, vec, True))
     assert ev._devices() == ["cuda:0", "cuda:1"]
+
+
+def test_compiled_rela_and_hanalearn_modules_build_and_carry_the_reference_names(tmp_path):
+    """bindings/*.cc -> build/rela*.so, build/hanalearn*.so (pybind11 over the C ABI; __graft_entry__.build_bindings): they must import
+    without a GPU -- nothing touches the device at import -- and expose every name the reference's bindings register
+    (rela/pybind.cc:16-93, cpp/pybind.cc:14-56).  The GPU side runs the reference-shaped drivers through them (test_compiled_boundary_gpu.py)."""
+    import subprocess
+    import sys
+    import __graft_entry__ as ge
+    ge.build_bindings()
+    build = os.path.join(ROOT, "build")
+    code = ("import sys; sys.path.insert(0, %r); import rela, hanalearn\n"
+            "assert rela.__file__.endswith('.so') and hanalearn.__file__.endswith('.so')\n"
+            "for n in ('RNNTransition', 'RNNPrioritizedReplay', 'ThreadLoop', 'Context', 'R2D2Actor', 'BatchRunner', 'aggregate_priority'):\n"
+            "    assert hasattr(rela, n), n\n"
+            "for n in ('HanabiEnv', 'HanabiVecEnv', 'HanabiThreadLoop'):\n"
+            "    assert hasattr(hanalearn, n), n\n"
+            "assert issubclass(hanalearn.HanabiThreadLoop, rela.ThreadLoop)\n"
+            "for m in ('push_env_thread', 'start', 'pause', 'resume', 'terminate', 'terminated'):\n"
+            "    assert hasattr(rela.Context, m), m\n"
+            "r = rela.RNNPrioritizedReplay(64, 1, 0.9, 0.6, 3); assert r.size() == 0 and r.num_add() == 0\n"
+            "g = hanalearn.HanabiEnv({'players': '2', 'seed': '3'}, [0.1], 80, True, False, False, False); v = hanalearn.HanabiVecEnv(); v.append(g); assert v.size() == 1\n"
+            "print('ok')") % build
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-1000:] + out.stderr[-3000:]

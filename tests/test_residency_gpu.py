@@ -70,7 +70,9 @@ def test_a_resident_foreign_kernel_stretches_the_update_it_runs_next_to():
         time.sleep(0.0003)          # they are on their CUs before the update is issued
     held = _median_update(upd, residents)
     lr.check_sync()                 # (slower, never wrong: the sibling waits are long enough to sit it out)
-    assert held > 1.3 * base, "4 workgroups resident for 2.5 ms: %.3f ms per update against %.3f undisturbed" % (held * 1e3, base * 1e3)
+    # (rounds 3-5: 1.5-2 x.  Round 6: the BPTT launch's workgroups -- 16 rows x 64 units, weights in registers, 25 KB of LDS -- leave room for
+    # a foreign workgroup on their CU; what still waits for the residents is the forward launch with its 153 KB of LDS per workgroup: 1.2 x)
+    assert held > 1.1 * base, "4 workgroups resident for 2.5 ms: %.3f ms per update against %.3f undisturbed" % (held * 1e3, base * 1e3)
 
 
 def test_the_ipc_transports_copies_leave_the_update_at_its_speed():
