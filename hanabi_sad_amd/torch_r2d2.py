@@ -83,12 +83,18 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, anchor, agent, batch, pred_weight):
         loss, prio = agent._learner_for(batch).loss(batch, agent._ones(loss_like=batch), pred_weight, compute_grad="later")
         ctx.agent = agent
+        # the learner keeps ONE forward state (activations of the last loss()): a backward that belongs to an older forward must not run on it
+        agent._forward_count = getattr(agent, "_forward_count", 0) + 1
+        ctx.forward_count = agent._forward_count
         ctx.mark_non_differentiable(prio)
         return loss, prio
 
     @staticmethod
     def backward(ctx, g_loss, g_prio):
         agent = ctx.agent
+        if ctx.forward_count != getattr(agent, "_forward_count", 0):
+            raise _lib.HsadError("R2D2Agent.loss() was called again before this loss was backpropagated: the learner holds the activations of ONE "
+                                 "forward pass (the reference's train loop calls loss -> backward -> step in turn, pyhanabi/selfplay.py:218-241)")
         ln = agent._learner
         ln.backward_weighted(g_loss * float(g_loss.shape[0]))
         for name, p in agent._named_online():

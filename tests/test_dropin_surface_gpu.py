@@ -373,6 +373,9 @@ def test_the_reference_agent_api_trains_on_the_kernels(tag, pw):
     l2, _ = agent.loss(batch, pw, None)
     l3, _ = agent.loss(batch, pw, None)
     assert not torch.equal(l2.detach(), torch.tensor(z["loss.%s.loss" % tag]).to(DEV)) and torch.equal(l2.detach(), l3.detach())
+    with pytest.raises(Exception, match="called again before this loss was backpropagated"):
+        l2.mean().backward()             # the learner holds the activations of l3's forward pass: a stale backward is refused, not silently wrong
+    l3.mean().backward()
     agent.sync_target_with_online()
     for (k, p), (_, q) in zip(agent.online_net.named_parameters(), agent.target_net.named_parameters()):
         assert torch.equal(p.detach(), q.detach()), k
