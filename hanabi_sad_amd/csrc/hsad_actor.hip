@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "hsad.h"
+#include "hsad_run_ahead.h"
 
 extern "C" int hsad_internal_set_error(int code, const char* msg);
 
@@ -61,6 +62,20 @@ __global__ void sum_players2_kernel(const float* __restrict__ a, const float* __
 
 }  // namespace
 
+// HIP behind hsad_run_ahead.h
+struct HipRunAheadRuntime {
+  using stream_t = hipStream_t;
+  using event_t = hipEvent_t;
+  static constexpr int not_ready = (int)hipErrorNotReady;
+  static event_t create() {
+    hipEvent_t e = nullptr;
+    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
+  }
+  static int record(event_t e, stream_t s) { return (int)hipEventRecord(e, s); }
+  static int query(event_t e) { return (int)hipEventQuery(e); }
+  static void yield() { std::this_thread::yield(); }
+};
+
 struct hsad_actor {
   hsad_env* env;
   hsad_r2d2_net *online, *target;
@@ -90,10 +105,8 @@ struct hsad_actor {
   bool reset_pending = false;
   hipStream_t side_reset = nullptr, side_flush = nullptr;
   hipEvent_t ev_main = nullptr, ev_reset = nullptr, ev_flush = nullptr;
-  // hsad_actor_set_run_ahead: the host may be at most `run_ahead` steps ahead of the device (0 = unbounded)
-  int run_ahead = 0;
   bool fuse_tail = getenv("HSAD_ACTOR_FUSE_TAIL") ? atoi(getenv("HSAD_ACTOR_FUSE_TAIL")) != 0 : true;      // developer switch (A/B)
-  hipEvent_t ev_step[8] = {};
+  RunAheadT<HipRunAheadRuntime, 8> ahead;      // hsad_run_ahead.h (the bound's ring of events; also compiled under the TSAN model)
 };
 
 extern "C" {
@@ -196,7 +209,7 @@ void hsad_actor_destroy(hsad_actor* ac) {
   if (ac->side_flush) (void)hipStreamDestroy(ac->side_flush);
   for (hipEvent_t e : {ac->ev_main, ac->ev_reset, ac->ev_flush})
     if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : ac->ev_step)
+  for (hipEvent_t e : ac->ahead.ev)
     if (e) (void)hipEventDestroy(e);
   delete ac;
 }
@@ -227,25 +240,16 @@ const float* hsad_actor_last_priority(const hsad_actor* ac, int32_t* n) {
 // streams; the host never waits for the device.
 int hsad_actor_set_run_ahead(hsad_actor* ac, int steps) {
   if (!ac || steps < 0 || steps > 7) return xfail(HSAD_ERR_INVALID, "actor_set_run_ahead: 0 (unbounded) .. 7 steps");
-  for (int i = 0; i < 8 && steps > 0; ++i)
-    if (!ac->ev_step[i]) HIP_TRY(hipEventCreateWithFlags(&ac->ev_step[i], hipEventDisableTiming));
-  ac->run_ahead = steps;
+  if (ac->ahead.set_bound(steps)) return xfail(HSAD_ERR_HIP, "actor_set_run_ahead: hipEventCreate failed");
   return HSAD_OK;
 }
 
 int hsad_actor_step(hsad_actor* ac, void* stream) {
   if (!ac) return xfail(HSAD_ERR_INVALID, "actor_step: null actor");
   hipStream_t s = (hipStream_t)stream;
-  // An actor's host issues a step in ~0.1 ms, the device runs it in ~0.9 ms: left alone the stream fills up with hundreds of
-  // steps, and anything stream-ordered behind them -- serving a learner's round (dist.ReplayLink), new parameters -- waits that
-  // long.  With a bound the host idles (polling: hipEventSynchronize has been seen to return only with the stream's NEWEST work)
-  // until step t - run_ahead has left the device; the device never runs dry while run_ahead >= 2.
-  if (ac->run_ahead > 0 && ac->step_no >= ac->run_ahead) {
-    hipEvent_t old = ac->ev_step[(ac->step_no - ac->run_ahead) & 7];
-    hipError_t q;
-    while ((q = hipEventQuery(old)) == hipErrorNotReady) std::this_thread::yield();
-    HIP_TRY(q);
-  }
+  // the host at most `bound` steps ahead of the device (hsad_run_ahead.h; polling: hipEventSynchronize has been seen to return only with
+  // the stream's NEWEST work)
+  if (const int q = ac->ahead.admit()) return xfail(HSAD_ERR_HIP, "actor_step: hipEventQuery failed: %s", hipGetErrorString((hipError_t)q));
   const int N = ac->N, P = ac->P, L = ac->L, Hd = ac->Hd, n = ac->multi_step;
   const int cur = ac->cur, nxt = (cur + 1) % ac->nslot;
   // `if (terminated) reset` (thread_loop.h:46-52): issued behind the previous env step on a side stream and joined at the end of
@@ -284,7 +288,7 @@ int hsad_actor_step(hsad_actor* ac, void* stream) {
     HIP_TRY(hipStreamWaitEvent(ac->side_flush, ac->ev_flush, 0));
     CK(hsad_seqwriter_flush_to_replay(ac->writer, ac->replay, ac->eta, ac->n_finished, (void*)ac->side_flush));
     HIP_TRY(hipStreamWaitEvent(s, ac->ev_reset, 0));
-    if (ac->run_ahead > 0) HIP_TRY(hipEventRecord(ac->ev_step[(ac->step_no - 1) & 7], s));
+    if (ac->ahead.mark(s)) return xfail(HSAD_ERR_HIP, "actor_step: hipEventRecord failed");
     return 0;
   }
   CK(hsad_seqwriter_push_reward_terminal_rep(ac->writer, ac->io.reward, ac->io.terminal, ac->vdn ? 1 : P, stream));
@@ -333,7 +337,7 @@ int hsad_actor_step(hsad_actor* ac, void* stream) {
     CK(hsad_seqwriter_flush_to_replay(ac->writer, ac->replay, ac->eta, ac->n_finished, (void*)ac->side_flush));
   }
   HIP_TRY(hipStreamWaitEvent(s, ac->ev_reset, 0));      // nothing outside a step ever runs next to the reset
-  if (ac->run_ahead > 0) HIP_TRY(hipEventRecord(ac->ev_step[(ac->step_no - 1) & 7], s));
+  if (ac->ahead.mark(s)) return xfail(HSAD_ERR_HIP, "actor_step: hipEventRecord failed");
   return 0;
 }
 
