@@ -758,7 +758,7 @@ struct hsad_r2d2_learner {
   // backward
   bf16_t *dheads, *dG[kMaxL], *dx1, *dx2, *hsT[kMaxL], *hpT[kMaxL], *x1T, *x2T, *a16T, *dGT, *dx1T, *dx2T, *dheadsT, *xchg_b[kMaxL], *xout_b = nullptr, *xout_b2 = nullptr;
   int Mp;                 // contraction length of the weight-gradient GEMMs: M padded to the GEMM's K tile (64)
-  float *dO[kMaxL], *dc[kMaxL], *wgrad_ws, *wgrad_ws2;
+  float *dO[kMaxL], *dc[kMaxL], *wgrad_ws, *wgrad_ws2, *heads_ws;
   bf16_t* dGT2;           // second transposed-gradient operand: layer 0's weight gradients on the main stream next to layer 1's on the side stream
   // ping-pong counter blocks of the persistent launches: [kind fwd/bwd][nrec - 1][flip]
   unsigned* sync[2][4][2];
@@ -899,6 +899,7 @@ int hsad_r2d2_learner_create(hsad_r2d2_net* online, hsad_r2d2_net* target, int T
   want(&L->dheadsT, NHp * Mp * 2);
   want(&L->wgrad_ws, (size_t)L->wgrad_split * H4 * std::max(H, (size_t)online->F) * 4);
   want(&L->wgrad_ws2, pipe0 ? (size_t)L->wgrad_split * H4 * H * 4 : 256);
+  want(&L->heads_ws, (size_t)4 * 8 * 64 * H * 4);      // slabs of the heads' weight gradient (<= 32 K ranges x <= 64 rows x H): summed in order, no float atomics
   want(&L->dGT2, pipe0 ? H4 * Mp * 2 : 256);
   {
     // the grouped weight-gradient launch: one work item per CU -- 3/4 of them for the four LSTM problems, 1/4 for the input layer's
@@ -1400,8 +1401,15 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
   // (NH = A + 1 + 3 hand rows: one row tile -- four column tiles x split; a deeper split than the big weight gradients' fills more CUs:
   // 30 -> 18 us, and with it the whole side-stream chain behind the BPTT launch starts earlier: 1.385 -> 1.362 ms per update)
   const int heads_split = (Mp % (64 * 4 * L->wgrad_split) == 0) ? 4 * L->wgrad_split : L->wgrad_split;
-  CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, heads_split, nullptr, 0, nullptr, wst));
-  CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
+  // (round 6: slabs + one ordered sum and a one-block column sum instead of float atomics -- with the BPTT launch's ticketed bias sums every
+  // gradient of an update is now the same bits run to run; the chain runs on the side stream next to the BPTT launch either way)
+  if (NH <= 64 && heads_split <= 32 && (H & 3) == 0) {
+    CK(hsad_gemm_nt_bf16_splitk_acc(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, heads_split, L->heads_ws, g[on->iWA], H, nullptr, wst));
+    CK(hsad_colsum_acc_ordered(L->dheads, 1, M, NH, NHp, g[on->iBA], wst));
+  } else {
+    CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, heads_split, nullptr, 0, nullptr, wst));
+    CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
+  }
   int nbc = L->bchunks;
   while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
   std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;
