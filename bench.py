@@ -482,11 +482,24 @@ def training_bench(dev, games=6400, iterations=150, warmup=20):
     tr.join_rollout()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iterations
+    # what the host needs to ISSUE an iteration when nothing holds it back (empty queue: device drained in front of every iteration) -- the
+    # figure above includes the back-pressure of a full queue (staging-slot ring, run-ahead bound), i.e. it reads ~ the device's iteration time
+    # whenever the device is the limiter
+    t_free = 0.0
+    for _ in range(30):
+        tr.join_rollout()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        iteration()
+        t_free += time.perf_counter() - t1
+    tr.join_rollout()
+    torch.cuda.synchronize()
     tr.learner.check_sync()
     tr.env.check_errors()
     tr.replay.check_errors()
     out = {"value": args.batchsize / dt, "unit": "sequences/s", "ms_per_iteration": dt * 1e3, "acts_per_sec": games * 2 / dt,
-           "host_issue_ms_per_iteration": t_issue / iterations * 1e3, "iterations": iterations,
+           "host_issue_ms_per_iteration": t_issue / iterations * 1e3, "host_issue_ms_per_iteration_on_an_empty_queue": t_free / 30 * 1e3,
+           "iterations": iterations,
            "config": {"workload": "%d concurrent 2-player SAD games, one rollout step (reset + observe + act + env step + n-step / priority / sequence push + "
                                   "flush into the prioritized replay) per learner update of %d sequences x 80 steps drawn from that replay; rollout on its own "
                                   "stream, the next batch drawn at the end of an update (selfplay --overlap_rollout 1 --draw_ahead 1)" % (games, args.batchsize)}}
