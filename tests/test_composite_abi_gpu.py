@@ -576,3 +576,29 @@ def test_the_two_launch_head_chain_gives_the_bits_of_the_four_launch_one(F, H, T
             if "bias" not in k:
                 assert torch.equal(g2[k], g4[k]), (k, relerr(g2[k], g4[k]))
         assert relerr(g2[k], g4[k]) < 1e-5, (k, relerr(g2[k], g4[k]))     # (bias sums and the head layers' split-K sums are float atomics)
+
+
+def test_every_gradient_of_an_update_is_the_same_bits_run_to_run():
+    """round 6: no float atomics left in the default update at the baseline shape -- the BPTT launch adds its per-row-block bias partial sums in
+    row-block order (ticket), the heads' weight gradient is slabs + an ordered sum, their bias gradient one workgroup per column block, the
+    five big weight gradients were slabs already.  Eight evaluations of the same update (a second learner object in between): loss, priorities
+    and EVERY gradient tensor bit for bit."""
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    F, A, H, T, B = 838, 21, 512, 80, 128
+    W, Wt = _rand_net(F, H, A, seed=31), _rand_net(F, H, A, seed=32)
+    batch, weight = _rand_batch(T, B, F, A, seed=9)
+    ref = None
+    for who in range(2):
+        L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+        for it in range(4):
+            loss, prio = L.loss(batch, weight, 0.25)
+            torch.cuda.synchronize()
+            got = {"loss": loss.clone(), "priority": prio.clone()}
+            got.update({k: v.clone() for k, v in L.grad.items()})
+            if ref is None:
+                ref = got
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), (who, it, k, relerr(got[k], ref[k]))
+        L.check_sync()
+        L.close()
