@@ -664,8 +664,40 @@ def device_state(local_dev=0):
     except Exception as e:
         return {"error": "%s: %s" % (type(e).__name__, str(e)[:120])}
     card = doc.get("card%d" % local_dev) or (list(doc.values())[0] if doc else {})
-    want = ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "partition")
+    want = ("sclk", "mclk", "fclk", "socclk", "power", "performance level", "partition", "temperature")
     return {k: v for k, v in card.items() if any(w in k.lower() for w in want)}
+
+
+class DeviceSampler:
+    """rocm-smi polled from a thread WHILE a region runs (clocks, power, temperatures as the tool prints them): the state the device is
+    actually in under the load, next to the before / after readings"""
+
+    def __init__(self, local_dev=0):
+        import threading
+        self.dev, self.samples, self._stop = local_dev, [], False
+        self.t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import shutil
+        import subprocess
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        while not self._stop:
+            try:
+                raw = subprocess.run([exe, "-c", "-P", "-t", "--json"], capture_output=True, text=True, timeout=10).stdout
+                doc = json.loads(raw[raw.index("{"):])
+                card = doc.get("card%d" % self.dev) or (list(doc.values())[0] if doc else {})
+                self.samples.append({k: v for k, v in card.items() if any(w in k.lower() for w in ("sclk clock speed", "mclk clock speed", "fclk clock speed", "power (w)", "temperature"))})
+            except Exception:
+                return
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self.t.join(timeout=15)
+        return False
 
 
 def streaming_ceilings(dev, nbytes=448 * 1024 * 1024, reps=15):
@@ -814,7 +846,10 @@ def main():
     iter_ms = k0.elapsed_time(k1) / args.steps                      # all partitions of one iteration (they overlap)
     # spread (not part of the contract's timed region): the same K-step region again and again until >= 0.5 s of GPU time
     rep_ms = []
-    while sum(rep_ms) < 500.0 or len(rep_ms) < 5:
+    sampler = DeviceSampler(local_dev) if rank == 0 else None
+    if sampler is not None:
+        sampler.__enter__()
+    while sum(rep_ms) < (1500.0 if rank == 0 else 500.0) or len(rep_ms) < 5:      # (rank 0: long enough for a few rocm-smi readings under load)
         r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         r0.record()
         env.rollout_random(args.steps, policy_seed)
@@ -823,6 +858,8 @@ def main():
         rep_ms.append(r0.elapsed_time(r1))
         if len(rep_ms) >= 2000:
             break
+    if sampler is not None:
+        sampler.__exit__()
     rep_sorted = sorted(x / args.steps for x in rep_ms)
     state_after = device_state(local_dev) if rank == 0 else None
     ceil = streaming_ceilings(dev) if rank == 0 else None
@@ -926,6 +963,7 @@ def main():
                                         "boundary (pipeline fill + tail) once per launch -- DESIGN 3a measures 80 us / iteration at 10 "
                                         "iterations per launch against 68 us at >= 50" % (args.chunk, args.steps, n_launch) if persistent else None,
                 "device_state_before": state_before, "device_state_after": state_after,
+                "device_state_during_repeats": sampler.samples[:6] if sampler is not None else None,
             },
             "roofline_step_kernel": {
                 "bound": "hbm", "kernel": "env_kernel<1,2,5> (HanabiEnv::step + observe with actions from HBM, the "

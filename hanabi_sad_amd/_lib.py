@@ -174,7 +174,7 @@ SIGNATURES = {
                                  C.c_float, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "hsad_colsum": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "hsad_colsum_acc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
-    "hsad_colsum_acc_ordered": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "hsad_colsum_acc_ordered": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "hsad_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, _P, _P]),
     "hsad_adam_step_zero_grad": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P,

@@ -1403,9 +1403,9 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
   const int heads_split = (Mp % (64 * 4 * L->wgrad_split) == 0) ? 4 * L->wgrad_split : L->wgrad_split;
   // (round 6: slabs + one ordered sum and a one-block column sum instead of float atomics -- with the BPTT launch's ticketed bias sums every
   // gradient of an update is now the same bits run to run; the chain runs on the side stream next to the BPTT launch either way)
-  if (NH <= 64 && heads_split <= 32 && (H & 3) == 0) {
+  if (NH <= 48 && heads_split <= 32 && (H & 3) == 0 && (size_t)((M + 127) / 128) * NH <= (size_t)8 * 64 * H) {
     CK(hsad_gemm_nt_bf16_splitk_acc(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, heads_split, L->heads_ws, g[on->iWA], H, nullptr, wst));
-    CK(hsad_colsum_acc_ordered(L->dheads, 1, M, NH, NHp, g[on->iBA], wst));
+    CK(hsad_colsum_acc_ordered(L->dheads, 1, M, NH, NHp, g[on->iBA], L->heads_ws + (size_t)3 * 8 * 64 * H, wst));      // (scratch: the last quarter of heads_ws; the slabs use <= 32 x 37 x H of the first three)
   } else {
     CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, heads_split, nullptr, 0, nullptr, wst));
     CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));

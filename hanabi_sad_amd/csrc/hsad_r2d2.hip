@@ -1088,16 +1088,18 @@ int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, 
   return HSAD_OK;
 }
 
-// out[c] += column sum c with ONE block per 64 columns walking all rows (no float atomics: the same bits run to run); for narrow matrices
-// (the heads' bias gradients: 37 columns x T*B rows) on a stream where latency is hidden
-int hsad_colsum_acc_ordered(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream) {
-  if (!src || !out) return nfail(HSAD_ERR_INVALID, "colsum_acc_ordered: null");
+// out[c] += column sum c without float atomics (the same bits run to run): every 128-row block leaves its partial sums in `scratch`
+// (fp32 [ceil(M / 128)][N]), a second small launch adds them up in row-block order
+int hsad_colsum_acc_ordered(const void* src, int is_bf16, int M, int N, int ld, float* out, float* scratch, void* stream) {
+  if (!src || !out || !scratch) return nfail(HSAD_ERR_INVALID, "colsum_acc_ordered: null");
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((N + 63) / 64, 1), block(64, 4);
+  const int nblk = (M + kColsumRows - 1) / kColsumRows;
+  const dim3 grid((N + 63) / 64, nblk), block(64, 4);
   if (is_bf16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, out, (float*)nullptr, (const int32_t*)nullptr, M);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, M, N, ld, scratch, (float*)nullptr, (const int32_t*)nullptr, -kColsumRows);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)src, M, N, ld, out, (float*)nullptr, (const int32_t*)nullptr, M);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)src, M, N, ld, scratch, (float*)nullptr, (const int32_t*)nullptr, -kColsumRows);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, s, scratch, nblk, N, out);
   HIP_TRY(hipGetLastError());
   return HSAD_OK;
 }

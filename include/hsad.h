@@ -495,9 +495,9 @@ int hsad_colsum(const void* src, int is_bf16, int M, int N, int ld, float* out, 
  * (the two LSTM bias gradients are both the un-blocked column sums of dG) */
 int hsad_colsum_acc(const void* src, int is_bf16, int M, int N, int ld, float* out, float* out2, const int32_t* col_map,
                     void* stream);
-/* out[c] += column sum c, computed by ONE workgroup per 64 columns walking all M rows in a fixed order -- no float atomics, the same bits run
- * to run (narrow matrices on a stream where latency is hidden: the heads' bias gradients, 37 columns x T*B rows) */
-int hsad_colsum_acc_ordered(const void* src, int is_bf16, int M, int N, int ld, float* out, void* stream);
+/* out[c] += column sum c without float atomics -- the same bits run to run: every 128-row block leaves its partial sums in `scratch`
+ * (fp32 [ceil(M / 128)][N]), a second small launch adds them up in row-block order */
+int hsad_colsum_acc_ordered(const void* src, int is_bf16, int M, int N, int ld, float* out, float* scratch, void* stream);
 /* clip_grad_norm_(max_grad_norm) + Adam step over flat fp32 buffers (selfplay.py:231-235); step counts from 1;
  * scratch: fp32 [1]. */
 int hsad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float max_grad_norm,
