@@ -74,6 +74,7 @@ struct EnvParams {
   unsigned long long policy_seed;  // MODE 2 (step with built-in random-legal policy)
   int n_iter;       // MODE 3: iterations this launch runs for its games (persistent rollout; 1 otherwise)
   int stagger_ticks;  // MODE 3, n_iter > 1: workgroup b starts (b % 8) * stagger_ticks (100 MHz) late, see env_kernel
+  int stagger_mode;   // which workgroups start late (developer switch HSAD_ENV_STAGGER_MODE, see env_rollout_kernel)
   int64_t* a_out;                  // MODE 2: where the sampled actions are recorded ([G,P] each)
   int64_t* g_out;
   uint32_t* planes;
@@ -1285,7 +1286,18 @@ __global__ __launch_bounds__(kEnvThreads) void env_kernel(EnvParams ep, const in
 template <int TP, int TH>
 __global__ __launch_bounds__(kEnvThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void env_rollout_kernel(EnvParams ep) {
   if (ep.stagger_ticks > 0) {
-    const unsigned long long t_in = wall_clock64(), wait = (unsigned long long)(blockIdx.x & 7u) * (unsigned long long)ep.stagger_ticks;
+    // which workgroups start late: (mode 0, rounds 1-5) by XCD = block id mod 8; (1) by block-id group of 32 inside the XCD -- the workgroups
+    // that share a CU when the dispatcher walks the XCD's CUs breadth first; (2) by block id inside the XCD mod 4 -- the same when it fills a
+    // CU first; (3) by the wave slot the hardware reports (HW_ID wave id bits: whatever the dispatcher did)
+    unsigned k = blockIdx.x & 7u;
+    if (ep.stagger_mode == 1) k = ((blockIdx.x >> 3) >> 5) & 3u;
+    else if (ep.stagger_mode == 2) k = (blockIdx.x >> 3) & 3u;
+    else if (ep.stagger_mode == 3) {
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      k = (hw & 15u) >> 1;      // wave id inside the SIMD (2 waves of a workgroup per SIMD pair... see the probe's printout)
+    }
+    const unsigned long long t_in = wall_clock64(), wait = (unsigned long long)k * (unsigned long long)ep.stagger_ticks;
     while (wall_clock64() - t_in < wait) __builtin_amdgcn_s_sleep(16);
   }
 #pragma clang loop unroll(disable)
@@ -1559,6 +1571,8 @@ void launch_env(hsad_env* e, int mode, const int64_t* a, const int64_t* g, hipSt
   ep.policy_seed = policy_seed;
   ep.n_iter = n_iter;
   ep.stagger_ticks = n_iter > 1 ? (int)(e->stagger_ns / 10) : 0;
+  static const int stagger_mode = getenv("HSAD_ENV_STAGGER_MODE") ? atoi(getenv("HSAD_ENV_STAGGER_MODE")) : 0;
+  ep.stagger_mode = stagger_mode;
   ep.a_out = a_out;
   ep.g_out = g_out;
   if (mode == 3 && n_iter > 1)
