@@ -789,7 +789,8 @@ struct FusePlan {
 };
 FusePlan fuse_plan(const hsad_r2d2_learner* L) {
   const int H = L->on->H, nrb = (L->B + 31) / 32, NL = L->on->L;
-  if (!L->fused_fwd || !(H == 256 || H == 512) || L->B % 32 || (size_t)L->T * L->B * H * 16 >= (1ull << 32)) return {0, 0};
+  // (T < 2: a one-step "sequence" has no recurrence to fuse -- the fused forward launch faulted on it, found in round 6; the chunked schedule runs it)
+  if (!L->fused_fwd || L->T < 2 || !(H == 256 || H == 512) || L->B % 32 || (size_t)L->T * L->B * H * 16 >= (1ull << 32)) return {0, 0};
   const int per_xcd = L->n_cu / 8;
   for (int g = std::min(NL, 2); g >= 1; --g)
     for (int nn = 2; nn >= 1; --nn)

@@ -1371,7 +1371,7 @@ int hsad_lstm_fused_timing_read(double* avg_ms, double* avg_flop, int32_t* launc
 int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hsad_lstm_fused_rec* recs, void* sync_scratch,
                             void* next_sync_scratch, void* stream) {
   const int nrec = nnet * nlayer;
-  if (nnet < 1 || nlayer < 1 || nrec > 6 || !recs || !sync_scratch || T < 1) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: bad arguments");
+  if (nnet < 1 || nlayer < 1 || nrec > 6 || !recs || !sync_scratch || T < 2) return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: bad arguments (needs T >= 2)");
   if (!((H == 256 || H == 512) && Bn >= 32 && Bn % 32 == 0 && (size_t)T * Bn * H * 16 < (1ull << 32)))
     return nfail(HSAD_ERR_INVALID, "lstm_forward_fused: needs H in {256,512} and a row count that is a multiple of 32 (pad the batch)");
   hipStream_t s = (hipStream_t)stream;
