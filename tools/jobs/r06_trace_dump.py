@@ -31,7 +31,13 @@ for t in range(T - 1, T - 4, -1):
         print("t=%2d %-5s nb0 " % (t, names[j]) + " ".join("%d:%7.2f" % (k, row[k] - base) if row[k] else "%d:   -   " % k for k in (0, 8, 2, 9, 10, 3, 4, 7, 5, 6, 11)))
     sig = b[2, :8, t, 5] - base
     print("      lower signals of all members:", " ".join("%.2f" % x for x in sig))
-for t in (40, 39, 38, 37):
+print("prologue of the BPTT launch (us relative to the earliest workgroup entry): entry, handshake done, first loop top, first signal; last signal of the launch")
+e0 = min(b[j, n, T - 1, 1] for j in (0, 1, 2, 3) for n in range(8) if b[j, n, T - 1, 1] > 0)
+for j in (0, 1, 2, 3):
+    for n in (0, 3, 7):
+        r = b[j, n, T - 1]
+        print("  %-5s nb%d entry %7.2f handshake %7.2f loop top %7.2f first signal %7.2f | step 0 signalled %8.2f" % (names[j], n, r[1] - e0, r[11] - e0, r[0] - e0, r[5] - e0, b[j, n, 0, 5] - e0))
+for t in ():
     for j in (0, 2):
         row = b[j, 0, t]
         print("t=%2d %-5s nb0 " % (t, names[j]) + " ".join("%d:%7.2f" % (k, row[k] - base) if row[k] else "%d:   -   " % k for k in (0, 8, 2, 9, 10, 3, 4, 7, 5, 6, 11)))
