@@ -1411,6 +1411,15 @@ static int loss_bwd_impl(hsad_r2d2_learner* L, void* stream) {
     CK(hsad_gemm_nt_bf16_ex(L->dheadsT, Mp, hs_x[top], ldh, NH, H, Mp, nullptr, g[on->iWA], H, nullptr, 0, 0, 0, heads_split, nullptr, 0, nullptr, wst));
     CK(hsad_colsum_acc(L->dheads, 1, M, NH, NHp, g[on->iBA], nullptr, nullptr, wst));
   }
+  {      // developer switch (measurement only): the BPTT launch starts behind everything issued on the side stream so far -- nothing runs next to it
+    static const bool alone = getenv("HSAD_DEV_BPTT_ALONE") != nullptr;
+    static hipEvent_t ev_alone = nullptr;
+    if (alone && pipe) {
+      if (!ev_alone) HIP_TRY(hipEventCreateWithFlags(&ev_alone, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(ev_alone, ws));
+      HIP_TRY(hipStreamWaitEvent(s, ev_alone, 0));
+    }
+  }
   int nbc = L->bchunks;
   while (nbc > 1 && (T % nbc || ((T / nbc) * B) % 64)) --nbc;
   std::function<int(int, int, void*, bf16_t*, float*)> chunk_wgrad;

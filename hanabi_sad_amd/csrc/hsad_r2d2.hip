@@ -1647,7 +1647,10 @@ static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* 
   const size_t words = seq_sync_words(R, TL, nrb32);
   if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
   BpttWideArgs m{};
-  auto ctr = [&](int j) { return counters + (size_t)j * TL * nrb; };
+  // one running counter word per (stage, row block), each on a line of its own (the region holds 8 TL nrb32 words: far more)
+  int ctr_stride = 32;
+  while (ctr_stride > 1 && (size_t)4 * nrb * ctr_stride > (size_t)R * TL * nrb32) ctr_stride >>= 1;
+  auto ctr = [&](int j) { return counters + (size_t)j * nrb * ctr_stride; };
   for (int k = 0; k < 2; ++k) {      // the two recurrences: stage 0 = top layer, stage 2 = the layer below
     const hsad_lstm_fused_bwd_rec& r = recs[k];
     BpttWideStage& q = m.st[2 * k];
@@ -1702,6 +1705,7 @@ static int lstm_bptt_wide_launch(int Tc, int Bn, const hsad_lstm_fused_bwd_rec* 
   m.group_words = reinterpret_cast<u64_t*>(sync);
   m.timeout = counters + (size_t)R * TL * nrb32;
   m.force_cross_xcd = g_force_cross_xcd;
+  m.ctr_stride = ctr_stride;
   m.zero_ptr = (unsigned*)next_sync_scratch;
   m.zero_words = next_sync_scratch ? (int)words : 0;
   // K-split reduction 16 KB + staging of the published block + verdict words
