@@ -1386,6 +1386,8 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
   const size_t words = seq_sync_words(nrec, T, nrb);
   if (!next_sync_scratch) HIP_TRY(hipMemsetAsync(sync, 0, sizeof(unsigned) * words, s));
   LstmFusedArgsN m{};
+  int fwd_ctr_stride = 32;
+  while (fwd_ctr_stride > T) fwd_ctr_stride >>= 1;
   for (int i = 0; i < nrec; ++i) {
     const hsad_lstm_fused_rec& r = recs[i];
     const int layer = i % nlayer;
@@ -1396,12 +1398,13 @@ int hsad_lstm_forward_fused(int nnet, int nlayer, int T, int Bn, int H, const hs
     q.Whh = (const bf16_t*)r.Whh_blocked;
     q.bias = r.bias_blocked;
     q.x = r.x16 ? (const bf16_t*)r.x16 : (const bf16_t*)recs[i - 1].hseq16;
-    q.xin_counters = r.x16 ? nullptr : counters + (size_t)(i - 1) * T * nrb;
+    q.xin_counters = r.x16 ? nullptr : counters + (size_t)(i - 1) * T * nrb;      // (a record's region keeps its [T][nrb] size: nrb ctr_stride <= T nrb words of it are used)
     q.gates = r.gates;
     q.cseq = r.cseq;
     q.hseq16 = (bf16_t*)r.hseq16;
     q.hT = r.hT;
     q.counters = counters + (size_t)i * T * nrb;
+    q.ctr_stride = fwd_ctr_stride;
     q.timeout = counters + (size_t)nrec * T * nrb;
     q.T = T;
     q.Bn = Bn;
