@@ -41,6 +41,21 @@ def test_no_instruction_touches_a_tile_register_of_the_wide_bptt_kernel_while_it
             "  line %d: %s (%s)" % (no, ins, " ".join("%s%d" % b for b in bad)) for no, ins, bad in hazards[:10])
 
 
+def test_the_chunked_recurrence_kernels_do_not_touch_in_flight_tile_registers_either(r2d2_isa):
+    """lstm_seq_fwd_kernel / lstm_seq_bwd_kernel (the chunk-pipelined schedule's recurrences) use the same hand-counted loads; their
+    inline-asm path and their compiler-visible cross-XCD path are separate branches with fragments of their own.  (lstm_fused_bwd_kernel,
+    the 32 x 32 blocking kept for A/B, issues its loads in two structurised copies of one path that this path-insensitive walk cannot tell
+    apart: not gated.)"""
+    import check_inflight_loads as chk
+    bodies = chk.kernel_bodies(r2d2_isa)
+    names = [n for n in bodies if "lstm_seq_fwd_kernel" in n or "lstm_seq_bwd_kernel" in n]
+    assert len(names) >= 4
+    for n in names:
+        hazards, followed = chk.check(bodies[n])
+        assert followed >= 8, (n, followed)
+        assert not hazards, n + ":\n" + "\n".join("  line %d: %s" % (no, ins) for no, ins, bad in hazards[:10])
+
+
 def test_the_wide_bptt_kernel_keeps_its_weights_in_registers_without_spilling(r2d2_isa):
     import re
     text = open(r2d2_isa).read()
