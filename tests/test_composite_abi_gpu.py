@@ -366,6 +366,41 @@ def test_fused_recurrences_equal_the_chunk_pipelined_schedule(F, H, T, B, pw):
                 assert relerr(res[a][2][k], res[b][2][k]) < (3e-4 if k.startswith("lstm.bias") else 1e-5), (b, k, relerr(res[a][2][k], res[b][2][k]))
 
 
+@pytest.mark.parametrize("T", [2, 3, 5, 9, 33])
+def test_short_sequences_run_the_persistent_launches_with_narrower_counter_strides(T):
+    """round 6: the exchange counters of both persistent launches are one running word per row block, 128 bytes apart -- when the sequence
+    is short the region (sized for one word per step) only holds a narrower stride (2 words at T = 2).  The 16-row x 64-unit BPTT launch
+    against the 32 x 32 one (own counter layout, a word per step) on the same forward: same loss, priorities and LSTM weight gradients bit
+    for bit, twice each (the second visit reuses the ping-pong counter blocks), and no timeout word set."""
+    from hanabi_sad_amd.composite import CompositeLearner
+    from tests.test_r2d2_kernels_gpu import _rand_batch, _rand_net
+    F, A, H, B = 838, 21, 512, 128
+    W, Wt = _rand_net(F, H, A, seed=41), _rand_net(F, H, A, seed=42)
+    batch, weight = _rand_batch(T, B, F, A, seed=T)
+    L = CompositeLearner(W, Wt, 3, 0.999, device=DEV)
+    res = {}
+    for rep in range(2):
+        for name, flags in (("wide", 57 | (1 << 8)), ("32 x 32", 57 | (1 << 8) | (1 << 25)), ("chunked", 0)):
+            L.set_fused(flags)
+            loss, prio = L.loss(batch, weight, 0.25)
+            torch.cuda.synchronize()
+            got = (loss.clone(), prio.clone(), {k: v.clone() for k, v in L.grad.items()})
+            if name in res:
+                assert torch.equal(got[0], res[name][0]) and torch.equal(got[1], res[name][1]), (T, name)
+                for k in got[2]:
+                    if k.startswith("lstm.weight"):
+                        assert torch.equal(got[2][k], res[name][2][k]), (T, name, k)
+            res[name] = got
+    L.check_sync()
+    (lw, pw_, gw), (l3, p3, g3), (lc, pc, gc) = res["wide"], res["32 x 32"], res["chunked"]
+    assert torch.equal(lw, l3) and torch.equal(pw_, p3)
+    for k in gw:
+        if k.startswith("lstm.weight"):
+            assert torch.equal(gw[k], g3[k]), (T, k, relerr(gw[k], g3[k]))
+        assert relerr(gw[k], g3[k]) < 3e-4, (T, k, relerr(gw[k], g3[k]))
+        assert relerr(gw[k], gc[k]) < 6e-3, (T, k, relerr(gw[k], gc[k]))     # another schedule: fp32 summation orders differ
+
+
 def test_fused_recurrences_soak_every_evaluation_gives_the_same_bits():
     """stress target for the counter / hand-off protocols of the persistent fused launches (forward: 4 recurrences x 80 steps, BPTT: 2 x 80):
     a stale tile, a counter read too early or a lost wake-up changes bits (or trips the sticky timeout flag).  360 evaluations of the full-size
