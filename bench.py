@@ -502,7 +502,8 @@ def training_bench(dev, games=6400, iterations=150, warmup=20):
            "iterations": iterations,
            "config": {"workload": "%d concurrent 2-player SAD games, one rollout step (reset + observe + act + env step + n-step / priority / sequence push + "
                                   "flush into the prioritized replay) per learner update of %d sequences x 80 steps drawn from that replay; rollout on its own "
-                                  "stream, the next batch drawn at the end of an update (selfplay --overlap_rollout 1 --draw_ahead 1)" % (games, args.batchsize)}}
+                                  "stream, priority write-back and the draw of the next batch on a third one behind the forward half of the update (selfplay "
+                                  "--overlap_rollout 1 --draw_ahead 1 --early_draw 1)" % (games, args.batchsize)}}
     del tr
     torch.cuda.empty_cache()
     return out

@@ -243,9 +243,12 @@ class CompositeLearner:
         if self.h is not None:
             _lib.check(self.lib.hsad_r2d2_learner_set_fused(self.h, int(self.fused)))
 
-    def loss(self, batch, weight, pred_weight=0.0, compute_grad=True):
+    def loss(self, batch, weight, pred_weight=0.0, compute_grad=True, between=None):
         """batch["priv_s"] float32 [T,B,(P,)F] -- or batch["priv_s_bf16"] [T,B,P,in_dim_padded] bf16, what DeviceReplay.sample
-        returns for the bit-packed observation with set_field_output("priv_s", "bf16", in_dim_padded) --, legal_move [T,B,(P,)A]"""
+        returns for the bit-packed observation with set_field_output("priv_s", "bf16", in_dim_padded) --, legal_move [T,B,(P,)A].
+        between: called as between(loss, priority) after the forward half is enqueued (hsad_r2d2_loss_fwd: loss and priorities are final
+        behind it) and before the BPTT is -- what the caller enqueues there on another stream runs next to the BPTT instead of behind it
+        (selfplay: priority write-back and the next draw)"""
         legal, a = batch["legal_move"], batch["a"]
         p16 = batch.get("priv_s_bf16")
         priv = p16 if p16 is not None else batch["priv_s"]
@@ -271,6 +274,8 @@ class CompositeLearner:
                                                p(batch["bootstrap"]), p(batch["seq_len"]), None if own is None else keep[3].data_ptr(),
                                                keep[4].data_ptr(), P, float(pred_weight), loss.data_ptr(), prio.data_ptr(),
                                                1 if compute_grad else 0, _s(d)))
+        if between is not None:
+            between(loss, prio)
         if compute_grad == "later":      # the autograd face: the importance weights arrive with the backward call (backward_weighted)
             self._seq_len = batch["seq_len"].contiguous()
         elif compute_grad:

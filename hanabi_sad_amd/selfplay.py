@@ -100,6 +100,8 @@ class Trainer:
                                  vdn=self.vdn, native=None if getattr(args, "native_actor", 1) else False) if self.acting else None
         self.num_update = 0
         self._drawn = None           # the batch of the next update, drawn ahead (--draw_ahead)
+        self._drawn_ev = None        # ... and the event behind that draw when it was issued on the draw stream
+        self.draw_stream = None      # (set below)
         # --overlap_rollout: the rollout issues on a stream of its own, next to the update on the caller's stream (one host thread feeds
         # both; replay and writer calls from the two sides are ordered by the library's stream fence).  The reference's actor threads
         # run concurrently with its training thread the same way (selfplay.py:208-244, rela/context.h:43-50).
@@ -107,6 +109,15 @@ class Trainer:
         if self.acting and self.learner is not None and getattr(args, "overlap_rollout", 0) and torch.device(device).type == "cuda":
             self.act_stream = torch.cuda.Stream(torch.device(device))
             self.act_stream.wait_stream(torch.cuda.current_stream(torch.device(device)))     # everything built so far precedes the first step
+        # --draw_ahead with the composite learner: priority write-back and the next draw are issued BETWEEN the two halves of the update, on a
+        # stream of their own that waits for the forward half only.  Behind the optimizer step on the caller's stream (round 5) the chain of small
+        # launches -- priorities, draw (one workgroup, 65 us), row unpacking -- sat between two updates: 0.15 ms in front of every forward launch.
+        # Replay calls from the three streams are ordered by the library's stream fence in the order they are issued, which is unchanged:
+        # rollout step's flush -> priority write-back -> draw -> next rollout step's flush.
+        if (self.learner is not None and composite and getattr(args, "draw_ahead", 0) and getattr(args, "early_draw", 1)
+                and self.sharded is not None and torch.device(device).type == "cuda"):
+            self.draw_stream = torch.cuda.Stream(torch.device(device))
+            self.draw_stream.wait_stream(torch.cuda.current_stream(torch.device(device)))
 
     def act_step(self, n=1):
         """n rollout steps, on the rollout stream when there is one"""
@@ -158,8 +169,37 @@ class Trainer:
         res, self._drawn = self._drawn, None
         if res is None:
             res = self.sharded.sample(a.batchsize)
+        elif self._drawn_ev is not None:          # drawn on the draw stream: the update reads it behind that
+            torch.cuda.current_stream(self._drawn_ev_dev).wait_event(self._drawn_ev)
+            self._drawn_ev = None
         mark("sample data", sync=False)
         batch, weight, seq_len = self.batch_of(res)
+        if self.draw_stream is not None:
+            dev = self.draw_stream.device
+            main = torch.cuda.current_stream(dev)
+
+            def between(loss_, priority_):
+                ev = torch.cuda.Event()
+                ev.record(main)                   # behind the forward half: loss and priorities are final
+                self.draw_stream.wait_event(ev)
+                with torch.cuda.stream(self.draw_stream):
+                    prio = aggregate_priority(priority_, seq_len, a.eta)
+                    self.sharded.update_priority(prio)
+                    self._drawn = self.sharded.sample(a.batchsize)
+                    self._drawn_ev, self._drawn_ev_dev = torch.cuda.Event(), dev
+                    self._drawn_ev.record(self.draw_stream)
+                # allocator bookkeeping: each side's blocks are in use on the other stream too
+                priority_.record_stream(self.draw_stream)
+                seq_len.record_stream(self.draw_stream)
+                for t in _tensors_of(self._drawn):
+                    t.record_stream(main)
+            loss, priority = self.learner.loss(batch, weight, a.pred_weight, between=between)
+            mark("forward & backward")
+            g_norm = self.learner.optimizer_step()
+            mark("update model")
+            mark("updating priority", sync=False)
+            self.num_update += 1
+            return (loss * weight).mean(), g_norm
         loss, priority = self.learner.loss(batch, weight, a.pred_weight)
         prio = aggregate_priority(priority, seq_len, a.eta)
         mark("forward & backward")
@@ -184,6 +224,18 @@ class Trainer:
             batch = {pk: f["priv_s"], "legal_move": f["legal_move"], "a": f["a"].squeeze(2), "reward": reward,
                      "bootstrap": bootstrap, "seq_len": seq_len, "own_hand": f["own_hand"]}
         return batch, weight, seq_len
+
+
+def _tensors_of(x):
+    """every tensor inside a nested tuple / list / dict (a sampled batch)"""
+    if torch.is_tensor(x):
+        yield x
+    elif isinstance(x, dict):
+        for v in x.values():
+            yield from _tensors_of(v)
+    elif isinstance(x, (tuple, list)):
+        for v in x:
+            yield from _tensors_of(v)
 
 
 def parse_args(argv=None):
@@ -233,6 +285,8 @@ def parse_args(argv=None):
     p.add_argument("--actor_sync_freq", type=int, default=10)
     p.add_argument("--act_steps_per_update", type=int, default=1)
     p.add_argument("--num_eval_game", type=int, default=1000)
+    p.add_argument("--early_draw", type=int, default=1, help="with --draw_ahead and the composite learner: priority write-back and the next draw are "
+                   "issued between the forward half and the BPTT of an update on a stream of their own (0: behind the optimizer step on the caller's stream)")
     p.add_argument("--draw_ahead", type=int, default=1, help="1: the batch of update u + 1 is drawn at the end of update u (behind its priority "
                    "write-back), in front of the next rollout step, as the reference's prefetching sampler thread does; 0: at the start of update u + 1")
     p.add_argument("--overlap_rollout", type=int, default=1, help="1: the rollout steps of a one-GPU job issue on a stream of their own, "

@@ -104,6 +104,38 @@ def test_num_lstm_layer_flag_trains_and_saves_that_architecture(tmp_path, nl):
     assert agent.get_h0(4)["h0"].shape[0] == nl
 
 
+def test_the_early_draw_sees_the_same_data_as_the_draw_behind_the_optimizer_step():
+    """selfplay --early_draw 1 (default, round 6): priority write-back and the next draw are issued between the forward half and the BPTT of
+    an update, on a stream of their own that waits for the forward half only -- instead of behind the optimizer step on the caller's stream.
+    The order of the replay operations (flush -> write-back -> draw -> next flush) is the same, so the loop must see the same batches: the
+    per-update losses and the replay's final state agree with --early_draw 0 and with the strictly alternating loop."""
+    from hanabi_sad_amd.selfplay import Trainer, parse_args
+    out = []
+    for early, overlap in ((0, 1), (1, 1), (1, 0)):
+        tr = Trainer(parse_args(["--num_game", "1024", "--sad", "1", "--seed", "5", "--burn_in_frames", "1000", "--replay_buffer_size", "8192",
+                                 "--batchsize", "64", "--overlap_rollout", str(overlap), "--actor_sync_freq", "5", "--early_draw", str(early)]), "cuda:0")
+        assert (tr.draw_stream is not None) == bool(early)
+        tr.act_step(120)
+        losses = []
+        for u in range(40):
+            tr.act_step(1)
+            loss, g_norm = tr.learner_update()
+            losses.append(loss.detach().float())
+        tr.join_rollout()
+        torch.cuda.synchronize()
+        tr.env.check_errors()
+        tr.replay.check_errors()
+        tr.learner.check_sync()
+        out.append((torch.stack(losses).cpu(), tr.replay.num_add(), tr.replay.size(), tr.replay.priority_sum()[0], tr.actor.num_act))
+        del tr
+        torch.cuda.empty_cache()
+    (l0, *s0) = out[0]
+    for (l1, *s1) in out[1:]:
+        assert s0[0] == s1[0] and s0[1] == s1[1] and s0[3] == s1[3]
+        assert torch.allclose(l0, l1, rtol=1e-4, atol=1e-5), (l0 - l1).abs().max()
+        assert abs(s0[2] - s1[2]) <= 1e-3 * abs(s0[2])
+
+
 def test_overlapped_rollout_sees_the_same_data_as_the_alternating_loop():
     """selfplay --overlap_rollout 1 (the default): rollout steps on a stream of their own next to the update on the caller's.  Every
     cross-stream dependency (sequence flush -> sample, sample / update_priority -> next flush, optimizer step -> actor weight sync ->
