@@ -459,12 +459,12 @@ def actor_bench(dev, games=16384, steps=160, warmup=120):
     return out
 
 
-def training_bench(dev, games=6400, iterations=150, warmup=20):
+def training_bench(dev, games=6400, iterations=150, warmup=20, extra_args=()):
     """One-GPU self-play training as `python -m hanabi_sad_amd.selfplay` runs it (the configuration of the committed convergence run: 6,400 games,
     one rollout step per update on the rollout stream, B = 128 sequences drawn from the replay the rollout fills, draw ahead): rollout step ->
     update (loss fwd + BPTT, clip + Adam, priorities written back) -> next draw, timed over whole iterations with the host running ahead."""
     from hanabi_sad_amd.selfplay import Trainer, parse_args
-    args = parse_args(["--num_game", str(games), "--replay_buffer_size", "131072", "--sad", "1"])
+    args = parse_args(["--num_game", str(games), "--replay_buffer_size", "131072", "--sad", "1"] + list(extra_args))
     tr = Trainer(args, str(dev))
     tr.act_step(130)                                       # past the first episode ends: the replay holds > 2 batches
     tr.join_rollout()
@@ -1024,7 +1024,7 @@ def main():
             out["learner"] = learner_bench(dev)
         if world == 1 and not args.no_actor:
             out["actor"] = actor_bench(dev)
-            out["one_gpu_training"] = training_bench(dev)
+            out["one_gpu_training"] = training_bench(dev, extra_args=tuple(os.environ.get("HSAD_BENCH_TRAINING_ARGS", "").split()))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         # what in this line is NOT measured by this run: the HBM-traffic and MFMA-busy counter figures are read from the committed rocprofv3
