@@ -41,15 +41,15 @@ def test_no_instruction_touches_a_tile_register_of_the_wide_bptt_kernel_while_it
             "  line %d: %s (%s)" % (no, ins, " ".join("%s%d" % b for b in bad)) for no, ins, bad in hazards[:10])
 
 
-def test_the_chunked_recurrence_kernels_do_not_touch_in_flight_tile_registers_either(r2d2_isa):
-    """lstm_seq_fwd_kernel / lstm_seq_bwd_kernel (the chunk-pipelined schedule's recurrences) use the same hand-counted loads; their
-    inline-asm path and their compiler-visible cross-XCD path are separate branches with fragments of their own.  (lstm_fused_bwd_kernel,
-    the 32 x 32 blocking kept for A/B, issues its loads in two structurised copies of one path that this path-insensitive walk cannot tell
-    apart: not gated.)"""
+def test_the_other_recurrence_kernels_do_not_touch_in_flight_tile_registers_either(r2d2_isa):
+    """lstm_seq_fwd_kernel / lstm_seq_bwd_kernel (the chunk-pipelined schedule's recurrences) and lstm_fused_bwd_kernel (the 32 x 32 blocking
+    of the four-stage launch: B = 256, H = 256, time chunks, and the A/B mode) use the same hand-counted loads.  The chunked kernels keep
+    their inline-asm path and their compiler-visible cross-XCD path in separate branches with fragments of their own; the 32 x 32 kernel's
+    loads sit in two structurised copies of one path selected by a scalar flag, which the walk follows (check_inflight_loads.check)."""
     import check_inflight_loads as chk
     bodies = chk.kernel_bodies(r2d2_isa)
-    names = [n for n in bodies if "lstm_seq_fwd_kernel" in n or "lstm_seq_bwd_kernel" in n]
-    assert len(names) >= 4
+    names = [n for n in bodies if "lstm_seq_fwd_kernel" in n or "lstm_seq_bwd_kernel" in n or "lstm_fused_bwd_kernel" in n]
+    assert len(names) >= 6
     for n in names:
         hazards, followed = chk.check(bodies[n])
         assert followed >= 8, (n, followed)

@@ -13,7 +13,8 @@ every path of the control-flow graph with the queue of VMEM operations in flight
 load (between #ASMSTART / #ASMEND) puts its destination registers on the queue, compiler-issued
 VMEM operations are counted as the hardware counts them, `s_waitcnt vmcnt(N)` retires all but the
 youngest N entries, and an instruction that names a register which is still in flight on some
-path is reported.
+path is reported.  The walk follows one scalar idiom (the structuriser's duplicated paths selected
+by a 0 / -1 flag, see check()); every other branch is taken both ways.
 
 usage: check_inflight_loads.py file.s kernel_name_substring [...]
 exit code 1 when a hazard is found, 2 when a named kernel is not in the file.
@@ -100,9 +101,31 @@ def norm(queue):
     return tuple(q[-63:])
 
 
-def run_block(blk, queue, hazards):
-    queue = list(queue)
-    tracked = 0
+_SPAIR = re.compile(r"^s\[(\d+):(\d+)\]$")
+
+
+def _sdst(ins):
+    """scalar registers an instruction writes (first operand): set of register numbers, 'vcc' in it when vcc is written"""
+    parts = ins.split(None, 1)
+    if len(parts) < 2:
+        return set()
+    op, first = parts[0], parts[1].split(",")[0].strip()
+    out = set()
+    m = _SPAIR.match(first)
+    if m:
+        out |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+    elif re.match(r"^s\d+$", first):
+        out.add(int(first[1:]))
+    elif first.startswith("vcc"):
+        out.add("vcc")
+    if op.startswith(("v_cmp", "v_div_scale", "v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_mad_u64", "v_mad_i64")) and ("vcc" in ins or op.endswith("_e32")):
+        out.add("vcc")
+    return out
+
+
+def run_block(blk, queue, consts, vcc, hazards):
+    """consts: known 64-bit scalar flags {(lo, hi): 0 | -1} (the structuriser's "which copy of the path runs" words); vcc: None | 'zero' | 'nonzero'"""
+    queue, consts = list(queue), dict(consts)
     for no, ins, in_asm in blk:
         op = ins.split()[0]
         if op == "s_waitcnt":
@@ -124,26 +147,48 @@ def run_block(blk, queue, hazards):
             dst = frozenset()
             if in_asm and op.startswith("global_load") and "lds" not in op:      # the compiler tracks its own loads
                 dst = frozenset(regs_of(ins.split(None, 1)[1].split(",")[0]))
-                tracked += 1
             queue.append(dst)
-    return norm(queue), tracked
+        # scalar flags
+        if op.startswith("s_cbranch") or op == "s_branch":
+            continue
+        m = re.match(r"^s_andn2_b64\s+vcc,\s*exec,\s*s\[(\d+):(\d+)\]$", ins)
+        if m and (int(m.group(1)), int(m.group(2))) in consts:
+            vcc = "nonzero" if consts[(int(m.group(1)), int(m.group(2)))] == 0 else "zero"       # (a wave that runs has a lane in exec)
+            continue
+        w = _sdst(ins) if not in_asm else set()
+        if "vcc" in w:
+            vcc = None
+        m = re.match(r"^s_mov_b64\s+s\[(\d+):(\d+)\],\s*(-1|0)$", ins)
+        for k in [k for k in consts if w & set(range(k[0], k[1] + 1))]:
+            del consts[k]
+        if m:
+            consts[(int(m.group(1)), int(m.group(2)))] = int(m.group(3))
+    return norm(queue), tuple(sorted(consts.items())), vcc
 
 
 def check(body):
-    """walk every path of the control-flow graph with the queue of VMEM operations in flight; -> (hazards, inline-asm loads in the text)"""
+    """walk the paths of the control-flow graph with the queue of VMEM operations in flight; -> (hazards, inline-asm loads in the text).
+    Path-sensitive for ONE idiom: the structuriser duplicates a path and selects the copy with a 64-bit scalar flag set to 0 / -1
+    (s_mov_b64 ... ; s_andn2_b64 vcc, exec, flag ; s_cbranch_vccnz) -- the infeasible combination "both copies" is not walked."""
     blocks, succ = basic_blocks(body)
-    hazards, seen, work = {}, set(), [(0, ())]
+    hazards, seen, work = {}, set(), [(0, (), (), None)]
     tracked = sum(1 for b in blocks for no, ins, in_asm in b if in_asm and ins.startswith("global_load") and "lds" not in ins.split()[0])
     while work:
-        i, q = work.pop()
-        if (i, q) in seen:
+        i, q, consts, vcc = work.pop()
+        if (i, q, consts, vcc) in seen:
             continue
-        seen.add((i, q))
-        if len(seen) > 200000:
+        seen.add((i, q, consts, vcc))
+        if len(seen) > 400000:
             raise RuntimeError("state explosion")
-        q2, _ = run_block(blocks[i], q, hazards)
-        for j in succ[i]:
-            work.append((j, q2))
+        q2, c2, v2 = run_block(blocks[i], q, consts, vcc, hazards)
+        nxt = succ[i]
+        if blocks[i] and len(nxt) == 2 and v2 is not None:
+            term = blocks[i][-1][1].split()[0]
+            if term in ("s_cbranch_vccnz", "s_cbranch_vccz"):
+                taken = (v2 == "nonzero") == (term == "s_cbranch_vccnz")
+                nxt = [nxt[1]] if taken else [nxt[0]]      # (basic_blocks lists the fall-through first, the branch target second)
+        for j in nxt:
+            work.append((j, q2, c2, v2))
     return [(no, ins, bad) for no, (ins, bad) in sorted(hazards.items())], tracked
 
 
