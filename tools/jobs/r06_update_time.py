@@ -1,6 +1,9 @@
 """ms per learner update (configs[2] shape) of the composite learner, median of 10 blocks of 50 updates: for A/B runs under developer switches"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from hanabi_sad_amd import _lib
+if os.environ.get("UPD_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["UPD_LIB"])      # A/B against another build of the library
 from hanabi_sad_amd.composite import CompositeLearner
 from hanabi_sad_amd.selfplay import init_weights
 from tests.test_r2d2_kernels_gpu import _rand_batch
@@ -23,4 +26,4 @@ for blk in range(10):
     ts.append(e0.elapsed_time(e1) / 50)
 L.check_sync()
 ts.sort()
-print("ms per update: median %.4f min %.4f max %.4f   (%s)" % (ts[5], ts[0], ts[-1], " ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("HSAD_"))))
+print("ms per update: median %.4f min %.4f max %.4f   (%s)" % (ts[5], ts[0], ts[-1], " ".join("%s=%s" % (k, v) for k, v in os.environ.items() if k.startswith("HSAD_") or k == "UPD_LIB")))
